@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native SCONE coverage-gain hot path.
+
+Metric (BASELINE.json): candidate-camera coverage-gain evals/sec (100k pts, 200 cams); NBV step p50 latency.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the scorer (SconeVis.compute_coverage_gain semantics) over one synthetic cloud of
+100 000 points x 200 candidate cameras per GPU, inputs already resident in HBM, followed (N>1) by the
+all-gather of each rank's (best gain, camera index).  One (cloud, camera) pair scored = one eval.
+Weak scaling: each rank owns a disjoint shard of 200 candidate cameras of the same cloud (the reference
+scores all cameras on one GPU).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     — dominant kernel (sh_score_kernel) algorithmic flop rate vs the fp32 vector peak
+  cpu_baseline — the plain-C port of the reference scorer (oracle/csrc) timed on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR = 370.0          # algorithmic flop per (point, camera) pair
+BYTES_PER_POINT = 268.0        # 12 B xyz + 256 B coefficients, read once per cloud
+PEAK_FP32_TFLOPS = 157.3       # MI355X fp32 vector (= fp32 MFMA) peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def make_inputs(N, C, seed, device, cam_offset=0, n_cam_total=None):
+    """Synthetic workload of SURVEY §8d: uniform points in [-0.5,0.5]^3 + occupancy U(0.1,1), coefficients
+    N(0,0.5^2), cameras on the radius-1.5 sphere."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    pts = torch.cat([torch.rand(1, N, 3, generator=g) - 0.5, 0.1 + 0.9 * torch.rand(1, N, 1, generator=g)], -1)
+    harm = torch.randn(1, N, 64, generator=g) * 0.5
+    n_tot = n_cam_total or C
+    cams = torch.randn(1, n_tot, 3, generator=g)
+    cams = 1.5 * cams / cams.norm(dim=-1, keepdim=True)
+    cams = cams[:, cam_offset:cam_offset + C].contiguous()
+    return pts.to(device), harm.to(device), cams.to(device)
+
+
+def cpu_baseline(N, C_sample, seed):
+    """Time the C port of the reference scorer on the host cores for a bounded sample of the workload."""
+    from oracle import cport
+    pts, harm, cams = make_inputs(N, C_sample, seed, "cpu")
+    p, h, c = pts.numpy(), harm.numpy(), cams.numpy()
+    cport.coverage_gain(p[:, :256], h[:, :256], c)        # warm-up / build
+    t0 = time.perf_counter()
+    g, nthreads = cport.coverage_gain(p, h, c)
+    dt = time.perf_counter() - t0
+    return {"value": C_sample / dt, "unit": "evals/s", "cores": int(nthreads), "kind": "port",
+            "sample": f"C port (oracle/csrc/scorer_port.c, OpenMP) on N={N} points x {C_sample} cameras, "
+                      f"{dt:.2f} s wall; host has {os.cpu_count()} cores"}, g
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--points", type=int, default=100_000)
+    ap.add_argument("--cams", type=int, default=200)
+    ap.add_argument("--cam-chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from macarons_amd import ops
+    N, C = args.points, args.cams
+    # every rank: same cloud, its own shard of C cameras out of world*C (weak scaling)
+    pts, harm, cams = make_inputs(N, C, 1234, dev, cam_offset=rank * C, n_cam_total=world * C)
+
+    def step():
+        gains = ops.sh_coverage_gain(pts, harm, cams, True, args.cam_chunk)
+        best = torch.max(gains, dim=1)                       # (value, local camera index)
+        if world > 1:
+            from macarons_amd import dist as mdist
+            return mdist.allgather_argmax(best.values, best.indices + rank * C)
+        return best.values, best.indices
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        out = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tw = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    dev_ms = ev0.elapsed_time(ev1)                 # HIP events on the launch stream (torch current stream)
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        evals_per_s = world * C * args.steps / wall
+        kern_ms = dev_ms / args.steps              # per-launch device time of the scorer pass
+        achieved = N * C * FLOP_PER_PAIR / (kern_ms * 1e-3) / 1e12
+        res = {
+            "metric": "candidate-camera coverage-gain evals/sec (100k pts, 200 cams)",
+            "value": evals_per_s, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"scorer: B=1 cloud x N={N} points x C={C} cameras per GPU "
+                                   f"(BASELINE headline 100k pts / 200 cams), inputs resident in HBM",
+                       "points": N, "cams_per_gpu": C, "parallelism": f"camera-shard x{world}"},
+            "roofline": {"bound": "valu-fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel": "sh_score_kernel<false,true>", "device_ms_per_launch": kern_ms,
+                         "hbm_algorithmic_GBs": N * BYTES_PER_POINT / (kern_ms * 1e-3) / 1e9},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb, g_cpu = cpu_baseline(N, 24, 1234)
+            res["cpu_baseline"] = cb
+            g_gpu = ops.sh_coverage_gain(pts, harm, cams[:, :24].contiguous()).cpu().numpy()
+            res["cpu_baseline"]["max_rel_diff_vs_gpu"] = float(np.abs(g_gpu - g_cpu).max() / np.abs(g_cpu).max())
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

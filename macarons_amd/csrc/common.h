@@ -1,0 +1,62 @@
+// Shared device/host helpers for the MI355X (gfx950, wave64) kernels of the SCONE coverage-gain path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MCR_WAVE 64
+
+namespace mcr {
+
+// ---- error plumbing (C-ABI returns int; message kept per thread) -----------------------------------
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+#define MCR_REQUIRE(cond, ...)                       \
+    do {                                             \
+        if (!(cond)) {                               \
+            ::mcr::set_error(__VA_ARGS__);           \
+            return 1;                                \
+        }                                            \
+    } while (0)
+
+#define MCR_LAUNCH_CHECK(name)                                           \
+    do {                                                                 \
+        if (int _e = ::mcr::check_hip(hipGetLastError(), name)) return _e; \
+    } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- wave64 DPP reductions ---------------------------------------------------------------------------
+// After wave_sum_to_last(), lane 63 holds the sum of all 64 lanes (other lanes hold partial garbage).
+__device__ __forceinline__ float dpp_add(float v, float src, int ctrl_unused) { return v + src; }
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov0(float v) {
+    // old = 0, bound_ctrl = true: lanes without a source read 0.
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK,
+                                                                 BANK_MASK, true));
+}
+
+__device__ __forceinline__ float wave_sum_to_last(float v) {
+    v += dpp_mov0<0x111>(v);             // row_shr:1
+    v += dpp_mov0<0x112>(v);             // row_shr:2
+    v += dpp_mov0<0x114>(v);             // row_shr:4
+    v += dpp_mov0<0x118>(v);             // row_shr:8   -> lane 15 of every row = row sum
+    v += dpp_mov0<0x142, 0xa>(v);        // row_bcast:15 into rows 1,3
+    v += dpp_mov0<0x143, 0xc>(v);        // row_bcast:31 into rows 2,3 -> lane 63 = wave sum
+    return v;
+}
+
+__device__ __forceinline__ float wave_max_all(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace mcr

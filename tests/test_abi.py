@@ -1,0 +1,48 @@
+"""The C-ABI library loads and exports every symbol include/macarons_hip.h declares (no GPU needed)."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+from macarons_amd import _lib, build
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    return build.build()
+
+
+def test_library_builds_and_loads(libpath):
+    assert os.path.exists(libpath)
+    L = _lib.lib()
+    assert L.mcr_abi_version() >= 1
+    assert L.mcr_target_arch() == b"gfx950"
+
+
+def test_every_declared_symbol_is_exported(libpath):
+    names = _lib.declared_symbols()
+    assert len(names) >= 5
+    L = ctypes.CDLL(libpath)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, f"declared in include/macarons_hip.h but not exported: {missing}"
+
+
+def test_exports_are_declared(libpath):
+    out = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T mcr_" in l}
+    undeclared = exported - set(_lib.declared_symbols())
+    assert not undeclared, f"exported but missing from include/macarons_hip.h: {sorted(undeclared)}"
+
+
+def test_code_object_is_gfx950(libpath):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", libpath], capture_output=True, text=True)
+    txt = out.stdout + out.stderr
+    assert "gfx950" in txt
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from macarons_amd import ops
+    with pytest.raises(_lib.MacaronsHipError):
+        ops.sh_coverage_gain(torch.zeros(1, 4, 4), torch.zeros(1, 4, 64), torch.zeros(1, 2, 3))

@@ -1,0 +1,96 @@
+"""Pin the oracle (our CPU restatement) to golden vectors produced by the real reference."""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err
+from oracle import sh, scorer
+
+
+def test_sh_basis_matches_reference():
+    g = golden("sh_basis")
+    Y32 = sh.sh_basis_literal(g["theta"], g["phi"], np.float32)
+    Y64 = sh.sh_basis_literal(g["theta"], g["phi"], np.float64)
+    assert np.abs(Y64 - g["Y_f64"]).max() < 1e-13
+    assert np.abs(Y32 - g["Y_f32"]).max() < 5e-6
+
+
+def test_sh_known_answers():
+    # SURVEY §8c known answers: Y_00, and the l=1 triple at theta=0.3, phi=0.5
+    Y = sh.sh_basis_literal(np.array([0.3]), np.array([0.5]), np.float64)[0]
+    assert abs(Y[0] - 0.28209479177387814) < 1e-15
+    k = np.sqrt(3 / (4 * np.pi))
+    np.testing.assert_allclose(Y[1:4], [-k * np.sin(0.3) * np.sin(0.5), k * np.cos(0.3), -k * np.sin(0.3) * np.cos(0.5)],
+                               rtol=1e-13)
+
+
+def test_sh_orthonormal():
+    # Gauss-Legendre x uniform-phi quadrature: the 64 real SH are orthonormal on the sphere
+    x, w = np.polynomial.legendre.leggauss(24)
+    phi = np.arange(48) * 2 * np.pi / 48
+    T, P = np.meshgrid(np.arccos(x), phi, indexing="ij")
+    W = (w[:, None] * np.ones_like(phi)[None, :] * 2 * np.pi / 48).reshape(-1)
+    Y = sh.sh_basis_literal(T.reshape(-1), P.reshape(-1), np.float64)
+    G = (Y * W[:, None]).T @ Y
+    assert np.abs(G - np.eye(64)).max() < 1e-12
+
+
+def test_trigfree_equals_literal_fp64():
+    rng = np.random.default_rng(0)
+    rays = rng.standard_normal((4000, 3))
+    _, e, a = sh.spherical_coords(rays)
+    Yl = sh.sh_basis_literal(np.pi / 2 - e, a, np.float64)
+    Yt = sh.sh_basis_trigfree(rays, np.float64)
+    assert np.abs(Yl - Yt).max() < 1e-11
+
+
+def test_spherical_coords_matches_reference():
+    g = golden("sh_basis")
+    for name, dt, tol in (("f32", np.float32, 5e-4), ("f64", np.float64, 1e-12)):
+        r, e, a = sh.spherical_coords(g["rays"].astype(dt))
+        assert np.array_equal(np.isnan(a), np.isnan(g["azim_" + name]))
+        ok = ~np.isnan(a)
+        assert np.abs(r - g["r_" + name]).max() < tol
+        assert np.abs(e - g["elev_" + name]).max() < tol
+        assert np.abs(a[ok] - g["azim_" + name][ok]).max() < tol      # fp32 acos near +-1 is ill-conditioned
+        # get_cartesian_coords on the reference's own angles (isolates it from the acos conditioning)
+        back = sh.cartesian_coords(g["r_" + name], g["elev_" + name], g["azim_" + name])
+        assert np.nanmax(np.abs(back - g["cart_" + name])) < (2e-6 if dt == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("name", ["scorer_b1_n2048_c20", "scorer_b2_n500_c7"])
+@pytest.mark.parametrize("sfx,use_sigmoid", [("sig", True), ("relu", False)])
+def test_scorer_matches_reference(name, sfx, use_sigmoid):
+    d = golden(name)
+    a = (d["pts"], d["harmonics"], d["cams"], use_sigmoid)
+    g64 = scorer.compute_coverage_gain(*a, "literal", np.float64)
+    assert rel_err(g64, d["gain64_" + sfx]) < 1e-12
+    v64 = scorer.compute_visibilities(*a, "literal", np.float64)
+    assert np.abs(v64 - d["vis64_" + sfx]).max() < 1e-9
+    # trig-free fp64 == reference fp64 (what the kernel is compared with for per-point values)
+    vt = scorer.compute_visibilities(*a, "trigfree", np.float64)
+    assert np.abs(vt - d["vis64_" + sfx]).max() < 1e-9
+    # fp32 literal restatement vs fp32 reference: gains agree to 1e-5 (per-point fp32 values are
+    # ill-conditioned in the reference itself: SURVEY §7)
+    g32 = scorer.compute_coverage_gain(*a, "literal", np.float32)
+    assert rel_err(g32, d["gain32_" + sfx]) < 2e-5
+    assert rel_err(d["gain32_" + sfx], d["gain64_" + sfx]) < 1e-4
+
+
+def test_scorer_multiple_matches_reference():
+    d = golden("scorer_b2_n500_c7")
+    m2, i2 = scorer.compute_coverage_gain_multiple(d["pts"], d["harmonics"], d["cams"], 2)
+    assert np.array_equal(i2, d["multi2_idx"])
+    assert rel_err(m2, d["multi2"]) < 1e-5
+    m3, i3 = scorer.compute_coverage_gain_multiple(d["pts"][:, :128], d["harmonics"][:, :128], d["cams"][:, :4], 3)
+    assert np.array_equal(i3, d["multi3_idx"])
+    assert rel_err(m3, d["multi3"]) < 1e-5
+    with pytest.raises(NameError):
+        scorer.compute_coverage_gain_multiple(d["pts"], d["harmonics"], d["cams"], 4)
+
+
+def test_scorer_zero_harmonics_is_half():
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-.5, .5, (1, 100, 4)).astype(np.float32)
+    cams = rng.standard_normal((1, 9, 3)).astype(np.float32)
+    g = scorer.compute_coverage_gain(pts, np.zeros((1, 100, 64), np.float32), cams)
+    assert np.all(g == 0.5)

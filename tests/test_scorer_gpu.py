@@ -1,0 +1,112 @@
+"""Parity of the HIP SH coverage-gain scorer (through the C ABI) against the oracle and the
+reference goldens.  Tolerances (north_star): gains within 1e-4 relative (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_err
+from oracle import scorer, cport
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(dev, pts, harm, cams, use_sigmoid=True, **kw):
+    from macarons_amd import ops
+    g = ops.sh_coverage_gain(torch.from_numpy(pts).to(dev), torch.from_numpy(harm).to(dev),
+                             torch.from_numpy(cams).to(dev), use_sigmoid, **kw)
+    v = ops.sh_visibilities(torch.from_numpy(pts).to(dev), torch.from_numpy(harm).to(dev),
+                            torch.from_numpy(cams).to(dev), use_sigmoid)
+    torch.cuda.synchronize()
+    return g.cpu().numpy(), v.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["scorer_b1_n2048_c20", "scorer_b2_n500_c7"])
+@pytest.mark.parametrize("sfx,use_sigmoid", [("sig", True), ("relu", False)])
+def test_golden(dev, name, sfx, use_sigmoid):
+    d = golden(name)
+    g, v = _run(dev, d["pts"], d["harmonics"], d["cams"], use_sigmoid)
+    assert g.shape == d["gain32_" + sfx].shape and v.shape == d["vis32_" + sfx].shape
+    assert rel_err(g, d["gain32_" + sfx]) < 1e-4          # the north_star bar, vs the fp32 reference
+    assert rel_err(g, d["gain64_" + sfx]) < 2e-5          # and much closer to the fp64 reference
+    # per-point values: vs the reference's fp64 run (its fp32 trig is ill-conditioned)
+    scale = max(1.0, np.abs(d["vis64_" + sfx]).max())
+    assert np.abs(v - d["vis64_" + sfx]).max() < 2e-5 * scale
+
+
+@pytest.mark.parametrize("B,N,C,P", [(1, 1, 1, 3), (1, 63, 3, 3), (3, 257, 65, 4), (2, 1000, 130, 5), (1, 5000, 52, 4)])
+def test_ragged_shapes_vs_oracle(dev, B, N, C, P):
+    rng = np.random.default_rng(B * 1000 + N + C)
+    pts = rng.uniform(-.5, .5, (B, N, P)).astype(np.float32)
+    harm = (rng.standard_normal((B, N, 64)) * 0.7).astype(np.float32)
+    cams = rng.standard_normal((B, C, 3)).astype(np.float32)
+    cams = (1.5 * cams / np.linalg.norm(cams, axis=-1, keepdims=True)).astype(np.float32)
+    g, v = _run(dev, pts, harm, cams)
+    ref_v = scorer.compute_visibilities(pts, harm, cams, True, "trigfree", np.float64)
+    assert np.abs(v - ref_v).max() < 2e-5
+    assert rel_err(g, ref_v.mean(-1)) < 2e-5
+    # C port (the literal fp32 restatement, also the timed CPU baseline)
+    gp, _ = cport.coverage_gain(pts, harm, cams)
+    assert rel_err(g, gp) < 1e-4
+
+
+def test_cam_chunk_invariance_and_determinism(dev):
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-.5, .5, (1, 3000, 4)).astype(np.float32)
+    harm = rng.standard_normal((1, 3000, 64)).astype(np.float32)
+    cams = rng.standard_normal((1, 77, 3)).astype(np.float32)
+    g0, _ = _run(dev, pts, harm, cams)
+    for chunk in (1, 7, 32, 64):
+        g, _ = _run(dev, pts, harm, cams, cam_chunk=chunk)
+        assert np.array_equal(g, g0)        # per-camera results do not depend on the chunking
+    g1, _ = _run(dev, pts, harm, cams)
+    assert np.array_equal(g0, g1)           # bit-stable run to run (no float atomics)
+
+
+def test_known_answers(dev):
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-.5, .5, (2, 777, 4)).astype(np.float32)
+    cams = rng.standard_normal((2, 9, 3)).astype(np.float32)
+    g, v = _run(dev, pts, np.zeros((2, 777, 64), np.float32), cams)
+    assert np.all(g == 0.5) and np.all(v == 0.5)           # sigmoid(0) for every camera
+    # permutation invariance over points
+    harm = rng.standard_normal((2, 777, 64)).astype(np.float32)
+    g0, _ = _run(dev, pts, harm, cams)
+    perm = rng.permutation(777)
+    g1, _ = _run(dev, pts[:, perm].copy(), harm[:, perm].copy(), cams)
+    assert rel_err(g1, g0) < 1e-6
+
+
+def test_axis_aligned_rays_are_finite(dev):
+    # ray exactly on +-Y (x = z = 0): the build returns the finite limit (all m != 0 terms vanish)
+    pts = np.zeros((1, 4, 3), np.float32)
+    cams = np.array([[[0, 1.5, 0], [0, -1.5, 0], [1.5, 0, 0], [0, 0, -1.5]]], np.float32)
+    harm = np.random.default_rng(0).standard_normal((1, 4, 64)).astype(np.float32)
+    g, v = _run(dev, pts, harm, cams)
+    assert np.isfinite(g).all() and np.isfinite(v).all()
+    ref = scorer.compute_visibilities(pts, harm, cams, True, "trigfree", np.float64)
+    assert np.abs(v - ref).max() < 2e-5
+
+
+def test_large_headline_properties(dev):
+    """BASELINE headline size (N=100k, C=200): size-independent properties instead of a full oracle run."""
+    from macarons_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    N, C = 100_000, 200
+    pts = (torch.rand(1, N, 4, generator=gen) - 0.5)
+    harm = torch.randn(1, N, 64, generator=gen) * 0.5
+    cams = torch.randn(1, C, 3, generator=gen)
+    cams = 1.5 * cams / cams.norm(dim=-1, keepdim=True)
+    g = ops.sh_coverage_gain(pts.to(dev), harm.to(dev), cams.to(dev))
+    # mean of per-point visibilities == gain
+    v = ops.sh_visibilities(pts.to(dev), harm.to(dev), cams.to(dev))
+    assert rel_err(g.cpu().numpy(), v.double().mean(-1).cpu().numpy()) < 1e-6
+    # splitting the cloud in two halves: gain = average of the halves' gains
+    h = N // 2
+    ga = ops.sh_coverage_gain(pts[:, :h].contiguous().to(dev), harm[:, :h].contiguous().to(dev), cams.to(dev))
+    gb = ops.sh_coverage_gain(pts[:, h:].contiguous().to(dev), harm[:, h:].contiguous().to(dev), cams.to(dev))
+    assert rel_err(((ga + gb) / 2).cpu().numpy(), g.cpu().numpy()) < 1e-6
+    # a bounded sample against the C port
+    sel = slice(0, 7)
+    gp, _ = cport.coverage_gain(pts.numpy(), harm.numpy(), cams[:, sel].numpy())
+    assert rel_err(g[:, sel].cpu().numpy(), gp) < 1e-4
+    assert 0.0 < float(g.min()) and float(g.max()) < 1.0
