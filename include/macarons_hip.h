@@ -31,11 +31,11 @@ const char* mcr_target_arch(void);
  * with the real SH basis of macarons/utility/spherical_harmonics.py:111-157 in the angle convention
  * of macarons/utility/CustomGeometry.py:27-45; act = sigmoid (use_sigmoid) or relu (SconeVis.py:242-245).
  *   pts [B,N,pts_dim] (pts_dim >= 3, only xyz read — SconeVis.py:224), harmonics [B,N,64],
- *   cams [B,C,3], gains [B,C].  cam_chunk: cameras per workgroup, 0 = auto.
+ *   cams [B,C,3], gains [B,C].  waves_per_simd: grid sizing override, 0 = auto (whole grid co-resident).
  * Deterministic (two-pass reduce, no float atomics). */
 size_t mcr_sh_coverage_gain_workspace_bytes(int64_t B, int64_t N, int64_t C);
 int mcr_sh_coverage_gain(const float* pts, int pts_dim, const float* harmonics, const float* cams, float* gains,
-                         int64_t B, int64_t N, int64_t C, int use_sigmoid, int cam_chunk, void* workspace,
+                         int64_t B, int64_t N, int64_t C, int use_sigmoid, int waves_per_simd, void* workspace,
                          size_t workspace_bytes, void* stream);
 
 /* Replaces SconeVis.compute_visibilities (SconeVis.py:164-208) == Macarons.compute_visibility_gains

@@ -36,6 +36,9 @@ def declared_symbols(header_path=HEADER_PATH):
 def lib():
     global _lib
     if _lib is None:
+        # torch first: it ships its own libamdhip64; loading ours before it would bring up a second HIP
+        # runtime (/opt/rocm) in the process and every launch would fail with "no ROCm-capable device".
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise MacaronsHipError(
                 f"{LIB_PATH} not found: build it with `python -m macarons_amd.build` "

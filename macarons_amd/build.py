@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libmacarons_hip.so")
 STAMP = LIB_PATH + ".stamp"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-ffp-contract=fast",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("MCR_HIPCC_FLAGS", "").split()
 
 
 def sources():

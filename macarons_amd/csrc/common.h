@@ -28,8 +28,6 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- wave64 DPP reductions ---------------------------------------------------------------------------
 // After wave_sum_to_last(), lane 63 holds the sum of all 64 lanes (other lanes hold partial garbage).
-__device__ __forceinline__ float dpp_add(float v, float src, int ctrl_unused) { return v + src; }
-
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
 __device__ __forceinline__ float dpp_mov0(float v) {
     // old = 0, bound_ctrl = true: lanes without a source read 0.
@@ -45,6 +43,23 @@ __device__ __forceinline__ float wave_sum_to_last(float v) {
     v += dpp_mov0<0x142, 0xa>(v);        // row_bcast:15 into rows 1,3
     v += dpp_mov0<0x143, 0xc>(v);        // row_bcast:31 into rows 2,3 -> lane 63 = wave sum
     return v;
+}
+
+// G independent reductions, step-major: the chains hide each other's DPP wait states.
+template <int G>
+__device__ __forceinline__ void wave_sum_to_last_multi(float (&v)[G]) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] += dpp_mov0<0x111>(v[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] += dpp_mov0<0x112>(v[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] += dpp_mov0<0x114>(v[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] += dpp_mov0<0x118>(v[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] += dpp_mov0<0x142, 0xa>(v[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] += dpp_mov0<0x143, 0xc>(v[g]);
 }
 
 __device__ __forceinline__ float wave_max_all(float v) {

@@ -5,76 +5,93 @@
 //   macarons/networks/SconeVis.py:164-208  compute_visibilities    -> vis   [B,C,N]
 //   (== macarons/networks/Macarons.py:138-178 compute_visibility_gains)
 // which materialise [B*C*N,64] SH tensors three times.  Here: one lane owns one point (its 64 SH
-// coefficients live in VGPRs, pre-scaled once by the recurrence constants), cameras are broadcast from
-// LDS, the 64 real SH of the ray direction are produced by trig-free recurrences and contracted on the
+// coefficients live in VGPRs, pre-scaled once by the recurrence constants), cameras come from wave-uniform
+// scalar loads, the 64 real SH of the ray direction are produced by trig-free recurrences and contracted on the
 // fly (~170 VALU ops per (point,camera) pair), sigmoid/relu applied, and the per-camera sum over points
-// is a wave64 DPP reduction -> per-tile partials -> a deterministic second-pass reduce (bit-stable
+// is a wave64 DPP reduction -> per-wave-tile partials -> a deterministic second-pass reduce (bit-stable
 // run to run).  Bound: fp32 VALU (370 algorithmic flop / pair; N*268 B of HBM per cloud).
 //
 // Conventions (reference CustomGeometry.py:27-45, spherical_harmonics.py:67-140): polar axis +Y,
 // azimuth from +Z toward +X; channel k = l*l + l + m; Condon-Shortley phase included.
 #include "common.h"
 #include "sh_consts.inc"
+#include <algorithm>
 
 namespace mcr {
 
 constexpr int SC_BLOCK = 256;       // 4 waves; one point per lane
-constexpr int SC_MAX_CHUNK = 64;    // cameras per block (LDS staging)
 
 __device__ __forceinline__ constexpr int shk(int l, int m) { return l * l + l + m; }
 
-// z = sum_k Y_k(d) h_k  with hs[k] = SH_LAMBDA[l][|m|] * h_k  (see gen_sh_consts.py for the algebra).
+// z = sum_k Y_k(d) h_k  with hs[k] = SH_LAMBDA[l][|m|] * h_k  (algebra in gen_sh_consts.py), trig-free:
+//   n = d / |d|  (one v_rsq);  cos(polar) = n_y;   sin(polar)^m {cos,sin}(m azim) = {Re,Im} (n_z + i n_x)^m
+// so sin(polar), the azimuth normalisation 1/rho and the rho = 0 special case never appear (a ray along +-Y
+// simply has n_x = n_z = 0 and every m != 0 term vanishes; the reference's acos path is ill-conditioned there).
+//   Rt_l^m : Rt_m^m = 1, Rt_{m+1}^m = ct, Rt_l^m = ct Rt_{l-1}^m - BP[l][m] Rt_{l-2}^m      (P_l^m / sin^m)
+//   z = sum_l Rt_l^0 h[l,0] + sum_{m>=1} ( C_m sum_l Rt_l^m h[l,+m] + S_m sum_l Rt_l^m h[l,-m] )
+// ~140 VALU ops per (point, camera) pair.  Measured on MI355X (tools/ubench): a dependent v_fma_f32 chain
+// issues every ~8.8 cycles per wave, 5 waves/SIMD of this code reach ~345 G pairs/s; v_pk_fma_f32 is half
+// rate and interleaving several cameras per lane buys nothing at that occupancy.
 __device__ __forceinline__ float sh_dot(float dx, float dy, float dz, const float (&hs)[64]) {
-    const float rho2 = fmaf(dz, dz, dx * dx);
-    const float r2 = fmaf(dy, dy, rho2);
+    const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const float ir = __builtin_amdgcn_rsqf(r2);
-    const float irho = rho2 > 0.f ? __builtin_amdgcn_rsqf(rho2) : 0.f;   // ray || Y: m>0 terms vanish
-    const float ct = dy * ir;                 // cos(polar)
-    const float st = (rho2 * irho) * ir;      // sin(polar) = rho / r
-    const float cp = dz * irho;               // cos(azim)
-    const float sp = dx * irho;               // sin(azim)
+    const float nx = dx * ir, ct = dy * ir, nz = dz * ir;
 
-    // m = 0 column
-    float z = hs[0];
+    float z = fmaf(ct, hs[shk(1, 0)], hs[0]);
     {
-        float r2_ = 1.f, r1_ = ct;
-        z = fmaf(r1_, hs[shk(1, 0)], z);
+        float r2_ = ct, r1_ = fmaf(ct, ct, -SH_BP[2][0]);
+        z = fmaf(r1_, hs[shk(2, 0)], z);
 #pragma unroll
-        for (int l = 2; l < 8; ++l) {
+        for (int l = 3; l < 8; ++l) {
             const float r = fmaf(ct, r1_, -SH_BP[l][0] * r2_);
             z = fmaf(r, hs[shk(l, 0)], z);
             r2_ = r1_;
             r1_ = r;
         }
     }
-    // m = 1..7 : U_m = sum_l R_l^m h[l,+m], V_m = sum_l R_l^m h[l,-m];  z += cos(m p) U_m + sin(m p) V_m
-    const float tc = cp + cp;
-    float cm1 = 1.f, cm = cp, sm1 = 0.f, sm = sp;
-    float stm = 1.f;
+    float cm = nz, sm = nx;                     // (n_z + i n_x)^m
 #pragma unroll
     for (int m = 1; m < 8; ++m) {
-        stm *= st;
-        float U = stm * hs[shk(m, m)];
-        float V = stm * hs[shk(m, -m)];
-        float r2_ = stm, r1_ = ct * stm;
+        float U = hs[shk(m, m)], V = hs[shk(m, -m)];
         if (m < 7) {
-            U = fmaf(r1_, hs[shk(m + 1, m)], U);
-            V = fmaf(r1_, hs[shk(m + 1, -m)], V);
+            U = fmaf(ct, hs[shk(m + 1, m)], U);
+            V = fmaf(ct, hs[shk(m + 1, -m)], V);
         }
+        if (m < 6) {
+            float r2_ = ct, r1_ = fmaf(ct, ct, -SH_BP[m + 2][m]);
+            U = fmaf(r1_, hs[shk(m + 2, m)], U);
+            V = fmaf(r1_, hs[shk(m + 2, -m)], V);
 #pragma unroll
-        for (int l = m + 2; l < 8; ++l) {
-            const float r = fmaf(ct, r1_, -SH_BP[l][m] * r2_);
-            U = fmaf(r, hs[shk(l, m)], U);
-            V = fmaf(r, hs[shk(l, -m)], V);
-            r2_ = r1_;
-            r1_ = r;
+            for (int l = m + 3; l < 8; ++l) {
+                const float r = fmaf(ct, r1_, -SH_BP[l][m] * r2_);
+                U = fmaf(r, hs[shk(l, m)], U);
+                V = fmaf(r, hs[shk(l, -m)], V);
+                r2_ = r1_;
+                r1_ = r;
+            }
         }
         z = fmaf(cm, U, z);
         z = fmaf(sm, V, z);
-        const float cn = fmaf(tc, cm, -cm1), sn = fmaf(tc, sm, -sm1);
-        cm1 = cm; cm = cn; sm1 = sm; sm = sn;
+        if (m < 7) {
+            const float cn = fmaf(nz, cm, -nx * sm), sn = fmaf(nz, sm, nx * cm);
+            cm = cn; sm = sn;
+        }
     }
     return z;
+}
+
+// One point's 64 SH coefficients -> VGPRs, pre-scaled by the recurrence constants.
+__device__ __forceinline__ void load_scaled_coeffs(const float* __restrict__ h, float (&hs)[64]) {
+    const float4* h4 = reinterpret_cast<const float4*>(h);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float4 v = h4[j];
+        hs[4 * j + 0] = v.x; hs[4 * j + 1] = v.y; hs[4 * j + 2] = v.z; hs[4 * j + 3] = v.w;
+    }
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+#pragma unroll
+        for (int m = -l; m <= l; ++m) hs[shk(l, m)] *= SH_LAMBDA[l][m < 0 ? -m : m];
 }
 
 template <bool SIGMOID>
@@ -87,92 +104,139 @@ __device__ __forceinline__ float activate(float z) {
     return fmaxf(z, 0.f);
 }
 
-// grid = (point tiles, camera chunks, B)
-template <bool PER_POINT, bool SIGMOID>
-__global__ __launch_bounds__(SC_BLOCK) void sh_score_kernel(const float* __restrict__ pts, int pts_stride,
-                                                            const float* __restrict__ harm,
-                                                            const float* __restrict__ cams, float* __restrict__ out,
-                                                            int N, int C, int chunk, int n_tiles) {
-    __shared__ float s_cam[SC_MAX_CHUNK * 3];
-    __shared__ float s_part[SC_BLOCK / MCR_WAVE][SC_MAX_CHUNK];
+// ---- work decomposition (both kernels) ----------------------------------------------------------------------
+// A "wave-unit" is (wave-tile of 64 points, camera).  The U = B * ceil(N/64) * C units are split into W equal
+// contiguous ranges, one per wave, with W = min(U, co-resident waves of the chip): the whole grid is resident
+// and every wave finishes at the same time (measured: equal-size blocks needing 2.14 rounds cost 3).  A wave
+// walks its range as segments (one wave-tile x a camera range): it loads the tile's 64x64 coefficients into
+// VGPRs once per segment, then loops over the cameras (wave-uniform -> scalar loads).  No LDS, no barriers.
+//
+// ---- coverage-gain kernel (mean over points) ---------------------------------------------------------------
+// Cameras are taken SC_G at a time so the SC_G six-step DPP wave reductions are independent chains that hide
+// each other's DPP wait states.  Each partial[b][wave-tile][c] is written by exactly one wave; the second
+// pass adds them in a fixed order -> bit-stable results (no float atomics).
+constexpr int SC_G = 4;
 
-    const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
-    const int c0 = blockIdx.y * chunk;
-    const int nc = min(chunk, C - c0);
-    const int b = blockIdx.z;
-
-    if (tid < nc * 3) s_cam[tid] = cams[((size_t)b * C + c0) * 3 + tid];
-
-    const int n = tile * SC_BLOCK + tid;
-    const bool valid = n < N;
-    const size_t pn = (size_t)b * N + (valid ? n : N - 1);
-
-    const float px = pts[pn * pts_stride + 0];
-    const float py = pts[pn * pts_stride + 1];
-    const float pz = pts[pn * pts_stride + 2];
-
-    float hs[64];
-    {
-        const float4* h4 = reinterpret_cast<const float4*>(harm + pn * 64);
+template <bool SIGMOID>
+__global__ __launch_bounds__(SC_BLOCK) void sh_gain_kernel(const float* __restrict__ pts, int pts_stride,
+                                                           const float* __restrict__ harm,
+                                                           const float* __restrict__ cams, float* __restrict__ partial,
+                                                           int N, int C, int n_wtiles, long long U, int W) {
+    const int lane = threadIdx.x & (MCR_WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (SC_BLOCK / MCR_WAVE) + threadIdx.x / MCR_WAVE);
+    if (w >= W) return;
+    long long u = (U * w) / W;
+    const long long u_end = (U * (w + 1)) / W;
+    while (u < u_end) {
+        const long long bt = u / C;                          // flattened (cloud, wave-tile)
+        const int c_begin = (int)(u - bt * C);
+        const int c_end = (int)min((long long)C, (long long)c_begin + (u_end - u));
+        const int b = (int)(bt / n_wtiles);
+        const int wt = (int)(bt - (long long)b * n_wtiles);
+        u += c_end - c_begin;
+        const int n = wt * MCR_WAVE + lane;
+        const bool valid = n < N;
+        const size_t pn = (size_t)b * N + (valid ? n : N - 1);
+        const float px = pts[pn * pts_stride + 0];
+        const float py = pts[pn * pts_stride + 1];
+        const float pz = pts[pn * pts_stride + 2];
+        float hs[64];
+        load_scaled_coeffs(harm + pn * 64, hs);
+        const float keep = valid ? 1.f : 0.f;
+        const float* cam_b = cams + (size_t)b * C * 3;
+        float* part_row = partial + (size_t)bt * C;          // partial[b][wt][:]
+        for (int ci = c_begin; ci < c_end; ci += SC_G) {
+            float v[SC_G];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float4 v = h4[j];
-            hs[4 * j + 0] = v.x; hs[4 * j + 1] = v.y; hs[4 * j + 2] = v.z; hs[4 * j + 3] = v.w;
-        }
+            for (int c = 0; c < SC_G; ++c) {
+                const int i = min(ci + c, c_end - 1);       // ragged tail: surplus slots repeat the last camera
+                // rays = X_cam - X_pts (SconeVis.py:230-231)
+                const float z = sh_dot(cam_b[3 * i + 0] - px, cam_b[3 * i + 1] - py, cam_b[3 * i + 2] - pz, hs);
+                v[c] = activate<SIGMOID>(z) * keep;
+            }
 #pragma unroll
-        for (int l = 0; l < 8; ++l)
+            for (int c = 0; c < SC_G; ++c) asm volatile("" : "+v"(v[c]));   // all SC_G values before the reductions
+            float sum[SC_G];
 #pragma unroll
-            for (int m = -l; m <= l; ++m) hs[shk(l, m)] *= SH_LAMBDA[l][m < 0 ? -m : m];
-    }
-    __syncthreads();
-
-    const int lane = tid & (MCR_WAVE - 1);
-    const int wave = tid / MCR_WAVE;
-
-    for (int ci = 0; ci < nc; ++ci) {
-        const float dx = s_cam[3 * ci + 0] - px;     // rays = X_cam - X_pts (SconeVis.py:230-231)
-        const float dy = s_cam[3 * ci + 1] - py;
-        const float dz = s_cam[3 * ci + 2] - pz;
-        float v = activate<SIGMOID>(sh_dot(dx, dy, dz, hs));
-        if (PER_POINT) {
-            if (valid) out[((size_t)b * C + c0 + ci) * N + n] = v;
-        } else {
-            v = valid ? v : 0.f;
-            const float s = wave_sum_to_last(v);
-            if (lane == MCR_WAVE - 1) s_part[wave][ci] = s;
-        }
-    }
-    if (!PER_POINT) {
-        __syncthreads();
-        if (tid < nc) {
-            const float s = (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
-            out[((size_t)b * n_tiles + tile) * C + c0 + tid] = s;     // partial[b][tile][c]
+            for (int c = 0; c < SC_G; ++c) sum[c] = v[c];
+            wave_sum_to_last_multi<SC_G>(sum);
+            if (lane == MCR_WAVE - 1) {
+#pragma unroll
+                for (int c = 0; c < SC_G; ++c)
+                    if (ci + c < c_end) part_row[ci + c] = sum[c];
+            }
         }
     }
 }
 
-// gains[b][c] = (sum_tile partial[b][tile][c]) / N      (fixed order -> deterministic)
-__global__ void sh_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gains, int n_tiles, int C,
-                                 int BC, float inv_n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BC) return;
-    const int b = i / C, c = i - b * C;
-    const float* p = partial + (size_t)b * n_tiles * C + c;
+// gains[b][c] = (sum_wt partial[b][wt][c]) / N ; one 256-thread block per (b,c), fixed tree order.
+__global__ __launch_bounds__(256) void sh_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gains,
+                                                        int n_wtiles, int C, float inv_n) {
+    __shared__ double s_w[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float* p = partial + (size_t)b * n_wtiles * C + c;
     double acc = 0.0;
-    for (int t = 0; t < n_tiles; ++t) acc += (double)p[(size_t)t * C];
-    gains[i] = (float)acc * inv_n;
+    for (int t = threadIdx.x; t < n_wtiles; t += 256) acc += (double)p[(size_t)t * C];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) gains[(size_t)b * C + c] = (float)((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])) * inv_n;
 }
 
-static int pick_chunk(int64_t B, int64_t N, int64_t C, int requested) {
-    if (requested > 0) return requested > SC_MAX_CHUNK ? SC_MAX_CHUNK : requested;
-    // Aim for >= ~8 blocks per CU (256 CUs) so the equal-length blocks tile the chip with a small tail,
-    // but keep >= 8 cameras per block so the 256 B/point coefficient load stays amortised.
-    const int64_t tiles = cdiv(N, SC_BLOCK) * B;
-    int chunk = SC_MAX_CHUNK;
-    while (chunk > 8 && tiles * cdiv(C, chunk) < 2048) chunk /= 2;
-    if (chunk > C) chunk = (int)C;
-    return chunk < 1 ? 1 : chunk;
+// ---- per-point kernel (visibilities [B,C,N]) ---------------------------------------------------------------
+template <bool SIGMOID>
+__global__ __launch_bounds__(SC_BLOCK) void sh_vis_kernel(const float* __restrict__ pts, int pts_stride,
+                                                          const float* __restrict__ harm,
+                                                          const float* __restrict__ cams, float* __restrict__ out,
+                                                          int N, int C, int n_wtiles, long long U, int W) {
+    const int lane = threadIdx.x & (MCR_WAVE - 1);
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (SC_BLOCK / MCR_WAVE) + threadIdx.x / MCR_WAVE);
+    if (w >= W) return;
+    long long u = (U * w) / W;
+    const long long u_end = (U * (w + 1)) / W;
+    while (u < u_end) {
+        const long long bt = u / C;                          // flattened (cloud, wave-tile)
+        const int c_begin = (int)(u - bt * C);
+        const int c_end = (int)min((long long)C, (long long)c_begin + (u_end - u));
+        const int b = (int)(bt / n_wtiles);
+        const int wt = (int)(bt - (long long)b * n_wtiles);
+        u += c_end - c_begin;
+        const int n = wt * MCR_WAVE + lane;
+        const bool valid = n < N;
+        const size_t pn = (size_t)b * N + (valid ? n : N - 1);
+        const float px = pts[pn * pts_stride + 0];
+        const float py = pts[pn * pts_stride + 1];
+        const float pz = pts[pn * pts_stride + 2];
+        float hs[64];
+        load_scaled_coeffs(harm + pn * 64, hs);
+        const float* cam_b = cams + (size_t)b * C * 3;
+        for (int ci = c_begin; ci < c_end; ++ci) {
+            const float z = sh_dot(cam_b[3 * ci + 0] - px, cam_b[3 * ci + 1] - py, cam_b[3 * ci + 2] - pz, hs);
+            const float v = activate<SIGMOID>(z);
+            if (valid) out[((size_t)b * C + ci) * N + n] = v;
+        }
+    }
+}
+
+// Waves that are co-resident on the chip for `kernel` (occupancy API: from its real VGPR allocation).
+template <typename Kern>
+static int resident_waves(Kern kernel, int waves_per_simd_override) {
+    int dev = 0, n_cu = 256, blocks_per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        n_cu = prop.multiProcessorCount;
+    if (waves_per_simd_override > 0) return n_cu * 4 * waves_per_simd_override;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, SC_BLOCK, 0) != hipSuccess || blocks_per_cu <= 0)
+        blocks_per_cu = 4;
+    return n_cu * blocks_per_cu * (SC_BLOCK / MCR_WAVE);
+}
+
+template <typename Kern>
+static int resident_waves_cached(Kern kernel, int waves_per_simd_override, int* cache) {
+    if (waves_per_simd_override > 0) return resident_waves(kernel, waves_per_simd_override);
+    if (!*cache) *cache = resident_waves(kernel, 0);
+    return *cache;
 }
 
 }  // namespace mcr
@@ -182,35 +246,37 @@ using namespace mcr;
 extern "C" {
 
 size_t mcr_sh_coverage_gain_workspace_bytes(int64_t B, int64_t N, int64_t C) {
-    return (size_t)B * (size_t)cdiv(N, SC_BLOCK) * (size_t)C * sizeof(float);
+    return (size_t)B * (size_t)cdiv(N, MCR_WAVE) * (size_t)C * sizeof(float);
 }
 
 int mcr_sh_coverage_gain(const float* pts, int pts_dim, const float* harmonics, const float* cams, float* gains,
-                         int64_t B, int64_t N, int64_t C, int use_sigmoid, int cam_chunk, void* workspace,
+                         int64_t B, int64_t N, int64_t C, int use_sigmoid, int waves_per_simd, void* workspace,
                          size_t workspace_bytes, void* stream) {
     MCR_REQUIRE(pts && harmonics && cams && gains, "mcr_sh_coverage_gain: null pointer");
     MCR_REQUIRE(pts_dim >= 3, "mcr_sh_coverage_gain: pts_dim must be >= 3 (got %d)", pts_dim);
     MCR_REQUIRE(B > 0 && N > 0 && C > 0, "mcr_sh_coverage_gain: empty problem B=%ld N=%ld C=%ld", (long)B, (long)N, (long)C);
-    MCR_REQUIRE(B <= 65535, "mcr_sh_coverage_gain: B too large");
+    MCR_REQUIRE(C <= 65535 * 64 && N < (1ll << 31) && B <= 65535, "mcr_sh_coverage_gain: problem too large");
+    MCR_REQUIRE(waves_per_simd >= 0 && waves_per_simd <= 16, "mcr_sh_coverage_gain: waves_per_simd out of range");
     MCR_REQUIRE(workspace && workspace_bytes >= mcr_sh_coverage_gain_workspace_bytes(B, N, C),
                 "mcr_sh_coverage_gain: workspace too small");
-    const int chunk = pick_chunk(B, N, C, cam_chunk);
-    const int n_tiles = (int)cdiv(N, SC_BLOCK);
-    const int n_chunks = (int)cdiv(C, chunk);
-    MCR_REQUIRE(n_chunks <= 65535, "mcr_sh_coverage_gain: too many camera chunks");
+    static int cache_sig = 0, cache_relu = 0;
+    const int resident = use_sigmoid ? resident_waves_cached(sh_gain_kernel<true>, waves_per_simd, &cache_sig)
+                                     : resident_waves_cached(sh_gain_kernel<false>, waves_per_simd, &cache_relu);
+    const int n_wtiles = (int)cdiv(N, MCR_WAVE);
+    const long long U = (long long)B * n_wtiles * C;
+    const int W = (int)std::min<long long>(U, resident);
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(n_tiles, n_chunks, (unsigned)B);
+    dim3 grid((unsigned)cdiv(W, SC_BLOCK / MCR_WAVE));
     float* partial = (float*)workspace;
     if (use_sigmoid)
-        hipLaunchKernelGGL((sh_score_kernel<false, true>), grid, dim3(SC_BLOCK), 0, s, pts, pts_dim, harmonics, cams,
-                           partial, (int)N, (int)C, chunk, n_tiles);
+        hipLaunchKernelGGL(sh_gain_kernel<true>, grid, dim3(SC_BLOCK), 0, s, pts, pts_dim, harmonics, cams, partial,
+                           (int)N, (int)C, n_wtiles, U, W);
     else
-        hipLaunchKernelGGL((sh_score_kernel<false, false>), grid, dim3(SC_BLOCK), 0, s, pts, pts_dim, harmonics, cams,
-                           partial, (int)N, (int)C, chunk, n_tiles);
-    MCR_LAUNCH_CHECK("sh_score_kernel");
-    const int BC = (int)(B * C);
-    hipLaunchKernelGGL(sh_reduce_kernel, dim3((unsigned)cdiv(BC, 128)), dim3(128), 0, s, partial, gains, n_tiles, (int)C,
-                       BC, 1.0f / (float)N);
+        hipLaunchKernelGGL(sh_gain_kernel<false>, grid, dim3(SC_BLOCK), 0, s, pts, pts_dim, harmonics, cams, partial,
+                           (int)N, (int)C, n_wtiles, U, W);
+    MCR_LAUNCH_CHECK("sh_gain_kernel");
+    hipLaunchKernelGGL(sh_reduce_kernel, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, partial, gains, n_wtiles, (int)C,
+                       1.0f / (float)N);
     MCR_LAUNCH_CHECK("sh_reduce_kernel");
     return 0;
 }
@@ -220,20 +286,22 @@ int mcr_sh_visibilities(const float* pts, int pts_dim, const float* harmonics, c
     MCR_REQUIRE(pts && harmonics && cams && vis, "mcr_sh_visibilities: null pointer");
     MCR_REQUIRE(pts_dim >= 3, "mcr_sh_visibilities: pts_dim must be >= 3 (got %d)", pts_dim);
     MCR_REQUIRE(B > 0 && N > 0 && C > 0, "mcr_sh_visibilities: empty problem");
-    MCR_REQUIRE(B <= 65535, "mcr_sh_visibilities: B too large");
-    const int chunk = pick_chunk(B, N, C, 0);
-    const int n_tiles = (int)cdiv(N, SC_BLOCK);
-    const int n_chunks = (int)cdiv(C, chunk);
-    MCR_REQUIRE(n_chunks <= 65535, "mcr_sh_visibilities: too many camera chunks");
+    MCR_REQUIRE(C < (1 << 24) && N < (1ll << 31), "mcr_sh_visibilities: problem too large");
+    static int cache_sig = 0, cache_relu = 0;
+    const int resident = use_sigmoid ? resident_waves_cached(sh_vis_kernel<true>, 0, &cache_sig)
+                                     : resident_waves_cached(sh_vis_kernel<false>, 0, &cache_relu);
+    const int n_wtiles = (int)cdiv(N, MCR_WAVE);
+    const long long U = (long long)B * n_wtiles * C;
+    const int W = (int)std::min<long long>(U, resident);
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(n_tiles, n_chunks, (unsigned)B);
+    dim3 grid((unsigned)cdiv(W, SC_BLOCK / MCR_WAVE));
     if (use_sigmoid)
-        hipLaunchKernelGGL((sh_score_kernel<true, true>), grid, dim3(SC_BLOCK), 0, s, pts, pts_dim, harmonics, cams, vis,
-                           (int)N, (int)C, chunk, n_tiles);
+        hipLaunchKernelGGL(sh_vis_kernel<true>, grid, dim3(SC_BLOCK), 0, s, pts, pts_dim, harmonics, cams, vis, (int)N,
+                           (int)C, n_wtiles, U, W);
     else
-        hipLaunchKernelGGL((sh_score_kernel<true, false>), grid, dim3(SC_BLOCK), 0, s, pts, pts_dim, harmonics, cams, vis,
-                           (int)N, (int)C, chunk, n_tiles);
-    MCR_LAUNCH_CHECK("sh_score_kernel<per_point>");
+        hipLaunchKernelGGL(sh_vis_kernel<false>, grid, dim3(SC_BLOCK), 0, s, pts, pts_dim, harmonics, cams, vis, (int)N,
+                           (int)C, n_wtiles, U, W);
+    MCR_LAUNCH_CHECK("sh_vis_kernel");
     return 0;
 }
 

@@ -29,7 +29,7 @@ def _p(t):
 
 
 # ---- K9 scorer -------------------------------------------------------------------------------------
-def sh_coverage_gain(pts, harmonics, cams, use_sigmoid=True, cam_chunk=0):
+def sh_coverage_gain(pts, harmonics, cams, use_sigmoid=True, waves_per_simd=0):
     """gains [B,C]; replaces SconeVis.compute_coverage_gain (SconeVis.py:210-252)."""
     pts, harmonics, cams = _req(pts, "pts"), _req(harmonics, "harmonics"), _req(cams, "X_cam")
     B, N, P = pts.shape
@@ -44,7 +44,7 @@ def sh_coverage_gain(pts, harmonics, cams, use_sigmoid=True, cam_chunk=0):
     ws = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=pts.device)
     with torch.cuda.device(pts.device):
         check(L.mcr_sh_coverage_gain(_p(pts), c_int(P), _p(harmonics), _p(cams), _p(gains), c_i64(B), c_i64(N),
-                                     c_i64(C), c_int(int(bool(use_sigmoid))), c_int(cam_chunk), _p(ws),
+                                     c_i64(C), c_int(int(bool(use_sigmoid))), c_int(waves_per_simd), _p(ws),
                                      c_size(ws.numel() * 4), _stream()), "mcr_sh_coverage_gain")
     return gains
 

@@ -49,15 +49,15 @@ def test_ragged_shapes_vs_oracle(dev, B, N, C, P):
     assert rel_err(g, gp) < 1e-4
 
 
-def test_cam_chunk_invariance_and_determinism(dev):
+def test_partition_invariance_and_determinism(dev):
     rng = np.random.default_rng(7)
     pts = rng.uniform(-.5, .5, (1, 3000, 4)).astype(np.float32)
     harm = rng.standard_normal((1, 3000, 64)).astype(np.float32)
     cams = rng.standard_normal((1, 77, 3)).astype(np.float32)
     g0, _ = _run(dev, pts, harm, cams)
-    for chunk in (1, 7, 32, 64):
-        g, _ = _run(dev, pts, harm, cams, cam_chunk=chunk)
-        assert np.array_equal(g, g0)        # per-camera results do not depend on the chunking
+    for wps in (1, 2, 3, 8):
+        g, _ = _run(dev, pts, harm, cams, waves_per_simd=wps)
+        assert np.array_equal(g, g0)        # per-camera results do not depend on the work partition
     g1, _ = _run(dev, pts, harm, cams)
     assert np.array_equal(g0, g1)           # bit-stable run to run (no float atomics)
 
