@@ -63,3 +63,21 @@ def sh_visibilities(pts, harmonics, cams, use_sigmoid=True):
         check(lib().mcr_sh_visibilities(_p(pts), c_int(P), _p(harmonics), _p(cams), _p(vis), c_i64(B), c_i64(N),
                                         c_i64(C), c_int(int(bool(use_sigmoid))), _stream()), "mcr_sh_visibilities")
     return vis
+
+
+# ---- K1 kNN ----------------------------------------------------------------------------------------
+def knn_points(X, pc, k, subtract_query=False):
+    """(pts [B,Q,k,3], dists [B,Q,k], idx [B,Q,k] int64); replaces utils.get_knn_points (utils.py:1497-1509);
+    subtract_query=True also applies SconeOcc.py:297-298 (neighbours minus the query)."""
+    X, pc = _req(X, "X"), _req(pc, "pc")
+    B, Q, d = X.shape
+    M = pc.shape[1]
+    if d != 3 or pc.shape[0] != B or pc.shape[2] != 3:
+        raise ValueError(f"X must be [B,Q,3] and pc [B,M,3]; got {tuple(X.shape)}, {tuple(pc.shape)}")
+    idx = torch.empty((B, Q, k), dtype=torch.int64, device=X.device)
+    dists = torch.empty((B, Q, k), dtype=torch.float32, device=X.device)
+    pts = torch.empty((B, Q, k, 3), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        check(lib().mcr_knn_points(_p(X), _p(pc), _p(idx), _p(dists), _p(pts), c_i64(B), c_i64(Q), c_i64(M), c_int(k),
+                                   c_int(int(bool(subtract_query))), _stream()), "mcr_knn_points")
+    return pts, dists, idx

@@ -109,7 +109,27 @@ def gen_sh():
     save("sh_basis", theta=TH, phi=PH, rays=rays, **res)
 
 
-GROUPS = {"scorer": gen_scorer, "sh": gen_sh}
+def gen_knn():
+    """G3: utils.get_knn_points (cdist + topk + knn_gather).  (a) inputs on a 2^-10 grid: d^2 is exact in fp32 in
+    any formulation, so indices are well defined up to exact ties; (b) real-valued inputs for the tie-aware check."""
+    get_knn_points = ref["utils"].get_knn_points
+    rng = np.random.default_rng(21)
+    Xg = (rng.integers(-512, 512, (1, 2000, 3)) / 1024.0).astype(np.float32)
+    pcg = (rng.integers(-512, 512, (1, 5000, 3)) / 1024.0).astype(np.float32)
+    pts, d, idx = get_knn_points(t(Xg), t(pcg), 16)
+    Xr = rng.uniform(-0.5, 0.5, (2, 700, 3)).astype(np.float32)
+    pcr = rng.uniform(-0.5, 0.5, (2, 1500, 3)).astype(np.float32)
+    ptsr, dr, idxr = get_knn_points(t(Xr), t(pcr), 16)
+    # tiny cloud: fewer than 25 points takes cdist's direct path
+    Xs = rng.uniform(-0.5, 0.5, (1, 9, 3)).astype(np.float32)
+    pcs = rng.uniform(-0.5, 0.5, (1, 20, 3)).astype(np.float32)
+    ptss, ds, idxs = get_knn_points(t(Xs), t(pcs), 16)
+    save("knn", Xg=Xg, pcg=pcg, idx_g=idx.numpy().astype(np.int32), dist_g=d.numpy(), pts_g=pts.numpy()[:, :50],
+         Xr=Xr, pcr=pcr, idx_r=idxr.numpy().astype(np.int32), dist_r=dr.numpy(),
+         Xs=Xs, pcs=pcs, idx_s=idxs.numpy().astype(np.int32), dist_s=ds.numpy())
+
+
+GROUPS = {"scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
