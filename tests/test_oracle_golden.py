@@ -94,3 +94,23 @@ def test_scorer_zero_harmonics_is_half():
     cams = rng.standard_normal((1, 9, 3)).astype(np.float32)
     g = scorer.compute_coverage_gain(pts, np.zeros((1, 100, 64), np.float32), cams)
     assert np.all(g == 0.5)
+
+
+def test_knn_matches_reference():
+    from oracle import knn
+    g = golden("knn")
+    # grid-quantised inputs: d^2 exact in fp32 in any formulation -> identical up to exact ties
+    p, d, i = knn.knn_points(g["Xg"], g["pcg"], 16)
+    assert (i == g["idx_g"]).mean() > 0.99
+    assert np.abs(d - g["dist_g"]).max() < 1e-7
+    assert knn.tie_aware_index_match(i, d, g["idx_g"], g["dist_g"], g["Xg"], g["pcg"], atol=1e-7)
+    same = i[:, :50] == g["idx_g"][:, :50]
+    assert np.array_equal(p[:, :50][same], g["pts_g"][same])
+    # real-valued inputs: the reference's |x|^2+|y|^2-2xy distances differ by ~5e-6 -> tie-aware check
+    for X, pc, idx, dist in ((g["Xr"], g["pcr"], g["idx_r"], g["dist_r"]), (g["Xs"], g["pcs"], g["idx_s"], g["dist_s"])):
+        p, d, i = knn.knn_points(X, pc, 16)
+        assert np.abs(d - dist).max() < 2e-5
+        assert knn.tie_aware_index_match(i, d, idx, dist, X, pc, atol=2e-5)
+    # a point of the cloud queried against the cloud: nearest distance is 0 and it is itself
+    p, d, i = knn.knn_points(g["pcs"], g["pcs"], 4)
+    assert np.all(d[..., 0] == 0) and np.array_equal(i[0, :, 0], np.arange(g["pcs"].shape[1]))
