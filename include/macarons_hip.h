@@ -49,7 +49,7 @@ int mcr_sh_visibilities(const float* pts, int pts_dim, const float* harmonics, c
  * (macarons/networks/SconeOcc.py:297-298).
  *   X [B,Q,3] queries, pc [B,M,3] surface points ->
  *   idx [B,Q,k] int64 (ascending distance; ties -> lower index), dists [B,Q,k], pts [B,Q,k,3]
- *   (neighbour coordinates, minus the query if subtract_query).  k in {1,4,8,16,32}, k <= M. */
+ *   (neighbour coordinates, minus the query if subtract_query).  k in {1,4,8,16}, k <= M. */
 int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B, int64_t Q,
                    int64_t M, int k, int subtract_query, void* stream);
 

@@ -40,6 +40,17 @@ def hipcc_path():
     return "hipcc"
 
 
+def per_file_flags(src):
+    """A source may carry a line `// MCR_HIPCC_FLAGS: <flags>`; those flags are appended for that file only
+    (e.g. knn.hip needs -ffp-contract=off: bit-exact parity forbids FMA contraction of the distance)."""
+    extra = []
+    with open(src) as f:
+        for line in f:
+            if line.startswith("// MCR_HIPCC_FLAGS:"):
+                extra += line.split(":", 1)[1].split()
+    return extra
+
+
 def build(force=False, verbose=False):
     dig = _digest()
     if not force and os.path.exists(LIB_PATH) and os.path.exists(STAMP):
@@ -52,7 +63,7 @@ def build(force=False, verbose=False):
     procs = []
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
-        cmd = [hipcc_path()] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-I", CSRC, "-o", obj]
+        cmd = [hipcc_path()] + [f for f in FLAGS if f != "-shared"] + per_file_flags(src) + ["-c", src, "-I", CSRC, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

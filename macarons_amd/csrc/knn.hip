@@ -5,24 +5,75 @@
 // offset step of macarons/networks/SconeOcc.py:297-298 (neighbours minus the query).
 //
 // One lane owns one query and keeps its k best (d2, index) pairs sorted in VGPRs; surface points stream
-// through LDS in tiles (one broadcast ds_read_b128 per candidate per wave).  Convention (shared with
+// through LDS in tiles (one broadcast ds_read_b128 per candidate per wave).  The 4 waves of a workgroup own the
+// SAME 64 queries and each scans a quarter of every tile (4x more waves in flight: Q/64 waves alone cannot
+// fill 1024 SIMDs), candidates are taken 4 at a time (independent distance computations, one branch per
+// batch), and the four sorted lists are merged through LDS at the end.  Convention (shared with
 // oracle/knn.py, see there why the reference's own tie order is unspecified):
 //   d2 = (dx*dx + dy*dy) + dz*dz in fp32 with every product and sum rounded (no FMA contraction),
 //   ascending by (d2, index): ties go to the lower index;  dists = sqrt(d2), correctly rounded.
+// MCR_HIPCC_FLAGS: -ffp-contract=off
 #include "common.h"
 
 namespace mcr {
 
 constexpr int KNN_BLOCK = 256;
-constexpr int KNN_TILE = 2048;     // surface points per LDS tile (32 KB as float4)
+constexpr int KNN_WAVES = KNN_BLOCK / MCR_WAVE;
+constexpr int KNN_TILE = 2048;     // surface points per LDS tile (32 KB as float4); multiple of 16
 
+// Insert (d2, idx) into the ascending list: slot j takes its upper neighbour if that one must move down,
+// the new element if it lands here, else keeps its value (one v_cmp + four v_cndmask per slot, no branches).
+template <int K>
+__device__ __forceinline__ void knn_insert(float (&bd)[K], int (&bi)[K], float d2, int idx) {
+    bool lands_or_below = d2 < bd[K - 1];    // strict: an equal distance never displaces an earlier index
+    if (lands_or_below) {
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) {
+            const bool up_moves = d2 < bd[j - 1];
+            const float nd = up_moves ? bd[j - 1] : d2;
+            const int ni = up_moves ? bi[j - 1] : idx;
+            bd[j] = lands_or_below ? nd : bd[j];
+            bi[j] = lands_or_below ? ni : bi[j];
+            lands_or_below = up_moves;
+        }
+        bd[0] = lands_or_below ? d2 : bd[0];
+        bi[0] = lands_or_below ? idx : bi[0];
+    }
+}
+
+// Correctly rounded fp32 sqrt (the device sqrtf / fp64 sqrt paths measured 1 ulp off in ~5% of cases):
+// start from v_sqrt_f32 (<= 1 ulp) and move to a neighbour if x lies beyond the midpoint, squared exactly in fp64.
+__device__ __forceinline__ float sqrt_cr(float x) {
+    if (!(x > 0.f)) return x;                                   // 0 (and NaN) pass through
+    float y = __builtin_amdgcn_sqrtf(x);
+    const float up = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+    const float dn = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
+    const double m_up = 0.5 * ((double)y + (double)up), m_dn = 0.5 * ((double)y + (double)dn);
+    const double xd = (double)x;
+    if (xd > m_up * m_up) y = up;
+    else if (xd < m_dn * m_dn) y = dn;
+    return y;
+}
+
+__device__ __forceinline__ float knn_d2(float qx, float qy, float qz, const float4 p) {
+    // every product and sum rounded separately (file is built with -ffp-contract=off; matches oracle/knn.py)
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const float s = xx + yy;
+    return s + zz;
+}
+
+// grid = (ceil(Q/64), B); block = 4 waves x 64 queries
 template <int K, bool OFFSETS>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict__ X, const float* __restrict__ pc,
                                                         long long* __restrict__ out_idx, float* __restrict__ out_dist,
                                                         float* __restrict__ out_pts, int Q, int M) {
-    __shared__ float4 s_pc[KNN_TILE];
+    __shared__ float4 s_pc[KNN_TILE];           // reused as the merge buffer at the end
+    static_assert(KNN_WAVES * K * MCR_WAVE * 8 <= KNN_TILE * 16, "merge buffer does not fit the tile buffer");
     const int b = blockIdx.y;
-    const int q = blockIdx.x * KNN_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & (MCR_WAVE - 1);
+    const int wave = threadIdx.x / MCR_WAVE;
+    const int q = blockIdx.x * MCR_WAVE + lane;
     const bool valid = q < Q;
     const float* xq = X + ((size_t)b * Q + (valid ? q : Q - 1)) * 3;
     const float qx = xq[0], qy = xq[1], qz = xq[2];
@@ -35,41 +86,66 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
 
     for (int t0 = 0; t0 < M; t0 += KNN_TILE) {
         const int nt = min(KNN_TILE, M - t0);
+        const int nt_pad = (nt + 15) & ~15;
         __syncthreads();
-        for (int i = threadIdx.x; i < nt; i += KNN_BLOCK) {
-            const float* p = pcb + (size_t)(t0 + i) * 3;
-            s_pc[i] = make_float4(p[0], p[1], p[2], 0.f);
+        for (int i = threadIdx.x; i < nt_pad; i += KNN_BLOCK) {
+            if (i < nt) {
+                const float* p = pcb + (size_t)(t0 + i) * 3;
+                s_pc[i] = make_float4(p[0], p[1], p[2], 0.f);
+            } else {
+                s_pc[i] = make_float4(3e18f, 3e18f, 3e18f, 0.f);        // d2 = +inf: never accepted
+            }
         }
         __syncthreads();
-        for (int i = 0; i < nt; ++i) {
-            const float4 p = s_pc[i];
-            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-            const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-            if (d2 < bd[K - 1]) {                    // strict: an equal distance never displaces an earlier index
-                bd[K - 1] = d2;
-                bi[K - 1] = t0 + i;
-#pragma unroll
-                for (int j = K - 1; j > 0; --j) {
-                    const bool sw = bd[j] < bd[j - 1];
-                    const float dlo = sw ? bd[j] : bd[j - 1], dhi = sw ? bd[j - 1] : bd[j];
-                    const int ilo = sw ? bi[j] : bi[j - 1], ihi = sw ? bi[j - 1] : bi[j];
-                    bd[j - 1] = dlo; bd[j] = dhi;
-                    bi[j - 1] = ilo; bi[j] = ihi;
-                }
+        // wave w scans candidates i = w, w+4, w+8, ... of the tile, 4 per iteration
+        for (int i = wave; i < nt_pad; i += 4 * KNN_WAVES) {
+            const float4 p0 = s_pc[i], p1 = s_pc[i + KNN_WAVES], p2 = s_pc[i + 2 * KNN_WAVES], p3 = s_pc[i + 3 * KNN_WAVES];
+            const float d0 = knn_d2(qx, qy, qz, p0), d1 = knn_d2(qx, qy, qz, p1);
+            const float d2 = knn_d2(qx, qy, qz, p2), d3 = knn_d2(qx, qy, qz, p3);
+            if (fminf(fminf(d0, d1), fminf(d2, d3)) < bd[K - 1]) {
+                knn_insert<K>(bd, bi, d0, t0 + i);
+                knn_insert<K>(bd, bi, d1, t0 + i + KNN_WAVES);
+                knn_insert<K>(bd, bi, d2, t0 + i + 2 * KNN_WAVES);
+                knn_insert<K>(bd, bi, d3, t0 + i + 3 * KNN_WAVES);
             }
         }
     }
-    if (!valid) return;
-    const size_t o = ((size_t)b * Q + q) * K;
+    // ---- 4-way merge of the waves' sorted lists (lexicographic on (d2, index)) ------------------------------
+    __syncthreads();
+    float* m_d = reinterpret_cast<float*>(s_pc);                        // [wave][K][lane]
+    int* m_i = reinterpret_cast<int*>(s_pc) + KNN_WAVES * K * MCR_WAVE;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        out_idx[o + j] = (long long)bi[j];
-        out_dist[o + j] = __fsqrt_rn(bd[j]);
-        const float* p = pcb + (size_t)bi[j] * 3;
-        const float ox = OFFSETS ? p[0] - qx : p[0], oy = OFFSETS ? p[1] - qy : p[1], oz = OFFSETS ? p[2] - qz : p[2];
-        out_pts[(o + j) * 3 + 0] = ox;
-        out_pts[(o + j) * 3 + 1] = oy;
-        out_pts[(o + j) * 3 + 2] = oz;
+        m_d[(wave * K + j) * MCR_WAVE + lane] = bd[j];
+        m_i[(wave * K + j) * MCR_WAVE + lane] = bi[j];
+    }
+    __syncthreads();
+    if (wave != 0 || !valid) return;
+    int head[KNN_WAVES];
+#pragma unroll
+    for (int w = 0; w < KNN_WAVES; ++w) head[w] = 0;
+    const size_t o = ((size_t)b * Q + q) * K;
+    for (int j = 0; j < K; ++j) {
+        float best_d = __builtin_inff();
+        int best_i = 0x7fffffff, best_w = 0;
+#pragma unroll
+        for (int w = 0; w < KNN_WAVES; ++w) {
+            const int h = head[w] < K ? head[w] : K - 1;
+            const float d = head[w] < K ? m_d[(w * K + h) * MCR_WAVE + lane] : __builtin_inff();
+            const int id = head[w] < K ? m_i[(w * K + h) * MCR_WAVE + lane] : 0x7fffffff;
+            const bool better = d < best_d || (d == best_d && id < best_i);
+            best_d = better ? d : best_d;
+            best_i = better ? id : best_i;
+            best_w = better ? w : best_w;
+        }
+#pragma unroll
+        for (int w = 0; w < KNN_WAVES; ++w) head[w] += (best_w == w) ? 1 : 0;
+        out_idx[o + j] = (long long)best_i;
+        out_dist[o + j] = sqrt_cr(best_d);
+        const float* p = pcb + (size_t)best_i * 3;
+        out_pts[(o + j) * 3 + 0] = OFFSETS ? p[0] - qx : p[0];
+        out_pts[(o + j) * 3 + 1] = OFFSETS ? p[1] - qy : p[1];
+        out_pts[(o + j) * 3 + 2] = OFFSETS ? p[2] - qz : p[2];
     }
 }
 
@@ -93,15 +169,15 @@ extern "C" int mcr_knn_points(const float* X, const float* pc, int64_t* idx, flo
     MCR_REQUIRE(k <= M, "mcr_knn_points: k=%d exceeds the number of points M=%ld (torch.topk would raise)", k, (long)M);
     MCR_REQUIRE(B <= 65535 && Q < (1ll << 31) && M < (1ll << 31), "mcr_knn_points: problem too large");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)cdiv(Q, KNN_BLOCK), (unsigned)B);
+    dim3 grid((unsigned)cdiv(Q, MCR_WAVE), (unsigned)B);
     long long* i64 = (long long*)idx;
     switch (k) {
         case 1: launch_knn<1>(subtract_query, grid, s, X, pc, i64, dists, pts, (int)Q, (int)M); break;
         case 4: launch_knn<4>(subtract_query, grid, s, X, pc, i64, dists, pts, (int)Q, (int)M); break;
         case 8: launch_knn<8>(subtract_query, grid, s, X, pc, i64, dists, pts, (int)Q, (int)M); break;
         case 16: launch_knn<16>(subtract_query, grid, s, X, pc, i64, dists, pts, (int)Q, (int)M); break;
-        case 32: launch_knn<32>(subtract_query, grid, s, X, pc, i64, dists, pts, (int)Q, (int)M); break;
-        default: MCR_REQUIRE(false, "mcr_knn_points: k must be one of 1,4,8,16,32 (got %d)", k);
+        
+        default: MCR_REQUIRE(false, "mcr_knn_points: k must be one of 1,4,8,16 (got %d)", k);
     }
     MCR_LAUNCH_CHECK("knn_kernel");
     return 0;
