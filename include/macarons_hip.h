@@ -53,6 +53,58 @@ int mcr_sh_visibilities(const float* pts, int pts_dim, const float* harmonics, c
 int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B, int64_t Q,
                    int64_t M, int k, int subtract_query, void* stream);
 
+/* ---- K4/K5 building blocks (macarons/networks/Attention.py) -------------------------------------------
+ * mcr_linear: nn.Linear (+ optional exact-erf GELU, + optional residual add):
+ *   Y[m*ldy+n] = act(sum_k X[m*ldx+k] * W[n*K+k] + bias[n]) + residual[m*ldr+n]     (Attention.py:98-103,186-188,232-235)
+ * mcr_layernorm: nn.LayerNorm(E), eps 1e-5 (Attention.py:274,292).
+ * mcr_attention: attention() of Attention.py:8-36 with the head split of :174-198 on a packed row
+ *   [q (qk_dim) | k (qk_dim) | v (v_dim)], head h owning channels [h*d,(h+1)*d); mask = None; S sequences of
+ *   L consecutive rows; scores are divided by sqrt(qk_dim / n_heads).  Supported: 4 heads, (32,128) | (64,256).
+ * mcr_colmax_broadcast: Embedding's cloud-wide max feature (Attention.py:117-121).
+ * mcr_pool_max_avg: PCTransformer's max || avg pooling over the sequence (SconeOcc.py:123-126). */
+int mcr_linear(const float* X, int64_t ldx, const float* W, const float* bias, const float* residual, int64_t ldr, float* Y,
+               int64_t ldy, int64_t M, int N, int K, int gelu, void* stream);
+int mcr_layernorm(const float* X, int64_t ldx, const float* gamma, const float* beta, float* Y, int64_t ldy, int64_t M, int E,
+                  void* stream);
+int mcr_attention(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim,
+                  int v_dim, void* stream);
+int mcr_colmax_broadcast(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int64_t L, int E, void* stream);
+int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int64_t L, int E, void* stream);
+
+/* ---- network forwards -----------------------------------------------------------------------------------
+ * Weight tables are arrays of device pointers to contiguous fp32 tensors in nn.Module layout ([out,in] weights):
+ *   ENCODER (12): norm1.weight, norm1.bias, qkv.weight, qkv.bias, out.weight, out.bias, norm2.weight, norm2.bias,
+ *                 ff.linear1.weight, ff.linear1.bias, ff.linear2.weight, ff.linear2.bias
+ *                 where qkv = rows of mhsa.w_q, mhsa.w_k, mhsa.w_v stacked ([2*qk_dim + E, E]) and likewise the bias.
+ *   PCT (32):     embedding.linear1.{weight,bias}, embedding.linear2.{weight,bias}, ENCODER x2, norm.{weight,bias},
+ *                 linear0.{weight,bias}
+ *   SCONE_VIS (48): embedding.linear1.{w,b}, embedding.linear2.{w,b}, ENCODER x3, norm.{w,b}, fc1.{w,b}, fc2.{w,b}, fc3.{w,b}
+ *   SCONE_OCC (140): PCT global_transformer, PCT local_transformers.{0,1,2}, x_embedding.linear{1,2,3}.{w,b},
+ *                 linear1.{w,b}, linear2.{w,b}, linear3.{w,b}
+ *
+ * mcr_pc_transformer_forward: PCTransformer.forward (macarons/networks/SconeOcc.py:104-130); pc [S,L,3] ->
+ *   features [S, feature_dim] (max || avg), feature_dim in {256, 512}.
+ * mcr_scone_vis_forward: SconeVis.forward (macarons/networks/SconeVis.py:121-162); pts [B,N,4], view_harmonics
+ *   [B,N,64] -> out [B,N,64].  Default architecture only (pts_embedding_dim 256, 4 heads, 3 encoders,
+ *   view_state_mode "end", global feature, concatenated input).
+ * mcr_scone_occ_forward: SconeOcc.forward (macarons/networks/SconeOcc.py:250-347) given the clouds the reference
+ *   would obtain from its torch.randperm draws (:269, :311), which the HOST performs so the RNG stream matches:
+ *   pc_global [B,Lg,3]; pc_scale[i] [B,M_scale[i],3] for the 3 neighbourhood scales; x [B,Q,3];
+ *   view_harmonics [B,Q,64] -> out [B,Q,1].  pc_scale / M_scale are HOST arrays of 3 entries. */
+size_t mcr_pc_transformer_workspace_bytes(int64_t S, int64_t L);
+int mcr_pc_transformer_forward(const float* pc, float* features, int64_t S, int64_t L, int feature_dim,
+                               const float* const* weights, int n_weights, void* workspace, size_t workspace_bytes,
+                               void* stream);
+size_t mcr_scone_vis_workspace_bytes(int64_t B, int64_t N);
+int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* out, int64_t B, int64_t N,
+                          const float* const* weights, int n_weights, void* workspace, size_t workspace_bytes,
+                          void* stream);
+size_t mcr_scone_occ_workspace_bytes(int64_t B, int64_t Q, int64_t Lg);
+int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const* pc_scale, const int64_t* M_scale,
+                          const float* x, const float* view_harmonics, float* out, int64_t B, int64_t Q,
+                          const float* const* weights, int n_weights, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

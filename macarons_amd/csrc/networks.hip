@@ -1,0 +1,306 @@
+// SconeVis.forward / PCTransformer.forward / SconeOcc.forward composed from the gfx950 building blocks
+// (nn_kernels.hip, knn.hip) behind single C-ABI entry points (include/macarons_hip.h).
+//
+// Reference (file:line, upstream tree):
+//   macarons/networks/Attention.py:98-128   Embedding.forward      (linear-GELU-linear, optional cloud max, concat x)
+//   macarons/networks/Attention.py:278-300  Encoder.forward        (pre-LN MHSA + residual, pre-LN FF + residual)
+//   macarons/networks/SconeVis.py:121-162   SconeVis.forward
+//   macarons/networks/SconeOcc.py:104-130   PCTransformer.forward
+//   macarons/networks/SconeOcc.py:250-347   SconeOcc.forward
+// Only the reference's default architecture hyper-parameters are implemented on the HIP path (every call site
+// uses them); the Python host classes refuse other configurations loudly.
+#include "nn_kernels.h"
+#include <algorithm>
+
+namespace mcr {
+
+// ---- weight tables (arrays of device pointers, order documented in include/macarons_hip.h) ------------------
+struct LinW { const float* w; const float* b; };
+struct EncW {                       // 12 pointers
+    const float *n1g, *n1b;         // norm1
+    LinW qkv;                       // rows of w_q, w_k, w_v stacked: [2*dqk + dv, E]
+    LinW out;
+    const float *n2g, *n2b;         // norm2
+    LinW ff1, ff2;
+};
+static EncW read_enc(const float* const*& p) {
+    EncW e;
+    e.n1g = *p++; e.n1b = *p++;
+    e.qkv.w = *p++; e.qkv.b = *p++;
+    e.out.w = *p++; e.out.b = *p++;
+    e.n2g = *p++; e.n2b = *p++;
+    e.ff1.w = *p++; e.ff1.b = *p++;
+    e.ff2.w = *p++; e.ff2.b = *p++;
+    return e;
+}
+
+// bump allocator over the caller's workspace (256-B aligned blocks)
+struct Arena {
+    char* base; size_t cap, off;
+    float* f(size_t n_floats) {
+        size_t bytes = (n_floats * sizeof(float) + 255) & ~(size_t)255;
+        float* p = reinterpret_cast<float*>(base + off);
+        off += bytes;
+        return p;
+    }
+    bool ok() const { return off <= cap; }
+};
+static size_t al(size_t n_floats) { return (n_floats * sizeof(float) + 255) & ~(size_t)255; }
+
+// x <- Encoder(x)  in place.  x [T, E]; scratch h [T, E], qkv [T, 2*dqk + E], ff [T, 2E]
+static void run_encoder(hipStream_t s, const EncW& w, float* x, float* h, float* qkv, float* ff, int64_t S, int L, int E,
+                        int H) {
+    const int64_t T = S * L;
+    const int dqk = E / 4, W3 = 2 * dqk + E;
+    launch_layernorm(s, x, E, w.n1g, w.n1b, h, E, T, E);                                   // Attention.py:287
+    launch_linear(s, h, E, w.qkv.w, w.qkv.b, nullptr, 0, qkv, W3, T, W3, E, ACT_NONE);       // :186-188
+    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E);                                     // :191-198
+    launch_linear(s, h, E, w.out.w, w.out.b, x, E, x, E, T, E, E, ACT_NONE);                 // :201-202 + residual :290
+    launch_layernorm(s, x, E, w.n2g, w.n2b, h, E, T, E);                                   // :293
+    launch_linear(s, h, E, w.ff1.w, w.ff1.b, nullptr, 0, ff, 2 * E, T, 2 * E, E, ACT_GELU);  // :232
+    launch_linear(s, ff, 2 * E, w.ff2.w, w.ff2.b, x, E, x, E, T, E, 2 * E, ACT_NONE);        // :235 + residual :298
+}
+
+// ---- PCTransformer (SconeOcc.py:45-130): S sequences of L points (pts_dim 3), E = 128, 2 encoders, 4 heads ----
+constexpr int PCT_E = 128, PCT_INNER = 125, PCT_NW = 4 + 2 * 12 + 2 + 2;
+struct PctW { LinW l1, l2; EncW enc[2]; const float *ng, *nb; LinW lin0; };
+static PctW read_pct(const float* const*& p) {
+    PctW w;
+    w.l1.w = *p++; w.l1.b = *p++; w.l2.w = *p++; w.l2.b = *p++;
+    w.enc[0] = read_enc(p); w.enc[1] = read_enc(p);
+    w.ng = *p++; w.nb = *p++;
+    w.lin0.w = *p++; w.lin0.b = *p++;
+    return w;
+}
+static size_t pct_ws_bytes(int64_t T) {
+    return al(T * PCT_E) * 2 + al(T * (PCT_E + 64)) + al(T * 2 * PCT_E);
+}
+// feat[s*ld_feat + 0 : feature_dim] ; feature_dim = 2 * half (max || avg)
+static void run_pct(hipStream_t s, const PctW& w, const float* pc, float* feat, int64_t ld_feat, int64_t S, int L, int half,
+                    Arena& a) {
+    const int64_t T = S * L;
+    float* x = a.f(T * PCT_E);
+    float* h = a.f(T * PCT_E);
+    float* qkv = a.f(T * (PCT_E + 64));
+    float* ff = a.f(T * 2 * PCT_E);
+    // Embedding (Attention.py:98-128): linear1 3->125, GELU, linear2 125->125, concat raw input -> 128
+    launch_linear(s, pc, 3, w.l1.w, w.l1.b, nullptr, 0, h, PCT_INNER, T, PCT_INNER, 3, ACT_GELU);
+    launch_linear(s, h, PCT_INNER, w.l2.w, w.l2.b, nullptr, 0, x, PCT_E, T, PCT_INNER, PCT_INNER, ACT_NONE);
+    launch_copy2d(s, pc, 3, x + PCT_INNER, PCT_E, T, 3);
+    for (int e = 0; e < 2; ++e) run_encoder(s, w.enc[e], x, h, qkv, ff, S, L, PCT_E, 4);
+    launch_layernorm(s, x, PCT_E, w.ng, w.nb, h, PCT_E, T, PCT_E);                          // SconeOcc.py:119
+    launch_linear(s, h, PCT_E, w.lin0.w, w.lin0.b, nullptr, 0, ff, half, T, half, PCT_E, ACT_NONE);   // :122
+    launch_pool_max_avg(s, ff, half, feat, ld_feat, S, L, half);                             // :124-126
+}
+
+}  // namespace mcr
+
+using namespace mcr;
+
+extern "C" {
+
+// ---- individual blocks (used by the host mirrors of Attention.py's modules and by the block-level tests) ----
+int mcr_linear(const float* X, int64_t ldx, const float* W, const float* bias, const float* residual, int64_t ldr, float* Y,
+               int64_t ldy, int64_t M, int N, int K, int gelu, void* stream) {
+    MCR_REQUIRE(X && W && Y, "mcr_linear: null pointer");
+    MCR_REQUIRE(M > 0 && N > 0 && K > 0, "mcr_linear: empty problem");
+    MCR_REQUIRE(ldx >= K && ldy >= N && (!residual || ldr >= N), "mcr_linear: leading dimension too small");
+    launch_linear((hipStream_t)stream, X, ldx, W, bias, residual, ldr, Y, ldy, M, N, K, gelu ? ACT_GELU : ACT_NONE);
+    MCR_LAUNCH_CHECK("mcr_linear");
+    return 0;
+}
+
+int mcr_layernorm(const float* X, int64_t ldx, const float* gamma, const float* beta, float* Y, int64_t ldy, int64_t M, int E,
+                  void* stream) {
+    MCR_REQUIRE(X && gamma && beta && Y, "mcr_layernorm: null pointer");
+    MCR_REQUIRE(M > 0 && E > 0 && E <= 512, "mcr_layernorm: need 0 < E <= 512 (got %d)", E);
+    launch_layernorm((hipStream_t)stream, X, ldx, gamma, beta, Y, ldy, M, E);
+    MCR_LAUNCH_CHECK("mcr_layernorm");
+    return 0;
+}
+
+int mcr_attention(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim,
+                  int v_dim, void* stream) {
+    MCR_REQUIRE(qkv && out, "mcr_attention: null pointer");
+    MCR_REQUIRE(S > 0 && L > 0, "mcr_attention: empty problem");
+    MCR_REQUIRE(n_heads == 4 && ((qk_dim == 32 && v_dim == 128) || (qk_dim == 64 && v_dim == 256)),
+                "mcr_attention: supported head layouts are 4 heads with (qk,v) = (32,128) or (64,256); got %d heads (%d,%d)",
+                n_heads, qk_dim, v_dim);
+    MCR_REQUIRE(L == 16 || S <= 65535, "mcr_attention: too many long sequences");
+    launch_attention((hipStream_t)stream, qkv, ldq, out, ldo, S, (int)L, n_heads, qk_dim, v_dim);
+    MCR_LAUNCH_CHECK("mcr_attention");
+    return 0;
+}
+
+int mcr_colmax_broadcast(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int64_t L, int E, void* stream) {
+    MCR_REQUIRE(X && Y && S > 0 && L > 0 && E > 0, "mcr_colmax_broadcast: bad arguments");
+    launch_colmax_broadcast((hipStream_t)stream, X, ldx, Y, ldy, S, (int)L, E);
+    MCR_LAUNCH_CHECK("mcr_colmax_broadcast");
+    return 0;
+}
+
+int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int64_t L, int E, void* stream) {
+    MCR_REQUIRE(X && Y && S > 0 && L > 0 && E > 0, "mcr_pool_max_avg: bad arguments");
+    launch_pool_max_avg((hipStream_t)stream, X, ldx, Y, ldy, S, (int)L, E);
+    MCR_LAUNCH_CHECK("mcr_pool_max_avg");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+size_t mcr_pc_transformer_workspace_bytes(int64_t S, int64_t L) { return pct_ws_bytes(S * L) + 4096; }
+
+int mcr_pc_transformer_forward(const float* pc, float* features, int64_t S, int64_t L, int feature_dim,
+                               const float* const* weights, int n_weights, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    MCR_REQUIRE(pc && features && weights, "mcr_pc_transformer_forward: null pointer");
+    MCR_REQUIRE(n_weights == PCT_NW, "mcr_pc_transformer_forward: expected %d weight pointers, got %d", PCT_NW, n_weights);
+    MCR_REQUIRE(S > 0 && L > 0, "mcr_pc_transformer_forward: empty problem");
+    MCR_REQUIRE(feature_dim == 256 || feature_dim == 512, "mcr_pc_transformer_forward: feature_dim must be 256 or 512");
+    MCR_REQUIRE(L == 16 || S <= 65535, "mcr_pc_transformer_forward: too many long sequences");
+    MCR_REQUIRE(workspace && workspace_bytes >= mcr_pc_transformer_workspace_bytes(S, L),
+                "mcr_pc_transformer_forward: workspace too small");
+    for (int i = 0; i < n_weights; ++i) MCR_REQUIRE(weights[i], "mcr_pc_transformer_forward: weight %d is null", i);
+    const float* const* p = weights;
+    const PctW w = read_pct(p);
+    Arena a{(char*)workspace, workspace_bytes, 0};
+    run_pct((hipStream_t)stream, w, pc, features, feature_dim, S, (int)L, feature_dim / 2, a);
+    MCR_LAUNCH_CHECK("mcr_pc_transformer_forward");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SconeVis.forward (SconeVis.py:121-162): E = 256, 3 encoders, 4 heads, view_state_mode "end".
+constexpr int VIS_E = 256, VIS_F = 126, VIS_NW = 4 + 3 * 12 + 2 + 6;
+
+size_t mcr_scone_vis_workspace_bytes(int64_t B, int64_t N) {
+    const int64_t T = B * N;
+    return al(T * VIS_E) * 2 + al(T * (VIS_E + 128)) + al(T * 2 * VIS_E) + 4096;
+}
+
+int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* out, int64_t B, int64_t N,
+                          const float* const* weights, int n_weights, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    MCR_REQUIRE(pts && view_harmonics && out && weights, "mcr_scone_vis_forward: null pointer");
+    MCR_REQUIRE(n_weights == VIS_NW, "mcr_scone_vis_forward: expected %d weight pointers, got %d", VIS_NW, n_weights);
+    MCR_REQUIRE(B > 0 && N > 0 && B <= 65535, "mcr_scone_vis_forward: bad problem size B=%ld N=%ld", (long)B, (long)N);
+    MCR_REQUIRE(workspace && workspace_bytes >= mcr_scone_vis_workspace_bytes(B, N), "mcr_scone_vis_forward: workspace too small");
+    for (int i = 0; i < n_weights; ++i) MCR_REQUIRE(weights[i], "mcr_scone_vis_forward: weight %d is null", i);
+    hipStream_t s = (hipStream_t)stream;
+    const float* const* p = weights;
+    LinW l1{p[0], p[1]}, l2{p[2], p[3]};
+    p += 4;
+    EncW enc[3] = {read_enc(p), read_enc(p), read_enc(p)};
+    const float *ng = *p++, *nb = *p++;
+    LinW fc1{p[0], p[1]}, fc2{p[2], p[3]}, fc3{p[4], p[5]};
+
+    const int64_t T = B * N;
+    Arena a{(char*)workspace, workspace_bytes, 0};
+    float* x = a.f(T * VIS_E);
+    float* h = a.f(T * VIS_E);
+    float* qkv = a.f(T * (VIS_E + 128));
+    float* ff = a.f(T * 2 * VIS_E);
+    // Embedding: 4 -> 126 GELU -> 126, || cloud-wide max (126) || raw input (4)  = 256   (Attention.py:98-128)
+    launch_linear(s, pts, 4, l1.w, l1.b, nullptr, 0, h, VIS_F, T, VIS_F, 4, ACT_GELU);
+    launch_linear(s, h, VIS_F, l2.w, l2.b, nullptr, 0, x, VIS_E, T, VIS_F, VIS_F, ACT_NONE);
+    launch_colmax_broadcast(s, x, VIS_E, x + VIS_F, VIS_E, B, (int)N, VIS_F);
+    launch_copy2d(s, pts, 4, x + 2 * VIS_F, VIS_E, T, 4);
+    for (int e = 0; e < 3; ++e) run_encoder(s, enc[e], x, h, qkv, ff, B, (int)N, VIS_E, 4);     // SconeVis.py:139-140
+    launch_layernorm(s, x, VIS_E, ng, nb, h, VIS_E, T, VIS_E);                                   // :143
+    // fc1 256->192 GELU, || view_harmonics (64), fc2 256->128 GELU, fc3 128->64                  (:146-152)
+    launch_linear(s, h, VIS_E, fc1.w, fc1.b, nullptr, 0, ff, VIS_E, T, 192, VIS_E, ACT_GELU);
+    launch_copy2d(s, view_harmonics, 64, ff + 192, VIS_E, T, 64);
+    launch_linear(s, ff, VIS_E, fc2.w, fc2.b, nullptr, 0, h, 128, T, 128, VIS_E, ACT_GELU);
+    launch_linear(s, h, 128, fc3.w, fc3.b, nullptr, 0, out, 64, T, 64, 128, ACT_NONE);
+    MCR_LAUNCH_CHECK("mcr_scone_vis_forward");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SconeOcc.forward (SconeOcc.py:250-347).  The host supplies the already down-sampled clouds (it consumes
+// torch's CPU generator exactly like the reference: randperm at :269 and :311):
+//   pc_global [B, Lg, 3]            Lg = min(M, 2048)
+//   pc_scale[i] [B, M_i, 3], i < 3  the cloud seen by scale i (M_0 = M, then M_i = M_{i-1} // ds_factor)
+constexpr int OCC_NW = PCT_NW * 4 + 6 + 6, OCC_CHUNK = 16384;
+
+size_t mcr_scone_occ_workspace_bytes(int64_t B, int64_t Q, int64_t Lg) {
+    const int64_t qc = std::min<int64_t>(Q, OCC_CHUNK);
+    size_t local = pct_ws_bytes(qc * 16) + al(qc * 16 * 3) + al(qc * 16) + al(qc * 16 * 2) + 1024;
+    size_t glob = pct_ws_bytes(B * Lg);
+    size_t head = al(B * Q * 1344) + al(B * Q * 512) + al(B * Q * 256) + al(B * 512) * 2;
+    return std::max(local, glob) + head + 8192;
+}
+
+int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B, int64_t Q, int64_t M,
+                   int k, int subtract_query, void* stream);
+
+int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const* pc_scale, const int64_t* M_scale,
+                          const float* x, const float* view_harmonics, float* out, int64_t B, int64_t Q,
+                          const float* const* weights, int n_weights, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    MCR_REQUIRE(pc_global && pc_scale && M_scale && x && view_harmonics && out && weights, "mcr_scone_occ_forward: null pointer");
+    MCR_REQUIRE(n_weights == OCC_NW, "mcr_scone_occ_forward: expected %d weight pointers, got %d", OCC_NW, n_weights);
+    MCR_REQUIRE(B > 0 && Q > 0 && Lg > 0 && B <= 65535, "mcr_scone_occ_forward: bad problem size");
+    MCR_REQUIRE(workspace && workspace_bytes >= mcr_scone_occ_workspace_bytes(B, Q, Lg), "mcr_scone_occ_forward: workspace too small");
+    for (int i = 0; i < n_weights; ++i) MCR_REQUIRE(weights[i], "mcr_scone_occ_forward: weight %d is null", i);
+    for (int i = 0; i < 3; ++i)
+        MCR_REQUIRE(pc_scale[i] && M_scale[i] >= 16, "mcr_scone_occ_forward: scale %d has %ld points (< k = 16)", i, (long)M_scale[i]);
+    hipStream_t s = (hipStream_t)stream;
+    const float* const* p = weights;
+    const PctW wg = read_pct(p);
+    const PctW wl[3] = {read_pct(p), read_pct(p), read_pct(p)};
+    LinW xe1{p[0], p[1]}, xe2{p[2], p[3]}, xe3{p[4], p[5]};
+    p += 6;
+    LinW lin1{p[0], p[1]}, lin2{p[2], p[3]}, lin3{p[4], p[5]};
+
+    Arena head{(char*)workspace, workspace_bytes, 0};
+    // per-query feature row: [ local 3x256 | x-embedding 512 | view harmonics 64 ] = 1344   (cat at SconeOcc.py:333
+    // is (global 512, local 768, x 512, harmonics 64); the per-cloud global part is folded into a row bias)
+    constexpr int FEAT = 1344;
+    float* feat = head.f(B * Q * FEAT);
+    float* h1 = head.f(B * Q * 512);
+    float* h2 = head.f(B * Q * 256);
+    float* gfeat = head.f(B * 512);
+    float* gbias = head.f(B * 512);
+    Arena scratch{(char*)workspace + head.off, workspace_bytes - head.off, 0};
+
+    // ---- global feature (SconeOcc.py:269-277) ----
+    {
+        Arena a = scratch;
+        run_pct(s, wg, pc_global, gfeat, 512, B, (int)Lg, 256, a);
+        MCR_REQUIRE(a.ok(), "mcr_scone_occ_forward: workspace overflow (global)");
+        // its contribution to linear1: gbias[b, n] = sum_k gfeat[b, k] * W1[n, k]  (columns 0..511 of linear1.weight)
+        launch_linear(s, gfeat, 512, lin1.w, nullptr, nullptr, 0, gbias, 512, B, 512, 512, ACT_NONE, nullptr, 0, 1856);
+    }
+    // ---- local multi-scale neighbourhood features (SconeOcc.py:290-311), chunked over queries ----
+    const int64_t qc = std::min<int64_t>(Q, OCC_CHUNK);
+    for (int sc = 0; sc < 3; ++sc) {
+        for (int64_t q0 = 0; q0 < Q; q0 += qc) {
+            const int64_t nq = std::min<int64_t>(qc, Q - q0);
+            for (int64_t b = 0; b < B; ++b) {
+                Arena a = scratch;
+                float* offs = a.f(nq * 16 * 3);
+                float* dist = a.f(nq * 16);
+                int64_t* idx = reinterpret_cast<int64_t*>(a.f(nq * 16 * 2));
+                if (int e = mcr_knn_points(x + (b * Q + q0) * 3, pc_scale[sc] + b * M_scale[sc] * 3, idx, dist, offs, 1, nq,
+                                           M_scale[sc], 16, 1, stream))
+                    return e;
+                run_pct(s, wl[sc], offs, feat + (b * Q + q0) * FEAT + sc * 256, FEAT, nq, 16, 128, a);
+                MCR_REQUIRE(a.ok(), "mcr_scone_occ_forward: workspace overflow (local)");
+            }
+        }
+    }
+    // ---- x embedding 3 -> 128 -> 256 -> 512, GELU each (SconeOcc.py:35-42) ----
+    const int64_t T = B * Q;
+    launch_linear(s, x, 3, xe1.w, xe1.b, nullptr, 0, h2, 128, T, 128, 3, ACT_GELU);
+    launch_linear(s, h2, 128, xe2.w, xe2.b, nullptr, 0, h1, 256, T, 256, 128, ACT_GELU);
+    launch_linear(s, h1, 256, xe3.w, xe3.b, nullptr, 0, feat + 768, FEAT, T, 512, 256, ACT_GELU);
+    launch_copy2d(s, view_harmonics, 64, feat + 1280, FEAT, T, 64);
+    // ---- head MLP 1856 -> 512 -> 256 -> 1, GELU after every layer incl. the last (SconeOcc.py:334-345) ----
+    launch_linear(s, feat, FEAT, lin1.w + 512, lin1.b, nullptr, 0, h1, 512, T, 512, FEAT, ACT_GELU, gbias, Q, 1856);
+    launch_linear(s, h1, 512, lin2.w, lin2.b, nullptr, 0, h2, 256, T, 256, 512, ACT_GELU);
+    launch_linear(s, h2, 256, lin3.w, lin3.b, nullptr, 0, out, 1, T, 1, 256, ACT_GELU);
+    MCR_LAUNCH_CHECK("mcr_scone_occ_forward");
+    return 0;
+}
+
+}  // extern "C"

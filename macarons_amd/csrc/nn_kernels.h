@@ -1,0 +1,39 @@
+// Device-side building blocks of the SCONE networks (K4-K8 of SURVEY §2.3) for gfx950.
+// Launch helpers are declared here and defined in nn_kernels.hip; networks.hip composes them.
+#pragma once
+#include "common.h"
+
+namespace mcr {
+
+enum Act { ACT_NONE = 0, ACT_GELU = 1 };
+
+// Y[m, n] = act( sum_k X[m*ldx + k] * W[n*K + k] + bias[n] ) (+ R[m*ldr + n]);   m < M, n < N
+// nn.Linear semantics (W is [N,K] row-major).  fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-fp32 products.
+// row_bias (optional): extra bias per group of rows, row_bias[(m / rows_per_group) * N + n]  (used to fold the
+// per-cloud global feature of SconeOcc into the head's first layer without materialising the concat).
+void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R,
+                   int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int act,
+                   const float* row_bias = nullptr, int64_t rows_per_group = 0, int64_t ldw = 0);
+
+// Row LayerNorm (eps 1e-5, affine): Y[m, :E] = (X[m, :E] - mean) * rstd * g + b     (Attention.py:274,292)
+void launch_layernorm(hipStream_t s, const float* X, int64_t ldx, const float* g, const float* b, float* Y, int64_t ldy,
+                      int64_t M, int E);
+
+// Multi-head self-attention core on a packed QKV buffer (Attention.py:8-36,174-198; mask=None, no dropout):
+//   qkv[m, 0:DQK | DQK:2DQK | 2DQK:2DQK+DV], head h owns channels [h*d,(h+1)*d); scores / sqrt(dqk_per_head);
+//   out[m, h*dv:(h+1)*dv].   Sequences are S consecutive blocks of L rows.
+void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
+                      int DQK, int DV);
+
+// Column max over the L rows of each of S sequences, broadcast into a column slice of every row:
+//   Y[(s*L + r)*ldy + c] = max_r' X[(s*L + r')*ldx + c], c < E          (Embedding global feature, Attention.py:117-121)
+void launch_colmax_broadcast(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E);
+
+// PCTransformer tail (SconeOcc.py:123-126): per sequence, max over rows then mean over rows:
+//   Y[s*ldy + c] = max_r X[(s*L+r)*ldx + c],  Y[s*ldy + E + c] = mean_r X[...]
+void launch_pool_max_avg(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E);
+
+// Strided 2-D copy: Y[m*ldy + c] = X[m*ldx + c], c < E
+void launch_copy2d(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t M, int E);
+
+}  // namespace mcr

@@ -1,0 +1,160 @@
+"""Host-side mirror of macarons/networks/SconeOcc.py: the occupancy-probability network, running on the
+MI355X through libmacarons_hip.so.  Same constructors, parameter names and tensor layouts as the reference
+(XEmbedding :7, PCTransformer :45, SconeOcc :133, forward :250).
+
+Hidden RNG: SconeOcc.forward draws torch.randperm on the CPU default generator three times
+(SconeOcc.py:269 and :311 twice).  This class draws them on the host in the same order, or takes them
+explicitly through `perms=` so tests can pin them.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from .Attention import Embedding, Encoder, _f32c, _inference_only
+
+
+class XEmbedding(nn.Module):
+    """SconeOcc.py:7-42: 3 -> E/4 -> E/2 -> E with GELU after every layer."""
+
+    def __init__(self, x_dim, x_embedding_dim, dropout=None, gelu=True):
+        super().__init__()
+        if not gelu or dropout is not None:
+            raise NotImplementedError("HIP path implements the GELU / no-dropout configuration")
+        self.linear1 = nn.Linear(x_dim, x_embedding_dim // 4)
+        self.linear2 = nn.Linear(x_embedding_dim // 4, x_embedding_dim // 2)
+        self.linear3 = nn.Linear(x_embedding_dim // 2, x_embedding_dim)
+        self.non_linear1, self.non_linear2, self.non_linear3 = nn.GELU(), nn.GELU(), nn.GELU()
+        self.dropout = None
+
+    def forward(self, x):
+        _inference_only(self, x)
+        res = ops.linear(x, _f32c(self.linear1.weight), _f32c(self.linear1.bias), gelu=True)
+        res = ops.linear(res, _f32c(self.linear2.weight), _f32c(self.linear2.bias), gelu=True)
+        return ops.linear(res, _f32c(self.linear3.weight), _f32c(self.linear3.bias), gelu=True)
+
+
+class PCTransformer(nn.Module):
+    """SconeOcc.py:45-130."""
+
+    def __init__(self, seq_len, pts_dim=3, pts_embedding_dim=256, feature_dim=512, concatenate_input=True, n_code=2,
+                 n_heads=4, FF=True, gelu=True, dropout=None):
+        super().__init__()
+        self.seq_len, self.pts_dim, self.pts_embedding_dim = seq_len, pts_dim, pts_embedding_dim
+        self.n_code, self.n_heads, self.FF, self.gelu = n_code, n_heads, FF, gelu
+        self.feature_dim = feature_dim
+        self.dropout = dropout
+        self.embedding = Embedding(input_dim=pts_dim, output_dim=pts_embedding_dim, dropout=None, gelu=gelu,
+                                   global_feature=False, additional_feature_dim=0, concatenate_input=concatenate_input,
+                                   k_for_knn=0)
+        self.encoders = nn.ModuleList([Encoder(seq_len=seq_len, embedding_dim=pts_embedding_dim,
+                                               qk_dim=pts_embedding_dim // 4, n_heads=n_heads, dropout=dropout, gelu=gelu,
+                                               FF=FF) for _ in range(n_code)])
+        self.norm = nn.LayerNorm(pts_embedding_dim)
+        self.linear0 = nn.Linear(pts_embedding_dim, feature_dim // 2)
+
+    def _is_default_arch(self):
+        return (self.pts_dim == 3 and self.pts_embedding_dim == 128 and self.n_code == 2 and self.n_heads == 4
+                and self.FF and self.embedding.concatenate_input and self.feature_dim in (256, 512))
+
+    def weight_table(self):
+        t = [_f32c(self.embedding.linear1.weight), _f32c(self.embedding.linear1.bias),
+             _f32c(self.embedding.linear2.weight), _f32c(self.embedding.linear2.bias)]
+        for e in self.encoders:
+            t += e.weight_table()
+        t += [_f32c(self.norm.weight), _f32c(self.norm.bias), _f32c(self.linear0.weight), _f32c(self.linear0.bias)]
+        return t
+
+    def forward(self, pc, mask=None):
+        """pc [n_clouds, seq_len, 3] -> [n_clouds, feature_dim]."""
+        _inference_only(self, pc)
+        if mask is not None:
+            raise NotImplementedError("mask is None in every call site of the hot path")
+        if not self._is_default_arch():
+            raise NotImplementedError("the fused MI355X PCTransformer implements the reference's default architecture")
+        return ops.pc_transformer_forward(pc, self.weight_table(), self.feature_dim)
+
+
+class SconeOcc(nn.Module):
+    def __init__(self, seq_len=2048, pts_dim=3, pts_embedding_dim=128, concatenate_input=True, n_code=2, n_heads=4,
+                 FF=True, gelu=True, global_feature_dim=512, n_scale=3, local_feature_dim=256, k_for_knn=16, x_dim=3,
+                 x_embedding_dim=512, n_harmonics=64, output_dim=1, dropout=None, offset=True):
+        super().__init__()
+        self.seq_len, self.pts_dim, self.pts_embedding_dim = seq_len, pts_dim, pts_embedding_dim
+        self.n_code, self.n_heads, self.FF, self.gelu = n_code, n_heads, FF, gelu
+        self.n_scale = n_scale
+        self.x_dim, self.x_embedding_dim = x_dim, x_embedding_dim
+        self.output_dim = output_dim
+        self.dropout = dropout
+        self.encoding_dim = pts_embedding_dim
+        self.k_for_knn = k_for_knn
+        self.offset = offset
+        if self.offset:
+            print("Offset set to True.")                                     # SconeOcc.py:199-200
+        self.global_feature_dim, self.local_feature_dim = global_feature_dim, local_feature_dim
+        self.n_harmonics = n_harmonics
+        self.all_feature_size = x_embedding_dim + n_scale * local_feature_dim + global_feature_dim + n_harmonics
+        self.global_transformer = PCTransformer(seq_len=seq_len, pts_dim=pts_dim, pts_embedding_dim=pts_embedding_dim,
+                                                feature_dim=global_feature_dim, concatenate_input=concatenate_input,
+                                                n_code=n_code, n_heads=n_heads, FF=FF, gelu=gelu, dropout=dropout)
+        self.local_transformers = nn.ModuleList([
+            PCTransformer(seq_len=k_for_knn, pts_dim=pts_dim, pts_embedding_dim=pts_embedding_dim,
+                          feature_dim=local_feature_dim, concatenate_input=concatenate_input, n_code=n_code,
+                          n_heads=n_heads, FF=FF, gelu=gelu, dropout=dropout) for _ in range(n_scale)])
+        self.x_embedding = XEmbedding(x_dim=x_dim, x_embedding_dim=x_embedding_dim, dropout=dropout, gelu=gelu)
+        self.linear1 = nn.Linear(self.all_feature_size, 512)
+        self.linear2 = nn.Linear(512, 256)
+        self.linear3 = nn.Linear(256, output_dim)
+        self.non_linear1, self.non_linear2, self.non_linear3 = nn.GELU(), nn.GELU(), nn.GELU()
+
+    def _is_default_arch(self):
+        return (self.n_scale == 3 and self.k_for_knn == 16 and self.offset and self.x_dim == 3 and self.x_embedding_dim == 512
+                and self.global_feature_dim == 512 and self.local_feature_dim == 256 and self.n_harmonics == 64
+                and self.output_dim == 1 and self.global_transformer._is_default_arch()
+                and all(t._is_default_arch() for t in self.local_transformers))
+
+    def weight_table(self):
+        t = self.global_transformer.weight_table()
+        for lt in self.local_transformers:
+            t += lt.weight_table()
+        for lin in (self.x_embedding.linear1, self.x_embedding.linear2, self.x_embedding.linear3, self.linear1,
+                    self.linear2, self.linear3):
+            t += [_f32c(lin.weight), _f32c(lin.bias)]
+        return t
+
+    def ds_factor(self, full_seq_len):
+        """SconeOcc.py:281-288."""
+        if self.n_scale > 1:
+            ds = int(np.power(full_seq_len / (self.k_for_knn * 8), 1. / (self.n_scale - 1)))
+            return 2 if ds == 0 else ds
+        return 1
+
+    def draw_perms(self, full_seq_len):
+        """The three torch.randperm draws of one forward, in the reference's order on the CPU default generator:
+        global down-sample (SconeOcc.py:269), then scale 0->1 and 1->2 (:311).  Returns index tensors (already cut)."""
+        perms = [torch.randperm(full_seq_len)[:self.seq_len]]
+        ds, m = self.ds_factor(full_seq_len), full_seq_len
+        for _ in range(self.n_scale - 1):
+            perms.append(torch.randperm(m)[:m // ds])
+            m = m // ds
+        return perms
+
+    def forward(self, pc, x, view_harmonics, mask=None, verbose=False, perms=None):
+        """pc [n_clouds, M, 3], x [n_clouds, Q, 3], view_harmonics [n_clouds, Q, 64] -> [n_clouds, Q, 1].
+        `perms` (optional): the three index tensors draw_perms() would return, to pin the hidden RNG."""
+        _inference_only(self, pc, x)
+        if mask is not None:
+            raise NotImplementedError("mask is None in every call site of the hot path")
+        if not self._is_default_arch():
+            raise NotImplementedError("the fused MI355X SconeOcc forward implements the reference's default architecture")
+        n_clouds, full_seq_len = pc.shape[0], pc.shape[1]
+        n_sample = x.shape[1]
+        if perms is None:
+            perms = self.draw_perms(full_seq_len)
+        dev = pc.device
+        pc_global = pc[:, perms[0].to(dev)].contiguous()                              # SconeOcc.py:269
+        scales = [pc.contiguous()]
+        for p in perms[1:]:
+            scales.append(scales[-1][:, p.to(dev)].contiguous())                      # :311
+        res = ops.scone_occ_forward(pc_global, scales, x, view_harmonics, self.weight_table())
+        return res.view(n_clouds, n_sample, self.output_dim)

@@ -1,0 +1,102 @@
+"""Host-side mirror of macarons/networks/SconeVis.py: the visibility-gain network and the per-candidate-camera
+coverage-gain scorer, running on the MI355X through libmacarons_hip.so.
+
+Same constructor, attributes (n_harmonics, max_harmonic_rank, use_sigmoid ...), sub-module / parameter names
+(reference checkpoints load unchanged) and method surface as the reference:
+  SconeVis.forward                         macarons/networks/SconeVis.py:121-162
+  SconeVis.compute_visibilities            :164-208
+  SconeVis.compute_coverage_gain           :210-252
+  SconeVis.compute_coverage_gain_multiple  :254-303
+The loss modules (:306-378) are training-only and out of this tier.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from .Attention import Embedding, Encoder, _f32c, _inference_only
+
+
+class SconeVis(nn.Module):
+    def __init__(self, pts_dim=4, seq_len=2048, pts_embedding_dim=256, n_heads=4, n_code=3, n_harmonics=64,
+                 max_harmonic_rank=8, FF=True, gelu=True, dropout=None, use_view_state=True, use_global_feature=True,
+                 view_state_mode="end", concatenate_input=True, k_for_knn=0, alt=False, use_sigmoid=True):
+        super().__init__()
+        self.n_harmonics = n_harmonics
+        self.pts_dim, self.seq_len, self.pts_embedding_dim = pts_dim, seq_len, pts_embedding_dim
+        self.n_heads, self.n_code, self.max_harmonic_rank = n_heads, n_code, max_harmonic_rank
+        self.use_view_state, self.use_global_feature, self.view_state_mode = use_view_state, use_global_feature, view_state_mode
+        self.alt = alt
+        self.use_sigmoid = use_sigmoid
+        print("Use sigmoid in model." if use_sigmoid else "Use ReLU for output in model.")      # SconeVis.py:72-75
+
+        additional_feature_dim = n_harmonics if (use_view_state and view_state_mode == "start") else 0
+        self.embedding = Embedding(pts_dim, pts_embedding_dim, gelu=gelu, global_feature=use_global_feature,
+                                   additional_feature_dim=additional_feature_dim, concatenate_input=concatenate_input,
+                                   k_for_knn=k_for_knn, dropout=None)
+        self.encoders = nn.ModuleList([Encoder(seq_len=seq_len, embedding_dim=pts_embedding_dim,
+                                               qk_dim=pts_embedding_dim // 4, n_heads=n_heads, dropout=dropout, gelu=gelu,
+                                               FF=FF) for _ in range(n_code)])
+        self.norm = nn.LayerNorm(pts_embedding_dim)
+        if not alt:
+            fc1_input_dim = pts_embedding_dim
+            inner_feature_factor = 3 if (use_view_state and view_state_mode == "end") else 4
+        else:
+            fc1_input_dim = pts_embedding_dim + n_harmonics
+            inner_feature_factor = 4
+        self.fc1 = nn.Linear(fc1_input_dim, inner_feature_factor * n_harmonics)
+        self.nonlinear1 = nn.GELU()
+        self.fc2 = nn.Linear(4 * n_harmonics, 2 * n_harmonics)
+        self.nonlinear2 = nn.GELU()
+        self.fc3 = nn.Linear(2 * n_harmonics, n_harmonics)
+
+    # ---- the architecture the fused HIP forward implements (the one every call site builds) ----
+    def _is_default_arch(self):
+        return (self.pts_dim == 4 and self.pts_embedding_dim == 256 and self.n_heads == 4 and self.n_code == 3
+                and self.n_harmonics == 64 and self.use_view_state and self.use_global_feature
+                and self.view_state_mode == "end" and self.embedding.concatenate_input and not self.alt
+                and all(e.FF for e in self.encoders))
+
+    def weight_table(self):
+        t = [_f32c(self.embedding.linear1.weight), _f32c(self.embedding.linear1.bias),
+             _f32c(self.embedding.linear2.weight), _f32c(self.embedding.linear2.bias)]
+        for e in self.encoders:
+            t += e.weight_table()
+        t += [_f32c(self.norm.weight), _f32c(self.norm.bias)]
+        for fc in (self.fc1, self.fc2, self.fc3):
+            t += [_f32c(fc.weight), _f32c(fc.bias)]
+        return t
+
+    def forward(self, pts, mask=None, view_harmonics=None):
+        """pts [n_clouds, seq_len, 4], view_harmonics [n_clouds, seq_len, 64] -> [n_clouds, seq_len, 64]."""
+        _inference_only(self, pts)
+        if mask is not None:
+            raise NotImplementedError("mask is None in every call site of the hot path (SURVEY §8 a6)")
+        if not self._is_default_arch():
+            raise NotImplementedError("the fused MI355X SconeVis forward implements the reference's default architecture")
+        if view_harmonics is None:
+            raise ValueError("view_harmonics is required (view_state_mode='end')")
+        n_clouds, seq_len = pts.shape[0], pts.shape[1]
+        res = ops.scone_vis_forward(pts, view_harmonics, self.weight_table())
+        return res.view(n_clouds, seq_len, self.n_harmonics)
+
+    def compute_visibilities(self, pts, harmonics, X_cam):
+        """-> [n_clouds, n_camera_candidates, seq_len]   (SconeVis.py:164-208)."""
+        self._check_scorer(harmonics)
+        return ops.sh_visibilities(pts, harmonics, X_cam, self.use_sigmoid)
+
+    def compute_coverage_gain(self, pts, harmonics, X_cam):
+        """-> [n_clouds, n_camera_candidates]   (SconeVis.py:210-252)."""
+        self._check_scorer(harmonics)
+        return ops.sh_coverage_gain(pts, harmonics, X_cam, self.use_sigmoid)
+
+    def compute_coverage_gain_multiple(self, pts, harmonics, X_cam, n_cam):
+        """Every ordered n_cam-tuple of cameras: mean over points of the max over the tuple (SconeVis.py:254-303)."""
+        self._check_scorer(harmonics)
+        if n_cam not in (2, 3):
+            raise NameError("n_cam is too large.")                       # SconeVis.py:298
+        return ops.coverage_gain_multiple(pts, harmonics, X_cam, n_cam, self.use_sigmoid)
+
+    def _check_scorer(self, harmonics):
+        if self.n_harmonics != 64 or self.max_harmonic_rank != 8 or harmonics.shape[-1] != 64:
+            # the reference hard-codes 64 at SconeVis.py:241
+            raise NotImplementedError("the SH scorer is specialised for 64 harmonics (rank 8), as the reference hard-codes")

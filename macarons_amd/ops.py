@@ -41,11 +41,11 @@ def sh_coverage_gain(pts, harmonics, cams, use_sigmoid=True, waves_per_simd=0):
     L = lib()
     gains = torch.empty((B, C), dtype=torch.float32, device=pts.device)
     ws_bytes = L.mcr_sh_coverage_gain_workspace_bytes(c_i64(B), c_i64(N), c_i64(C))
-    ws = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=pts.device)
+    ws = _workspace(pts.device, max(ws_bytes, 4))
     with torch.cuda.device(pts.device):
         check(L.mcr_sh_coverage_gain(_p(pts), c_int(P), _p(harmonics), _p(cams), _p(gains), c_i64(B), c_i64(N),
                                      c_i64(C), c_int(int(bool(use_sigmoid))), c_int(waves_per_simd), _p(ws),
-                                     c_size(ws.numel() * 4), _stream()), "mcr_sh_coverage_gain")
+                                     c_size(ws.numel()), _stream()), "mcr_sh_coverage_gain")
     return gains
 
 
@@ -81,3 +81,149 @@ def knn_points(X, pc, k, subtract_query=False):
         check(lib().mcr_knn_points(_p(X), _p(pc), _p(idx), _p(dists), _p(pts), c_i64(B), c_i64(Q), c_i64(M), c_int(k),
                                    c_int(int(bool(subtract_query))), _stream()), "mcr_knn_points")
     return pts, dists, idx
+
+
+# ---- K4/K5 building blocks ---------------------------------------------------------------------------
+def _rows(t):
+    """View a [..., E] tensor as rows: returns (2-D contiguous tensor, leading shape)."""
+    lead = t.shape[:-1]
+    return t.reshape(-1, t.shape[-1]), lead
+
+
+def linear(x, weight, bias=None, gelu=False, residual=None):
+    """nn.Linear (+ exact GELU) (+ residual) on the last dim; replaces Attention.py:98-103,186-188,232-235."""
+    x = _req(x, "x")
+    weight = _req(weight, "weight")
+    x2, lead = _rows(x)
+    M, K = x2.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"weight {tuple(weight.shape)} does not match input width {K}")
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    b = _req(bias, "bias") if bias is not None else None
+    r = _req(residual, "residual").reshape(M, N) if residual is not None else None
+    with torch.cuda.device(x.device):
+        check(lib().mcr_linear(_p(x2), c_i64(K), _p(weight), _p(b) if b is not None else c_vp(0),
+                               _p(r) if r is not None else c_vp(0), c_i64(N), _p(y), c_i64(N), c_i64(M), c_int(N), c_int(K),
+                               c_int(int(gelu)), _stream()), "mcr_linear")
+    return y.reshape(*lead, N)
+
+
+def layernorm(x, weight, bias):
+    x = _req(x, "x")
+    x2, lead = _rows(x)
+    M, E = x2.shape
+    y = torch.empty_like(x2)
+    with torch.cuda.device(x.device):
+        check(lib().mcr_layernorm(_p(x2), c_i64(E), _p(_req(weight, "weight")), _p(_req(bias, "bias")), _p(y), c_i64(E),
+                                  c_i64(M), c_int(E), _stream()), "mcr_layernorm")
+    return y.reshape(*lead, E)
+
+
+def attention_packed(qkv, n_heads, qk_dim, v_dim):
+    """qkv [S, L, 2*qk_dim + v_dim] -> [S, L, v_dim]; attention() + head split/merge of Attention.py:8-36,174-198."""
+    qkv = _req(qkv, "qkv")
+    S, L, W = qkv.shape
+    if W != 2 * qk_dim + v_dim:
+        raise ValueError("packed qkv width mismatch")
+    out = torch.empty((S, L, v_dim), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        check(lib().mcr_attention(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads),
+                                  c_int(qk_dim), c_int(v_dim), _stream()), "mcr_attention")
+    return out
+
+
+def colmax_broadcast(x):
+    """x [S, L, E] -> [S, L, E] where every row holds the column-wise max over the L rows (Attention.py:117-121)."""
+    x = _req(x, "x")
+    S, L, E = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().mcr_colmax_broadcast(_p(x), c_i64(E), _p(y), c_i64(E), c_i64(S), c_i64(L), c_int(E), _stream()),
+              "mcr_colmax_broadcast")
+    return y
+
+
+def pool_max_avg(x):
+    """x [S, L, E] -> [S, 2E] = (max over L || mean over L)   (SconeOcc.py:123-126)."""
+    x = _req(x, "x")
+    S, L, E = x.shape
+    y = torch.empty((S, 2 * E), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().mcr_pool_max_avg(_p(x), c_i64(E), _p(y), c_i64(2 * E), c_i64(S), c_i64(L), c_int(E), _stream()),
+              "mcr_pool_max_avg")
+    return y
+
+
+# ---- network forwards ----------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    """One grow-only scratch buffer per device (the C ABI never allocates)."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.1) + 256, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _ptr_table(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def pc_transformer_forward(pc, weights, feature_dim):
+    pc = _req(pc, "pc")
+    S, L, d = pc.shape
+    if d != 3:
+        raise ValueError("PCTransformer HIP path needs pts_dim = 3")
+    L_ = lib()
+    out = torch.empty((S, feature_dim), dtype=torch.float32, device=pc.device)
+    nb = L_.mcr_pc_transformer_workspace_bytes(c_i64(S), c_i64(L))
+    ws = _workspace(pc.device, nb)
+    tab = _ptr_table(weights)
+    with torch.cuda.device(pc.device):
+        check(L_.mcr_pc_transformer_forward(_p(pc), _p(out), c_i64(S), c_i64(L), c_int(feature_dim), tab,
+                                            c_int(len(weights)), _p(ws), c_size(ws.numel()), _stream()),
+              "mcr_pc_transformer_forward")
+    return out
+
+
+def scone_vis_forward(pts, view_harmonics, weights):
+    pts, view_harmonics = _req(pts, "pts"), _req(view_harmonics, "view_harmonics")
+    B, N, d = pts.shape
+    if d != 4 or view_harmonics.shape != (B, N, 64):
+        raise ValueError(f"SconeVis HIP path needs pts [B,N,4] and view_harmonics [B,N,64]; got {tuple(pts.shape)}, "
+                         f"{tuple(view_harmonics.shape)}")
+    L_ = lib()
+    out = torch.empty((B, N, 64), dtype=torch.float32, device=pts.device)
+    nb = L_.mcr_scone_vis_workspace_bytes(c_i64(B), c_i64(N))
+    ws = _workspace(pts.device, nb)
+    tab = _ptr_table(weights)
+    with torch.cuda.device(pts.device):
+        check(L_.mcr_scone_vis_forward(_p(pts), _p(view_harmonics), _p(out), c_i64(B), c_i64(N), tab, c_int(len(weights)),
+                                       _p(ws), c_size(ws.numel()), _stream()), "mcr_scone_vis_forward")
+    return out
+
+
+def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights):
+    pc_global, x, view_harmonics = _req(pc_global, "pc_global"), _req(x, "x"), _req(view_harmonics, "view_harmonics")
+    pc_scales = [_req(p, "pc_scale") for p in pc_scales]
+    B, Lg, _ = pc_global.shape
+    Q = x.shape[1]
+    if len(pc_scales) != 3 or x.shape != (B, Q, 3) or view_harmonics.shape != (B, Q, 64):
+        raise ValueError("SconeOcc HIP path needs 3 scales, x [B,Q,3] and view_harmonics [B,Q,64]")
+    L_ = lib()
+    out = torch.empty((B, Q, 1), dtype=torch.float32, device=x.device)
+    nb = L_.mcr_scone_occ_workspace_bytes(c_i64(B), c_i64(Q), c_i64(Lg))
+    ws = _workspace(x.device, nb)
+    tab = _ptr_table(weights)
+    sc_ptrs = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in pc_scales])
+    sc_m = (ctypes.c_int64 * 3)(*[p.shape[1] for p in pc_scales])
+    with torch.cuda.device(x.device):
+        check(L_.mcr_scone_occ_forward(_p(pc_global), c_i64(Lg), sc_ptrs, sc_m, _p(x), _p(view_harmonics), _p(out), c_i64(B),
+                                       c_i64(Q), tab, c_int(len(weights)), _p(ws), c_size(ws.numel()), _stream()),
+              "mcr_scone_occ_forward")
+    return out

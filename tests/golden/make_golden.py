@@ -129,7 +129,104 @@ def gen_knn():
          Xs=Xs, pcs=pcs, idx_s=idxs.numpy().astype(np.int32), dist_s=ds.numpy())
 
 
-GROUPS = {"scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn}
+def _load(module, seed):
+    import weights
+    sd = weights.make_state_dict(weights.shapes_of(module), seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return module.eval()
+
+
+def gen_blocks():
+    """G8: attention / Embedding / Encoder for the dimension sets of the hot path."""
+    A = ref["Attention"]
+    rng = np.random.default_rng(31)
+    out = {}
+    for tag, (E, qk, N, Bb) in {"vis": (256, 64, 130, 1), "occ": (128, 32, 16, 9)}.items():
+        x = rng.standard_normal((Bb, N, E)).astype(np.float32)
+        enc = _load(A.Encoder(seq_len=N, qk_dim=qk, embedding_dim=E, n_heads=4), 100 + E)
+        with torch.no_grad():
+            out[f"enc_{tag}_x"] = x
+            out[f"enc_{tag}_y"] = enc(t(x)).numpy()
+            q = rng.standard_normal((Bb, 4, N, qk // 4)).astype(np.float32)
+            k = rng.standard_normal((Bb, 4, N, qk // 4)).astype(np.float32)
+            v = rng.standard_normal((Bb, 4, N, E // 4)).astype(np.float32)
+            out[f"att_{tag}_q"], out[f"att_{tag}_k"], out[f"att_{tag}_v"] = q, k, v
+            out[f"att_{tag}_y"] = A.attention(t(q), t(k), t(v)).numpy()
+    emb_v = _load(A.Embedding(4, 256, global_feature=True, concatenate_input=True), 7)
+    emb_o = _load(A.Embedding(3, 128, global_feature=False, concatenate_input=True), 8)
+    xv = rng.uniform(-0.5, 0.5, (2, 77, 4)).astype(np.float32)
+    xo = rng.uniform(-0.2, 0.2, (11, 16, 3)).astype(np.float32)
+    with torch.no_grad():
+        out.update(emb_vis_x=xv, emb_vis_y=emb_v(t(xv)).numpy(), emb_occ_x=xo, emb_occ_y=emb_o(t(xo)).numpy())
+    save("blocks", **out)
+
+
+def gen_vis():
+    """G5: SconeVis.forward with deterministic weights (tests/golden/weights.py, seed 1)."""
+    m = _load(ref["SconeVis"].SconeVis(), 1)
+    rng = np.random.default_rng(41)
+    out = {}
+    for N in (16, 333, 2048):
+        pts = np.concatenate([rng.uniform(-0.5, 0.5, (1, N, 3)), rng.uniform(0.1, 1.0, (1, N, 1))], -1).astype(np.float32)
+        vh = (rng.standard_normal((1, N, 64)) * 0.3).astype(np.float32)
+        with torch.no_grad():
+            y = m(t(pts), view_harmonics=t(vh)).numpy()
+            y64 = m.double()(t(pts, torch.float64), view_harmonics=t(vh, torch.float64)).numpy()
+            m.float()
+        out[f"pts_{N}"], out[f"vh_{N}"], out[f"y_{N}"] = pts, vh, y
+        if N != 2048:
+            out[f"y64_{N}"] = y64.astype(np.float32)
+        else:
+            out["fp32_vs_fp64_maxabs_2048"] = np.float64(np.abs(y - y64).max())
+    B2 = np.concatenate([rng.uniform(-0.5, 0.5, (3, 100, 3)), rng.uniform(0.1, 1.0, (3, 100, 1))], -1).astype(np.float32)
+    vh2 = (rng.standard_normal((3, 100, 64)) * 0.3).astype(np.float32)
+    with torch.no_grad():
+        out.update(pts_b3=B2, vh_b3=vh2, y_b3=m(t(B2), view_harmonics=t(vh2)).numpy())
+    save("scone_vis", **out)
+
+
+def shell_cloud(rng, M):
+    """Points on a unit-diagonal ellipsoid shell + small noise (SURVEY §8d synthetic surface cloud)."""
+    d = rng.standard_normal((M, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return (d * np.array([0.35, 0.25, 0.3]) + rng.standard_normal((M, 3)) * 0.002).astype(np.float32)
+
+
+def gen_occ():
+    """G6: SconeOcc.forward with deterministic weights (seed 2) and the three randperm draws CAPTURED."""
+    m = _load(ref["SconeOcc"].SconeOcc(), 2)
+    rng = np.random.default_rng(51)
+    out = {}
+    for tag, (M, Q) in {"m100_q17": (100, 17), "m1024_q300": (1024, 300), "m4096_q512": (4096, 512)}.items():
+        pc = shell_cloud(rng, M)[None]
+        x = rng.uniform(-0.5, 0.5, (1, Q, 3)).astype(np.float32)
+        vh = (rng.standard_normal((1, Q, 64)) * 0.3).astype(np.float32)
+        perms = []
+        real = torch.randperm
+
+        def capture(n, *a, **kw):
+            p = real(n, *a, **kw)
+            perms.append(p.numpy().copy())
+            return p
+        torch.randperm = capture
+        try:
+            torch.manual_seed(1000 + M)
+            with torch.no_grad():
+                y = m(t(pc), t(x), t(vh)).numpy()
+        finally:
+            torch.randperm = real
+        ds = m.n_scale and int(np.power(M / (16 * 8), 1. / 2)) or 2
+        ds = 2 if ds == 0 else ds
+        cut = [perms[0][:2048], perms[1][:M // ds], perms[2][:(M // ds) // ds]]
+        with torch.no_grad():
+            gf = m.global_transformer(t(pc)[:, torch.from_numpy(cut[0])]).numpy()
+        out.update({f"{tag}_pc": pc, f"{tag}_x": x, f"{tag}_vh": vh, f"{tag}_y": y, f"{tag}_gfeat": gf,
+                    f"{tag}_perm0": cut[0].astype(np.int32), f"{tag}_perm1": cut[1].astype(np.int32),
+                    f"{tag}_perm2": cut[2].astype(np.int32), f"{tag}_seed": np.int64(1000 + M)})
+    save("scone_occ", **out)
+
+
+GROUPS = {"scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -1,0 +1,147 @@
+"""Parity of the HIP network path (through the C ABI) with the reference goldens and the numpy oracle.
+Bar: 1e-4 relative (max-norm) in fp32, the north_star tolerance."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_err
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import weights  # noqa: E402
+from oracle import nets  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _mod(cls, seed, dev, **kw):
+    m = cls(**kw)
+    sd = weights.make_state_dict(weights.shapes_of(m), seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.to(dev).eval(), sd
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def test_blocks(dev):
+    from macarons_amd.networks import Attention as A
+    g = golden("blocks")
+    with torch.no_grad():
+        for tag, (E, qk) in {"vis": (256, 64), "occ": (128, 32)}.items():
+            enc, _ = _mod(lambda: A.Encoder(seq_len=16, qk_dim=qk, embedding_dim=E, n_heads=4), 100 + E, dev)
+            y = enc(T(g[f"enc_{tag}_x"], dev)).cpu().numpy()
+            assert rel_err(y, g[f"enc_{tag}_y"]) < TOL
+            y = A.attention(T(g[f"att_{tag}_q"], dev), T(g[f"att_{tag}_k"], dev), T(g[f"att_{tag}_v"], dev)).cpu().numpy()
+            assert rel_err(y, g[f"att_{tag}_y"]) < TOL
+        ev, _ = _mod(lambda: A.Embedding(4, 256, global_feature=True, concatenate_input=True), 7, dev)
+        eo, _ = _mod(lambda: A.Embedding(3, 128, global_feature=False, concatenate_input=True), 8, dev)
+        assert rel_err(ev(T(g["emb_vis_x"], dev)).cpu().numpy(), g["emb_vis_y"]) < TOL
+        assert rel_err(eo(T(g["emb_occ_x"], dev)).cpu().numpy(), g["emb_occ_y"]) < TOL
+
+
+@pytest.mark.parametrize("M,N,K,gelu,res", [(1, 1, 1, False, False), (130, 126, 4, True, False), (1000, 125, 125, False, False),
+                                             (257, 512, 256, True, False), (4097, 128, 256, False, True),
+                                             (300, 1, 256, True, False), (64, 192, 128, False, False), (33, 64, 1344, True, True)])
+def test_linear_vs_numpy(dev, M, N, K, gelu, res):
+    from macarons_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    y = ops.linear(T(x, dev), T(w, dev), T(b, dev), gelu=gelu, residual=T(r, dev) if res else None).cpu().numpy()
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    if gelu:
+        ref = nets.gelu(ref)
+    if res:
+        ref = ref + r
+    assert np.abs(y - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_layernorm_and_pools(dev):
+    from macarons_amd import ops
+    rng = np.random.default_rng(0)
+    for E in (128, 256):
+        x = (rng.standard_normal((37, 5, E)) * 3 + 1).astype(np.float32)
+        g_, b_ = rng.standard_normal(E).astype(np.float32), rng.standard_normal(E).astype(np.float32)
+        y = ops.layernorm(T(x, dev), T(g_, dev), T(b_, dev)).cpu().numpy()
+        ref = nets.layernorm({"n.weight": g_, "n.bias": b_}, "n", x.astype(np.float64))
+        assert np.abs(y - ref).max() < 2e-5
+    x = rng.standard_normal((3, 333, 126)).astype(np.float32)
+    assert np.array_equal(ops.colmax_broadcast(T(x, dev)).cpu().numpy(), np.broadcast_to(x.max(1, keepdims=True), x.shape))
+    x = rng.standard_normal((70000, 16, 128)).astype(np.float32)        # > 65535 sequences
+    y = ops.pool_max_avg(T(x, dev)).cpu().numpy()
+    assert np.array_equal(y[:, :128], x.max(1)) and np.abs(y[:, 128:] - x.mean(1)).max() < 1e-6
+
+
+def test_scone_vis_forward(dev):
+    from macarons_amd.networks import SconeVis
+    m, sd = _mod(SconeVis, 1, dev)
+    g = golden("scone_vis")
+    with torch.no_grad():
+        for N in (16, 333, 2048):
+            y = m(T(g[f"pts_{N}"], dev), view_harmonics=T(g[f"vh_{N}"], dev)).cpu().numpy()
+            assert y.shape == (1, N, 64)
+            assert rel_err(y, g[f"y_{N}"]) < TOL
+        assert rel_err(m(T(g["pts_333"], dev), view_harmonics=T(g["vh_333"], dev)).cpu().numpy(), g["y64_333"]) < TOL
+        y = m(T(g["pts_b3"], dev), view_harmonics=T(g["vh_b3"], dev)).cpu().numpy()
+        assert rel_err(y, g["y_b3"]) < TOL
+        # ragged size vs the oracle, and the module-by-module path agrees with the fused one
+        rng = np.random.default_rng(3)
+        pts = rng.uniform(-.5, .5, (2, 777, 4)).astype(np.float32)
+        vh = (rng.standard_normal((2, 777, 64)) * .3).astype(np.float32)
+        y = m(T(pts, dev), view_harmonics=T(vh, dev)).cpu().numpy()
+        assert rel_err(y, nets.scone_vis_forward(sd, pts, vh, np.float64)) < TOL
+        x = m.embedding(T(pts, dev))
+        for e in m.encoders:
+            x = e(x)
+        assert rel_err(x.cpu().numpy(), nets_encoders(sd, pts)) < TOL
+
+
+def nets_encoders(sd, pts):
+    x = nets.embedding(sd, "embedding", pts.astype(np.float64), True)
+    for i in range(3):
+        x = nets.encoder(sd, f"encoders.{i}", x)
+    return x
+
+
+def test_scone_occ_forward(dev):
+    from macarons_amd.networks import SconeOcc
+    m, sd = _mod(SconeOcc, 2, dev)
+    g = golden("scone_occ")
+    with torch.no_grad():
+        for tag in ("m100_q17", "m1024_q300", "m4096_q512"):
+            perms = [torch.from_numpy(g[f"{tag}_perm{i}"].astype(np.int64)) for i in range(3)]
+            pc, x, vh = T(g[f"{tag}_pc"], dev), T(g[f"{tag}_x"], dev), T(g[f"{tag}_vh"], dev)
+            gf = m.global_transformer(pc[:, perms[0].to(dev)].contiguous()).cpu().numpy()
+            assert rel_err(gf, g[f"{tag}_gfeat"]) < TOL
+            y = m(pc, x, vh, perms=perms).cpu().numpy()
+            assert y.shape == g[f"{tag}_y"].shape
+            assert rel_err(y, g[f"{tag}_y"]) < TOL
+            # hidden-RNG path: seeding torch like the reference run reproduces the same draws and output
+            torch.manual_seed(int(g[f"{tag}_seed"]))
+            y2 = m(pc, x, vh).cpu().numpy()
+            assert np.array_equal(y, y2)
+
+
+def test_scone_occ_chunking_and_batch(dev):
+    """Q larger than one chunk and B > 1 against the oracle on a sample of queries."""
+    from macarons_amd.networks import SconeOcc
+    m, sd = _mod(SconeOcc, 2, dev)
+    rng = np.random.default_rng(9)
+    B, M, Q = 2, 700, 20000
+    pc = rng.uniform(-.4, .4, (B, M, 3)).astype(np.float32)
+    x = rng.uniform(-.5, .5, (B, Q, 3)).astype(np.float32)
+    vh = (rng.standard_normal((B, Q, 64)) * .3).astype(np.float32)
+    torch.manual_seed(5)
+    perms = m.draw_perms(M)
+    with torch.no_grad():
+        y = m(T(pc, dev), T(x, dev), T(vh, dev), perms=perms).cpu().numpy()
+    sel = np.concatenate([np.arange(5), rng.choice(Q, 40, replace=False), [Q - 1, 16383, 16384]])
+    ref = nets.scone_occ_forward(sd, pc, x[:, sel], vh[:, sel], [p.numpy() for p in perms], np.float64)
+    assert rel_err(y[:, sel], ref) < TOL

@@ -114,3 +114,63 @@ def test_knn_matches_reference():
     # a point of the cloud queried against the cloud: nearest distance is 0 and it is itself
     p, d, i = knn.knn_points(g["pcs"], g["pcs"], 4)
     assert np.all(d[..., 0] == 0) and np.array_equal(i[0, :, 0], np.arange(g["pcs"].shape[1]))
+
+
+def _weights(cls, seed):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import weights
+    m = cls()
+    return m, weights.make_state_dict(weights.shapes_of(m), seed)
+
+
+def test_network_oracle_matches_reference():
+    from oracle import nets
+    from macarons_amd.networks import SconeVis, SconeOcc
+    _, sdv = _weights(SconeVis, 1)
+    g = golden("scone_vis")
+    for N in (16, 333):
+        y = nets.scone_vis_forward(sdv, g[f"pts_{N}"], g[f"vh_{N}"])
+        assert rel_err(y, g[f"y_{N}"]) < 1e-5
+    y64 = nets.scone_vis_forward(sdv, g["pts_333"], g["vh_333"], np.float64)
+    assert rel_err(y64, g["y64_333"]) < 1e-6
+    assert rel_err(nets.scone_vis_forward(sdv, g["pts_b3"], g["vh_b3"]), g["y_b3"]) < 1e-5
+    _, sdo = _weights(SconeOcc, 2)
+    g = golden("scone_occ")
+    for tag in ("m100_q17", "m1024_q300"):
+        perms = [g[f"{tag}_perm{i}"] for i in range(3)]
+        y = nets.scone_occ_forward(sdo, g[f"{tag}_pc"], g[f"{tag}_x"], g[f"{tag}_vh"], perms)
+        assert rel_err(y, g[f"{tag}_y"]) < 1e-5
+        gf = nets.pc_transformer(sdo, "global_transformer.", g[f"{tag}_pc"][:, perms[0]])
+        assert rel_err(gf, g[f"{tag}_gfeat"]) < 1e-5
+
+
+def test_state_dict_layout_matches_reference_contract():
+    """60 / 172 tensors, 1 392 888 / 2 257 769 parameters, reference key names."""
+    from macarons_amd.networks import SconeVis, SconeOcc
+    v, o = SconeVis(), SconeOcc()
+    assert len(v.state_dict()) == 60 and sum(p.numel() for p in v.parameters()) == 1_392_888
+    assert len(o.state_dict()) == 172 and sum(p.numel() for p in o.parameters()) == 2_257_769
+    sv, so = v.state_dict(), o.state_dict()
+    assert sv["embedding.linear1.weight"].shape == (126, 4) and sv["encoders.2.mhsa.w_q.weight"].shape == (64, 256)
+    assert sv["encoders.0.ff.linear1.weight"].shape == (512, 256) and sv["fc1.weight"].shape == (192, 256)
+    assert sv["fc2.weight"].shape == (128, 256) and sv["fc3.weight"].shape == (64, 128)
+    assert so["global_transformer.linear0.weight"].shape == (256, 128)
+    assert so["local_transformers.1.linear0.weight"].shape == (128, 128)
+    assert so["local_transformers.2.encoders.1.mhsa.w_k.weight"].shape == (32, 128)
+    assert so["x_embedding.linear3.weight"].shape == (512, 256) and so["linear1.weight"].shape == (512, 1856)
+    assert so["linear3.weight"].shape == (1, 256)
+    assert len(v.weight_table()) == 48 and len(o.weight_table()) == 140
+
+
+def test_occ_perm_draw_order_matches_reference():
+    """The host draws the hidden randperms exactly like SconeOcc.py:269,311 (same generator, same order)."""
+    import torch
+    from macarons_amd.networks import SconeOcc
+    g = golden("scone_occ")
+    o = SconeOcc()
+    for tag, M in (("m100_q17", 100), ("m1024_q300", 1024), ("m4096_q512", 4096)):
+        torch.manual_seed(int(g[f"{tag}_seed"]))
+        perms = o.draw_perms(M)
+        for i in range(3):
+            assert np.array_equal(perms[i].numpy(), g[f"{tag}_perm{i}"])
