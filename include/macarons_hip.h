@@ -102,7 +102,17 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
 size_t mcr_scone_occ_workspace_bytes(int64_t B, int64_t Q, int64_t Lg);
 int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const* pc_scale, const int64_t* M_scale,
                           const float* x, const float* view_harmonics, float* out, int64_t B, int64_t Q,
-                          const float* const* weights, int n_weights, void* workspace, size_t workspace_bytes,
+                          const float* const* weights, int n_weights, const float* const* local_blobs, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* Fused per-query local PCTransformer (the FLOP majority of SconeOcc.forward, SconeOcc.py:293-304 + :104-130):
+ *   offsets [S,16,3] (kNN neighbours minus the query) -> features[s*ld_features + 0:256] = max(128) || avg(128).
+ * `blob`: 16-byte-aligned device image of ONE local transformer's parameters, mcr_local_pct_blob_floats() floats,
+ * laid out as macarons_amd/networks/packing.py builds it (MFMA-fragment order, LayerNorm folded into the
+ * following linear layer).  mcr_scone_occ_forward uses the fused kernel for scale i when local_blobs != NULL and
+ * local_blobs[i] != NULL (HOST array of 3 device pointers), else the layer-by-layer path. */
+int mcr_local_pct_blob_floats(void);
+int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,
                           void* stream);
 
 #ifdef __cplusplus

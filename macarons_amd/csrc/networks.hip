@@ -146,6 +146,18 @@ int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t
     return 0;
 }
 
+int mcr_local_pct_blob_floats(void) { return local_pct_blob_floats(); }
+
+int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,
+                          void* stream) {
+    MCR_REQUIRE(offsets && features && blob, "mcr_local_pct_forward: null pointer");
+    MCR_REQUIRE(S > 0 && ld_features >= 256, "mcr_local_pct_forward: bad sizes");
+    MCR_REQUIRE((reinterpret_cast<uintptr_t>(blob) & 15) == 0, "mcr_local_pct_forward: blob must be 16-byte aligned");
+    launch_local_pct((hipStream_t)stream, offsets, features, ld_features, S, blob);
+    MCR_LAUNCH_CHECK("mcr_local_pct_forward");
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 size_t mcr_pc_transformer_workspace_bytes(int64_t S, int64_t L) { return pct_ws_bytes(S * L) + 4096; }
 
@@ -235,8 +247,8 @@ int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, 
 
 int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const* pc_scale, const int64_t* M_scale,
                           const float* x, const float* view_harmonics, float* out, int64_t B, int64_t Q,
-                          const float* const* weights, int n_weights, void* workspace, size_t workspace_bytes,
-                          void* stream) {
+                          const float* const* weights, int n_weights, const float* const* local_blobs, void* workspace,
+                          size_t workspace_bytes, void* stream) {
     MCR_REQUIRE(pc_global && pc_scale && M_scale && x && view_harmonics && out && weights, "mcr_scone_occ_forward: null pointer");
     MCR_REQUIRE(n_weights == OCC_NW, "mcr_scone_occ_forward: expected %d weight pointers, got %d", OCC_NW, n_weights);
     MCR_REQUIRE(B > 0 && Q > 0 && Lg > 0 && B <= 65535, "mcr_scone_occ_forward: bad problem size");
@@ -284,7 +296,10 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
                 if (int e = mcr_knn_points(x + (b * Q + q0) * 3, pc_scale[sc] + b * M_scale[sc] * 3, idx, dist, offs, 1, nq,
                                            M_scale[sc], 16, 1, stream))
                     return e;
-                run_pct(s, wl[sc], offs, feat + (b * Q + q0) * FEAT + sc * 256, FEAT, nq, 16, 128, a);
+                if (local_blobs && local_blobs[sc])      // fused LDS-resident kernel (local_pct.hip)
+                    launch_local_pct(s, offs, feat + (b * Q + q0) * FEAT + sc * 256, FEAT, nq, local_blobs[sc]);
+                else                                      // layer-by-layer path through HBM
+                    run_pct(s, wl[sc], offs, feat + (b * Q + q0) * FEAT + sc * 256, FEAT, nq, 16, 128, a);
                 MCR_REQUIRE(a.ok(), "mcr_scone_occ_forward: workspace overflow (local)");
             }
         }

@@ -42,43 +42,64 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    for (int k0 = 0; k0 < K; k0 += LIN_BK) {
-        // ---- stage A (128 x 32) and B (NT*32 x 32), zero-padded ----
+    // Staging registers: chunk k+1 is fetched from global memory while chunk k is in the MFMA phase
+    // (issue-early / write-late split), so HBM/L2 latency hides behind the matrix pipe.
+    float4 ra[4], rb[NT];
+    auto fetch = [&](int k0) {
         if (vec_x) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m0 + row < M && k0 + c4 < K) v = *reinterpret_cast<const float4*>(X + (m0 + row) * ldx + k0 + c4);
-                *reinterpret_cast<float4*>(&As[row * LIN_LD + c4]) = v;
+                ra[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m0 + row < M && k0 + c4 < K) ra[r] = *reinterpret_cast<const float4*>(X + (m0 + row) * ldx + k0 + c4);
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int idx = tid + r * 256, row = idx >> 5, c = idx & 31;
-                float v = 0.f;
-                if (m0 + row < M && k0 + c < K) v = X[(m0 + row) * ldx + k0 + c];
-                As[row * LIN_LD + c] = v;
+            for (int r = 0; r < 4; ++r) {
+                const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+                const float* px = X + (m0 + row) * ldx + k0 + c4;
+                const bool rv = m0 + row < M;
+                ra[r].x = rv && k0 + c4 + 0 < K ? px[0] : 0.f;
+                ra[r].y = rv && k0 + c4 + 1 < K ? px[1] : 0.f;
+                ra[r].z = rv && k0 + c4 + 2 < K ? px[2] : 0.f;
+                ra[r].w = rv && k0 + c4 + 3 < K ? px[3] : 0.f;
             }
         }
         if (vec_w) {
 #pragma unroll
             for (int r = 0; r < NT; ++r) {
                 const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n0 + row < N && k0 + c4 < K) v = *reinterpret_cast<const float4*>(W + (long long)(n0 + row) * ldw + k0 + c4);
-                *reinterpret_cast<float4*>(&Bs[row * LIN_LD + c4]) = v;
+                rb[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n0 + row < N && k0 + c4 < K) rb[r] = *reinterpret_cast<const float4*>(W + (long long)(n0 + row) * ldw + k0 + c4);
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < NT * 4; ++r) {
-                const int idx = tid + r * 256, row = idx >> 5, c = idx & 31;
-                float v = 0.f;
-                if (n0 + row < N && k0 + c < K) v = W[(long long)(n0 + row) * ldw + k0 + c];
-                Bs[row * LIN_LD + c] = v;
+            for (int r = 0; r < NT; ++r) {
+                const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+                const float* pw = W + (long long)(n0 + row) * ldw + k0 + c4;
+                const bool rv = n0 + row < N;
+                rb[r].x = rv && k0 + c4 + 0 < K ? pw[0] : 0.f;
+                rb[r].y = rv && k0 + c4 + 1 < K ? pw[1] : 0.f;
+                rb[r].z = rv && k0 + c4 + 2 < K ? pw[2] : 0.f;
+                rb[r].w = rv && k0 + c4 + 3 < K ? pw[3] : 0.f;
             }
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += LIN_BK) {
+        // ---- write the staged chunk to LDS (A: 128 x 32, B: NT*32 x 32, zero-padded) ----
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+            *reinterpret_cast<float4*>(&As[row * LIN_LD + c4]) = ra[r];
+        }
+#pragma unroll
+        for (int r = 0; r < NT; ++r) {
+            const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+            *reinterpret_cast<float4*>(&Bs[row * LIN_LD + c4]) = rb[r];
+        }
         __syncthreads();
+        if (k0 + LIN_BK < K) fetch(k0 + LIN_BK);       // in flight during the MFMA phase
         // ---- MFMA over the chunk ----
         const float* a_row = &As[(wave * 32 + i) * LIN_LD + h * 16];
 #pragma unroll

@@ -12,6 +12,7 @@ from torch import nn
 
 from .. import ops
 from .Attention import Embedding, Encoder, _f32c, _inference_only
+from .packing import BlobCache
 
 
 class XEmbedding(nn.Module):
@@ -106,6 +107,9 @@ class SconeOcc(nn.Module):
         self.linear2 = nn.Linear(512, 256)
         self.linear3 = nn.Linear(256, output_dim)
         self.non_linear1, self.non_linear2, self.non_linear3 = nn.GELU(), nn.GELU(), nn.GELU()
+        # fused LDS-resident local transformers (local_pct.hip); set False to run them layer by layer
+        self.fused_local = True
+        self._blob_caches = [BlobCache() for _ in range(n_scale)]
 
     def _is_default_arch(self):
         return (self.n_scale == 3 and self.k_for_knn == 16 and self.offset and self.x_dim == 3 and self.x_embedding_dim == 512
@@ -156,5 +160,6 @@ class SconeOcc(nn.Module):
         scales = [pc.contiguous()]
         for p in perms[1:]:
             scales.append(scales[-1][:, p.to(dev)].contiguous())                      # :311
-        res = ops.scone_occ_forward(pc_global, scales, x, view_harmonics, self.weight_table())
+        blobs = [c.get(t) for c, t in zip(self._blob_caches, self.local_transformers)] if self.fused_local else None
+        res = ops.scone_occ_forward(pc_global, scales, x, view_harmonics, self.weight_table(), blobs)
         return res.view(n_clouds, n_sample, self.output_dim)

@@ -1,0 +1,79 @@
+"""Host-side packing of one local PCTransformer's parameters into the image local_pct.hip consumes.
+
+Layout (must match macarons_amd/csrc/local_pct.hip):
+  matrices, each stored as MFMA-fragment tiles [N/32][K/8][64 lanes][4]:
+     lane = h*32 + j reads W[32*nt + j][h*K/2 + 4*g + e]  (the two lane halves own the two halves of K)
+     0 emb1 (128 x 8, zero padded from 125 x 3)   1 emb2 (128 x 128, zero padded from 125 x 125)
+     per encoder: qkv (192 x 128, LayerNorm-1 gamma folded)  out  ff1a ff1b (rows 0:128 / 128:256 of ff.linear1,
+     LayerNorm-2 gamma folded)  ff2a ff2b (columns 0:128 / 128:256 of ff.linear2)
+     14 lin0 (final norm gamma folded)
+  vectors: emb1_b[128] emb2_b[128] | per encoder: qkv_c[192] out_b[128] ff1_c[256] ff2_b[128] | lin0_c[128]
+     where c = bias + W @ beta (the LayerNorm shift folded through the linear layer).
+Folding is algebraically exact; it only moves fp32 roundings (covered by the 1e-4 parity tests).
+"""
+import torch
+
+from .. import _lib
+
+
+def _pack(W):
+    """[N, K] -> flat fragment order [N/32][K/8][64][4]."""
+    N, K = W.shape
+    assert N % 32 == 0 and K % 8 == 0
+    t = W.reshape(N // 32, 32, 2, K // 8, 4)          # [nt, j, h, g, e]
+    return t.permute(0, 3, 2, 1, 4).contiguous().reshape(-1)   # [nt, g, h, j, e]
+
+
+def _pad(W, n, k):
+    out = W.new_zeros(n, k)
+    out[:W.shape[0], :W.shape[1]] = W
+    return out
+
+
+def _padv(v, n):
+    out = v.new_zeros(n)
+    out[:v.shape[0]] = v
+    return out
+
+
+def pack_local_pct(pct):
+    """pct: macarons_amd.networks.SconeOcc.PCTransformer (default local architecture). Returns a 1-D fp32 tensor."""
+    with torch.no_grad():
+        f = lambda p: p.detach().float()
+        mats, vecs = [], []
+        emb = pct.embedding
+        mats.append(_pack(_pad(f(emb.linear1.weight), 128, 8)))
+        mats.append(_pack(_pad(f(emb.linear2.weight), 128, 128)))
+        vecs += [_padv(f(emb.linear1.bias), 128), _padv(f(emb.linear2.bias), 128)]
+        for enc in pct.encoders:
+            g1, b1 = f(enc.norm1.weight), f(enc.norm1.bias)
+            g2, b2 = f(enc.norm2.weight), f(enc.norm2.bias)
+            wqkv = torch.cat((f(enc.mhsa.w_q.weight), f(enc.mhsa.w_k.weight), f(enc.mhsa.w_v.weight)), 0)
+            bqkv = torch.cat((f(enc.mhsa.w_q.bias), f(enc.mhsa.w_k.bias), f(enc.mhsa.w_v.bias)), 0)
+            w1, w2 = f(enc.ff.linear1.weight), f(enc.ff.linear2.weight)
+            mats += [_pack(wqkv * g1[None, :]), _pack(f(enc.mhsa.out.weight)),
+                     _pack((w1 * g2[None, :])[:128]), _pack((w1 * g2[None, :])[128:]),
+                     _pack(w2[:, :128].contiguous()), _pack(w2[:, 128:].contiguous())]
+            vecs += [bqkv + wqkv @ b1, f(enc.mhsa.out.bias), f(enc.ff.linear1.bias) + w1 @ b2, f(enc.ff.linear2.bias)]
+        gn, bn = f(pct.norm.weight), f(pct.norm.bias)
+        w0 = f(pct.linear0.weight)
+        mats.append(_pack(w0 * gn[None, :]))
+        vecs.append(f(pct.linear0.bias) + w0 @ bn)
+        blob = torch.cat(mats + vecs).contiguous()
+    expect = _lib.lib().mcr_local_pct_blob_floats()
+    if blob.numel() != expect:
+        raise RuntimeError(f"packed local transformer has {blob.numel()} floats, kernel expects {expect}")
+    return blob
+
+
+class BlobCache:
+    """Re-pack only when a parameter changed (data_ptr / version / device)."""
+
+    def __init__(self):
+        self._key, self._blob = None, None
+
+    def get(self, pct):
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in pct.parameters())
+        if key != self._key:
+            self._blob, self._key = pack_local_pct(pct), key
+        return self._blob

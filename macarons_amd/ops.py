@@ -208,7 +208,20 @@ def scone_vis_forward(pts, view_harmonics, weights):
     return out
 
 
-def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights):
+def local_pct_forward(offsets, blob):
+    """offsets [S,16,3] -> [S,256]: fused local PCTransformer (local_pct.hip)."""
+    offsets, blob = _req(offsets, "offsets"), _req(blob, "blob")
+    S = offsets.shape[0]
+    if tuple(offsets.shape[1:]) != (16, 3):
+        raise ValueError("offsets must be [S,16,3]")
+    out = torch.empty((S, 256), dtype=torch.float32, device=offsets.device)
+    with torch.cuda.device(offsets.device):
+        check(lib().mcr_local_pct_forward(_p(offsets), _p(out), c_i64(256), c_i64(S), _p(blob), _stream()),
+              "mcr_local_pct_forward")
+    return out
+
+
+def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_blobs=None):
     pc_global, x, view_harmonics = _req(pc_global, "pc_global"), _req(x, "x"), _req(view_harmonics, "view_harmonics")
     pc_scales = [_req(p, "pc_scale") for p in pc_scales]
     B, Lg, _ = pc_global.shape
@@ -222,8 +235,9 @@ def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights):
     tab = _ptr_table(weights)
     sc_ptrs = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in pc_scales])
     sc_m = (ctypes.c_int64 * 3)(*[p.shape[1] for p in pc_scales])
+    blobs = (ctypes.c_void_p * 3)(*[_req(b, "local_blob").data_ptr() for b in local_blobs]) if local_blobs else None
     with torch.cuda.device(x.device):
         check(L_.mcr_scone_occ_forward(_p(pc_global), c_i64(Lg), sc_ptrs, sc_m, _p(x), _p(view_harmonics), _p(out), c_i64(B),
-                                       c_i64(Q), tab, c_int(len(weights)), _p(ws), c_size(ws.numel()), _stream()),
+                                       c_i64(Q), tab, c_int(len(weights)), blobs, _p(ws), c_size(ws.numel()), _stream()),
               "mcr_scone_occ_forward")
     return out

@@ -145,3 +145,37 @@ def test_scone_occ_chunking_and_batch(dev):
     sel = np.concatenate([np.arange(5), rng.choice(Q, 40, replace=False), [Q - 1, 16383, 16384]])
     ref = nets.scone_occ_forward(sd, pc, x[:, sel], vh[:, sel], [p.numpy() for p in perms], np.float64)
     assert rel_err(y[:, sel], ref) < TOL
+
+
+def test_fused_local_transformer(dev):
+    """local_pct.hip (fused, LayerNorm folded) vs the layer-by-layer HIP path and the fp64 oracle."""
+    from macarons_amd import ops
+    from macarons_amd.networks import SconeOcc
+    from macarons_amd.networks.packing import pack_local_pct
+    m, sd = _mod(SconeOcc, 2, dev)
+    rng = np.random.default_rng(4)
+    for S in (1, 3, 4, 1001):
+        offs = (rng.standard_normal((S, 16, 3)) * 0.05).astype(np.float32)
+        for sc in range(3):
+            lt = m.local_transformers[sc]
+            with torch.no_grad():
+                fused = ops.local_pct_forward(T(offs, dev), pack_local_pct(lt)).cpu().numpy()
+                plain = lt(T(offs, dev)).cpu().numpy()
+            ref = nets.pc_transformer(sd, f"local_transformers.{sc}.", offs, np.float64)
+            assert rel_err(fused, ref) < TOL and rel_err(plain, ref) < TOL
+            assert rel_err(fused, plain) < TOL
+
+
+def test_scone_occ_fused_equals_unfused(dev):
+    from macarons_amd.networks import SconeOcc
+    m, sd = _mod(SconeOcc, 2, dev)
+    g = golden("scone_occ")
+    tag = "m1024_q300"
+    perms = [torch.from_numpy(g[f"{tag}_perm{i}"].astype(np.int64)) for i in range(3)]
+    pc, x, vh = T(g[f"{tag}_pc"], dev), T(g[f"{tag}_x"], dev), T(g[f"{tag}_vh"], dev)
+    with torch.no_grad():
+        m.fused_local = True
+        y1 = m(pc, x, vh, perms=perms).cpu().numpy()
+        m.fused_local = False
+        y0 = m(pc, x, vh, perms=perms).cpu().numpy()
+    assert rel_err(y1, g[f"{tag}_y"]) < TOL and rel_err(y0, g[f"{tag}_y"]) < TOL
