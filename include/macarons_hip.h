@@ -115,6 +115,31 @@ int mcr_local_pct_blob_floats(void);
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,
                           void* stream);
 
+/* ---- glue either side of the networks --------------------------------------------------------
+ * mcr_view_state: compute_view_state (macarons/utility/scone_utils.py:799-860): for every (point, view) the
+ *   elevation/azimuth of (X_view[v] - pts[p,:3]) is binned on the n_elev x n_azim lattice with the reference's
+ *   exact clamp / wrap rules; view_state [n_points, n_elev*n_azim] fp32 0/1 (zeroed here, then set).
+ * mcr_sample_proxy: sample_proxy_points (scone_utils.py:1030-1061) with the uniforms `u` supplied by the host:
+ *   keeps points with preds > min_occ, draws n_sample points with probability proportional to preds (inverse
+ *   CDF in fp64: first i with C_i >= u * C_last), then unique (sorted) + inverse.  Outputs are padded to
+ *   n_sample rows; *n_unique (device int) says how many are valid.  uniq holds ORIGINAL point indices.
+ *   res [n_sample,4] = (X, pred), res_harmonics [n_sample,64].  preds may be strided (pred_stride floats).
+ * mcr_points_in_fov: Camera.get_points_in_fov (macarons/utility/macarons_utils.py:2400-2435) for n_cam cameras
+ *   at once.  Each camera is 40 floats: M_view[16] and M_proj[16] (row-major 4x4, row-vector convention
+ *   p' = [x y z 1] M, as pytorch3d's get_world_to_view_transform / get_full_projection_transform matrices),
+ *   {min_ndc_x, max_ndc_x, min_ndc_y, max_ndc_y}, camera centre[3], range (<= 0: no range test).
+ *   mask [n_cam, P] bytes (0/1).
+ * mcr_coverage_gain_multiple: the tuple stage of SconeVis.compute_coverage_gain_multiple (SconeVis.py:289-301):
+ *   vis [B,C,N] -> gains [B, C^n_cam] over ordered tuples in torch.cartesian_prod order, n_cam in {2,3}. */
+int mcr_view_state(const float* pts, int pts_dim, const float* X_view, float* view_state, int64_t n_points, int n_view,
+                   int n_elev, int n_azim, void* stream);
+size_t mcr_sample_proxy_workspace_bytes(int64_t P, int n_sample);
+int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t P,
+                     float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
+                     int64_t* inverse, int* n_unique, void* workspace, size_t workspace_bytes, void* stream);
+int mcr_points_in_fov(const float* pts, int64_t P, const float* cameras, int n_cam, unsigned char* mask, void* stream);
+int mcr_coverage_gain_multiple(const float* vis, float* gains, int64_t B, int64_t C, int64_t N, int n_cam, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,326 @@
+// Glue kernels either side of the networks for gfx950:
+//   K3  view-state binning              macarons/utility/scone_utils.py:799-860  compute_view_state
+//   K10 occupancy-weighted proxy sampling macarons/utility/scone_utils.py:1030-1061 sample_proxy_points
+//   K2  camera-frustum / range mask     macarons/utility/macarons_utils.py:2400-2435 Camera.get_points_in_fov
+//   a3  n-camera coverage gains         macarons/networks/SconeVis.py:289-301
+// These are HBM-bound byte/index passes: one coalesced sweep each, no reshaping into GEMMs.
+// MCR_HIPCC_FLAGS: -ffp-contract=off
+#include "common.h"
+
+namespace mcr {
+
+// ---------------------------------------------------------------------------------------------------------
+// K3: one thread per (point, view).  Literal fp32 restatement of the reference's binning (asin / acos / Python-
+// style mod / its clamps and wrap-arounds, including the (-n_elev)//2 precedence quirk): the 98-bin state must
+// be bit-exact away from bin boundaries.
+__device__ __forceinline__ float py_mod(float a, float b) {       // torch.remainder / Python %, b > 0
+    float m = fmodf(a, b);
+    if (m != 0.f && m < 0.f) m += b;
+    return m;
+}
+
+__global__ void view_state_kernel(const float* __restrict__ pts, int pts_dim, const float* __restrict__ X_view,
+                                  float* __restrict__ view_state, long long n_points, int n_view, int n_elev, int n_azim) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_points * n_view) return;
+    const long long p = gid / n_view;
+    const int v = (int)(gid - p * n_view);
+    const float PI = 3.14159265358979323846f;
+    const float x = X_view[3 * v + 0] - pts[p * pts_dim + 0];
+    const float y = X_view[3 * v + 1] - pts[p * pts_dim + 1];
+    const float z = X_view[3 * v + 2] - pts[p * pts_dim + 2];
+    // get_spherical_coords (CustomGeometry.py:27-45)
+    const float r = sqrtf(x * x + y * y + z * z);
+    const float yr = y / r;
+    float elev = asinf(yr);
+    if (yr <= -1.f) elev = -PI / 2;
+    if (yr >= 1.f) elev = PI / 2;
+    const float q = z / (r * cosf(elev));
+    float azim = acosf(q);
+    if (q <= -1.f) azim = PI;
+    if (q >= 1.f) azim = 0.f;
+    if (x < 0.f) azim = -azim;
+    // scone_utils.py:830-849
+    const float es = (float)(3.14159265358979323846 / (n_elev + 1)), as = (float)(2.0 * 3.14159265358979323846 / n_azim);
+    const float me = py_mod(elev, es), ma = py_mod(azim, as);
+    float ie = (elev - me) / es, ia = (azim - ma) / as;               // floor_divide (utils.py:113-117)
+    if (me > (float)(3.14159265358979323846 / (n_elev + 1) / 2.0)) ie += 1.f;
+    if (ma > (float)(2.0 * 3.14159265358979323846 / n_azim / 2.0)) ia += 1.f;
+    const int lo_e = -((n_elev + 1) / 2);                              // Python: -n_elev // 2  (= -4 for 7)
+    const int lo_a = -((n_azim + 1) / 2);                              // Python: -n_azim // 2  (= -7 for 14)
+    if (ie >= (float)n_elev) ie = (float)(n_elev - 1);
+    if (ie < (float)lo_e) ie = (float)lo_e;
+    if (ia > (float)(n_azim / 2)) ia = (float)lo_a;
+    ie += (float)(n_elev / 2);
+    if (ia < 0.f) ia += (float)n_azim;
+    long long idx = (long long)ie * n_azim + (long long)ia;
+    const int nb = n_elev * n_azim;
+    idx %= nb;
+    if (idx < 0) idx += nb;                                            // Python % on a negative product
+    view_state[p * nb + idx] = 1.0f;                                   // idempotent (scone_utils.py:857-858)
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K10: sampling.  Convention (oracle/view_state.py sample_proxy_points(exact=True)): C_i = fp64 running sum of
+// the occupancies above min_occ (others contribute 0), sample u picks the first i with C_i >= u * C_last.
+// 1) block sums  2) scan of block sums (one block)  3) per-sample search  4) sort / unique / inverse (one block)
+constexpr int SMP_BLOCK = 256;
+
+__global__ __launch_bounds__(SMP_BLOCK) void smp_block_sums(const float* __restrict__ preds, long long pred_stride,
+                                                            float min_occ, long long P, double* __restrict__ block_sums) {
+    __shared__ double s[SMP_BLOCK / 64];
+    const long long i = (long long)blockIdx.x * SMP_BLOCK + threadIdx.x;
+    double v = 0.0;
+    if (i < P) {
+        const float p = preds[i * pred_stride];
+        v = p > min_occ ? (double)p : 0.0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+// exclusive scan of block sums in place (single block, sequential chunks: n_blocks is a few hundred)
+__global__ __launch_bounds__(256) void smp_scan_blocks(double* __restrict__ block_sums, int n_blocks, double* __restrict__ total) {
+    __shared__ double s[256];
+    __shared__ double carry;
+    if (threadIdx.x == 0) carry = 0.0;
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += 256) {
+        const int i = base + threadIdx.x;
+        const double v = i < n_blocks ? block_sums[i] : 0.0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {                      // Hillis-Steele inclusive scan
+            const double t = threadIdx.x >= o ? s[threadIdx.x - o] : 0.0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_blocks) block_sums[i] = carry + s[threadIdx.x] - v;      // exclusive
+        __syncthreads();
+        if (threadIdx.x == 255) carry += s[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+// per sample: find the block by binary search on the exclusive block offsets, then walk the block sequentially
+__global__ void smp_search(const float* __restrict__ preds, long long pred_stride, float min_occ, long long P,
+                           const double* __restrict__ block_off, int n_blocks, const double* __restrict__ total,
+                           const float* __restrict__ u, int n_sample, long long* __restrict__ picked) {
+    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= n_sample) return;
+    const double target = (double)u[sidx] * (*total);
+    int lo = 0, hi = n_blocks - 1;                 // last block whose exclusive offset < target (or 0)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (block_off[mid] < target) lo = mid; else hi = mid - 1;
+    }
+    // walk forward from block lo until the running sum reaches the target on a kept point
+    double c = block_off[lo];
+    long long i = (long long)lo * SMP_BLOCK, last_kept = -1;
+    long long ans = -1;
+    for (; i < P; ++i) {
+        const float p = preds[i * pred_stride];
+        if (p > min_occ) {
+            c += (double)p;
+            last_kept = i;
+            if (c >= target) { ans = i; break; }
+        }
+    }
+    if (ans < 0) {                                  // target beyond the total by rounding: last kept point
+        if (last_kept < 0) {
+            for (i = (long long)lo * SMP_BLOCK - 1; i >= 0; --i)
+                if (preds[i * pred_stride] > min_occ) { last_kept = i; break; }
+        }
+        ans = last_kept;
+    }
+    picked[sidx] = ans;
+}
+
+// one block: bitonic sort of (picked, sample id), unique, inverse.  n_sample <= SMP_MAX.
+constexpr int SMP_MAX = 4096;
+__global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__ picked, int n_sample,
+                                                   long long* __restrict__ uniq, long long* __restrict__ inverse,
+                                                   int* __restrict__ n_unique) {
+    __shared__ long long key[SMP_MAX];
+    __shared__ int rank[SMP_MAX];
+    int n2 = 1;
+    while (n2 < n_sample) n2 <<= 1;
+    for (int i = threadIdx.x; i < n2; i += 1024)
+        key[i] = i < n_sample ? ((picked[i] << 13) | (long long)i) : 0x7fffffffffffffffLL;   // sample id in the low 13 bits
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool up = (i & k) == 0;
+                    const long long a = key[i], b = key[ixj];
+                    if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // flags -> inclusive scan (sequential per thread chunk + block scan)
+    for (int i = threadIdx.x; i < n2; i += 1024)
+        rank[i] = (i < n_sample && (i == 0 || (key[i] >> 13) != (key[i - 1] >> 13))) ? 1 : 0;
+    __syncthreads();
+    for (int o = 1; o < n2; o <<= 1) {
+        int t[SMP_MAX / 1024];
+        int c = 0;
+        for (int i = threadIdx.x; i < n2; i += 1024) t[c++] = i >= o ? rank[i - o] : 0;
+        __syncthreads();
+        c = 0;
+        for (int i = threadIdx.x; i < n2; i += 1024) rank[i] += t[c++];
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n_sample; i += 1024) {
+        const int r = rank[i] - 1;
+        const long long id = key[i] >> 13;
+        if (i == 0 || id != (key[i - 1] >> 13)) uniq[r] = id;
+        inverse[key[i] & 8191] = r;
+    }
+    if (threadIdx.x == 0) *n_unique = rank[n_sample - 1];
+}
+
+// res[r] = (X[uniq[r]], pred[uniq[r]]), res_h[r] = vh[uniq[r]]   for r < n_unique  (scone_utils.py:1060-1061)
+__global__ void smp_gather(const float* __restrict__ X, const float* __restrict__ preds, long long pred_stride,
+                           const float* __restrict__ vh, const long long* __restrict__ uniq, const int* __restrict__ n_unique,
+                           float* __restrict__ res, float* __restrict__ res_h) {
+    const int r = blockIdx.x;
+    if (r >= *n_unique) return;
+    const long long i = uniq[r];
+    const int c = threadIdx.x;          // 64 threads
+    res_h[(long long)r * 64 + c] = vh[i * 64 + c];
+    if (c < 3) res[r * 4 + c] = X[i * 3 + c];
+    if (c == 3) res[r * 4 + 3] = preds[i * pred_stride];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2: frustum + range mask.  Row-vector convention of the reference's camera transforms:
+//   p_view = [x y z 1] * M_view (4x4 row-major),   p_ndc = ([x y z 1] * M_proj)[:3] / w
+// mask = ndc_x in [min_x,max_x] & ndc_y in [min_y,max_y] & z_view > 0 [& |p - c| < range]   (macarons_utils.py:2420-2430)
+__global__ void fov_kernel(const float* __restrict__ pts, long long P, const float* __restrict__ cam, int n_cam,
+                           unsigned char* __restrict__ mask) {
+    // cam record (40 floats): M_view[16], M_proj[16], ndc bounds {min_x,max_x,min_y,max_y}, center[3], range (<=0: none)
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= P * n_cam) return;
+    const int c = (int)(gid / P);
+    const long long p = gid - (long long)c * P;
+    const float* K = cam + c * 40;
+    const float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
+    const float zv = ((x * K[2] + y * K[6]) + z * K[10]) + K[14];
+    const float* Mp = K + 16;
+    const float px = ((x * Mp[0] + y * Mp[4]) + z * Mp[8]) + Mp[12];
+    const float py = ((x * Mp[1] + y * Mp[5]) + z * Mp[9]) + Mp[13];
+    const float pw = ((x * Mp[3] + y * Mp[7]) + z * Mp[11]) + Mp[15];
+    const float nx = px / pw, ny = py / pw;
+    bool m = nx >= K[32] && nx <= K[33] && ny >= K[34] && ny <= K[35] && zv > 0.f;
+    if (K[39] > 0.f) {
+        const float dx = x - K[36], dy = y - K[37], dz = z - K[38];
+        m = m && sqrtf((dx * dx + dy * dy) + dz * dz) < K[39];
+    }
+    mask[gid] = m ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// a3: gains of every ordered n-tuple of cameras: mean_n max_t vis[b, c_t, n]   (SconeVis.py:289-301)
+// grid = (C^n tuples, B); one block per tuple, tree reduce in fixed order.
+__global__ __launch_bounds__(256) void multi_gain_kernel(const float* __restrict__ vis, float* __restrict__ out, int C, int N,
+                                                         int n_cam) {
+    __shared__ double s[4];
+    const int tup = blockIdx.x, b = blockIdx.y;
+    int c[3];
+    int t = tup;
+    for (int k = n_cam - 1; k >= 0; --k) { c[k] = t % C; t /= C; }       // cartesian_prod order: last index fastest
+    const float* v = vis + (size_t)b * C * N;
+    double acc = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float m = v[(size_t)c[0] * N + n];
+        for (int k = 1; k < n_cam; ++k) m = fmaxf(m, v[(size_t)c[k] * N + n]);
+        acc += (double)m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long tuples = 1;
+        for (int k = 0; k < n_cam; ++k) tuples *= C;
+        out[(size_t)b * tuples + tup] = (float)(((s[0] + s[1]) + (s[2] + s[3])) / (double)N);
+    }
+}
+
+}  // namespace mcr
+
+using namespace mcr;
+
+extern "C" {
+
+int mcr_view_state(const float* pts, int pts_dim, const float* X_view, float* view_state, int64_t n_points, int n_view,
+                   int n_elev, int n_azim, void* stream) {
+    MCR_REQUIRE(pts && X_view && view_state, "mcr_view_state: null pointer");
+    MCR_REQUIRE(pts_dim >= 3 && n_points > 0 && n_view > 0 && n_elev > 0 && n_azim > 0, "mcr_view_state: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t bytes = (size_t)n_points * n_elev * n_azim * sizeof(float);
+    if (int e = check_hip(hipMemsetAsync(view_state, 0, bytes, s), "mcr_view_state: memset")) return e;
+    const long long total = (long long)n_points * n_view;
+    hipLaunchKernelGGL(view_state_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, pts, pts_dim, X_view, view_state,
+                       (long long)n_points, n_view, n_elev, n_azim);
+    MCR_LAUNCH_CHECK("view_state_kernel");
+    return 0;
+}
+
+size_t mcr_sample_proxy_workspace_bytes(int64_t P, int n_sample) {
+    return (size_t)(cdiv(P, SMP_BLOCK) + 2) * sizeof(double) + (size_t)n_sample * sizeof(long long) + 256;
+}
+
+int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t P,
+                     float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
+                     int64_t* inverse, int* n_unique, void* workspace, size_t workspace_bytes, void* stream) {
+    MCR_REQUIRE(X && preds && view_harmonics && u && res && res_harmonics && uniq && inverse && n_unique,
+                "mcr_sample_proxy: null pointer");
+    MCR_REQUIRE(P > 0 && n_sample > 0 && n_sample <= SMP_MAX, "mcr_sample_proxy: need 0 < n_sample <= %d", SMP_MAX);
+    MCR_REQUIRE(P < (1ll << 49), "mcr_sample_proxy: P too large");
+    MCR_REQUIRE(workspace && workspace_bytes >= mcr_sample_proxy_workspace_bytes(P, n_sample), "mcr_sample_proxy: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)cdiv(P, SMP_BLOCK);
+    double* block_sums = (double*)workspace;
+    double* total = block_sums + nb;
+    long long* picked = (long long*)(total + 2);
+    hipLaunchKernelGGL(smp_block_sums, dim3(nb), dim3(SMP_BLOCK), 0, s, preds, (long long)pred_stride, min_occ, (long long)P, block_sums);
+    hipLaunchKernelGGL(smp_scan_blocks, dim3(1), dim3(256), 0, s, block_sums, nb, total);
+    hipLaunchKernelGGL(smp_search, dim3((unsigned)cdiv(n_sample, 128)), dim3(128), 0, s, preds, (long long)pred_stride, min_occ,
+                       (long long)P, block_sums, nb, total, u, n_sample, picked);
+    hipLaunchKernelGGL(smp_unique, dim3(1), dim3(1024), 0, s, picked, n_sample, (long long*)uniq, (long long*)inverse, n_unique);
+    hipLaunchKernelGGL(smp_gather, dim3((unsigned)n_sample), dim3(64), 0, s, X, preds, (long long)pred_stride, view_harmonics,
+                       (const long long*)uniq, n_unique, res, res_harmonics);
+    MCR_LAUNCH_CHECK("mcr_sample_proxy");
+    return 0;
+}
+
+int mcr_points_in_fov(const float* pts, int64_t P, const float* cameras, int n_cam, unsigned char* mask, void* stream) {
+    MCR_REQUIRE(pts && cameras && mask && P > 0 && n_cam > 0, "mcr_points_in_fov: bad arguments");
+    hipLaunchKernelGGL(fov_kernel, dim3((unsigned)cdiv(P * n_cam, 256)), dim3(256), 0, (hipStream_t)stream, pts, (long long)P,
+                       cameras, n_cam, mask);
+    MCR_LAUNCH_CHECK("fov_kernel");
+    return 0;
+}
+
+int mcr_coverage_gain_multiple(const float* vis, float* gains, int64_t B, int64_t C, int64_t N, int n_cam, void* stream) {
+    MCR_REQUIRE(vis && gains && B > 0 && C > 0 && N > 0, "mcr_coverage_gain_multiple: bad arguments");
+    MCR_REQUIRE(n_cam == 2 || n_cam == 3, "n_cam is too large.");
+    long long tuples = 1;
+    for (int k = 0; k < n_cam; ++k) tuples *= C;
+    MCR_REQUIRE(tuples < (1ll << 31) && B <= 65535, "mcr_coverage_gain_multiple: too many tuples");
+    hipLaunchKernelGGL(multi_gain_kernel, dim3((unsigned)tuples, (unsigned)B), dim3(256), 0, (hipStream_t)stream, vis, gains, (int)C,
+                       (int)N, n_cam);
+    MCR_LAUNCH_CHECK("multi_gain_kernel");
+    return 0;
+}
+
+}  // extern "C"

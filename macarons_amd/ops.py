@@ -241,3 +241,64 @@ def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_bl
                                        c_i64(Q), tab, c_int(len(weights)), blobs, _p(ws), c_size(ws.numel()), _stream()),
               "mcr_scone_occ_forward")
     return out
+
+
+# ---- glue (SURVEY §8f) -----------------------------------------------------------------------------------
+def view_state(pts, X_view, n_elev, n_azim):
+    """[n_clouds, seq_len, n_elev*n_azim] fp32 0/1; replaces compute_view_state (scone_utils.py:799-860)."""
+    pts, X_view = _req(pts, "pts"), _req(X_view, "X_view")
+    B, Q, d = pts.shape
+    V = X_view.shape[0]
+    out = torch.empty((B, Q, n_elev * n_azim), dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        check(lib().mcr_view_state(_p(pts), c_int(d), _p(X_view), _p(out), c_i64(B * Q), c_int(V), c_int(n_elev),
+                                   c_int(n_azim), _stream()), "mcr_view_state")
+    return out
+
+
+def sample_proxy(X, preds, view_harmonics, u, min_occ):
+    """(res [n_u,4], res_harmonics [n_u,64], inverse [n_sample] int64, unique original indices [n_u] int64);
+    replaces sample_proxy_points (scone_utils.py:1030-1061).  One host sync to read n_u (torch.unique syncs too)."""
+    X, preds, vh, u = _req(X, "X"), _req(preds, "preds"), _req(view_harmonics, "view_harmonics"), _req(u, "samples")
+    P = X.shape[0]
+    n = u.numel()
+    dev = X.device
+    res = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    resh = torch.empty((n, 64), dtype=torch.float32, device=dev)
+    uniq = torch.empty(n, dtype=torch.int64, device=dev)
+    inv = torch.empty(n, dtype=torch.int64, device=dev)
+    nu = torch.zeros(1, dtype=torch.int32, device=dev)
+    L_ = lib()
+    ws = _workspace(dev, L_.mcr_sample_proxy_workspace_bytes(c_i64(P), c_int(n)))
+    with torch.cuda.device(dev):
+        check(L_.mcr_sample_proxy(_p(X), _p(preds), c_i64(1), _p(vh), c_i64(P), c_f32(float(min_occ)), _p(u), c_int(n),
+                                  _p(res), _p(resh), _p(uniq), _p(inv), _p(nu), _p(ws), c_size(ws.numel()), _stream()),
+              "mcr_sample_proxy")
+    k = int(nu.item())
+    return res[:k], resh[:k], inv, uniq[:k]
+
+
+def points_in_fov(pts, cameras):
+    """pts [P,3], cameras [n_cam,40] (layout in include/macarons_hip.h) -> bool mask [n_cam,P];
+    replaces Camera.get_points_in_fov (macarons_utils.py:2400-2435)."""
+    pts, cameras = _req(pts, "pts"), _req(cameras, "cameras")
+    P, C = pts.shape[0], cameras.shape[0]
+    if cameras.shape[1] != 40 or pts.shape[1] != 3:
+        raise ValueError("cameras must be [n_cam,40] and pts [P,3]")
+    mask = torch.empty((C, P), dtype=torch.uint8, device=pts.device)
+    with torch.cuda.device(pts.device):
+        check(lib().mcr_points_in_fov(_p(pts), c_i64(P), _p(cameras), c_int(C), _p(mask), _stream()), "mcr_points_in_fov")
+    return mask.bool()
+
+
+def coverage_gain_multiple(pts, harmonics, cams, n_cam, use_sigmoid=True):
+    """(gains [B, C^n], idx [C^n, n]); replaces SconeVis.compute_coverage_gain_multiple (SconeVis.py:254-303)."""
+    vis = sh_visibilities(pts, harmonics, cams, use_sigmoid)
+    B, C, N = vis.shape
+    out = torch.empty((B, C ** n_cam), dtype=torch.float32, device=vis.device)
+    with torch.cuda.device(vis.device):
+        check(lib().mcr_coverage_gain_multiple(_p(vis), _p(out), c_i64(B), c_i64(C), c_i64(N), c_int(n_cam), _stream()),
+              "mcr_coverage_gain_multiple")
+    single = torch.arange(0, C)
+    n_idx = torch.cartesian_prod(*([single] * n_cam))                  # SconeVis.py:292-296 (index table, host)
+    return out, n_idx

@@ -1,0 +1,107 @@
+"""Mirror of the hot-path helpers of macarons/utility/scone_utils.py — same names, arguments and tensor layouts —
+backed by the MI355X kernels (include/macarons_hip.h).  Reference lines:
+  get_all_harmonics_under_degree :714   get_cameras_on_sphere :741   normalize_points_in_prediction_box :788
+  compute_view_state :799   compute_view_harmonics :934   compute_occupancy_probability :965
+  sample_proxy_points :1030
+(filter_proxy_points :1001 needs PyTorch3D camera objects; filter_proxy_points_from_matrices takes the
+projection matrices instead — camera objects stay outside the kernels)
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from .CustomGeometry import get_cartesian_coords
+from .spherical_harmonics import get_spherical_harmonics
+
+
+def get_all_harmonics_under_degree(degree, n_elev, n_azim, device):
+    """-> (z [degree^2, n_elev*n_azim], h_polar, h_azim); elevation-major grid (scone_utils.py:714-738)."""
+    h_elev = torch.Tensor([-np.pi / 2 + (i + 1) / (n_elev + 1) * np.pi for i in range(n_elev) for j in range(n_azim)]).to(device)
+    h_polar = -h_elev + np.pi / 2
+    h_azim = torch.Tensor([2 * np.pi * j / n_azim for i in range(n_elev) for j in range(n_azim)]).to(device)
+    z = torch.cat([get_spherical_harmonics(l, h_polar, h_azim) for l in range(degree)], dim=-1)
+    return z.transpose(dim0=0, dim1=1).contiguous(), h_polar, h_azim
+
+
+def get_cameras_on_sphere(params=None, device="cpu", pole_cameras=False, n_elev=None, n_azim=None, camera_dist=None):
+    """(X_cam [n,3], dist, elev, azim) on the reference's lattice (scone_utils.py:741-785)."""
+    if n_elev is None or n_azim is None:
+        n_elev, n_azim, n_camera = params.n_camera_elev, params.n_camera_azim, params.n_camera
+    else:
+        n_camera = n_elev * n_azim + (2 if pole_cameras else 0)
+    if camera_dist is None:
+        camera_dist = params.camera_dist
+    candidate_dist = torch.Tensor([camera_dist for _ in range(n_camera)]).to(device)
+    candidate_elev = [-90. + (i + 1) / (n_elev + 1) * 180. for i in range(n_elev) for j in range(n_azim)]
+    candidate_azim = [360. * j / n_azim for i in range(n_elev) for j in range(n_azim)]
+    if pole_cameras:
+        candidate_elev = [-89.9] + candidate_elev + [89.9]
+        candidate_azim = [0.] + candidate_azim + [0.]
+    candidate_elev = torch.Tensor(candidate_elev).to(device)
+    candidate_azim = torch.Tensor(candidate_azim).to(device)
+    X_cam = get_cartesian_coords(r=candidate_dist.view(-1, 1), elev=candidate_elev.view(-1, 1),
+                                 azim=candidate_azim.view(-1, 1), in_degrees=True)
+    return X_cam, candidate_dist, candidate_elev, candidate_azim
+
+
+def normalize_points_in_prediction_box(points, prediction_box_center, prediction_box_diag):
+    return (points - prediction_box_center) / prediction_box_diag
+
+
+def compute_view_state(pts, X_view, n_elev, n_azim):
+    """pts [n_cloud, seq_len, >=3], X_view [n_view, 3] -> [n_cloud, seq_len, n_elev*n_azim]  (scone_utils.py:799-860)."""
+    return ops.view_state(pts, X_view, n_elev, n_azim)
+
+
+_vh_cache = {}
+
+
+def _view_harmonics_matrix(base_harmonics, h_polar, n_elev, n_azim):
+    key = (base_harmonics.data_ptr(), base_harmonics._version, h_polar.data_ptr(), n_elev, n_azim)
+    m = _vh_cache.get(key)
+    if m is None:
+        polar_step, azim_step = np.pi / (n_elev + 1), 2 * np.pi / n_azim
+        # the constant factor of scone_utils.py:958, in the reference's multiplication order
+        m = (base_harmonics * torch.sin(h_polar).view(1, -1) * polar_step * azim_step).float().contiguous()
+        _vh_cache.clear()
+        _vh_cache[key] = m
+    return m
+
+
+def compute_view_harmonics(view_state, base_harmonics, h_polar, h_azim, n_elev, n_azim):
+    """[n_cloud, seq_len, n_elev*n_azim] -> [n_cloud, seq_len, n_harmonics]  (scone_utils.py:934-960): one
+    [.,98] x [98,64] product instead of the reference's [., 64, 98] broadcast."""
+    return ops.linear(view_state, _view_harmonics_matrix(base_harmonics, h_polar, n_elev, n_azim))
+
+
+def compute_occupancy_probability(scone_occ, pc, X, view_harmonics, mask=None, max_points_per_pass=20000):
+    """Chunked occupancy inference with the reference's chunk boundaries (scone_utils.py:965-998), so the hidden
+    randperm draws of SconeOcc.forward happen once per chunk exactly like upstream."""
+    n_clouds = pc.shape[0]
+    n_sample = X.shape[1]
+    p = max_points_per_pass // n_clouds
+    q, r = n_sample // p, n_sample % p
+    n_loop = q + (1 if r != 0 else 0)
+    preds = []
+    for i in range(n_loop):
+        low, up = i * p, (i + 1) * p
+        if i == q:
+            up = q * p + r
+        preds.append(scone_occ(pc, X[:, low:up].contiguous(), view_harmonics[:, low:up].contiguous(), verbose=False)
+                     .view(n_clouds, up - low, -1))
+    return preds[0] if len(preds) == 1 else torch.cat(preds, dim=1)
+
+
+def sample_proxy_points(X_world, preds, view_harmonics, n_sample, min_occ, use_occ_to_sample=True, return_index=False,
+                        samples=None):
+    """scone_utils.py:1030-1076.  `samples` (optional, [n_sample]) pins the uniforms; otherwise they are drawn with
+    torch.rand(n_sample, 1, device=...) like the reference (:1052)."""
+    if not use_occ_to_sample:
+        mask = preds[..., 0] > min_occ
+        res_X, res_preds, res_h = X_world[mask][:n_sample], preds[mask][:n_sample], view_harmonics[mask][:n_sample]
+        res = torch.cat((res_X, res_preds), dim=-1)
+        return (res, res_h, None) if return_index else (res, res_h)
+    if samples is None:
+        samples = torch.rand(n_sample, 1, device=X_world.device)
+    res, res_h, inverse_idx, _ = ops.sample_proxy(X_world, preds.reshape(-1), view_harmonics, samples.reshape(-1), min_occ)
+    return (res, res_h, inverse_idx) if return_index else (res, res_h)

@@ -226,7 +226,46 @@ def gen_occ():
     save("scone_occ", **out)
 
 
-GROUPS = {"scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
+def gen_view():
+    """G4: get_all_harmonics_under_degree(8,7,14), compute_view_state, compute_view_harmonics;
+    G7: sample_proxy_points with the uniforms captured."""
+    import importlib
+    su = importlib.import_module("macarons.utility.scone_utils")
+    base, h_polar, h_azim = su.get_all_harmonics_under_degree(8, 7, 14, "cpu")
+    rng = np.random.default_rng(61)
+    Q = 1000
+    pts = rng.uniform(-0.5, 0.5, (2, Q, 3)).astype(np.float32)
+    pts[0, :4] = [[0, 0, 0], [0.1, 0, 0.1], [0, 0.2, 0], [-0.3, 0.1, 0]]
+    X_view = cameras_on_sphere(4, 5)[[0, 3, 7, 12, 19]].astype(np.float32)
+    X_view = np.concatenate([X_view, [[0, 1.5, 0], [0, 0, -1.5], [1.5, 0, 0]]]).astype(np.float32)   # axis-aligned views
+    vs = su.compute_view_state(t(pts), t(X_view), 7, 14)
+    vh = su.compute_view_harmonics(vs, base, h_polar, h_azim, 7, 14)
+    out = dict(base=base.numpy(), h_polar=h_polar.numpy(), h_azim=h_azim.numpy(), pts=pts, X_view=X_view,
+               view_state=np.packbits(vs.numpy().astype(np.uint8), axis=-1), view_harmonics=vh.numpy())
+    # sampler
+    P = 4000
+    Xw = rng.uniform(-0.5, 0.5, (P, 3)).astype(np.float32)
+    preds = rng.uniform(-0.1, 1.0, (P, 1)).astype(np.float32)
+    vhp = (rng.standard_normal((P, 64)) * 0.3).astype(np.float32)
+    drawn = []
+    real = torch.rand
+
+    def capture(*a, **kw):
+        r = real(*a, **kw)
+        drawn.append(r.numpy().copy())
+        return r
+    torch.rand = capture
+    try:
+        torch.manual_seed(77)
+        res, resh, inv = su.sample_proxy_points(t(Xw), t(preds), t(vhp), 2048, 0.1, use_occ_to_sample=True, return_index=True)
+    finally:
+        torch.rand = real
+    out.update(s_X=Xw, s_preds=preds, s_vh=vhp, s_u=drawn[0].reshape(-1), s_res=res.numpy(), s_resh=resh.numpy(),
+               s_inv=inv.numpy().astype(np.int32))
+    save("view_sampler", **out)
+
+
+GROUPS = {"view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

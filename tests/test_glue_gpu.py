@@ -1,0 +1,117 @@
+"""Parity of the glue kernels (view state, view harmonics, proxy sampling, frustum mask, n-camera gains)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_err
+from oracle import view_state as V, scorer
+
+pytestmark = pytest.mark.gpu
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def test_view_state_and_harmonics_golden(dev):
+    from macarons_amd.utility import scone_utils as su
+    g = golden("view_sampler")
+    base, h_polar, h_azim = su.get_all_harmonics_under_degree(8, 7, 14, dev)
+    assert np.abs(base.cpu().numpy() - g["base"]).max() < 1e-6
+    assert np.array_equal(h_polar.cpu().numpy(), g["h_polar"]) and np.array_equal(h_azim.cpu().numpy(), g["h_azim"])
+    vs = su.compute_view_state(T(g["pts"], dev), T(g["X_view"], dev), 7, 14).cpu().numpy()
+    ref = np.unpackbits(g["view_state"], axis=-1)[..., :98].astype(np.float32)
+    bad = np.argwhere((vs != ref).any(-1))
+    margin = V.bin_boundary_margin(g["pts"], g["X_view"], 7, 14)
+    # bit-exact except for rays within 2e-6 rad of a binning boundary (asin/acos differ by an ulp between libms)
+    for b in bad:
+        assert margin[tuple(b)].min() < 2e-6
+    assert len(bad) <= 2
+    vh = su.compute_view_harmonics(T(ref, dev), T(g["base"], dev), T(g["h_polar"], dev), T(g["h_azim"], dev), 7, 14)
+    assert rel_err(vh.cpu().numpy(), g["view_harmonics"]) < 1e-5
+
+
+def test_view_state_vs_oracle_large(dev):
+    from macarons_amd import ops
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(-.5, .5, (1, 100_000, 3)).astype(np.float32)
+    Xv = rng.standard_normal((9, 3)).astype(np.float32)
+    Xv = (1.5 * Xv / np.linalg.norm(Xv, axis=1, keepdims=True)).astype(np.float32)
+    vs = ops.view_state(T(pts, dev), T(Xv, dev), 7, 14).cpu().numpy()
+    ref = V.compute_view_state(pts, Xv, 7, 14)
+    bad = np.argwhere((vs != ref).any(-1))
+    margin = V.bin_boundary_margin(pts, Xv, 7, 14)
+    assert len(bad) < 20
+    for b in bad:
+        assert margin[tuple(b)].min() < 2e-6
+    assert np.all((vs == 0) | (vs == 1)) and np.all(vs.sum(-1) >= 1) and np.all(vs.sum(-1) <= 9)
+
+
+def test_sampler_golden_and_properties(dev):
+    from macarons_amd.utility import scone_utils as su
+    g = golden("view_sampler")
+    res, resh, inv = su.sample_proxy_points(T(g["s_X"], dev), T(g["s_preds"], dev), T(g["s_vh"], dev), 2048, 0.1,
+                                            return_index=True, samples=T(g["s_u"], dev))
+    res, resh, inv = res.cpu().numpy(), resh.cpu().numpy(), inv.cpu().numpy()
+    assert res.shape == g["s_res"].shape and np.array_equal(res, g["s_res"])      # identical to the reference run
+    assert np.array_equal(resh, g["s_resh"]) and np.array_equal(inv, g["s_inv"])
+    # vs the oracle's exact-CDF convention on other data, incl. everything below / above the threshold
+    rng = np.random.default_rng(8)
+    for P, n in ((257, 64), (100_000, 2048), (5, 4096)):
+        X = rng.uniform(-.5, .5, (P, 3)).astype(np.float32)
+        preds = rng.uniform(0.0, 1.0, (P, 1)).astype(np.float32)
+        vh = rng.standard_normal((P, 64)).astype(np.float32)
+        u = rng.uniform(0, 1, n).astype(np.float32)
+        u[:3] = [0.0, 0.99999994, 0.5]
+        r, h, i = su.sample_proxy_points(T(X, dev), T(preds, dev), T(vh, dev), n, 0.1, return_index=True, samples=T(u, dev))
+        ro, ho, io, _ = V.sample_proxy_points(X, preds, vh, u, 0.1, exact=True)
+        assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(h.cpu().numpy(), ho) and np.array_equal(i.cpu().numpy(), io)
+        assert np.all(r.cpu().numpy()[:, 3] > 0.1)
+
+
+def test_points_in_fov(dev):
+    from macarons_amd import ops
+    rng = np.random.default_rng(3)
+    P, C = 100_003, 5
+    pts = rng.uniform(-30, 30, (P, 3)).astype(np.float32)
+    cams = np.zeros((C, 40), np.float32)
+    for c in range(C):
+        R = np.linalg.qr(rng.standard_normal((3, 3)))[0].astype(np.float32)
+        Tt = rng.uniform(-5, 5, 3).astype(np.float32)
+        Mv = np.eye(4, dtype=np.float32); Mv[:3, :3] = R; Mv[3, :3] = Tt
+        f = 1.0 / np.tan(np.deg2rad(60) / 2)
+        zn, zf = 1.0, 100.0
+        K = np.array([[f, 0, 0, 0], [0, f, 0, 0], [0, 0, zf / (zf - zn), 1], [0, 0, -zf * zn / (zf - zn), 0]], np.float32)
+        cams[c, :16] = Mv.reshape(-1)
+        cams[c, 16:32] = (Mv @ K).astype(np.float32).reshape(-1)
+        cams[c, 32:36] = [456 / 256 - 2 * 455 / 255, 456 / 256, -1.0, 1.0]          # macarons_utils.py:1929-1938
+        cams[c, 36:39] = (-Tt @ R.T)
+        cams[c, 39] = 0.0 if c == 0 else 40.0
+    mask = ops.points_in_fov(T(pts, dev), T(cams, dev)).cpu().numpy()
+    F = np.float32
+    for c in range(C):
+        Mv, Mp = cams[c, :16].reshape(4, 4), cams[c, 16:32].reshape(4, 4)
+        x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+        lin = lambda M, j: ((x * M[0, j] + y * M[1, j]) + z * M[2, j]) + M[3, j]
+        zv, px, py, pw = lin(Mv, 2), lin(Mp, 0), lin(Mp, 1), lin(Mp, 3)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            nx, ny = px / pw, py / pw
+        m = (nx >= cams[c, 32]) & (nx <= cams[c, 33]) & (ny >= cams[c, 34]) & (ny <= cams[c, 35]) & (zv > 0)
+        if cams[c, 39] > 0:
+            d = pts - cams[c, 36:39]
+            m &= np.sqrt(((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).astype(F)) < cams[c, 39]
+        assert np.array_equal(mask[c], m)                                           # bit-exact mask
+        assert 0 < m.sum() < P
+
+
+def test_coverage_gain_multiple(dev):
+    from macarons_amd.networks import SconeVis
+    d = golden("scorer_b2_n500_c7")
+    m = SconeVis().to(dev)
+    g2, i2 = m.compute_coverage_gain_multiple(T(d["pts"], dev), T(d["harmonics"], dev), T(d["cams"], dev), 2)
+    assert np.array_equal(i2.numpy(), d["multi2_idx"]) and rel_err(g2.cpu().numpy(), d["multi2"]) < 1e-4
+    g3, i3 = m.compute_coverage_gain_multiple(T(d["pts"][:, :128], dev), T(d["harmonics"][:, :128], dev),
+                                              T(d["cams"][:, :4], dev), 3)
+    assert np.array_equal(i3.numpy(), d["multi3_idx"]) and rel_err(g3.cpu().numpy(), d["multi3"]) < 1e-4
+    with pytest.raises(NameError):
+        m.compute_coverage_gain_multiple(T(d["pts"], dev), T(d["harmonics"], dev), T(d["cams"], dev), 4)

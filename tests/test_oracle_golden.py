@@ -174,3 +174,17 @@ def test_occ_perm_draw_order_matches_reference():
         perms = o.draw_perms(M)
         for i in range(3):
             assert np.array_equal(perms[i].numpy(), g[f"{tag}_perm{i}"])
+
+
+def test_view_state_and_sampler_oracle_match_reference():
+    from oracle import view_state as V
+    g = golden("view_sampler")
+    base, hp, ha = V.all_harmonics_under_degree(8, 7, 14)
+    assert np.abs(base - g["base"]).max() < 1e-6 and np.array_equal(hp, g["h_polar"]) and np.array_equal(ha, g["h_azim"])
+    ref = np.unpackbits(g["view_state"], axis=-1)[..., :98].astype(np.float32)
+    vs = V.compute_view_state(g["pts"], g["X_view"], 7, 14)
+    assert (vs != ref).sum() <= 4                                      # bit-exact up to libm ulps at bin boundaries
+    vh = V.compute_view_harmonics(ref, g["base"], g["h_polar"], g["h_azim"], 7, 14)
+    assert rel_err(vh, g["view_harmonics"]) < 1e-6
+    res, resh, inv, _ = V.sample_proxy_points(g["s_X"], g["s_preds"], g["s_vh"], g["s_u"], 0.1, exact=True)
+    assert np.array_equal(res, g["s_res"]) and np.array_equal(resh, g["s_resh"]) and np.array_equal(inv, g["s_inv"])
