@@ -113,3 +113,23 @@ def sample_proxy_points(X_world, preds, view_harmonics, samples, min_occ, exact=
     uniq, inverse = np.unique(res_idx, return_inverse=True)
     res = np.concatenate((res_X[uniq], res_preds[uniq]), axis=-1)
     return res, res_h[uniq], inverse.astype(np.int64), orig[uniq]
+
+
+def sampler_tie_aware_match(res_a, inv_a, res_b, inv_b, X_world, preds, min_occ, max_mismatch=4):
+    """Two sampling results agree if, sample by sample, they picked the same point, except for at most a few
+    samples whose uniform falls within rounding distance of a CDF step (fp32 sequential cumsum of the reference
+    vs the exact CDF): those must have picked ADJACENT kept points."""
+    pa, pb = np.asarray(res_a)[np.asarray(inv_a)], np.asarray(res_b)[np.asarray(inv_b)]      # per-sample (x,y,z,occ)
+    if pa.shape != pb.shape:
+        return False
+    diff = np.nonzero((pa != pb).any(axis=1))[0]
+    if len(diff) > max_mismatch:
+        return False
+    kept = np.nonzero(np.asarray(preds)[..., 0] > np.float32(min_occ))[0]
+    Xk = np.asarray(X_world, np.float32)[kept]
+    for s in diff:
+        ia = np.nonzero((Xk == pa[s, :3]).all(axis=1))[0]
+        ib = np.nonzero((Xk == pb[s, :3]).all(axis=1))[0]
+        if len(ia) == 0 or len(ib) == 0 or abs(int(ia[0]) - int(ib[0])) != 1:
+            return False
+    return True
