@@ -41,3 +41,17 @@ def allgather_argmax(best_vals, best_global_idx, group=None):
     cand = torch.where(vals == vmax[None], idx, torch.full_like(idx, float("inf")))
     best_idx = cand.min(dim=0).values
     return vmax, best_idx.to(torch.int64)
+
+
+def allgather_rows(local, n_total, group=None):
+    """Concatenate the ranks' row blocks (block-partitioned with shard_range) into the full [n_total, ...] tensor.
+    Shards may differ by one row, so every rank pads to the largest shard for one all_gather_into_tensor."""
+    world = dist.get_world_size(group)
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    m = max(b - a for a, b in sizes)
+    tail = local.shape[1:]
+    send = local.new_zeros((m,) + tuple(tail))
+    send[:local.shape[0]] = local
+    recv = local.new_empty((world * m,) + tuple(tail))
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return torch.cat([recv[r * m: r * m + (b - a)] for r, (a, b) in enumerate(sizes)], dim=0)

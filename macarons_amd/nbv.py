@@ -1,0 +1,76 @@
+"""One SCONE next-best-view decision on the MI355X: the sequence macarons/testers/shapenet.py:126-172 runs per
+step, as one host routine over the HIP kernels, optionally sharded over the GPUs of a node.
+
+    view state + view harmonics (Q proxy points)  ->  SconeOcc (Q queries vs M surface points)
+    -> occupancy-weighted sampling of seq_len proxy points -> SconeVis -> SH coverage gains over C cameras -> argmax
+
+Multi-GPU: the occupancy pass shards the Q queries across ranks (the surface cloud is replicated) and
+all-gathers the occupancies; sampling and SconeVis (cheap, N <= 2048) run redundantly with identical draws; the
+C candidate cameras are block-partitioned and the only other exchange is the all-gather of each rank's
+(best gain, global camera index).
+"""
+import torch
+
+from . import dist as mdist
+from .utility import scone_utils as su
+
+
+class ViewStateGrid:
+    """The constant tables of the view-state lattice (get_all_harmonics_under_degree, scone_utils.py:714-738)."""
+
+    def __init__(self, device, degree=8, n_elev=7, n_azim=14):
+        self.n_elev, self.n_azim = n_elev, n_azim
+        self.base_harmonics, self.h_polar, self.h_azim = su.get_all_harmonics_under_degree(degree, n_elev, n_azim, device)
+
+
+def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1,
+             max_points_per_pass=300000, true_monte_carlo_sampling=True, occ_perms=None, samples=None, group=None):
+    """pc [1,M,3] surface points, X [1,Q,3] proxy points, X_view [n_view,3] past camera positions, X_cam [C,3]
+    candidate cameras (all in the normalised prediction-view space, as the reference feeds its networks).
+    Returns dict(gains [C_local or C], nbv_idx (global camera index, int), max_gain, occ [Q,1], n_unique).
+    `occ_perms` / `samples` pin the hidden RNG draws (SconeOcc randperms; sampling uniforms)."""
+    world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+    rank = torch.distributed.get_rank(group) if world > 1 else 0
+    dev = X.device
+    Q = X.shape[1]
+    with torch.no_grad():
+        # ---- view state -> harmonics for this rank's slice of the queries (testers/shapenet.py:126-130) ----
+        q0, q1 = mdist.shard_range(Q, rank, world)
+        Xl = X[:, q0:q1].contiguous()
+        view_state = su.compute_view_state(Xl, X_view, grid.n_elev, grid.n_azim)
+        vh_l = su.compute_view_harmonics(view_state, grid.base_harmonics, grid.h_polar, grid.h_azim, grid.n_elev, grid.n_azim)
+        # ---- occupancy (:139-144) ----
+        if occ_perms is not None:
+            occ_l = scone_occ(pc, Xl, vh_l, perms=occ_perms).view(-1, 1)
+        else:
+            occ_l = su.compute_occupancy_probability(scone_occ, pc, Xl, vh_l, max_points_per_pass=max_points_per_pass).view(-1, 1)
+        if world > 1:
+            occ = mdist.allgather_rows(occ_l, Q, group)
+            vh = mdist.allgather_rows(vh_l[0], Q, group)
+        else:
+            occ, vh = occ_l, vh_l[0]
+        # ---- occupancy-weighted Monte-Carlo sampling (:146-154); identical on every rank ----
+        if samples is None:
+            samples = torch.rand(seq_len, 1, device=dev)
+            if world > 1:
+                torch.distributed.broadcast(samples, 0, group=group)
+        proxy_points, vh_s, sample_idx = su.sample_proxy_points(X[0], occ, vh, n_sample=seq_len, min_occ=min_occ,
+                                                                return_index=True, samples=samples)
+        n_unique = proxy_points.shape[0]
+        # ---- visibility-gain harmonics (:157-160) ----
+        harm = scone_vis(proxy_points[None], view_harmonics=vh_s[None])
+        if true_monte_carlo_sampling:
+            proxy_points, harm = proxy_points[sample_idx][None].contiguous(), harm[0][sample_idx][None].contiguous()
+        else:
+            proxy_points = proxy_points[None]
+        # ---- coverage gains over this rank's camera shard + arg-max (:167-172) ----
+        C = X_cam.shape[0]
+        c0, c1 = mdist.shard_range(C, rank, world)
+        gains = scone_vis.compute_coverage_gain(proxy_points, harm, X_cam[c0:c1].contiguous().view(1, -1, 3))
+        best = torch.max(gains, dim=1)
+        if world > 1:
+            max_gain, nbv_idx = mdist.allgather_argmax(best.values, best.indices + c0, group)
+        else:
+            max_gain, nbv_idx = best.values, best.indices
+    return {"gains": gains[0], "cam_range": (c0, c1), "nbv_idx": nbv_idx, "max_gain": max_gain, "occ": occ,
+            "n_unique": n_unique}

@@ -265,7 +265,57 @@ def gen_view():
     save("view_sampler", **out)
 
 
-GROUPS = {"view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
+def gen_e2e():
+    """G9: config-1 end-to-end NBV decision through the reference's own functions (testers/shapenet.py:126-172):
+    chair-like shell cloud of 1024 points, 2048 proxy points, 1 past view, 20 candidate cameras.  Weights: seeds 2/1
+    with occupancy linear3.bias shifted by +0.5 so untrained occupancies pass min_occ (SURVEY §8c gotcha)."""
+    import importlib
+    import weights
+    su = importlib.import_module("macarons.utility.scone_utils")
+    occ = _load(ref["SconeOcc"].SconeOcc(), 2)
+    vis = _load(ref["SconeVis"].SconeVis(), 1)
+    with torch.no_grad():
+        occ.linear3.bias += 0.5
+    rng = np.random.default_rng(71)
+    pc = shell_cloud(rng, 1024)[None]
+    X = rng.uniform(-0.5, 0.5, (1, 2048, 3)).astype(np.float32)
+    X_cam = cameras_on_sphere(4, 5).astype(np.float32)
+    X_view = X_cam[[6]]
+    base, h_polar, h_azim = su.get_all_harmonics_under_degree(8, 7, 14, "cpu")
+    perms, drawn = [], []
+    real_perm, real_rand = torch.randperm, torch.rand
+
+    def cap_perm(n, *a, **kw):
+        p = real_perm(n, *a, **kw); perms.append(p.numpy().copy()); return p
+
+    def cap_rand(*a, **kw):
+        r = real_rand(*a, **kw); drawn.append(r.numpy().copy()); return r
+    torch.randperm, torch.rand = cap_perm, cap_rand
+    try:
+        torch.manual_seed(123)
+        with torch.no_grad():
+            vs = su.compute_view_state(t(X), t(X_view), 7, 14)
+            vh = su.compute_view_harmonics(vs, base, h_polar, h_azim, 7, 14)
+            occ_prob = su.compute_occupancy_probability(occ, t(pc), t(X), vh, max_points_per_pass=300000).view(-1, 1)
+            proxy, vh_s, sample_idx = su.sample_proxy_points(t(X)[0], occ_prob, vh.squeeze(0), n_sample=2048, min_occ=0.1,
+                                                             use_occ_to_sample=True, return_index=True)
+            harm = vis(proxy[None], view_harmonics=vh_s[None])
+            proxy_mc = proxy[sample_idx][None]
+            harm_mc = harm[0][sample_idx][None]
+            gains = vis.compute_coverage_gain(proxy_mc, harm_mc, t(X_cam).view(1, -1, 3)).view(-1)
+            max_gain, max_idx = torch.max(gains, dim=0)
+    finally:
+        torch.randperm, torch.rand = real_perm, real_rand
+    M = 1024
+    ds = int(np.power(M / (16 * 8), 1. / 2)) or 2
+    cut = [perms[0][:2048], perms[1][:M // ds], perms[2][:(M // ds) // ds]]
+    save("e2e_config1", pc=pc, X=X, X_view=X_view, X_cam=X_cam, occ=occ_prob.numpy(), n_unique=np.int64(proxy.shape[0]),
+         gains=gains.numpy(), nbv_idx=np.int64(max_idx.item()), samples=drawn[0].reshape(-1), seed=np.int64(123),
+         perm0=cut[0].astype(np.int32), perm1=cut[1].astype(np.int32), perm2=cut[2].astype(np.int32),
+         occ_bias_shift=np.float32(0.5))
+
+
+GROUPS = {"e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

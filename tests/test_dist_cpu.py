@@ -1,0 +1,66 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU exchange logic: shard ranges, the all-gather of per-rank
+(best gain, camera index) records and the all-gather of occupancy rows."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from macarons_amd import dist as mdist
+    try:
+        # camera shards: every rank scores its block of a known gain vector
+        gains_all = torch.tensor([[0.2, 0.9, 0.1, 0.9, 0.3, 0.05, 0.7], [0.5, 0.1, 0.1, 0.2, 0.8, 0.8, 0.0]])   # [B=2, C=7]
+        c0, c1 = mdist.shard_range(7, rank, world)
+        local = gains_all[:, c0:c1]
+        best = torch.max(local, dim=1)
+        v, i = mdist.allgather_argmax(best.values, best.indices + c0)
+        ref = torch.max(gains_all, dim=1)                    # first occurrence wins ties, like the reference
+        ok1 = torch.equal(v, ref.values) and torch.equal(i, ref.indices)
+        # occupancy rows: uneven shards
+        full = torch.arange(11 * 3, dtype=torch.float32).view(11, 3)
+        q0, q1 = mdist.shard_range(11, rank, world)
+        got = mdist.allgather_rows(full[q0:q1].clone(), 11)
+        ok2 = torch.equal(got, full)
+        q.put((rank, bool(ok1), bool(ok2), (c0, c1), (q0, q1)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partition():
+    from macarons_amd.dist import shard_range
+    for n in (1, 7, 8, 200, 512, 100_000):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(120)
+def test_allgather_argmax_and_rows_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90) for _ in range(2)]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] and r[2] for r in res), res

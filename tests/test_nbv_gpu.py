@@ -1,0 +1,80 @@
+"""End-to-end NBV decision (config 1 of BASELINE.json: 2048 proxy points, 20 candidate cameras) on the HIP path
+vs (a) the golden produced by the reference's own functions and (b) the numpy oracle with identical conventions."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_err
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import weights  # noqa: E402
+from oracle import nbv as onbv  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def _models(dev):
+    from macarons_amd.networks import SconeVis, SconeOcc
+    occ, vis = SconeOcc(), SconeVis()
+    sdo = weights.make_state_dict(weights.shapes_of(occ), 2)
+    sdv = weights.make_state_dict(weights.shapes_of(vis), 1)
+    sdo["linear3.bias"] = sdo["linear3.bias"] + np.float32(0.5)        # untrained occupancies must pass min_occ
+    occ.load_state_dict({k: torch.from_numpy(v) for k, v in sdo.items()})
+    vis.load_state_dict({k: torch.from_numpy(v) for k, v in sdv.items()})
+    return occ.to(dev).eval(), vis.to(dev).eval(), sdo, sdv
+
+
+def test_config1_end_to_end(dev):
+    from macarons_amd.nbv import nbv_step, ViewStateGrid
+    g = golden("e2e_config1")
+    occ, vis, sdo, sdv = _models(dev)
+    grid = ViewStateGrid(dev)
+    perms = [torch.from_numpy(g[f"perm{i}"].astype(np.int64)) for i in range(3)]
+    r = nbv_step(occ, vis, T(g["pc"], dev), T(g["X"], dev), T(g["X_view"], dev), T(g["X_cam"], dev), grid,
+                 occ_perms=perms, samples=T(g["samples"], dev))
+    o = r["occ"].cpu().numpy()
+    # (a) vs the reference: occupancies within 1e-4 except queries whose 16th neighbour is a near-tie for
+    # torch.cdist's |x|^2+|y|^2-2xy distances -- at most a handful
+    d = np.abs(o - g["occ"]).reshape(-1)
+    assert (d > 1e-4 * np.abs(g["occ"]).max()).sum() <= 3
+    assert int(r["nbv_idx"]) == int(g["nbv_idx"])
+    assert rel_err(r["gains"].cpu().numpy(), g["gains"]) < 2e-2          # sampling set shifts with those few points
+    # (b) vs the oracle with the same conventions: everything tight
+    ref = onbv.nbv_step(sdo, sdv, g["pc"], g["X"], g["X_view"], g["X_cam"], [g["perm0"], g["perm1"], g["perm2"]], g["samples"])
+    assert rel_err(o, ref["occ"]) < 1e-4
+    assert r["n_unique"] == ref["n_unique"]
+    assert rel_err(r["gains"].cpu().numpy(), ref["gains"]) < 1e-4
+    assert int(r["nbv_idx"]) == ref["nbv_idx"]
+    # hidden-RNG path: seeding torch like the reference run reproduces its draws (randperms on CPU, rand on device
+    # differs from the CPU stream, so pin only the uniforms)
+    torch.manual_seed(int(g["seed"]))
+    r2 = nbv_step(occ, vis, T(g["pc"], dev), T(g["X"], dev), T(g["X_view"], dev), T(g["X_cam"], dev), grid,
+                  samples=T(g["samples"], dev))
+    assert np.array_equal(r2["occ"].cpu().numpy(), o) and int(r2["nbv_idx"]) == int(r["nbv_idx"])
+
+
+def test_headline_step_runs_and_is_consistent(dev):
+    """BASELINE headline size: Q = 100k proxy points, M = 10240 surface points, C = 200 cameras."""
+    from macarons_amd.nbv import nbv_step, ViewStateGrid
+    occ, vis, _, _ = _models(dev)
+    gen = torch.Generator().manual_seed(0)
+    pc = (torch.rand(1, 10240, 3, generator=gen) - 0.5).to(dev)
+    X = (torch.rand(1, 100_000, 3, generator=gen) - 0.5).to(dev)
+    cams = torch.randn(200, 3, generator=gen)
+    cams = (1.5 * cams / cams.norm(dim=1, keepdim=True)).to(dev)
+    grid = ViewStateGrid(dev)
+    torch.manual_seed(1)
+    perms = occ.draw_perms(10240)
+    u = torch.rand(2048, generator=gen).to(dev)
+    a = nbv_step(occ, vis, pc, X, cams[:3].contiguous(), cams, grid, occ_perms=perms, samples=u)
+    b = nbv_step(occ, vis, pc, X, cams[:3].contiguous(), cams, grid, occ_perms=perms, samples=u)
+    assert torch.equal(a["gains"], b["gains"]) and int(a["nbv_idx"]) == int(b["nbv_idx"])      # deterministic
+    assert a["gains"].shape == (200,) and torch.isfinite(a["gains"]).all() and torch.isfinite(a["occ"]).all()
+    assert int(a["nbv_idx"]) == int(torch.argmax(a["gains"]))
