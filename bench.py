@@ -7,14 +7,20 @@ Metric (BASELINE.json): candidate-camera coverage-gain evals/sec (100k pts, 200 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the scorer (SconeVis.compute_coverage_gain semantics) over one synthetic cloud of
+Two quantities are reported:
+  (A) `value`: scorer throughput.  A "step" = one pass of the scorer (SconeVis.compute_coverage_gain semantics) over one synthetic cloud of
 100 000 points x 200 candidate cameras per GPU, inputs already resident in HBM, followed (N>1) by the
 all-gather of each rank's (best gain, camera index).  One (cloud, camera) pair scored = one eval.
 Weak scaling: each rank owns a disjoint shard of 200 candidate cameras of the same cloud (the reference
 scores all cameras on one GPU).
 
+  (B) `nbv_step`: p50 latency of the full SCONE NBV decision (macarons_amd.nbv.nbv_step: view state + harmonics on
+      Q = 100k proxy points -> SconeOcc vs M = 10 240 surface points -> sample 2048 -> SconeVis -> gains over C = 200
+      cameras -> arg-max), device-synchronised per iteration, random-init weights; with N GPUs the queries and the
+      cameras are sharded (strong scaling of one decision).
+
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel (sh_score_kernel) algorithmic flop rate vs the fp32 vector peak
+  roofline     — dominant kernel (sh_gain_kernel) algorithmic flop rate vs the fp32 vector peak
   cpu_baseline — the plain-C port of the reference scorer (oracle/csrc) timed on the host cores
 """
 import argparse
@@ -68,6 +74,81 @@ def cpu_baseline(pts, harm, cams):
                       f"host has {os.cpu_count()} cores"}, g
 
 
+def measure_nbv_step(dev, rank, world, args):
+    """(B) p50 latency of one NBV decision at Q=100k / M=10240 / C=200 (sharded over `world` GPUs)."""
+    from macarons_amd.networks import SconeVis, SconeOcc
+    from macarons_amd.nbv import nbv_step, ViewStateGrid
+    import io, contextlib
+    torch.manual_seed(7)                                   # identical random-init weights on every rank
+    with contextlib.redirect_stdout(io.StringIO()):
+        occ, vis = SconeOcc(), SconeVis()
+    with torch.no_grad():
+        occ.linear3.bias += 0.5                            # untrained occupancies must pass min_occ (SURVEY §8c)
+    occ, vis = occ.to(dev).eval(), vis.to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    Q, M, C = 100_000, 10_240, args.cams
+    d = torch.randn(M, 3, generator=g)
+    pc = (d / d.norm(dim=1, keepdim=True) * torch.tensor([0.35, 0.25, 0.3]) + 0.002 * torch.randn(M, 3, generator=g))[None].to(dev)
+    X = (torch.rand(1, Q, 3, generator=g) - 0.5).to(dev)
+    cams = torch.randn(C, 3, generator=g)
+    cams = (1.5 * cams / cams.norm(dim=1, keepdim=True)).to(dev)
+    X_view = cams[:3].contiguous()
+    u = torch.rand(2048, generator=g).to(dev)
+    grid = ViewStateGrid(dev)
+    torch.manual_seed(11)
+    perms = occ.draw_perms(M)
+    times = []
+    for it in range(10 + args.nbv_iters):
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        r = nbv_step(occ, vis, pc, X, X_view, cams, grid, occ_perms=perms, samples=u)
+        int(r["nbv_idx"])                                  # the decision reaches the host
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tw = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tw.item())
+        if it >= 10:
+            times.append(dt)
+    p50 = float(np.median(times))
+    return {"p50_ms": p50 * 1e3, "p90_ms": float(np.percentile(times, 90)) * 1e3, "evals_per_s": C / p50, "iters": len(times),
+            "config": {"proxy_points": Q, "surface_points": M, "cams": C, "seq_len": 2048, "dtype": "f32",
+                       "parallelism": f"query+camera shard x{world}"},
+            "algorithmic_TFLOP": 26.5e6 * Q / 1e12 + 0.0037 + 0.0137, "nbv_idx": int(r["nbv_idx"]), "n_unique": r["n_unique"]}
+
+
+def measure_local_pct(dev):
+    """Roofline of the dominant kernel of the NBV step (fused local transformer, fp32 MFMA): HIP events around
+    back-to-back launches on the launch stream."""
+    from macarons_amd import ops
+    from macarons_amd.networks import SconeOcc
+    from macarons_amd.networks.packing import pack_local_pct
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        occ = SconeOcc().to(dev)
+    blob = pack_local_pct(occ.local_transformers[0])
+    S = 16384
+    offs = torch.randn(S, 16, 3, device=dev) * 0.05
+    for _ in range(3):
+        ops.local_pct_forward(offs, blob)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        ops.local_pct_forward(offs, blob)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = S * (16 * 0.49e6 + 0.164e6)                    # SURVEY Appendix B: 16 tokens x 0.49 MF + attention 0.16 MF
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "local_pct_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_FP32_TFLOPS, "traffic": None, "device_ms_per_launch": ms, "queries_per_launch": S,
+            "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) peak = 157.3 TFLOP/s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +158,8 @@ def main():
     ap.add_argument("--cams", type=int, default=200)
     ap.add_argument("--waves-per-simd", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nbv", action="store_true", help="skip the NBV-step latency measurement")
+    ap.add_argument("--nbv-iters", type=int, default=50)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,6 +214,9 @@ def main():
         wall = float(tw.item())
     dev_ms = ev0.elapsed_time(ev1)                 # HIP events on the launch stream (torch current stream)
 
+    nbv = measure_nbv_step(dev, rank, world, args) if not args.no_nbv else None
+    lp = measure_local_pct(dev) if (rank == 0 and not args.no_nbv) else None
+
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         evals_per_s = world * C * args.steps / wall
@@ -146,9 +232,13 @@ def main():
                        "points": N, "cams_per_gpu": C, "parallelism": f"camera-shard x{world}"},
             "roofline": {"bound": "valu-fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                         "kernel": "sh_score_kernel<false,true>", "device_ms_per_launch": kern_ms,
+                         "kernel": "sh_gain_kernel<true>", "device_ms_per_launch": kern_ms,
                          "hbm_algorithmic_GBs": N * BYTES_PER_POINT / (kern_ms * 1e-3) / 1e9},
         }
+        if nbv is not None:
+            res["nbv_step"] = nbv
+        if lp is not None:
+            res["roofline_nbv_dominant"] = lp
         if not args.no_cpu_baseline and world == 1:
             n_s = min(C, max(24, os.cpu_count() or 1))
             cb, g_cpu = cpu_baseline(pts, harm, cams[:, :n_s].contiguous())
