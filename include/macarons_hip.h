@@ -112,6 +112,7 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
  * following linear layer).  mcr_scone_occ_forward uses the fused kernel for scale i when local_blobs != NULL and
  * local_blobs[i] != NULL (HOST array of 3 device pointers), else the layer-by-layer path. */
 int mcr_local_pct_blob_floats(void);
+int mcr_set_local_pct_variant(int variant);   /* 1 (default): one workgroup/CU kernel; 2: experimental two-workgroups/CU kernel */
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,
                           void* stream);
 

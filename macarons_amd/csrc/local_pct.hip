@@ -54,7 +54,19 @@ constexpr int LP_VEC_EMB1 = 0, LP_VEC_EMB2 = 128, LP_VEC_ENC0 = 256, LP_VEC_ENC_
               LP_VEC_LIN0 = LP_VEC_ENC0 + 2 * LP_VEC_ENC_STRIDE, LP_VECS_TOTAL = LP_VEC_LIN0 + 128;
 constexpr int LP_BLOB_FLOATS = LP_MATS_TOTAL + LP_VECS_TOTAL;
 
-__device__ __forceinline__ float lp_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7): ~14 VALU ops instead of the ~35 of
+// the branchy libm erff; the epilogues are not overlapped with MFMA work in this kernel, so they matter.
+__device__ __forceinline__ float lp_gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float erfa = fmaf(-p * t, e, 1.0f);
+    return 0.5f * x + 0.5f * fabsf(x) * erfa;
+}
 
 // ---- block GEMM: acc[t] (+)= A[64 x K] * Wp^T for this wave's TPW output tiles -----------------------------------
 // tile id = wave*TPW + t  ->  n-tile = id >> 1, m-tile = id & 1.   A: LDS, row stride lda, K-halves per lane half.
@@ -75,32 +87,49 @@ __device__ __forceinline__ void lp_gemm(f32x16 (&acc)[TPW], const float* __restr
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         }
     }
-    constexpr int PF = G < 3 ? G : 3;              // weight groups in flight
+    // Software pipeline: A fragments (LDS) one group ahead, B fragments (L2) PF groups ahead of the MFMAs that
+    // consume them.  The scheduler otherwise sinks each ds_read next to its first use and waits lgkmcnt(0) in
+    // front of every MFMA group (measured: 28 % of the wave's life in s_waitcnt); sched_group_barrier pins the
+    // order  [next A reads][next B loads][4*TPW MFMAs]  per group.
+    constexpr int PF = G < 3 ? G : 3;
     float4 b[PF][TPW];
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
         for (int t = 0; t < TPW; ++t) b[p][t] = bp[t][p * 64];
+    float4 a_cur[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) a_cur[t] = *reinterpret_cast<const float4*>(ap[t]);
+    __builtin_amdgcn_sched_group_barrier(0x020, PF * TPW, 0);                     // prologue: PF weight groups in flight
+    __builtin_amdgcn_sched_group_barrier(0x100, TPW, 0);                          // and the first A fragments
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        float4 a[TPW], bc[TPW];
+        float4 a_nxt[TPW], bc[TPW];
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            a[t] = *reinterpret_cast<const float4*>(ap[t] + 4 * g);
-            bc[t] = b[g % PF][t];
+        for (int t = 0; t < TPW; ++t) bc[t] = b[g % PF][t];
+        if (g + 1 < G) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) a_nxt[t] = *reinterpret_cast<const float4*>(ap[t] + 4 * (g + 1));
         }
         if (g + PF < G) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t) b[g % PF][t] = bp[t][(g + PF) * 64];
         }
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, bc[t].x, acc[t], 0, 0, 0);
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].x, bc[t].x, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, bc[t].y, acc[t], 0, 0, 0);
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].y, bc[t].y, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, bc[t].z, acc[t], 0, 0, 0);
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].z, bc[t].z, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, bc[t].w, acc[t], 0, 0, 0);
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].w, bc[t].w, acc[t], 0, 0, 0);
+        if (g + 1 < G) __builtin_amdgcn_sched_group_barrier(0x100, TPW, 0);       // DS reads of group g+1
+        if (g + PF < G) __builtin_amdgcn_sched_group_barrier(0x020, TPW, 0);      // VMEM reads of group g+PF
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TPW, 0);                  // this group's MFMAs
+        if (g + 1 < G) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) a_cur[t] = a_nxt[t];
+        }
     }
 }
 
@@ -305,6 +334,5 @@ void launch_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld_
                        (long long)S, blob);
 }
 
-int local_pct_blob_floats() { return LP_BLOB_FLOATS; }
 
 }  // namespace mcr

@@ -148,12 +148,23 @@ int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t
 
 int mcr_local_pct_blob_floats(void) { return local_pct_blob_floats(); }
 
+static int g_local_pct_variant = 1;      // 1 (default, measured faster): local_pct.hip, 1 workgroup/CU; 2: local_pct2.hip, 2 workgroups/CU (spills)
+int mcr_set_local_pct_variant(int v) {
+    MCR_REQUIRE(v == 1 || v == 2, "mcr_set_local_pct_variant: variant must be 1 or 2");
+    g_local_pct_variant = v;
+    return 0;
+}
+static void run_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld, int64_t S, const float* blob) {
+    if (g_local_pct_variant == 1) launch_local_pct(s, offs, feat, ld, S, blob);
+    else launch_local_pct2(s, offs, feat, ld, S, blob);
+}
+
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,
                           void* stream) {
     MCR_REQUIRE(offsets && features && blob, "mcr_local_pct_forward: null pointer");
     MCR_REQUIRE(S > 0 && ld_features >= 256, "mcr_local_pct_forward: bad sizes");
     MCR_REQUIRE((reinterpret_cast<uintptr_t>(blob) & 15) == 0, "mcr_local_pct_forward: blob must be 16-byte aligned");
-    launch_local_pct((hipStream_t)stream, offsets, features, ld_features, S, blob);
+    run_local_pct((hipStream_t)stream, offsets, features, ld_features, S, blob);
     MCR_LAUNCH_CHECK("mcr_local_pct_forward");
     return 0;
 }
@@ -297,7 +308,7 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
                                            M_scale[sc], 16, 1, stream))
                     return e;
                 if (local_blobs && local_blobs[sc])      // fused LDS-resident kernel (local_pct.hip)
-                    launch_local_pct(s, offs, feat + (b * Q + q0) * FEAT + sc * 256, FEAT, nq, local_blobs[sc]);
+                    run_local_pct(s, offs, feat + (b * Q + q0) * FEAT + sc * 256, FEAT, nq, local_blobs[sc]);
                 else                                      // layer-by-layer path through HBM
                     run_pct(s, wl[sc], offs, feat + (b * Q + q0) * FEAT + sc * 256, FEAT, nq, 16, 128, a);
                 MCR_REQUIRE(a.ok(), "mcr_scone_occ_forward: workspace overflow (local)");

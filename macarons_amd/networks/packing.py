@@ -8,7 +8,9 @@ Layout (must match macarons_amd/csrc/local_pct.hip):
      LayerNorm-2 gamma folded)  ff2a ff2b (columns 0:128 / 128:256 of ff.linear2)
      14 lin0 (final norm gamma folded)
   vectors: emb1_b[128] emb2_b[128] | per encoder: qkv_c[192] out_b[128] ff1_c[256] ff2_b[128] | lin0_c[128]
-     where c = bias + W @ beta (the LayerNorm shift folded through the linear layer).
+     where c = bias + W @ beta (the LayerNorm shift folded through the linear layer);
+     then (v2 kernel) per encoder: qkv_s[192] ff1_s[256] | lin0_s[128] with s = row sums of the gamma-folded weight
+     (y = rstd * (x W'^T - mu * s) + c lets the kernel skip centring x).
 Folding is algebraically exact; it only moves fp32 roundings (covered by the 1e-4 parity tests).
 """
 import torch
@@ -40,7 +42,7 @@ def pack_local_pct(pct):
     """pct: macarons_amd.networks.SconeOcc.PCTransformer (default local architecture). Returns a 1-D fp32 tensor."""
     with torch.no_grad():
         f = lambda p: p.detach().float()
-        mats, vecs = [], []
+        mats, vecs, svecs = [], [], []
         emb = pct.embedding
         mats.append(_pack(_pad(f(emb.linear1.weight), 128, 8)))
         mats.append(_pack(_pad(f(emb.linear2.weight), 128, 128)))
@@ -55,11 +57,13 @@ def pack_local_pct(pct):
                      _pack((w1 * g2[None, :])[:128]), _pack((w1 * g2[None, :])[128:]),
                      _pack(w2[:, :128].contiguous()), _pack(w2[:, 128:].contiguous())]
             vecs += [bqkv + wqkv @ b1, f(enc.mhsa.out.bias), f(enc.ff.linear1.bias) + w1 @ b2, f(enc.ff.linear2.bias)]
+            svecs += [(wqkv * g1[None, :]).sum(1), (w1 * g2[None, :]).sum(1)]      # column sums s_n (un-centred LayerNorm fold)
         gn, bn = f(pct.norm.weight), f(pct.norm.bias)
         w0 = f(pct.linear0.weight)
         mats.append(_pack(w0 * gn[None, :]))
         vecs.append(f(pct.linear0.bias) + w0 @ bn)
-        blob = torch.cat(mats + vecs).contiguous()
+        svecs.append((w0 * gn[None, :]).sum(1))
+        blob = torch.cat(mats + vecs + svecs).contiguous()
     expect = _lib.lib().mcr_local_pct_blob_floats()
     if blob.numel() != expect:
         raise RuntimeError(f"packed local transformer has {blob.numel()} floats, kernel expects {expect}")
