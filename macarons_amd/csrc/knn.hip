@@ -20,6 +20,7 @@ namespace mcr {
 constexpr int KNN_BLOCK = 256;
 constexpr int KNN_WAVES = KNN_BLOCK / MCR_WAVE;
 constexpr int KNN_TILE = 2048;     // surface points per LDS tile (32 KB as float4); multiple of 16
+constexpr int KNN_QCAP = 8;        // per-lane queue of accepted candidates (LDS, [slot][thread])
 
 // Insert (d2, idx) into the ascending list: slot j takes its upper neighbour if that one must move down,
 // the new element if it lands here, else keeps its value (one v_cmp + four v_cndmask per slot, no branches).
@@ -69,6 +70,8 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
                                                         long long* __restrict__ out_idx, float* __restrict__ out_dist,
                                                         float* __restrict__ out_pts, int Q, int M) {
     __shared__ float4 s_pc[KNN_TILE];           // reused as the merge buffer at the end
+    __shared__ float s_qd[KNN_QCAP * KNN_BLOCK];
+    __shared__ int s_qi[KNN_QCAP * KNN_BLOCK];
     static_assert(KNN_WAVES * K * MCR_WAVE * 8 <= KNN_TILE * 16, "merge buffer does not fit the tile buffer");
     const int b = blockIdx.y;
     const int lane = threadIdx.x & (MCR_WAVE - 1);
@@ -83,6 +86,31 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
     int bi[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { bd[j] = __builtin_inff(); bi[j] = 0x7fffffff; }
+
+    // Accepted candidates are first pushed to a small per-lane LDS queue (a predicated ds_write) and inserted
+    // into the sorted register list in batches: the ~90-instruction insertion then runs once per ~KNN_QCAP
+    // accepted candidates of the fastest-filling lane instead of once per candidate any lane accepts.  The
+    // filter threshold tau is the (possibly stale, hence larger) current k-th distance: never a false reject.
+    float tau = __builtin_inff();
+    int cnt = 0;
+    float* q_d = s_qd + threadIdx.x;
+    int* q_i = s_qi + threadIdx.x;
+    auto flush = [&]() {
+        int maxc = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
+        for (int sidx = 0; sidx < maxc; ++sidx)
+            if (sidx < cnt) knn_insert<K>(bd, bi, q_d[sidx * KNN_BLOCK], q_i[sidx * KNN_BLOCK]);
+        tau = bd[K - 1];
+        cnt = 0;
+    };
+    auto push = [&](float d, int idx) {
+        if (d < tau) {
+            q_d[cnt * KNN_BLOCK] = d;
+            q_i[cnt * KNN_BLOCK] = idx;
+            ++cnt;
+        }
+    };
 
     for (int t0 = 0; t0 < M; t0 += KNN_TILE) {
         const int nt = min(KNN_TILE, M - t0);
@@ -102,14 +130,14 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
             const float4 p0 = s_pc[i], p1 = s_pc[i + KNN_WAVES], p2 = s_pc[i + 2 * KNN_WAVES], p3 = s_pc[i + 3 * KNN_WAVES];
             const float d0 = knn_d2(qx, qy, qz, p0), d1 = knn_d2(qx, qy, qz, p1);
             const float d2 = knn_d2(qx, qy, qz, p2), d3 = knn_d2(qx, qy, qz, p3);
-            if (fminf(fminf(d0, d1), fminf(d2, d3)) < bd[K - 1]) {
-                knn_insert<K>(bd, bi, d0, t0 + i);
-                knn_insert<K>(bd, bi, d1, t0 + i + KNN_WAVES);
-                knn_insert<K>(bd, bi, d2, t0 + i + 2 * KNN_WAVES);
-                knn_insert<K>(bd, bi, d3, t0 + i + 3 * KNN_WAVES);
-            }
+            push(d0, t0 + i);
+            push(d1, t0 + i + KNN_WAVES);
+            push(d2, t0 + i + 2 * KNN_WAVES);
+            push(d3, t0 + i + 3 * KNN_WAVES);
+            if (__any(cnt > KNN_QCAP - 4)) flush();
         }
     }
+    flush();
     // ---- 4-way merge of the waves' sorted lists (lexicographic on (d2, index)) ------------------------------
     __syncthreads();
     float* m_d = reinterpret_cast<float*>(s_pc);                        // [wave][K][lane]

@@ -248,6 +248,7 @@ constexpr int OCC_NW = PCT_NW * 4 + 6 + 6, OCC_CHUNK = 16384;
 size_t mcr_scone_occ_workspace_bytes(int64_t B, int64_t Q, int64_t Lg) {
     const int64_t qc = std::min<int64_t>(Q, OCC_CHUNK);
     size_t local = pct_ws_bytes(qc * 16) + al(qc * 16 * 3) + al(qc * 16) + al(qc * 16 * 2) + 1024;
+    local = std::max(local, al(Q * 16 * 3) + al(Q * 16) + al(Q * 16 * 2) + 1024);      // fused path: kNN outputs for all Q
     size_t glob = pct_ws_bytes(B * Lg);
     size_t head = al(B * Q * 1344) + al(B * Q * 512) + al(B * Q * 256) + al(B * 512) * 2;
     return std::max(local, glob) + head + 8192;
@@ -294,8 +295,11 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
         // its contribution to linear1: gbias[b, n] = sum_k gfeat[b, k] * W1[n, k]  (columns 0..511 of linear1.weight)
         launch_linear(s, gfeat, 512, lin1.w, nullptr, nullptr, 0, gbias, 512, B, 512, 512, ACT_NONE, nullptr, 0, 1856);
     }
-    // ---- local multi-scale neighbourhood features (SconeOcc.py:290-311), chunked over queries ----
-    const int64_t qc = std::min<int64_t>(Q, OCC_CHUNK);
+    // ---- local multi-scale neighbourhood features (SconeOcc.py:290-311) ----
+    // fused path: one kNN + one LDS-resident transformer launch per (cloud, scale) over ALL queries (nothing but
+    // the [Q,16,3] offsets is materialised); layer-by-layer path: chunked over queries to bound its workspace.
+    const bool fused_all = local_blobs && local_blobs[0] && local_blobs[1] && local_blobs[2];
+    const int64_t qc = fused_all ? Q : std::min<int64_t>(Q, OCC_CHUNK);
     for (int sc = 0; sc < 3; ++sc) {
         for (int64_t q0 = 0; q0 < Q; q0 += qc) {
             const int64_t nq = std::min<int64_t>(qc, Q - q0);
@@ -304,6 +308,7 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
                 float* offs = a.f(nq * 16 * 3);
                 float* dist = a.f(nq * 16);
                 int64_t* idx = reinterpret_cast<int64_t*>(a.f(nq * 16 * 2));
+                MCR_REQUIRE(a.ok(), "mcr_scone_occ_forward: workspace overflow (kNN)");
                 if (int e = mcr_knn_points(x + (b * Q + q0) * 3, pc_scale[sc] + b * M_scale[sc] * 3, idx, dist, offs, 1, nq,
                                            M_scale[sc], 16, 1, stream))
                     return e;
