@@ -125,6 +125,7 @@ int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_feat
  *   CDF in fp64: first i with C_i >= u * C_last), then unique (sorted) + inverse.  Outputs are padded to
  *   n_sample rows; *n_unique (device int) says how many are valid.  uniq holds ORIGINAL point indices.
  *   res [n_sample,4] = (X, pred), res_harmonics [n_sample,64].  preds may be strided (pred_stride floats).
+ *   volume (optional device double): sum of the kept occupancies (fov_proxy_volume of macarons_utils.py:1620).
  * mcr_points_in_fov: Camera.get_points_in_fov (macarons/utility/macarons_utils.py:2400-2435) for n_cam cameras
  *   at once.  Each camera is 40 floats: M_view[16] and M_proj[16] (row-major 4x4, row-vector convention
  *   p' = [x y z 1] M, as pytorch3d's get_world_to_view_transform / get_full_projection_transform matrices),
@@ -137,9 +138,21 @@ int mcr_view_state(const float* pts, int pts_dim, const float* X_view, float* vi
 size_t mcr_sample_proxy_workspace_bytes(int64_t P, int n_sample);
 int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t P,
                      float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
-                     int64_t* inverse, int* n_unique, void* workspace, size_t workspace_bytes, void* stream);
+                     int64_t* inverse, int* n_unique, double* volume, void* workspace, size_t workspace_bytes, void* stream);
 int mcr_points_in_fov(const float* pts, int64_t P, const float* cameras, int n_cam, unsigned char* mask, void* stream);
 int mcr_coverage_gain_multiple(const float* vis, float* gains, int64_t B, int64_t C, int64_t N, int n_cam, void* stream);
+
+/* MACARONS per-camera scoring (predict_coverage_gain_for_single_camera, macarons/utility/macarons_utils.py:1580-1738):
+ * mcr_fov_mask_occ: occ_out[c,p] = mask[c,p] ? occ[p] : 0  (frustum mask AND'ed into the sampler's occupancy, :1603-1613)
+ * mcr_transform_points: in place pts[i,:3] = (([x y z 1] M_view)[:3] - center) * inv_diag   (:1641-1660)
+ * mcr_macarons_gain: vis[b,n] *= min(1, (th/|pts_world[b,n]-cam_world[b]|)^2) (get_distance_factor_threshold :1768-1776);
+ *   gains[b] = mean_n vis[b,n] * volume[b]   (:1699-1704) */
+int mcr_fov_mask_occ(const unsigned char* mask, const float* occ, int64_t occ_stride, float* occ_out, int64_t P, int n_cam,
+                     void* stream);
+int mcr_transform_points(float* pts, int pts_dim, int64_t n, const float* M_view, const float* center, float inv_diag,
+                         void* stream);
+int mcr_macarons_gain(float* vis, const float* pts_world, int pts_dim, const float* cam_world, const float* volume,
+                      float distance_th, int64_t B, int64_t N, float* gains, void* stream);
 
 #ifdef __cplusplus
 }

@@ -255,6 +255,57 @@ __global__ __launch_bounds__(256) void multi_gain_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// MACARONS per-camera scoring helpers (macarons_utils.py:1580-1738):
+// masked occupancy: occ_out[c][p] = in_fov(c, p) ? occ[p] : 0   (feeds the sampler: fov mask AND occ > min_occ)
+__global__ void fov_mask_occ_kernel(const unsigned char* __restrict__ mask, const float* __restrict__ occ, long long occ_stride,
+                                    float* __restrict__ occ_out, long long P, int n_cam) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= P * n_cam) return;
+    const long long p = gid % P;
+    occ_out[gid] = mask[gid] ? occ[p * occ_stride] : 0.f;
+}
+
+// in place: pts[i, :3] = ((pts[i, :3] 1) * M_view - center) * inv_diag     (world -> normalised prediction-view space,
+// macarons_utils.py:1641-1660); row stride pts_dim
+__global__ void transform_points_kernel(float* __restrict__ pts, int pts_dim, long long n, const float* __restrict__ M,
+                                        const float* __restrict__ center, float inv_diag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* p = pts + i * pts_dim;
+    const float x = p[0], y = p[1], z = p[2];
+    p[0] = ((((x * M[0] + y * M[4]) + z * M[8]) + M[12]) - center[0]) * inv_diag;
+    p[1] = ((((x * M[1] + y * M[5]) + z * M[9]) + M[13]) - center[1]) * inv_diag;
+    p[2] = ((((x * M[2] + y * M[6]) + z * M[10]) + M[14]) - center[2]) * inv_diag;
+}
+
+// gains[b] = mean_n( vis[b,n] * min(1, (th / |pts_world[b,n] - cam_world[b]|)^2) ) * volume[b]; vis is scaled in place
+// (get_distance_factor_threshold macarons_utils.py:1768-1776 and the final product :1699-1704).  One block per b.
+__global__ __launch_bounds__(256) void macarons_gain_kernel(float* __restrict__ vis, const float* __restrict__ pts_world,
+                                                            int pts_dim, const float* __restrict__ cam_world,
+                                                            const float* __restrict__ volume, float distance_th, int N,
+                                                            float* __restrict__ gains) {
+    __shared__ double s[4];
+    const int b = blockIdx.x;
+    const float cx = cam_world[3 * b], cy = cam_world[3 * b + 1], cz = cam_world[3 * b + 2];
+    double acc = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float* p = pts_world + ((size_t)b * N + n) * pts_dim;
+        const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+        const float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+        float f = 1.f;
+        if (d > distance_th) f = (distance_th * distance_th) / (d * d);
+        const float v = vis[(size_t)b * N + n] * f;
+        vis[(size_t)b * N + n] = v;
+        acc += (double)v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) gains[b] = (float)(((s[0] + s[1]) + (s[2] + s[3])) / (double)N) * volume[b];
+}
+
 }  // namespace mcr
 
 using namespace mcr;
@@ -281,7 +332,7 @@ size_t mcr_sample_proxy_workspace_bytes(int64_t P, int n_sample) {
 
 int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t P,
                      float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
-                     int64_t* inverse, int* n_unique, void* workspace, size_t workspace_bytes, void* stream) {
+                     int64_t* inverse, int* n_unique, double* volume, void* workspace, size_t workspace_bytes, void* stream) {
     MCR_REQUIRE(X && preds && view_harmonics && u && res && res_harmonics && uniq && inverse && n_unique,
                 "mcr_sample_proxy: null pointer");
     MCR_REQUIRE(P > 0 && n_sample > 0 && n_sample <= SMP_MAX, "mcr_sample_proxy: need 0 < n_sample <= %d", SMP_MAX);
@@ -299,6 +350,8 @@ int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, co
     hipLaunchKernelGGL(smp_unique, dim3(1), dim3(1024), 0, s, picked, n_sample, (long long*)uniq, (long long*)inverse, n_unique);
     hipLaunchKernelGGL(smp_gather, dim3((unsigned)n_sample), dim3(64), 0, s, X, preds, (long long)pred_stride, view_harmonics,
                        (const long long*)uniq, n_unique, res, res_harmonics);
+    if (volume)
+        if (int e = check_hip(hipMemcpyAsync(volume, total, sizeof(double), hipMemcpyDeviceToDevice, s), "mcr_sample_proxy: volume")) return e;
     MCR_LAUNCH_CHECK("mcr_sample_proxy");
     return 0;
 }
@@ -308,6 +361,33 @@ int mcr_points_in_fov(const float* pts, int64_t P, const float* cameras, int n_c
     hipLaunchKernelGGL(fov_kernel, dim3((unsigned)cdiv(P * n_cam, 256)), dim3(256), 0, (hipStream_t)stream, pts, (long long)P,
                        cameras, n_cam, mask);
     MCR_LAUNCH_CHECK("fov_kernel");
+    return 0;
+}
+
+int mcr_fov_mask_occ(const unsigned char* mask, const float* occ, int64_t occ_stride, float* occ_out, int64_t P, int n_cam,
+                     void* stream) {
+    MCR_REQUIRE(mask && occ && occ_out && P > 0 && n_cam > 0, "mcr_fov_mask_occ: bad arguments");
+    hipLaunchKernelGGL(fov_mask_occ_kernel, dim3((unsigned)cdiv(P * n_cam, 256)), dim3(256), 0, (hipStream_t)stream, mask, occ,
+                       (long long)occ_stride, occ_out, (long long)P, n_cam);
+    MCR_LAUNCH_CHECK("fov_mask_occ_kernel");
+    return 0;
+}
+
+int mcr_transform_points(float* pts, int pts_dim, int64_t n, const float* M_view, const float* center, float inv_diag,
+                         void* stream) {
+    MCR_REQUIRE(pts && M_view && center && pts_dim >= 3 && n > 0, "mcr_transform_points: bad arguments");
+    hipLaunchKernelGGL(transform_points_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, pts_dim,
+                       (long long)n, M_view, center, inv_diag);
+    MCR_LAUNCH_CHECK("transform_points_kernel");
+    return 0;
+}
+
+int mcr_macarons_gain(float* vis, const float* pts_world, int pts_dim, const float* cam_world, const float* volume,
+                      float distance_th, int64_t B, int64_t N, float* gains, void* stream) {
+    MCR_REQUIRE(vis && pts_world && cam_world && volume && gains && B > 0 && N > 0 && pts_dim >= 3, "mcr_macarons_gain: bad arguments");
+    hipLaunchKernelGGL(macarons_gain_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, vis, pts_world, pts_dim, cam_world,
+                       volume, distance_th, (int)N, gains);
+    MCR_LAUNCH_CHECK("macarons_gain_kernel");
     return 0;
 }
 

@@ -256,8 +256,8 @@ def view_state(pts, X_view, n_elev, n_azim):
     return out
 
 
-def sample_proxy(X, preds, view_harmonics, u, min_occ):
-    """(res [n_u,4], res_harmonics [n_u,64], inverse [n_sample] int64, unique original indices [n_u] int64);
+def sample_proxy(X, preds, view_harmonics, u, min_occ, return_volume=False):
+    """(res [n_u,4], res_harmonics [n_u,64], inverse [n_sample] int64, unique original indices [n_u] int64[, volume]);
     replaces sample_proxy_points (scone_utils.py:1030-1061).  One host sync to read n_u (torch.unique syncs too)."""
     X, preds, vh, u = _req(X, "X"), _req(preds, "preds"), _req(view_harmonics, "view_harmonics"), _req(u, "samples")
     P = X.shape[0]
@@ -268,13 +268,16 @@ def sample_proxy(X, preds, view_harmonics, u, min_occ):
     uniq = torch.empty(n, dtype=torch.int64, device=dev)
     inv = torch.empty(n, dtype=torch.int64, device=dev)
     nu = torch.zeros(1, dtype=torch.int32, device=dev)
+    vol = torch.zeros(1, dtype=torch.float64, device=dev)
     L_ = lib()
     ws = _workspace(dev, L_.mcr_sample_proxy_workspace_bytes(c_i64(P), c_int(n)))
     with torch.cuda.device(dev):
         check(L_.mcr_sample_proxy(_p(X), _p(preds), c_i64(1), _p(vh), c_i64(P), c_f32(float(min_occ)), _p(u), c_int(n),
-                                  _p(res), _p(resh), _p(uniq), _p(inv), _p(nu), _p(ws), c_size(ws.numel()), _stream()),
+                                  _p(res), _p(resh), _p(uniq), _p(inv), _p(nu), _p(vol), _p(ws), c_size(ws.numel()), _stream()),
               "mcr_sample_proxy")
     k = int(nu.item())
+    if return_volume:
+        return res[:k], resh[:k], inv, uniq[:k], vol
     return res[:k], resh[:k], inv, uniq[:k]
 
 
@@ -302,3 +305,35 @@ def coverage_gain_multiple(pts, harmonics, cams, n_cam, use_sigmoid=True):
     single = torch.arange(0, C)
     n_idx = torch.cartesian_prod(*([single] * n_cam))                  # SconeVis.py:292-296 (index table, host)
     return out, n_idx
+
+
+def fov_mask_occ(mask, occ):
+    """mask [n_cam,P] bool/uint8, occ [P] -> [n_cam,P] occupancy zeroed outside each frustum."""
+    occ = _req(occ, "occ")
+    m = mask.to(torch.uint8).contiguous()
+    C, P = m.shape
+    out = torch.empty((C, P), dtype=torch.float32, device=occ.device)
+    with torch.cuda.device(occ.device):
+        check(lib().mcr_fov_mask_occ(_p(m), _p(occ), c_i64(1), _p(out), c_i64(P), c_int(C), _stream()), "mcr_fov_mask_occ")
+    return out
+
+
+def transform_points_(pts, M_view, center, inv_diag):
+    """In place: pts[:, :3] <- (([x y z 1] M_view)[:3] - center) * inv_diag."""
+    pts = _req(pts, "pts")
+    n, d = pts.shape
+    with torch.cuda.device(pts.device):
+        check(lib().mcr_transform_points(_p(pts), c_int(d), c_i64(n), _p(_req(M_view, "M_view")), _p(_req(center, "center")),
+                                         c_f32(float(inv_diag)), _stream()), "mcr_transform_points")
+    return pts
+
+
+def macarons_gain_(vis, pts_world, cam_world, volume, distance_th):
+    """vis [B,N] (scaled in place by the distance factor), pts_world [B,N,>=3], cam_world [B,3], volume [B] -> gains [B]."""
+    vis, pts_world, cam_world, volume = _req(vis, "vis"), _req(pts_world, "pts_world"), _req(cam_world, "cam_world"), _req(volume, "volume")
+    B, N = vis.shape
+    gains = torch.empty(B, dtype=torch.float32, device=vis.device)
+    with torch.cuda.device(vis.device):
+        check(lib().mcr_macarons_gain(_p(vis), _p(pts_world), c_int(pts_world.shape[-1]), _p(cam_world), _p(volume),
+                                      c_f32(float(distance_th)), c_i64(B), c_i64(N), _p(gains), _stream()), "mcr_macarons_gain")
+    return gains

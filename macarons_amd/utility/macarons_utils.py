@@ -1,0 +1,69 @@
+"""Mirror of the MACARONS-regime scoring helpers of macarons/utility/macarons_utils.py on the MI355X kernels:
+  get_distance_factor_threshold :1768-1776
+  predict_coverage_gain_for_single_camera :1580-1738  (here batched over the <= 30 neighbour cameras)
+PyTorch3D camera objects stay outside: cameras are passed as the 40-float records of mcr_points_in_fov
+(M_view, M_proj, ndc bounds, centre, range) and a prediction-view matrix.
+"""
+import torch
+
+from .. import ops
+from .scone_utils import sample_proxy_points  # noqa: F401  (same sampler as the SCONE regime)
+
+
+def camera_record(M_view, M_proj, ndc_bounds, center, fov_range=None):
+    """Pack one camera for points_in_fov: 4x4 row-vector matrices (pytorch3d get_matrix()[0] layout)."""
+    rec = torch.zeros(40, dtype=torch.float32)
+    rec[:16] = torch.as_tensor(M_view, dtype=torch.float32).reshape(-1)
+    rec[16:32] = torch.as_tensor(M_proj, dtype=torch.float32).reshape(-1)
+    rec[32:36] = torch.as_tensor(ndc_bounds, dtype=torch.float32)
+    rec[36:39] = torch.as_tensor(center, dtype=torch.float32)
+    rec[39] = 0.0 if fov_range is None else float(fov_range)
+    return rec
+
+
+def get_distance_factor_threshold(pts, X_cam, distance_th=17.):
+    """[n_pts, 1] factor min(1, (th/d)^2)  (macarons_utils.py:1768-1776)."""
+    n = pts.shape[0]
+    ones = torch.ones(1, n, dtype=torch.float32, device=pts.device)
+    ops.macarons_gain_(ones, pts.reshape(1, n, -1)[..., :3].contiguous(), X_cam.reshape(1, 3).contiguous(),
+                       torch.ones(1, dtype=torch.float32, device=pts.device), distance_th)
+    return ones.view(n, 1)
+
+
+def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harmonics, occ_probs, cameras, X_cam_world,
+                                      prediction_view_matrices, prediction_box_diag, seq_len=2048, min_occ=0.1,
+                                      distance_th=17., samples=None):
+    """The per-neighbour-camera scoring loop of testers/scene.py:434-454 around
+    predict_coverage_gain_for_single_camera (macarons_utils.py:1580-1738), for K cameras:
+      frustum mask (all K at once) -> occupancy-weighted sampling inside each frustum -> prediction-view space ->
+      SconeVis -> per-point visibility gains (C = 1) x distance factor -> mean x sum(occ in frustum).
+    X_world [P,3], proxy_view_harmonics [P,64], occ_probs [P,1], cameras [K,40], X_cam_world [K,3],
+    prediction_view_matrices [K,4,4] (world -> prediction-camera view, row-vector).  Returns gains [K]."""
+    K = cameras.shape[0]
+    dev = X_world.device
+    mask = ops.points_in_fov(X_world, cameras)                                            # :1603
+    occ_k = ops.fov_mask_occ(mask, occ_probs.reshape(-1).contiguous())                    # :1606-1613 folded into the sampler
+    gains = torch.zeros(K, dtype=torch.float32, device=dev)
+    for k in range(K):
+        u = samples[k] if samples is not None else torch.rand(seq_len, device=dev)
+        res, res_h, inv, uniq, vol = ops.sample_proxy(X_world, occ_k[k], proxy_view_harmonics, u.reshape(-1), min_occ,
+                                                      return_volume=True)                 # :1624
+        if res.shape[0] == 0:
+            continue                                                                      # empty frustum: gain 0 (:1707-1736)
+        world = res[inv].contiguous()                                                     # MC duplicates (:1668-1671)
+        center_w = (res[:, :3].max(dim=0)[0] + res[:, :3].min(dim=0)[0]).view(1, 3) / 2.  # :1631-1633
+        Mv = prediction_view_matrices[k].contiguous()
+        c_view = torch.cat((center_w, torch.ones(1, 1, device=dev)), 1) @ Mv              # prediction_box_center (:1641)
+        center = c_view[0, :3].contiguous()
+        pts = res.clone()
+        ops.transform_points_(pts, Mv, center, 1.0 / prediction_box_diag)                 # :1647-1650
+        cam = X_cam_world[k].view(1, 3).clone()
+        cam4 = torch.cat((cam, torch.ones(1, 1, device=dev)), 1)
+        ops.transform_points_(cam4, Mv, center, 1.0 / prediction_box_diag)                # :1655-1659
+        harm = visibility_model(pts[None], view_harmonics=res_h[None])                    # :1664
+        vis = ops.sh_visibilities(pts[inv][None].contiguous(), harm[0][inv][None].contiguous(),
+                                  cam4[:, :3].reshape(1, 1, 3).contiguous(), True)        # :1683  [1,1,N]
+        g = ops.macarons_gain_(vis.view(1, -1), world[None], X_cam_world[k].view(1, 3).contiguous(),
+                               vol.float(), distance_th)                                  # :1699-1704
+        gains[k] = g[0]
+    return gains

@@ -315,7 +315,19 @@ def gen_e2e():
          occ_bias_shift=np.float32(0.5))
 
 
-GROUPS = {"e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
+def gen_macarons():
+    """get_distance_factor_threshold (macarons_utils.py:1768-1776) + the final product of
+    predict_coverage_gain_for_single_camera (:1699-1704) on reference pieces."""
+    import importlib
+    mu = importlib.import_module("macarons.utility.macarons_utils")
+    rng = np.random.default_rng(81)
+    pts = rng.uniform(-40, 40, (3000, 3)).astype(np.float32)
+    cam = np.array([[3.0, -2.0, 5.0]], np.float32)
+    fac = mu.get_distance_factor_threshold(t(pts), t(cam), distance_th=17.)
+    save("macarons_regime", pts=pts, cam=cam, factor=fac.numpy())
+
+
+GROUPS = {"macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

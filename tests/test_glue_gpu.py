@@ -115,3 +115,45 @@ def test_coverage_gain_multiple(dev):
     assert np.array_equal(i3.numpy(), d["multi3_idx"]) and rel_err(g3.cpu().numpy(), d["multi3"]) < 1e-4
     with pytest.raises(NameError):
         m.compute_coverage_gain_multiple(T(d["pts"], dev), T(d["harmonics"], dev), T(d["cams"], dev), 4)
+
+
+def test_macarons_regime_scoring(dev):
+    """Batched per-neighbour-camera scoring (predict_coverage_gain_for_single_camera) vs the oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import weights
+    from macarons_amd.networks import SconeVis
+    from macarons_amd.utility import macarons_utils as mu
+    from oracle import macarons_regime as MR
+    g = golden("macarons_regime")
+    fac = mu.get_distance_factor_threshold(T(g["pts"], dev), T(g["cam"], dev), 17.).cpu().numpy()
+    assert np.abs(fac - g["factor"]).max() < 1e-6 and np.abs(MR.distance_factor_threshold(g["pts"], g["cam"]) - g["factor"]).max() < 1e-6
+    vis = SconeVis()
+    sdv = weights.make_state_dict(weights.shapes_of(vis), 1)
+    vis.load_state_dict({k: torch.from_numpy(v) for k, v in sdv.items()})
+    vis = vis.to(dev).eval()
+    rng = np.random.default_rng(12)
+    P, K = 20000, 4
+    X = rng.uniform(-20, 20, (P, 3)).astype(np.float32)
+    vh = (rng.standard_normal((P, 64)) * .3).astype(np.float32)
+    occ = rng.uniform(0, 1, (P, 1)).astype(np.float32)
+    recs, Mpred, cams_w = [], [], []
+    f = 1.0 / np.tan(np.deg2rad(60) / 2)
+    Kp = np.array([[f, 0, 0, 0], [0, f, 0, 0], [0, 0, 100 / 99, 1], [0, 0, -100 / 99, 0]], np.float32)
+    for k in range(K):
+        R = np.linalg.qr(rng.standard_normal((3, 3)))[0].astype(np.float32)
+        Tt = rng.uniform(-3, 3, 3).astype(np.float32)
+        Mv = np.eye(4, dtype=np.float32); Mv[:3, :3] = R; Mv[3, :3] = Tt
+        c = (-Tt @ R.T).astype(np.float32)
+        recs.append(mu.camera_record(Mv, (Mv @ Kp).astype(np.float32), [456 / 256 - 2 * 455 / 255, 456 / 256, -1.0, 1.0], c,
+                                     fov_range=0.0 if k == 3 else 45.0).numpy())
+        Mpred.append(Mv); cams_w.append(c)
+    recs[3][33] = recs[3][32] - 1.0            # camera 3: empty frustum (max_ndc_x < min_ndc_x) -> gain 0
+    recs, Mpred, cams_w = np.stack(recs), np.stack(Mpred), np.stack(cams_w)
+    u = rng.uniform(0, 1, (K, 2048)).astype(np.float32)
+    with torch.no_grad():
+        gains = mu.predict_coverage_gain_for_cameras(vis, T(X, dev), T(vh, dev), T(occ, dev), T(recs, dev), T(cams_w, dev),
+                                                     T(Mpred, dev), 57.0, samples=T(u, dev)).cpu().numpy()
+    ref = np.array([MR.coverage_gain_for_camera(sdv, X, vh, occ, recs[k], cams_w[k], Mpred[k], 57.0, u[k]) for k in range(K)])
+    assert gains[3] == 0.0 and ref[3] == 0.0
+    assert rel_err(gains, ref) < 1e-4
