@@ -151,7 +151,8 @@ __global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__
     int n2 = 1;
     while (n2 < n_sample) n2 <<= 1;
     for (int i = threadIdx.x; i < n2; i += 1024)
-        key[i] = i < n_sample ? ((picked[i] << 13) | (long long)i) : 0x7fffffffffffffffLL;   // sample id in the low 13 bits
+        key[i] = (i < n_sample && picked[i] >= 0) ? ((picked[i] << 13) | (long long)i)
+                                                  : (0x7fffffffffffe000LL | (long long)(i & 8191));   // invalid / padding sort last
     __syncthreads();
     for (int k = 2; k <= n2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__
         }
     // flags -> inclusive scan (sequential per thread chunk + block scan)
     for (int i = threadIdx.x; i < n2; i += 1024)
-        rank[i] = (i < n_sample && (i == 0 || (key[i] >> 13) != (key[i - 1] >> 13))) ? 1 : 0;
+        rank[i] = (i < n_sample && (key[i] >> 13) != (0x7fffffffffffe000LL >> 13) &&
+                   (i == 0 || (key[i] >> 13) != (key[i - 1] >> 13))) ? 1 : 0;
     __syncthreads();
     for (int o = 1; o < n2; o <<= 1) {
         int t[SMP_MAX / 1024];
@@ -179,8 +181,12 @@ __global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__
         __syncthreads();
     }
     for (int i = threadIdx.x; i < n_sample; i += 1024) {
-        const int r = rank[i] - 1;
         const long long id = key[i] >> 13;
+        if (id == (0x7fffffffffffe000LL >> 13)) {                 // no point above min_occ: nothing sampled
+            inverse[key[i] & 8191] = 0;
+            continue;
+        }
+        const int r = rank[i] - 1;
         if (i == 0 || id != (key[i - 1] >> 13)) uniq[r] = id;
         inverse[key[i] & 8191] = r;
     }
