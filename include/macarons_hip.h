@@ -154,6 +154,17 @@ int mcr_transform_points(float* pts, int pts_dim, int64_t n, const float* M_view
 int mcr_macarons_gain(float* vis, const float* pts_world, int pts_dim, const float* cam_world, const float* volume,
                       float distance_th, int64_t B, int64_t N, float* gains, void* stream);
 
+/* ---- scene-side point bookkeeping ---------------------------------------------------------
+ * mcr_min_dist_segmented (K11): dmin[i] = min_j |A[i] - B[j]| in fp64 over the B points of A[i]'s segment (grid cell);
+ *   replaces torch.min(torch.cdist(a.double(), b.double())) of Cell.fill / camera_coverage_gain / scene_coverage
+ *   (macarons/utility/macarons_utils.py:2566, :3022, :3049).  Offsets are CSR int64 [n_segments+1]; +inf if B is empty.
+ * mcr_unproject_depth (K12): Camera.project_depth_in_3D / utils.project_depth_back_to_3D (macarons_utils.py:2339-2360,
+ *   utils.py:1458-1487): depth [n_cam,H,W] -> world [n_cam,H*W,3]; each camera = 18 floats: inverse full projection
+ *   matrix (row-major, row-vector convention) + k22, k32 of the projection matrix (scaled-depth conversion). */
+int mcr_min_dist_segmented(const float* A, const int64_t* a_offsets, const float* B, const int64_t* b_offsets, int64_t n_segments,
+                           int64_t max_a_per_segment, double* dmin, void* stream);
+int mcr_unproject_depth(const float* depth, int H, int W, const float* cameras, int64_t n_cam, float* world, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -312,6 +312,62 @@ __global__ __launch_bounds__(256) void macarons_gain_kernel(float* __restrict__ 
     if (threadIdx.x == 0) gains[b] = (float)(((s[0] + s[1]) + (s[2] + s[3])) / (double)N) * volume[b];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// K11: segmented nearest-distance in fp64 ("is any point of B within eps of each point of A", per grid cell):
+//   dmin[i] = min_j |A[i] - B[j]|  over the B points of A[i]'s segment  (torch.min(torch.cdist(a.double(), b.double())),
+//   macarons_utils.py:2566 Cell.fill, :3022 camera_coverage_gain, :3049 scene_coverage).  +inf for an empty B segment.
+// grid = (ceil(max_a/256), n_seg): one block column per segment, B streamed through LDS.
+__global__ __launch_bounds__(256) void min_dist_seg_kernel(const float* __restrict__ A, const long long* __restrict__ a_off,
+                                                           const float* __restrict__ B, const long long* __restrict__ b_off,
+                                                           double* __restrict__ dmin) {
+    __shared__ double sb[512 * 3];
+    const int seg = blockIdx.y;
+    const long long a0 = a_off[seg], a1 = a_off[seg + 1], b0 = b_off[seg], b1 = b_off[seg + 1];
+    const long long i = a0 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if ((long long)blockIdx.x * 256 >= a1 - a0) return;
+    const bool valid = i < a1;
+    double ax = 0, ay = 0, az = 0;
+    if (valid) { ax = A[3 * i]; ay = A[3 * i + 1]; az = A[3 * i + 2]; }
+    double best = __builtin_inf();
+    for (long long t0 = b0; t0 < b1; t0 += 512) {
+        const int nt = (int)min((long long)512, b1 - t0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nt * 3; k += 256) sb[k] = (double)B[3 * t0 + k];
+        __syncthreads();
+        for (int j = 0; j < nt; ++j) {
+            const double dx = ax - sb[3 * j], dy = ay - sb[3 * j + 1], dz = az - sb[3 * j + 2];
+            best = fmin(best, (dx * dx + dy * dy) + dz * dz);
+        }
+    }
+    if (valid) dmin[i] = sqrt(best);
+}
+
+// K12: depth map -> world points (Camera.project_depth_in_3D macarons_utils.py:2339-2360 / utils.project_depth_back_to_3D
+// utils.py:1458-1487 with pytorch3d FoVPerspectiveCameras.unproject_points(scaled_depth_input=False)):
+//   ndc_x = W/m - 2 j/(m-1), ndc_y = H/m - 2 i/(m-1), m = min(W,H);  sdepth = (k22 * d + k32) / d;
+//   world = ([ndc_x ndc_y sdepth 1] * Minv)[:3] / w          (Minv = inverse full projection, row-vector)
+__global__ void unproject_depth_kernel(const float* __restrict__ depth, int H, int W, const float* __restrict__ cam,
+                                       float* __restrict__ out, long long n_cam) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long hw = (long long)H * W;
+    if (gid >= n_cam * hw) return;
+    const long long c = gid / hw, pix = gid - c * hw;
+    const int i = (int)(pix / W), j = (int)(pix - (long long)i * W);
+    const float m = (float)min(H, W);
+    const float nx = (float)W / m - ((float)j / (m - 1.f)) * 2.f;
+    const float ny = (float)H / m - ((float)i / (m - 1.f)) * 2.f;
+    const float* K = cam + c * 18;            // Minv[16], k22, k32
+    const float d = depth[gid];
+    const float sd = (K[16] * d + K[17]) / d;
+    const float x = ((nx * K[0] + ny * K[4]) + sd * K[8]) + K[12];
+    const float y = ((nx * K[1] + ny * K[5]) + sd * K[9]) + K[13];
+    const float z = ((nx * K[2] + ny * K[6]) + sd * K[10]) + K[14];
+    const float w = ((nx * K[3] + ny * K[7]) + sd * K[11]) + K[15];
+    out[3 * gid + 0] = x / w;
+    out[3 * gid + 1] = y / w;
+    out[3 * gid + 2] = z / w;
+}
+
 }  // namespace mcr
 
 using namespace mcr;
@@ -394,6 +450,24 @@ int mcr_macarons_gain(float* vis, const float* pts_world, int pts_dim, const flo
     hipLaunchKernelGGL(macarons_gain_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, vis, pts_world, pts_dim, cam_world,
                        volume, distance_th, (int)N, gains);
     MCR_LAUNCH_CHECK("macarons_gain_kernel");
+    return 0;
+}
+
+int mcr_min_dist_segmented(const float* A, const int64_t* a_offsets, const float* B, const int64_t* b_offsets, int64_t n_segments,
+                           int64_t max_a_per_segment, double* dmin, void* stream) {
+    MCR_REQUIRE(A && a_offsets && B && b_offsets && dmin, "mcr_min_dist_segmented: null pointer");
+    MCR_REQUIRE(n_segments > 0 && n_segments <= 65535 && max_a_per_segment > 0, "mcr_min_dist_segmented: bad sizes");
+    hipLaunchKernelGGL(min_dist_seg_kernel, dim3((unsigned)cdiv(max_a_per_segment, 256), (unsigned)n_segments), dim3(256), 0,
+                       (hipStream_t)stream, A, (const long long*)a_offsets, B, (const long long*)b_offsets, dmin);
+    MCR_LAUNCH_CHECK("min_dist_seg_kernel");
+    return 0;
+}
+
+int mcr_unproject_depth(const float* depth, int H, int W, const float* cameras, int64_t n_cam, float* world, void* stream) {
+    MCR_REQUIRE(depth && cameras && world && H > 1 && W > 1 && n_cam > 0, "mcr_unproject_depth: bad arguments");
+    hipLaunchKernelGGL(unproject_depth_kernel, dim3((unsigned)cdiv(n_cam * H * W, 256)), dim3(256), 0, (hipStream_t)stream, depth, H,
+                       W, cameras, world, (long long)n_cam);
+    MCR_LAUNCH_CHECK("unproject_depth_kernel");
     return 0;
 }
 

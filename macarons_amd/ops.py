@@ -337,3 +337,32 @@ def macarons_gain_(vis, pts_world, cam_world, volume, distance_th):
         check(lib().mcr_macarons_gain(_p(vis), _p(pts_world), c_int(pts_world.shape[-1]), _p(cam_world), _p(volume),
                                       c_f32(float(distance_th)), c_i64(B), c_i64(N), _p(gains), _stream()), "mcr_macarons_gain")
     return gains
+
+
+# ---- scene-side bookkeeping ---------------------------------------------------------------
+def min_dist_segmented(A, a_offsets, B, b_offsets):
+    """fp64 distance of every A point to the nearest B point of its segment (grid cell); +inf for empty B segments.
+    Replaces torch.min(torch.cdist(a.double(), b.double())) (macarons_utils.py:2566, 3022, 3049)."""
+    A, B = _req(A, "A"), _req(B, "B")
+    a_off = _req(a_offsets, "a_offsets", torch.int64)
+    b_off = _req(b_offsets, "b_offsets", torch.int64)
+    nseg = a_off.numel() - 1
+    out = torch.empty(A.shape[0], dtype=torch.float64, device=A.device)
+    max_a = int((a_off[1:] - a_off[:-1]).max().item()) if nseg > 0 else 0
+    if max_a == 0:
+        return out
+    with torch.cuda.device(A.device):
+        check(lib().mcr_min_dist_segmented(_p(A), _p(a_off), _p(B), _p(b_off), c_i64(nseg), c_i64(max_a), _p(out), _stream()),
+              "mcr_min_dist_segmented")
+    return out
+
+
+def unproject_depth(depth, cameras):
+    """depth [n_cam,H,W(,1)], cameras [n_cam,18] (Minv[16], k22, k32) -> world points [n_cam, H*W, 3]."""
+    depth, cameras = _req(depth, "depth"), _req(cameras, "cameras")
+    n, H, W = depth.shape[0], depth.shape[1], depth.shape[2]
+    out = torch.empty((n, H * W, 3), dtype=torch.float32, device=depth.device)
+    with torch.cuda.device(depth.device):
+        check(lib().mcr_unproject_depth(_p(depth), c_int(H), c_int(W), _p(cameras), c_i64(n), _p(out), _stream()),
+              "mcr_unproject_depth")
+    return out

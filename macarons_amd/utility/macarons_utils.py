@@ -67,3 +67,46 @@ def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harm
                                vol.float(), distance_th)                                  # :1699-1704
         gains[k] = g[0]
     return gains
+
+
+# ---- scene-side point bookkeeping -----------------------------------------------------------
+def depth_camera_record(M_full_projection, k22, k32):
+    """18 floats for ops.unproject_depth: inverse of the full (world->view->ndc) projection matrix + the two
+    projection entries used by pytorch3d's scaled-depth conversion."""
+    Minv = torch.linalg.inv(torch.as_tensor(M_full_projection, dtype=torch.float64)).float().reshape(-1)
+    return torch.cat((Minv, torch.tensor([k22, k32], dtype=torch.float32)))
+
+
+def compute_partial_point_cloud(depth, mask, camera, gathering_factor, fov_range=None, perm=None):
+    """Camera.compute_partial_point_cloud (macarons_utils.py:2362-2398): depth [1,H,W,1] -> world points of the pixels
+    kept by `mask` (and depth < fov_range), then a random `gathering_factor` fraction (torch.randperm on the CPU
+    generator like the reference, or `perm`)."""
+    H, W = depth.shape[1], depth.shape[2]
+    pts = ops.unproject_depth(depth.reshape(1, H, W).contiguous(), camera.reshape(1, 18).to(depth.device))[0]
+    keep = mask.reshape(-1).bool()
+    if fov_range is not None:
+        keep = keep & (depth.reshape(-1) < fov_range)
+    world = pts[keep]
+    n_points = int(len(world) * gathering_factor)
+    idx = (torch.randperm(len(world)) if perm is None else perm)[:n_points]
+    return world[idx.to(world.device)]
+
+
+def cell_fill_mask(pts_to_add, cell_pts, resolution, a_offsets=None, b_offsets=None):
+    """The admission test of Cell.fill (macarons_utils.py:2565-2568): keep a candidate iff its fp64 distance to every
+    point already in the (same) cell exceeds `resolution`.  With offsets, many cells are tested in one launch."""
+    dev = pts_to_add.device
+    if a_offsets is None:
+        a_offsets = torch.tensor([0, pts_to_add.shape[0]], dtype=torch.int64, device=dev)
+        b_offsets = torch.tensor([0, cell_pts.shape[0]], dtype=torch.int64, device=dev)
+    return ops.min_dist_segmented(pts_to_add, a_offsets, cell_pts, b_offsets) > resolution
+
+
+def covered_mask(surface_pts, seen_pts, epsilon, a_offsets=None, b_offsets=None):
+    """heaviside(epsilon - min cdist, 0) of camera_coverage_gain / scene_coverage (macarons_utils.py:3022-3024,
+    3049-3051): a surface point is covered iff some seen point lies strictly within epsilon (fp64)."""
+    dev = surface_pts.device
+    if a_offsets is None:
+        a_offsets = torch.tensor([0, surface_pts.shape[0]], dtype=torch.int64, device=dev)
+        b_offsets = torch.tensor([0, seen_pts.shape[0]], dtype=torch.int64, device=dev)
+    return ops.min_dist_segmented(surface_pts, a_offsets, seen_pts, b_offsets) < epsilon

@@ -157,3 +157,45 @@ def test_macarons_regime_scoring(dev):
     ref = np.array([MR.coverage_gain_for_camera(sdv, X, vh, occ, recs[k], cams_w[k], Mpred[k], 57.0, u[k]) for k in range(K)])
     assert gains[3] == 0.0 and ref[3] == 0.0
     assert rel_err(gains, ref) < 1e-4
+
+
+def test_scene_side_kernels(dev):
+    """K11 segmented fp64 nearest distance (Cell.fill / coverage tests) and K12 depth unprojection."""
+    from macarons_amd import ops
+    from oracle import scene as S
+    rng = np.random.default_rng(21)
+    na = [0, 700, 1, 1300, 257]
+    nb = [5, 900, 0, 2000, 513]
+    A = rng.uniform(0, 10, (sum(na), 3)).astype(np.float32)
+    B = rng.uniform(0, 10, (sum(nb), 3)).astype(np.float32)
+    ao, bo = np.concatenate([[0], np.cumsum(na)]).astype(np.int64), np.concatenate([[0], np.cumsum(nb)]).astype(np.int64)
+    d = ops.min_dist_segmented(T(A, dev), T(ao, dev), T(B, dev), T(bo, dev)).cpu().numpy()
+    for s in range(len(na)):
+        ref = S.min_dist(A[ao[s]:ao[s + 1]], B[bo[s]:bo[s + 1]])
+        got = d[ao[s]:ao[s + 1]]
+        assert np.array_equal(np.isinf(ref), np.isinf(got))
+        ok = ~np.isinf(ref)
+        assert np.abs(got[ok] - ref[ok]).max(initial=0) < 1e-12
+        # the decisions the reference takes on it (strict > resolution, heaviside(eps - d) i.e. d < eps) are identical
+        for eps in (0.05, 0.3, 1.0):
+            assert np.array_equal(got > eps, ref > eps) and np.array_equal(got < eps, ref < eps)
+    # depth unprojection: round trip through an explicit perspective camera
+    H, W = 24, 40
+    f = 1.0 / np.tan(np.deg2rad(60) / 2)
+    zn, zf = 1.0, 100.0
+    K = np.array([[f, 0, 0, 0], [0, f, 0, 0], [0, 0, zf / (zf - zn), 1], [0, 0, -zf * zn / (zf - zn), 0]], np.float64)
+    R = np.linalg.qr(rng.standard_normal((3, 3)))[0]
+    Mv = np.eye(4); Mv[:3, :3] = R; Mv[3, :3] = rng.uniform(-2, 2, 3)
+    Minv = np.linalg.inv(Mv @ K)
+    depth = rng.uniform(2, 50, (1, H, W)).astype(np.float32)
+    cam = np.concatenate([Minv.reshape(-1), [K[2, 2], K[3, 2]]]).astype(np.float32)[None]
+    w = ops.unproject_depth(T(depth, dev), T(cam, dev)).cpu().numpy()[0]
+    ref = S.unproject_depth(depth[0], cam[0, :16].reshape(4, 4), cam[0, 16], cam[0, 17])
+    assert np.abs(w - ref).max() < 2e-3 * np.abs(ref).max()
+    # and the geometry closes: re-projecting the world points gives back the pixel ndc and the depth
+    ph = np.concatenate([w.astype(np.float64), np.ones((H * W, 1))], 1)
+    view = ph @ Mv
+    assert np.abs(view[:, 2] - depth.reshape(-1)).max() < 1e-2
+    nx, ny = S.ndc_tabs(H, W)
+    proj = ph @ (Mv @ K)
+    assert np.abs(proj[:, 0] / proj[:, 3] - nx.reshape(-1)).max() < 1e-3 and np.abs(proj[:, 1] / proj[:, 3] - ny.reshape(-1)).max() < 1e-3
