@@ -70,50 +70,73 @@ __device__ __forceinline__ float lp_gelu(float x) {
 
 // ---- block GEMM: acc[t] (+)= A[64 x K] * Wp^T for this wave's TPW output tiles -----------------------------------
 // tile id = wave*TPW + t  ->  n-tile = id >> 1, m-tile = id & 1.   A: LDS, row stride lda, K-halves per lane half.
-template <int K, int TPW, bool INIT>
-__device__ __forceinline__ void lp_gemm(f32x16 (&acc)[TPW], const float* __restrict__ A, int lda,
-                                        const float* __restrict__ Wp, int wave, int lane) {
-    constexpr int G = K / 8;                       // k-groups of 4 steps per lane half
+//
+// Software pipeline (the scheduler otherwise sinks every ds_read next to its first use and waits lgkmcnt(0) in
+// front of each MFMA group: measured 28 % of the wave's life in s_waitcnt):
+//   * A fragments (LDS) one k-group ahead, B fragments (L2) LP_PF k-groups ahead of the MFMAs consuming them;
+//     sched_group_barrier pins  [next A reads][next B loads][4*TPW MFMAs]  per group;
+//   * the B ring is SHARED BY CONSECUTIVE GEMMs: while the last LP_PF groups of this product are in the matrix pipe
+//     the first LP_PF groups of the NEXT product's weights are already requested, so the epilogue / LayerNorm /
+//     attention / barrier between two products hides the L2 latency instead of exposing a pipeline refill
+//     (13 refills per workgroup otherwise).  Needs G % LP_PF == 0 so ring slots line up.
+constexpr int LP_PF = 4;
+typedef float4 lp_ring_t[LP_PF][3];
+
+template <int TPW>
+__device__ __forceinline__ const float4* lp_bptr(const float* Wp, int G, int wave, int lane, int t) {
+    const int id = wave * TPW + t, nt = id >> 1;
+    return reinterpret_cast<const float4*>(Wp) + (size_t)nt * G * 64 + lane;
+}
+
+// K = 128 products of the chain.  PRE: the ring already holds this product's first LP_PF groups.
+// NEXT_TPW: tiles per wave of the next product whose first LP_PF groups are requested at the tail (0 = none).
+template <int TPW, bool INIT, bool PRE, int NEXT_TPW>
+__device__ __forceinline__ void lp_gemm128(f32x16 (&acc)[TPW], const float* __restrict__ A, int lda,
+                                           const float* __restrict__ Wp, lp_ring_t& b, const float* __restrict__ next_Wp,
+                                           int wave, int lane) {
+    constexpr int K = 128, G = K / 8;
+    static_assert(G % LP_PF == 0, "ring slots of consecutive products must line up");
     const int i = lane & 31, h = lane >> 5;
     const float4* bp[TPW];
     const float* ap[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int id = wave * TPW + t, nt = id >> 1, mt = id & 1;
-        bp[t] = reinterpret_cast<const float4*>(Wp) + (size_t)nt * G * 64 + lane;
-        ap[t] = A + (mt * 32 + i) * lda + h * (K / 2);
+        bp[t] = lp_bptr<TPW>(Wp, G, wave, lane, t);
+        ap[t] = A + (((wave * TPW + t) & 1) * 32 + i) * lda + h * (K / 2);
         if (INIT) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         }
     }
-    // Software pipeline: A fragments (LDS) one group ahead, B fragments (L2) PF groups ahead of the MFMAs that
-    // consume them.  The scheduler otherwise sinks each ds_read next to its first use and waits lgkmcnt(0) in
-    // front of every MFMA group (measured: 28 % of the wave's life in s_waitcnt); sched_group_barrier pins the
-    // order  [next A reads][next B loads][4*TPW MFMAs]  per group.
-    constexpr int PF = G < 3 ? G : 3;
-    float4 b[PF][TPW];
+    const float4* np[NEXT_TPW > 0 ? NEXT_TPW : 1];
 #pragma unroll
-    for (int p = 0; p < PF; ++p)
+    for (int t = 0; t < NEXT_TPW; ++t) np[t] = lp_bptr<(NEXT_TPW > 0 ? NEXT_TPW : 1)>(next_Wp, G, wave, lane, t);
+    if (!PRE) {
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) b[p][t] = bp[t][p * 64];
+        for (int p = 0; p < LP_PF; ++p)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) b[p][t] = bp[t][p * 64];
+    }
     float4 a_cur[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) a_cur[t] = *reinterpret_cast<const float4*>(ap[t]);
-    __builtin_amdgcn_sched_group_barrier(0x020, PF * TPW, 0);                     // prologue: PF weight groups in flight
-    __builtin_amdgcn_sched_group_barrier(0x100, TPW, 0);                          // and the first A fragments
+    if (!PRE) __builtin_amdgcn_sched_group_barrier(0x020, LP_PF * TPW, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, TPW, 0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         float4 a_nxt[TPW], bc[TPW];
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) bc[t] = b[g % PF][t];
+        for (int t = 0; t < TPW; ++t) bc[t] = b[g % LP_PF][t];
         if (g + 1 < G) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t) a_nxt[t] = *reinterpret_cast<const float4*>(ap[t] + 4 * (g + 1));
         }
-        if (g + PF < G) {
+        if (g + LP_PF < G) {
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) b[g % PF][t] = bp[t][(g + PF) * 64];
+            for (int t = 0; t < TPW; ++t) b[g % LP_PF][t] = bp[t][(g + LP_PF) * 64];
+        } else if (NEXT_TPW > 0) {
+#pragma unroll
+            for (int t = 0; t < NEXT_TPW; ++t) b[g % LP_PF][t] = np[t][(g + LP_PF - G) * 64];
         }
 #pragma unroll
         for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].x, bc[t].x, acc[t], 0, 0, 0);
@@ -123,13 +146,32 @@ __device__ __forceinline__ void lp_gemm(f32x16 (&acc)[TPW], const float* __restr
         for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].z, bc[t].z, acc[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].w, bc[t].w, acc[t], 0, 0, 0);
-        if (g + 1 < G) __builtin_amdgcn_sched_group_barrier(0x100, TPW, 0);       // DS reads of group g+1
-        if (g + PF < G) __builtin_amdgcn_sched_group_barrier(0x020, TPW, 0);      // VMEM reads of group g+PF
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TPW, 0);                  // this group's MFMAs
+        if (g + 1 < G) __builtin_amdgcn_sched_group_barrier(0x100, TPW, 0);
+        if (g + LP_PF < G) __builtin_amdgcn_sched_group_barrier(0x020, TPW, 0);
+        else if (NEXT_TPW > 0) __builtin_amdgcn_sched_group_barrier(0x020, NEXT_TPW, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TPW, 0);
         if (g + 1 < G) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t) a_cur[t] = a_nxt[t];
         }
+    }
+}
+
+// the K = 8 embedding product (one k-group, no ring)
+template <int TPW>
+__device__ __forceinline__ void lp_gemm8(f32x16 (&acc)[TPW], const float* __restrict__ A, int lda,
+                                         const float* __restrict__ Wp, int wave, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const float4 bq = lp_bptr<TPW>(Wp, 1, wave, lane, t)[0];
+        const float4 aq = *reinterpret_cast<const float4*>(A + (((wave * TPW + t) & 1) * 32 + i) * lda + h * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.x, bq.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.y, bq.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.z, bq.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.w, bq.w, acc[t], 0, 0, 0);
     }
 }
 
@@ -203,12 +245,13 @@ __global__ __launch_bounds__(256, 1) void local_pct_kernel(const float* __restri
     }
     __syncthreads();
     f32x16 acc2[2];
+    lp_ring_t ring;
     // ---- Embedding (Attention.py:98-128): linear1 3->125, GELU -> xs ; linear2 125->125 -> sc ; || xyz ----
-    lp_gemm<8, 2, true>(acc2, sc, LP_SLD, mats + lp_mat_off(0), wave, lane);
+    lp_gemm8<2>(acc2, sc, LP_SLD, mats + lp_mat_off(0), wave, lane);
     lp_foreach<2>(acc2, wave, lane, [&](int row, int col, float v) { xs[row * LP_XLD + col] = lp_gelu(v + vecs[LP_VEC_EMB1 + col]); });
     __syncthreads();
     // xyz must survive in sc[:, 0:3] until the concat: linear2's output goes to sc[:, 64:192]
-    lp_gemm<128, 2, true>(acc2, xs, LP_XLD, mats + lp_mat_off(1), wave, lane);
+    lp_gemm128<2, true, false, 3>(acc2, xs, LP_XLD, mats + lp_mat_off(1), ring, mats + lp_mat_off(2), wave, lane);
     lp_foreach<2>(acc2, wave, lane, [&](int row, int col, float v) {
         sc[row * LP_SLD + 64 + col] = col < 125 ? v + vecs[LP_VEC_EMB2 + col] : sc[row * LP_SLD + (col - 125)];   // concat raw xyz
     });
@@ -225,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void local_pct_kernel(const float* __restri
         __syncthreads();
         {
             f32x16 acc3[3];
-            lp_gemm<128, 3, true>(acc3, xs, LP_XLD, em, wave, lane);
+            lp_gemm128<3, true, true, 2>(acc3, xs, LP_XLD, em, ring, em + LP_MAT_QKV, wave, lane);
             lp_foreach<3>(acc3, wave, lane, [&](int row, int col, float v) { sc[row * LP_SLD + col] = fmaf(stats[2 * row + 1], v, ev[col]); });
         }
         __syncthreads();
@@ -275,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void local_pct_kernel(const float* __restri
         }
         __syncthreads();
         // ---- out projection + residual (Attention.py:201-202, 290): x = (x~ + mu) + att W_o^T + b ----
-        lp_gemm<128, 2, true>(acc2, sc + 64, LP_SLD, em + LP_MAT_QKV, wave, lane);
+        lp_gemm128<2, true, true, 2>(acc2, sc + 64, LP_SLD, em + LP_MAT_QKV, ring, em + LP_MAT_QKV + LP_MAT_128, wave, lane);
         lp_foreach<2>(acc2, wave, lane, [&](int row, int col, float v) {
             float* px = xs + row * LP_XLD + col;
             *px = (*px + stats[2 * row]) + (v + ev[192 + col]);
@@ -285,17 +328,26 @@ __global__ __launch_bounds__(256, 1) void local_pct_kernel(const float* __restri
         lp_center(xs, LP_XLD, xs, stats, tid);
         __syncthreads();
         f32x16 accf[2];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            lp_gemm<128, 2, true>(acc2, xs, LP_XLD, em + LP_MAT_QKV + LP_MAT_128 * (1 + half), wave, lane);
-            lp_foreach<2>(acc2, wave, lane, [&](int row, int col, float v) {
-                sc[row * LP_SLD + col] = lp_gelu(fmaf(stats[2 * row + 1], v, ev[192 + 128 + half * 128 + col]));
-            });
-            __syncthreads();
-            if (half == 0) lp_gemm<128, 2, true>(accf, sc, LP_SLD, em + LP_MAT_QKV + LP_MAT_128 * 3, wave, lane);
-            else lp_gemm<128, 2, false>(accf, sc, LP_SLD, em + LP_MAT_QKV + LP_MAT_128 * 4, wave, lane);
-            __syncthreads();
-        }
+        // product order: ff1a, ff2a, ff1b, ff2b; each requests the next one's first weight groups at its tail
+        const float* w_ff1a = em + LP_MAT_QKV + LP_MAT_128 * 1;
+        const float* w_ff1b = em + LP_MAT_QKV + LP_MAT_128 * 2;
+        const float* w_ff2a = em + LP_MAT_QKV + LP_MAT_128 * 3;
+        const float* w_ff2b = em + LP_MAT_QKV + LP_MAT_128 * 4;
+        lp_gemm128<2, true, true, 2>(acc2, xs, LP_XLD, w_ff1a, ring, w_ff2a, wave, lane);
+        lp_foreach<2>(acc2, wave, lane, [&](int row, int col, float v) {
+            sc[row * LP_SLD + col] = lp_gelu(fmaf(stats[2 * row + 1], v, ev[192 + 128 + col]));
+        });
+        __syncthreads();
+        lp_gemm128<2, true, true, 2>(accf, sc, LP_SLD, w_ff2a, ring, w_ff1b, wave, lane);
+        __syncthreads();
+        lp_gemm128<2, true, true, 2>(acc2, xs, LP_XLD, w_ff1b, ring, w_ff2b, wave, lane);
+        lp_foreach<2>(acc2, wave, lane, [&](int row, int col, float v) {
+            sc[row * LP_SLD + col] = lp_gelu(fmaf(stats[2 * row + 1], v, ev[192 + 128 + 128 + col]));
+        });
+        __syncthreads();
+        if (e == 0) lp_gemm128<2, false, true, 3>(accf, sc, LP_SLD, w_ff2b, ring, mats + lp_mat_off(8), wave, lane);   // next: qkv of encoder 1
+        else lp_gemm128<2, false, true, 2>(accf, sc, LP_SLD, w_ff2b, ring, mats + lp_mat_off(14), wave, lane);       // next: linear0
+        __syncthreads();
         lp_foreach<2>(accf, wave, lane, [&](int row, int col, float v) {
             float* px = xs + row * LP_XLD + col;
             *px = (*px + stats[2 * row]) + (v + ev[192 + 128 + 256 + col]);
@@ -307,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void local_pct_kernel(const float* __restri
     // ---- final norm (folded) + linear0 128 -> 128 (SconeOcc.py:119-122) ----
     lp_center(xs, LP_XLD, xs, stats, tid);
     __syncthreads();
-    lp_gemm<128, 2, true>(acc2, xs, LP_XLD, mats + lp_mat_off(14), wave, lane);
+    lp_gemm128<2, true, true, 0>(acc2, xs, LP_XLD, mats + lp_mat_off(14), ring, nullptr, wave, lane);
     lp_foreach<2>(acc2, wave, lane, [&](int row, int col, float v) { sc[row * LP_SLD + col] = fmaf(stats[2 * row + 1], v, vecs[LP_VEC_LIN0 + col]); });
     __syncthreads();
     // ---- max || avg pool over the 16 tokens of each query (SconeOcc.py:124-126) ----
