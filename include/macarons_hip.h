@@ -112,7 +112,13 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
  * following linear layer).  mcr_scone_occ_forward uses the fused kernel for scale i when local_blobs != NULL and
  * local_blobs[i] != NULL (HOST array of 3 device pointers), else the layer-by-layer path. */
 int mcr_local_pct_blob_floats(void);
-int mcr_set_local_pct_variant(int variant);   /* 1 (default): one workgroup/CU kernel; 2: experimental two-workgroups/CU kernel */
+int mcr_local_pct3_blob_floats(void);
+/* Kernel variant behind mcr_local_pct_forward / the fused path of mcr_scone_occ_forward.  The blob must have been packed
+ * for the selected variant: 1: exact-fp32 MFMA, one workgroup/CU (local_pct.hip); 2: experimental two-workgroups/CU
+ * layout (local_pct2.hip, same blob as 1); 3: split-precision bf16x6 matrix products, fp32-class accuracy
+ * (local_pct3.hip, blob of mcr_local_pct3_blob_floats() floats). */
+int mcr_set_local_pct_variant(int variant);
+int mcr_get_local_pct_variant(void);
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,
                           void* stream);
 

@@ -146,17 +146,21 @@ int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t
     return 0;
 }
 
+int mcr_get_local_pct_variant(void);
 int mcr_local_pct_blob_floats(void) { return local_pct_blob_floats(); }
+int mcr_local_pct3_blob_floats(void) { return local_pct3_blob_floats(); }
 
 static int g_local_pct_variant = 1;      // 1 (default, measured faster): local_pct.hip, 1 workgroup/CU; 2: local_pct2.hip, 2 workgroups/CU (spills)
 int mcr_set_local_pct_variant(int v) {
-    MCR_REQUIRE(v == 1 || v == 2, "mcr_set_local_pct_variant: variant must be 1 or 2");
+    MCR_REQUIRE(v >= 1 && v <= 3, "mcr_set_local_pct_variant: variant must be 1, 2 or 3");
     g_local_pct_variant = v;
     return 0;
 }
+int mcr_get_local_pct_variant(void) { return g_local_pct_variant; }
 static void run_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld, int64_t S, const float* blob) {
     if (g_local_pct_variant == 1) launch_local_pct(s, offs, feat, ld, S, blob);
-    else launch_local_pct2(s, offs, feat, ld, S, blob);
+    else if (g_local_pct_variant == 2) launch_local_pct2(s, offs, feat, ld, S, blob);
+    else launch_local_pct3(s, offs, feat, ld, S, blob);
 }
 
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,

@@ -40,6 +40,8 @@ void launch_copy2d(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t
 // `blob` is the host-packed parameter image of one local transformer (local_pct_blob_floats() floats).
 void launch_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);
 void launch_local_pct2(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);
+void launch_local_pct3(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);
 int local_pct_blob_floats();
+int local_pct3_blob_floats();
 
 }  // namespace mcr

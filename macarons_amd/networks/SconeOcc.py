@@ -10,7 +10,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .. import ops
+from .. import ops, _lib
 from .Attention import Embedding, Encoder, _f32c, _inference_only
 from .packing import BlobCache
 
@@ -160,6 +160,10 @@ class SconeOcc(nn.Module):
         scales = [pc.contiguous()]
         for p in perms[1:]:
             scales.append(scales[-1][:, p.to(dev)].contiguous())                      # :311
-        blobs = [c.get(t) for c, t in zip(self._blob_caches, self.local_transformers)] if self.fused_local else None
+        if self.fused_local:
+            variant = _lib.lib().mcr_get_local_pct_variant()
+            blobs = [c.get(t, variant) for c, t in zip(self._blob_caches, self.local_transformers)]
+        else:
+            blobs = None
         res = ops.scone_occ_forward(pc_global, scales, x, view_harmonics, self.weight_table(), blobs)
         return res.view(n_clouds, n_sample, self.output_dim)

@@ -38,8 +38,31 @@ def _padv(v, n):
     return out
 
 
-def pack_local_pct(pct):
-    """pct: macarons_amd.networks.SconeOcc.PCTransformer (default local architecture). Returns a 1-D fp32 tensor."""
+def _pack_bf16x3(W):
+    """[N, K] fp32 -> exact hi/mid/lo bf16 planes in the fragment order of local_pct3.hip
+    [N/32][K/16][plane][64 lanes][8], returned as a float32-typed view (1.5 floats per weight).
+    hi = W with the low 16 bits cleared, mid likewise from the exact remainder, lo = the exact rest: hi+mid+lo == W."""
+    N, K = W.shape
+    assert N % 32 == 0 and K % 16 == 0
+    top = lambda t: (t.contiguous().view(torch.int32) >> 16).to(torch.int16)
+    mask = lambda t: (t.contiguous().view(torch.int32) & -65536).view(torch.float32)
+    hi = mask(W)
+    r = W - hi
+    mid = mask(r)
+    lo = r - mid
+    assert torch.equal(hi + mid + lo, W) and torch.equal(mask(lo), lo)
+    planes = torch.stack([top(hi), top(mid), top(lo)], 0)                       # [3, N, K] int16 (bf16 bit patterns)
+    t = planes.reshape(3, N // 32, 32, K // 16, 2, 8)                           # [pl, nt, j, s, h, e]
+    t = t.permute(1, 3, 0, 4, 2, 5).contiguous()                                # [nt, s, pl, h, j, e]
+    return t.reshape(-1).view(torch.float32)
+
+
+def pack_local_pct(pct, variant=1):
+    """pct: macarons_amd.networks.SconeOcc.PCTransformer (default local architecture). Returns a 1-D fp32 tensor.
+    variant 1/2: fp32 fragment image (local_pct.hip / local_pct2.hip); variant 3: exact bf16 hi/mid/lo planes
+    (local_pct3.hip, split-precision matrix products)."""
+    if variant == 3:
+        return _pack_local_pct3(pct)
     with torch.no_grad():
         f = lambda p: p.detach().float()
         mats, vecs, svecs = [], [], []
@@ -76,8 +99,37 @@ class BlobCache:
     def __init__(self):
         self._key, self._blob = None, None
 
-    def get(self, pct):
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in pct.parameters())
+    def get(self, pct, variant=1):
+        key = (variant,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in pct.parameters())
         if key != self._key:
-            self._blob, self._key = pack_local_pct(pct), key
+            self._blob, self._key = pack_local_pct(pct, variant), key
         return self._blob
+
+
+def _pack_local_pct3(pct):
+    with torch.no_grad():
+        f = lambda p: p.detach().float()
+        mats, vecs = [], []
+        emb = pct.embedding
+        mats.append(_pack_bf16x3(_pad(f(emb.linear1.weight), 128, 16)))
+        mats.append(_pack_bf16x3(_pad(f(emb.linear2.weight), 128, 128)))
+        vecs += [_padv(f(emb.linear1.bias), 128), _padv(f(emb.linear2.bias), 128)]
+        for enc in pct.encoders:
+            g1, b1 = f(enc.norm1.weight), f(enc.norm1.bias)
+            g2, b2 = f(enc.norm2.weight), f(enc.norm2.bias)
+            wqkv = torch.cat((f(enc.mhsa.w_q.weight), f(enc.mhsa.w_k.weight), f(enc.mhsa.w_v.weight)), 0)
+            bqkv = torch.cat((f(enc.mhsa.w_q.bias), f(enc.mhsa.w_k.bias), f(enc.mhsa.w_v.bias)), 0)
+            w1, w2 = f(enc.ff.linear1.weight), f(enc.ff.linear2.weight)
+            mats += [_pack_bf16x3(wqkv * g1[None, :]), _pack_bf16x3(f(enc.mhsa.out.weight)),
+                     _pack_bf16x3((w1 * g2[None, :])[:128].contiguous()), _pack_bf16x3((w1 * g2[None, :])[128:].contiguous()),
+                     _pack_bf16x3(w2[:, :128].contiguous()), _pack_bf16x3(w2[:, 128:].contiguous())]
+            vecs += [bqkv + wqkv @ b1, f(enc.mhsa.out.bias), f(enc.ff.linear1.bias) + w1 @ b2, f(enc.ff.linear2.bias)]
+        gn, bn = f(pct.norm.weight), f(pct.norm.bias)
+        w0 = f(pct.linear0.weight)
+        mats.append(_pack_bf16x3(w0 * gn[None, :]))
+        vecs.append(f(pct.linear0.bias) + w0 @ bn)
+        blob = torch.cat(mats + vecs).contiguous()
+    expect = _lib.lib().mcr_local_pct3_blob_floats()
+    if blob.numel() != expect:
+        raise RuntimeError(f"packed local transformer (v3) has {blob.numel()} floats, kernel expects {expect}")
+    return blob

@@ -1,22 +1,29 @@
 import sys, os, torch, io, contextlib, time, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+import numpy as np
+import weights
+from oracle import nets
 from macarons_amd import ops, _lib
 from macarons_amd.networks import SconeOcc
 from macarons_amd.networks.packing import pack_local_pct
 dev = torch.device("cuda:0")
 with contextlib.redirect_stdout(io.StringIO()):
-    occ = SconeOcc().to(dev)
-blob = pack_local_pct(occ.local_transformers[0])
+    occ = SconeOcc()
+sd = weights.make_state_dict(weights.shapes_of(occ), 2)
+occ.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+occ = occ.to(dev)
 S = 16384
 offs = torch.randn(S, 16, 3, device=dev) * 0.05
-outs = {}
-for rnd in range(3):
-    for v in (1, 2):
+ref = nets.pc_transformer(sd, "local_transformers.0.", offs[:600].cpu().numpy(), np.float64)
+variants = [int(v) for v in os.environ.get("VARIANTS", "1,3").split(",")]
+for rnd in range(2):
+    for v in variants:
         _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(v))
+        blob = pack_local_pct(occ.local_transformers[0], v)
         for _ in range(3): y = ops.local_pct_forward(offs, blob)
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(20): y = ops.local_pct_forward(offs, blob)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 20
-        outs[v] = y
-        print(f"variant {v}: {dt*1e3:.3f} ms  {S*8.0e6/dt/1e12:.1f} TFLOP/s")
-print("max rel diff v1 vs v2:", float((outs[1] - outs[2]).abs().max() / outs[1].abs().max()))
+        err = float(np.abs(y[:600].cpu().numpy() - ref).max() / np.abs(ref).max())
+        print(f"variant {v}: {dt*1e3:.3f} ms  {S*8.0e6/dt/1e12:.1f} TFLOP/s-equivalent   rel err vs fp64 oracle {err:.2e}")
