@@ -121,32 +121,51 @@ def measure_nbv_step(dev, rank, world, args):
 
 
 def measure_local_pct(dev):
-    """Roofline of the dominant kernel of the NBV step (fused local transformer, fp32 MFMA): HIP events around
-    back-to-back launches on the launch stream."""
-    from macarons_amd import ops
+    """Roofline of the dominant kernel of the NBV step (fused local transformer): HIP events around back-to-back
+    launches on the launch stream.  Default kernel = split-precision bf16x6 (local_pct3.hip): every algorithmic
+    fp32 multiply-add runs as 6 bf16 MFMA multiply-adds, so the matrix pipe executes 6x the algorithmic GEMM flops and
+    is priced against the dense bf16 MFMA peak; the exact-fp32-MFMA kernel (local_pct.hip) is timed beside it."""
+    import ctypes
+    from macarons_amd import ops, _lib
     from macarons_amd.networks import SconeOcc
     from macarons_amd.networks.packing import pack_local_pct
     import io, contextlib
     with contextlib.redirect_stdout(io.StringIO()):
         occ = SconeOcc().to(dev)
-    blob = pack_local_pct(occ.local_transformers[0])
     S = 16384
     offs = torch.randn(S, 16, 3, device=dev) * 0.05
-    for _ in range(3):
-        ops.local_pct_forward(offs, blob)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 20
-    e0.record()
-    for _ in range(n):
-        ops.local_pct_forward(offs, blob)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
-    flops = S * (16 * 0.49e6 + 0.164e6)                    # SURVEY Appendix B: 16 tokens x 0.49 MF + attention 0.16 MF
-    ach = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "local_pct_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_FP32_TFLOPS, "traffic": None, "device_ms_per_launch": ms, "queries_per_launch": S,
-            "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) peak = 157.3 TFLOP/s"}
+    gemm_flops = S * 16 * 0.49e6                            # SURVEY Appendix B: 0.49 MFLOP per token in linear layers
+    alg_flops = gemm_flops + S * 0.164e6                    # + 16x16 attention per query
+    L = _lib.lib()
+    default_variant = L.mcr_get_local_pct_variant()
+    out = {}
+    for v in (1, 3):
+        L.mcr_set_local_pct_variant(ctypes.c_int(v))
+        blob = pack_local_pct(occ.local_transformers[0], v)
+        for _ in range(3):
+            ops.local_pct_forward(offs, blob)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            ops.local_pct_forward(offs, blob)
+        e1.record()
+        torch.cuda.synchronize()
+        out[v] = e0.elapsed_time(e1) / n
+    L.mcr_set_local_pct_variant(ctypes.c_int(default_variant))
+    ms = out[default_variant]
+    if default_variant == 3:
+        executed = 6.0 * gemm_flops / (ms * 1e-3) / 1e12
+        peak, kern, note = 2500.0, "local_pct3_kernel", "bf16 MFMA dense peak 2.5 PFLOP/s; 6 bf16 MFMAs per exact fp32 product"
+    else:
+        executed = gemm_flops / (ms * 1e-3) / 1e12
+        peak, kern, note = PEAK_FP32_TFLOPS, "local_pct_kernel", "fp32 MFMA (v_mfma_f32_32x32x2_f32) peak = 157.3 TFLOP/s"
+    return {"kernel": kern, "bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak,
+            "traffic": None, "device_ms_per_launch": ms, "queries_per_launch": S,
+            "algorithmic_fp32_TFLOPs": alg_flops / (ms * 1e-3) / 1e12, "note": note,
+            "exact_fp32_mfma_variant": {"kernel": "local_pct_kernel", "device_ms_per_launch": out[1],
+                                        "achieved": gemm_flops / (out[1] * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
+                                        "frac": gemm_flops / (out[1] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}}
 
 
 def main():

@@ -147,23 +147,51 @@ def test_scone_occ_chunking_and_batch(dev):
     assert rel_err(y[:, sel], ref) < TOL
 
 
-def test_fused_local_transformer(dev):
-    """local_pct.hip (fused, LayerNorm folded) vs the layer-by-layer HIP path and the fp64 oracle."""
-    from macarons_amd import ops
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_fused_local_transformer(dev, variant):
+    """Fused local transformer kernels (1: exact-fp32 MFMA, 2: two-workgroup layout, 3: split-precision bf16x6) vs the
+    layer-by-layer HIP path and the fp64 oracle.  All three must be fp32-class: 2e-5, far inside the 1e-4 bar."""
+    import ctypes
+    from macarons_amd import ops, _lib
     from macarons_amd.networks import SconeOcc
     from macarons_amd.networks.packing import pack_local_pct
     m, sd = _mod(SconeOcc, 2, dev)
     rng = np.random.default_rng(4)
-    for S in (1, 3, 4, 1001):
-        offs = (rng.standard_normal((S, 16, 3)) * 0.05).astype(np.float32)
-        for sc in range(3):
-            lt = m.local_transformers[sc]
-            with torch.no_grad():
-                fused = ops.local_pct_forward(T(offs, dev), pack_local_pct(lt)).cpu().numpy()
-                plain = lt(T(offs, dev)).cpu().numpy()
-            ref = nets.pc_transformer(sd, f"local_transformers.{sc}.", offs, np.float64)
-            assert rel_err(fused, ref) < TOL and rel_err(plain, ref) < TOL
-            assert rel_err(fused, plain) < TOL
+    prev = _lib.lib().mcr_get_local_pct_variant()
+    _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(variant))
+    try:
+        for S in (1, 3, 4, 1001):
+            offs = (rng.standard_normal((S, 16, 3)) * (0.05 if S != 3 else 0.5)).astype(np.float32)
+            for sc in range(3):
+                lt = m.local_transformers[sc]
+                with torch.no_grad():
+                    fused = ops.local_pct_forward(T(offs, dev), pack_local_pct(lt, variant)).cpu().numpy()
+                    plain = lt(T(offs, dev)).cpu().numpy()
+                ref = nets.pc_transformer(sd, f"local_transformers.{sc}.", offs, np.float64)
+                assert rel_err(fused, ref) < 2e-5 and rel_err(plain, ref) < 2e-5
+    finally:
+        _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(prev))
+
+
+def test_split_precision_is_exact_split(dev):
+    """The host-side hi/mid/lo bf16 planes of the v3 blob reconstruct every weight bit for bit (asserted inside
+    _pack_bf16x3) and the kernel's result does not depend on the magnitude scale of the inputs."""
+    import ctypes
+    from macarons_amd import ops, _lib
+    from macarons_amd.networks import SconeOcc
+    from macarons_amd.networks.packing import pack_local_pct
+    m, sd = _mod(SconeOcc, 2, dev)
+    rng = np.random.default_rng(6)
+    offs = (rng.standard_normal((257, 16, 3)) * 0.05).astype(np.float32)
+    prev = _lib.lib().mcr_get_local_pct_variant()
+    try:
+        out = {}
+        for v in (1, 3):
+            _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(v))
+            out[v] = ops.local_pct_forward(T(offs, dev), pack_local_pct(m.local_transformers[1], v)).cpu().numpy()
+        assert rel_err(out[3], out[1]) < 5e-6
+    finally:
+        _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(prev))
 
 
 def test_scone_occ_fused_equals_unfused(dev):
