@@ -150,9 +150,9 @@ int mcr_get_local_pct_variant(void);
 int mcr_local_pct_blob_floats(void) { return local_pct_blob_floats(); }
 int mcr_local_pct3_blob_floats(void) { return local_pct3_blob_floats(); }
 
-static int g_local_pct_variant = 3;      // 1: local_pct.hip exact-fp32 MFMA; 2: local_pct2.hip (experimental); 3 (default): local_pct3.hip split-precision bf16x6
+static int g_local_pct_variant = 3;      // 1: local_pct.hip exact-fp32 MFMA; 2: local_pct2.hip (experimental); 3 (default): local_pct3.hip split-precision bf16x6; 4: local_pct4.hip = 3 with two workgroups/CU (same blob as 3)
 int mcr_set_local_pct_variant(int v) {
-    MCR_REQUIRE(v >= 1 && v <= 3, "mcr_set_local_pct_variant: variant must be 1, 2 or 3");
+    MCR_REQUIRE(v >= 1 && v <= 4, "mcr_set_local_pct_variant: variant must be 1..4");
     g_local_pct_variant = v;
     return 0;
 }
@@ -160,6 +160,7 @@ int mcr_get_local_pct_variant(void) { return g_local_pct_variant; }
 static void run_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld, int64_t S, const float* blob) {
     if (g_local_pct_variant == 1) launch_local_pct(s, offs, feat, ld, S, blob);
     else if (g_local_pct_variant == 2) launch_local_pct2(s, offs, feat, ld, S, blob);
+    else if (g_local_pct_variant == 4) launch_local_pct4(s, offs, feat, ld, S, blob);
     else launch_local_pct3(s, offs, feat, ld, S, blob);
 }
 

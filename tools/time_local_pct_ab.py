@@ -5,6 +5,8 @@ import numpy as np
 import weights
 from oracle import nets
 from macarons_amd import ops, _lib
+if os.environ.get("MCR_DEV_LIB"):      # experimental build from tools/build_variant.py
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_libs", f"libmacarons_hip_{os.environ['MCR_DEV_LIB']}.so")
 from macarons_amd.networks import SconeOcc
 from macarons_amd.networks.packing import pack_local_pct
 dev = torch.device("cuda:0")
@@ -26,4 +28,4 @@ for rnd in range(2):
         for _ in range(20): y = ops.local_pct_forward(offs, blob)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 20
         err = float(np.abs(y[:600].cpu().numpy() - ref).max() / np.abs(ref).max())
-        print(f"variant {v}: {dt*1e3:.3f} ms  {S*8.0e6/dt/1e12:.1f} TFLOP/s-equivalent   rel err vs fp64 oracle {err:.2e}")
+        print(f"[{os.environ.get('MCR_DEV_LIB', 'main')}] variant {v}: {dt*1e3:.3f} ms  {S*8.0e6/dt/1e12:.1f} TFLOP/s-equivalent   rel err vs fp64 oracle {err:.2e}")
