@@ -43,6 +43,26 @@ struct Split3 { uint4 hi, mid, lo; };
 __device__ __forceinline__ unsigned pack_top(float a, float b) {           // {top16(b), top16(a)}: element 0 in the low half
     return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
 }
+#ifdef L3_SPLIT_PK          // experiment: residuals with v_pk_add_f32 (two elements per instruction)
+typedef float l3_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned l3_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ Split3 split8(const float4 p, const float4 q) {
+    const l3_f32x2 x[4] = {{p.x, p.y}, {p.z, p.w}, {q.x, q.y}, {q.z, q.w}};
+    l3_f32x2 r[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const l3_f32x2 hi = __builtin_bit_cast(l3_f32x2, __builtin_bit_cast(l3_u32x2, x[e]) & 0xffff0000u);
+        r[e] = x[e] - hi;
+        const l3_f32x2 mid = __builtin_bit_cast(l3_f32x2, __builtin_bit_cast(l3_u32x2, r[e]) & 0xffff0000u);
+        r2[e] = r[e] - mid;
+    }
+    Split3 s;
+    s.hi = make_uint4(pack_top(x[0].x, x[0].y), pack_top(x[1].x, x[1].y), pack_top(x[2].x, x[2].y), pack_top(x[3].x, x[3].y));
+    s.mid = make_uint4(pack_top(r[0].x, r[0].y), pack_top(r[1].x, r[1].y), pack_top(r[2].x, r[2].y), pack_top(r[3].x, r[3].y));
+    s.lo = make_uint4(pack_top(r2[0].x, r2[0].y), pack_top(r2[1].x, r2[1].y), pack_top(r2[2].x, r2[2].y), pack_top(r2[3].x, r2[3].y));
+    return s;
+}
+#else
 __device__ __forceinline__ Split3 split8(const float4 p, const float4 q) {
     const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
     float r[8], r2[8];
@@ -59,6 +79,7 @@ __device__ __forceinline__ Split3 split8(const float4 p, const float4 q) {
     s.lo = make_uint4(pack_top(r2[0], r2[1]), pack_top(r2[2], r2[3]), pack_top(r2[4], r2[5]), pack_top(r2[6], r2[7]));
     return s;
 }
+#endif
 __device__ __forceinline__ f32x16 mfma_bf(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }

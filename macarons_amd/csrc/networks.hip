@@ -150,7 +150,7 @@ int mcr_get_local_pct_variant(void);
 int mcr_local_pct_blob_floats(void) { return local_pct_blob_floats(); }
 int mcr_local_pct3_blob_floats(void) { return local_pct3_blob_floats(); }
 
-static int g_local_pct_variant = 3;      // 1: local_pct.hip exact-fp32 MFMA; 2: local_pct2.hip (experimental); 3 (default): local_pct3.hip split-precision bf16x6; 4: local_pct4.hip = 3 with two workgroups/CU (same blob as 3)
+static int g_local_pct_variant = 4;      // 1: local_pct.hip exact-fp32 MFMA; 2: local_pct2.hip (experimental); 3: local_pct3.hip split-precision bf16x6; 4 (default): local_pct4.hip = 3 restructured for two workgroups/CU (same blob as 3)
 int mcr_set_local_pct_variant(int v) {
     MCR_REQUIRE(v >= 1 && v <= 4, "mcr_set_local_pct_variant: variant must be 1..4");
     g_local_pct_variant = v;
