@@ -122,7 +122,7 @@ def measure_nbv_step(dev, rank, world, args):
 
 def measure_local_pct(dev):
     """Roofline of the dominant kernel of the NBV step (fused local transformer): HIP events around back-to-back
-    launches on the launch stream.  Default kernel = split-precision bf16x6 (local_pct4.hip): every algorithmic
+    launches on the launch stream.  Default kernel = split-precision bf16x6 (local_pct5.hip): every algorithmic
     fp32 multiply-add runs as 6 bf16 MFMA multiply-adds, so the matrix pipe executes 6x the algorithmic GEMM flops and
     is priced against the dense bf16 MFMA peak; the exact-fp32-MFMA kernel (local_pct.hip) is timed beside it."""
     import ctypes
@@ -154,7 +154,7 @@ def measure_local_pct(dev):
         out[v] = e0.elapsed_time(e1) / n
     L.mcr_set_local_pct_variant(ctypes.c_int(default_variant))
     ms = out[default_variant]
-    if default_variant in (3, 4):
+    if default_variant in (3, 4, 5):
         executed = 6.0 * gemm_flops / (ms * 1e-3) / 1e12
         peak, kern, note = 2500.0, f"local_pct{default_variant}_kernel", "bf16 MFMA dense peak 2.5 PFLOP/s; 6 bf16 MFMAs per exact fp32 product"
     else:

@@ -117,7 +117,8 @@ int mcr_local_pct3_blob_floats(void);
  * for the selected variant: 1: exact-fp32 MFMA, one workgroup/CU (local_pct.hip); 2: experimental two-workgroups/CU
  * layout (local_pct2.hip, same blob as 1); 3: split-precision bf16x6 matrix products, fp32-class accuracy
  * (local_pct3.hip, blob of mcr_local_pct3_blob_floats() floats); 4: variant 3 restructured for two workgroups per CU
- * (local_pct4.hip: residual stream in registers, 67.6 KB LDS; same blob as 3). */
+ * (local_pct4.hip: residual stream in registers, 67.6 KB LDS; same blob as 3); 5 (default): variant 4 with the
+ * LayerNorm outputs kept pre-split (bf16 planes) in an 80 KB swizzled LDS image (local_pct5.hip; same blob as 3). */
 int mcr_set_local_pct_variant(int variant);
 int mcr_get_local_pct_variant(void);
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,

@@ -1,0 +1,428 @@
+// K5-local v5 — v4 (split-precision, two workgroups per CU) with the LayerNorm outputs kept PRE-SPLIT in LDS.
+//
+// Same mathematics and parameter blob as local_pct3/4.hip (exact bf16 hi/mid/lo split, six MFMAs per fp32 product;
+// reference mapping in local_pct.hip: SconeOcc.py:104-130).  In v4 every wave splits the A rows of both m-tiles on
+// the fly, i.e. each activation is split by all four waves: 66 % of the kernel's vector instructions, and the vector
+// ALU, not the matrix pipe, is what the two resident workgroups saturate.  The operands that come out of a LayerNorm
+// (A of qkv, ff1a+ff1b, linear0: 8 of the 14 products) are produced row-wise by l5_norm anyway, so it writes them as
+// three bf16 planes once and those products read ready-made MFMA fragments (3 x ds_read_b128 per 32 x 16 block).
+// The other operands (attention output, FF hidden halves, embedding) stay fp32 and are split on the fly as in v4.
+//
+// LDS = exactly 80 KB (two workgroups per CU), both tiles XOR-swizzled in 16-byte chunks by (row & 15) instead of
+// padded:   P  48 KB  x^ as planes [3][64 rows][16 chunks of 8 bf16], or q|k as fp32 [64][64] during attention
+//           F  32 KB  fp32 [64][128]: raw x for the LayerNorm / v and the attention output / a half of the FF hidden
+#include "lp_split.h"
+
+namespace mcr {
+
+// ---- swizzled addressing ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ int f_idx(int row, int col) { return row * 128 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); }
+__device__ __forceinline__ int f_chunk(int row, int chunk) { return row * 128 + ((chunk ^ (row & 15)) << 2); }     // float index of a float4
+__device__ __forceinline__ int q_idx(int row, int col) { return row * 64 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); }
+__device__ __forceinline__ int q_chunk(int row, int chunk) { return row * 64 + ((chunk ^ (row & 15)) << 2); }
+__device__ __forceinline__ int p_chunk(int plane, int row, int chunk) { return (plane * 64 + row) * 16 + (chunk ^ (row & 15)); }   // uint4 index
+
+// The swizzled addresses are loop-invariant functions of the lane; left alone, LLVM hoists all of them out of the encoder
+// loop and spills them (172 scratch stores).  Re-deriving them from an opaque copy of the lane id per phase is cheaper.
+__device__ __forceinline__ int l5_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+#ifdef L5_PROBE_SAMEW       // timing probes only (wrong results)
+#define L5_IDX(i) ((i) % 192)
+#else
+#define L5_IDX(i) (i)
+#endif
+#ifndef L5_PF_N
+#define L5_PF_N 3
+#endif
+constexpr int L5_PF = L5_PF_N;                    // k16-steps of weights in flight per wave
+
+// acc[u][mt] (+)= A[64 x 16 S] * W^T; wave owns n-tiles {nt0 + 4u} for both m-tiles (see local_pct4.hip).
+// PLANES: A comes pre-split from P (uint4 planes); else fp32 from F, split here.
+template <int S, int NTW, bool INIT, bool PLANES>
+__device__ __forceinline__ void l5_gemm(f32x16 (&acc)[NTW][2], const void* __restrict__ Asrc, const float* __restrict__ Wp,
+                                        int nt0, int lane_) {
+    const int lane = l5_opaque(lane_);
+    const int i = lane & 31, h = lane >> 5, key = i & 15;
+    const uint4* bp[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        bp[u] = reinterpret_cast<const uint4*>(Wp) + (size_t)(nt0 + 4 * u) * S * 3 * 64 + lane;
+        if (INIT) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][mt][r] = 0.f;
+        }
+    }
+    constexpr int PF = S < L5_PF ? S : L5_PF;
+    uint4 b[PF][NTW][3];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int u = 0; u < NTW; ++u)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[p][u][pl] = bp[u][L5_IDX((p * 3 + pl) * 64)];
+    const float* F = reinterpret_cast<const float*>(Asrc);
+    const uint4* P = reinterpret_cast<const uint4*>(Asrc);
+    float4 ra[2][2];                                        // fp32 mode: raw A rows of the next step
+    Split3 sn[2];                                           // planes mode: fragments of the next step
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (PLANES) {
+                const int c = (2 * s + h) ^ key;
+                sn[mt].hi = P[(0 * 64 + mt * 32 + i) * 16 + c];
+                sn[mt].mid = P[(1 * 64 + mt * 32 + i) * 16 + c];
+                sn[mt].lo = P[(2 * 64 + mt * 32 + i) * 16 + c];
+            } else {
+                const float* row = F + (mt * 32 + i) * 128;
+                ra[mt][0] = *reinterpret_cast<const float4*>(row + (((4 * s + 2 * h) ^ key) << 2));
+                ra[mt][1] = *reinterpret_cast<const float4*>(row + (((4 * s + 2 * h + 1) ^ key) << 2));
+            }
+        }
+    };
+    fetch(0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        Split3 sa[2];
+#pragma unroll
+#ifdef L5_PROBE_NOSPLIT
+        for (int mt = 0; mt < 2; ++mt) {
+            if (PLANES) sa[mt] = sn[mt];
+            else { sa[mt].hi = __builtin_bit_cast(uint4, ra[mt][0]); sa[mt].mid = __builtin_bit_cast(uint4, ra[mt][1]); sa[mt].lo = sa[mt].hi; }
+        }
+#else
+        for (int mt = 0; mt < 2; ++mt) sa[mt] = PLANES ? sn[mt] : split8(ra[mt][0], ra[mt][1]);
+#endif
+        if (s + 1 < S) fetch(s + 1);
+        uint4 bc[NTW][3];
+#pragma unroll
+        for (int u = 0; u < NTW; ++u)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bc[u][pl] = b[s % PF][u][pl];
+        if (s + PF < S) {
+#pragma unroll
+            for (int u = 0; u < NTW; ++u)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[s % PF][u][pl] = bp[u][L5_IDX(((s + PF) * 3 + pl) * 64)];
+        }
+#pragma unroll
+        for (int u = 0; u < NTW; ++u)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[u][mt] = mfma_bf(sa[mt].lo, bc[u][0], acc[u][mt]);      // smallest terms first
+                acc[u][mt] = mfma_bf(sa[mt].hi, bc[u][2], acc[u][mt]);
+                acc[u][mt] = mfma_bf(sa[mt].mid, bc[u][1], acc[u][mt]);
+                acc[u][mt] = mfma_bf(sa[mt].mid, bc[u][0], acc[u][mt]);
+                acc[u][mt] = mfma_bf(sa[mt].hi, bc[u][1], acc[u][mt]);
+                acc[u][mt] = mfma_bf(sa[mt].hi, bc[u][0], acc[u][mt]);
+            }
+    }
+}
+
+// Write one 64 x 32 column block held as C fragments (t[0], t[1] = the two m-tiles; lane (j, h) owns column j and rows
+// mt*32 + (r&3) + 8(r>>2) + 4h) into a swizzled fp32 tile with row stride LD at column tile ct, through g(value).
+// row & 15 = Kc(r) | 4h with Kc(r) = (r&3) + 8((r>>2)&1), so the swizzle splits into a per-lane word w and a compile-time
+// XOR: one v_xor per element, the row part goes into the ds_write offset field.
+template <int LD, class G>
+__device__ __forceinline__ void l5_put(const f32x16 (&t)[2], float* buf, int ct, int lane_, G g) {
+    const int lane = l5_opaque(lane_);
+    const int j = lane & 31, h = lane >> 5;
+    const int w = ((((ct << 3) | (j >> 2)) ^ (h << 2)) << 2) | (j & 3) | (h * 4 * LD);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            buf[(mt * 32 + (r & 3) + 8 * (r >> 2)) * LD + (w ^ ((((r & 3) + 8 * ((r >> 2) & 1))) << 2))] = g((float)t[mt][r]);
+}
+
+// LayerNorm (eps 1e-5, affine folded into the next weights) of the 64 rows of F, written as bf16 planes into P:
+// 4 threads per row, 32 columns each; two-pass (mean, then centred variance) like torch's.
+__device__ __forceinline__ void l5_norm(const float* F, uint4* P, int tid_) {
+    const int tid = l5_opaque(tid_);
+    const int row = tid >> 2, part = tid & 3;
+    float v[32];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 q = *reinterpret_cast<const float4*>(F + f_chunk(row, part * 8 + c));
+        v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
+        sum += (q.x + q.y) + (q.z + q.w);
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    const float mu = sum * (1.0f / 128.f);
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        v[c] -= mu;
+        sq = fmaf(v[c], v[c], sq);
+    }
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    const float rstd = 1.0f / sqrtf(sq * (1.0f / 128.f) + 1e-5f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const Split3 s = split8(make_float4(v[8 * c] * rstd, v[8 * c + 1] * rstd, v[8 * c + 2] * rstd, v[8 * c + 3] * rstd),
+                                make_float4(v[8 * c + 4] * rstd, v[8 * c + 5] * rstd, v[8 * c + 6] * rstd, v[8 * c + 7] * rstd));
+        P[p_chunk(0, row, part * 4 + c)] = s.hi;
+        P[p_chunk(1, row, part * 4 + c)] = s.mid;
+        P[p_chunk(2, row, part * 4 + c)] = s.lo;
+    }
+}
+
+#ifdef L5_TRACE             // dev only: per-phase timestamps of one workgroup (tools/build_variant.py ... -DL5_TRACE=<block>)
+__device__ long long l5_trace_buf[64];
+#define L5_T() do { if (blockIdx.x == (L5_TRACE) && tid == 0) l5_trace_buf[tp] = clock64(); ++tp; } while (0)
+extern "C" int mcr_dev_read_trace(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(l5_trace_buf), sizeof(long long) * 64); }
+#else
+#define L5_T() do { } while (0)
+#endif
+
+// grid = ceil(S / 4); S sequences of 16 offsets [S,16,3]; features[s*ld_feat + 0:256] = max(128) || avg(128)
+__global__ __launch_bounds__(256, 2) void local_pct5_kernel(const float* __restrict__ offs, float* __restrict__ feat,
+                                                          long long ld_feat, long long S,
+                                                          const float* __restrict__ blob) {
+    __shared__ __attribute__((aligned(16))) uint4 P[3 * 64 * 16];
+    __shared__ __attribute__((aligned(16))) float F[64 * 128];
+    float* Pq = reinterpret_cast<float*>(P);               // fp32 [64][64] view: q | k, and the raw xyz during the embedding
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* mats = blob;
+    const float* vecs = blob + L3_MATS_TOTAL;
+    const long long s0 = (long long)blockIdx.x * L3_QPB;
+    int tp = 0; (void)tp;
+    L5_T();
+#if defined(L5_PRIO)        // experiments: de-phase the two co-resident workgroups of a CU
+    {
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11));
+        const unsigned sel = L5_PRIO == 1 ? (hw & 1u) : L5_PRIO == 2 ? ((hw >> 16) & 1u) : ((blockIdx.x >> 8) & 1u);
+        if (sel) {
+#ifdef L5_SLEEP
+            for (int k = 0; k < L5_SLEEP; ++k) __builtin_amdgcn_s_sleep(127);
+#else
+            __builtin_amdgcn_s_setprio(3);
+#endif
+        }
+    }
+#endif
+
+    // ---- stage the 64 x 3 offsets, zero-padded to K = 16, into F[:, 0:16]; a copy of xyz into Pq[:, 0:4] ----
+    if (tid < L3_T) {
+        const long long seq = s0 + (tid >> 4);
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (seq < S) {
+            const float* p = offs + (seq * 16 + (tid & 15)) * 3;
+            x = p[0]; y = p[1]; z = p[2];
+        }
+        *reinterpret_cast<float4*>(F + f_chunk(tid, 0)) = make_float4(x, y, z, 0.f);
+        *reinterpret_cast<float4*>(F + f_chunk(tid, 1)) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(F + f_chunk(tid, 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(F + f_chunk(tid, 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Pq + q_chunk(tid, 0)) = make_float4(x, y, z, 0.f);
+    }
+    __syncthreads();
+    L5_T();
+    f32x16 acc[1][2], xres[1][2];
+    // ---- Embedding (Attention.py:98-128): linear1 3->125, GELU -> F ; linear2 125->125 || xyz -> xres ----
+    l5_gemm<1, 1, true, false>(acc, F, mats + l3_mat_off(0), wave, lane);
+    __syncthreads();                               // the offsets in F[:, 0:16] are consumed
+    L5_T();
+    {
+        const float b = vecs[L3_VEC_EMB1 + wave * 32 + (lane & 31)];
+        l5_put<128>(acc[0], F, wave, lane, [&](float v) { return l3_gelu(v + b); });
+    }
+    __syncthreads();
+    L5_T();
+    l5_gemm<8, 1, true, false>(xres, F, mats + l3_mat_off(1), wave, lane);
+    {
+        const int j = lane & 31, h = lane >> 5;
+        const float b = vecs[L3_VEC_EMB2 + wave * 32 + j];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xres[0][mt][r] += b;
+        if (wave == 3 && j >= 29) {                // columns 125..127: concat the raw xyz (Attention.py:123-126)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xres[0][mt][r] = Pq[q_idx(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, j - 29)];
+        }
+    }
+    __syncthreads();                               // every wave is done reading F as the A operand
+    L5_T();
+    l5_put<128>(xres[0], F, wave, lane, [](float v) { return v; });
+
+#pragma unroll 1
+    for (int e = 0; e < 2; ++e) {
+        const float* em = mats + l3_mat_off(2 + 6 * e);
+        const float* ev = vecs + L3_VEC_ENC0 + e * L3_VEC_ENC_STRIDE;
+        // ---- norm1 (folded) -> planes ; QKV (Attention.py:186-188, 287): q|k -> Pq, v -> F ----
+        // 6 n-tiles over 4 waves: waves 0,1 take two (w, w + 4), waves 2,3 one.
+        __syncthreads();
+        L5_T();
+        l5_norm(F, P, tid);
+        __syncthreads();
+        L5_T();
+        {
+            f32x16 aq[2][2];
+            if (wave < 2) l5_gemm<8, 2, true, true>(aq, P, em, wave, lane);
+            else l5_gemm<8, 1, true, true>(reinterpret_cast<f32x16 (&)[1][2]>(aq), P, em, wave, lane);
+            __syncthreads();                       // x^ planes consumed: P may take q|k (F's raw x died with the norm)
+            L5_T();
+            // n-tiles 0,1 = q,k -> Pq column tiles 0,1; n-tiles 2..5 = v -> F column tiles 0..3
+            {
+                const float b0 = ev[wave * 32 + (lane & 31)];
+                if (wave < 2) l5_put<64>(aq[0], Pq, wave, lane, [&](float v) { return v + b0; });
+                else l5_put<128>(aq[0], F, wave - 2, lane, [&](float v) { return v + b0; });
+                if (wave < 2) {
+                    const float b1 = ev[(wave + 4) * 32 + (lane & 31)];
+                    l5_put<128>(aq[1], F, wave + 2, lane, [&](float v) { return v + b1; });
+                }
+            }
+        }
+        __syncthreads();
+        L5_T();
+        // ---- attention (Attention.py:8-36): thread = (query, head, row); output overwrites the head's V block ----
+        {
+            const int t2 = l5_opaque(tid);
+            const int r0 = (t2 >> 6) * 16, hh = (t2 >> 4) & 3, qi = t2 & 15;
+            float q[8];
+            {
+                const float4 qa = *reinterpret_cast<const float4*>(Pq + q_chunk(r0 + qi, 2 * hh));
+                const float4 qb = *reinterpret_cast<const float4*>(Pq + q_chunk(r0 + qi, 2 * hh + 1));
+                q[0] = qa.x; q[1] = qa.y; q[2] = qa.z; q[3] = qa.w; q[4] = qb.x; q[5] = qb.y; q[6] = qb.z; q[7] = qb.w;
+            }
+            float p[16];
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float4 ka = *reinterpret_cast<const float4*>(Pq + q_chunk(r0 + j, 8 + 2 * hh));
+                const float4 kb = *reinterpret_cast<const float4*>(Pq + q_chunk(r0 + j, 8 + 2 * hh + 1));
+                float a = q[0] * ka.x;
+                a = fmaf(q[1], ka.y, a); a = fmaf(q[2], ka.z, a); a = fmaf(q[3], ka.w, a);
+                a = fmaf(q[4], kb.x, a); a = fmaf(q[5], kb.y, a); a = fmaf(q[6], kb.z, a); a = fmaf(q[7], kb.w, a);
+                p[j] = a * 0.35355339059327376220f;            // / sqrt(8)
+                mx = fmaxf(mx, p[j]);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                p[j] = __expf(p[j] - mx);
+                den += p[j];
+            }
+            const float inv = 1.0f / den;
+            float o[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) o[c] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float pj = p[j] * inv;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float4 vv = *reinterpret_cast<const float4*>(F + f_chunk(r0 + j, hh * 8 + c));
+                    o[4 * c] = fmaf(pj, vv.x, o[4 * c]); o[4 * c + 1] = fmaf(pj, vv.y, o[4 * c + 1]);
+                    o[4 * c + 2] = fmaf(pj, vv.z, o[4 * c + 2]); o[4 * c + 3] = fmaf(pj, vv.w, o[4 * c + 3]);
+                }
+            }
+            // the 16 threads sharing this V block are consecutive lanes of this wave: all reads precede the writes
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                *reinterpret_cast<float4*>(F + f_chunk(r0 + qi, hh * 8 + c)) = make_float4(o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+        }
+        __syncthreads();
+        L5_T();
+        // ---- out projection + residual (Attention.py:201-202, 290): x += att W_o^T + b ----
+        l5_gemm<8, 1, true, false>(acc, F, em + L3_MAT_QKV, wave, lane);
+        {
+            const float b = ev[192 + wave * 32 + (lane & 31)];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xres[0][mt][r] += acc[0][mt][r] + b;
+        }
+        __syncthreads();                           // the attention output in F is consumed
+        L5_T();
+        l5_put<128>(xres[0], F, wave, lane, [](float v) { return v; });
+        __syncthreads();
+        L5_T();
+        // ---- norm2 (folded) -> planes ; FF 128 -> 256 (GELU) -> 128 + residual (Attention.py:293-298), two halves ----
+        l5_norm(F, P, tid);
+        __syncthreads();
+        L5_T();
+        f32x16 accf[1][2];
+        const float* w_ff1a = em + L3_MAT_QKV + L3_MAT_128 * 1;
+        const float* w_ff1b = em + L3_MAT_QKV + L3_MAT_128 * 2;
+        const float* w_ff2a = em + L3_MAT_QKV + L3_MAT_128 * 3;
+        const float* w_ff2b = em + L3_MAT_QKV + L3_MAT_128 * 4;
+        l5_gemm<8, 1, true, true>(acc, P, w_ff1a, wave, lane);
+        {
+            const float b = ev[192 + 128 + wave * 32 + (lane & 31)];
+            l5_put<128>(acc[0], F, wave, lane, [&](float v) { return l3_gelu(v + b); });
+        }
+        __syncthreads();
+        L5_T();
+        l5_gemm<8, 1, true, false>(accf, F, w_ff2a, wave, lane);
+        l5_gemm<8, 1, true, true>(acc, P, w_ff1b, wave, lane);          // reads P only: no barrier needed before it
+        __syncthreads();                           // the first hidden half in F is consumed
+        L5_T();
+        {
+            const float b = ev[192 + 128 + 128 + wave * 32 + (lane & 31)];
+            l5_put<128>(acc[0], F, wave, lane, [&](float v) { return l3_gelu(v + b); });
+        }
+        __syncthreads();
+        L5_T();
+        l5_gemm<8, 1, false, false>(accf, F, w_ff2b, wave, lane);
+        {
+            const float b = ev[192 + 128 + 256 + wave * 32 + (lane & 31)];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xres[0][mt][r] += accf[0][mt][r] + b;
+        }
+        __syncthreads();                           // the second hidden half in F is consumed
+        L5_T();
+        l5_put<128>(xres[0], F, wave, lane, [](float v) { return v; });
+    }
+    // ---- final norm (folded) + linear0 128 -> 128 (SconeOcc.py:119-122) ----
+    __syncthreads();
+    L5_T();
+    l5_norm(F, P, tid);
+    __syncthreads();
+    L5_T();
+    l5_gemm<8, 1, true, true>(acc, P, mats + l3_mat_off(14), wave, lane);
+    {
+        const float b = vecs[L3_VEC_LIN0 + wave * 32 + (lane & 31)];
+        l5_put<128>(acc[0], F, wave, lane, [&](float v) { return v + b; });
+    }
+    __syncthreads();
+    L5_T();
+    // ---- max || avg pool over the 16 tokens of each query (SconeOcc.py:124-126) ----
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int o = tid + r * 256, q = o >> 7, c = o & 127;
+        if (s0 + q < S) {
+            float mx = -__builtin_inff(), sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = F[f_idx(q * 16 + j, c)];
+                mx = fmaxf(mx, v);
+                sm += v;
+            }
+            feat[(s0 + q) * ld_feat + c] = mx;
+            feat[(s0 + q) * ld_feat + 128 + c] = sm * (1.0f / 16.f);
+        }
+    }
+    L5_T();
+}
+
+void launch_local_pct5(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob) {
+    if (S <= 0) return;
+    hipLaunchKernelGGL(local_pct5_kernel, dim3((unsigned)cdiv(S, L3_QPB)), dim3(256), 0, s, offs, feat, (long long)ld_feat,
+                       (long long)S, blob);
+}
+
+}  // namespace mcr

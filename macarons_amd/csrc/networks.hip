@@ -150,9 +150,9 @@ int mcr_get_local_pct_variant(void);
 int mcr_local_pct_blob_floats(void) { return local_pct_blob_floats(); }
 int mcr_local_pct3_blob_floats(void) { return local_pct3_blob_floats(); }
 
-static int g_local_pct_variant = 4;      // 1: local_pct.hip exact-fp32 MFMA; 2: local_pct2.hip (experimental); 3: local_pct3.hip split-precision bf16x6; 4 (default): local_pct4.hip = 3 restructured for two workgroups/CU (same blob as 3)
+static int g_local_pct_variant = 5;      // 1: local_pct.hip exact-fp32 MFMA; 2: local_pct2.hip (experimental); 3: local_pct3.hip split-precision bf16x6; 4: local_pct4.hip = 3 restructured for two workgroups/CU; 5 (default): local_pct5.hip = 4 with LayerNorm outputs pre-split in LDS (3, 4, 5 share one blob)
 int mcr_set_local_pct_variant(int v) {
-    MCR_REQUIRE(v >= 1 && v <= 4, "mcr_set_local_pct_variant: variant must be 1..4");
+    MCR_REQUIRE(v >= 1 && v <= 5, "mcr_set_local_pct_variant: variant must be 1..5");
     g_local_pct_variant = v;
     return 0;
 }
@@ -161,6 +161,7 @@ static void run_local_pct(hipStream_t s, const float* offs, float* feat, int64_t
     if (g_local_pct_variant == 1) launch_local_pct(s, offs, feat, ld, S, blob);
     else if (g_local_pct_variant == 2) launch_local_pct2(s, offs, feat, ld, S, blob);
     else if (g_local_pct_variant == 4) launch_local_pct4(s, offs, feat, ld, S, blob);
+    else if (g_local_pct_variant == 5) launch_local_pct5(s, offs, feat, ld, S, blob);
     else launch_local_pct3(s, offs, feat, ld, S, blob);
 }
 

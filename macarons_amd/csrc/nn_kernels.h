@@ -42,6 +42,7 @@ void launch_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld_
 void launch_local_pct2(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);
 void launch_local_pct3(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);
 void launch_local_pct4(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);   // same blob as v3
+void launch_local_pct5(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);   // same blob as v3
 int local_pct_blob_floats();
 int local_pct3_blob_floats();
 

@@ -61,7 +61,7 @@ def pack_local_pct(pct, variant=1):
     """pct: macarons_amd.networks.SconeOcc.PCTransformer (default local architecture). Returns a 1-D fp32 tensor.
     variant 1/2: fp32 fragment image (local_pct.hip / local_pct2.hip); variant 3/4: exact bf16 hi/mid/lo planes
     (local_pct3.hip / local_pct4.hip, split-precision matrix products)."""
-    if variant in (3, 4):
+    if variant in (3, 4, 5):
         return _pack_local_pct3(pct)
     with torch.no_grad():
         f = lambda p: p.detach().float()

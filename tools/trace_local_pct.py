@@ -1,0 +1,28 @@
+"""Dev: per-phase cycle stamps of one workgroup of the fused local transformer (lib built with -DL5_TRACE=<block>)."""
+import sys, os, torch, io, contextlib, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from macarons_amd import ops, _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_libs", f"libmacarons_hip_{os.environ['MCR_DEV_LIB']}.so")
+from macarons_amd.networks import SconeOcc
+from macarons_amd.networks.packing import pack_local_pct
+dev = torch.device("cuda:0")
+v = int(os.environ.get("VARIANT", 5))
+L = _lib.lib(); L.mcr_set_local_pct_variant(ctypes.c_int(v))
+with contextlib.redirect_stdout(io.StringIO()):
+    occ = SconeOcc().to(dev)
+blob = pack_local_pct(occ.local_transformers[0], v)
+offs = torch.randn(16384, 16, 3, device=dev) * 0.05
+names = ["stage", "emb1 gemm", "emb1 gelu", "emb2 gemm+epi"]
+for e in range(2):
+    names += [f"e{e} store_x", f"e{e} norm1", f"e{e} qkv gemm", f"e{e} qkv put", f"e{e} attention", f"e{e} out gemm+res", f"e{e} store_x",
+              f"e{e} norm2", f"e{e} ff1a gemm+gelu", f"e{e} ff2a+ff1b gemm", f"e{e} ff1b gelu", f"e{e} ff2b gemm+res"]
+names += ["store_x", "final norm", "lin0 gemm+epi", "pool"]
+acc = None
+for it in range(5):
+    ops.local_pct_forward(offs, blob); torch.cuda.synchronize()
+    buf = (ctypes.c_longlong * 64)(); L.mcr_dev_read_trace(buf)
+    d = [buf[i + 1] - buf[i] for i in range(len(names))]
+    acc = d if acc is None else [a + b for a, b in zip(acc, d)]
+tot = sum(acc) / 5
+print(f"total {tot:.0f} ticks")
+for n, a in zip(names, acc): print(f"  {n:22s} {a/5:9.0f}  {100*a/5/tot:5.1f} %")
