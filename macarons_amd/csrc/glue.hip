@@ -372,6 +372,46 @@ __global__ void unproject_depth_kernel(const float* __restrict__ depth, int H, i
 
 using namespace mcr;
 
+
+// ---- arg-max exchange records (multi-GPU camera sharding, testers/shapenet.py:172 = torch.max over cameras) ------------
+// record[b] = (max_c gains[b,c], idx_offset + first arg-max) as two fp32 (camera indices < 2^24 are exact): one 8-byte record
+// per cloud is what the ranks all-gather.  One wave per cloud; ties -> lowest index like torch.max.
+__global__ __launch_bounds__(64) void best_record_kernel(const float* __restrict__ gains, int C, long long idx_offset,
+                                                         float* __restrict__ rec) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* g = gains + (size_t)b * C;
+    float bv = -__builtin_inff();
+    int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = g[c];
+        if (v > bv) { bv = v; bi = c; }                      // strided scan keeps the lowest index per lane
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        rec[2 * b] = bv;
+        rec[2 * b + 1] = (float)(idx_offset + bi);
+    }
+}
+
+// recs [world, B, 2] -> (vals[b], idx[b]) of the global arg-max; ties -> lowest camera index.
+__global__ __launch_bounds__(64) void best_merge_kernel(const float* __restrict__ recs, int world, int B, float* __restrict__ vals,
+                                                        long long* __restrict__ idx) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float bv = recs[2 * b], bi = recs[2 * b + 1];
+    for (int r = 1; r < world; ++r) {
+        const float v = recs[((size_t)r * B + b) * 2], i = recs[((size_t)r * B + b) * 2 + 1];
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+    vals[b] = bv;
+    idx[b] = (long long)bi;
+}
+
 extern "C" {
 
 int mcr_view_state(const float* pts, int pts_dim, const float* X_view, float* view_state, int64_t n_points, int n_view,
@@ -480,6 +520,23 @@ int mcr_coverage_gain_multiple(const float* vis, float* gains, int64_t B, int64_
     hipLaunchKernelGGL(multi_gain_kernel, dim3((unsigned)tuples, (unsigned)B), dim3(256), 0, (hipStream_t)stream, vis, gains, (int)C,
                        (int)N, n_cam);
     MCR_LAUNCH_CHECK("multi_gain_kernel");
+    return 0;
+}
+
+int mcr_best_record(const float* gains, int64_t B, int64_t C, int64_t idx_offset, float* records, void* stream) {
+    MCR_REQUIRE(gains && records && B > 0 && C > 0, "mcr_best_record: bad arguments");
+    MCR_REQUIRE(idx_offset >= 0 && idx_offset + C <= (1ll << 24), "mcr_best_record: camera indices must stay below 2^24");
+    hipLaunchKernelGGL(best_record_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, gains, (int)C, (long long)idx_offset,
+                       records);
+    MCR_LAUNCH_CHECK("best_record_kernel");
+    return 0;
+}
+
+int mcr_best_merge(const float* records, int world, int64_t B, float* vals, int64_t* idx, void* stream) {
+    MCR_REQUIRE(records && vals && idx && world > 0 && B > 0, "mcr_best_merge: bad arguments");
+    hipLaunchKernelGGL(best_merge_kernel, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, records, world, (int)B, vals,
+                       reinterpret_cast<long long*>(idx));
+    MCR_LAUNCH_CHECK("best_merge_kernel");
     return 0;
 }
 

@@ -55,3 +55,78 @@ def allgather_rows(local, n_total, group=None):
     recv = local.new_empty((world * m,) + tuple(tail))
     dist.all_gather_into_tensor(recv, send, group=group)
     return torch.cat([recv[r * m: r * m + (b - a)] for r, (a, b) in enumerate(sizes)], dim=0)
+
+
+def allgather_best(gains, idx_offset, group=None):
+    """gains [B, C_local] of this rank's camera shard (global index of column 0 = idx_offset) -> (max_gain [B], nbv_idx [B])
+    over all ranks' shards, identical on every rank.  On a HIP device: one record kernel, one all-gather of 8 B per cloud,
+    one merge kernel (ops.best_record / ops.best_merge); on CPU tensors (gloo tests of the host logic) plain torch."""
+    if not gains.is_cuda:
+        best = torch.max(gains, dim=1)
+        return allgather_argmax(best.values, best.indices + idx_offset, group)
+    from . import ops
+    world = dist.get_world_size(group)
+    B = gains.shape[0]
+    send = ops.best_record(gains, idx_offset)
+    recv = torch.empty((world, B, 2), dtype=torch.float32, device=gains.device)
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    return ops.best_merge(recv)
+
+
+class PipelinedBest:
+    """Arg-max exchange for a stream of decisions, sized for xGMI: the record kernel of every decision runs on the scoring
+    stream, and once `batch` decisions have accumulated ONE all-gather (8 B x batch x clouds per rank) and ONE merge run on a
+    side stream under the scoring of the following decisions -- a per-decision collective costs more host and link latency
+    than the 90 us scoring pass it follows.  `depth` batches may be in flight; every slot owns its buffers, so nothing is
+    allocated (or freed across streams) inside the loop."""
+
+    def __init__(self, B, device, group=None, batch=8, depth=3):
+        from . import ops
+        self._ops, self.group, self.depth, self.batch, self.B = ops, group, depth, batch, B
+        self.world = dist.get_world_size(group)
+        self.comm = torch.cuda.Stream(device=device)
+        mk = lambda *shape, dtype=torch.float32: torch.empty(shape, dtype=dtype, device=device)
+        self.slots = [dict(send=mk(batch, B, 2), recv=mk(self.world, batch * B, 2), vals=mk(batch * B),
+                           idx=mk(batch * B, dtype=torch.int64), ready=torch.cuda.Event(), done=torch.cuda.Event(),
+                           used=False, fill=0) for _ in range(depth)]
+        self._cur = 0
+
+    def submit(self, gains, idx_offset):
+        """Queue the exchange for `gains` [B, C_local] (produced on the current stream); returns a handle for result()."""
+        s = self.slots[self._cur]
+        if s["fill"] == 0 and s["used"]:
+            torch.cuda.current_stream(gains.device).wait_event(s["done"])   # its previous exchange has consumed the send buffer
+        j = s["fill"]
+        self._ops.best_record(gains, idx_offset, out=s["send"][j])
+        s["fill"] = j + 1
+        if s["fill"] == self.batch:
+            self._exchange(s)
+        return (s, j)
+
+    def _exchange(self, s):
+        n = s["fill"]
+        if n == 0:
+            return
+        dev = s["send"].device
+        if n < self.batch:
+            s["send"][n:].zero_()                            # a short last batch: defined bytes on the wire
+        s["ready"].record(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(s["ready"])
+            dist.all_gather_into_tensor(s["recv"].view(-1), s["send"].view(-1), group=self.group)
+            self._ops.best_merge(s["recv"], out_vals=s["vals"], out_idx=s["idx"])
+            s["done"].record(self.comm)
+        s["used"], s["fill"] = True, 0
+        self._cur = (self._cur + 1) % self.depth
+
+    def flush(self):
+        """Exchange a partially filled batch (call after the last submit)."""
+        self._exchange(self.slots[self._cur])
+
+    def result(self, handle):
+        """(max_gain [B], nbv_idx [B]) of one submitted decision; the current stream waits for its batch's exchange."""
+        s, j = handle
+        if s["fill"] > j:
+            raise RuntimeError("PipelinedBest.result: the decision's batch has not been exchanged yet (call flush())")
+        torch.cuda.current_stream(s["vals"].device).wait_event(s["done"])
+        return s["vals"][j * self.B:(j + 1) * self.B], s["idx"][j * self.B:(j + 1) * self.B]

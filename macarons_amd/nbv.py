@@ -67,10 +67,10 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
         C = X_cam.shape[0]
         c0, c1 = mdist.shard_range(C, rank, world)
         gains = scone_vis.compute_coverage_gain(proxy_points, harm, X_cam[c0:c1].contiguous().view(1, -1, 3))
-        best = torch.max(gains, dim=1)
         if world > 1:
-            max_gain, nbv_idx = mdist.allgather_argmax(best.values, best.indices + c0, group)
+            max_gain, nbv_idx = mdist.allgather_best(gains, c0, group)
         else:
+            best = torch.max(gains, dim=1)
             max_gain, nbv_idx = best.values, best.indices
     return {"gains": gains[0], "cam_range": (c0, c1), "nbv_idx": nbv_idx, "max_gain": max_gain, "occ": occ,
             "n_unique": n_unique}

@@ -307,6 +307,28 @@ def coverage_gain_multiple(pts, harmonics, cams, n_cam, use_sigmoid=True):
     return out, n_idx
 
 
+def best_record(gains, idx_offset=0, out=None):
+    """gains [B,C] -> records [B,2] fp32 = (max, idx_offset + first arg-max): torch.max(gains, dim=1) as one 8-byte record."""
+    gains = _req(gains, "gains")
+    B, C = gains.shape
+    if out is None:
+        out = torch.empty((B, 2), dtype=torch.float32, device=gains.device)
+    with torch.cuda.device(gains.device):
+        check(lib().mcr_best_record(_p(gains), c_i64(B), c_i64(C), c_i64(int(idx_offset)), _p(out), _stream()), "mcr_best_record")
+    return out
+
+
+def best_merge(records, out_vals=None, out_idx=None):
+    """records [world,B,2] -> (vals [B] fp32, idx [B] int64) of the global arg-max, ties to the lowest index."""
+    records = _req(records, "records")
+    world, B = records.shape[0], records.shape[1]
+    vals = out_vals if out_vals is not None else torch.empty(B, dtype=torch.float32, device=records.device)
+    idx = out_idx if out_idx is not None else torch.empty(B, dtype=torch.int64, device=records.device)
+    with torch.cuda.device(records.device):
+        check(lib().mcr_best_merge(_p(records), c_int(world), c_i64(B), _p(vals), _p(idx), _stream()), "mcr_best_merge")
+    return vals, idx
+
+
 def fov_mask_occ(mask, occ):
     """mask [n_cam,P] bool/uint8, occ [P] -> [n_cam,P] occupancy zeroed outside each frustum."""
     occ = _req(occ, "occ")

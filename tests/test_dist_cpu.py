@@ -32,6 +32,8 @@ def _worker(rank, world, port, q):
         v, i = mdist.allgather_argmax(best.values, best.indices + c0)
         ref = torch.max(gains_all, dim=1)                    # first occurrence wins ties, like the reference
         ok1 = torch.equal(v, ref.values) and torch.equal(i, ref.indices)
+        v2, i2 = mdist.allgather_best(local.contiguous(), c0)      # the entry nbv_step uses (HIP kernels on a GPU, torch on CPU)
+        ok1 = ok1 and torch.equal(v2, ref.values) and torch.equal(i2, ref.indices)
         # occupancy rows: uneven shards
         full = torch.arange(11 * 3, dtype=torch.float32).view(11, 3)
         q0, q1 = mdist.shard_range(11, rank, world)

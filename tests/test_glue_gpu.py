@@ -199,3 +199,27 @@ def test_scene_side_kernels(dev):
     nx, ny = S.ndc_tabs(H, W)
     proj = ph @ (Mv @ K)
     assert np.abs(proj[:, 0] / proj[:, 3] - nx.reshape(-1)).max() < 1e-3 and np.abs(proj[:, 1] / proj[:, 3] - ny.reshape(-1)).max() < 1e-3
+
+
+def test_best_record_and_merge(dev):
+    """The arg-max exchange records of the camera-sharded decision == torch.max over the full gain vector
+    (testers/shapenet.py:172), first occurrence on ties, for every way of cutting the cameras into shards."""
+    from macarons_amd import ops
+    rng = np.random.default_rng(12)
+    for B, C in ((1, 200), (3, 7), (2, 1000), (5, 64)):
+        g = rng.random((B, C)).astype(np.float32)
+        g[:, C // 3] = g.max(axis=1)                         # an exact tie at a lower ...
+        g[:, C // 3 + 2 if C // 3 + 2 < C else C - 1] = g[:, C // 3]   # ... and a higher index
+        G = torch.from_numpy(g).to(dev)
+        ref = torch.max(G, dim=1)
+        for world in (1, 2, 3, 8):
+            if world > C:
+                continue
+            recs = []
+            for r in range(world):
+                q, rem = divmod(C, world)
+                lo = r * q + min(r, rem)
+                hi = lo + q + (1 if r < rem else 0)
+                recs.append(ops.best_record(G[:, lo:hi].contiguous(), lo))
+            vals, idx = ops.best_merge(torch.stack(recs, 0).contiguous())
+            assert torch.equal(vals, ref.values) and torch.equal(idx, ref.indices), (B, C, world)

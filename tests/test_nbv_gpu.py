@@ -78,3 +78,30 @@ def test_headline_step_runs_and_is_consistent(dev):
     assert torch.equal(a["gains"], b["gains"]) and int(a["nbv_idx"]) == int(b["nbv_idx"])      # deterministic
     assert a["gains"].shape == (200,) and torch.isfinite(a["gains"]).all() and torch.isfinite(a["occ"]).all()
     assert int(a["nbv_idx"]) == int(torch.argmax(a["gains"]))
+
+
+def test_pipelined_best_exchange_nccl_single_rank(dev):
+    """PipelinedBest (batched arg-max exchange on a side stream, RCCL) returns torch.max's decision for every submitted
+    gain vector, including a short last batch; single-rank process group on the one GPU of the test box."""
+    import socket
+    import torch.distributed as dist
+    from macarons_amd import dist as mdist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        B, C, n = 2, 200, 21                                 # 21 decisions = 2 full batches of 8 + a short one
+        g = torch.Generator(device="cpu").manual_seed(5)
+        gains = [torch.rand(B, C, generator=g).to(dev) for _ in range(n)]
+        pipe = mdist.PipelinedBest(B, dev, batch=8, depth=2)
+        handles = [pipe.submit(x, 1000) for x in gains]
+        pipe.flush()
+        # a slot is reused after `depth` batches: the last batch (the short one, 5 decisions) and the one before are held
+        for k in range(n - 13, n):
+            v, i = pipe.result(handles[k])
+            ref = torch.max(gains[k], dim=1)
+            assert torch.equal(v, ref.values) and torch.equal(i, ref.indices + 1000), k
+        v, i = mdist.allgather_best(gains[3], 7)
+        ref = torch.max(gains[3], dim=1)
+        assert torch.equal(v, ref.values) and torch.equal(i, ref.indices + 7)
+    finally:
+        dist.destroy_process_group()
