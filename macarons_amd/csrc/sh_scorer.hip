@@ -5,9 +5,9 @@
 //   macarons/networks/SconeVis.py:164-208  compute_visibilities    -> vis   [B,C,N]
 //   (== macarons/networks/Macarons.py:138-178 compute_visibility_gains)
 // which materialise [B*C*N,64] SH tensors three times.  Here: one lane owns one point (its 64 SH
-// coefficients live in VGPRs, pre-scaled once by the recurrence constants), cameras come from wave-uniform
-// scalar loads, the 64 real SH of the ray direction are produced by trig-free recurrences and contracted on the
-// fly (~170 VALU ops per (point,camera) pair), sigmoid/relu applied, and the per-camera sum over points
+// coefficients live in VGPRs, turned once into the monomial coefficients of 15 polynomials in cos(polar)), cameras
+// come from wave-uniform scalar loads, the dot with the 64 real SH of the ray direction is evaluated trig-free by
+// Horner steps (94 VALU ops per (point,camera) pair, ~130 with activation and reduction), sigmoid/relu applied, and the per-camera sum over points
 // is a wave64 DPP reduction -> per-wave-tile partials -> a deterministic second-pass reduce (bit-stable
 // run to run).  Bound: fp32 VALU (370 algorithmic flop / pair; N*268 B of HBM per cloud).
 //
@@ -23,52 +23,34 @@ constexpr int SC_BLOCK = 256;       // 4 waves; one point per lane
 
 __device__ __forceinline__ constexpr int shk(int l, int m) { return l * l + l + m; }
 
-// z = sum_k Y_k(d) h_k  with hs[k] = SH_LAMBDA[l][|m|] * h_k  (algebra in gen_sh_consts.py), trig-free:
-//   n = d / |d|  (one v_rsq);  cos(polar) = n_y;   sin(polar)^m {cos,sin}(m azim) = {Re,Im} (n_z + i n_x)^m
+// z = sum_k Y_k(d) h_k, trig-free and in monomial form (algebra and constants: gen_sh_consts.py):
+//   n = d / |d|  (one v_rsq);  x = cos(polar) = n_y;   sin(polar)^m {cos,sin}(m azim) = {Re,Im} (n_z + i n_x)^m
 // so sin(polar), the azimuth normalisation 1/rho and the rho = 0 special case never appear (a ray along +-Y
 // simply has n_x = n_z = 0 and every m != 0 term vanishes; the reference's acos path is ill-conditioned there).
-//   Rt_l^m : Rt_m^m = 1, Rt_{m+1}^m = ct, Rt_l^m = ct Rt_{l-1}^m - BP[l][m] Rt_{l-2}^m      (P_l^m / sin^m)
-//   z = sum_l Rt_l^0 h[l,0] + sum_{m>=1} ( C_m sum_l Rt_l^m h[l,+m] + S_m sum_l Rt_l^m h[l,-m] )
-// ~140 VALU ops per (point, camera) pair.  Measured on MI355X (tools/ubench): a dependent v_fma_f32 chain
-// issues every ~8.8 cycles per wave, 5 waves/SIMD of this code reach ~345 G pairs/s; v_pk_fma_f32 is half
-// rate and interleaving several cameras per lane buys nothing at that occupancy.
-__device__ __forceinline__ float sh_dot(float dx, float dy, float dz, const float (&hs)[64]) {
+// P_l^m / sin^m is a polynomial of degree l-m in x, so for one point the sum over l of each order m collapses into
+// ONE polynomial per (m, cos|sin):  U_m(x) = sum_k a[m+k,+m] x^k,  V_m(x) = sum_k a[m+k,-m] x^k, whose coefficients
+// a (64 per point, same storage as the SH coefficients) are produced once per point by load_mono_coeffs.  Then
+//   z = U_0(x) + sum_{m>=1} ( Re w^m U_m(x) + Im w^m V_m(x) ),   w = n_z + i n_x
+// = 49 Horner FMAs + 24 ops for the powers + 14 to combine + 7 to normalise: 94 VALU ops per (point, camera) pair --
+// the floor for 64 per-point coefficients (the rescaled-recurrence form this replaces needed 130).
+// Measured on MI355X (tools/ubench): a dependent v_fma_f32 chain issues every ~8.8 cycles per wave; the 15 Horner
+// chains are independent; v_pk_fma_f32 is half rate and buys nothing.
+__device__ __forceinline__ float sh_dot(float dx, float dy, float dz, const float (&a)[64]) {
     const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const float ir = __builtin_amdgcn_rsqf(r2);
     const float nx = dx * ir, ct = dy * ir, nz = dz * ir;
 
-    float z = fmaf(ct, hs[shk(1, 0)], hs[0]);
-    {
-        float r2_ = ct, r1_ = fmaf(ct, ct, -SH_BP[2][0]);
-        z = fmaf(r1_, hs[shk(2, 0)], z);
+    float z = a[shk(7, 0)];
 #pragma unroll
-        for (int l = 3; l < 8; ++l) {
-            const float r = fmaf(ct, r1_, -SH_BP[l][0] * r2_);
-            z = fmaf(r, hs[shk(l, 0)], z);
-            r2_ = r1_;
-            r1_ = r;
-        }
-    }
+    for (int l = 6; l >= 0; --l) z = fmaf(ct, z, a[shk(l, 0)]);
     float cm = nz, sm = nx;                     // (n_z + i n_x)^m
 #pragma unroll
     for (int m = 1; m < 8; ++m) {
-        float U = hs[shk(m, m)], V = hs[shk(m, -m)];
-        if (m < 7) {
-            U = fmaf(ct, hs[shk(m + 1, m)], U);
-            V = fmaf(ct, hs[shk(m + 1, -m)], V);
-        }
-        if (m < 6) {
-            float r2_ = ct, r1_ = fmaf(ct, ct, -SH_BP[m + 2][m]);
-            U = fmaf(r1_, hs[shk(m + 2, m)], U);
-            V = fmaf(r1_, hs[shk(m + 2, -m)], V);
+        float U = a[shk(7, m)], V = a[shk(7, -m)];
 #pragma unroll
-            for (int l = m + 3; l < 8; ++l) {
-                const float r = fmaf(ct, r1_, -SH_BP[l][m] * r2_);
-                U = fmaf(r, hs[shk(l, m)], U);
-                V = fmaf(r, hs[shk(l, -m)], V);
-                r2_ = r1_;
-                r1_ = r;
-            }
+        for (int l = 6; l >= m; --l) {
+            U = fmaf(ct, U, a[shk(l, m)]);
+            V = fmaf(ct, V, a[shk(l, -m)]);
         }
         z = fmaf(cm, U, z);
         z = fmaf(sm, V, z);
@@ -80,18 +62,29 @@ __device__ __forceinline__ float sh_dot(float dx, float dy, float dz, const floa
     return z;
 }
 
-// One point's 64 SH coefficients -> VGPRs, pre-scaled by the recurrence constants.
-__device__ __forceinline__ void load_scaled_coeffs(const float* __restrict__ h, float (&hs)[64]) {
+// One point's 64 SH coefficients -> VGPRs as the monomial coefficients of its 15 polynomials in cos(polar):
+//   a[m+k, +-m] = sum_{l = m+k, m+k+2, ... < 8} SH_MONO[m][l][k] * h[l, +-m]      (in place: a[m+k] only needs h[l >= m+k])
+__device__ __forceinline__ void load_mono_coeffs(const float* __restrict__ h, float (&a)[64]) {
     const float4* h4 = reinterpret_cast<const float4*>(h);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const float4 v = h4[j];
-        hs[4 * j + 0] = v.x; hs[4 * j + 1] = v.y; hs[4 * j + 2] = v.z; hs[4 * j + 3] = v.w;
+        a[4 * j + 0] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
     }
 #pragma unroll
-    for (int l = 0; l < 8; ++l)
+    for (int m = 0; m < 8; ++m)
 #pragma unroll
-        for (int m = -l; m <= l; ++m) hs[shk(l, m)] *= SH_LAMBDA[l][m < 0 ? -m : m];
+        for (int k = 0; k + m < 8; ++k) {
+            float u = a[shk(m + k, m)] * SH_MONO[m][m + k][k];
+            float v = a[shk(m + k, -m)] * SH_MONO[m][m + k][k];
+#pragma unroll
+            for (int l = m + k + 2; l < 8; l += 2) {
+                u = fmaf(a[shk(l, m)], SH_MONO[m][l][k], u);
+                v = fmaf(a[shk(l, -m)], SH_MONO[m][l][k], v);
+            }
+            a[shk(m + k, m)] = u;
+            if (m) a[shk(m + k, -m)] = v;
+        }
 }
 
 template <bool SIGMOID>
@@ -141,7 +134,7 @@ __global__ __launch_bounds__(SC_BLOCK) void sh_gain_kernel(const float* __restri
         const float py = pts[pn * pts_stride + 1];
         const float pz = pts[pn * pts_stride + 2];
         float hs[64];
-        load_scaled_coeffs(harm + pn * 64, hs);
+        load_mono_coeffs(harm + pn * 64, hs);
         const float keep = valid ? 1.f : 0.f;
         const float* cam_b = cams + (size_t)b * C * 3;
         float* part_row = partial + (size_t)bt * C;          // partial[b][wt][:]
@@ -209,7 +202,7 @@ __global__ __launch_bounds__(SC_BLOCK) void sh_vis_kernel(const float* __restric
         const float py = pts[pn * pts_stride + 1];
         const float pz = pts[pn * pts_stride + 2];
         float hs[64];
-        load_scaled_coeffs(harm + pn * 64, hs);
+        load_mono_coeffs(harm + pn * 64, hs);
         const float* cam_b = cams + (size_t)b * C * 3;
         for (int ci = c_begin; ci < c_end; ++ci) {
             const float z = sh_dot(cam_b[3 * ci + 0] - px, cam_b[3 * ci + 1] - py, cam_b[3 * ci + 2] - pz, hs);
