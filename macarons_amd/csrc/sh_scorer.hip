@@ -105,10 +105,14 @@ __device__ __forceinline__ float activate(float z) {
 // VGPRs once per segment, then loops over the cameras (wave-uniform -> scalar loads).  No LDS, no barriers.
 //
 // ---- coverage-gain kernel (mean over points) ---------------------------------------------------------------
-// Cameras are taken SC_G at a time so the SC_G six-step DPP wave reductions are independent chains that hide
-// each other's DPP wait states.  Each partial[b][wave-tile][c] is written by exactly one wave; the second
+// Cameras can be taken SC_G at a time (independent DPP reduction chains); with the 94-op Horner dot the extra
+// registers cost a resident wave per SIMD (79 VGPRs -> 6 waves at SC_G = 1, 91 -> 5 at 4) and SC_G = 1 measures fastest
+// (61.0 / 63.4 / 66.8 / 69.8 us for SC_G = 1 / 2 / 4 / 8).  Each partial[b][wave-tile][c] is written by exactly one wave; the second
 // pass adds them in a fixed order -> bit-stable results (no float atomics).
-constexpr int SC_G = 4;
+#ifndef SC_G_N
+#define SC_G_N 1
+#endif
+constexpr int SC_G = SC_G_N;
 
 template <bool SIGMOID>
 __global__ __launch_bounds__(SC_BLOCK) void sh_gain_kernel(const float* __restrict__ pts, int pts_stride,
