@@ -107,7 +107,7 @@ __device__ __forceinline__ float activate(float z) {
 // ---- coverage-gain kernel (mean over points) ---------------------------------------------------------------
 // Cameras can be taken SC_G at a time (independent DPP reduction chains); with the 94-op Horner dot the extra
 // registers cost a resident wave per SIMD (79 VGPRs -> 6 waves at SC_G = 1, 91 -> 5 at 4) and SC_G = 1 measures fastest
-// (61.0 / 63.4 / 66.8 / 69.8 us for SC_G = 1 / 2 / 4 / 8).  Each partial[b][wave-tile][c] is written by exactly one wave; the second
+// (61.0 / 63.4 / 66.8 / 69.8 us for SC_G = 1 / 2 / 4 / 8).  Each partial[b][c][wave-tile] is written by exactly one wave; the second
 // pass adds them in a fixed order -> bit-stable results (no float atomics).
 #ifndef SC_G_N
 #define SC_G_N 1
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(SC_BLOCK) void sh_gain_kernel(const float* __restri
         load_mono_coeffs(harm + pn * 64, hs);
         const float keep = valid ? 1.f : 0.f;
         const float* cam_b = cams + (size_t)b * C * 3;
-        float* part_row = partial + (size_t)bt * C;          // partial[b][wt][:]
+        float* part_col = partial + (size_t)b * C * n_wtiles + wt;   // partial[b][:][wt]  (camera-major: the reduce reads rows)
         for (int ci = c_begin; ci < c_end; ci += SC_G) {
             float v[SC_G];
 #pragma unroll
@@ -160,20 +160,20 @@ __global__ __launch_bounds__(SC_BLOCK) void sh_gain_kernel(const float* __restri
             if (lane == MCR_WAVE - 1) {
 #pragma unroll
                 for (int c = 0; c < SC_G; ++c)
-                    if (ci + c < c_end) part_row[ci + c] = sum[c];
+                    if (ci + c < c_end) part_col[(size_t)(ci + c) * n_wtiles] = sum[c];
             }
         }
     }
 }
 
-// gains[b][c] = (sum_wt partial[b][wt][c]) / N ; one 256-thread block per (b,c), fixed tree order.
+// gains[b][c] = (sum_wt partial[b][c][wt]) / N ; one 256-thread block per (b,c) reading its contiguous row, fixed tree order.
 __global__ __launch_bounds__(256) void sh_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gains,
                                                         int n_wtiles, int C, float inv_n) {
     __shared__ double s_w[4];
     const int c = blockIdx.x, b = blockIdx.y;
-    const float* p = partial + (size_t)b * n_wtiles * C + c;
+    const float* p = partial + ((size_t)b * C + c) * n_wtiles;
     double acc = 0.0;
-    for (int t = threadIdx.x; t < n_wtiles; t += 256) acc += (double)p[(size_t)t * C];
+    for (int t = threadIdx.x; t < n_wtiles; t += 256) acc += (double)p[t];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
