@@ -15,6 +15,13 @@ void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, c
                    int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int act,
                    const float* row_bias = nullptr, int64_t rows_per_group = 0, int64_t ldw = 0);
 
+// Split-precision (exact bf16 hi/mid/lo, six MFMAs per product) variant for the large GEMMs (linear3.hip); launch_linear
+// routes to it when linear3_applicable().
+bool linear3_applicable(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int N, int K);
+void launch_linear3(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R, int64_t ldr,
+                    float* Y, int64_t ldy, int64_t M, int N, int K, int act, const float* row_bias, int64_t rows_per_group,
+                    int64_t ldw);
+
 // Row LayerNorm (eps 1e-5, affine): Y[m, :E] = (X[m, :E] - mean) * rstd * g + b     (Attention.py:274,292)
 void launch_layernorm(hipStream_t s, const float* X, int64_t ldx, const float* g, const float* b, float* Y, int64_t ldy,
                       int64_t M, int E);

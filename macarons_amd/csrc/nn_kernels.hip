@@ -6,6 +6,7 @@
 // All arithmetic is fp32; matrix products use v_mfma_f32_32x32x2_f32, which is bit-for-bit an fp32 fma chain
 // (no TF32/bf16 anywhere), so results differ from PyTorch only by summation order.
 #include "nn_kernels.h"
+#include <cstdlib>
 
 namespace mcr {
 
@@ -147,6 +148,11 @@ void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, c
                    int64_t rows_per_group, int64_t ldw) {
     if (M <= 0 || N <= 0) return;
     if (ldw == 0) ldw = K;
+    static const bool use_split = []() { const char* e = getenv("MCR_LINEAR3"); return !(e && e[0] == '0'); }();   // dev A/B knob
+    if (use_split && linear3_applicable(X, ldx, W, ldw, M, N, K)) {
+        launch_linear3(s, X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, act, row_bias, rows_per_group, ldw);
+        return;
+    }
     const int vec_x = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
     const int vec_w = (K % 4 == 0) && (ldw % 4 == 0) && aligned16(W);
     const long long mb = cdiv(M, LIN_BM);

@@ -16,4 +16,9 @@ for (M, N, K, gelu, res) in shapes:
     for _ in range(n): ops.linear(x, w, b, gelu=bool(gelu), residual=r)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
     fl = 2.0 * M * N * K; by = 4.0 * (M * K + M * N * (2 if res else 1) + N * K)
-    print(f"M={M:7d} N={N:4d} K={K:5d} gelu={gelu} res={res}: {dt*1e6:9.1f} us  {fl/dt/1e12:6.1f} TFLOP/s  {by/dt/1e9:7.0f} GB/s")
+    ref = torch.nn.functional.linear(x[:4096].double(), w.double(), b.double())
+    if gelu: ref = torch.nn.functional.gelu(ref)
+    if res: ref = ref + r[:4096].double()
+    y = ops.linear(x, w, b, gelu=bool(gelu), residual=r)[:4096].double()
+    err = float((y - ref).abs().max() / ref.abs().max())
+    print(f"[MCR_LINEAR3={os.environ.get('MCR_LINEAR3','1')}] err {err:.1e} M={M:7d} N={N:4d} K={K:5d} gelu={gelu} res={res}: {dt*1e6:9.1f} us  {fl/dt/1e12:6.1f} TFLOP/s  {by/dt/1e9:7.0f} GB/s")
