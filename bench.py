@@ -74,6 +74,15 @@ def cpu_baseline(pts, harm, cams):
                       f"host has {os.cpu_count()} cores"}, g
 
 
+def pmc_traffic_bytes():
+    """HBM read bytes per launch of the scorer kernel from the committed PMC pass (None if the profile is absent)."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_scorer_pmc.json")) as f:
+            return float(json.load(f)["hbm_read_bytes_per_launch_corrected"])
+    except Exception:
+        return None
+
+
 def measure_nbv_step(dev, rank, world, args):
     """(B) p50 latency of one NBV decision at Q=100k / M=10240 / C=200 (sharded over `world` GPUs)."""
     from macarons_amd.networks import SconeVis, SconeOcc
@@ -215,7 +224,7 @@ def main():
         gains = ops.sh_coverage_gain(pts, harm, cams, True, args.waves_per_simd)
         if pipe is not None:
             return pipe.submit(gains, rank * C)
-        return torch.max(gains, dim=1)                       # (value, camera index)
+        return ops.best_record(gains)                        # [B,2] = (max gain, arg-max camera): the decision (torch.max semantics)
 
     for _ in range(args.warmup):
         step()
@@ -261,7 +270,9 @@ def main():
                                    f"(BASELINE headline 100k pts / 200 cams), inputs resident in HBM",
                        "points": N, "cams_per_gpu": C, "parallelism": f"camera-shard x{world}"},
             "roofline": {"bound": "valu-fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": pmc_traffic_bytes(),
+                         "traffic_source": "profiles/r01_scorer_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 per MI355X_MICROARCH.md, own pass)",
+                         "algorithmic_bytes": N * BYTES_PER_POINT,
                          "kernel": "sh_gain_kernel<true>", "device_ms_per_launch": kern_ms,
                          "hbm_algorithmic_GBs": N * BYTES_PER_POINT / (kern_ms * 1e-3) / 1e9},
         }

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round profile on the GPU box: bench line, rocprofv3 kernel stats of the same command, PMC passes (own runs, --pmc only)
+# for the scorer and the fused local transformer.  Outputs under gpurun_out/round/ (copy the summaries into profiles/).
+R=/root/repo
+OUT=$R/gpurun_out/round
+mkdir -p $OUT
+cd $R && python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats -o bench -- python $R/bench.py --steps 500 --warmup 100 --no-cpu-baseline --nbv-iters 20 > $OUT/kstats.log 2>&1
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU_TRANS_F32" \
+           "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+  i=$((i+1))
+  WPS=0 timeout -s KILL 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_scorer -o p$i -- python $R/tools/time_scorer.py > $OUT/pmc_scorer.p$i.log 2>&1 || echo "scorer pmc pass $i failed"
+done
+python - <<PY
+import csv, collections, glob, json
+d = collections.defaultdict(list)
+for f in sorted(glob.glob("$OUT/pmc_scorer/*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if 'sh_gain_kernel' in r['Kernel_Name']:
+            d[r['Counter_Name']].append(float(r['Counter_Value']))
+res = {"kernel": "sh_gain_kernel<true>", "workload": "N=100000 C=200 B=1", "per_dispatch_mean": {k: sum(v) / len(v) for k, v in d.items()},
+       "notes": "rocprofv3 --pmc passes (separate runs, no tracing); SQ_* cycle counters in quad-cycles; FETCH_SIZE in KiB as reported "
+                "(gfx950: x2 for wide streaming reads per MI355X_MICROARCH.md)"}
+if "FETCH_SIZE" in res["per_dispatch_mean"]:
+    res["hbm_read_bytes_per_launch_corrected"] = res["per_dispatch_mean"]["FETCH_SIZE"] * 1024 * 2
+json.dump(res, open("$OUT/scorer_pmc.json", "w"), indent=1)
+print(json.dumps(res)[:600])
+PY
+VARIANT=5 $R/tools/pmc_local_pct.sh > $OUT/local_pct5_pmc.txt 2>&1
+VARIANT=5 $R/tools/pmc_local_pct_mem.sh >> $OUT/local_pct5_pmc.txt 2>&1
+grep -c . $OUT/local_pct5_pmc.txt
