@@ -21,6 +21,15 @@ namespace mcr {
 
 constexpr int SC_BLOCK = 256;       // 4 waves; one point per lane
 
+// Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2.  Consecutive wave ranges
+// share a wave-tile's coefficients at their boundary, so the ranges are handed out in XCD-major order: the blocks of one
+// XCD own one contiguous stretch of the unit space and a tile cut by a block boundary is fetched into one L2 only
+// (measured HBM reads per launch: 68.6 MB with the plain order, 27.6 MB with this one; algorithmic 26.8 MB).
+__device__ __forceinline__ int xcd_major_block(int b, int nb) {
+    const int x = b & 7, q = nb >> 3, r = nb & 7;            // XCD x holds q + (x < r) blocks
+    return x * q + (x < r ? x : r) + (b >> 3);
+}
+
 __device__ __forceinline__ constexpr int shk(int l, int m) { return l * l + l + m; }
 
 // z = sum_k Y_k(d) h_k, trig-free and in monomial form (algebra and constants: gen_sh_consts.py):
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(SC_BLOCK) void sh_gain_kernel(const float* __restri
                                                            const float* __restrict__ cams, float* __restrict__ partial,
                                                            int N, int C, int n_wtiles, long long U, int W) {
     const int lane = threadIdx.x & (MCR_WAVE - 1);
-    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (SC_BLOCK / MCR_WAVE) + threadIdx.x / MCR_WAVE);
+    const int w = __builtin_amdgcn_readfirstlane(xcd_major_block(blockIdx.x, gridDim.x) * (SC_BLOCK / MCR_WAVE) + threadIdx.x / MCR_WAVE);
     if (w >= W) return;
     long long u = (U * w) / W;
     const long long u_end = (U * (w + 1)) / W;
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(SC_BLOCK) void sh_vis_kernel(const float* __restric
                                                           const float* __restrict__ cams, float* __restrict__ out,
                                                           int N, int C, int n_wtiles, long long U, int W) {
     const int lane = threadIdx.x & (MCR_WAVE - 1);
-    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (SC_BLOCK / MCR_WAVE) + threadIdx.x / MCR_WAVE);
+    const int w = __builtin_amdgcn_readfirstlane(xcd_major_block(blockIdx.x, gridDim.x) * (SC_BLOCK / MCR_WAVE) + threadIdx.x / MCR_WAVE);
     if (w >= W) return;
     long long u = (U * w) / W;
     const long long u_end = (U * (w + 1)) / W;
