@@ -11,6 +11,7 @@
 // LDS = exactly 80 KB (two workgroups per CU), both tiles XOR-swizzled in 16-byte chunks by (row & 15) instead of
 // padded:   P  48 KB  x^ as planes [3][64 rows][16 chunks of 8 bf16], or q|k as fp32 [64][64] during attention
 //           F  32 KB  fp32 [64][128]: raw x for the LayerNorm / v and the attention output / a half of the FF hidden
+// Attention runs on the fp32 matrix pipe too (v_mfma_f32_16x16x4_f32, exact fp32): one wave per query, see the kernel body.
 #include "lp_split.h"
 
 namespace mcr {
@@ -285,53 +286,63 @@ __global__ __launch_bounds__(256, 2) void local_pct5_kernel(const float* __restr
         }
         __syncthreads();
         L5_T();
-        // ---- attention (Attention.py:8-36): thread = (query, head, row); output overwrites the head's V block ----
+        // ---- attention (Attention.py:8-36) on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32 = exact fp32 fma chains):
+        // wave = query (16 tokens); per head  S^T = K Q^T (j rows, query rows qi as columns: lane (qi, g) then owns
+        // S[qi][4g..4g+3]), softmax over j = 4 registers x the 4 lane groups, O = P V with the k index j = 4g + s so the
+        // probabilities are used as the A operand straight from their registers.  The output overwrites the head's V block.
         {
-            const int t2 = l5_opaque(tid);
-            const int r0 = (t2 >> 6) * 16, hh = (t2 >> 4) & 3, qi = t2 & 15;
-            float q[8];
-            {
-                const float4 qa = *reinterpret_cast<const float4*>(Pq + q_chunk(r0 + qi, 2 * hh));
-                const float4 qb = *reinterpret_cast<const float4*>(Pq + q_chunk(r0 + qi, 2 * hh + 1));
-                q[0] = qa.x; q[1] = qa.y; q[2] = qa.z; q[3] = qa.w; q[4] = qb.x; q[5] = qb.y; q[6] = qb.z; q[7] = qb.w;
-            }
-            float p[16];
-            float mx = -__builtin_inff();
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const int ln = l5_opaque(lane);
+            const int r0 = wave * 16, li = ln & 15, g = ln >> 4;
+            // swizzled addresses as one per-lane word XOR a compile-time constant (row & 15 = li for q|k, 4g + s for v):
+            const int wq = ((r0 + li) * 64) | (li << 2) | g;                                   // Pq[row = r0+li][chunk c][g]   = wq ^ (c << 2)
+            const int wv = ((r0 + 4 * g) * 128) | ((((li >> 2) | (g << 2)) << 2)) | (li & 3);    // F[row = r0+4g+s][chunk C][li&3] = s*128 + (wv ^ ((C ^ s) << 2))
+            f32x4 pr[4];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float4 ka = *reinterpret_cast<const float4*>(Pq + q_chunk(r0 + j, 8 + 2 * hh));
-                const float4 kb = *reinterpret_cast<const float4*>(Pq + q_chunk(r0 + j, 8 + 2 * hh + 1));
-                float a = q[0] * ka.x;
-                a = fmaf(q[1], ka.y, a); a = fmaf(q[2], ka.z, a); a = fmaf(q[3], ka.w, a);
-                a = fmaf(q[4], kb.x, a); a = fmaf(q[5], kb.y, a); a = fmaf(q[6], kb.z, a); a = fmaf(q[7], kb.w, a);
-                p[j] = a * 0.35355339059327376220f;            // / sqrt(8)
-                mx = fmaxf(mx, p[j]);
-            }
-            float den = 0.f;
+            for (int hh = 0; hh < 4; ++hh) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                p[j] = __expf(p[j] - mx);
-                den += p[j];
-            }
-            const float inv = 1.0f / den;
-            float o[32];
-#pragma unroll
-            for (int c = 0; c < 32; ++c) o[c] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float pj = p[j] * inv;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float4 vv = *reinterpret_cast<const float4*>(F + f_chunk(r0 + j, hh * 8 + c));
-                    o[4 * c] = fmaf(pj, vv.x, o[4 * c]); o[4 * c + 1] = fmaf(pj, vv.y, o[4 * c + 1]);
-                    o[4 * c + 2] = fmaf(pj, vv.z, o[4 * c + 2]); o[4 * c + 3] = fmaf(pj, vv.w, o[4 * c + 3]);
+                for (int sk = 0; sk < 2; ++sk) {
+                    const float kk = Pq[wq ^ ((8 + 2 * hh + sk) << 2)];                  // A[i = j][k = d]      = k[j][hh*8 + 4 sk + g]
+                    const float qq = Pq[wq ^ ((2 * hh + sk) << 2)];                      // B[k = d][n = qi]     = q[qi][hh*8 + 4 sk + g]
+                    st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk, qq, st, 0, 0, 0);
                 }
+                float mx = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx *= 0.35355339059327376220f;                                           // scores / sqrt(8)
+                float den = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[r] = __expf(fmaf(st[r], 0.35355339059327376220f, -mx));
+                    den += st[r];
+                }
+                den += __shfl_xor(den, 16, 64);
+                den += __shfl_xor(den, 32, 64);
+                const float inv = __builtin_amdgcn_rcpf(den);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[hh][r] = st[r] * inv;
             }
-            // the 16 threads sharing this V block are consecutive lanes of this wave: all reads precede the writes
+            f32x4 o[4][2];
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    o[hh][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int sk = 0; sk < 4; ++sk) {
+                        const float vv = F[sk * 128 + (wv ^ (((hh * 8 + nt * 4) ^ sk) << 2))];   // B[k = g][n = c] = V[j = 4g + sk][hh*32 + nt*16 + li]
+                        o[hh][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[hh][sk], vv, o[hh][nt], 0, 0, 0);
+                    }
+                }
+            // every V read of this wave's 16 rows precedes the writes (other waves own other rows)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                *reinterpret_cast<float4*>(F + f_chunk(r0 + qi, hh * 8 + c)) = make_float4(o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+            for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) F[r * 128 + (wv ^ (((hh * 8 + nt * 4) ^ r) << 2))] = o[hh][nt][r];
         }
         __syncthreads();
         L5_T();
