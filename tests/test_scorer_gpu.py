@@ -87,14 +87,14 @@ def test_axis_aligned_rays_are_finite(dev):
     assert np.abs(v - ref).max() < 2e-5
 
 
-def test_large_headline_properties(dev):
-    """BASELINE headline size (N=100k, C=200): size-independent properties instead of a full oracle run."""
+@pytest.mark.parametrize("B,N,C", [(1, 100_000, 200), (1, 16_384, 100), (8, 32_768, 200), (1, 100_000, 512)])
+def test_large_headline_properties(dev, B, N, C):
+    """BASELINE.json sizes (headline N=100k / C=200; configs 2, 3, 4): size-independent properties instead of a full oracle run."""
     from macarons_amd import ops
     gen = torch.Generator(device="cpu").manual_seed(1234)
-    N, C = 100_000, 200
-    pts = (torch.rand(1, N, 4, generator=gen) - 0.5)
-    harm = torch.randn(1, N, 64, generator=gen) * 0.5
-    cams = torch.randn(1, C, 3, generator=gen)
+    pts = (torch.rand(B, N, 4, generator=gen) - 0.5)
+    harm = torch.randn(B, N, 64, generator=gen) * 0.5
+    cams = torch.randn(B, C, 3, generator=gen)
     cams = 1.5 * cams / cams.norm(dim=-1, keepdim=True)
     g = ops.sh_coverage_gain(pts.to(dev), harm.to(dev), cams.to(dev))
     # mean of per-point visibilities == gain
@@ -105,8 +105,12 @@ def test_large_headline_properties(dev):
     ga = ops.sh_coverage_gain(pts[:, :h].contiguous().to(dev), harm[:, :h].contiguous().to(dev), cams.to(dev))
     gb = ops.sh_coverage_gain(pts[:, h:].contiguous().to(dev), harm[:, h:].contiguous().to(dev), cams.to(dev))
     assert rel_err(((ga + gb) / 2).cpu().numpy(), g.cpu().numpy()) < 1e-6
-    # a bounded sample against the C port
+    # a bounded sample against the C port (first cloud, 7 cameras)
     sel = slice(0, 7)
-    gp, _ = cport.coverage_gain(pts.numpy(), harm.numpy(), cams[:, sel].numpy())
-    assert rel_err(g[:, sel].cpu().numpy(), gp) < 1e-4
+    gp, _ = cport.coverage_gain(pts[:1].numpy(), harm[:1].numpy(), cams[:1, sel].numpy())
+    assert rel_err(g[:1, sel].cpu().numpy(), gp) < 1e-4
     assert 0.0 < float(g.min()) and float(g.max()) < 1.0
+    # the decision record == torch.max over the cameras
+    rec = ops.best_record(g)
+    ref = torch.max(g, dim=1)
+    assert torch.equal(rec[:, 0], ref.values) and torch.equal(rec[:, 1].long(), ref.indices)
