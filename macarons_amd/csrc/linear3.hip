@@ -7,21 +7,26 @@
 // result is fp32-class (dropped terms <= 2^-24 relative), at 6 x 32 matrix-pipe cycles per 32x32x16 block instead of the
 // 8 x 64 of v_mfma_f32_32x32x2_f32.
 //
-// Block = 4 waves = 128 rows x 256 columns, K in chunks of 32.  LDS per chunk: A planes 3 x 128 x 32 bf16 = 24 KB,
-// W planes 3 x 256 x 32 bf16 = 48 KB -> 72 KB, two blocks per CU (the second block's MFMA phase covers this block's
-// split/stage phase).  Plane rows are 64 B; 16-byte chunks are XOR-swizzled by (row >> 2) & 3 so the fragment reads
+// Block = 4 waves = 128 rows x 128 columns (L3G_NT = 4 column tiles per wave), K in chunks of 32.  LDS per chunk: A planes
+// 3 x 128 x 32 bf16 = 24 KB + W planes 24 KB = 48 KB -> three blocks per CU: the other blocks' MFMA phases cover this
+// block's split/stage phase and the LDS latency in front of its MFMA groups (measured on the SconeOcc head at Q = 100k,
+// us: lin1 1047 / lin2 240 / xe3 263 / xe2 121 against 1065 / 260 / 366 / 155 with 256-column blocks, two per CU).  Plane rows are 64 B; 16-byte chunks are XOR-swizzled by (row >> 2) & 3 so the fragment reads
 // (lane = row, one ds_read_b128 per plane) are conflict-free.  The next chunk's global loads are issued before the
 // MFMA phase and split + written after it.
 #include "lp_split.h"
 
 namespace mcr {
 
-constexpr int L3G_BM = 128, L3G_BN = 256, L3G_BK = 32, L3G_NT = L3G_BN / 32;
+constexpr int L3G_BM = 128, L3G_BK = 32;
+#ifndef L3G_NT_N
+#define L3G_NT_N 4
+#endif
+constexpr int L3G_NT = L3G_NT_N, L3G_BN = 32 * L3G_NT;      // 8: 72 KB LDS, 2 blocks/CU; 4: 48 KB, 3 blocks/CU; 2: 36 KB, 4 blocks/CU
 
 // uint4 index of chunk c (8 bf16) of row `row` in a plane image [rows][4 chunks]
 __device__ __forceinline__ int l3g_chunk(int row, int c) { return row * 4 + (c ^ ((row >> 2) & 3)); }
 
-__global__ __launch_bounds__(256, 2) void linear3_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ W,
+__global__ __launch_bounds__(256, L3G_NT == 8 ? 2 : (L3G_NT == 4 ? 3 : 4)) void linear3_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ W,
                                                         long long ldw, const float* __restrict__ bias,
                                                         const float* __restrict__ row_bias, long long rows_per_group,
                                                         const float* __restrict__ R, long long ldr, float* __restrict__ Y,
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void linear3_kernel(const float* __restrict
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // staging: a thread owns 16-byte plane chunks = 8 consecutive k of one row: 2 chunks of A, 4 of W per K-chunk
-    float4 ra[2][2], rb[4][2];
+    float4 ra[2][2], rb[L3G_NT / 2][2];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void linear3_kernel(const float* __restrict
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < L3G_NT / 2; ++r) {
             const int idx = tid + r * 256, row = idx >> 2, c = idx & 3;
             rb[r][0] = rb[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (n0 + row < N && k0 + c * 8 < K) {
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void linear3_kernel(const float* __restrict
             As[0][l3g_chunk(row, c)] = sp.hi; As[1][l3g_chunk(row, c)] = sp.mid; As[2][l3g_chunk(row, c)] = sp.lo;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < L3G_NT / 2; ++r) {
             const int idx = tid + r * 256, row = idx >> 2, c = idx & 3;
             const Split3 sp = split8(rb[r][0], rb[r][1]);
             Bs[0][l3g_chunk(row, c)] = sp.hi; Bs[1][l3g_chunk(row, c)] = sp.mid; Bs[2][l3g_chunk(row, c)] = sp.lo;

@@ -2,9 +2,12 @@
 import sys, time, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from macarons_amd import _lib
+if os.environ.get('MCR_DEV_LIB'):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_libs', f"libmacarons_hip_{os.environ['MCR_DEV_LIB']}.so")
 from macarons_amd import ops
 dev = torch.device("cuda:0")
-shapes = [(262144, 128, 128, 0, 0), (262144, 192, 128, 0, 0), (262144, 256, 128, 1, 0), (262144, 128, 256, 0, 1),
+shapes = [(100000, 512, 1344, 1, 0), (100000, 256, 512, 1, 0), (100000, 512, 256, 1, 0), (100000, 256, 128, 1, 0)] if os.environ.get('HEAD') else [(262144, 128, 128, 0, 0), (262144, 192, 128, 0, 0), (262144, 256, 128, 1, 0), (262144, 128, 256, 0, 1),
           (262144, 125, 3, 1, 0), (262144, 125, 125, 0, 0), (100000, 512, 1344, 1, 0), (100000, 256, 512, 1, 0),
           (2048, 384, 256, 0, 0), (2048, 512, 256, 1, 0), (2048, 256, 512, 0, 1)]
 for (M, N, K, gelu, res) in shapes:
