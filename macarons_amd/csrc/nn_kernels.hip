@@ -383,6 +383,161 @@ __global__ __launch_bounds__(64 * KS) void attention_flash_kernel(const float* _
     for (int c = 0; c < DV; ++c) orow[c] = o[c] * inv;
 }
 
+// =====================================================================================================
+// attention, long sequences, on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32 = exact fp32 fma chains; same math as
+// attention_flash_kernel, which stays as the VALU reference path, env MCR_ATTN_MFMA=0).
+//   block = 4 waves x 16 queries of one (sequence, head); keys/values stream through LDS in tiles of 64.
+//   Per 16-key sub-tile a wave computes S^T = K Q^T (A = K rows from LDS, B = Q^T held in registers, pre-scaled by
+//   1/sqrt(d)): lane (qi = l & 15, g = l >> 4) then owns S[qi][j0 + 4g + r], r = 0..3.  Online softmax per query over the
+//   4 registers x 4 lane groups (two xor-shuffles per 64 keys).  O += P V uses the k index j = 4g + s, so the
+//   probabilities are the A operand straight from their registers; O lives in C layout (lane (c, g) owns queries 4g + r),
+//   so the per-query rescale factors are fetched across lane groups (4 ds_bpermute per 64 keys).
+// grid = (ceil(L/64), H, S)
+// =====================================================================================================
+template <int DQ, int DV>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, long long ldq,
+                                                             float* __restrict__ out, long long ldo, int L, int H) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int TK = 64, LDK = DQ + 1, LDV = DV + 4, NT = DV / 16, KQ = DQ / 4;
+    __shared__ float s_k[TK * LDK];
+    __shared__ __attribute__((aligned(16))) float s_v[TK * LDV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+    const int hh = blockIdx.y;
+    const long long seq0 = (long long)blockIdx.z * L;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int koff = H * DQ + hh * DQ, voff = 2 * H * DQ + hh * DV;
+    const float scale = 1.0f / sqrtf((float)DQ);
+
+    float qb[KQ];                                       // B operand of S^T: Q[q0 + li][4s + g] * scale
+    {
+        const int qi = min(q0 + li, L - 1);
+        const float* qp = qkv + (seq0 + qi) * ldq + hh * DQ;
+#pragma unroll
+        for (int sk = 0; sk < KQ; ++sk) qb[sk] = qp[4 * sk + g] * scale;
+    }
+    float m = -__builtin_inff(), l = 0.f;              // running max (shared by the 4 lanes of a query), this lane's part of the sum
+    f32x4 o[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: every thread moves PT float4 of the [64 keys x (DQ + DV)] tile; the next tile's loads are all issued before
+    // this tile's MFMA phase and land in LDS after it (the per-element copy loop of the VALU kernel serialises ~20 load
+    // latencies per tile and is what bounds it)
+    constexpr int F4K = (DQ + DV) / 4, NF4 = TK * F4K, PT = (NF4 + 255) / 256;
+    float4 stage[PT];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int idx = threadIdx.x + p * 256, r = idx / F4K, c4 = idx - r * F4K;
+            stage[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NF4 && t0 + r < L)
+                stage[p] = *reinterpret_cast<const float4*>(qkv + (seq0 + t0 + r) * ldq + (c4 < DQ / 4 ? koff + 4 * c4 : voff + 4 * (c4 - DQ / 4)));
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int idx = threadIdx.x + p * 256, r = idx / F4K, c4 = idx - r * F4K;
+            if (idx < NF4) {
+                if (c4 < DQ / 4) {
+                    float* d = s_k + r * LDK + 4 * c4;          // odd row stride (bank-conflict-free fragment reads): scalar stores
+                    d[0] = stage[p].x; d[1] = stage[p].y; d[2] = stage[p].z; d[3] = stage[p].w;
+                } else {
+                    *reinterpret_cast<float4*>(s_v + r * LDV + 4 * (c4 - DQ / 4)) = stage[p];
+                }
+            }
+        }
+    };
+    fetch(0);
+    for (int t0 = 0; t0 < L; t0 += TK) {
+        __syncthreads();                                  // the previous tile is consumed
+        commit();
+        __syncthreads();
+        if (t0 + TK < L) fetch(t0 + TK);
+        // ---- scores of the 64 keys of the tile (all A fragments first: LLVM otherwise issues every ds_read right in
+        // front of its MFMA and each one waits out the LDS latency) ----
+        const float* kbase = s_k + li * LDK + g;             // K[sub*16 + li][4 sk + g]
+        const float* vbase = s_v + (4 * g) * LDV + li;       // V[sub*16 + 4g + sk][nt*16 + li]
+        float ka[4][KQ];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int sk = 0; sk < KQ; ++sk) ka[sub][sk] = kbase[sub * 16 * LDK + 4 * sk];
+        float vb[2][4][NT];
+#pragma unroll
+        for (int sk = 0; sk < 4; ++sk)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) vb[0][sk][nt] = vbase[sk * LDV + nt * 16];
+        f32x4 st[4];
+        float tmax = -__builtin_inff();
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            st[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sk = 0; sk < KQ; ++sk) st[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[sub][sk], qb[sk], st[sub], 0, 0, 0);
+        }
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (t0 + sub * 16 + 4 * g + r >= L) st[sub][r] = -__builtin_inff();      // keys past the sequence end
+                tmax = fmaxf(tmax, st[sub][r]);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        const float alpha = __expf(m - m_new);           // m = -inf on the first tile -> 0 (o = l = 0 anyway)
+        m = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[sub][r] = __expf(st[sub][r] - m_new);
+                psum += st[sub][r];
+            }
+        l = fmaf(l, alpha, psum);
+        // ---- rescale O (rows = queries 4g + r live in lane group g) and accumulate P V ----
+        float ar[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r, 64);   // alpha of query 4g + r (any lane group holds it)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[nt][r] *= ar[r];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            if (sub + 1 < 4) {
+#pragma unroll
+                for (int sk = 0; sk < 4; ++sk)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) vb[(sub + 1) & 1][sk][nt] = vbase[((sub + 1) * 16 + sk) * LDV + nt * 16];
+            }
+#pragma unroll
+            for (int sk = 0; sk < 4; ++sk)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[sub][sk], vb[sub & 1][sk][nt], o[nt], 0, 0, 0);
+            if (sub + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4 * NT, 0);     // next sub-tile's V fragments ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);                      // ... then this one's MFMAs
+        }
+    }
+    // ---- normalise and write: lane (c = li, g) owns O[q0 + 4g + r][nt*16 + li] ----
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float ir = __shfl(inv, 4 * g + r, 64);
+        const int qi = q0 + 4 * g + r;
+        if (qi < L) {
+            float* orow = out + (seq0 + qi) * ldo + hh * DV;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) orow[nt * 16 + li] = o[nt][r] * ir;
+        }
+    }
+}
+
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
                       int DQK, int DV) {
     if (S <= 0 || L <= 0) return;
@@ -395,6 +550,16 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
     }
     constexpr int KS = 4;
     dim3 grid((unsigned)cdiv(L, 64), (unsigned)H, (unsigned)S);
+    static const bool use_mfma = []() { const char* e = getenv("MCR_ATTN_MFMA"); return !(e && e[0] == '0'); }();   // dev A/B knob
+    const bool al16 = aligned16(qkv) && ldq % 4 == 0 && (H * dq) % 4 == 0;
+    if (use_mfma && al16 && dq == 8 && dv == 32) {
+        hipLaunchKernelGGL((attention_mfma_kernel<8, 32>), grid, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H);
+        return;
+    }
+    if (use_mfma && al16 && dq == 16 && dv == 64) {
+        hipLaunchKernelGGL((attention_mfma_kernel<16, 64>), grid, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H);
+        return;
+    }
     if (dq == 8 && dv == 32)
         hipLaunchKernelGGL((attention_flash_kernel<8, 32, KS>), grid, dim3(64 * KS), 0, s, qkv, (long long)ldq, out,
                            (long long)ldo, L, H);
