@@ -5,10 +5,12 @@
 // offset step of macarons/networks/SconeOcc.py:297-298 (neighbours minus the query).
 //
 // One lane owns one query and keeps its k best (d2, index) pairs sorted in VGPRs; surface points stream
-// through LDS in tiles (one broadcast ds_read_b128 per candidate per wave).  The 4 waves of a workgroup own the
-// SAME 64 queries and each scans a quarter of every tile (4x more waves in flight: Q/64 waves alone cannot
-// fill 1024 SIMDs), candidates are taken 4 at a time (independent distance computations, one branch per
-// batch), and the four sorted lists are merged through LDS at the end.  Convention (shared with
+// through LDS in tiles (one broadcast ds_read_b128 per candidate per wave).  A workgroup = 2 query tiles of 64 x 2
+// waves per tile; the two waves of a tile each scan every other candidate (Q/64 waves alone cannot fill 1024 SIMDs)
+// and their sorted lists are merged through LDS at the end.  A 4-way split was measured first: every extra split
+// re-pays the ~16 ln(M/16) list insertions per lane, and its 6252 waves at 3 blocks/CU needed 2.03 rounds of the chip
+// = 3; this shape needs 40 KB of LDS (4 blocks/CU) and 782 blocks = 0.76 rounds at Q = 100k with 35 % fewer
+// instructions.  Candidates are taken 4 at a time (independent distance computations, one branch per batch).  Convention (shared with
 // oracle/knn.py, see there why the reference's own tie order is unspecified):
 //   d2 = (dx*dx + dy*dy) + dz*dz in fp32 with every product and sum rounded (no FMA contraction),
 //   ascending by (d2, index): ties go to the lower index;  dists = sqrt(d2), correctly rounded.
@@ -19,7 +21,9 @@ namespace mcr {
 
 constexpr int KNN_BLOCK = 256;
 constexpr int KNN_WAVES = KNN_BLOCK / MCR_WAVE;
-constexpr int KNN_TILE = 2048;     // surface points per LDS tile (32 KB as float4); multiple of 16
+constexpr int KNN_SPLIT = 2;                       // waves sharing one 64-query tile
+constexpr int KNN_QT = KNN_WAVES / KNN_SPLIT;      // query tiles per workgroup
+constexpr int KNN_TILE = 1536;     // surface points per LDS tile (24 KB as float4); multiple of 16
 constexpr int KNN_QCAP = 8;        // per-lane queue of accepted candidates (LDS, [slot][thread])
 
 // Insert (d2, idx) into the ascending list: slot j takes its upper neighbour if that one must move down,
@@ -64,19 +68,22 @@ __device__ __forceinline__ float knn_d2(float qx, float qy, float qz, const floa
     return s + zz;
 }
 
-// grid = (ceil(Q/64), B); block = 4 waves x 64 queries
+// grid = (ceil(Q/128), B); block = 2 query tiles x 2 waves
 template <int K, bool OFFSETS>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict__ X, const float* __restrict__ pc,
                                                         long long* __restrict__ out_idx, float* __restrict__ out_dist,
                                                         float* __restrict__ out_pts, int Q, int M) {
-    __shared__ float4 s_pc[KNN_TILE];           // reused as the merge buffer at the end
-    __shared__ float s_qd[KNN_QCAP * KNN_BLOCK];
-    __shared__ int s_qi[KNN_QCAP * KNN_BLOCK];
-    static_assert(KNN_WAVES * K * MCR_WAVE * 8 <= KNN_TILE * 16, "merge buffer does not fit the tile buffer");
+    // 40 KB: [tile 24 KB][queue distances 8 KB][queue indices 8 KB]; the first 32 KB are reused as the merge buffer
+    __shared__ __attribute__((aligned(16))) char smem[KNN_TILE * 16 + 2 * KNN_QCAP * KNN_BLOCK * 4];
+    float4* s_pc = reinterpret_cast<float4*>(smem);
+    float* s_qd = reinterpret_cast<float*>(smem + KNN_TILE * 16);
+    int* s_qi = reinterpret_cast<int*>(smem + KNN_TILE * 16 + KNN_QCAP * KNN_BLOCK * 4);
+    static_assert(KNN_WAVES * K * MCR_WAVE * 8 <= KNN_TILE * 16 + KNN_QCAP * KNN_BLOCK * 4, "merge buffer does not fit");
     const int b = blockIdx.y;
     const int lane = threadIdx.x & (MCR_WAVE - 1);
     const int wave = threadIdx.x / MCR_WAVE;
-    const int q = blockIdx.x * MCR_WAVE + lane;
+    const int qt = wave / KNN_SPLIT, part = wave % KNN_SPLIT;
+    const int q = (blockIdx.x * KNN_QT + qt) * MCR_WAVE + lane;
     const bool valid = q < Q;
     const float* xq = X + ((size_t)b * Q + (valid ? q : Q - 1)) * 3;
     const float qx = xq[0], qy = xq[1], qz = xq[2];
@@ -125,39 +132,41 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
             }
         }
         __syncthreads();
-        // wave w scans candidates i = w, w+4, w+8, ... of the tile, 4 per iteration
-        for (int i = wave; i < nt_pad; i += 4 * KNN_WAVES) {
-            const float4 p0 = s_pc[i], p1 = s_pc[i + KNN_WAVES], p2 = s_pc[i + 2 * KNN_WAVES], p3 = s_pc[i + 3 * KNN_WAVES];
+        // the wave scans candidates i = part, part + SPLIT, ... of the tile, 4 per iteration
+        for (int i = part; i < nt_pad; i += 4 * KNN_SPLIT) {
+            const float4 p0 = s_pc[i], p1 = s_pc[i + KNN_SPLIT], p2 = s_pc[i + 2 * KNN_SPLIT], p3 = s_pc[i + 3 * KNN_SPLIT];
             const float d0 = knn_d2(qx, qy, qz, p0), d1 = knn_d2(qx, qy, qz, p1);
             const float d2 = knn_d2(qx, qy, qz, p2), d3 = knn_d2(qx, qy, qz, p3);
             push(d0, t0 + i);
-            push(d1, t0 + i + KNN_WAVES);
-            push(d2, t0 + i + 2 * KNN_WAVES);
-            push(d3, t0 + i + 3 * KNN_WAVES);
+            push(d1, t0 + i + KNN_SPLIT);
+            push(d2, t0 + i + 2 * KNN_SPLIT);
+            push(d3, t0 + i + 3 * KNN_SPLIT);
             if (__any(cnt > KNN_QCAP - 4)) flush();
         }
     }
     flush();
-    // ---- 4-way merge of the waves' sorted lists (lexicographic on (d2, index)) ------------------------------
+    // ---- merge of the tile's KNN_SPLIT sorted lists (lexicographic on (d2, index)) ----------------------------
     __syncthreads();
-    float* m_d = reinterpret_cast<float*>(s_pc);                        // [wave][K][lane]
-    int* m_i = reinterpret_cast<int*>(s_pc) + KNN_WAVES * K * MCR_WAVE;
+    float* m_d = reinterpret_cast<float*>(smem);                        // [wave][K][lane]
+    int* m_i = reinterpret_cast<int*>(smem) + KNN_WAVES * K * MCR_WAVE;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         m_d[(wave * K + j) * MCR_WAVE + lane] = bd[j];
         m_i[(wave * K + j) * MCR_WAVE + lane] = bi[j];
     }
     __syncthreads();
-    if (wave != 0 || !valid) return;
-    int head[KNN_WAVES];
+    if (part != 0 || !valid) return;
+    m_d += qt * KNN_SPLIT * K * MCR_WAVE;                               // this tile's lists
+    m_i += qt * KNN_SPLIT * K * MCR_WAVE;
+    int head[KNN_SPLIT];
 #pragma unroll
-    for (int w = 0; w < KNN_WAVES; ++w) head[w] = 0;
+    for (int w = 0; w < KNN_SPLIT; ++w) head[w] = 0;
     const size_t o = ((size_t)b * Q + q) * K;
     for (int j = 0; j < K; ++j) {
         float best_d = __builtin_inff();
         int best_i = 0x7fffffff, best_w = 0;
 #pragma unroll
-        for (int w = 0; w < KNN_WAVES; ++w) {
+        for (int w = 0; w < KNN_SPLIT; ++w) {
             const int h = head[w] < K ? head[w] : K - 1;
             const float d = head[w] < K ? m_d[(w * K + h) * MCR_WAVE + lane] : __builtin_inff();
             const int id = head[w] < K ? m_i[(w * K + h) * MCR_WAVE + lane] : 0x7fffffff;
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
             best_w = better ? w : best_w;
         }
 #pragma unroll
-        for (int w = 0; w < KNN_WAVES; ++w) head[w] += (best_w == w) ? 1 : 0;
+        for (int w = 0; w < KNN_SPLIT; ++w) head[w] += (best_w == w) ? 1 : 0;
         out_idx[o + j] = (long long)best_i;
         out_dist[o + j] = sqrt_cr(best_d);
         const float* p = pcb + (size_t)best_i * 3;
@@ -197,7 +206,7 @@ extern "C" int mcr_knn_points(const float* X, const float* pc, int64_t* idx, flo
     MCR_REQUIRE(k <= M, "mcr_knn_points: k=%d exceeds the number of points M=%ld (torch.topk would raise)", k, (long)M);
     MCR_REQUIRE(B <= 65535 && Q < (1ll << 31) && M < (1ll << 31), "mcr_knn_points: problem too large");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)cdiv(Q, MCR_WAVE), (unsigned)B);
+    dim3 grid((unsigned)cdiv(Q, MCR_WAVE * KNN_QT), (unsigned)B);
     long long* i64 = (long long*)idx;
     switch (k) {
         case 1: launch_knn<1>(subtract_query, grid, s, X, pc, i64, dists, pts, (int)Q, (int)M); break;
