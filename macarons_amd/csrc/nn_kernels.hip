@@ -573,18 +573,20 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
 // =====================================================================================================
 // pooling / broadcast / copy helpers
 // =====================================================================================================
-// grid = (S, ceil(E/64)); block = 64 columns x 4 row lanes
+// grid = (S, ceil(E/64)); block = 64 columns x 16 row lanes (the long sequences here are one or two per launch, so the
+// rows have to be spread inside the block: with 4 row lanes the 2048-row reductions of an NBV step took 0.27 ms)
+constexpr int POOL_RL = 16;
 template <bool BROADCAST>
-__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ X, long long ldx, float* __restrict__ Y,
-                                                   long long ldy, int L, int E) {
-    __shared__ float s_max[4][64];
-    __shared__ float s_sum[4][64];
+__global__ __launch_bounds__(64 * POOL_RL) void pool_kernel(const float* __restrict__ X, long long ldx, float* __restrict__ Y,
+                                                            long long ldy, int L, int E) {
+    __shared__ float s_max[POOL_RL][64];
+    __shared__ float s_sum[POOL_RL][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
     const long long row0 = (long long)blockIdx.x * L;
     float mx = -__builtin_inff(), sm = 0.f;
     if (c < E)
-        for (int r = g; r < L; r += 4) {
+        for (int r = g; r < L; r += POOL_RL) {
             const float v = X[(row0 + r) * ldx + c];
             mx = fmaxf(mx, v);
             sm += v;
@@ -592,11 +594,16 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ X, 
     s_max[g][cl] = mx;
     s_sum[g][cl] = sm;
     __syncthreads();
-    mx = fmaxf(fmaxf(s_max[0][cl], s_max[1][cl]), fmaxf(s_max[2][cl], s_max[3][cl]));
-    sm = (s_sum[0][cl] + s_sum[1][cl]) + (s_sum[2][cl] + s_sum[3][cl]);
+    mx = s_max[0][cl];
+    sm = s_sum[0][cl];
+#pragma unroll
+    for (int k = 1; k < POOL_RL; ++k) {
+        mx = fmaxf(mx, s_max[k][cl]);
+        sm += s_sum[k][cl];
+    }
     if (c >= E) return;
     if (BROADCAST) {
-        for (int r = g; r < L; r += 4) Y[(row0 + r) * ldy + c] = mx;
+        for (int r = g; r < L; r += POOL_RL) Y[(row0 + r) * ldy + c] = mx;
     } else if (g == 0) {
         Y[(long long)blockIdx.x * ldy + c] = mx;
         Y[(long long)blockIdx.x * ldy + E + c] = sm / (float)L;
@@ -605,13 +612,13 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ X, 
 
 void launch_colmax_broadcast(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E) {
     if (S <= 0) return;
-    hipLaunchKernelGGL((pool_kernel<true>), dim3((unsigned)S, (unsigned)cdiv(E, 64)), dim3(256), 0, s, X, (long long)ldx, Y,
+    hipLaunchKernelGGL((pool_kernel<true>), dim3((unsigned)S, (unsigned)cdiv(E, 64)), dim3(64 * POOL_RL), 0, s, X, (long long)ldx, Y,
                        (long long)ldy, L, E);
 }
 
 void launch_pool_max_avg(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E) {
     if (S <= 0) return;
-    hipLaunchKernelGGL((pool_kernel<false>), dim3((unsigned)S, (unsigned)cdiv(E, 64)), dim3(256), 0, s, X, (long long)ldx, Y,
+    hipLaunchKernelGGL((pool_kernel<false>), dim3((unsigned)S, (unsigned)cdiv(E, 64)), dim3(64 * POOL_RL), 0, s, X, (long long)ldx, Y,
                        (long long)ldy, L, E);
 }
 
