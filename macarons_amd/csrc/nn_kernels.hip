@@ -20,17 +20,20 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 //   lane halves take k = h*16 + s (s = 0..15), so every lane reads 16 consecutive floats of "its" row with
 //   four ds_read_b128 (row stride 36 floats keeps the 16-lane read groups on distinct banks).
 // =====================================================================================================
-constexpr int LIN_BM = 128, LIN_BK = 32, LIN_LD = LIN_BK + 4;
+constexpr int LIN_BM = 128;
+// K chunk per barrier pair: 32 for the streaming shapes; 128 for the small-M GEMMs of the 2048-token networks, which are a
+// handful of blocks deep in a chain of (global load -> LDS -> barrier -> MFMA) latencies: 4x fewer links per product.
 
 // NT = 8 holds 128 accumulator registers: capping it at 256 total keeps two waves per SIMD resident (measured
 // 1.84 -> 1.57 ms on the 1344 -> 512 head GEMM); pipelining the LDS fragment reads on top of that spills.
-template <int NT>
+template <int NT, int LIN_BK = 32>
 __global__ __launch_bounds__(256, NT == 8 ? 2 : 1) void linear_kernel(const float* __restrict__ X, long long ldx,
                                                      const float* __restrict__ W, long long ldw,
                                                      const float* __restrict__ bias, const float* __restrict__ row_bias,
                                                      long long rows_per_group, const float* __restrict__ R, long long ldr,
                                                      float* __restrict__ Y, long long ldy, long long M, int N, int K,
                                                      int act, int vec_x, int vec_w) {
+    constexpr int LIN_LD = LIN_BK + 4, F4 = LIN_BK / 4, RA = F4 / 2, RB = NT * F4 / 8;     // float4 per row; per-thread staging counts
     __shared__ __attribute__((aligned(16))) float As[LIN_BM * LIN_LD];
     __shared__ __attribute__((aligned(16))) float Bs[NT * 32 * LIN_LD];
     const int tid = threadIdx.x;
@@ -47,19 +50,19 @@ __global__ __launch_bounds__(256, NT == 8 ? 2 : 1) void linear_kernel(const floa
 
     // Staging registers: chunk k+1 is fetched from global memory while chunk k is in the MFMA phase
     // (issue-early / write-late split), so HBM/L2 latency hides behind the matrix pipe.
-    float4 ra[4], rb[NT];
+    float4 ra[RA], rb[RB];
     auto fetch = [&](int k0) {
         if (vec_x) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+            for (int r = 0; r < RA; ++r) {
+                const int idx = tid + r * 256, row = idx / F4, c4 = (idx % F4) * 4;
                 ra[r] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (m0 + row < M && k0 + c4 < K) ra[r] = *reinterpret_cast<const float4*>(X + (m0 + row) * ldx + k0 + c4);
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+            for (int r = 0; r < RA; ++r) {
+                const int idx = tid + r * 256, row = idx / F4, c4 = (idx % F4) * 4;
                 const float* px = X + (m0 + row) * ldx + k0 + c4;
                 const bool rv = m0 + row < M;
                 ra[r].x = rv && k0 + c4 + 0 < K ? px[0] : 0.f;
@@ -70,15 +73,15 @@ __global__ __launch_bounds__(256, NT == 8 ? 2 : 1) void linear_kernel(const floa
         }
         if (vec_w) {
 #pragma unroll
-            for (int r = 0; r < NT; ++r) {
-                const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+            for (int r = 0; r < RB; ++r) {
+                const int idx = tid + r * 256, row = idx / F4, c4 = (idx % F4) * 4;
                 rb[r] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (n0 + row < N && k0 + c4 < K) rb[r] = *reinterpret_cast<const float4*>(W + (long long)(n0 + row) * ldw + k0 + c4);
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < NT; ++r) {
-                const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+            for (int r = 0; r < RB; ++r) {
+                const int idx = tid + r * 256, row = idx / F4, c4 = (idx % F4) * 4;
                 const float* pw = W + (long long)(n0 + row) * ldw + k0 + c4;
                 const bool rv = n0 + row < N;
                 rb[r].x = rv && k0 + c4 + 0 < K ? pw[0] : 0.f;
@@ -92,25 +95,25 @@ __global__ __launch_bounds__(256, NT == 8 ? 2 : 1) void linear_kernel(const floa
     for (int k0 = 0; k0 < K; k0 += LIN_BK) {
         // ---- write the staged chunk to LDS (A: 128 x 32, B: NT*32 x 32, zero-padded) ----
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+        for (int r = 0; r < RA; ++r) {
+            const int idx = tid + r * 256, row = idx / F4, c4 = (idx % F4) * 4;
             *reinterpret_cast<float4*>(&As[row * LIN_LD + c4]) = ra[r];
         }
 #pragma unroll
-        for (int r = 0; r < NT; ++r) {
-            const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+        for (int r = 0; r < RB; ++r) {
+            const int idx = tid + r * 256, row = idx / F4, c4 = (idx % F4) * 4;
             *reinterpret_cast<float4*>(&Bs[row * LIN_LD + c4]) = rb[r];
         }
         __syncthreads();
         if (k0 + LIN_BK < K) fetch(k0 + LIN_BK);       // in flight during the MFMA phase
         // ---- MFMA over the chunk ----
-        const float* a_row = &As[(wave * 32 + i) * LIN_LD + h * 16];
+        const float* a_row = &As[(wave * 32 + i) * LIN_LD + h * (LIN_BK / 2)];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
+        for (int s4 = 0; s4 < LIN_BK / 8; ++s4) {
             const float4 a4 = *reinterpret_cast<const float4*>(a_row + s4 * 4);
             float4 b4[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b4[t] = *reinterpret_cast<const float4*>(&Bs[(t * 32 + i) * LIN_LD + h * 16 + s4 * 4]);
+            for (int t = 0; t < NT; ++t) b4[t] = *reinterpret_cast<const float4*>(&Bs[(t * 32 + i) * LIN_LD + h * (LIN_BK / 2) + s4 * 4]);
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[t].x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -162,6 +165,17 @@ void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, c
     while (nt > 1 && (nt / 2) * 32 >= N) nt >>= 1;
     while (nt > 1 && mb * cdiv(N, nt * 32) < 512) nt >>= 1;
     dim3 grid((unsigned)mb, (unsigned)cdiv(N, nt * 32));
+    if (nt <= 2 && K >= 128 && K % 4 == 0 && mb * cdiv(N, nt * 32) <= 512) {      // small problem: latency chain, deep K chunks
+        if (nt == 2)
+            hipLaunchKernelGGL((linear_kernel<2, 128>), grid, dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw, bias, row_bias,
+                               (long long)(rows_per_group > 0 ? rows_per_group : 1), R, (long long)ldr, Y, (long long)ldy, (long long)M,
+                               N, K, act, vec_x, vec_w);
+        else
+            hipLaunchKernelGGL((linear_kernel<1, 128>), grid, dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw, bias, row_bias,
+                               (long long)(rows_per_group > 0 ? rows_per_group : 1), R, (long long)ldr, Y, (long long)ldy, (long long)M,
+                               N, K, act, vec_x, vec_w);
+        return;
+    }
 #define MCR_LIN(NT)                                                                                                   \
     hipLaunchKernelGGL((linear_kernel<NT>), grid, dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw, bias, row_bias, \
                        (long long)(rows_per_group > 0 ? rows_per_group : 1), R, (long long)ldr, Y, (long long)ldy,       \
