@@ -78,6 +78,9 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
+    for tmp in glob.glob(LIB_PATH + ".*"):          # hipcc leaves its per-object unbundled images next to the output
+        if tmp != STAMP:
+            os.remove(tmp)
     with open(STAMP, "w") as f:
         f.write(dig)
     return LIB_PATH

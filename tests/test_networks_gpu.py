@@ -46,7 +46,9 @@ def test_blocks(dev):
 
 @pytest.mark.parametrize("M,N,K,gelu,res", [(1, 1, 1, False, False), (130, 126, 4, True, False), (1000, 125, 125, False, False),
                                              (257, 512, 256, True, False), (4097, 128, 256, False, True),
-                                             (300, 1, 256, True, False), (64, 192, 128, False, False), (33, 64, 1344, True, True)])
+                                             (300, 1, 256, True, False), (64, 192, 128, False, False), (33, 64, 1344, True, True),
+                                             # large enough for the split-precision GEMM (linear3.hip), ragged in M, N and the K chunk
+                                             (40000, 200, 72, True, True), (33000, 128, 256, False, False)])
 def test_linear_vs_numpy(dev, M, N, K, gelu, res):
     from macarons_amd import ops
     rng = np.random.default_rng(M + N + K)
@@ -60,6 +62,23 @@ def test_linear_vs_numpy(dev, M, N, K, gelu, res):
         ref = nets.gelu(ref)
     if res:
         ref = ref + r
+    assert np.abs(y - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("S,L,H,qk,v", [(1, 2048, 4, 64, 256), (1, 1777, 4, 64, 256), (3, 333, 4, 32, 128), (2, 65, 4, 32, 128)])
+def test_long_sequence_attention_vs_numpy(dev, S, L, H, qk, v):
+    """The MFMA flash-attention kernel (attention() of Attention.py:8-36 on packed q|k|v, mask=None) against an fp64
+    softmax(QK^T/sqrt(d))V, incl. sequence lengths that are not a multiple of the 64-key tile / 16-query wave."""
+    from macarons_amd import ops
+    rng = np.random.default_rng(S * 1000 + L)
+    qkv = rng.standard_normal((S, L, 2 * qk + v)).astype(np.float32)
+    y = ops.attention_packed(T(qkv, dev), H, qk, v).cpu().numpy()
+    x = qkv.astype(np.float64)
+    hs = lambda t, d: t.reshape(S, L, H, d).transpose(0, 2, 1, 3)
+    q, k, vv = hs(x[..., :qk], qk // H), hs(x[..., qk:2 * qk], qk // H), hs(x[..., 2 * qk:], v // H)
+    sc = q @ k.transpose(0, 1, 3, 2) / np.sqrt(qk // H)
+    sc = np.exp(sc - sc.max(-1, keepdims=True))
+    ref = ((sc / sc.sum(-1, keepdims=True)) @ vv).transpose(0, 2, 1, 3).reshape(S, L, v)
     assert np.abs(y - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
