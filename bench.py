@@ -105,7 +105,7 @@ def measure_nbv_step(dev, rank, world, args):
     u = torch.rand(2048, generator=g).to(dev)
     grid = ViewStateGrid(dev)
     torch.manual_seed(11)
-    perms = occ.draw_perms(M)
+    perms = [p.to(dev) for p in occ.draw_perms(M)]       # the three randperm draws of SconeOcc.forward, pinned and resident
     group = torch.distributed.group.WORLD if torch.distributed.is_initialized() else None     # shards Q and C over the ranks
     times = []
     for it in range(10 + args.nbv_iters):
