@@ -148,6 +148,13 @@ int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, co
                      float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
                      int64_t* inverse, int* n_unique, double* volume, void* workspace, size_t workspace_bytes, void* stream);
 int mcr_points_in_fov(const float* pts, int64_t P, const float* cameras, int n_cam, unsigned char* mask, void* stream);
+/* filter_proxy_points (macarons/utility/scone_utils.py:1001-1027; call site testers/shapenet.py:122): mask[p] = 1 iff in every
+ * view v the projection ([x y z 1] * proj[v])[:2] / w of X[p] lies strictly inside the bounding box of the projected surface
+ * cloud pc grown by filter_tol.  proj = n_view row-major 4x4 full-projection matrices (row-vector convention, as
+ * pytorch3d's get_full_projection_transform().get_matrix()); bounds = n_view*4 floats of scratch, left holding
+ * {min_x, max_x, min_y, max_y} per view. */
+int mcr_filter_proxy_points(const float* X, int64_t P, const float* pc, int64_t M, const float* proj, int n_view, float filter_tol,
+                            float* bounds, unsigned char* mask, void* stream);
 int mcr_coverage_gain_multiple(const float* vis, float* gains, int64_t B, int64_t C, int64_t N, int n_cam, void* stream);
 
 /* Arg-max exchange of the camera-sharded decision (the reference takes torch.max over all cameras on one GPU,

@@ -233,6 +233,65 @@ __global__ void fov_kernel(const float* __restrict__ pts, long long P, const flo
     mask[gid] = m ? 1 : 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// filter_proxy_points (macarons/utility/scone_utils.py:1001-1027): keep the proxy points whose projection falls, in EVERY
+// view camera, inside the screen-space bounding box of the projected surface cloud grown by filter_tol (strict compares).
+// Same camera convention as K2: ndc = ([x y z 1] * M_proj)[:2] / w with M_proj row-major 4x4 per view.
+// Pass 1: per view min/max of the projected cloud (one block per view, order-independent);  pass 2: the mask.
+__device__ __forceinline__ void project_xy(const float* __restrict__ Mp, float x, float y, float z, float& nx, float& ny) {
+    const float px = ((x * Mp[0] + y * Mp[4]) + z * Mp[8]) + Mp[12];
+    const float py = ((x * Mp[1] + y * Mp[5]) + z * Mp[9]) + Mp[13];
+    const float pw = ((x * Mp[3] + y * Mp[7]) + z * Mp[11]) + Mp[15];
+    nx = px / pw;
+    ny = py / pw;
+}
+
+__global__ __launch_bounds__(256) void proj_bounds_kernel(const float* __restrict__ pc, long long M, const float* __restrict__ proj,
+                                                          float* __restrict__ bounds) {
+    __shared__ float s[4][4];
+    const float* Mp = proj + blockIdx.x * 16;
+    float mnx = __builtin_inff(), mxx = -__builtin_inff(), mny = __builtin_inff(), mxy = -__builtin_inff();
+    for (long long i = threadIdx.x; i < M; i += 256) {
+        float nx, ny;
+        project_xy(Mp, pc[3 * i], pc[3 * i + 1], pc[3 * i + 2], nx, ny);
+        mnx = fminf(mnx, nx); mxx = fmaxf(mxx, nx);
+        mny = fminf(mny, ny); mxy = fmaxf(mxy, ny);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64));
+        mny = fminf(mny, __shfl_xor(mny, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        float* r = s[threadIdx.x >> 6];
+        r[0] = mnx; r[1] = mxx; r[2] = mny; r[3] = mxy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* b = bounds + blockIdx.x * 4;                  // {min_x, max_x, min_y, max_y}
+        b[0] = fminf(fminf(s[0][0], s[1][0]), fminf(s[2][0], s[3][0]));
+        b[1] = fmaxf(fmaxf(s[0][1], s[1][1]), fmaxf(s[2][1], s[3][1]));
+        b[2] = fminf(fminf(s[0][2], s[1][2]), fminf(s[2][2], s[3][2]));
+        b[3] = fmaxf(fmaxf(s[0][3], s[1][3]), fmaxf(s[2][3], s[3][3]));
+    }
+}
+
+__global__ void filter_proxy_kernel(const float* __restrict__ X, long long P, const float* __restrict__ proj, int n_view,
+                                    const float* __restrict__ bounds, float tol, unsigned char* __restrict__ mask) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float x = X[3 * p], y = X[3 * p + 1], z = X[3 * p + 2];
+    bool keep = true;
+    for (int v = 0; v < n_view; ++v) {
+        float nx, ny;
+        project_xy(proj + v * 16, x, y, z, nx, ny);
+        const float* b = bounds + v * 4;
+        keep = keep && (nx < b[1] + tol) && (nx > b[0] - tol) && (ny < b[3] + tol) && (ny > b[2] - tol);
+    }
+    mask[p] = keep ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // a3: gains of every ordered n-tuple of cameras: mean_n max_t vis[b, c_t, n]   (SconeVis.py:289-301)
 // grid = (C^n tuples, B); one block per tuple, tree reduce in fixed order.
@@ -463,6 +522,17 @@ int mcr_points_in_fov(const float* pts, int64_t P, const float* cameras, int n_c
     hipLaunchKernelGGL(fov_kernel, dim3((unsigned)cdiv(P * n_cam, 256)), dim3(256), 0, (hipStream_t)stream, pts, (long long)P,
                        cameras, n_cam, mask);
     MCR_LAUNCH_CHECK("fov_kernel");
+    return 0;
+}
+
+int mcr_filter_proxy_points(const float* X, int64_t P, const float* pc, int64_t M, const float* proj, int n_view, float filter_tol,
+                            float* bounds, unsigned char* mask, void* stream) {
+    MCR_REQUIRE(X && pc && proj && bounds && mask && P > 0 && M > 0 && n_view > 0, "mcr_filter_proxy_points: bad arguments");
+    hipLaunchKernelGGL(proj_bounds_kernel, dim3((unsigned)n_view), dim3(256), 0, (hipStream_t)stream, pc, (long long)M, proj, bounds);
+    MCR_LAUNCH_CHECK("proj_bounds_kernel");
+    hipLaunchKernelGGL(filter_proxy_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, X, (long long)P, proj,
+                       n_view, bounds, filter_tol, mask);
+    MCR_LAUNCH_CHECK("filter_proxy_kernel");
     return 0;
 }
 

@@ -307,6 +307,22 @@ def coverage_gain_multiple(pts, harmonics, cams, n_cam, use_sigmoid=True):
     return out, n_idx
 
 
+def filter_proxy_mask(X, pc, proj, filter_tol):
+    """X [P,3], pc [M,3], proj [n_view,4,4] (row-vector full-projection matrices) -> (mask bool [P], bounds [n_view,4])."""
+    X, pc, proj = _req(X, "X"), _req(pc, "pc"), _req(proj, "proj")
+    if X.dim() != 2 or pc.dim() != 2 or X.shape[1] != 3 or pc.shape[1] != 3:
+        raise NameError("Wrong shapes! X must have shape (n_proxy_points, 3) and pc must have shape (N, 3).")
+    n_view = proj.shape[0]
+    if tuple(proj.shape[1:]) != (4, 4):
+        raise ValueError("proj must be [n_view,4,4]")
+    mask = torch.empty(X.shape[0], dtype=torch.uint8, device=X.device)
+    bounds = torch.empty((n_view, 4), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        check(lib().mcr_filter_proxy_points(_p(X), c_i64(X.shape[0]), _p(pc), c_i64(pc.shape[0]), _p(proj), c_int(n_view),
+                                            c_f32(float(filter_tol)), _p(bounds), _p(mask), _stream()), "mcr_filter_proxy_points")
+    return mask.bool(), bounds
+
+
 def best_record(gains, idx_offset=0, out=None):
     """gains [B,C] -> records [B,2] fp32 = (max, idx_offset + first arg-max): torch.max(gains, dim=1) as one 8-byte record."""
     gains = _req(gains, "gains")

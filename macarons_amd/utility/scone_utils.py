@@ -92,6 +92,18 @@ def compute_occupancy_probability(scone_occ, pc, X, view_harmonics, mask=None, m
     return preds[0] if len(preds) == 1 else torch.cat(preds, dim=1)
 
 
+def filter_proxy_points(view_cameras, X, pc, filter_tol=0.01):
+    """(X[mask], mask): scone_utils.py:1001-1027.  `view_cameras` is either the reference's PyTorch3D camera batch (anything
+    with get_full_projection_transform().get_matrix() -> [n_view,4,4], row-vector convention) or that matrix stack itself;
+    PyTorch3D objects stay outside the kernels.  Works for a single scene: X [P,3], pc [N,3]."""
+    if (len(X.shape) != 2) or (len(pc.shape) != 2):
+        raise NameError("Wrong shapes! X must have shape (n_proxy_points, 3) and pc must have shape (N, 3).")
+    proj = view_cameras if torch.is_tensor(view_cameras) else view_cameras.get_full_projection_transform().get_matrix()
+    proj = proj.to(device=X.device, dtype=torch.float32).contiguous()
+    mask, _ = ops.filter_proxy_mask(X.contiguous(), pc.contiguous(), proj, filter_tol)
+    return X[mask], mask
+
+
 def sample_proxy_points(X_world, preds, view_harmonics, n_sample, min_occ, use_occ_to_sample=True, return_index=False,
                         samples=None):
     """scone_utils.py:1030-1076.  `samples` (optional, [n_sample]) pins the uniforms; otherwise they are drawn with

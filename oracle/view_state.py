@@ -133,3 +133,32 @@ def sampler_tie_aware_match(res_a, inv_a, res_b, inv_b, X_world, preds, min_occ,
         if len(ia) == 0 or len(ib) == 0 or abs(int(ia[0]) - int(ib[0])) != 1:
             return False
     return True
+
+
+def project_xy(M, pts):
+    """ndc xy of pts [P,3] under a row-vector 4x4 projection (pytorch3d Transform3d.transform_points: [x y z 1] M, / w),
+    fp32 with the evaluation order of the HIP kernels."""
+    F = np.float32
+    pts = np.asarray(pts, F)
+    M = np.asarray(M, F).reshape(4, 4)
+    x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+    lin = lambda j: ((x * M[0, j] + y * M[1, j]) + z * M[2, j]) + M[3, j]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (lin(0) / lin(3)).astype(F), (lin(1) / lin(3)).astype(F)
+
+
+def filter_proxy_points(proj, X, pc, filter_tol=0.01):
+    """Restates macarons/utility/scone_utils.py:1001-1027 given the views' full-projection matrices proj [n_view,4,4]:
+    mask = AND over views and over {x, y} of (X_proj < max(pc_proj) + tol) & (X_proj > min(pc_proj) - tol).  Returns
+    (mask bool [P], bounds [n_view,4] = min_x, max_x, min_y, max_y)."""
+    F = np.float32
+    proj = np.asarray(proj, F)
+    mask = np.ones(len(X), bool)
+    bounds = np.zeros((proj.shape[0], 4), F)
+    tol = F(filter_tol)
+    for v in range(proj.shape[0]):
+        cx, cy = project_xy(proj[v], pc)
+        nx, ny = project_xy(proj[v], X)
+        bounds[v] = [cx.min(), cx.max(), cy.min(), cy.max()]
+        mask &= (nx < F(bounds[v, 1] + tol)) & (nx > F(bounds[v, 0] - tol)) & (ny < F(bounds[v, 3] + tol)) & (ny > F(bounds[v, 2] - tol))
+    return mask, bounds

@@ -327,7 +327,85 @@ def gen_macarons():
     save("macarons_regime", pts=pts, cam=cam, factor=fac.numpy())
 
 
-GROUPS = {"macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
+
+class _StandInCameras:
+    """PyTorch3D is not installed in the build container.  The reference helpers that take a camera batch only use
+    `.R.shape[0]`, `get_full_projection_transform().transform_points(p)` and (move_view_state_to_view_space)
+    `get_world_to_view_transform().inverse().transform_points(p)` / `get_camera_center()`: this stand-in supplies them from
+    explicit row-vector matrices, with Transform3d.transform_points as published ([x y z 1] M, divided by w) evaluated in
+    the fixed order the HIP kernels and the oracle use.  The reference FUNCTION's own logic is what the golden pins."""
+
+    class _T:
+        def __init__(self, M):
+            self.M = M                                   # [n,4,4]
+
+        def transform_points(self, p):
+            p = p.reshape(-1, 3)
+            x, y, z = p[:, 0], p[:, 1], p[:, 2]
+            cols = [((x[None] * self.M[:, 0, j, None] + y[None] * self.M[:, 1, j, None]) + z[None] * self.M[:, 2, j, None])
+                    + self.M[:, 3, j, None] for j in range(4)]
+            return torch.stack([cols[0] / cols[3], cols[1] / cols[3], cols[2] / cols[3]], -1)       # [n,P,3]
+
+        def inverse(self):
+            return _StandInCameras._T(torch.linalg.inv(self.M.double()).float())
+
+    def __init__(self, R, T, P=None):
+        self.R, self.T = R, T
+        n = R.shape[0]
+        self.Mv = torch.zeros(n, 4, 4)
+        self.Mv[:, :3, :3] = R
+        self.Mv[:, 3, :3] = T
+        self.Mv[:, 3, 3] = 1.0
+        self.P = P
+
+    def get_world_to_view_transform(self):
+        return self._T(self.Mv)
+
+    def get_full_projection_transform(self):
+        return self._T(self.Mv @ self.P)
+
+    def get_camera_center(self):
+        return -torch.einsum("nj,nij->ni", self.T, self.R)            # C = -T R^T
+
+
+def _look_at(eye):
+    """pytorch3d look_at_view_transform(eye=eye, at=0, up=+Y) as published: z = normalize(at - eye), x = normalize(up x z),
+    y = z x x;  R = [x y z] as columns, T = -R^T eye."""
+    eye = np.asarray(eye, np.float64)
+    z = -eye / np.linalg.norm(eye, axis=-1, keepdims=True)
+    up = np.broadcast_to([0.0, 1.0, 0.0], eye.shape)
+    x = np.cross(up, z)
+    x /= np.linalg.norm(x, axis=-1, keepdims=True)
+    y = np.cross(z, x)
+    R = np.stack([x, y, z], -1)                                       # columns
+    T = -np.einsum("nij,ni->nj", R, eye)
+    return R.astype(np.float32), T.astype(np.float32)
+
+
+def _fov_projection(fov_deg=60.0, znear=1.0, zfar=1000.0):
+    """FoVPerspectiveCameras default projection (row-vector convention = transpose of the published K)."""
+    s = 1.0 / np.tan(np.deg2rad(fov_deg) / 2)
+    K = np.array([[s, 0, 0, 0], [0, s, 0, 0], [0, 0, zfar / (zfar - znear), 1], [0, 0, -zfar * znear / (zfar - znear), 0]], np.float32)
+    return K
+
+
+def gen_filter():
+    """filter_proxy_points (scone_utils.py:1001-1027) with the tester's camera construction (testers/shapenet.py:117-122)."""
+    import importlib
+    su = importlib.import_module("macarons.utility.scone_utils")
+    rng = np.random.default_rng(91)
+    X_view = cameras_on_sphere(4, 5)[[2, 9, 16]].astype(np.float32)
+    R, T = _look_at(X_view)
+    cams = _StandInCameras(t(R), t(T), t(np.broadcast_to(_fov_projection(), (3, 4, 4)).copy()))
+    d = rng.standard_normal((3000, 3))
+    pc = (d / np.linalg.norm(d, axis=1, keepdims=True) * [0.3, 0.2, 0.25] + 0.002 * rng.standard_normal((3000, 3))).astype(np.float32)
+    X = rng.uniform(-0.5, 0.5, (20000, 3)).astype(np.float32)
+    Xf, mask = su.filter_proxy_points(cams, t(X), t(pc), filter_tol=0.01)
+    proj = cams.get_full_projection_transform().M.numpy()
+    save("filter_proxy", X=X, pc=pc, proj=proj, tol=np.float32(0.01), mask=np.packbits(mask.numpy()), n_keep=np.int64(Xf.shape[0]))
+
+
+GROUPS = {"filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

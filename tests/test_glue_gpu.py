@@ -223,3 +223,45 @@ def test_best_record_and_merge(dev):
                 recs.append(ops.best_record(G[:, lo:hi].contiguous(), lo))
             vals, idx = ops.best_merge(torch.stack(recs, 0).contiguous())
             assert torch.equal(vals, ref.values) and torch.equal(idx, ref.indices), (B, C, world)
+
+
+def test_filter_proxy_points(dev):
+    """mcr_filter_proxy_points: the reference golden (bit-exact mask), a larger random case against the oracle, and the host
+    mirror's two ways of receiving the view cameras."""
+    from macarons_amd import ops
+    from macarons_amd.utility import scone_utils as su
+    from oracle import view_state as V
+    g = golden("filter_proxy")
+    ref_mask = np.unpackbits(g["mask"])[:len(g["X"])].astype(bool)
+    mask, bounds = ops.filter_proxy_mask(T(g["X"], dev), T(g["pc"], dev), T(g["proj"], dev), float(g["tol"]))
+    assert np.array_equal(mask.cpu().numpy(), ref_mask)
+    _, ob = V.filter_proxy_points(g["proj"], g["X"], g["pc"], float(g["tol"]))
+    assert np.array_equal(bounds.cpu().numpy(), ob)
+    # larger, 7 views, with points behind some cameras (w < 0 flips the projection like the reference's division does)
+    rng = np.random.default_rng(5)
+    P, M, nv = 100_003, 10_240, 7
+    X = rng.uniform(-0.6, 0.6, (P, 3)).astype(np.float32)
+    d = rng.standard_normal((M, 3))
+    pc = (d / np.linalg.norm(d, axis=1, keepdims=True) * [0.35, 0.25, 0.3]).astype(np.float32)
+    proj = np.zeros((nv, 4, 4), np.float32)
+    f = 1.0 / np.tan(np.deg2rad(60) / 2)
+    K = np.array([[f, 0, 0, 0], [0, f, 0, 0], [0, 0, 1000 / 999, 1], [0, 0, -1000 / 999, 0]], np.float32)
+    for v in range(nv):
+        R = np.linalg.qr(rng.standard_normal((3, 3)))[0].astype(np.float32)
+        Mv = np.eye(4, dtype=np.float32); Mv[:3, :3] = R; Mv[3, :3] = [0, 0, 1.5]
+        proj[v] = Mv @ K
+    om, _ = V.filter_proxy_points(proj, X, pc, 0.01)
+    Xf, m = su.filter_proxy_points(T(proj, dev), T(X, dev), T(pc, dev), filter_tol=0.01)
+    assert np.array_equal(m.cpu().numpy(), om) and 0 < om.sum() < P
+    assert torch.equal(Xf, T(X, dev)[m])
+
+    class Cams:                                              # what a PyTorch3D camera batch offers
+        def get_full_projection_transform(self):
+            class Tr:
+                def get_matrix(s):
+                    return torch.from_numpy(proj)
+            return Tr()
+    _, m2 = su.filter_proxy_points(Cams(), T(X, dev), T(pc, dev), filter_tol=0.01)
+    assert torch.equal(m2, m)
+    with pytest.raises(NameError):
+        su.filter_proxy_points(T(proj, dev), T(X[None], dev), T(pc, dev))

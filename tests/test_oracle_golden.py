@@ -189,3 +189,14 @@ def test_view_state_and_sampler_oracle_match_reference():
     res, resh, inv, orig = V.sample_proxy_points(g["s_X"], g["s_preds"], g["s_vh"], g["s_u"], 0.1, exact=True)
     assert V.sampler_tie_aware_match(res, inv, g["s_res"], g["s_inv"], g["s_X"], g["s_preds"], 0.1)
     assert np.array_equal(resh, g["s_vh"][orig]) and np.array_equal(res[:, :3], g["s_X"][orig])
+
+
+def test_filter_proxy_points_oracle_matches_reference():
+    """oracle.view_state.filter_proxy_points == the reference's filter_proxy_points (scone_utils.py:1001-1027) run on a
+    stand-in camera batch (tests/golden/make_golden.py: gen_filter), bit for bit."""
+    from oracle import view_state as V
+    g = golden("filter_proxy")
+    mask = np.unpackbits(g["mask"])[:len(g["X"])].astype(bool)
+    m, bounds = V.filter_proxy_points(g["proj"], g["X"], g["pc"], float(g["tol"]))
+    assert np.array_equal(m, mask) and int(m.sum()) == int(g["n_keep"])
+    assert bounds.shape == (3, 4) and np.all(bounds[:, 0] < bounds[:, 1]) and np.all(bounds[:, 2] < bounds[:, 3])
