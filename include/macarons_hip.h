@@ -153,6 +153,10 @@ int mcr_points_in_fov(const float* pts, int64_t P, const float* cameras, int n_c
  * cloud pc grown by filter_tol.  proj = n_view row-major 4x4 full-projection matrices (row-vector convention, as
  * pytorch3d's get_full_projection_transform().get_matrix()); bounds = n_view*4 floats of scratch, left holding
  * {min_x, max_x, min_y, max_y} per view. */
+/* Column gather of move_view_state_to_view_space (macarons/utility/scone_utils.py:863-931, line :928; callers
+ * macarons_utils.py:1356,1488): out[r, v] = in[r, idx[v]]; idx = the V bin indices the host derives from the camera rotation
+ * (device int32, every entry in [0, V)). */
+int mcr_gather_columns(const float* in, const int* idx, float* out, int64_t rows, int V, void* stream);
 int mcr_filter_proxy_points(const float* X, int64_t P, const float* pc, int64_t M, const float* proj, int n_view, float filter_tol,
                             float* bounds, unsigned char* mask, void* stream);
 int mcr_coverage_gain_multiple(const float* vis, float* gains, int64_t B, int64_t C, int64_t N, int n_cam, void* stream);

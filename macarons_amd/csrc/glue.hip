@@ -293,6 +293,17 @@ __global__ void filter_proxy_kernel(const float* __restrict__ X, long long P, co
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Column gather of move_view_state_to_view_space (scone_utils.py:928): out[r, v] = in[r, idx[v]], v < V (V = 98 view bins).
+__global__ void gather_columns_kernel(const float* __restrict__ in, const int* __restrict__ idx, float* __restrict__ out, long long rows,
+                                      int V) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rows * V) return;
+    const long long r = gid / V;
+    const int v = (int)(gid - r * V);
+    out[gid] = in[r * V + idx[v]];
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // a3: gains of every ordered n-tuple of cameras: mean_n max_t vis[b, c_t, n]   (SconeVis.py:289-301)
 // grid = (C^n tuples, B); one block per tuple, tree reduce in fixed order.
 __global__ __launch_bounds__(256) void multi_gain_kernel(const float* __restrict__ vis, float* __restrict__ out, int C, int N,
@@ -533,6 +544,14 @@ int mcr_filter_proxy_points(const float* X, int64_t P, const float* pc, int64_t 
     hipLaunchKernelGGL(filter_proxy_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, X, (long long)P, proj,
                        n_view, bounds, filter_tol, mask);
     MCR_LAUNCH_CHECK("filter_proxy_kernel");
+    return 0;
+}
+
+int mcr_gather_columns(const float* in, const int* idx, float* out, int64_t rows, int V, void* stream) {
+    MCR_REQUIRE(in && idx && out && rows > 0 && V > 0, "mcr_gather_columns: bad arguments");
+    hipLaunchKernelGGL(gather_columns_kernel, dim3((unsigned)cdiv(rows * V, 256)), dim3(256), 0, (hipStream_t)stream, in, idx, out,
+                       (long long)rows, V);
+    MCR_LAUNCH_CHECK("gather_columns_kernel");
     return 0;
 }
 

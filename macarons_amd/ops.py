@@ -307,6 +307,19 @@ def coverage_gain_multiple(pts, harmonics, cams, n_cam, use_sigmoid=True):
     return out, n_idx
 
 
+def gather_columns(x, idx):
+    """x [..., V] fp32, idx [V] integer (values in [0, V)) -> x[..., idx] (torch.gather along the last dim with one index row)."""
+    x = _req(x, "x")
+    V = x.shape[-1]
+    idx = idx.to(device=x.device, dtype=torch.int32).contiguous()
+    if idx.numel() != V or int(idx.min()) < 0 or int(idx.max()) >= V:
+        raise ValueError("gather_columns: idx must hold V indices in [0, V)")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().mcr_gather_columns(_p(x), _p(idx), _p(out), c_i64(x.numel() // V), c_int(V), _stream()), "mcr_gather_columns")
+    return out
+
+
 def filter_proxy_mask(X, pc, proj, filter_tol):
     """X [P,3], pc [M,3], proj [n_view,4,4] (row-vector full-projection matrices) -> (mask bool [P], bounds [n_view,4])."""
     X, pc, proj = _req(X, "X"), _req(pc, "pc"), _req(proj, "proj")

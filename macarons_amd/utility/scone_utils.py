@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from .CustomGeometry import get_cartesian_coords
+from .CustomGeometry import get_cartesian_coords, get_spherical_coords
 from .spherical_harmonics import get_spherical_harmonics
 
 
@@ -90,6 +90,42 @@ def compute_occupancy_probability(scone_occ, pc, X, view_harmonics, mask=None, m
         preds.append(scone_occ(pc, X[:, low:up].contiguous(), view_harmonics[:, low:up].contiguous(), verbose=False)
                      .view(n_clouds, up - low, -1))
     return preds[0] if len(preds) == 1 else torch.cat(preds, dim=1)
+
+
+def view_space_bin_indices(X_cam_inv, n_elev, n_azim):
+    """Bin index of each rotated grid direction (scone_utils.py:901-926): nearest (elevation, azimuth) bin, elevation clamped to
+    +-(n_elev//2), azimuth wrapped at 180 degrees.  X_cam_inv [n_elev*n_azim, 3] fp32 (any device) -> int64 indices (CPU)."""
+    X = X_cam_inv.detach().to("cpu", torch.float32).view(-1, 3)
+    elev_step, azim_step = np.pi / (n_elev + 1), 2 * np.pi / n_azim
+    _, ray_elev, ray_azim = get_spherical_coords(X)
+    fd = lambda a, st: (a - a % st) / st                                # utils.floor_divide (utils.py:113-117)
+    idx_elev, idx_azim = fd(ray_elev, elev_step), fd(ray_azim, azim_step)
+    idx_elev = idx_elev + (ray_elev % elev_step > elev_step / 2.).to(idx_elev.dtype)
+    idx_azim = idx_azim + (ray_azim % azim_step > azim_step / 2.).to(idx_azim.dtype)
+    idx_elev = idx_elev.clamp(-(n_elev // 2), n_elev // 2)
+    idx_azim = torch.where(idx_azim > n_azim // 2, torch.full_like(idx_azim, -(n_azim // 2)), idx_azim)
+    idx_elev = idx_elev + n_elev // 2
+    idx_azim = torch.where(idx_azim < 0, idx_azim + n_azim, idx_azim)
+    return idx_elev.long() * n_azim + idx_azim.long()
+
+
+def move_view_state_to_view_space(view_state, fov_camera, n_elev, n_azim):
+    """"Rotate" the view-state vectors into a camera's view space (scone_utils.py:863-931): view_state [n_cloud, seq_len,
+    n_elev*n_azim] -> same shape, column v taken from the bin the v-th grid direction lands in after the inverse
+    world-to-view transform.  `fov_camera`: the reference's camera object (its get_world_to_view_transform().inverse()
+    .transform_points and get_camera_center are called exactly as the reference does; PyTorch3D stays outside the kernels)
+    or the 3x3 world-to-view rotation R of the row-vector convention X_view = X_world R + T."""
+    n_view = n_elev * n_azim
+    elev = torch.Tensor([-90. + (i + 1) / (n_elev + 1) * 180. for i in range(n_elev) for j in range(n_azim)])
+    azim = torch.Tensor([360. * j / n_azim for i in range(n_elev) for j in range(n_azim)])
+    X_ref = get_cartesian_coords(r=torch.ones(n_view, 1), elev=elev.view(-1, 1), azim=azim.view(-1, 1), in_degrees=True)
+    if torch.is_tensor(fov_camera):
+        X_inv = X_ref @ fov_camera.detach().to("cpu", torch.float32).view(3, 3).T
+    else:
+        dev = view_state.device
+        X_inv = fov_camera.get_world_to_view_transform().inverse().transform_points(X_ref.to(dev)) - fov_camera.get_camera_center()
+    indices = view_space_bin_indices(X_inv.reshape(-1, 3), n_elev, n_azim)
+    return ops.gather_columns(view_state.contiguous(), indices)
 
 
 def filter_proxy_points(view_cameras, X, pc, filter_tol=0.01):

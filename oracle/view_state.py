@@ -162,3 +162,48 @@ def filter_proxy_points(proj, X, pc, filter_tol=0.01):
         bounds[v] = [cx.min(), cx.max(), cy.min(), cy.max()]
         mask &= (nx < F(bounds[v, 1] + tol)) & (nx > F(bounds[v, 0] - tol)) & (ny < F(bounds[v, 3] + tol)) & (ny > F(bounds[v, 2] - tol))
     return mask, bounds
+
+
+def view_space_bin_indices(X_cam_inv, n_elev, n_azim):
+    """scone_utils.py:901-926 in fp32: bin index of each grid direction once moved to the camera's view space."""
+    X = np.asarray(X_cam_inv, F).reshape(-1, 3)
+    elev_step, azim_step = F(np.pi / (n_elev + 1)), F(2 * np.pi / n_azim)
+    _, ray_elev, ray_azim = sh.spherical_coords(X)
+    idx_elev = floor_divide(ray_elev, elev_step)
+    idx_azim = floor_divide(ray_azim, azim_step)
+    idx_elev[np.mod(ray_elev, elev_step) > F(np.pi / (n_elev + 1) / 2.)] += 1
+    idx_azim[np.mod(ray_azim, azim_step) > F(2 * np.pi / n_azim / 2.)] += 1
+    idx_elev[idx_elev > n_elev // 2] = n_elev // 2
+    idx_elev[idx_elev < -(n_elev // 2)] = -(n_elev // 2)         # parenthesised here, unlike compute_view_state (:916-917 vs :839)
+    idx_azim[idx_azim > n_azim // 2] = -(n_azim // 2)
+    idx_elev += n_elev // 2
+    idx_azim[idx_azim < 0] += n_azim
+    return idx_elev.astype(np.int64) * n_azim + idx_azim.astype(np.int64)
+
+
+def view_space_grid(n_elev, n_azim):
+    """The unit grid directions X_cam_ref of scone_utils.py:880-895 (elevation-major)."""
+    elev = np.array([-90. + (i + 1) / (n_elev + 1) * 180. for i in range(n_elev) for j in range(n_azim)], F)
+    azim = np.array([360. * j / n_azim for i in range(n_elev) for j in range(n_azim)], F)
+    return sh.cartesian_coords(np.ones(len(elev), F), elev, azim, in_degrees=True)
+
+
+def move_view_state_to_view_space(view_state, X_cam_inv, n_elev, n_azim):
+    """scone_utils.py:863-931 given the grid directions already moved to view space (the camera transform is PyTorch3D's)."""
+    idx = view_space_bin_indices(X_cam_inv, n_elev, n_azim)
+    return np.asarray(view_state)[..., idx], idx
+
+
+def view_space_bin_margin(X_cam_inv, n_elev, n_azim):
+    """Angular distance (rad) of each moved grid direction from the nearest decision boundary of the binning above (the
+    half-way points between bins and the +-180 degree wrap): closer than a few ulps of asin/acos, the bin depends on the libm
+    at hand (an axis-aligned camera puts a dozen of the 98 directions exactly there)."""
+    X = np.asarray(X_cam_inv, np.float64).reshape(-1, 3)
+    r = np.linalg.norm(X, axis=1)
+    elev = np.arcsin(np.clip(X[:, 1] / r, -1, 1))
+    azim = np.arctan2(X[:, 0], X[:, 2])
+    es, az = np.pi / (n_elev + 1), 2 * np.pi / n_azim
+    fe = np.abs(((elev / es) - 0.5) - np.round((elev / es) - 0.5)) * es
+    fa = np.abs(((azim / az) - 0.5) - np.round((azim / az) - 0.5)) * az
+    pole = np.hypot(X[:, 0], X[:, 2]) / r                                # azimuth is ill-defined at the poles
+    return np.minimum(np.minimum(fe, fa), np.where(pole < 1e-6, 0.0, np.inf))

@@ -405,7 +405,36 @@ def gen_filter():
     save("filter_proxy", X=X, pc=pc, proj=proj, tol=np.float32(0.01), mask=np.packbits(mask.numpy()), n_keep=np.int64(Xf.shape[0]))
 
 
-GROUPS = {"filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
+def gen_viewspace():
+    """move_view_state_to_view_space (scone_utils.py:863-931) on stand-in cameras; the grid directions moved to view space
+    (the input of the reference's get_spherical_coords call) are captured so the binning + gather are pinned exactly."""
+    import importlib
+    su = importlib.import_module("macarons.utility.scone_utils")
+    rng = np.random.default_rng(95)
+    eyes = np.concatenate([cameras_on_sphere(4, 5)[[1, 8, 13, 18]], [[0.3, 1.2, -0.8], [1.5, 0.0, 0.0], [0.0, 0.0, 1.5]]]).astype(np.float32)
+    R, T = _look_at(eyes)
+    vs = (rng.random((2, 300, 98)) < 0.15).astype(np.float32)
+    out = dict(view_state=np.packbits(vs.astype(np.uint8), axis=-1), R=R, T=T)
+    real = su.get_spherical_coords
+    for c in range(len(eyes)):
+        cam = _StandInCameras(t(R[c:c + 1]), t(T[c:c + 1]), t(_fov_projection()[None]))
+        seen = []
+
+        def capture(X):
+            seen.append(X.numpy().copy())
+            return real(X)
+        su.get_spherical_coords = capture
+        try:
+            rot = su.move_view_state_to_view_space(t(vs), cam, 7, 14)
+        finally:
+            su.get_spherical_coords = real
+        idx = None
+        out[f"xinv_{c}"] = seen[0].astype(np.float32)
+        out[f"rot_{c}"] = np.packbits(rot.numpy().astype(np.uint8), axis=-1)
+    save("view_space", n_cam=np.int64(len(eyes)), **out)
+
+
+GROUPS = {"viewspace": gen_viewspace, "filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

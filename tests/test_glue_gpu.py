@@ -265,3 +265,39 @@ def test_filter_proxy_points(dev):
     assert torch.equal(m2, m)
     with pytest.raises(NameError):
         su.filter_proxy_points(T(proj, dev), T(X[None], dev), T(pc, dev))
+
+
+def test_move_view_state_to_view_space(dev):
+    """Host mirror + mcr_gather_columns against the reference golden: the mirror bins with the same torch CPU ops the
+    reference used, so all seven cameras (incl. the axis-aligned ones on bin boundaries) must match bit for bit."""
+    from macarons_amd import ops
+    from macarons_amd.utility import scone_utils as su
+    g = golden("view_space")
+    vs = np.unpackbits(g["view_state"], axis=-1)[..., :98].astype(np.float32)
+    for c in range(int(g["n_cam"])):
+        rot = np.unpackbits(g[f"rot_{c}"], axis=-1)[..., :98].astype(np.float32)
+        xinv = torch.from_numpy(g[f"xinv_{c}"])
+
+        class Cam:                                           # the three calls the reference makes on a PyTorch3D camera
+            def get_world_to_view_transform(self):
+                class Tr:
+                    def inverse(s):
+                        return s
+
+                    def transform_points(s, p):
+                        return xinv.to(p.device)             # moved grid + centre (captured from the reference run)
+                return Tr()
+
+            def get_camera_center(self):
+                return torch.zeros(1, 3, device=dev)
+        out = su.move_view_state_to_view_space(T(vs, dev), Cam(), 7, 14)
+        assert np.array_equal(out.cpu().numpy(), rot), c
+    # handed the rotation itself: same result wherever the direction is not on a bin boundary
+    from oracle import view_state as V
+    out = su.move_view_state_to_view_space(T(vs, dev), torch.from_numpy(g["R"][0]), 7, 14).cpu().numpy()
+    rot0 = np.unpackbits(g["rot_0"], axis=-1)[..., :98].astype(np.float32)
+    safe = V.view_space_bin_margin(g["xinv_0"], 7, 14) > 3e-6
+    assert np.array_equal(out[..., safe], rot0[..., safe])
+    idx = torch.randperm(98)
+    x = torch.randn(5, 1000, 98, device=dev)
+    assert torch.equal(ops.gather_columns(x, idx), x[..., idx.to(dev)])

@@ -200,3 +200,23 @@ def test_filter_proxy_points_oracle_matches_reference():
     m, bounds = V.filter_proxy_points(g["proj"], g["X"], g["pc"], float(g["tol"]))
     assert np.array_equal(m, mask) and int(m.sum()) == int(g["n_keep"])
     assert bounds.shape == (3, 4) and np.all(bounds[:, 0] < bounds[:, 1]) and np.all(bounds[:, 2] < bounds[:, 3])
+
+
+def test_move_view_state_to_view_space_oracle_matches_reference():
+    """oracle.view_state.move_view_state_to_view_space == the reference function (scone_utils.py:863-931) on stand-in cameras:
+    bit-exact for every grid direction that is not within libm ulps of a bin boundary (the axis-aligned cameras put some
+    exactly on the half-way points), and exact outright for the generic cameras."""
+    from oracle import view_state as V
+    g = golden("view_space")
+    vs = np.unpackbits(g["view_state"], axis=-1)[..., :98].astype(np.float32)
+    exact = 0
+    for c in range(int(g["n_cam"])):
+        rot = np.unpackbits(g[f"rot_{c}"], axis=-1)[..., :98].astype(np.float32)
+        out, idx = V.move_view_state_to_view_space(vs, g[f"xinv_{c}"], 7, 14)
+        safe = V.view_space_bin_margin(g[f"xinv_{c}"], 7, 14) > 3e-6
+        assert idx.min() >= 0 and idx.max() < 98
+        assert np.array_equal(out[..., safe], rot[..., safe])
+        exact += int(np.array_equal(out, rot))
+        # the moved grid is the grid rotated by R^T (what the host mirror computes when handed R)
+        assert np.abs(V.view_space_grid(7, 14) @ g["R"][c].T - g[f"xinv_{c}"]).max() < 1e-6
+    assert exact >= 5
