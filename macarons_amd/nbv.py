@@ -24,14 +24,18 @@ class ViewStateGrid:
 
 
 def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1,
-             max_points_per_pass=300000, true_monte_carlo_sampling=True, occ_perms=None, samples=None, group=None):
+             max_points_per_pass=300000, true_monte_carlo_sampling=True, occ_perms=None, samples=None, group=None,
+             view_proj=None, filter_tol=0.01):
     """pc [1,M,3] surface points, X [1,Q,3] proxy points, X_view [n_view,3] past camera positions, X_cam [C,3]
     candidate cameras (all in the normalised prediction-view space, as the reference feeds its networks).
     Returns dict(gains [C_local or C], nbv_idx (global camera index, int), max_gain, occ [Q,1], n_unique).
-    `occ_perms` / `samples` pin the hidden RNG draws (SconeOcc randperms; sampling uniforms)."""
+    `occ_perms` / `samples` pin the hidden RNG draws (SconeOcc randperms; sampling uniforms).  `view_proj` [n_view,4,4]
+    (full-projection matrices of the past views) switches on the tester's proxy-point filter (testers/shapenet.py:117-122)."""
     world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
     rank = torch.distributed.get_rank(group) if world > 1 else 0
     dev = X.device
+    if view_proj is not None:                                                       # testers/shapenet.py:122
+        X = su.filter_proxy_points(view_proj, X[0], pc.reshape(-1, 3), filter_tol=filter_tol)[0][None]
     Q = X.shape[1]
     with torch.no_grad():
         # ---- view state -> harmonics for this rank's slice of the queries (testers/shapenet.py:126-130) ----

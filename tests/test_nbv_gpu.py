@@ -105,3 +105,43 @@ def test_pipelined_best_exchange_nccl_single_rank(dev):
         assert torch.equal(v, ref.values) and torch.equal(i, ref.indices + 7)
     finally:
         dist.destroy_process_group()
+
+
+def test_nbv_step_with_proxy_filter(dev):
+    """nbv_step(view_proj=...) == filter_proxy_points first, then the same step on the kept proxy points
+    (testers/shapenet.py:117-172)."""
+    import io, contextlib
+    from macarons_amd.networks import SconeVis, SconeOcc
+    from macarons_amd.nbv import nbv_step, ViewStateGrid
+    from macarons_amd.utility import scone_utils as su
+    torch.manual_seed(3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        occ, vis = SconeOcc(), SconeVis()
+    with torch.no_grad():
+        occ.linear3.bias += 0.5
+    occ, vis = occ.to(dev).eval(), vis.to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    M, Q, C = 2048, 6000, 20
+    d = torch.randn(M, 3, generator=g)
+    pc = (d / d.norm(dim=1, keepdim=True) * torch.tensor([0.3, 0.2, 0.25]))[None].to(dev)
+    X = (torch.rand(1, Q, 3, generator=g) - 0.5).to(dev)
+    cams = torch.randn(C, 3, generator=g)
+    cams = (1.5 * cams / cams.norm(dim=1, keepdim=True)).to(dev)
+    X_view = cams[:2].contiguous()
+    f = 1.0 / np.tan(np.deg2rad(60) / 2)
+    K = torch.tensor([[f, 0, 0, 0], [0, f, 0, 0], [0, 0, 1000 / 999, 1], [0, 0, -1000 / 999, 0]], dtype=torch.float32)
+    proj = []
+    for e in X_view.cpu().numpy():
+        z = -e / np.linalg.norm(e); x = np.cross([0, 1, 0], z); x /= np.linalg.norm(x); y = np.cross(z, x)
+        R = np.stack([x, y, z], -1).astype(np.float32)
+        Mv = np.eye(4, dtype=np.float32); Mv[:3, :3] = R; Mv[3, :3] = -(R.T @ e)
+        proj.append(torch.from_numpy(Mv) @ K)
+    proj = torch.stack(proj).to(dev)
+    grid = ViewStateGrid(dev)
+    perms = occ.draw_perms(M)
+    u = torch.rand(2048, generator=g).to(dev)
+    a = nbv_step(occ, vis, pc, X, X_view, cams, grid, occ_perms=perms, samples=u, view_proj=proj)
+    Xf, mask = su.filter_proxy_points(proj, X[0], pc[0], filter_tol=0.01)
+    assert 0 < int(mask.sum()) < Q
+    b = nbv_step(occ, vis, pc, Xf[None].contiguous(), X_view, cams, grid, occ_perms=perms, samples=u)
+    assert int(a["nbv_idx"]) == int(b["nbv_idx"]) and torch.equal(a["gains"], b["gains"]) and a["occ"].shape[0] == int(mask.sum())
