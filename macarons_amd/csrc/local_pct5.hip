@@ -140,6 +140,85 @@ __device__ __forceinline__ void l5_put(const f32x16 (&t)[2], float* buf, int ct,
             buf[(mt * 32 + (r & 3) + 8 * (r >> 2)) * LD + (w ^ ((((r & 3) + 8 * ((r >> 2) & 1))) << 2))] = g((float)t[mt][r]);
 }
 
+// QKV product (N = 192 = 6 n-tiles over 4 waves), balanced: every wave takes its own n-tile w for both m-tiles plus HALF
+// of n-tile 4 + (w >> 1): the m-tile w & 1.  (Giving waves 0,1 two whole n-tiles and waves 2,3 one made this the longest
+// phase of an encoder: 4 tile-units of matrix work on the critical path instead of 3.)  The two waves sharing n-tile 4 or
+// 5 are not in lock-step on it -- one starts with its own tile's fragments in flight -- so their requests do not collide in
+// the L1.  A comes pre-split from P.
+__device__ __forceinline__ void l5_gemm_qkv(f32x16 (&acc)[1][2], f32x16& acch, const uint4* __restrict__ P,
+                                            const float* __restrict__ Wp, int wave, int lane_) {
+    constexpr int S = 8, PF = L5_PF;
+    const int lane = l5_opaque(lane_);
+    const int i = lane & 31, h = lane >> 5, key = i & 15, mh = wave & 1;
+    const uint4* bp[2] = {reinterpret_cast<const uint4*>(Wp) + (size_t)wave * S * 3 * 64 + lane,
+                          reinterpret_cast<const uint4*>(Wp) + (size_t)(4 + (wave >> 1)) * S * 3 * 64 + lane};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acch[r] = 0.f; }
+    uint4 b[PF][2][3];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[p][u][pl] = bp[u][L5_IDX((p * 3 + pl) * 64)];
+    Split3 sn[3];                                           // fragments of the next step: m-tile 0, m-tile 1, m-tile mh again
+    auto fetch = [&](int s) {
+        const int c = (2 * s + h) ^ key;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const int row = (f < 2 ? f : mh) * 32 + i;
+            sn[f].hi = P[(0 * 64 + row) * 16 + c];
+            sn[f].mid = P[(1 * 64 + row) * 16 + c];
+            sn[f].lo = P[(2 * 64 + row) * 16 + c];
+        }
+    };
+    fetch(0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        Split3 sa[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) sa[f] = sn[f];
+        if (s + 1 < S) fetch(s + 1);
+        uint4 bc[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bc[u][pl] = b[s % PF][u][pl];
+        if (s + PF < S) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[s % PF][u][pl] = bp[u][L5_IDX(((s + PF) * 3 + pl) * 64)];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            acc[0][mt] = mfma_bf(sa[mt].lo, bc[0][0], acc[0][mt]);
+            acc[0][mt] = mfma_bf(sa[mt].hi, bc[0][2], acc[0][mt]);
+            acc[0][mt] = mfma_bf(sa[mt].mid, bc[0][1], acc[0][mt]);
+            acc[0][mt] = mfma_bf(sa[mt].mid, bc[0][0], acc[0][mt]);
+            acc[0][mt] = mfma_bf(sa[mt].hi, bc[0][1], acc[0][mt]);
+            acc[0][mt] = mfma_bf(sa[mt].hi, bc[0][0], acc[0][mt]);
+        }
+        acch = mfma_bf(sa[2].lo, bc[1][0], acch);
+        acch = mfma_bf(sa[2].hi, bc[1][2], acch);
+        acch = mfma_bf(sa[2].mid, bc[1][1], acch);
+        acch = mfma_bf(sa[2].mid, bc[1][0], acch);
+        acch = mfma_bf(sa[2].hi, bc[1][1], acch);
+        acch = mfma_bf(sa[2].hi, bc[1][0], acch);
+    }
+}
+
+// l5_put for ONE 32 x 32 C fragment: m-tile mt (wave-uniform) of column tile ct
+template <int LD, class G>
+__device__ __forceinline__ void l5_put_half(const f32x16& t, float* buf, int ct, int mt, int lane_, G g) {
+    const int lane = l5_opaque(lane_);
+    const int j = lane & 31, h = lane >> 5;
+    const int w = (((((ct << 3) | (j >> 2)) ^ (h << 2)) << 2) | (j & 3) | (h * 4 * LD)) + mt * 32 * LD;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        buf[((r & 3) + 8 * (r >> 2)) * LD + (w ^ ((((r & 3) + 8 * ((r >> 2) & 1))) << 2))] = g((float)t[r]);
+}
+
 // LayerNorm (eps 1e-5, affine folded into the next weights) of the 64 rows of F, written as bf16 planes into P:
 // 4 threads per row, 32 columns each; two-pass (mean, then centred variance) like torch's.
 __device__ __forceinline__ void l5_norm(const float* F, uint4* P, int tid_) {
@@ -261,16 +340,15 @@ __global__ __launch_bounds__(256, 2) void local_pct5_kernel(const float* __restr
         const float* em = mats + l3_mat_off(2 + 6 * e);
         const float* ev = vecs + L3_VEC_ENC0 + e * L3_VEC_ENC_STRIDE;
         // ---- norm1 (folded) -> planes ; QKV (Attention.py:186-188, 287): q|k -> Pq, v -> F ----
-        // 6 n-tiles over 4 waves: waves 0,1 take two (w, w + 4), waves 2,3 one.
+        // 6 n-tiles over 4 waves: one each plus half of n-tile 4 or 5 (l5_gemm_qkv).
         __syncthreads();
         L5_T();
         l5_norm(F, P, tid);
         __syncthreads();
         L5_T();
         {
-            f32x16 aq[2][2];
-            if (wave < 2) l5_gemm<8, 2, true, true>(aq, P, em, wave, lane);
-            else l5_gemm<8, 1, true, true>(reinterpret_cast<f32x16 (&)[1][2]>(aq), P, em, wave, lane);
+            f32x16 aq[1][2], ah;
+            l5_gemm_qkv(aq, ah, P, em, wave, lane);
             __syncthreads();                       // x^ planes consumed: P may take q|k (F's raw x died with the norm)
             L5_T();
             // n-tiles 0,1 = q,k -> Pq column tiles 0,1; n-tiles 2..5 = v -> F column tiles 0..3
@@ -278,10 +356,9 @@ __global__ __launch_bounds__(256, 2) void local_pct5_kernel(const float* __restr
                 const float b0 = ev[wave * 32 + (lane & 31)];
                 if (wave < 2) l5_put<64>(aq[0], Pq, wave, lane, [&](float v) { return v + b0; });
                 else l5_put<128>(aq[0], F, wave - 2, lane, [&](float v) { return v + b0; });
-                if (wave < 2) {
-                    const float b1 = ev[(wave + 4) * 32 + (lane & 31)];
-                    l5_put<128>(aq[1], F, wave + 2, lane, [&](float v) { return v + b1; });
-                }
+                const int nth = 4 + (wave >> 1);
+                const float b1 = ev[nth * 32 + (lane & 31)];
+                l5_put_half<128>(ah, F, nth - 2, wave & 1, lane, [&](float v) { return v + b1; });
             }
         }
         __syncthreads();
