@@ -137,11 +137,15 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
             const float4 p0 = s_pc[i], p1 = s_pc[i + KNN_SPLIT], p2 = s_pc[i + 2 * KNN_SPLIT], p3 = s_pc[i + 3 * KNN_SPLIT];
             const float d0 = knn_d2(qx, qy, qz, p0), d1 = knn_d2(qx, qy, qz, p1);
             const float d2 = knn_d2(qx, qy, qz, p2), d3 = knn_d2(qx, qy, qz, p3);
-            push(d0, t0 + i);
-            push(d1, t0 + i + KNN_SPLIT);
-            push(d2, t0 + i + 2 * KNN_SPLIT);
-            push(d3, t0 + i + 3 * KNN_SPLIT);
-            if (__any(cnt > KNN_QCAP - 4)) flush();
+            // once the lists have warmed up almost every batch is rejected by every lane: one wave-uniform test on the batch
+            // minimum then skips the four predicated pushes
+            if (__any(fminf(fminf(d0, d1), fminf(d2, d3)) < tau)) {
+                push(d0, t0 + i);
+                push(d1, t0 + i + KNN_SPLIT);
+                push(d2, t0 + i + 2 * KNN_SPLIT);
+                push(d3, t0 + i + 3 * KNN_SPLIT);
+                if (__any(cnt > KNN_QCAP - 4)) flush();
+            }
         }
     }
     flush();
