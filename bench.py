@@ -216,9 +216,9 @@ def main():
 
     pipe = None
     if use_dist:
-        # the arg-max exchanges are batched (8 decisions per all-gather) and run on a side stream under the next scoring passes
+        # the arg-max exchanges are batched (16 decisions per all-gather) and run on a side stream under the next scoring passes
         from macarons_amd import dist as mdist
-        pipe = mdist.PipelinedBest(1, dev, batch=8, depth=3)
+        pipe = mdist.PipelinedBest(1, dev, batch=16, depth=3)
 
     def step():
         gains = ops.sh_coverage_gain(pts, harm, cams, True, args.waves_per_simd)
