@@ -232,8 +232,8 @@ __device__ __forceinline__ void l5_norm(const float* F, uint4* P, int tid_) {
         v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
         sum += (q.x + q.y) + (q.z + q.w);
     }
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
+    sum += dpp_mov0<0xB1>(sum);          // quad_perm [1,0,3,2]: the row's 4 threads are one quad (DPP, not an LDS bpermute)
+    sum += dpp_mov0<0x4E>(sum);          // quad_perm [2,3,0,1]
     const float mu = sum * (1.0f / 128.f);
     float sq = 0.f;
 #pragma unroll
@@ -241,8 +241,8 @@ __device__ __forceinline__ void l5_norm(const float* F, uint4* P, int tid_) {
         v[c] -= mu;
         sq = fmaf(v[c], v[c], sq);
     }
-    sq += __shfl_xor(sq, 1, 64);
-    sq += __shfl_xor(sq, 2, 64);
+    sq += dpp_mov0<0xB1>(sq);
+    sq += dpp_mov0<0x4E>(sq);
     const float rstd = 1.0f / sqrtf(sq * (1.0f / 128.f) + 1e-5f);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
