@@ -219,6 +219,19 @@ __device__ __forceinline__ void l5_put_half(const f32x16& t, float* buf, int ct,
         buf[((r & 3) + 8 * (r >> 2)) * LD + (w ^ ((((r & 3) + 8 * ((r >> 2) & 1))) << 2))] = g((float)t[r]);
 }
 
+// All-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) without the LDS crossbar: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange rows / halves between two registers; fed the same value twice they return
+// (this row pair's even row | odd row) resp. (lower half | upper half) replicated, so one op on the pair is the reduction.
+template <class Op>
+__device__ __forceinline__ float l5_rows_allreduce(float v, Op op) {
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    v = op(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    const unsigned c = __builtin_bit_cast(unsigned, v);
+    const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+    return op(__builtin_bit_cast(float, (unsigned)q[0]), __builtin_bit_cast(float, (unsigned)q[1]));
+}
+
 // LayerNorm (eps 1e-5, affine folded into the next weights) of the 64 rows of F, written as bf16 planes into P:
 // 4 threads per row, 32 columns each; two-pass (mean, then centred variance) like torch's.
 __device__ __forceinline__ void l5_norm(const float* F, uint4* P, int tid_) {
@@ -385,8 +398,7 @@ __global__ __launch_bounds__(256, 2) void local_pct5_kernel(const float* __restr
                     st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk, qq, st, 0, 0, 0);
                 }
                 float mx = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = l5_rows_allreduce(mx, [](float a, float b) { return fmaxf(a, b); });
                 mx *= 0.35355339059327376220f;                                           // scores / sqrt(8)
                 float den = 0.f;
 #pragma unroll
@@ -394,8 +406,7 @@ __global__ __launch_bounds__(256, 2) void local_pct5_kernel(const float* __restr
                     st[r] = __expf(fmaf(st[r], 0.35355339059327376220f, -mx));
                     den += st[r];
                 }
-                den += __shfl_xor(den, 16, 64);
-                den += __shfl_xor(den, 32, 64);
+                den = l5_rows_allreduce(den, [](float a, float b) { return a + b; });
                 const float inv = __builtin_amdgcn_rcpf(den);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pr[hh][r] = st[r] * inv;
