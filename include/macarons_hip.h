@@ -113,12 +113,14 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
  * local_blobs[i] != NULL (HOST array of 3 device pointers), else the layer-by-layer path. */
 int mcr_local_pct_blob_floats(void);
 int mcr_local_pct3_blob_floats(void);
+int mcr_local_pct6_blob_floats(void);
 /* Kernel variant behind mcr_local_pct_forward / the fused path of mcr_scone_occ_forward.  The blob must have been packed
- * for the selected variant: 1: exact-fp32 MFMA, one workgroup/CU (local_pct.hip); 2: experimental two-workgroups/CU
- * layout (local_pct2.hip, same blob as 1); 3: split-precision bf16x6 matrix products, fp32-class accuracy
- * (local_pct3.hip, blob of mcr_local_pct3_blob_floats() floats); 4: variant 3 restructured for two workgroups per CU
- * (local_pct4.hip: residual stream in registers, 67.6 KB LDS; same blob as 3); 5 (default): variant 4 with the
- * LayerNorm outputs kept pre-split (bf16 planes) in an 80 KB swizzled LDS image (local_pct5.hip; same blob as 3). */
+ * for the selected variant (macarons_amd/networks/packing.py):
+ *   1: exact-fp32 MFMA, one workgroup/CU (local_pct.hip; mcr_local_pct_blob_floats() floats);
+ *   5: split precision, every fp32 operand as exact bf16 hi/mid/lo, six MFMAs per product, two workgroups per CU, valid
+ *      for the whole fp32 range (local_pct5.hip; mcr_local_pct3_blob_floats() floats);
+ *   6 (default): two-term fp16 split (hi + lo, 22 significant bits), three MFMAs per product, same structure
+ *      (local_pct6.hip; mcr_local_pct6_blob_floats() floats); needs |activation| < 65504. */
 int mcr_set_local_pct_variant(int variant);
 int mcr_get_local_pct_variant(void);
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,

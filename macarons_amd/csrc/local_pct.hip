@@ -387,4 +387,6 @@ void launch_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld_
 }
 
 
+int local_pct_blob_floats() { return LP_BLOB_FLOATS; }
+
 }  // namespace mcr

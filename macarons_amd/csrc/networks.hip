@@ -149,20 +149,21 @@ int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t
 int mcr_get_local_pct_variant(void);
 int mcr_local_pct_blob_floats(void) { return local_pct_blob_floats(); }
 int mcr_local_pct3_blob_floats(void) { return local_pct3_blob_floats(); }
+int mcr_local_pct6_blob_floats(void) { return local_pct6_blob_floats(); }
 
-static int g_local_pct_variant = 5;      // 1: local_pct.hip exact-fp32 MFMA; 2: local_pct2.hip (experimental); 3: local_pct3.hip split-precision bf16x6; 4: local_pct4.hip = 3 restructured for two workgroups/CU; 5 (default): local_pct5.hip = 4 with LayerNorm outputs pre-split in LDS (3, 4, 5 share one blob)
+// 1: local_pct.hip exact-fp32 MFMA; 5: local_pct5.hip split-precision bf16 hi/mid/lo (6 MFMAs per product, whole fp32
+// range); 6 (default): local_pct6.hip two-term fp16 split (3 MFMAs per product).  Each has its own blob format.
+static int g_local_pct_variant = 6;
 int mcr_set_local_pct_variant(int v) {
-    MCR_REQUIRE(v >= 1 && v <= 5, "mcr_set_local_pct_variant: variant must be 1..5");
+    MCR_REQUIRE(v == 1 || v == 5 || v == 6, "mcr_set_local_pct_variant: variant must be 1, 5 or 6 (got %d)", v);
     g_local_pct_variant = v;
     return 0;
 }
 int mcr_get_local_pct_variant(void) { return g_local_pct_variant; }
 static void run_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld, int64_t S, const float* blob) {
     if (g_local_pct_variant == 1) launch_local_pct(s, offs, feat, ld, S, blob);
-    else if (g_local_pct_variant == 2) launch_local_pct2(s, offs, feat, ld, S, blob);
-    else if (g_local_pct_variant == 4) launch_local_pct4(s, offs, feat, ld, S, blob);
     else if (g_local_pct_variant == 5) launch_local_pct5(s, offs, feat, ld, S, blob);
-    else launch_local_pct3(s, offs, feat, ld, S, blob);
+    else launch_local_pct6(s, offs, feat, ld, S, blob);
 }
 
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,

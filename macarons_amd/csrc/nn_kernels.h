@@ -46,11 +46,10 @@ void launch_copy2d(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t
 // Fused per-query local PCTransformer (local_pct.hip): offs [S,16,3] -> feat[s*ld_feat + 0:256] (max || avg).
 // `blob` is the host-packed parameter image of one local transformer (local_pct_blob_floats() floats).
 void launch_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);
-void launch_local_pct2(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);
-void launch_local_pct3(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);
-void launch_local_pct4(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);   // same blob as v3
-void launch_local_pct5(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);   // same blob as v3
+void launch_local_pct5(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);   // bf16 hi/mid/lo blob
+void launch_local_pct6(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);   // fp16 hi/lo blob
 int local_pct_blob_floats();
 int local_pct3_blob_floats();
+int local_pct6_blob_floats();
 
 }  // namespace mcr

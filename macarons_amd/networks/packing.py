@@ -8,9 +8,7 @@ Layout (must match macarons_amd/csrc/local_pct.hip):
      LayerNorm-2 gamma folded)  ff2a ff2b (columns 0:128 / 128:256 of ff.linear2)
      14 lin0 (final norm gamma folded)
   vectors: emb1_b[128] emb2_b[128] | per encoder: qkv_c[192] out_b[128] ff1_c[256] ff2_b[128] | lin0_c[128]
-     where c = bias + W @ beta (the LayerNorm shift folded through the linear layer);
-     then (v2 kernel) per encoder: qkv_s[192] ff1_s[256] | lin0_s[128] with s = row sums of the gamma-folded weight
-     (y = rstd * (x W'^T - mu * s) + c lets the kernel skip centring x).
+     where c = bias + W @ beta (the LayerNorm shift folded through the linear layer).
 Folding is algebraically exact; it only moves fp32 roundings (covered by the 1e-4 parity tests).
 """
 import torch
@@ -59,13 +57,17 @@ def _pack_bf16x3(W):
 
 def pack_local_pct(pct, variant=1):
     """pct: macarons_amd.networks.SconeOcc.PCTransformer (default local architecture). Returns a 1-D fp32 tensor.
-    variant 1/2: fp32 fragment image (local_pct.hip / local_pct2.hip); variant 3/4: exact bf16 hi/mid/lo planes
-    (local_pct3.hip / local_pct4.hip, split-precision matrix products)."""
-    if variant in (3, 4, 5):
+    variant 1: fp32 fragment image (local_pct.hip); variant 5: exact bf16 hi/mid/lo planes (local_pct5.hip);
+    variant 6: fp16 hi/lo planes of the power-of-two scaled weights (local_pct6.hip)."""
+    if variant == 5:
         return _pack_local_pct3(pct)
+    if variant == 6:
+        return _pack_local_pct6(pct)
+    if variant != 1:
+        raise ValueError(f"unknown fused local transformer variant {variant}")
     with torch.no_grad():
         f = lambda p: p.detach().float()
-        mats, vecs, svecs = [], [], []
+        mats, vecs = [], []
         emb = pct.embedding
         mats.append(_pack(_pad(f(emb.linear1.weight), 128, 8)))
         mats.append(_pack(_pad(f(emb.linear2.weight), 128, 128)))
@@ -80,13 +82,11 @@ def pack_local_pct(pct, variant=1):
                      _pack((w1 * g2[None, :])[:128]), _pack((w1 * g2[None, :])[128:]),
                      _pack(w2[:, :128].contiguous()), _pack(w2[:, 128:].contiguous())]
             vecs += [bqkv + wqkv @ b1, f(enc.mhsa.out.bias), f(enc.ff.linear1.bias) + w1 @ b2, f(enc.ff.linear2.bias)]
-            svecs += [(wqkv * g1[None, :]).sum(1), (w1 * g2[None, :]).sum(1)]      # column sums s_n (un-centred LayerNorm fold)
         gn, bn = f(pct.norm.weight), f(pct.norm.bias)
         w0 = f(pct.linear0.weight)
         mats.append(_pack(w0 * gn[None, :]))
         vecs.append(f(pct.linear0.bias) + w0 @ bn)
-        svecs.append((w0 * gn[None, :]).sum(1))
-        blob = torch.cat(mats + vecs + svecs).contiguous()
+        blob = torch.cat(mats + vecs).contiguous()
     expect = _lib.lib().mcr_local_pct_blob_floats()
     if blob.numel() != expect:
         raise RuntimeError(f"packed local transformer has {blob.numel()} floats, kernel expects {expect}")
@@ -132,4 +132,67 @@ def _pack_local_pct3(pct):
     expect = _lib.lib().mcr_local_pct3_blob_floats()
     if blob.numel() != expect:
         raise RuntimeError(f"packed local transformer (v3) has {blob.numel()} floats, kernel expects {expect}")
+    return blob
+
+
+def _pow2_scale(*Ws):
+    """Power of two 2^e that brings max |W| into [2^13, 2^14): the fp16 low plane of every weight down to 2^-16 of the
+    largest one is then a normal fp16 number.  Shared by matrices whose products are accumulated together."""
+    m = max(float(W.abs().max()) for W in Ws)
+    if m == 0.0 or not (m < float("inf")):
+        return 1.0
+    import math
+    return 2.0 ** (13 - math.floor(math.log2(m)))
+
+
+def _pack_f16x2(W, scale):
+    """[N, K] fp32 -> fp16 hi/lo planes of W * scale in the fragment order of local_pct6.hip [N/32][K/16][plane][64 lanes][8],
+    returned as a float32-typed view (1 float per weight).  hi = fp16(Ws), lo = fp16(Ws - hi) (round to nearest even)."""
+    N, K = W.shape
+    assert N % 32 == 0 and K % 16 == 0
+    Ws = W * scale                                                              # exact (power of two, no overflow: < 2^14)
+    hi = Ws.to(torch.float16)
+    lo = (Ws - hi.float()).to(torch.float16)
+    planes = torch.stack([hi.view(torch.int16), lo.view(torch.int16)], 0)      # [2, N, K]
+    t = planes.reshape(2, N // 32, 32, K // 16, 2, 8)                           # [pl, nt, j, s, h, e]
+    t = t.permute(1, 3, 0, 4, 2, 5).contiguous()                                # [nt, s, pl, h, j, e]
+    return t.reshape(-1).view(torch.float32)
+
+
+def _pack_local_pct6(pct):
+    with torch.no_grad():
+        f = lambda p: p.detach().float()
+        mats, vecs, inv = [], [], []
+
+        def add(*Ws):
+            sc = _pow2_scale(*Ws)
+            for W in Ws:
+                mats.append(_pack_f16x2(W.contiguous(), sc))
+                inv.append(1.0 / sc)
+        emb = pct.embedding
+        add(_pad(f(emb.linear1.weight), 128, 16))
+        add(_pad(f(emb.linear2.weight), 128, 128))
+        vecs += [_padv(f(emb.linear1.bias), 128), _padv(f(emb.linear2.bias), 128)]
+        for enc in pct.encoders:
+            g1, b1 = f(enc.norm1.weight), f(enc.norm1.bias)
+            g2, b2 = f(enc.norm2.weight), f(enc.norm2.bias)
+            wqkv = torch.cat((f(enc.mhsa.w_q.weight), f(enc.mhsa.w_k.weight), f(enc.mhsa.w_v.weight)), 0)
+            bqkv = torch.cat((f(enc.mhsa.w_q.bias), f(enc.mhsa.w_k.bias), f(enc.mhsa.w_v.bias)), 0)
+            w1, w2 = f(enc.ff.linear1.weight), f(enc.ff.linear2.weight)
+            add(wqkv * g1[None, :])
+            add(f(enc.mhsa.out.weight))
+            add((w1 * g2[None, :])[:128])
+            add((w1 * g2[None, :])[128:])
+            add(w2[:, :128], w2[:, 128:])                  # one exponent: both halves accumulate into the same registers
+            vecs += [bqkv + wqkv @ b1, f(enc.mhsa.out.bias), f(enc.ff.linear1.bias) + w1 @ b2, f(enc.ff.linear2.bias)]
+        gn, bn = f(pct.norm.weight), f(pct.norm.bias)
+        w0 = f(pct.linear0.weight)
+        add(w0 * gn[None, :])
+        vecs.append(f(pct.linear0.bias) + w0 @ bn)
+        assert len(inv) == 15
+        dev = mats[0].device
+        blob = torch.cat(mats + vecs + [torch.tensor(inv + [0.0], dtype=torch.float32, device=dev)]).contiguous()
+    expect = _lib.lib().mcr_local_pct6_blob_floats()
+    if blob.numel() != expect:
+        raise RuntimeError(f"packed local transformer (v6) has {blob.numel()} floats, kernel expects {expect}")
     return blob

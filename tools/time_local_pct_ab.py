@@ -18,7 +18,7 @@ occ = occ.to(dev)
 S = 16384
 offs = torch.randn(S, 16, 3, device=dev) * 0.05
 ref = nets.pc_transformer(sd, "local_transformers.0.", offs[:600].cpu().numpy(), np.float64)
-variants = [int(v) for v in os.environ.get("VARIANTS", "1,3").split(",")]
+variants = [int(v) for v in os.environ.get("VARIANTS", "1,5,6").split(",")]
 for rnd in range(2):
     for v in variants:
         _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(v))
