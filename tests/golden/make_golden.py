@@ -336,21 +336,32 @@ class _StandInCameras:
     the fixed order the HIP kernels and the oracle use.  The reference FUNCTION's own logic is what the golden pins."""
 
     class _T:
-        def __init__(self, M):
+        def __init__(self, M, squeeze=False):
             self.M = M                                   # [n,4,4]
+            self.squeeze = squeeze
+            self._shape = None
+
+        def _in_shape(self, p):
+            return self._shape
 
         def transform_points(self, p):
+            self._shape = tuple(p.shape)
             p = p.reshape(-1, 3)
             x, y, z = p[:, 0], p[:, 1], p[:, 2]
             cols = [((x[None] * self.M[:, 0, j, None] + y[None] * self.M[:, 1, j, None]) + z[None] * self.M[:, 2, j, None])
                     + self.M[:, 3, j, None] for j in range(4)]
-            return torch.stack([cols[0] / cols[3], cols[1] / cols[3], cols[2] / cols[3]], -1)       # [n,P,3]
+            out = torch.stack([cols[0] / cols[3], cols[1] / cols[3], cols[2] / cols[3]], -1)        # [n,P,3]
+            if self.squeeze and out.shape[0] == 1 and len(self._in_shape(p)) == 2:
+                out = out[0]                        # Transform3d.transform_points: [P,3] in, batch of one -> [P,3] out
+            return out
 
         def inverse(self):
-            return _StandInCameras._T(torch.linalg.inv(self.M.double()).float())
+            return _StandInCameras._T(torch.linalg.inv(self.M.double()).float(), self.squeeze)
 
-    def __init__(self, R, T, P=None):
+    def __init__(self, R, T, P=None, squeeze=False, fov=60.0):
         self.R, self.T = R, T
+        self.squeeze = squeeze
+        self.fov = torch.tensor([fov])
         n = R.shape[0]
         self.Mv = torch.zeros(n, 4, 4)
         self.Mv[:, :3, :3] = R
@@ -359,10 +370,23 @@ class _StandInCameras:
         self.P = P
 
     def get_world_to_view_transform(self):
-        return self._T(self.Mv)
+        return self._T(self.Mv, self.squeeze)
 
     def get_full_projection_transform(self):
-        return self._T(self.Mv @ self.P)
+        return self._T(self.Mv @ self.P, self.squeeze)
+
+    def unproject_points(self, xy_depth, scaled_depth_input=False):
+        """FoVPerspectiveCameras.unproject_points as published (pytorch3d 0.6.2 cameras.py): depth -> scaled depth with the
+        projection entries K[2,2], K[2,3] (= P[2,2], P[3,2] in the row-vector matrices used here), then the inverse of the
+        full projection transform."""
+        assert not scaled_depth_input
+        f1 = self.P[:, 2, 2].reshape(-1, 1, 1)
+        f2 = self.P[:, 3, 2].reshape(-1, 1, 1)
+        sdepth = (f1 * xy_depth[..., 2:3] + f2) / xy_depth[..., 2:3]
+        xy_sdepth = torch.cat((xy_depth[..., 0:2], sdepth), dim=-1)
+        Minv = torch.linalg.inv((self.Mv @ self.P).double())
+        p4 = torch.cat((xy_sdepth.double(), torch.ones_like(xy_sdepth[..., :1]).double()), -1) @ Minv
+        return (p4[..., :3] / p4[..., 3:4]).float()
 
     def get_camera_center(self):
         return -torch.einsum("nj,nij->ni", self.T, self.R)            # C = -T R^T
@@ -434,7 +458,349 @@ def gen_viewspace():
     save("view_space", n_cam=np.int64(len(eyes)), **out)
 
 
-GROUPS = {"viewspace": gen_viewspace, "filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 2: the MACARONS-regime rows pinned on the reference's own functions.
+def _grid(a, step=1024.0):
+    """Quantise to the 2^-10 grid: squared distances are then exact in fp32 in ANY formulation (|x|^2+|y|^2-2xy or
+    (x-y)^2), so torch.cdist + topk of the reference and a direct-form kNN see identical values."""
+    return (np.round(np.asarray(a, np.float64) * step) / step).astype(np.float32)
+
+
+def _boundary_ties(X, pc, k=16):
+    """Mask of the queries whose k-th and (k+1)-th neighbour sit at the same (exact) squared distance."""
+    Xi = np.round(X.astype(np.float64) * 1024).astype(np.int64)
+    Pi = np.round(pc.astype(np.float64) * 1024).astype(np.int64)
+    bad = np.zeros(len(Xi), bool)
+    for lo in range(0, len(Xi), 2048):
+        d = ((Xi[lo:lo + 2048, None, :] - Pi[None, :, :]) ** 2).sum(-1)
+        part = np.partition(d, k, axis=1)[:, :k + 1]
+        part.sort(axis=1)
+        bad[lo:lo + 2048] = part[:, k - 1] == part[:, k]
+    return bad
+
+
+def _e2e(tag, M, Q, n_elev_cam, n_azim_cam, view_ids, seed, torch_seed):
+    """One SCONE NBV decision through the reference's own functions (testers/shapenet.py:126-172) on grid-quantised clouds."""
+    import importlib
+    su = importlib.import_module("macarons.utility.scone_utils")
+    occ = _load(ref["SconeOcc"].SconeOcc(), 2)
+    vis = _load(ref["SconeVis"].SconeVis(), 1)
+    with torch.no_grad():
+        occ.linear3.bias += 0.5
+    rng = np.random.default_rng(seed)
+    ds = int(np.power(M / (16 * 8), 1. / 2)) or 2
+    pc = np.unique(_grid(shell_cloud(rng, M + 64)), axis=0)
+    rng.shuffle(pc)
+    pc = pc[:M]
+    assert pc.shape == (M, 3)
+    # the three randperm draws SconeOcc.forward will make under this seed (checked below against the captured ones)
+    torch.manual_seed(torch_seed)
+    pp = [torch.randperm(M).numpy(), torch.randperm(M).numpy(), torch.randperm(M // ds).numpy()]
+    pc1 = pc[pp[1][:M // ds]]
+    pc2 = pc1[pp[2][:(M // ds) // ds]]
+    # queries: redraw every query that has a k / k+1 distance tie in one of the three clouds, until none has: the
+    # 16-neighbour SET of every query is then unique, whatever the tie order of topk
+    X = _grid(rng.uniform(-0.5, 0.5, (Q, 3)))
+    for it in range(100):
+        bad = _boundary_ties(X, pc) | _boundary_ties(X, pc1) | _boundary_ties(X, pc2)
+        _, first = np.unique(X, axis=0, return_index=True)
+        dup = np.ones(Q, bool); dup[first] = False
+        bad |= dup
+        print(f"  {tag}: pass {it}: {int(bad.sum())} queries with boundary ties / duplicates")
+        if not bad.any():
+            break
+        X[bad] = _grid(rng.uniform(-0.5, 0.5, (int(bad.sum()), 3)))
+    else:
+        raise RuntimeError("no tie-free query set found")
+    perms, drawn = [], []
+    real_perm, real_rand = torch.randperm, torch.rand
+
+    def cap_perm(n, *a, **kw):
+        p_ = real_perm(n, *a, **kw); perms.append(p_.numpy().copy()); return p_
+
+    def cap_rand(*a, **kw):
+        r_ = real_rand(*a, **kw); drawn.append(r_.numpy().copy()); return r_
+    attempt = 0
+    X_cam = cameras_on_sphere(n_elev_cam, n_azim_cam).astype(np.float32)
+    X_view = X_cam[view_ids]
+    base, h_polar, h_azim = su.get_all_harmonics_under_degree(8, 7, 14, "cpu")
+    torch.randperm, torch.rand = cap_perm, cap_rand
+    try:
+        torch.manual_seed(torch_seed + attempt)
+        with torch.no_grad():
+            vs = su.compute_view_state(t(X[None]), t(X_view), 7, 14)
+            vh = su.compute_view_harmonics(vs, base, h_polar, h_azim, 7, 14)
+            occ_prob = su.compute_occupancy_probability(occ, t(pc[None]), t(X[None]), vh, max_points_per_pass=300000).view(-1, 1)
+            proxy, vh_s, sample_idx = su.sample_proxy_points(t(X), occ_prob, vh.squeeze(0), n_sample=2048, min_occ=0.1,
+                                                             use_occ_to_sample=True, return_index=True)
+            harm = vis(proxy[None], view_harmonics=vh_s[None])
+            proxy_mc = proxy[sample_idx][None]
+            harm_mc = harm[0][sample_idx][None]
+            gains = vis.compute_coverage_gain(proxy_mc, harm_mc, t(X_cam).view(1, -1, 3)).view(-1)
+            max_gain, max_idx = torch.max(gains, dim=0)
+    finally:
+        torch.randperm, torch.rand = real_perm, real_rand
+    assert all(np.array_equal(a, b) for a, b in zip(perms, pp)), "predicted permutations differ from the ones forward drew"
+    cut = [perms[0][:2048], perms[1][:M // ds], perms[2][:(M // ds) // ds]]
+    # unique original indices of the sampled points (the reference returns only the points): recover them by matching rows
+    keep = np.nonzero(occ_prob.numpy()[:, 0] > np.float32(0.1))[0]
+    save(tag, pc=pc[None], X=X[None], X_view=X_view, X_cam=X_cam, occ=occ_prob.numpy(), n_unique=np.int64(proxy.shape[0]),
+         proxy=proxy.numpy(), sample_idx=sample_idx.numpy().astype(np.int32), harm_sum=harm.numpy().astype(np.float64).sum(1),
+         gains=gains.numpy(), nbv_idx=np.int64(max_idx.item()), samples=drawn[0].reshape(-1), seed=np.int64(torch_seed + attempt),
+         perm0=cut[0].astype(np.int32), perm1=cut[1].astype(np.int32), perm2=cut[2].astype(np.int32),
+         occ_bias_shift=np.float32(0.5), n_kept=np.int64(len(keep)))
+
+
+def gen_e2e_grid():
+    """G9 on the 2^-10 grid (config 1: M=1024, Q=2048, C=20) and the config-2 shape (M=4096, Q=16384, C=100)."""
+    _e2e("e2e_grid_config1", 1024, 2048, 4, 5, [6], 171, 1230)
+    _e2e("e2e_grid_config2", 4096, 16384, 10, 10, [3, 47, 88], 172, 2230)
+
+
+def _stub_renderer(H=256, W=456):
+    from types import SimpleNamespace as NS
+    return NS(rasterizer=NS(raster_settings=NS(image_size=(H, W))))
+
+
+def _ref_camera(mu, H=256, W=456):
+    """A REAL reference Camera (macarons_utils.py:1852): only its renderer is a stub that carries the image size, so the NDC
+    tables and bounds (:1929-1938) are the reference's own arithmetic."""
+    return mu.Camera(x_min=torch.tensor([-40., -40., -40.]), x_max=torch.tensor([40., 40., 40.]), pose_l=2, pose_w=2, pose_h=2,
+                     pose_n_elev=3, pose_n_azim=4, n_interpolation_steps=1, zfar=500., renderer=_stub_renderer(H, W), device="cpu")
+
+
+def _scene_cams(eyes, zfar=500.):
+    R, T = _look_at(np.asarray(eyes, np.float32))
+    P = np.broadcast_to(_fov_projection(60.0, 1.0, zfar), (len(R), 4, 4)).copy()
+    return R, T, P
+
+
+def gen_fov():
+    """Camera.get_points_in_fov (macarons_utils.py:2400-2435) on a real Camera object + stand-in FoV cameras."""
+    import importlib
+    mu = importlib.import_module("macarons.utility.macarons_utils")
+    cam = _ref_camera(mu)
+    rng = np.random.default_rng(101)
+    pts = rng.uniform(-40, 40, (30000, 3)).astype(np.float32)
+    eyes = np.array([[30., 5., -20.], [0., 35., 1.], [-25., -10., 25.], [3., 2., 1.]], np.float32)
+    R, T, P = _scene_cams(eyes)
+    allc = _StandInCameras(t(R), t(T), t(P))
+    out = dict(pts=pts, eyes=eyes, R=R, T=T, P=P, ndc=np.array([cam.min_ndc_x, cam.max_ndc_x, cam.min_ndc_y, cam.max_ndc_y], np.float32),
+               Mview=allc.Mv.numpy(), Mfull=allc.get_full_projection_transform().M.numpy(), center=allc.get_camera_center().numpy(),
+               ndc_x_tab=cam.ndc_x_tab.numpy()[::37, ::41], ndc_y_tab=cam.ndc_y_tab.numpy()[::37, ::41])
+    for c in range(len(eyes)):
+        fc = _StandInCameras(t(R[c:c + 1]), t(T[c:c + 1]), t(P[c:c + 1]), squeeze=True)
+        for tag, rg in (("r40", 40.0), ("none", None)):
+            sel, mask = cam.get_points_in_fov(t(pts), return_mask=True, fov_camera=fc, fov_range=rg)
+            assert torch.equal(sel, t(pts)[mask])
+            out[f"mask_{c}_{tag}"] = np.packbits(mask.numpy())
+            out[f"n_{c}_{tag}"] = np.int64(mask.sum())
+    save("fov_camera", **out)
+
+
+def gen_distance():
+    """get_distance_factor / _threshold / _smooth (macarons_utils.py:1741-1788)."""
+    import importlib
+    from types import SimpleNamespace as NS
+    mu = importlib.import_module("macarons.utility.macarons_utils")
+    rng = np.random.default_rng(103)
+    pts = rng.uniform(-40, 40, (3000, 3)).astype(np.float32)
+    cam = np.array([[3.0, -2.0, 5.0]], np.float32)
+    params = NS(image_height=256, image_width=456)
+    fc = NS(fov=torch.tensor([60.0]))
+    res = 0.1                                                        # distance_th = f eps / pixel = 19.6 here
+    save("distance_factors", pts=pts, cam=cam, cell_resolution=np.float32(res), fov=np.float32(60.0), hw=np.array([256, 456]),
+         f_plain=mu.get_distance_factor(params, t(pts), t(cam), fc, res).numpy(),
+         f_smooth=mu.get_distance_factor_smooth(params, t(pts), t(cam), fc, res).numpy(),
+         f_th=mu.get_distance_factor_threshold(t(pts), t(cam), distance_th=17.).numpy())
+
+
+def _ref_macarons(shift=0.5):
+    M = importlib_macarons()
+    occ = _load(ref["SconeOcc"].SconeOcc(), 2)
+    vis = _load(ref["SconeVis"].SconeVis(), 1)
+    with torch.no_grad():
+        occ.linear3.bias += shift
+    return M.Macarons(None, occ, vis).eval()
+
+
+def importlib_macarons():
+    import importlib
+    return importlib.import_module("macarons.networks.Macarons")
+
+
+def gen_macarons_wrapper():
+    """Macarons.forward(mode=...) dispatch and compute_visibility_gains (Macarons.py:110-178)."""
+    m = _ref_macarons()
+    rng = np.random.default_rng(105)
+    pc = shell_cloud(rng, 600)[None]
+    x = rng.uniform(-0.5, 0.5, (1, 150, 3)).astype(np.float32)
+    vh = (rng.standard_normal((1, 150, 64)) * 0.3).astype(np.float32)
+    pts = np.concatenate([rng.uniform(-0.5, 0.5, (1, 200, 3)), rng.uniform(0.1, 1, (1, 200, 1))], -1).astype(np.float32)
+    vh2 = (rng.standard_normal((1, 200, 64)) * 0.3).astype(np.float32)
+    cams = rng.standard_normal((1, 5, 3)).astype(np.float32)
+    cams = (1.5 * cams / np.linalg.norm(cams, axis=-1, keepdims=True)).astype(np.float32)
+    perms = []
+    real = torch.randperm
+
+    def cap(n, *a, **kw):
+        p_ = real(n, *a, **kw); perms.append(p_.numpy().copy()); return p_
+    torch.randperm = cap
+    try:
+        torch.manual_seed(9)
+        with torch.no_grad():
+            o = m(mode='occupancy', partial_point_cloud=t(pc), proxy_points=t(x), view_harmonics=t(vh)).numpy()
+    finally:
+        torch.randperm = real
+    with torch.no_grad():
+        h = m(mode='visibility', proxy_points=t(pts), view_harmonics=t(vh2))
+        g32 = m.compute_visibility_gains(pts=t(pts), harmonics=h, X_cam=t(cams)).numpy()
+        g64 = m.double().compute_visibility_gains(pts=t(pts, torch.float64), harmonics=h.double(), X_cam=t(cams, torch.float64)).numpy()
+    errs = {}
+    for mode, kw in (("occupancy", dict(proxy_points=t(x))), ("visibility", dict(proxy_points=t(pts))), ("depth", {}), ("bogus", {})):
+        try:
+            m(mode=mode, **kw)
+        except NameError as e:
+            errs[mode] = str(e)
+    M0, ds = 600, int(np.power(600 / (16 * 8), 1. / 2)) or 2
+    save("macarons_wrapper", pc=pc, x=x, vh=vh, occ=o, perm0=perms[0][:2048].astype(np.int32), perm1=perms[1][:M0 // ds].astype(np.int32),
+         perm2=perms[2][:(M0 // ds) // ds].astype(np.int32), pts=pts, vh2=vh2, cams=cams, harm=h.numpy(), gains32=g32, gains64=g64,
+         err_occupancy=errs["occupancy"], err_visibility=errs["visibility"], err_depth=errs["depth"], err_bogus=errs["bogus"], seed=np.int64(9))
+
+
+def gen_single_camera():
+    """predict_coverage_gain_for_single_camera (macarons_utils.py:1580-1738): frustum -> occupancy filter -> sampling ->
+    prediction-view space -> SconeVis -> per-point gains x distance factor -> mean x frustum volume; for several neighbour
+    cameras incl. one whose frustum holds no occupied proxy point (the dummy branch, gain 0)."""
+    import importlib
+    from types import SimpleNamespace as NS
+    mu = importlib.import_module("macarons.utility.macarons_utils")
+    cam = _ref_camera(mu)
+    m = _ref_macarons()
+    rng = np.random.default_rng(107)
+    P_ = 20000
+    X_world = rng.uniform(-40, 40, (P_, 3)).astype(np.float32)
+    # view harmonics as an elementwise (bit-reproducible) expression of three small stored factors: 20000 x 64 floats stay out of git
+    vh_u, vh_v = (rng.standard_normal(P_) * 0.3).astype(np.float32), rng.standard_normal(64).astype(np.float32)
+    vh_w = (rng.standard_normal((16, 64)) * 0.2).astype(np.float32)
+    vh = (vh_u[:, None] * vh_v[None, :] + vh_w[np.arange(P_) % 16]).astype(np.float32)
+    occ = rng.uniform(-0.1, 1.0, (P_, 1)).astype(np.float32)
+    occ[X_world[:, 0] < -20] = 0.0                                  # an empty slab: the last camera looks only at it
+    eyes = np.array([[30., 5., -20.], [0., 35., 1.], [3., 2., 1.], [-39., 0., 0.]], np.float32)
+    at = np.array([[0, 0, 0], [0, 0, 0], [0, 0, 0], [-80., 0., 0.]], np.float32)
+    # look-at towards `at`: shift eyes so that _look_at (which looks at the origin) can be reused
+    R, T = [], []
+    for e, a in zip(eyes, at):
+        r, _ = _look_at((e - a)[None])
+        R.append(r[0]); T.append(-(r[0].T @ e))
+    R, T = np.stack(R).astype(np.float32), np.stack(T).astype(np.float32)
+    P = np.broadcast_to(_fov_projection(60.0, 1.0, 500.), (len(R), 4, 4)).copy()
+    Rp, Tp, Pp = _scene_cams(np.array([[10., 20., -30.]], np.float32))
+    pred = _StandInCameras(t(Rp), t(Tp), t(Pp), squeeze=True)
+    proxy_scene = NS(x_min=torch.tensor([-40., -40., -40.]), x_max=torch.tensor([40., 40., 40.]))
+    surface_scene = NS(cell_resolution=0.1)
+    params = NS(sensor_range=60.0, min_occ_for_proxy_points=0.1, seq_len=2048, use_occ_to_sample_proxy_points=True, jz=False,
+                ddp=False, distance_factor_th=17.0, k_for_knn=16, n_harmonics=64, image_height=256, image_width=456)
+    allc = _StandInCameras(t(R), t(T), t(P))
+    out = dict(X_world=X_world, vh_u=vh_u, vh_v=vh_v, vh_w=vh_w, occ=occ, eyes=eyes, R=R, T=T, P=P, Rp=Rp, Tp=Tp,
+               Mview=allc.Mv.numpy(), Mfull=allc.get_full_projection_transform().M.numpy(), center=allc.get_camera_center().numpy(),
+               Mpred=pred.Mv.numpy(),
+               ndc=np.array([cam.min_ndc_x, cam.max_ndc_x, cam.min_ndc_y, cam.max_ndc_y], np.float32),
+               box_diag=np.float32(torch.linalg.norm(proxy_scene.x_max - proxy_scene.x_min).item()), sensor_range=np.float32(60.0))
+    real = torch.rand
+    for c in range(len(eyes)):
+        fc = _StandInCameras(t(R[c:c + 1]), t(T[c:c + 1]), t(P[c:c + 1]), squeeze=True)
+        drawn = []
+
+        def cap(*a, **kw):
+            r_ = real(*a, **kw); drawn.append(r_.numpy().copy()); return r_
+        torch.rand = cap
+        try:
+            torch.manual_seed(500 + c)
+            with torch.no_grad():
+                pw, vhs, vg, cg = mu.predict_coverage_gain_for_single_camera(
+                    params, m, proxy_scene, surface_scene, t(X_world), t(vh), t(occ), cam, t(eyes[c:c + 1]), fc, prediction_camera=pred)
+        finally:
+            torch.rand = real
+        out[f"gain_{c}"] = cg.numpy()
+        out[f"vis_{c}"] = vg.numpy()
+        out[f"world_{c}"] = pw.numpy()
+        if drawn:
+            out[f"u_{c}"] = drawn[0].reshape(-1)
+        print(f"  camera {c}: gain {cg.numpy().ravel()}  sampled {pw.shape}")
+    # the 'smooth' and None distance-factor branches on camera 0 (same uniforms)
+    for tag, th in (("smooth", "smooth"), ("plain", None)):
+        params.distance_factor_th = th
+        fc = _StandInCameras(t(R[0:1]), t(T[0:1]), t(P[0:1]), squeeze=True)
+        torch.manual_seed(500)
+        with torch.no_grad():
+            _, _, _, cg = mu.predict_coverage_gain_for_single_camera(params, m, proxy_scene, surface_scene, t(X_world), t(vh), t(occ), cam,
+                                                                     t(eyes[0:1]), fc, prediction_camera=pred)
+        out[f"gain_0_{tag}"] = cg.numpy()
+    save("single_camera", **out)
+
+
+def gen_cell():
+    """Cell.fill (macarons_utils.py:2551-2577): bounding-box masks, fp64 admission test against the points already in the
+    cell, random cap at capacity (randperm captured), two successive fills."""
+    import importlib
+    mu = importlib.import_module("macarons.utility.macarons_utils")
+    rng = np.random.default_rng(109)
+    center = torch.tensor([[1.0, -2.0, 0.5]])
+    cell = mu.Cell(center=center, l=torch.tensor(4.0), w=torch.tensor(3.0), h=torch.tensor(2.0), capacity=400, resolution=0.12, device="cpu")
+    out = dict(center=center.numpy(), lwh=np.array([4.0, 3.0, 2.0], np.float32), capacity=np.int64(cell.capacity), resolution=np.float64(cell.resolution))
+    real = torch.randperm
+    for i in range(3):
+        pts = (rng.uniform(-1, 1, (1500, 3)) * [2.6, 2.0, 1.4] + center.numpy()).astype(np.float32)
+        perms = []
+
+        def cap(n, *a, **kw):
+            p_ = real(n, *a, **kw); perms.append(p_.numpy().copy()); return p_
+        torch.randperm = cap
+        before = cell.cell_pts.numpy().copy()
+        try:
+            torch.manual_seed(40 + i)
+            cell.fill(t(pts))
+        finally:
+            torch.randperm = real
+        out[f"pts_{i}"], out[f"before_{i}"], out[f"after_{i}"], out[f"perm_{i}"] = pts, before, cell.cell_pts.numpy().copy(), perms[0].astype(np.int32)
+    save("cell_fill", **out)
+
+
+def gen_unproject():
+    """utils.project_depth_back_to_3D (utils.py:1458-1487) and Camera.compute_partial_point_cloud (macarons_utils.py:2362-2398)
+    on stand-in cameras whose unproject_points restates PyTorch3D's published algorithm."""
+    import importlib
+    mu = importlib.import_module("macarons.utility.macarons_utils")
+    H, W = 32, 57
+    cam = _ref_camera(mu, H, W)
+    rng = np.random.default_rng(111)
+    eyes = np.array([[30., 5., -20.], [-25., -10., 25.]], np.float32)
+    R, T, P = _scene_cams(eyes)
+    fc = _StandInCameras(t(R), t(T), t(P))
+    depth = rng.uniform(2.0, 80.0, (2, H, W, 1)).astype(np.float32)
+    depth[0, :3, :5] = -1.0                                           # background pixels of project_depth_back_to_3D (depth > -1 kept)
+    depth[:, 10:12] = -1.0
+    world = ref["utils"].project_depth_back_to_3D(t(depth), fc)
+    mask = (rng.random((1, H, W, 1)) < 0.8)
+    fc1 = _StandInCameras(t(R[:1]), t(T[:1]), t(P[:1]))
+    d1 = np.abs(depth[:1]) + 1.0
+    perms = []
+    real = torch.randperm
+
+    def cap(n, *a, **kw):
+        p_ = real(n, *a, **kw); perms.append(p_.numpy().copy()); return p_
+    torch.randperm = cap
+    try:
+        torch.manual_seed(77)
+        part = cam.compute_partial_point_cloud(t(d1), torch.from_numpy(mask), fov_cameras=fc1, gathering_factor=0.25, fov_range=60.0)
+    finally:
+        torch.randperm = real
+    save("unproject", depth=depth, eyes=eyes, R=R, T=T, P=P, Mfull=fc.get_full_projection_transform().M.numpy(), world=world.numpy(), d1=d1, mask=np.packbits(mask), part=part.numpy(),
+         perm=perms[0].astype(np.int32), H=np.int64(H), W=np.int64(W))
+
+
+GROUPS = {"e2e_grid": gen_e2e_grid, "fov": gen_fov, "distance": gen_distance, "wrapper": gen_macarons_wrapper, "single_camera": gen_single_camera, "cell": gen_cell, "unproject": gen_unproject, "viewspace": gen_viewspace, "filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
