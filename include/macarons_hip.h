@@ -174,14 +174,15 @@ int mcr_best_merge(const float* records, int world, int64_t B, float* vals, int6
 /* MACARONS per-camera scoring (predict_coverage_gain_for_single_camera, macarons/utility/macarons_utils.py:1580-1738):
  * mcr_fov_mask_occ: occ_out[c,p] = mask[c,p] ? occ[p] : 0  (frustum mask AND'ed into the sampler's occupancy, :1603-1613)
  * mcr_transform_points: in place pts[i,:3] = (([x y z 1] M_view)[:3] - center) * inv_diag   (:1641-1660)
- * mcr_macarons_gain: vis[b,n] *= min(1, (th/|pts_world[b,n]-cam_world[b]|)^2) (get_distance_factor_threshold :1768-1776);
- *   gains[b] = mean_n vis[b,n] * volume[b]   (:1699-1704) */
+ * mcr_macarons_gain: vis[b,n] *= factor(d = |pts_world[b,n]-cam_world[b]|), gains[b] = mean_n vis[b,n] * volume[b] (:1699-1704);
+ *   factor_mode 0: min(1, (th/d)^2) = get_distance_factor_threshold (:1768-1776) and, with th = focal * epsilon / pixel_size,
+ *   get_distance_factor (:1741-1765); factor_mode 1: 1 / (1 + (d/th)^2) = get_distance_factor_smooth (:1779-1788). */
 int mcr_fov_mask_occ(const unsigned char* mask, const float* occ, int64_t occ_stride, float* occ_out, int64_t P, int n_cam,
                      void* stream);
 int mcr_transform_points(float* pts, int pts_dim, int64_t n, const float* M_view, const float* center, float inv_diag,
                          void* stream);
 int mcr_macarons_gain(float* vis, const float* pts_world, int pts_dim, const float* cam_world, const float* volume,
-                      float distance_th, int64_t B, int64_t N, float* gains, void* stream);
+                      float distance_th, int factor_mode, int64_t B, int64_t N, float* gains, void* stream);
 
 /* ---- scene-side point bookkeeping ---------------------------------------------------------
  * mcr_min_dist_segmented (K11): dmin[i] = min_j |A[i] - B[j]| in fp64 over the B points of A[i]'s segment (grid cell);

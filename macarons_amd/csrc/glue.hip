@@ -355,11 +355,13 @@ __global__ void transform_points_kernel(float* __restrict__ pts, int pts_dim, lo
     p[2] = ((((x * M[2] + y * M[6]) + z * M[10]) + M[14]) - center[2]) * inv_diag;
 }
 
-// gains[b] = mean_n( vis[b,n] * min(1, (th / |pts_world[b,n] - cam_world[b]|)^2) ) * volume[b]; vis is scaled in place
-// (get_distance_factor_threshold macarons_utils.py:1768-1776 and the final product :1699-1704).  One block per b.
+// gains[b] = mean_n( vis[b,n] * factor(|pts_world[b,n] - cam_world[b]|) ) * volume[b]; vis is scaled in place (the final
+// product of macarons_utils.py:1699-1704).  factor: mode 0 = min(1, (th / d)^2) (get_distance_factor_threshold :1768-1776;
+// get_distance_factor :1741-1765 is the same function with th = focal * epsilon / pixel), mode 1 = 1 / (1 + (d / th)^2)
+// (get_distance_factor_smooth :1779-1788).  One block per b.
 __global__ __launch_bounds__(256) void macarons_gain_kernel(float* __restrict__ vis, const float* __restrict__ pts_world,
                                                             int pts_dim, const float* __restrict__ cam_world,
-                                                            const float* __restrict__ volume, float distance_th, int N,
+                                                            const float* __restrict__ volume, float distance_th, int mode, int N,
                                                             float* __restrict__ gains) {
     __shared__ double s[4];
     const int b = blockIdx.x;
@@ -370,7 +372,12 @@ __global__ __launch_bounds__(256) void macarons_gain_kernel(float* __restrict__ 
         const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
         const float d = sqrtf((dx * dx + dy * dy) + dz * dz);
         float f = 1.f;
-        if (d > distance_th) f = (distance_th * distance_th) / (d * d);
+        if (mode == 1) {
+            const float q = d / distance_th;
+            f = 1.f / (1.f + q * q);
+        } else if (d > distance_th) {
+            f = (distance_th * distance_th) / (d * d);
+        }
         const float v = vis[(size_t)b * N + n] * f;
         vis[(size_t)b * N + n] = v;
         acc += (double)v;
@@ -574,10 +581,12 @@ int mcr_transform_points(float* pts, int pts_dim, int64_t n, const float* M_view
 }
 
 int mcr_macarons_gain(float* vis, const float* pts_world, int pts_dim, const float* cam_world, const float* volume,
-                      float distance_th, int64_t B, int64_t N, float* gains, void* stream) {
+                      float distance_th, int factor_mode, int64_t B, int64_t N, float* gains, void* stream) {
     MCR_REQUIRE(vis && pts_world && cam_world && volume && gains && B > 0 && N > 0 && pts_dim >= 3, "mcr_macarons_gain: bad arguments");
+    MCR_REQUIRE(factor_mode == 0 || factor_mode == 1, "mcr_macarons_gain: factor_mode must be 0 (threshold) or 1 (smooth)");
+    MCR_REQUIRE(distance_th > 0.f, "mcr_macarons_gain: distance_th must be positive");
     hipLaunchKernelGGL(macarons_gain_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, vis, pts_world, pts_dim, cam_world,
-                       volume, distance_th, (int)N, gains);
+                       volume, distance_th, factor_mode, (int)N, gains);
     MCR_LAUNCH_CHECK("macarons_gain_kernel");
     return 0;
 }

@@ -25,7 +25,7 @@ class ViewStateGrid:
 
 def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1,
              max_points_per_pass=300000, true_monte_carlo_sampling=True, occ_perms=None, samples=None, group=None,
-             view_proj=None, filter_tol=0.01):
+             view_proj=None, filter_tol=0.01, return_samples=False):
     """pc [1,M,3] surface points, X [1,Q,3] proxy points, X_view [n_view,3] past camera positions, X_cam [C,3]
     candidate cameras (all in the normalised prediction-view space, as the reference feeds its networks).
     Returns dict(gains [C_local or C], nbv_idx (global camera index, int), max_gain, occ [Q,1], n_unique).
@@ -61,6 +61,7 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
         proxy_points, vh_s, sample_idx = su.sample_proxy_points(X[0], occ, vh, n_sample=seq_len, min_occ=min_occ,
                                                                 return_index=True, samples=samples)
         n_unique = proxy_points.shape[0]
+        sampled = (proxy_points, sample_idx)
         # ---- visibility-gain harmonics (:157-160) ----
         harm = scone_vis(proxy_points[None], view_harmonics=vh_s[None])
         if true_monte_carlo_sampling:
@@ -76,5 +77,8 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
         else:
             best = torch.max(gains, dim=1)
             max_gain, nbv_idx = best.values, best.indices
-    return {"gains": gains[0], "cam_range": (c0, c1), "nbv_idx": nbv_idx, "max_gain": max_gain, "occ": occ,
-            "n_unique": n_unique}
+    out = {"gains": gains[0], "cam_range": (c0, c1), "nbv_idx": nbv_idx, "max_gain": max_gain, "occ": occ,
+           "n_unique": n_unique}
+    if return_samples:                              # the unique sampled proxy points [n_unique,4] and the inverse map [seq_len]
+        out["proxy_points"], out["sample_idx"] = sampled
+    return out

@@ -379,14 +379,16 @@ def transform_points_(pts, M_view, center, inv_diag):
     return pts
 
 
-def macarons_gain_(vis, pts_world, cam_world, volume, distance_th):
-    """vis [B,N] (scaled in place by the distance factor), pts_world [B,N,>=3], cam_world [B,3], volume [B] -> gains [B]."""
+def macarons_gain_(vis, pts_world, cam_world, volume, distance_th, smooth=False):
+    """vis [B,N] (scaled in place by the distance factor), pts_world [B,N,>=3], cam_world [B,3], volume [B] -> gains [B].
+    smooth=False: min(1, (th/d)^2); smooth=True: 1/(1+(d/th)^2)."""
     vis, pts_world, cam_world, volume = _req(vis, "vis"), _req(pts_world, "pts_world"), _req(cam_world, "cam_world"), _req(volume, "volume")
     B, N = vis.shape
     gains = torch.empty(B, dtype=torch.float32, device=vis.device)
     with torch.cuda.device(vis.device):
         check(lib().mcr_macarons_gain(_p(vis), _p(pts_world), c_int(pts_world.shape[-1]), _p(cam_world), _p(volume),
-                                      c_f32(float(distance_th)), c_i64(B), c_i64(N), _p(gains), _stream()), "mcr_macarons_gain")
+                                      c_f32(float(distance_th)), c_int(int(bool(smooth))), c_i64(B), c_i64(N), _p(gains), _stream()),
+              "mcr_macarons_gain")
     return gains
 
 

@@ -1,5 +1,5 @@
 """Mirror of the MACARONS-regime scoring helpers of macarons/utility/macarons_utils.py on the MI355X kernels:
-  get_distance_factor_threshold :1768-1776
+  get_distance_factor :1741-1765, get_distance_factor_threshold :1768-1776, get_distance_factor_smooth :1779-1788
   predict_coverage_gain_for_single_camera :1580-1738  (here batched over the <= 30 neighbour cameras)
 PyTorch3D camera objects stay outside: cameras are passed as the 40-float records of mcr_points_in_fov
 (M_view, M_proj, ndc bounds, centre, range) and a prediction-view matrix.
@@ -21,34 +21,63 @@ def camera_record(M_view, M_proj, ndc_bounds, center, fov_range=None):
     return rec
 
 
-def get_distance_factor_threshold(pts, X_cam, distance_th=17.):
-    """[n_pts, 1] factor min(1, (th/d)^2)  (macarons_utils.py:1768-1776)."""
+def _factor(pts, X_cam, distance_th, smooth):
     n = pts.shape[0]
     ones = torch.ones(1, n, dtype=torch.float32, device=pts.device)
     ops.macarons_gain_(ones, pts.reshape(1, n, -1)[..., :3].contiguous(), X_cam.reshape(1, 3).contiguous(),
-                       torch.ones(1, dtype=torch.float32, device=pts.device), distance_th)
+                       torch.ones(1, dtype=torch.float32, device=pts.device), distance_th, smooth)
     return ones.view(n, 1)
+
+
+def get_distance_factor_threshold(pts, X_cam, distance_th=17.):
+    """[n_pts, 1] factor min(1, (th/d)^2)  (macarons_utils.py:1768-1776)."""
+    return _factor(pts, X_cam, distance_th, False)
+
+
+def sensor_distance_threshold(params, fov_camera, cell_resolution):
+    """distance_th = focal_length * epsilon / pixel_size of macarons_utils.py:1752-1755 (= :1780-1783)."""
+    import math
+    fov = float(torch.as_tensor(fov_camera.fov).reshape(-1)[0])
+    focal_length = 1. / math.tan(math.pi / 180. * fov / 2.)
+    pixel_size = 2. / min(params.image_height, params.image_width)
+    epsilon = math.sqrt(math.pi) / 2. * cell_resolution
+    return focal_length * epsilon / pixel_size
+
+
+def get_distance_factor(params, pts, X_cam, fov_camera, cell_resolution):
+    """macarons_utils.py:1741-1765: 1 within distance_th, epsilon^2 (focal / pixel / d)^2 = (distance_th / d)^2 beyond."""
+    return _factor(pts, X_cam, sensor_distance_threshold(params, fov_camera, cell_resolution), False)
+
+
+def get_distance_factor_smooth(params, pts, X_cam, fov_camera, cell_resolution):
+    """macarons_utils.py:1779-1788: 1 / (1 + (d / distance_th)^2)."""
+    return _factor(pts, X_cam, sensor_distance_threshold(params, fov_camera, cell_resolution), True)
 
 
 def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harmonics, occ_probs, cameras, X_cam_world,
                                       prediction_view_matrices, prediction_box_diag, seq_len=2048, min_occ=0.1,
-                                      distance_th=17., samples=None):
+                                      distance_th=17., samples=None, smooth=False, return_parts=False):
     """The per-neighbour-camera scoring loop of testers/scene.py:434-454 around
     predict_coverage_gain_for_single_camera (macarons_utils.py:1580-1738), for K cameras:
       frustum mask (all K at once) -> occupancy-weighted sampling inside each frustum -> prediction-view space ->
       SconeVis -> per-point visibility gains (C = 1) x distance factor -> mean x sum(occ in frustum).
     X_world [P,3], proxy_view_harmonics [P,64], occ_probs [P,1], cameras [K,40], X_cam_world [K,3],
-    prediction_view_matrices [K,4,4] (world -> prediction-camera view, row-vector).  Returns gains [K]."""
+    prediction_view_matrices [K,4,4] (world -> prediction-camera view, row-vector).  distance_th / smooth select the distance
+    factor (params.distance_factor_th: a number -> threshold factor; None -> sensor_distance_threshold(...), smooth=False;
+    'smooth' -> sensor_distance_threshold(...), smooth=True).  Returns gains [K] (and, with return_parts, the per-camera lists of
+    factored per-point gains [N] and sampled world points [N,4])."""
     K = cameras.shape[0]
     dev = X_world.device
     mask = ops.points_in_fov(X_world, cameras)                                            # :1603
     occ_k = ops.fov_mask_occ(mask, occ_probs.reshape(-1).contiguous())                    # :1606-1613 folded into the sampler
     gains = torch.zeros(K, dtype=torch.float32, device=dev)
+    parts_vis, parts_world = [], []
     for k in range(K):
         u = samples[k] if samples is not None else torch.rand(seq_len, device=dev)
         res, res_h, inv, uniq, vol = ops.sample_proxy(X_world, occ_k[k], proxy_view_harmonics, u.reshape(-1), min_occ,
                                                       return_volume=True)                 # :1624
         if res.shape[0] == 0:
+            parts_vis.append(None); parts_world.append(None)
             continue                                                                      # empty frustum: gain 0 (:1707-1736)
         world = res[inv].contiguous()                                                     # MC duplicates (:1668-1671)
         center_w = (res[:, :3].max(dim=0)[0] + res[:, :3].min(dim=0)[0]).view(1, 3) / 2.  # :1631-1633
@@ -64,8 +93,11 @@ def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harm
         vis = ops.sh_visibilities(pts[inv][None].contiguous(), harm[0][inv][None].contiguous(),
                                   cam4[:, :3].reshape(1, 1, 3).contiguous(), True)        # :1683  [1,1,N]
         g = ops.macarons_gain_(vis.view(1, -1), world[None], X_cam_world[k].view(1, 3).contiguous(),
-                               vol.float(), distance_th)                                  # :1699-1704
+                               vol.float(), distance_th, smooth)                          # :1699-1704
         gains[k] = g[0]
+        parts_vis.append(vis.view(-1)); parts_world.append(world)
+    if return_parts:
+        return gains, parts_vis, parts_world
     return gains
 
 
@@ -90,6 +122,32 @@ def compute_partial_point_cloud(depth, mask, camera, gathering_factor, fov_range
     n_points = int(len(world) * gathering_factor)
     idx = (torch.randperm(len(world)) if perm is None else perm)[:n_points]
     return world[idx.to(world.device)]
+
+
+def project_depth_back_to_3D(depth, cameras):
+    """utils.project_depth_back_to_3D (utils.py:1458-1487): depth [n_cam,H,W,1], cameras [n_cam,18] (depth_camera_record) ->
+    world points of the pixels with depth > -1, camera-major."""
+    n, H, W = depth.shape[0], depth.shape[1], depth.shape[2]
+    pts = ops.unproject_depth(depth.reshape(n, H, W).contiguous(), cameras.to(depth.device))
+    return pts[(depth > -1).view(n, -1)]
+
+
+def cell_fill(cell_pts, pts, x_min, x_max, resolution, capacity, n_point_min=0, perm=None):
+    """Cell.fill (macarons_utils.py:2551-2577) as a function of the cell state: strict bounding-box masks, fp64 admission test
+    against the points already in the cell (HIP kernel), append, then keep a random `capacity` subset (torch.randperm on the
+    CPU generator like the reference, or `perm`).  Returns the new cell points."""
+    mask = torch.max(pts - x_max.view(1, 3), dim=-1)[0] < 0.
+    add = pts[mask]
+    if add.shape[0] == 0:
+        return cell_pts
+    add = add[torch.min(add - x_min.view(1, 3), dim=-1)[0] > 0.]
+    if add.shape[0] <= n_point_min:
+        return cell_pts
+    if cell_pts.shape[0] > 0:
+        add = add[cell_fill_mask(add.contiguous(), cell_pts.contiguous(), resolution)]
+    out = torch.vstack((cell_pts, add))
+    idx = (torch.randperm(len(out)) if perm is None else perm)[:capacity]
+    return out[idx.to(out.device)]
 
 
 def cell_fill_mask(pts_to_add, cell_pts, resolution, a_offsets=None, b_offsets=None):

@@ -1,0 +1,138 @@
+"""HIP path vs goldens the REFERENCE's own functions produced for the MACARONS-regime rows:
+Camera.get_points_in_fov on a real Camera object, the three distance factors, predict_coverage_gain_for_single_camera,
+Cell.fill, depth unprojection and the Macarons wrapper (tests/golden/make_golden.py: gen_fov, gen_distance,
+gen_single_camera, gen_cell, gen_unproject, gen_macarons_wrapper).  Masks and kept point sets bit-exact, gains at 1e-4."""
+import os
+import sys
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_err
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import weights  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def _records(g, fov_range):
+    from macarons_amd.utility.macarons_utils import camera_record
+    return torch.stack([camera_record(g["Mview"][c], g["Mfull"][c], g["ndc"], g["center"][c], fov_range) for c in range(len(g["eyes"]))])
+
+
+def _models(dev):
+    from macarons_amd.networks import SconeVis, SconeOcc, Macarons
+    occ, vis = SconeOcc(), SconeVis()
+    sdo = weights.make_state_dict(weights.shapes_of(occ), 2)
+    sdv = weights.make_state_dict(weights.shapes_of(vis), 1)
+    sdo["linear3.bias"] = sdo["linear3.bias"] + np.float32(0.5)
+    occ.load_state_dict({k: torch.from_numpy(v) for k, v in sdo.items()})
+    vis.load_state_dict({k: torch.from_numpy(v) for k, v in sdv.items()})
+    return Macarons(None, occ, vis).to(dev).eval()
+
+
+def test_points_in_fov_matches_reference_camera(dev):
+    from macarons_amd import ops
+    g = golden("fov_camera")
+    n = len(g["pts"])
+    for tag, rg in (("r40", 40.0), ("none", None)):
+        mask = ops.points_in_fov(T(g["pts"], dev), _records(g, rg).to(dev)).cpu().numpy()
+        for c in range(len(g["eyes"])):
+            ref = np.unpackbits(g[f"mask_{c}_{tag}"])[:n].astype(bool)
+            assert np.array_equal(mask[c], ref), (tag, c)
+
+
+def test_distance_factors_match_reference(dev):
+    from macarons_amd.utility import macarons_utils as mu
+    g = golden("distance_factors")
+    params = NS(image_height=int(g["hw"][0]), image_width=int(g["hw"][1]))
+    fc = NS(fov=torch.tensor([float(g["fov"])]))
+    pts, cam, res = T(g["pts"], dev), T(g["cam"], dev), float(g["cell_resolution"])
+    assert rel_err(mu.get_distance_factor_threshold(pts, cam, 17.).cpu().numpy(), g["f_th"]) < 1e-6
+    assert rel_err(mu.get_distance_factor(params, pts, cam, fc, res).cpu().numpy(), g["f_plain"]) < 2e-6
+    assert rel_err(mu.get_distance_factor_smooth(params, pts, cam, fc, res).cpu().numpy(), g["f_smooth"]) < 2e-6
+
+
+def test_single_camera_gain_matches_reference(dev):
+    """predict_coverage_gain_for_cameras (all neighbour cameras in one call) vs predict_coverage_gain_for_single_camera of the
+    reference, camera by camera: gains 1e-4, identical sampled world points, the empty frustum scores 0."""
+    from macarons_amd.utility import macarons_utils as mu
+    g = golden("single_camera")
+    m = _models(dev)
+    P_ = len(g["X_world"])
+    vh = (g["vh_u"][:, None] * g["vh_v"][None, :] + g["vh_w"][np.arange(P_) % 16]).astype(np.float32)
+    recs = _records(g, float(g["sensor_range"])).to(dev)
+    u = torch.zeros(4, 2048, device=dev)
+    for c in range(3):
+        u[c] = T(g[f"u_{c}"], dev)
+    Mpred = T(np.repeat(g["Mpred"], 4, 0), dev)
+    args = (m.visibility, T(g["X_world"], dev), T(vh, dev), T(g["occ"], dev), recs, T(g["eyes"], dev), Mpred, float(g["box_diag"]))
+    gains, vis, world = mu.predict_coverage_gain_for_cameras(*args, samples=u, return_parts=True)
+    gains = gains.cpu().numpy()
+    for c in range(3):
+        ref = float(g[f"gain_{c}"].ravel()[0])
+        assert abs(gains[c] - ref) < 1e-4 * ref, (c, gains[c], ref)
+        assert np.array_equal(world[c].cpu().numpy(), g[f"world_{c}"][0])
+        assert np.abs(vis[c].cpu().numpy() - g[f"vis_{c}"][0, 0]).max() < 2e-3     # reference fp32 trig conditioning
+    assert gains[3] == 0.0 and float(g["gain_3"].ravel()[0]) == 0.0
+    # the two other distance-factor branches (:1686-1698)
+    params, fc = NS(image_height=256, image_width=456), NS(fov=torch.tensor([60.0]))
+    th = mu.sensor_distance_threshold(params, fc, 0.1)
+    for tag, smooth in (("plain", False), ("smooth", True)):
+        gk = mu.predict_coverage_gain_for_cameras(*[a[:1] if i in (4, 5, 6) else a for i, a in enumerate(args)], samples=u[:1],
+                                                  distance_th=th, smooth=smooth).cpu().numpy()
+        ref = float(g[f"gain_0_{tag}"].ravel()[0])
+        assert abs(gk[0] - ref) < 1e-4 * ref, (tag, gk[0], ref)
+
+
+def test_cell_fill_matches_reference(dev):
+    from macarons_amd.utility import macarons_utils as mu
+    g = golden("cell_fill")
+    x_min, x_max = T(g["center"] - g["lwh"] / 2, dev), T(g["center"] + g["lwh"] / 2, dev)
+    for i in range(3):
+        out = mu.cell_fill(T(g[f"before_{i}"], dev), T(g[f"pts_{i}"], dev), x_min, x_max, float(g["resolution"]), int(g["capacity"]),
+                           perm=torch.from_numpy(g[f"perm_{i}"].astype(np.int64)))
+        assert np.array_equal(out.cpu().numpy(), g[f"after_{i}"]), i
+
+
+def test_unproject_matches_reference(dev):
+    from macarons_amd.utility import macarons_utils as mu
+    g = golden("unproject")
+    cams = torch.stack([mu.depth_camera_record(g["Mfull"][c], float(g["P"][c, 2, 2]), float(g["P"][c, 3, 2])) for c in range(2)])
+    w = mu.project_depth_back_to_3D(T(g["depth"], dev), cams.to(dev)).cpu().numpy()
+    assert w.shape == g["world"].shape and rel_err(w, g["world"]) < 1e-5
+    H, W = int(g["H"]), int(g["W"])
+    mask = torch.from_numpy(np.unpackbits(g["mask"])[:H * W].astype(bool)).to(dev)
+    part = mu.compute_partial_point_cloud(T(g["d1"], dev), mask, cams[0], 0.25, fov_range=60.0,
+                                          perm=torch.from_numpy(g["perm"].astype(np.int64))).cpu().numpy()
+    assert part.shape == g["part"].shape and rel_err(part, g["part"]) < 1e-5
+
+
+def test_macarons_wrapper_matches_reference(dev):
+    """Macarons.forward(mode='occupancy' | 'visibility'), compute_visibility_gains and the NameError paths (Macarons.py:110-178)."""
+    g = golden("macarons_wrapper")
+    m = _models(dev)
+    torch.manual_seed(int(g["seed"]))                       # the hidden randperm draws of SconeOcc.forward come from the CPU generator
+    with torch.no_grad():
+        o = m(mode='occupancy', partial_point_cloud=T(g["pc"], dev), proxy_points=T(g["x"], dev), view_harmonics=T(g["vh"], dev))
+        h = m(mode='visibility', proxy_points=T(g["pts"], dev), view_harmonics=T(g["vh2"], dev))
+        v = m.compute_visibility_gains(pts=T(g["pts"], dev), harmonics=T(g["harm"], dev), X_cam=T(g["cams"], dev))
+    assert o.shape == g["occ"].shape and rel_err(o.cpu().numpy(), g["occ"]) < 1e-4
+    assert rel_err(h.cpu().numpy(), g["harm"]) < 1e-4
+    assert v.shape == g["gains64"].shape and np.abs(v.cpu().numpy() - g["gains64"]).max() < 2e-5
+    for mode, kw, key in (("occupancy", dict(proxy_points=T(g["x"], dev)), "err_occupancy"),
+                          ("visibility", dict(proxy_points=T(g["pts"], dev)), "err_visibility"), ("depth", {}, "err_depth"),
+                          ("bogus", {}, "err_bogus")):
+        with pytest.raises(NameError) as e:
+            m(mode=mode, **kw)
+        assert str(e.value) == str(g[key])
+    m.visibility.use_sigmoid = False
+    with pytest.raises(NameError):
+        m.compute_visibility_gains(pts=T(g["pts"], dev), harmonics=T(g["harm"], dev), X_cam=T(g["cams"], dev))

@@ -31,7 +31,36 @@ def _models(dev):
     return occ.to(dev).eval(), vis.to(dev).eval(), sdo, sdv
 
 
-def test_config1_end_to_end(dev):
+@pytest.mark.parametrize("name", ["e2e_grid_config1", "e2e_grid_config2"])
+def test_end_to_end_matches_reference_on_grid(dev, name):
+    """One whole NBV decision vs the golden the REFERENCE produced on 2^-10-grid clouds (config 1: M=1024, Q=2048, C=20;
+    config-2 shape: M=4096, Q=16384, C=100).  On the grid every squared distance is exact in fp32 in any formulation and the
+    golden inputs have no k / k+1 distance tie, so the reference's cdist + topk and the HIP kNN see the same neighbour sets
+    (SURVEY §7): occupancies, the sampled point set, its inverse map, the gains (1e-4) and the arg-max must all match."""
+    from macarons_amd.nbv import nbv_step, ViewStateGrid
+    g = golden(name)
+    occ, vis, sdo, sdv = _models(dev)
+    grid = ViewStateGrid(dev)
+    perms = [torch.from_numpy(g[f"perm{i}"].astype(np.int64)) for i in range(3)]
+    r = nbv_step(occ, vis, T(g["pc"], dev), T(g["X"], dev), T(g["X_view"], dev), T(g["X_cam"], dev), grid,
+                 occ_perms=perms, samples=T(g["samples"], dev), return_samples=True)
+    o = r["occ"].cpu().numpy()
+    assert np.abs(o - g["occ"]).max() < 1e-4 * np.abs(g["occ"]).max()
+    assert r["n_unique"] == int(g["n_unique"])
+    assert np.array_equal(r["proxy_points"].cpu().numpy()[:, :3], g["proxy"][:, :3])              # the same points were sampled
+    assert np.array_equal(r["sample_idx"].cpu().numpy(), g["sample_idx"])
+    assert rel_err(r["gains"].cpu().numpy(), g["gains"]) < 1e-4
+    assert int(r["nbv_idx"]) == int(g["nbv_idx"])
+    # hidden-RNG path: seeding torch like the reference run reproduces its randperm draws (CPU generator)
+    torch.manual_seed(int(g["seed"]))
+    r2 = nbv_step(occ, vis, T(g["pc"], dev), T(g["X"], dev), T(g["X_view"], dev), T(g["X_cam"], dev), grid, samples=T(g["samples"], dev))
+    assert np.array_equal(r2["occ"].cpu().numpy(), o) and int(r2["nbv_idx"]) == int(r["nbv_idx"])
+
+
+def test_config1_real_valued_vs_oracle(dev):
+    """Config 1 on REAL-valued clouds: the reference's cdist (|x|^2+|y|^2-2xy) breaks kNN near-ties differently there, so the
+    tight comparison is with the oracle (same conventions; itself pinned to the reference on the grid goldens); against the
+    reference golden the decision and all but a handful of occupancies must still agree."""
     from macarons_amd.nbv import nbv_step, ViewStateGrid
     g = golden("e2e_config1")
     occ, vis, sdo, sdv = _models(dev)
@@ -40,24 +69,13 @@ def test_config1_end_to_end(dev):
     r = nbv_step(occ, vis, T(g["pc"], dev), T(g["X"], dev), T(g["X_view"], dev), T(g["X_cam"], dev), grid,
                  occ_perms=perms, samples=T(g["samples"], dev))
     o = r["occ"].cpu().numpy()
-    # (a) vs the reference: occupancies within 1e-4 except queries whose 16th neighbour is a near-tie for
-    # torch.cdist's |x|^2+|y|^2-2xy distances -- at most a handful
     d = np.abs(o - g["occ"]).reshape(-1)
-    assert (d > 1e-4 * np.abs(g["occ"]).max()).sum() <= 3
-    assert int(r["nbv_idx"]) == int(g["nbv_idx"])
-    assert rel_err(r["gains"].cpu().numpy(), g["gains"]) < 2e-2          # sampling set shifts with those few points
-    # (b) vs the oracle with the same conventions: everything tight
+    assert (d > 1e-4 * np.abs(g["occ"]).max()).sum() <= 3 and int(r["nbv_idx"]) == int(g["nbv_idx"])
     ref = onbv.nbv_step(sdo, sdv, g["pc"], g["X"], g["X_view"], g["X_cam"], [g["perm0"], g["perm1"], g["perm2"]], g["samples"])
     assert rel_err(o, ref["occ"]) < 1e-4
     assert r["n_unique"] == ref["n_unique"]
     assert rel_err(r["gains"].cpu().numpy(), ref["gains"]) < 1e-4
     assert int(r["nbv_idx"]) == ref["nbv_idx"]
-    # hidden-RNG path: seeding torch like the reference run reproduces its draws (randperms on CPU, rand on device
-    # differs from the CPU stream, so pin only the uniforms)
-    torch.manual_seed(int(g["seed"]))
-    r2 = nbv_step(occ, vis, T(g["pc"], dev), T(g["X"], dev), T(g["X_view"], dev), T(g["X_cam"], dev), grid,
-                  samples=T(g["samples"], dev))
-    assert np.array_equal(r2["occ"].cpu().numpy(), o) and int(r2["nbv_idx"]) == int(r["nbv_idx"])
 
 
 def test_headline_step_runs_and_is_consistent(dev):
