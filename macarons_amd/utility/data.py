@@ -20,12 +20,18 @@ from collections import OrderedDict
 import torch
 
 
+def _load(path, device, trusted=False):
+    """torch.load restricted to tensors / plain containers (weights_only=True): every file of the reference's formats is a
+    dict / list of tensors and scalars.  trusted=True unpickles arbitrary objects (only for files you produced yourself)."""
+    return torch.load(path, map_location=device, weights_only=not trusted)
+
+
 def _tensors_dir(path):
     return os.path.join(os.path.dirname(path), "tensors")
 
 
 def get_gt_partial_point_clouds(path, device, normalization_factor=None):
-    pc_dict = torch.load(os.path.join(_tensors_dir(path), "partial_point_clouds.pt"), map_location=device, weights_only=False)
+    pc_dict = _load(os.path.join(_tensors_dir(path), "partial_point_clouds.pt"), device)
     part_pc = pc_dict['partial_point_cloud']
     coverage = torch.vstack(pc_dict['coverage'])
     if (normalization_factor is not None) and (normalization_factor != 1.):
@@ -35,17 +41,23 @@ def get_gt_partial_point_clouds(path, device, normalization_factor=None):
 
 
 def get_gt_occupancy_field(path, device):
-    pc_dict = torch.load(os.path.join(_tensors_dir(path), "occupancy_field.pt"), map_location=device, weights_only=False)
+    pc_dict = _load(os.path.join(_tensors_dir(path), "occupancy_field.pt"), device)
     return pc_dict['occupancy_field'][..., :3], pc_dict['occupancy_field'][..., 3:]
 
 
 def get_gt_surface(params, path, device, normalization_factor=None):
-    d = torch.load(os.path.join(_tensors_dir(path), "surface_points.pt"), map_location=device, weights_only=False)
+    d = _load(os.path.join(_tensors_dir(path), "surface_points.pt"), device)
     gt_surface = d['surface_points']
     eps = params.surface_epsilon if params.surface_epsilon_is_constant else d['epsilon']
     if (normalization_factor is not None) and (normalization_factor != 1.):
         gt_surface, eps = gt_surface * normalization_factor, eps * normalization_factor
     return gt_surface, eps
+
+
+def get_validation_optimal_sequences(path, device="cpu"):
+    """scone_utils.py:699-711: the dict {object id: {'idx': [10 camera ids], 'coverage': [10 tensors]}} of greedy-optimal view
+    sequences (data/ShapeNetCore.v1/validation_optimal_trajectories.pt in the reference tree; `path` = that file)."""
+    return _load(path, device)
 
 
 def get_optimal_sequence(optimal_sequences, mesh_path, n_views):
@@ -78,7 +90,7 @@ def strip_ddp_prefix(state_dict):
 def load_weights(model, trained_weights_file, ddp_model, device):
     """utils.py:161-185: checkpoint dict {'epoch','model_state_dict','optimizer_state_dict','loss',...}."""
     model = model.to(device)
-    checkpoint = torch.load(trained_weights_file, map_location=device, weights_only=False)
+    checkpoint = _load(trained_weights_file, device)
     sd = checkpoint['model_state_dict']
     model.load_state_dict(strip_ddp_prefix(sd) if ddp_model else sd)
     return model
@@ -87,7 +99,7 @@ def load_weights(model, trained_weights_file, ddp_model, device):
 def load_scone_from_macarons_checkpoint(occupancy_model, visibility_model, checkpoint_file, device):
     """pretrained_macarons.pth-style checkpoints nest {'depth': …, 'scone': {'occupancy.*', 'visibility.*'}}
     (Macarons.py:38-52, 85-104).  Loads the two SCONE modules, ignores the depth net (out of scope)."""
-    ck = torch.load(checkpoint_file, map_location=device, weights_only=False)
+    ck = _load(checkpoint_file, device)
     sd = ck['model_state_dict'] if 'model_state_dict' in ck else ck
     scone = strip_ddp_prefix(sd['scone'] if 'scone' in sd else sd)
     occupancy_model.load_state_dict(OrderedDict((k[len('occupancy.'):], v) for k, v in scone.items() if k.startswith('occupancy.')))
@@ -99,5 +111,22 @@ def load_scene(scene_dir, device="cpu"):
     """CustomDataset.py:313-362: a scene directory holds settings.json and occupied_pose.pt."""
     with open(os.path.join(scene_dir, "settings.json")) as f:
         settings = json.load(f)
-    pose = torch.load(os.path.join(scene_dir, "occupied_pose.pt"), map_location=device, weights_only=False)
+    pose = _load(os.path.join(scene_dir, "occupied_pose.pt"), device)
     return settings, pose['X_idx'], pose['occupied']
+
+
+def scene_item(data_path, scene_name, use_occupied_pose=True):
+    """SceneDataset.__getitem__ (CustomDataset.py:337-362): {'scene_name', 'obj_name', 'settings'[, 'occupied_pose']}; the mesh
+    name is the first *.obj in the directory, '<scene>.obj' if there is none."""
+    scene_path = os.path.join(data_path, scene_name)
+    obj_name = scene_name + '.obj'
+    for file_name in os.listdir(scene_path):
+        if file_name[-4:] == '.obj':
+            obj_name = file_name
+            break
+    with open(os.path.join(scene_path, 'settings.json'), "r") as f:
+        settings = json.load(f)
+    scene = {'scene_name': scene_name, 'obj_name': obj_name, 'settings': settings}
+    if use_occupied_pose:
+        scene['occupied_pose'] = _load(os.path.join(scene_path, 'occupied_pose.pt'), "cpu")
+    return scene

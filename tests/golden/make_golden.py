@@ -800,7 +800,49 @@ def gen_unproject():
          perm=perms[0].astype(np.int32), H=np.int64(H), W=np.int64(W))
 
 
-GROUPS = {"e2e_grid": gen_e2e_grid, "fov": gen_fov, "distance": gen_distance, "wrapper": gen_macarons_wrapper, "single_camera": gen_single_camera, "cell": gen_cell, "unproject": gen_unproject, "viewspace": gen_viewspace, "filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
+def gen_formats():
+    """On-disk formats read through the REFERENCE's own loaders from the files it ships:
+    get_validation_optimal_sequences + get_optimal_sequence (scone_utils.py:639-646, 699-711) on
+    data/ShapeNetCore.v1/validation_optimal_trajectories.pt, SceneDataset (CustomDataset.py:313-362) on data/scenes/liberty.
+    Committed: a 6-object slice of the trajectories file re-saved in the same pickle schema, the liberty scene directory's two
+    data files verbatim (data, 6.6 KB), and what the reference's loaders returned for them."""
+    import importlib
+    import json
+    import shutil
+    su = importlib.import_module("macarons.utility.scone_utils")
+    cd = importlib.import_module("macarons.utility.CustomDataset")
+    out_dir = os.path.join(HERE, "ref_data")
+    os.makedirs(os.path.join(out_dir, "scenes", "liberty"), exist_ok=True)
+    real_load = torch.load
+    torch.load = lambda *a, **kw: real_load(*a, **{**kw, "weights_only": False})       # reference predates the weights_only default
+    try:
+        seqs = su.get_validation_optimal_sequences(False, "cpu")
+        keys = sorted(seqs.keys())
+        sub = {k: seqs[k] for k in keys[:3] + keys[-3:]}
+        torch.save(sub, os.path.join(out_dir, "validation_optimal_trajectories_slice.pt"))
+        exp = {}
+        for k in sub:
+            idx, cov = su.get_optimal_sequence(seqs, f"/x/ShapeNetCore.v1/03001627/{k}/model.obj", 4)
+            exp[k] = {"idx": idx.tolist(), "coverage": [float(c) for c in cov]}
+        for f in ("settings.json", "occupied_pose.pt"):
+            shutil.copyfile(os.path.join(_ref_import.REFERENCE_ROOT, "data", "scenes", "liberty", f), os.path.join(out_dir, "scenes", "liberty", f))
+        ds = cd.SceneDataset(os.path.join(_ref_import.REFERENCE_ROOT, "data", "scenes"), scene_names=["liberty"])
+        item = ds[0]
+    finally:
+        torch.load = real_load
+    pose = item["occupied_pose"]
+    meta = {"n_objects_in_full_file": len(seqs), "keys": list(sub.keys()), "expected": exp,
+            "scene": {"scene_name": item["scene_name"], "obj_name": item["obj_name"], "settings": item["settings"],
+                      "X_idx_shape": list(pose["X_idx"].shape), "occupied_shape": list(pose["occupied"].shape),
+                      "X_idx_dtype": str(pose["X_idx"].dtype), "occupied_dtype": str(pose["occupied"].dtype),
+                      "n_occupied": int(torch.as_tensor(pose["occupied"]).sum()), "X_idx_first": torch.as_tensor(pose["X_idx"])[:5].tolist(),
+                      "X_idx_last": torch.as_tensor(pose["X_idx"])[-1].tolist()}}
+    with open(os.path.join(out_dir, "expected.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote", out_dir, os.path.getsize(os.path.join(out_dir, "validation_optimal_trajectories_slice.pt")), "bytes slice")
+
+
+GROUPS = {"formats": gen_formats, "e2e_grid": gen_e2e_grid, "fov": gen_fov, "distance": gen_distance, "wrapper": gen_macarons_wrapper, "single_camera": gen_single_camera, "cell": gen_cell, "unproject": gen_unproject, "viewspace": gen_viewspace, "filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

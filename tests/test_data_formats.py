@@ -58,3 +58,32 @@ def test_checkpoints_and_scene(tmp_path):
     torch.save({'X_idx': torch.zeros(4, 3), 'occupied': torch.ones(4)}, scene / "occupied_pose.pt")
     st, xi, oc = D.load_scene(str(scene))
     assert st["grid"]["l"] == 5 and xi.shape == (4, 3) and oc.shape == (4,)
+
+
+def test_reference_shipped_files():
+    """The files the reference itself ships (tests/golden/ref_data: a 6-object slice of
+    data/ShapeNetCore.v1/validation_optimal_trajectories.pt in its own pickle schema, and data/scenes/liberty verbatim) read
+    through macarons_amd.utility.data with weights_only=True give what the REFERENCE's loaders returned for them
+    (expected.json, written by tests/golden/make_golden.py: gen_formats from scone_utils.py:639-646,699-711 and
+    CustomDataset.py:313-362)."""
+    root = os.path.join(os.path.dirname(__file__), "golden", "ref_data")
+    exp = json.load(open(os.path.join(root, "expected.json")))
+    seqs = D.get_validation_optimal_sequences(os.path.join(root, "validation_optimal_trajectories_slice.pt"))
+    assert sorted(seqs.keys()) == sorted(exp["keys"]) and exp["n_objects_in_full_file"] == 399
+    for k, e in exp["expected"].items():
+        assert len(seqs[k]["idx"]) == 10 and len(seqs[k]["coverage"]) == 10
+        idx, cov = D.get_optimal_sequence(seqs, f"/any/where/03001627/{k}/model.obj", 4)
+        assert idx.dtype == torch.int64 and idx.tolist() == e["idx"] and [float(c) for c in cov] == e["coverage"]
+    item = D.scene_item(os.path.join(root, "scenes"), "liberty")
+    s = exp["scene"]
+    assert item["scene_name"] == s["scene_name"] and item["obj_name"] == s["obj_name"] and item["settings"] == s["settings"]
+    pose = item["occupied_pose"]
+    assert list(pose["X_idx"].shape) == s["X_idx_shape"] and list(pose["occupied"].shape) == s["occupied_shape"]
+    assert str(pose["X_idx"].dtype) == s["X_idx_dtype"] and str(pose["occupied"].dtype) == s["occupied_dtype"]
+    assert int(pose["occupied"].sum()) == s["n_occupied"] and pose["X_idx"][:5].tolist() == s["X_idx_first"]
+    assert pose["X_idx"][-1].tolist() == s["X_idx_last"]
+    st, xi, oc = D.load_scene(os.path.join(root, "scenes", "liberty"))
+    assert st == s["settings"] and torch.equal(xi, pose["X_idx"]) and torch.equal(oc, pose["occupied"])
+    # the pose lattice of settings.json matches the occupied-pose table: pose_l * pose_w * pose_h entries
+    cam = st["camera"]
+    assert xi.shape[0] == cam["pose_l"] * cam["pose_w"] * cam["pose_h"]
