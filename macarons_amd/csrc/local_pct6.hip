@@ -1,209 +1,230 @@
-// K5-local v6 (default) — the structure of local_pct5.hip (two workgroups per CU, residual stream in registers, LayerNorm
-// outputs pre-split in LDS, one n-tile column per wave) on a TWO-TERM FP16 SPLIT: three MFMAs per fp32 product instead of
-// six, and a split that costs ~3 instead of 5.5 vector instructions per element.
+// K5-local v6 (default) — fused per-query local PCTransformer of SconeOcc on a TWO-TERM FP16 SPLIT (three MFMAs per fp32
+// product), two workgroups per CU, every activation split exactly ONCE where it is produced.
+// Reference mapping (SconeOcc.py:104-130: Embedding -> 2 x Encoder -> LayerNorm -> linear0 -> max || avg pool) in local_pct.hip.
 //
 // Numerics.  Every fp32 operand x is carried as hi = fp16(x), lo = fp16(x - hi): 22 significant bits, |x - hi - lo| <=
-// max(2^-22 |x|, 2^-25).  A product a w is evaluated as a_lo w_hi + a_hi w_lo + a_hi w_hi on v_mfma_f32_32x32x16_f16
-// (fp16 x fp16 products are exact in the fp32 accumulator); the dropped a_lo w_lo term is <= 2^-22 |a w|.  Weights are
+// max(2^-22 |x|, 2^-25).  A product a w is evaluated as w_lo a_hi + w_hi a_lo + w_hi a_hi on v_mfma_f32_32x32x16_f16
+// (fp16 x fp16 products are exact in the fp32 accumulator); the dropped lo x lo term is <= 2^-22 |a w|.  Weights are
 // multiplied by a per-matrix power of two on the host (their low plane then stays a normal fp16 number) and the exact
-// inverse is applied in the epilogue FMA that adds the bias.  Measured against the fp64 oracle: see DESIGN.md / the
-// test test_fused_local_transformer[6].  Range: |activation| < 65504 (LayerNorm outputs are <= sqrt(128); variant 5
-// covers the whole fp32 range).
+// inverse is applied in the epilogue FMA that adds the bias.  Measured 5e-7 against the fp64 oracle
+// (tests/test_networks_gpu.py::test_fused_local_transformer[6]).  Range: |activation| < 65504 (LayerNorm outputs are
+// <= sqrt(128)); variant 5 (bf16 hi/mid/lo) covers the whole fp32 range.
 //
-// LDS = 64 KB, both tiles XOR-swizzled in 16-byte chunks by (row & 15):
-//           P  32 KB  x^ as planes [2][64 rows][16 chunks of 8 fp16], or q|k as fp32 [64][64] during attention
-//           F  32 KB  fp32 [64][128]: raw x for the LayerNorm / v and the attention output / a half of the FF hidden
-// Reference mapping in local_pct.hip (SconeOcc.py:104-130).
+// Structure.  A workgroup = 4 waves = 64 tokens (4 queries x 16 neighbours) x 128 channels, on chip from the xyz offsets to the
+// pooled feature.  All products are evaluated TRANSPOSED, D^T[n][token] = W[n][:] . act[token][:]: the weight fragment is the
+// MFMA A operand, the activation fragment the B operand (same register contents as the untransposed form, operands swapped),
+// so in the result a lane owns ONE token and 4 CONSECUTIVE features per register quad.  That makes every epilogue cheap:
+//   * activations that feed a product (LayerNorm outputs, GELU(FF1), attention output, GELU(emb1)) are split to fp16 hi/lo
+//     right there and stored as packed planes with one ds_write_b64 per 4 features and plane -- no wave ever splits an
+//     operand on the fly (in the first version of this kernel each of the 4 waves re-split every A row: 30 % of its vector
+//     instructions), and the products read ready-made fragments (2 x ds_read_b128 per 32 x 16 block);
+//   * the residual stream stays in registers; LayerNorm statistics come from those registers (per-wave mean / M2 over its 32
+//     features, combined across the 4 waves through 2 KB of LDS with Chan's formula: as accurate as two-pass), so x is never
+//     written to or re-read from LDS in fp32;
+//   * q | k | v go to LDS as fp32 with ds_write_b128; the 16-token attention runs on v_mfma_f32_16x16x4_f32 (exact fp32) with
+//     one wave per query, also transposed (O^T = V^T P^T), and writes its output planes over its own dead q | k rows.
+// One n-tile column per wave (no two waves request the same weight line); the first k-steps of the NEXT product's weights are
+// requested before the current product's epilogue.
+//
+// LDS = 66 KB:  P  32 KB  fp16 planes [2][64 rows][16 chunks of 8], or q|k as fp32 [64][64] in its first half
+//               H  32 KB  fp16 planes (FF hidden half / GELU(emb1)), or v as fp32 [64][128], or the final fp32 tile
+//               St  2 KB  LayerNorm partials [4 waves][64 tokens] (mean, M2)
+// 16-byte chunks are XOR-swizzled by (row & 15) in every view.
 #include "lp_split.h"
 
 namespace mcr {
 namespace v6 {
 
-// ---- swizzled addressing ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ int f_idx(int row, int col) { return row * 128 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); }
-__device__ __forceinline__ int f_chunk(int row, int chunk) { return row * 128 + ((chunk ^ (row & 15)) << 2); }     // float index of a float4
-__device__ __forceinline__ int q_idx(int row, int col) { return row * 64 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); }
-__device__ __forceinline__ int q_chunk(int row, int chunk) { return row * 64 + ((chunk ^ (row & 15)) << 2); }
-__device__ __forceinline__ int p_chunk(int plane, int row, int chunk) { return (plane * 64 + row) * 16 + (chunk ^ (row & 15)); }   // uint4 index
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // The swizzled addresses are loop-invariant functions of the lane; left alone, LLVM hoists all of them out of the encoder
-// loop and spills them (172 scratch stores).  Re-deriving them from an opaque copy of the lane id per phase is cheaper.
-__device__ __forceinline__ int l6_opaque(int v) {
+// loop and spills them.  Re-deriving them from an opaque copy of the lane id per phase is cheaper.
+__device__ __forceinline__ int opaque(int v) {
     asm volatile("" : "+v"(v));
     return v;
 }
 
-#ifndef L6_PF_N
-#define L6_PF_N 3
-#endif
-constexpr int L6_PF = L6_PF_N;                    // k16-steps of weights in flight per wave
+constexpr int PF = 3;                              // k16-steps of weights in flight per wave and tile
+struct WRing { uint4 b[PF][2]; };                  // [slot][plane hi, lo]
 
-// acc[u][mt] (+)= A[64 x 16 S] * W^T; wave owns n-tiles {nt0 + 4u} for both m-tiles (see local_pct4.hip).
-// PLANES: A comes pre-split from P (uint4 planes); else fp32 from F, split here.
-template <int S, int NTW, bool INIT, bool PLANES>
-__device__ __forceinline__ void l6_gemm(f32x16 (&acc)[NTW][2], const void* __restrict__ Asrc, const float* __restrict__ Wp,
-                                        int nt0, int lane_) {
-    const int lane = l6_opaque(lane_);
+__device__ __forceinline__ const uint4* wptr(const float* Wp, int nt, int S, int lane) {
+    return reinterpret_cast<const uint4*>(Wp) + (size_t)nt * S * 2 * 64 + lane;
+}
+// Request the first PF k-steps of a weight tile.  The sched_barrier pins the requests HERE (in front of the epilogue /
+// LayerNorm / barrier that precedes the product): left alone, LLVM sinks them down to their first use and every product
+// starts with an exposed L2 round trip.
+template <int S>
+__device__ __forceinline__ void wload(WRing& r, const uint4* bp) {
+#pragma unroll
+    for (int p = 0; p < (S < PF ? S : PF); ++p) {
+        r.b[p][0] = bp[(p * 2 + 0) * 64];
+        r.b[p][1] = bp[(p * 2 + 1) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Pin accumulator chains to this point of the program: the MFMA builtins are pure, so instruction selection is free to delay a
+// whole chain to its next use (it deferred one m-tile's 24 MFMAs of a product past the following product and two barriers,
+// spilling the fragments it had loaded for them).  An empty asm that "rewrites" the accumulators orders them like a fence.
+__device__ __forceinline__ void pin(f32x16& a, f32x16& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void pin(f32x16& a, f32x16& b, f32x16& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+
+__device__ __forceinline__ void zero(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// acc[mt] (+)= W(n-tile) . act^T for both 32-token m-tiles; act = fp16 planes A [2][64][16] in LDS; the ring holds the
+// first PF k-steps of the weight tile (wload) and is refilled here.
+template <int S>
+__device__ __forceinline__ void gemm(f32x16 (&acc)[2], const uint4* __restrict__ A, WRing& r, const uint4* __restrict__ bp,
+                                     int lane_) {
+    const int lane = opaque(lane_);
     const int i = lane & 31, h = lane >> 5, key = i & 15;
-    const uint4* bp[NTW];
-#pragma unroll
-    for (int u = 0; u < NTW; ++u) {
-        bp[u] = reinterpret_cast<const uint4*>(Wp) + (size_t)(nt0 + 4 * u) * S * 2 * 64 + lane;
-        if (INIT) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[u][mt][r] = 0.f;
-        }
-    }
-    constexpr int PF = S < L6_PF ? S : L6_PF;
-    uint4 b[PF][NTW][2];
-#pragma unroll
-    for (int p = 0; p < PF; ++p)
-#pragma unroll
-        for (int u = 0; u < NTW; ++u)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) b[p][u][pl] = bp[u][((p * 2 + pl) * 64)];
-    const float* F = reinterpret_cast<const float*>(Asrc);
-    const uint4* P = reinterpret_cast<const uint4*>(Asrc);
-    float4 ra[2][2];                                        // fp32 mode: raw A rows of the next step
-    Split2 sn[2];                                           // planes mode: fragments of the next step
-    auto fetch = [&](int s) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            if (PLANES) {
-                const int c = (2 * s + h) ^ key;
-                sn[mt].hi = P[(0 * 64 + mt * 32 + i) * 16 + c];
-                sn[mt].lo = P[(1 * 64 + mt * 32 + i) * 16 + c];
-            } else {
-                const float* row = F + (mt * 32 + i) * 128;
-                ra[mt][0] = *reinterpret_cast<const float4*>(row + (((4 * s + 2 * h) ^ key) << 2));
-                ra[mt][1] = *reinterpret_cast<const float4*>(row + (((4 * s + 2 * h + 1) ^ key) << 2));
-            }
-        }
-    };
-    fetch(0);
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        Split2 sa[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) sa[mt] = PLANES ? sn[mt] : split8h(ra[mt][0], ra[mt][1]);
-        if (s + 1 < S) fetch(s + 1);
-        uint4 bc[NTW][2];
-#pragma unroll
-        for (int u = 0; u < NTW; ++u)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) bc[u][pl] = b[s % PF][u][pl];
-        if (s + PF < S) {
-#pragma unroll
-            for (int u = 0; u < NTW; ++u)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) b[s % PF][u][pl] = bp[u][(((s + PF) * 2 + pl) * 64)];
-        }
-#pragma unroll
-        for (int u = 0; u < NTW; ++u)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                acc[u][mt] = mfma_h(sa[mt].lo, bc[u][0], acc[u][mt]);       // smallest terms first
-                acc[u][mt] = mfma_h(sa[mt].hi, bc[u][1], acc[u][mt]);
-                acc[u][mt] = mfma_h(sa[mt].hi, bc[u][0], acc[u][mt]);
-            }
-    }
-}
-
-// Write one 64 x 32 column block held as C fragments (t[0], t[1] = the two m-tiles; lane (j, h) owns column j and rows
-// mt*32 + (r&3) + 8(r>>2) + 4h) into a swizzled fp32 tile with row stride LD at column tile ct, through g(value).
-// row & 15 = Kc(r) | 4h with Kc(r) = (r&3) + 8((r>>2)&1), so the swizzle splits into a per-lane word w and a compile-time
-// XOR: one v_xor per element, the row part goes into the ds_write offset field.
-template <int LD, class G>
-__device__ __forceinline__ void l6_put(const f32x16 (&t)[2], float* buf, int ct, int lane_, G g) {
-    const int lane = l6_opaque(lane_);
-    const int j = lane & 31, h = lane >> 5;
-    const int w = ((((ct << 3) | (j >> 2)) ^ (h << 2)) << 2) | (j & 3) | (h * 4 * LD);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            buf[(mt * 32 + (r & 3) + 8 * (r >> 2)) * LD + (w ^ ((((r & 3) + 8 * ((r >> 2) & 1))) << 2))] = g((float)t[mt][r]);
-}
-
-// QKV product (N = 192 = 6 n-tiles over 4 waves), balanced: every wave takes its own n-tile w for both m-tiles plus HALF
-// of n-tile 4 + (w >> 1): the m-tile w & 1.  (Giving waves 0,1 two whole n-tiles and waves 2,3 one made this the longest
-// phase of an encoder: 4 tile-units of matrix work on the critical path instead of 3.)  The two waves sharing n-tile 4 or
-// 5 are not in lock-step on it -- one starts with its own tile's fragments in flight -- so their requests do not collide in
-// the L1.  A comes pre-split from P.
-__device__ __forceinline__ void l6_gemm_qkv(f32x16 (&acc)[1][2], f32x16& acch, const uint4* __restrict__ P,
-                                            const float* __restrict__ Wp, int wave, int lane_) {
-    constexpr int S = 8, PF = L6_PF;
-    const int lane = l6_opaque(lane_);
-    const int i = lane & 31, h = lane >> 5, key = i & 15, mh = wave & 1;
-    const uint4* bp[2] = {reinterpret_cast<const uint4*>(Wp) + (size_t)wave * S * 2 * 64 + lane,
-                          reinterpret_cast<const uint4*>(Wp) + (size_t)(4 + (wave >> 1)) * S * 2 * 64 + lane};
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acch[r] = 0.f; }
-    uint4 b[PF][2][2];
-#pragma unroll
-    for (int p = 0; p < PF; ++p)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) b[p][u][pl] = bp[u][((p * 2 + pl) * 64)];
-    Split2 sn[3];                                           // fragments of the next step: m-tile 0, m-tile 1, m-tile mh again
+    Split2 an[2];
     auto fetch = [&](int s) {
         const int c = (2 * s + h) ^ key;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            const int row = (f < 2 ? f : mh) * 32 + i;
-            sn[f].hi = P[(0 * 64 + row) * 16 + c];
-            sn[f].lo = P[(1 * 64 + row) * 16 + c];
+        for (int mt = 0; mt < 2; ++mt) {
+            an[mt].hi = A[(0 * 64 + mt * 32 + i) * 16 + c];
+            an[mt].lo = A[(1 * 64 + mt * 32 + i) * 16 + c];
+        }
+    };
+    fetch(0);
+    // software pipeline in program order, fenced: [next step's 4 fragment reads][the weight requests PF steps ahead] |
+    // [this step's 6 MFMAs].  Without the fences the scheduler sinks every ds_read next to its first use and each step waits
+    // out the LDS latency in front of its first MFMA.
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const Split2 a0 = an[0], a1 = an[1];
+        if (s + 1 < S) fetch(s + 1);
+        const uint4 whi = r.b[s % PF][0], wlo = r.b[s % PF][1];
+        if (s + PF < S) {
+            r.b[s % PF][0] = bp[((s + PF) * 2 + 0) * 64];
+            r.b[s % PF][1] = bp[((s + PF) * 2 + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = mfma_h(wlo, a0.hi, acc[0]);               // smallest terms first
+        acc[1] = mfma_h(wlo, a1.hi, acc[1]);
+        acc[0] = mfma_h(whi, a0.lo, acc[0]);
+        acc[1] = mfma_h(whi, a1.lo, acc[1]);
+        acc[0] = mfma_h(whi, a0.hi, acc[0]);
+        acc[1] = mfma_h(whi, a1.hi, acc[1]);
+        pin(acc[0], acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// QKV product (N = 192 = 6 n-tiles over 4 waves), balanced: every wave takes its own n-tile w for both m-tiles plus HALF of
+// n-tile 4 + (w >> 1): the m-tile w & 1.
+__device__ __forceinline__ void gemm_qkv(f32x16 (&acc)[2], f32x16& acch, const uint4* __restrict__ A, WRing& r0, WRing& r1,
+                                         const uint4* __restrict__ bp0, const uint4* __restrict__ bp1, int wave, int lane_) {
+    constexpr int S = 8;
+    const int lane = opaque(lane_);
+    const int i = lane & 31, h = lane >> 5, key = i & 15, mh = wave & 1;
+    Split2 an[2];
+    auto fetch = [&](int s) {
+        const int c = (2 * s + h) ^ key;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            an[mt].hi = A[(0 * 64 + mt * 32 + i) * 16 + c];
+            an[mt].lo = A[(1 * 64 + mt * 32 + i) * 16 + c];
         }
     };
     fetch(0);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        Split2 sa[3];
-#pragma unroll
-        for (int f = 0; f < 3; ++f) sa[f] = sn[f];
+        const Split2 a0 = an[0], a1 = an[1];
+        const Split2 ah = mh ? a1 : a0;
         if (s + 1 < S) fetch(s + 1);
-        uint4 bc[2][2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) bc[u][pl] = b[s % PF][u][pl];
+        const uint4 whi = r0.b[s % PF][0], wlo = r0.b[s % PF][1], vhi = r1.b[s % PF][0], vlo = r1.b[s % PF][1];
         if (s + PF < S) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) b[s % PF][u][pl] = bp[u][(((s + PF) * 2 + pl) * 64)];
+            r0.b[s % PF][0] = bp0[((s + PF) * 2 + 0) * 64];
+            r0.b[s % PF][1] = bp0[((s + PF) * 2 + 1) * 64];
+            r1.b[s % PF][0] = bp1[((s + PF) * 2 + 0) * 64];
+            r1.b[s % PF][1] = bp1[((s + PF) * 2 + 1) * 64];
         }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            acc[0][mt] = mfma_h(sa[mt].lo, bc[0][0], acc[0][mt]);
-            acc[0][mt] = mfma_h(sa[mt].hi, bc[0][1], acc[0][mt]);
-            acc[0][mt] = mfma_h(sa[mt].hi, bc[0][0], acc[0][mt]);
-        }
-        acch = mfma_h(sa[2].lo, bc[1][0], acch);
-        acch = mfma_h(sa[2].hi, bc[1][1], acch);
-        acch = mfma_h(sa[2].hi, bc[1][0], acch);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = mfma_h(wlo, a0.hi, acc[0]);
+        acc[1] = mfma_h(wlo, a1.hi, acc[1]);
+        acch = mfma_h(vlo, ah.hi, acch);
+        acc[0] = mfma_h(whi, a0.lo, acc[0]);
+        acc[1] = mfma_h(whi, a1.lo, acc[1]);
+        acch = mfma_h(vhi, ah.lo, acch);
+        acc[0] = mfma_h(whi, a0.hi, acc[0]);
+        acc[1] = mfma_h(whi, a1.hi, acc[1]);
+        acch = mfma_h(vhi, ah.hi, acch);
+        pin(acc[0], acc[1], acch);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// l6_put for ONE 32 x 32 C fragment: m-tile mt (wave-uniform) of column tile ct
-template <int LD, class G>
-__device__ __forceinline__ void l6_put_half(const f32x16& t, float* buf, int ct, int mt, int lane_, G g) {
-    const int lane = l6_opaque(lane_);
-    const int j = lane & 31, h = lane >> 5;
-    const int w = (((((ct << 3) | (j >> 2)) ^ (h << 2)) << 2) | (j & 3) | (h * 4 * LD)) + mt * 32 * LD;
+// ---- epilogue helpers: a C fragment t (n-tile nt, m-tile mt) holds, in lane (j, h), the features 32 nt + 8 g + 4 h + e
+// (register r = 4 g + e) of token 32 mt + j ----------------------------------------------------------------------------------
+// The accumulator of a product starts from its bias (times the matrix's power-of-two scale, folded on the host): the four
+// 16-byte loads land directly in the accumulator registers, the epilogue is a single multiply by 2^-e.  Products whose result
+// is added to the residual stream (out projection, FF2) accumulate IN PLACE: x <- x 2^e + b 2^e, the MFMAs add W' a on top,
+// x <- x 2^-e (power-of-two scalings are exact), so no second accumulator set is live next to the residual registers.
+__device__ __forceinline__ void scale_add_bias(f32x16& x, float scale, const float* __restrict__ vec, int nt, int lane_) {
+    const float4* p = reinterpret_cast<const float4*>(vec + 32 * nt + 4 * (opaque(lane_) >> 5));
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        buf[((r & 3) + 8 * (r >> 2)) * LD + (w ^ ((((r & 3) + 8 * ((r >> 2) & 1))) << 2))] = g((float)t[r]);
+    for (int g = 0; g < 4; ++g) {
+        const float4 b = p[2 * g];
+        x[4 * g] = fmaf(x[4 * g], scale, b.x); x[4 * g + 1] = fmaf(x[4 * g + 1], scale, b.y);
+        x[4 * g + 2] = fmaf(x[4 * g + 2], scale, b.z); x[4 * g + 3] = fmaf(x[4 * g + 3], scale, b.w);
+    }
+}
+__device__ __forceinline__ void init_bias(f32x16& a, const float* __restrict__ vec, int nt, int lane_) {
+    const float4* p = reinterpret_cast<const float4*>(vec + 32 * nt + 4 * (opaque(lane_) >> 5));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 b = p[2 * g];
+        a[4 * g] = b.x; a[4 * g + 1] = b.y; a[4 * g + 2] = b.z; a[4 * g + 3] = b.w;
+    }
 }
 
-// All-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) without the LDS crossbar: gfx950's
-// v_permlane16_swap / v_permlane32_swap exchange rows / halves between two registers; fed the same value twice they return
-// (this row pair's even row | odd row) resp. (lower half | upper half) replicated, so one op on the pair is the reduction.
+// store 4 consecutive features of one token as fp16 hi/lo: one ds_write_b64 per plane
+__device__ __forceinline__ void put4(uint2* __restrict__ planes, int idx, float v0, float v1, float v2, float v3) {
+    uint2 hi, lo;
+    split2h(v0, v1, hi.x, lo.x);
+    split2h(v2, v3, hi.y, lo.y);
+    planes[idx] = hi;
+    planes[idx + 64 * 16 * 2] = lo;
+}
+// planes[...] of one 32-feature column block (n-tile nt) for m-tile mt from t through f(value, g, e)
+template <class Fn>
+__device__ __forceinline__ void put_planes(uint4* __restrict__ buf, int nt, int mt, const f32x16& t, int lane_, Fn f) {
+    const int lane = opaque(lane_);
+    const int j = lane & 31, h = lane >> 5, key = j & 15;
+    uint2* b2 = reinterpret_cast<uint2*>(buf);
+    const int base = (mt * 32 + j) * 32 + h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        put4(b2, base + (((4 * nt + g) ^ key) << 1), f(t[4 * g], g, 0), f(t[4 * g + 1], g, 1), f(t[4 * g + 2], g, 2),
+             f(t[4 * g + 3], g, 3));
+        __builtin_amdgcn_sched_barrier(0);         // one quad at a time: interleaving all 32 GELUs of an epilogue spills
+    }
+}
+// fp32 tile with row stride LD floats: features (4 floats = one chunk) chunk0 + 2 g + h of token 32 mt + j, ds_write_b128
+template <class Fn>
+__device__ __forceinline__ void put_f32(float* __restrict__ buf, int LD, int chunk0, int mt, const f32x16& t, int lane_, Fn f) {
+    const int lane = opaque(lane_);
+    const int j = lane & 31, h = lane >> 5, key = j & 15;
+    float* row = buf + (mt * 32 + j) * LD;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(row + (((chunk0 + 2 * g + h) ^ key) << 2)) =
+            make_float4(f(t[4 * g], g, 0), f(t[4 * g + 1], g, 1), f(t[4 * g + 2], g, 2), f(t[4 * g + 3], g, 3));
+}
+
+// lanes l and l ^ 32 (the two halves of a token's 32 features in this wave): sum on both
+__device__ __forceinline__ float halves_sum(float v) {
+    const unsigned c = __builtin_bit_cast(unsigned, v);
+    const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+    return __builtin_bit_cast(float, (unsigned)q[0]) + __builtin_bit_cast(float, (unsigned)q[1]);
+}
 template <class Op>
-__device__ __forceinline__ float l6_rows_allreduce(float v, Op op) {
+__device__ __forceinline__ float rows_allreduce(float v, Op op) {           // over lanes l, l^16, l^32, l^48
     const unsigned b = __builtin_bit_cast(unsigned, v);
     const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
     v = op(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
@@ -212,37 +233,45 @@ __device__ __forceinline__ float l6_rows_allreduce(float v, Op op) {
     return op(__builtin_bit_cast(float, (unsigned)q[0]), __builtin_bit_cast(float, (unsigned)q[1]));
 }
 
-// LayerNorm (eps 1e-5, affine folded into the next weights) of the 64 rows of F, written as fp16 hi/lo planes into P:
-// 4 threads per row, 32 columns each; two-pass (mean, then centred variance) like torch's.
-__device__ __forceinline__ void l6_norm(const float* F, uint4* P, int tid_) {
-    const int tid = l6_opaque(tid_);
-    const int row = tid >> 2, part = tid & 3;
-    float v[32];
-    float sum = 0.f;
+// LayerNorm, part 1: this wave's (mean, M2) over its 32 features of every token -> St[wave][token]
+__device__ __forceinline__ void ln_partial(const f32x16 (&x)[2], float2* __restrict__ St, int wave, int lane_) {
+    const int lane = opaque(lane_);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float4 q = *reinterpret_cast<const float4*>(F + f_chunk(row, part * 8 + c));
-        v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
-        sum += (q.x + q.y) + (q.z + q.w);
+    for (int mt = 0; mt < 2; ++mt) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) s += (x[mt][r] + x[mt][r + 1]) + (x[mt][r + 2] + x[mt][r + 3]);
+        const float m = halves_sum(s) * (1.0f / 32.f);
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = x[mt][r] - m;
+            q = fmaf(d, d, q);
+        }
+        q = halves_sum(q);
+        St[wave * 64 + mt * 32 + (lane & 31)] = make_float2(m, q);      // both lane halves hold (and store) the same pair: no branch
     }
-    sum += dpp_mov0<0xB1>(sum);          // quad_perm [1,0,3,2]: the row's 4 threads are one quad (DPP, not an LDS bpermute)
-    sum += dpp_mov0<0x4E>(sum);          // quad_perm [2,3,0,1]
-    const float mu = sum * (1.0f / 128.f);
-    float sq = 0.f;
+}
+// part 2 (after a barrier): combine the 4 partials (Chan), normalise (eps 1e-5; gamma / beta are folded into the next
+// weights), split, store this wave's 32 features of every token as planes
+__device__ __forceinline__ void ln_finish(const f32x16 (&x)[2], const float2* __restrict__ St, uint4* __restrict__ P, int wave,
+                                          int lane_) {
+    const int j = opaque(lane_) & 31;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        v[c] -= mu;
-        sq = fmaf(v[c], v[c], sq);
-    }
-    sq += dpp_mov0<0xB1>(sq);
-    sq += dpp_mov0<0x4E>(sq);
-    const float rstd = 1.0f / sqrtf(sq * (1.0f / 128.f) + 1e-5f);
+    for (int mt = 0; mt < 2; ++mt) {
+        float2 p[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const Split2 s = split8h(make_float4(v[8 * c] * rstd, v[8 * c + 1] * rstd, v[8 * c + 2] * rstd, v[8 * c + 3] * rstd),
-                                make_float4(v[8 * c + 4] * rstd, v[8 * c + 5] * rstd, v[8 * c + 6] * rstd, v[8 * c + 7] * rstd));
-        P[p_chunk(0, row, part * 4 + c)] = s.hi;
-        P[p_chunk(1, row, part * 4 + c)] = s.lo;
+        for (int w = 0; w < 4; ++w) p[w] = St[w * 64 + mt * 32 + j];
+        const float mu = ((p[0].x + p[1].x) + (p[2].x + p[3].x)) * 0.25f;
+        float m2 = (p[0].y + p[1].y) + (p[2].y + p[3].y), dd = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float d = p[w].x - mu;
+            dd = fmaf(d, d, dd);
+        }
+        m2 = fmaf(32.f, dd, m2);
+        const float rstd = 1.0f / sqrtf(m2 * (1.0f / 128.f) + 1e-5f);
+        put_planes(P, wave, mt, x[mt], lane_, [&](float v, int, int) { return (v - mu) * rstd; });
     }
 }
 
@@ -251,91 +280,122 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
                                                           long long ld_feat, long long S,
                                                           const float* __restrict__ blob) {
     __shared__ __attribute__((aligned(16))) uint4 P[2 * 64 * 16];
-    __shared__ __attribute__((aligned(16))) float F[64 * 128];
-    float* Pq = reinterpret_cast<float*>(P);               // fp32 [64][64] view: q | k, and the raw xyz during the embedding
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) uint4 H[2 * 64 * 16];
+    __shared__ __attribute__((aligned(16))) float2 St[4 * 64];
+    float* Pq = reinterpret_cast<float*>(P);               // fp32 [64][64] view: q | k
+    float* F = reinterpret_cast<float*>(H);                // fp32 [64][128] view: v / the final tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably uniform: weight / bias addresses = SGPR base + lane offset
     const float* mats = blob;
     const float* vecs = blob + L6_MATS_TOTAL;
     const float* isc = vecs + L6_SCALES;                   // 2^-e of every matrix (the host stores W * 2^e)
     const long long s0 = (long long)blockIdx.x * L3_QPB;
 
-    // ---- stage the 64 x 3 offsets, zero-padded to K = 16, into F[:, 0:16]; a copy of xyz into Pq[:, 0:4] ----
-    if (tid < L3_T) {
-        const long long seq = s0 + (tid >> 4);
-        float x = 0.f, y = 0.f, z = 0.f;
-        if (seq < S) {
-            const float* p = offs + (seq * 16 + (tid & 15)) * 3;
-            x = p[0]; y = p[1]; z = p[2];
+    WRing ring;
+    f32x16 acc[2], xres[2];
+    // ---- Embedding (Attention.py:98-128): linear1 3->125 (K padded to 16), GELU -> H planes ; linear2 125->125 || xyz ----
+    wload<1>(ring, wptr(mats + l6_mat_off(0), wave, 1, lane));
+    init_bias(acc[0], vecs + L3_VEC_EMB1, wave, lane);
+    init_bias(acc[1], vecs + L3_VEC_EMB1, wave, lane);
+    float xyz[2][3];
+    {
+        const int j = lane & 31;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int t = mt * 32 + j;
+            const long long seq = s0 + (t >> 4);
+            xyz[mt][0] = xyz[mt][1] = xyz[mt][2] = 0.f;
+            if (seq < S) {
+                const float* p = offs + (seq * 16 + (t & 15)) * 3;
+                xyz[mt][0] = p[0]; xyz[mt][1] = p[1]; xyz[mt][2] = p[2];
+            }
         }
-        *reinterpret_cast<float4*>(F + f_chunk(tid, 0)) = make_float4(x, y, z, 0.f);
-        *reinterpret_cast<float4*>(F + f_chunk(tid, 1)) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(F + f_chunk(tid, 2)) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(F + f_chunk(tid, 3)) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(Pq + q_chunk(tid, 0)) = make_float4(x, y, z, 0.f);
+        // the activation fragment of the K = 16 step straight from registers: k = 0..2 = xyz in the lower lane half, zeros elsewhere
+        const bool lowh = lane < 32;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            Split2 a;
+            a.hi = make_uint4(0, 0, 0, 0); a.lo = make_uint4(0, 0, 0, 0);
+            split2h(lowh ? xyz[mt][0] : 0.f, lowh ? xyz[mt][1] : 0.f, a.hi.x, a.lo.x);
+            split2h(lowh ? xyz[mt][2] : 0.f, 0.f, a.hi.y, a.lo.y);
+            acc[mt] = mfma_h(ring.b[0][1], a.hi, acc[mt]);
+            acc[mt] = mfma_h(ring.b[0][0], a.lo, acc[mt]);
+            acc[mt] = mfma_h(ring.b[0][0], a.hi, acc[mt]);
+        }
     }
-    __syncthreads();
-    f32x16 acc[1][2], xres[1][2];
-    // ---- Embedding (Attention.py:98-128): linear1 3->125, GELU -> F ; linear2 125->125 || xyz -> xres ----
-    l6_gemm<1, 1, true, false>(acc, F, mats + l6_mat_off(0), wave, lane);
-    __syncthreads();                               // the offsets in F[:, 0:16] are consumed
+    wload<8>(ring, wptr(mats + l6_mat_off(1), wave, 8, lane));
     {
-        const float b = vecs[L3_VEC_EMB1 + wave * 32 + (lane & 31)];
         const float sc = isc[0];
-        l6_put<128>(acc[0], F, wave, lane, [&](float v) { return l3_gelu(fmaf(v, sc, b)); });
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            put_planes(H, wave, mt, acc[mt], lane, [&](float v, int, int) { return l3_gelu(v * sc); });
     }
+    init_bias(xres[0], vecs + L3_VEC_EMB2, wave, lane);
+    init_bias(xres[1], vecs + L3_VEC_EMB2, wave, lane);
     __syncthreads();
-    l6_gemm<8, 1, true, false>(xres, F, mats + l6_mat_off(1), wave, lane);
+    gemm<8>(xres, H, ring, wptr(mats + l6_mat_off(1), wave, 8, lane), lane);
     {
-        const int j = lane & 31, h = lane >> 5;
-        const float b = vecs[L3_VEC_EMB2 + wave * 32 + j], sc = isc[1];
+        const float sc = isc[1];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xres[0][mt][r] = fmaf(xres[0][mt][r], sc, b);
-        if (wave == 3 && j >= 29) {                // columns 125..127: concat the raw xyz (Attention.py:123-126)
+            for (int r = 0; r < 16; ++r) xres[mt][r] *= sc;
+        const bool cat = wave == 3 && lane >= 32;  // features 125..127 = the raw xyz (Attention.py:123-126): n-tile 3, g = 3, h = 1, e = 1..3
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xres[0][mt][r] = Pq[q_idx(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, j - 29)];
+        for (int mt = 0; mt < 2; ++mt) {
+            xres[mt][13] = cat ? xyz[mt][0] : xres[mt][13];
+            xres[mt][14] = cat ? xyz[mt][1] : xres[mt][14];
+            xres[mt][15] = cat ? xyz[mt][2] : xres[mt][15];
         }
     }
-    __syncthreads();                               // every wave is done reading F as the A operand
-    l6_put<128>(xres[0], F, wave, lane, [](float v) { return v; });
 
 #pragma unroll 1
     for (int e = 0; e < 2; ++e) {
-        const float* em = mats + l6_mat_off(2 + 6 * e);
+        const float* em = mats + l6_mat_off(2) + e * (L6_MAT_QKV + 5 * L6_MAT_128);
         const float* ev = vecs + L3_VEC_ENC0 + e * L3_VEC_ENC_STRIDE;
-        const float* es = isc + 2 + 6 * e;          // qkv, out, ff1a, ff1b, ff2a (= ff2b)
-        // ---- norm1 (folded) -> planes ; QKV (Attention.py:186-188, 287): q|k -> Pq, v -> F ----
-        // 6 n-tiles over 4 waves: one each plus half of n-tile 4 or 5 (l6_gemm_qkv).
-        __syncthreads();
-        l6_norm(F, P, tid);
-        __syncthreads();
+        const float* es = isc + 2 + 6 * e;          // 2^-e of qkv, out, ff1a, ff1b, ff2a (= ff2b); the forward scales 2^e sit 16 floats later
+        const float* w_out = em + L6_MAT_QKV;
+        const float* w_ff1a = w_out + L6_MAT_128;
+        const float* w_ff1b = w_out + L6_MAT_128 * 2;
+        const float* w_ff2a = w_out + L6_MAT_128 * 3;
+        const float* w_ff2b = w_out + L6_MAT_128 * 4;
+        // ---- norm1 (folded) -> planes P ; QKV (Attention.py:186-188, 287): q|k -> Pq, v -> F ----
+        WRing ring1;
+        const uint4* bq0 = wptr(em, wave, 8, lane);
+        const uint4* bq1 = wptr(em, 4 + (wave >> 1), 8, lane);
+        wload<8>(ring, bq0);
+        wload<8>(ring1, bq1);
+        ln_partial(xres, St, wave, lane);
+        __syncthreads();                           // St visible; every wave is past its last read of P and H
+        ln_finish(xres, St, P, wave, lane);
+        __syncthreads();                           // x^ planes visible
         {
-            f32x16 aq[1][2], ah;
-            l6_gemm_qkv(aq, ah, P, em, wave, lane);
-            __syncthreads();                       // x^ planes consumed: P may take q|k (F's raw x died with the norm)
-            // n-tiles 0,1 = q,k -> Pq column tiles 0,1; n-tiles 2..5 = v -> F column tiles 0..3
-            {
-                const float b0 = ev[wave * 32 + (lane & 31)], sc = es[0];
-                if (wave < 2) l6_put<64>(aq[0], Pq, wave, lane, [&](float v) { return fmaf(v, sc, b0); });
-                else l6_put<128>(aq[0], F, wave - 2, lane, [&](float v) { return fmaf(v, sc, b0); });
-                const int nth = 4 + (wave >> 1);
-                const float b1 = ev[nth * 32 + (lane & 31)];
-                l6_put_half<128>(ah, F, nth - 2, wave & 1, lane, [&](float v) { return fmaf(v, sc, b1); });
-            }
+            f32x16 aq[2], ah;
+            const int nth = 4 + (wave >> 1);
+            init_bias(aq[0], ev, wave, lane);
+            init_bias(aq[1], ev, wave, lane);
+            init_bias(ah, ev, nth, lane);
+            gemm_qkv(aq, ah, P, ring, ring1, bq0, bq1, wave, lane);
+            wload<8>(ring, wptr(w_out, wave, 8, lane));
+            const float sc = es[0];
+            __syncthreads();                       // x^ planes consumed: P may take q|k
+            // n-tiles 0,1 = q,k -> Pq chunks 0..7 / 8..15; n-tiles 2..5 = v -> F chunks 8 (nt - 2) ..
+            auto fb = [&](float v, int, int) { return v * sc; };
+            float* dst = wave < 2 ? Pq : F;         // branch-free: the whole encoder stays one basic block
+            const int ld = wave < 2 ? 64 : 128, c0 = wave < 2 ? 8 * wave : 8 * (wave - 2);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) put_f32(dst, ld, c0, mt, aq[mt], lane, fb);
+            put_f32(F, 128, 8 * (nth - 2), wave & 1, ah, lane, fb);
         }
         __syncthreads();
         // ---- attention (Attention.py:8-36) on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32 = exact fp32 fma chains):
-        // wave = query (16 tokens); per head  S^T = K Q^T (j rows, query rows qi as columns: lane (qi, g) then owns
-        // S[qi][4g..4g+3]), softmax over j = 4 registers x the 4 lane groups, O = P V with the k index j = 4g + s so the
-        // probabilities are used as the A operand straight from their registers.  The output overwrites the head's V block.
+        // wave = query (16 tokens); per head  S^T = K Q^T (key rows, query columns: lane (qi, g) then owns S[qi][4g..4g+3]),
+        // softmax over the keys = 4 registers x the 4 lane groups, O^T = V^T P^T with the key index j = 4g + s: lane (qi, g)
+        // ends up with the features 4g..4g+3 of every 16-feature block of its token -> fp16 planes, written over the wave's
+        // own q | k rows (plane 0) and the free second half of P (plane 1).
         {
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const int ln = l6_opaque(lane);
+            const int ln = opaque(lane);
             const int r0 = wave * 16, li = ln & 15, g = ln >> 4;
-            // swizzled addresses as one per-lane word XOR a compile-time constant (row & 15 = li for q|k, 4g + s for v):
             const int wq = ((r0 + li) * 64) | (li << 2) | g;                                   // Pq[row = r0+li][chunk c][g]   = wq ^ (c << 2)
             const int wv = ((r0 + 4 * g) * 128) | ((((li >> 2) | (g << 2)) << 2)) | (li & 3);    // F[row = r0+4g+s][chunk C][li&3] = s*128 + (wv ^ ((C ^ s) << 2))
             f32x4 pr[4];
@@ -349,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
                     st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk, qq, st, 0, 0, 0);
                 }
                 float mx = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
-                mx = l6_rows_allreduce(mx, [](float a, float b) { return fmaxf(a, b); });
+                mx = rows_allreduce(mx, [](float a, float b) { return fmaxf(a, b); });
                 mx *= 0.35355339059327376220f;                                           // scores / sqrt(8)
                 float den = 0.f;
 #pragma unroll
@@ -357,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
                     st[r] = __expf(fmaf(st[r], 0.35355339059327376220f, -mx));
                     den += st[r];
                 }
-                den = l6_rows_allreduce(den, [](float a, float b) { return a + b; });
+                den = rows_allreduce(den, [](float a, float b) { return a + b; });
                 const float inv = __builtin_amdgcn_rcpf(den);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pr[hh][r] = st[r] * inv;
@@ -370,73 +430,88 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
                     o[hh][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int sk = 0; sk < 4; ++sk) {
-                        const float vv = F[sk * 128 + (wv ^ (((hh * 8 + nt * 4) ^ sk) << 2))];   // B[k = g][n = c] = V[j = 4g + sk][hh*32 + nt*16 + li]
-                        o[hh][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[hh][sk], vv, o[hh][nt], 0, 0, 0);
+                        const float vv = F[sk * 128 + (wv ^ (((hh * 8 + nt * 4) ^ sk) << 2))];   // A[i = c][k = g] = V[j = 4g + sk][hh*32 + nt*16 + c]
+                        o[hh][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pr[hh][sk], o[hh][nt], 0, 0, 0);
                     }
                 }
-            // every V read of this wave's 16 rows precedes the writes (other waves own other rows)
+            // every q | k read of this wave's 16 rows precedes the plane writes over them (other waves own other rows)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            uint2* p2 = reinterpret_cast<uint2*>(P);
+            const int base = (r0 + li) * 32 + (g & 1);
 #pragma unroll
             for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) F[r * 128 + (wv ^ (((hh * 8 + nt * 4) ^ r) << 2))] = o[hh][nt][r];
+                    put4(p2, base + (((4 * hh + 2 * nt + (g >> 1)) ^ li) << 1), o[hh][nt][0], o[hh][nt][1], o[hh][nt][2], o[hh][nt][3]);
         }
+        // ---- out projection + residual (Attention.py:201-202, 290): x += att W_o^T + b, accumulated in place ----
+        scale_add_bias(xres[0], es[16 + 1], ev + 192, wave, lane);
+        scale_add_bias(xres[1], es[16 + 1], ev + 192, wave, lane);
         __syncthreads();
-        // ---- out projection + residual (Attention.py:201-202, 290): x += att W_o^T + b ----
-        l6_gemm<8, 1, true, false>(acc, F, em + L6_MAT_QKV, wave, lane);
+        gemm<8>(xres, P, ring, wptr(w_out, wave, 8, lane), lane);
+        wload<8>(ring, wptr(w_ff1a, wave, 8, lane));
         {
-            const float b = ev[192 + wave * 32 + (lane & 31)], sc = es[1];
+            const float sc = es[1];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xres[0][mt][r] += fmaf(acc[0][mt][r], sc, b);
+                for (int r = 0; r < 16; ++r) xres[mt][r] *= sc;
         }
-        __syncthreads();                           // the attention output in F is consumed
-        l6_put<128>(xres[0], F, wave, lane, [](float v) { return v; });
+        // ---- norm2 (folded) -> planes P ; FF 128 -> 256 (GELU) -> 128 + residual (Attention.py:293-298), two halves ----
+        ln_partial(xres, St, wave, lane);
+        init_bias(acc[0], ev + 192 + 128, wave, lane);
+        init_bias(acc[1], ev + 192 + 128, wave, lane);
+        __syncthreads();                           // St visible; the attention output in P is consumed by every wave
+        ln_finish(xres, St, P, wave, lane);
         __syncthreads();
-        // ---- norm2 (folded) -> planes ; FF 128 -> 256 (GELU) -> 128 + residual (Attention.py:293-298), two halves ----
-        l6_norm(F, P, tid);
-        __syncthreads();
-        f32x16 accf[1][2];
-        const float* w_ff1a = em + L6_MAT_QKV + L6_MAT_128 * 1;
-        const float* w_ff1b = em + L6_MAT_QKV + L6_MAT_128 * 2;
-        const float* w_ff2a = em + L6_MAT_QKV + L6_MAT_128 * 3;
-        const float* w_ff2b = em + L6_MAT_QKV + L6_MAT_128 * 4;
-        l6_gemm<8, 1, true, true>(acc, P, w_ff1a, wave, lane);
+        gemm<8>(acc, P, ring, wptr(w_ff1a, wave, 8, lane), lane);
+        wload<8>(ring, wptr(w_ff2a, wave, 8, lane));
         {
-            const float b = ev[192 + 128 + wave * 32 + (lane & 31)], sc = es[2];
-            l6_put<128>(acc[0], F, wave, lane, [&](float v) { return l3_gelu(fmaf(v, sc, b)); });
+            const float sc = es[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                put_planes(H, wave, mt, acc[mt], lane, [&](float v, int, int) { return l3_gelu(v * sc); });
+        }
+        scale_add_bias(xres[0], es[16 + 4], ev + 192 + 128 + 256, wave, lane);   // FF2 accumulates onto the residual in place
+        scale_add_bias(xres[1], es[16 + 4], ev + 192 + 128 + 256, wave, lane);
+        __syncthreads();                           // first hidden half visible
+        gemm<8>(xres, H, ring, wptr(w_ff2a, wave, 8, lane), lane);
+        wload<8>(ring, wptr(w_ff1b, wave, 8, lane));
+        init_bias(acc[0], ev + 192 + 128 + 128, wave, lane);
+        init_bias(acc[1], ev + 192 + 128 + 128, wave, lane);
+        gemm<8>(acc, P, ring, wptr(w_ff1b, wave, 8, lane), lane);                // reads P only: no barrier needed before it
+        wload<8>(ring, wptr(w_ff2b, wave, 8, lane));
+        __syncthreads();                           // the first hidden half in H is consumed
+        {
+            const float sc = es[3];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                put_planes(H, wave, mt, acc[mt], lane, [&](float v, int, int) { return l3_gelu(v * sc); });
         }
         __syncthreads();
-        l6_gemm<8, 1, true, false>(accf, F, w_ff2a, wave, lane);
-        l6_gemm<8, 1, true, true>(acc, P, w_ff1b, wave, lane);          // reads P only: no barrier needed before it
-        __syncthreads();                           // the first hidden half in F is consumed
+        gemm<8>(xres, H, ring, wptr(w_ff2b, wave, 8, lane), lane);
         {
-            const float b = ev[192 + 128 + 128 + wave * 32 + (lane & 31)], sc = es[3];
-            l6_put<128>(acc[0], F, wave, lane, [&](float v) { return l3_gelu(fmaf(v, sc, b)); });
-        }
-        __syncthreads();
-        l6_gemm<8, 1, false, false>(accf, F, w_ff2b, wave, lane);
-        {
-            const float b = ev[192 + 128 + 256 + wave * 32 + (lane & 31)], sc = es[4];    // ff2a and ff2b share one exponent
+            const float sc = es[4];                 // ff2a and ff2b share one exponent
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xres[0][mt][r] += fmaf(accf[0][mt][r], sc, b);
+                for (int r = 0; r < 16; ++r) xres[mt][r] *= sc;
         }
-        __syncthreads();                           // the second hidden half in F is consumed
-        l6_put<128>(xres[0], F, wave, lane, [](float v) { return v; });
     }
     // ---- final norm (folded) + linear0 128 -> 128 (SconeOcc.py:119-122) ----
+    wload<8>(ring, wptr(mats + l6_mat_off(14), wave, 8, lane));
+    ln_partial(xres, St, wave, lane);
+    init_bias(acc[0], vecs + L3_VEC_LIN0, wave, lane);
+    init_bias(acc[1], vecs + L3_VEC_LIN0, wave, lane);
     __syncthreads();
-    l6_norm(F, P, tid);
+    ln_finish(xres, St, P, wave, lane);
     __syncthreads();
-    l6_gemm<8, 1, true, true>(acc, P, mats + l6_mat_off(14), wave, lane);
+    gemm<8>(acc, P, ring, wptr(mats + l6_mat_off(14), wave, 8, lane), lane);
     {
-        const float b = vecs[L3_VEC_LIN0 + wave * 32 + (lane & 31)], sc = isc[14];
-        l6_put<128>(acc[0], F, wave, lane, [&](float v) { return fmaf(v, sc, b); });
+        const float sc = isc[14];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            put_f32(F, 128, 8 * wave, mt, acc[mt], lane, [&](float v, int, int) { return v * sc; });
     }
     __syncthreads();
     // ---- max || avg pool over the 16 tokens of each query (SconeOcc.py:124-126) ----
@@ -447,7 +522,8 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
             float mx = -__builtin_inff(), sm = 0.f;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float v = F[f_idx(q * 16 + j, c)];
+                const int row = q * 16 + j;
+                const float v = F[row * 128 + ((((c >> 2) ^ (row & 15)) << 2) | (c & 3))];
                 mx = fmaxf(mx, v);
                 sm += v;
             }

@@ -31,7 +31,8 @@ constexpr int L3_BLOB_FLOATS = L3_MATS_TOTAL + L3_VECS_TOTAL;
 
 // ---- blob of variant 6: matrices as [n-tile][k16 step][plane hi,lo][lane][8 fp16] (1 float per weight), every matrix
 // multiplied by a power of two 2^e_i on the host so that its fp16 low plane stays in the normal range; then the same
-// vectors; then 16 floats: 2^-e_i for the 15 matrices (applied in the epilogues) + one pad
+// vectors (every bias times its matrix's 2^e_i); then 16 floats: 2^-e_i for the 15 matrices (applied in the epilogues) + one
+// pad; then 16 floats: 2^e_i (products accumulated onto the residual stream scale it up first)
 constexpr int L6_MAT_K16 = 128 * 16, L6_MAT_128 = 128 * 128, L6_MAT_QKV = 192 * 128;
 __host__ __device__ constexpr int l6_mat_off(int idx) {
     int off = 0;
@@ -43,7 +44,7 @@ __host__ __device__ constexpr int l6_mat_off(int idx) {
 }
 constexpr int L6_MATS_TOTAL = l6_mat_off(15);
 constexpr int L6_SCALES = L3_VECS_TOTAL;                      // offset of the 16 inverse scales inside the vector section
-constexpr int L6_BLOB_FLOATS = L6_MATS_TOTAL + L3_VECS_TOTAL + 16;
+constexpr int L6_BLOB_FLOATS = L6_MATS_TOTAL + L3_VECS_TOTAL + 32;
 
 __device__ __forceinline__ float l3_gelu(float x) {           // exact-erf GELU, erf by Abramowitz-Stegun 7.1.26
     const float z = fabsf(x) * 0.70710678118654752440f;

@@ -169,29 +169,34 @@ def _pack_local_pct6(pct):
             for W in Ws:
                 mats.append(_pack_f16x2(W.contiguous(), sc))
                 inv.append(1.0 / sc)
+            return sc
+        # every bias is stored multiplied by its matrix's scale: the kernel starts the accumulator from it
         emb = pct.embedding
-        add(_pad(f(emb.linear1.weight), 128, 16))
-        add(_pad(f(emb.linear2.weight), 128, 128))
-        vecs += [_padv(f(emb.linear1.bias), 128), _padv(f(emb.linear2.bias), 128)]
+        s1 = add(_pad(f(emb.linear1.weight), 128, 16))
+        s2 = add(_pad(f(emb.linear2.weight), 128, 128))
+        vecs += [_padv(f(emb.linear1.bias), 128) * s1, _padv(f(emb.linear2.bias), 128) * s2]
         for enc in pct.encoders:
             g1, b1 = f(enc.norm1.weight), f(enc.norm1.bias)
             g2, b2 = f(enc.norm2.weight), f(enc.norm2.bias)
             wqkv = torch.cat((f(enc.mhsa.w_q.weight), f(enc.mhsa.w_k.weight), f(enc.mhsa.w_v.weight)), 0)
             bqkv = torch.cat((f(enc.mhsa.w_q.bias), f(enc.mhsa.w_k.bias), f(enc.mhsa.w_v.bias)), 0)
             w1, w2 = f(enc.ff.linear1.weight), f(enc.ff.linear2.weight)
-            add(wqkv * g1[None, :])
-            add(f(enc.mhsa.out.weight))
-            add((w1 * g2[None, :])[:128])
-            add((w1 * g2[None, :])[128:])
-            add(w2[:, :128], w2[:, 128:])                  # one exponent: both halves accumulate into the same registers
-            vecs += [bqkv + wqkv @ b1, f(enc.mhsa.out.bias), f(enc.ff.linear1.bias) + w1 @ b2, f(enc.ff.linear2.bias)]
+            sq = add(wqkv * g1[None, :])
+            so = add(f(enc.mhsa.out.weight))
+            sa = add((w1 * g2[None, :])[:128])
+            sb = add((w1 * g2[None, :])[128:])
+            s2_ = add(w2[:, :128], w2[:, 128:])            # one exponent: both halves accumulate into the same registers
+            c1 = f(enc.ff.linear1.bias) + w1 @ b2
+            vecs += [(bqkv + wqkv @ b1) * sq, f(enc.mhsa.out.bias) * so, torch.cat((c1[:128] * sa, c1[128:] * sb)),
+                     f(enc.ff.linear2.bias) * s2_]
         gn, bn = f(pct.norm.weight), f(pct.norm.bias)
         w0 = f(pct.linear0.weight)
-        add(w0 * gn[None, :])
-        vecs.append(f(pct.linear0.bias) + w0 @ bn)
+        s0 = add(w0 * gn[None, :])
+        vecs.append((f(pct.linear0.bias) + w0 @ bn) * s0)
         assert len(inv) == 15
         dev = mats[0].device
-        blob = torch.cat(mats + vecs + [torch.tensor(inv + [0.0], dtype=torch.float32, device=dev)]).contiguous()
+        fwd = [1.0 / v for v in inv]
+        blob = torch.cat(mats + vecs + [torch.tensor(inv + [0.0] + fwd + [0.0], dtype=torch.float32, device=dev)]).contiguous()
     expect = _lib.lib().mcr_local_pct6_blob_floats()
     if blob.numel() != expect:
         raise RuntimeError(f"packed local transformer (v6) has {blob.numel()} floats, kernel expects {expect}")
