@@ -275,6 +275,13 @@ __device__ __forceinline__ void ln_finish(const f32x16 (&x)[2], const float2* __
     }
 }
 
+#ifdef L6_TRACE             // dev only: per-phase timestamps of one workgroup (tools/build_variant.py ... -DL6_TRACE=<block>)
+__device__ long long l6_trace_buf[64];
+#define L6_T() do { if (blockIdx.x == (L6_TRACE) && tid == 0) l6_trace_buf[tp] = clock64(); ++tp; } while (0)
+#else
+#define L6_T() do { } while (0)
+#endif
+
 // grid = ceil(S / 4); S sequences of 16 offsets [S,16,3]; features[s*ld_feat + 0:256] = max(128) || avg(128)
 __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restrict__ offs, float* __restrict__ feat,
                                                           long long ld_feat, long long S,
@@ -284,13 +291,18 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
     __shared__ __attribute__((aligned(16))) float2 St[4 * 64];
     float* Pq = reinterpret_cast<float*>(P);               // fp32 [64][64] view: q | k
     float* F = reinterpret_cast<float*>(H);                // fp32 [64][128] view: v / the final tile
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane0 = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably uniform: weight / bias addresses = SGPR base + lane offset
     const float* mats = blob;
     const float* vecs = blob + L6_MATS_TOTAL;
     const float* isc = vecs + L6_SCALES;                   // 2^-e of every matrix (the host stores W * 2^e)
+    // One workgroup per 4-query group, NOT persistent: persistent workgroups (2 per CU, looping over groups with the next group's
+    // offsets prefetched) measured 5 % slower -- the two co-resident workgroups then run in lock-step and collide in the same
+    // phase (both on the matrix pipe, then both on the vector ALU); fresh workgroups start staggered and overlap better.
     const long long s0 = (long long)blockIdx.x * L3_QPB;
-
+    const int lane = lane0;
+    int tp = 0; (void)tp;
+    L6_T();
     WRing ring;
     f32x16 acc[2], xres[2];
     // ---- Embedding (Attention.py:98-128): linear1 3->125 (K padded to 16), GELU -> H planes ; linear2 125->125 || xyz ----
@@ -323,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
             acc[mt] = mfma_h(ring.b[0][0], a.hi, acc[mt]);
         }
     }
+    L6_T();                                        // emb1 product done
     wload<8>(ring, wptr(mats + l6_mat_off(1), wave, 8, lane));
     {
         const float sc = isc[0];
@@ -333,7 +346,9 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
     init_bias(xres[0], vecs + L3_VEC_EMB2, wave, lane);
     init_bias(xres[1], vecs + L3_VEC_EMB2, wave, lane);
     __syncthreads();
+    L6_T();                                        // emb1 gelu + barrier
     gemm<8>(xres, H, ring, wptr(mats + l6_mat_off(1), wave, 8, lane), lane);
+    L6_T();                                        // emb2 gemm
     {
         const float sc = isc[1];
 #pragma unroll
@@ -365,10 +380,13 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
         const uint4* bq1 = wptr(em, 4 + (wave >> 1), 8, lane);
         wload<8>(ring, bq0);
         wload<8>(ring1, bq1);
+        L6_T();                                    // (previous epilogue)
         ln_partial(xres, St, wave, lane);
         __syncthreads();                           // St visible; every wave is past its last read of P and H
+        L6_T();                                    // norm1 partial + barrier
         ln_finish(xres, St, P, wave, lane);
         __syncthreads();                           // x^ planes visible
+        L6_T();                                    // norm1 finish + barrier
         {
             f32x16 aq[2], ah;
             const int nth = 4 + (wave >> 1);
@@ -376,9 +394,11 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
             init_bias(aq[1], ev, wave, lane);
             init_bias(ah, ev, nth, lane);
             gemm_qkv(aq, ah, P, ring, ring1, bq0, bq1, wave, lane);
+            L6_T();                                // qkv gemm
             wload<8>(ring, wptr(w_out, wave, 8, lane));
             const float sc = es[0];
             __syncthreads();                       // x^ planes consumed: P may take q|k
+            L6_T();                                // barrier
             // n-tiles 0,1 = q,k -> Pq chunks 0..7 / 8..15; n-tiles 2..5 = v -> F chunks 8 (nt - 2) ..
             auto fb = [&](float v, int, int) { return v * sc; };
             float* dst = wave < 2 ? Pq : F;         // branch-free: the whole encoder stays one basic block
@@ -388,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
             put_f32(F, 128, 8 * (nth - 2), wave & 1, ah, lane, fb);
         }
         __syncthreads();
+        L6_T();                                    // qkv put + barrier
         // ---- attention (Attention.py:8-36) on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32 = exact fp32 fma chains):
         // wave = query (16 tokens); per head  S^T = K Q^T (key rows, query columns: lane (qi, g) then owns S[qi][4g..4g+3]),
         // softmax over the keys = 4 registers x the 4 lane groups, O^T = V^T P^T with the key index j = 4g + s: lane (qi, g)
@@ -445,10 +466,13 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
                     put4(p2, base + (((4 * hh + 2 * nt + (g >> 1)) ^ li) << 1), o[hh][nt][0], o[hh][nt][1], o[hh][nt][2], o[hh][nt][3]);
         }
         // ---- out projection + residual (Attention.py:201-202, 290): x += att W_o^T + b, accumulated in place ----
+        L6_T();                                    // attention
         scale_add_bias(xres[0], es[16 + 1], ev + 192, wave, lane);
         scale_add_bias(xres[1], es[16 + 1], ev + 192, wave, lane);
         __syncthreads();
+        L6_T();                                    // bias + barrier
         gemm<8>(xres, P, ring, wptr(w_out, wave, 8, lane), lane);
+        L6_T();                                    // out gemm
         wload<8>(ring, wptr(w_ff1a, wave, 8, lane));
         {
             const float sc = es[1];
@@ -462,9 +486,12 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
         init_bias(acc[0], ev + 192 + 128, wave, lane);
         init_bias(acc[1], ev + 192 + 128, wave, lane);
         __syncthreads();                           // St visible; the attention output in P is consumed by every wave
+        L6_T();                                    // res + norm2 partial + barrier
         ln_finish(xres, St, P, wave, lane);
         __syncthreads();
+        L6_T();                                    // norm2 finish + barrier
         gemm<8>(acc, P, ring, wptr(w_ff1a, wave, 8, lane), lane);
+        L6_T();                                    // ff1a gemm
         wload<8>(ring, wptr(w_ff2a, wave, 8, lane));
         {
             const float sc = es[2];
@@ -475,13 +502,17 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
         scale_add_bias(xres[0], es[16 + 4], ev + 192 + 128 + 256, wave, lane);   // FF2 accumulates onto the residual in place
         scale_add_bias(xres[1], es[16 + 4], ev + 192 + 128 + 256, wave, lane);
         __syncthreads();                           // first hidden half visible
+        L6_T();                                    // gelu a + barrier
         gemm<8>(xres, H, ring, wptr(w_ff2a, wave, 8, lane), lane);
+        L6_T();                                    // ff2a gemm
         wload<8>(ring, wptr(w_ff1b, wave, 8, lane));
         init_bias(acc[0], ev + 192 + 128 + 128, wave, lane);
         init_bias(acc[1], ev + 192 + 128 + 128, wave, lane);
         gemm<8>(acc, P, ring, wptr(w_ff1b, wave, 8, lane), lane);                // reads P only: no barrier needed before it
+        L6_T();                                    // ff1b gemm
         wload<8>(ring, wptr(w_ff2b, wave, 8, lane));
         __syncthreads();                           // the first hidden half in H is consumed
+        L6_T();                                    // barrier
         {
             const float sc = es[3];
 #pragma unroll
@@ -489,7 +520,9 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
                 put_planes(H, wave, mt, acc[mt], lane, [&](float v, int, int) { return l3_gelu(v * sc); });
         }
         __syncthreads();
+        L6_T();                                    // gelu b + barrier
         gemm<8>(xres, H, ring, wptr(w_ff2b, wave, 8, lane), lane);
+        L6_T();                                    // ff2b gemm
         {
             const float sc = es[4];                 // ff2a and ff2b share one exponent
 #pragma unroll
@@ -498,6 +531,7 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
                 for (int r = 0; r < 16; ++r) xres[mt][r] *= sc;
         }
     }
+    L6_T();
     // ---- final norm (folded) + linear0 128 -> 128 (SconeOcc.py:119-122) ----
     wload<8>(ring, wptr(mats + l6_mat_off(14), wave, 8, lane));
     ln_partial(xres, St, wave, lane);
@@ -514,6 +548,7 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
             put_f32(F, 128, 8 * wave, mt, acc[mt], lane, [&](float v, int, int) { return v * sc; });
     }
     __syncthreads();
+    L6_T();                                        // final norm + lin0
     // ---- max || avg pool over the 16 tokens of each query (SconeOcc.py:124-126) ----
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -531,9 +566,14 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
             feat[(s0 + q) * ld_feat + 128 + c] = sm * (1.0f / 16.f);
         }
     }
+    L6_T();
 }
 
 }  // namespace v6
+
+#ifdef L6_TRACE
+extern "C" int mcr_dev_read_trace(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(v6::l6_trace_buf), sizeof(long long) * 64); }
+#endif
 
 void launch_local_pct6(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob) {
     if (S <= 0) return;

@@ -1,4 +1,4 @@
-"""Dev: per-phase cycle stamps of one workgroup of the fused local transformer (lib built with -DL5_TRACE=<block>)."""
+"""Dev: per-phase cycle stamps of one workgroup of the fused local transformer (lib built with -DL6_TRACE=<block>)."""
 import sys, os, torch, io, contextlib, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from macarons_amd import ops, _lib
@@ -6,17 +6,18 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_libs"
 from macarons_amd.networks import SconeOcc
 from macarons_amd.networks.packing import pack_local_pct
 dev = torch.device("cuda:0")
-v = int(os.environ.get("VARIANT", 5))
+v = int(os.environ.get("VARIANT", 6))
 L = _lib.lib(); L.mcr_set_local_pct_variant(ctypes.c_int(v))
 with contextlib.redirect_stdout(io.StringIO()):
     occ = SconeOcc().to(dev)
 blob = pack_local_pct(occ.local_transformers[0], v)
 offs = torch.randn(16384, 16, 3, device=dev) * 0.05
-names = ["stage", "emb1 gemm", "emb1 gelu", "emb2 gemm+epi"]
+names = ["emb1 product", "emb1 gelu+barrier", "emb2 gemm"]
 for e in range(2):
-    names += [f"e{e} store_x", f"e{e} norm1", f"e{e} qkv gemm", f"e{e} qkv put", f"e{e} attention", f"e{e} out gemm+res", f"e{e} store_x",
-              f"e{e} norm2", f"e{e} ff1a gemm+gelu", f"e{e} ff2a+ff1b gemm", f"e{e} ff1b gelu", f"e{e} ff2b gemm+res"]
-names += ["store_x", "final norm", "lin0 gemm+epi", "pool"]
+    names += [f"e{e} prev epilogue", f"e{e} norm1 partial+barrier", f"e{e} norm1 finish+barrier", f"e{e} qkv gemm", f"e{e} barrier", f"e{e} qkv put+barrier",
+              f"e{e} attention", f"e{e} bias+barrier", f"e{e} out gemm", f"e{e} res+norm2 partial+barrier", f"e{e} norm2 finish+barrier", f"e{e} ff1a gemm",
+              f"e{e} gelu a+barrier", f"e{e} ff2a gemm", f"e{e} ff1b gemm", f"e{e} barrier", f"e{e} gelu b+barrier", f"e{e} ff2b gemm"]
+names += ["epilogue", "final norm+lin0", "pool"]
 acc = None
 for it in range(5):
     ops.local_pct_forward(offs, blob); torch.cuda.synchronize()
