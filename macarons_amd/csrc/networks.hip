@@ -258,6 +258,7 @@ size_t mcr_scone_occ_workspace_bytes(int64_t B, int64_t Q, int64_t Lg) {
     local = std::max(local, al(Q * 16 * 3) + al(Q * 16) + al(Q * 16 * 2) + 1024);      // fused path: kNN outputs for all Q
     size_t glob = pct_ws_bytes(B * Lg);
     size_t head = al(B * Q * 1344) + al(B * Q * 512) + al(B * Q * 256) + al(B * 512) * 2;
+    head += linear3h_planes_bytes(512, 1344);        // split weight planes of the largest head layer (reused layer after layer)
     return std::max(local, glob) + head + 8192;
 }
 
@@ -292,6 +293,7 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     float* h2 = head.f(B * Q * 256);
     float* gfeat = head.f(B * 512);
     float* gbias = head.f(B * 512);
+    void* wplanes = head.f(linear3h_planes_bytes(512, 1344) / sizeof(float));
     Arena scratch{(char*)workspace + head.off, workspace_bytes - head.off, 0};
 
     // ---- global feature (SconeOcc.py:269-277) ----
@@ -327,15 +329,25 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
             }
         }
     }
+    // the large layers run on the split-precision matrix path of the selected variant (6: fp16 x 3 with the weights split once per
+    // call into `wplanes`; otherwise launch_linear's own routing: bf16 x 6 / exact fp32 MFMA)
+    const bool f16 = g_local_pct_variant == 6;
+    auto big_linear = [&](const float* X_, int64_t ldx, const float* W_, int64_t ldw, const float* b_, float* Y_, int64_t ldy, int64_t M_,
+                          int N_, int K_, const float* rb, int64_t rpg) {
+        if (f16 && linear3h_applicable(X_, ldx, W_, ldw, M_, N_, K_))
+            launch_linear3h(s, X_, ldx, W_, ldw, wplanes, b_, nullptr, 0, Y_, ldy, M_, N_, K_, ACT_GELU, rb, rpg);
+        else
+            launch_linear(s, X_, ldx, W_, b_, nullptr, 0, Y_, ldy, M_, N_, K_, ACT_GELU, rb, rpg, ldw);
+    };
     // ---- x embedding 3 -> 128 -> 256 -> 512, GELU each (SconeOcc.py:35-42) ----
     const int64_t T = B * Q;
     launch_linear(s, x, 3, xe1.w, xe1.b, nullptr, 0, h2, 128, T, 128, 3, ACT_GELU);
-    launch_linear(s, h2, 128, xe2.w, xe2.b, nullptr, 0, h1, 256, T, 256, 128, ACT_GELU);
-    launch_linear(s, h1, 256, xe3.w, xe3.b, nullptr, 0, feat + 768, FEAT, T, 512, 256, ACT_GELU);
+    big_linear(h2, 128, xe2.w, 128, xe2.b, h1, 256, T, 256, 128, nullptr, 0);
+    big_linear(h1, 256, xe3.w, 256, xe3.b, feat + 768, FEAT, T, 512, 256, nullptr, 0);
     launch_copy2d(s, view_harmonics, 64, feat + 1280, FEAT, T, 64);
     // ---- head MLP 1856 -> 512 -> 256 -> 1, GELU after every layer incl. the last (SconeOcc.py:334-345) ----
-    launch_linear(s, feat, FEAT, lin1.w + 512, lin1.b, nullptr, 0, h1, 512, T, 512, FEAT, ACT_GELU, gbias, Q, 1856);
-    launch_linear(s, h1, 512, lin2.w, lin2.b, nullptr, 0, h2, 256, T, 256, 512, ACT_GELU);
+    big_linear(feat, FEAT, lin1.w + 512, 1856, lin1.b, h1, 512, T, 512, FEAT, gbias, Q);
+    big_linear(h1, 512, lin2.w, 512, lin2.b, h2, 256, T, 256, 512, nullptr, 0);
     launch_linear(s, h2, 256, lin3.w, lin3.b, nullptr, 0, out, 1, T, 1, 256, ACT_GELU);
     MCR_LAUNCH_CHECK("mcr_scone_occ_forward");
     return 0;
