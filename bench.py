@@ -127,7 +127,7 @@ def measure_nbv_step(dev, rank, world, args):
     return {"p50_ms": p50 * 1e3, "p90_ms": float(np.percentile(times, 90)) * 1e3, "evals_per_s": C / p50, "iters": len(times),
             "config": {"proxy_points": Q, "surface_points": M, "cams": C, "seq_len": 2048, "dtype": "f32",
                        "parallelism": f"query+camera shard x{world}"},
-            "algorithmic_TFLOP": 26.5e6 * Q / 1e12 + 0.0037 + 0.0137, "nbv_idx": int(r["nbv_idx"]), "n_unique": r["n_unique"]}
+            "algorithmic_TFLOP": 26.5e6 * Q / 1e12 + 0.0037 + 0.0137, "nbv_idx": int(r["nbv_idx"]), "n_unique": int(r["n_unique"])}
 
 
 def measure_local_pct(dev):

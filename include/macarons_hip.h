@@ -86,7 +86,10 @@ int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t
  *   features [S, feature_dim] (max || avg), feature_dim in {256, 512}.
  * mcr_scone_vis_forward: SconeVis.forward (macarons/networks/SconeVis.py:121-162); pts [B,N,4], view_harmonics
  *   [B,N,64] -> out [B,N,64].  Default architecture only (pts_embedding_dim 256, 4 heads, 3 encoders,
- *   view_state_mode "end", global feature, concatenated input).
+ *   view_state_mode "end", global feature, concatenated input).  lengths (optional, DEVICE int32 [B], may be NULL): cloud b
+ *   consists of its first min(N, lengths[b]) rows only -- the cloud-wide max of the embedding and the attention keys stop
+ *   there; rows beyond still produce (meaningless) outputs.  This is how the padded output of mcr_sample_proxy is consumed
+ *   without its count ever reaching the host (the reference slices with the count on the host, testers/shapenet.py:146-157).
  * mcr_scone_occ_forward: SconeOcc.forward (macarons/networks/SconeOcc.py:250-347) given the clouds the reference
  *   would obtain from its torch.randperm draws (:269, :311), which the HOST performs so the RNG stream matches:
  *   pc_global [B,Lg,3]; pc_scale[i] [B,M_scale[i],3] for the 3 neighbourhood scales; x [B,Q,3];
@@ -97,8 +100,8 @@ int mcr_pc_transformer_forward(const float* pc, float* features, int64_t S, int6
                                void* stream);
 size_t mcr_scone_vis_workspace_bytes(int64_t B, int64_t N);
 int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* out, int64_t B, int64_t N,
-                          const float* const* weights, int n_weights, void* workspace, size_t workspace_bytes,
-                          void* stream);
+                          const float* const* weights, int n_weights, const int* lengths, void* workspace,
+                          size_t workspace_bytes, void* stream);
 size_t mcr_scone_occ_workspace_bytes(int64_t B, int64_t Q, int64_t Lg);
 int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const* pc_scale, const int64_t* M_scale,
                           const float* x, const float* view_harmonics, float* out, int64_t B, int64_t Q,
@@ -133,7 +136,9 @@ int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_feat
  * mcr_sample_proxy: sample_proxy_points (scone_utils.py:1030-1061) with the uniforms `u` supplied by the host:
  *   keeps points with preds > min_occ, draws n_sample points with probability proportional to preds (inverse
  *   CDF in fp64: first i with C_i >= u * C_last), then unique (sorted) + inverse.  Outputs are padded to
- *   n_sample rows; *n_unique (device int) says how many are valid.  uniq holds ORIGINAL point indices.
+ *   n_sample rows (rows >= *n_unique are zero-filled); *n_unique (device int) says how many are valid.  uniq holds
+ *   ORIGINAL point indices.  Three launches: block sums + scan of them by the last block to finish, one wave per sample
+ *   for the search, one block for sort / unique / inverse / gather.
  *   res [n_sample,4] = (X, pred), res_harmonics [n_sample,64].  preds may be strided (pred_stride floats).
  *   volume (optional device double): sum of the kept occupancies (fov_proxy_volume of macarons_utils.py:1620).
  * mcr_points_in_fov: Camera.get_points_in_fov (macarons/utility/macarons_utils.py:2400-2435) for n_cam cameras

@@ -63,12 +63,16 @@ __global__ void view_state_kernel(const float* __restrict__ pts, int pts_dim, co
 // ---------------------------------------------------------------------------------------------------------
 // K10: sampling.  Convention (oracle/view_state.py sample_proxy_points(exact=True)): C_i = fp64 running sum of
 // the occupancies above min_occ (others contribute 0), sample u picks the first i with C_i >= u * C_last.
-// 1) block sums  2) scan of block sums (one block)  3) per-sample search  4) sort / unique / inverse (one block)
+// 1) block sums; the LAST block to finish scans them (exclusive offsets + total)  2) search, one wave per sample
+// 3) one block: sort / unique / inverse, then the gather of the unique rows (rows beyond n_unique zero-filled).
 constexpr int SMP_BLOCK = 256;
 
 __global__ __launch_bounds__(SMP_BLOCK) void smp_block_sums(const float* __restrict__ preds, long long pred_stride,
-                                                            float min_occ, long long P, double* __restrict__ block_sums) {
-    __shared__ double s[SMP_BLOCK / 64];
+                                                            float min_occ, long long P, double* __restrict__ block_sums,
+                                                            int n_blocks, double* __restrict__ total, unsigned* __restrict__ done) {
+    __shared__ double s[SMP_BLOCK];
+    __shared__ double carry;
+    __shared__ bool last;
     const long long i = (long long)blockIdx.x * SMP_BLOCK + threadIdx.x;
     double v = 0.0;
     if (i < P) {
@@ -79,39 +83,43 @@ __global__ __launch_bounds__(SMP_BLOCK) void smp_block_sums(const float* __restr
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
-}
-
-// exclusive scan of block sums in place (single block, sequential chunks: n_blocks is a few hundred)
-__global__ __launch_bounds__(256) void smp_scan_blocks(double* __restrict__ block_sums, int n_blocks, double* __restrict__ total) {
-    __shared__ double s[256];
-    __shared__ double carry;
-    if (threadIdx.x == 0) carry = 0.0;
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+        __threadfence();                                              // the sum is visible before the ticket
+        last = atomicAdd(done, 1u) == (unsigned)(n_blocks - 1);
+        carry = 0.0;
+    }
     __syncthreads();
-    for (int base = 0; base < n_blocks; base += 256) {
-        const int i = base + threadIdx.x;
-        const double v = i < n_blocks ? block_sums[i] : 0.0;
-        s[threadIdx.x] = v;
+    if (!last) return;
+    __threadfence();
+    // exclusive scan of the block sums in place (sequential chunks of 256: n_blocks is a few hundred)
+    for (int base = 0; base < n_blocks; base += SMP_BLOCK) {
+        const int k = base + threadIdx.x;
+        const double x = k < n_blocks ? __builtin_nontemporal_load(block_sums + k) : 0.0;
+        s[threadIdx.x] = x;
         __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {                      // Hillis-Steele inclusive scan
+        for (int o = 1; o < SMP_BLOCK; o <<= 1) {                     // Hillis-Steele inclusive scan
             const double t = threadIdx.x >= o ? s[threadIdx.x - o] : 0.0;
             __syncthreads();
             s[threadIdx.x] += t;
             __syncthreads();
         }
-        if (i < n_blocks) block_sums[i] = carry + s[threadIdx.x] - v;      // exclusive
+        if (k < n_blocks) block_sums[k] = carry + s[threadIdx.x] - x;  // exclusive
         __syncthreads();
-        if (threadIdx.x == 255) carry += s[255];
+        if (threadIdx.x == SMP_BLOCK - 1) carry += s[SMP_BLOCK - 1];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) { *total = carry; *done = 0u; }              // the counter is left ready for the next call
 }
 
-// per sample: find the block by binary search on the exclusive block offsets, then walk the block sequentially
-__global__ void smp_search(const float* __restrict__ preds, long long pred_stride, float min_occ, long long P,
-                           const double* __restrict__ block_off, int n_blocks, const double* __restrict__ total,
-                           const float* __restrict__ u, int n_sample, long long* __restrict__ picked) {
-    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per sample: binary search of the block on the exclusive offsets, then the 256 occupancies of that block (4 per
+// lane) are scanned in the wave and the first position whose running sum reaches the target is taken.  (A thread per sample
+// walking its block serially cost 42 us: 256 dependent loads.)  If rounding puts the target past the last kept point of the
+// block, the search moves on to the next block (and ends on the last kept point overall).
+__global__ __launch_bounds__(256) void smp_search(const float* __restrict__ preds, long long pred_stride, float min_occ, long long P,
+                                                  const double* __restrict__ block_off, int n_blocks, const double* __restrict__ total,
+                                                  const float* __restrict__ u, int n_sample, long long* __restrict__ picked) {
+    const int sidx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (sidx >= n_sample) return;
     const double target = (double)u[sidx] * (*total);
     int lo = 0, hi = n_blocks - 1;                 // last block whose exclusive offset < target (or 0)
@@ -119,33 +127,70 @@ __global__ void smp_search(const float* __restrict__ preds, long long pred_strid
         const int mid = (lo + hi + 1) >> 1;
         if (block_off[mid] < target) lo = mid; else hi = mid - 1;
     }
-    // walk forward from block lo until the running sum reaches the target on a kept point
-    double c = block_off[lo];
-    long long i = (long long)lo * SMP_BLOCK, last_kept = -1;
-    long long ans = -1;
-    for (; i < P; ++i) {
-        const float p = preds[i * pred_stride];
-        if (p > min_occ) {
-            c += (double)p;
-            last_kept = i;
-            if (c >= target) { ans = i; break; }
+    long long ans = -1, last_kept = -1;
+    for (int blk = lo; blk < n_blocks && ans < 0; ++blk) {
+        const long long i0 = (long long)blk * SMP_BLOCK + 4 * lane;
+        double v[4], run = 0.0;
+        bool kept[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float p = (i0 + e < P) ? preds[(i0 + e) * pred_stride] : 0.f;
+            kept[e] = (i0 + e < P) && p > min_occ;
+            run += kept[e] ? (double)p : 0.0;
+            v[e] = run;                            // inclusive sums inside the lane's quad
+        }
+        double incl = run;                         // inclusive scan of the lane totals across the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        const double base = block_off[blk] + (incl - run);
+        int first = 4;                             // first kept element of the quad that reaches the target
+        int lastk = -1;
+#pragma unroll
+        for (int e = 3; e >= 0; --e) {
+            if (kept[e] && base + v[e] >= target) first = e;
+            if (kept[e] && lastk < 0) lastk = e;
+        }
+        const unsigned long long hit = __ballot(first < 4), anyk = __ballot(lastk >= 0);
+        if (hit) {
+            const int src = __ffsll((long long)hit) - 1;
+            ans = (long long)blk * SMP_BLOCK + 4 * src + __shfl(first, src, 64);
+        }
+        if (anyk) {
+            const int src = 63 - __clzll((long long)anyk);
+            last_kept = (long long)blk * SMP_BLOCK + 4 * src + __shfl(lastk, src, 64);
         }
     }
-    if (ans < 0) {                                  // target beyond the total by rounding: last kept point
+    if (ans < 0) {                                  // target beyond the total by rounding: the last kept point
         if (last_kept < 0) {
-            for (i = (long long)lo * SMP_BLOCK - 1; i >= 0; --i)
-                if (preds[i * pred_stride] > min_occ) { last_kept = i; break; }
+            for (int blk = lo - 1; blk >= 0 && last_kept < 0; --blk) {
+                const long long i0 = (long long)blk * SMP_BLOCK + 4 * lane;
+                int lastk = -1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i0 + e < P && preds[(i0 + e) * pred_stride] > min_occ) lastk = e;
+                const unsigned long long anyk = __ballot(lastk >= 0);
+                if (anyk) {
+                    const int src = 63 - __clzll((long long)anyk);
+                    last_kept = (long long)blk * SMP_BLOCK + 4 * src + __shfl(lastk, src, 64);
+                }
+            }
         }
         ans = last_kept;
     }
-    picked[sidx] = ans;
+    if (lane == 0) picked[sidx] = ans;
 }
 
-// one block: bitonic sort of (picked, sample id), unique, inverse.  n_sample <= SMP_MAX.
+// one block: bitonic sort of (picked, sample id), unique, inverse, gather.  n_sample <= SMP_MAX.
+//   res[r] = (X[uniq[r]], pred[uniq[r]]), res_h[r] = vh[uniq[r]] for r < n_unique (scone_utils.py:1060-1061), zeros beyond
 constexpr int SMP_MAX = 4096;
 __global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__ picked, int n_sample,
                                                    long long* __restrict__ uniq, long long* __restrict__ inverse,
-                                                   int* __restrict__ n_unique) {
+                                                   int* __restrict__ n_unique, const float* __restrict__ X,
+                                                   const float* __restrict__ preds, long long pred_stride,
+                                                   const float* __restrict__ vh, float* __restrict__ res, float* __restrict__ res_h) {
     __shared__ long long key[SMP_MAX];
     __shared__ int rank[SMP_MAX];
     int n2 = 1;
@@ -180,6 +225,7 @@ __global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__
         for (int i = threadIdx.x; i < n2; i += 1024) rank[i] += t[c++];
         __syncthreads();
     }
+    const int nu = rank[n_sample - 1];
     for (int i = threadIdx.x; i < n_sample; i += 1024) {
         const long long id = key[i] >> 13;
         if (id == (0x7fffffffffffe000LL >> 13)) {                 // no point above min_occ: nothing sampled
@@ -190,20 +236,22 @@ __global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__
         if (i == 0 || id != (key[i - 1] >> 13)) uniq[r] = id;
         inverse[key[i] & 8191] = r;
     }
-    if (threadIdx.x == 0) *n_unique = rank[n_sample - 1];
-}
-
-// res[r] = (X[uniq[r]], pred[uniq[r]]), res_h[r] = vh[uniq[r]]   for r < n_unique  (scone_utils.py:1060-1061)
-__global__ void smp_gather(const float* __restrict__ X, const float* __restrict__ preds, long long pred_stride,
-                           const float* __restrict__ vh, const long long* __restrict__ uniq, const int* __restrict__ n_unique,
-                           float* __restrict__ res, float* __restrict__ res_h) {
-    const int r = blockIdx.x;
-    if (r >= *n_unique) return;
-    const long long i = uniq[r];
-    const int c = threadIdx.x;          // 64 threads
-    res_h[(long long)r * 64 + c] = vh[i * 64 + c];
-    if (c < 3) res[r * 4 + c] = X[i * 3 + c];
-    if (c == 3) res[r * 4 + 3] = preds[i * pred_stride];
+    if (threadIdx.x == 0) *n_unique = nu;
+    __syncthreads();                                               // uniq[] (global, written by this block) is complete
+    // gather: 16 rows x 64 columns per pass
+    for (int r = threadIdx.x >> 6; r < n_sample; r += 16) {
+        const int c = threadIdx.x & 63;
+        if (r < nu) {
+            const long long i = uniq[r];
+            res_h[(long long)r * 64 + c] = vh[i * 64 + c];
+            if (c < 3) res[r * 4 + c] = X[i * 3 + c];
+            if (c == 3) res[r * 4 + 3] = preds[i * pred_stride];
+        } else {
+            uniq[r] = 0;
+            res_h[(long long)r * 64 + c] = 0.f;
+            if (c < 4) res[r * 4 + c] = 0.f;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -506,8 +554,9 @@ int mcr_view_state(const float* pts, int pts_dim, const float* X_view, float* vi
 }
 
 size_t mcr_sample_proxy_workspace_bytes(int64_t P, int n_sample) {
-    return (size_t)(cdiv(P, SMP_BLOCK) + 2) * sizeof(double) + (size_t)n_sample * sizeof(long long) + 256;
+    return (size_t)(cdiv(P, SMP_BLOCK) + 2) * sizeof(double) + (size_t)n_sample * sizeof(long long) + 512;
 }
+
 
 int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t P,
                      float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
@@ -522,13 +571,14 @@ int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, co
     double* block_sums = (double*)workspace;
     double* total = block_sums + nb;
     long long* picked = (long long*)(total + 2);
-    hipLaunchKernelGGL(smp_block_sums, dim3(nb), dim3(SMP_BLOCK), 0, s, preds, (long long)pred_stride, min_occ, (long long)P, block_sums);
-    hipLaunchKernelGGL(smp_scan_blocks, dim3(1), dim3(256), 0, s, block_sums, nb, total);
-    hipLaunchKernelGGL(smp_search, dim3((unsigned)cdiv(n_sample, 128)), dim3(128), 0, s, preds, (long long)pred_stride, min_occ,
+    unsigned* ticket = (unsigned*)(picked + n_sample);          // "last block scans" counter of smp_block_sums, in the caller's scratch
+    if (int e = check_hip(hipMemsetAsync(ticket, 0, sizeof(unsigned), s), "mcr_sample_proxy: ticket")) return e;
+    hipLaunchKernelGGL(smp_block_sums, dim3(nb), dim3(SMP_BLOCK), 0, s, preds, (long long)pred_stride, min_occ, (long long)P, block_sums,
+                       nb, total, ticket);
+    hipLaunchKernelGGL(smp_search, dim3((unsigned)cdiv(n_sample, 4)), dim3(256), 0, s, preds, (long long)pred_stride, min_occ,
                        (long long)P, block_sums, nb, total, u, n_sample, picked);
-    hipLaunchKernelGGL(smp_unique, dim3(1), dim3(1024), 0, s, picked, n_sample, (long long*)uniq, (long long*)inverse, n_unique);
-    hipLaunchKernelGGL(smp_gather, dim3((unsigned)n_sample), dim3(64), 0, s, X, preds, (long long)pred_stride, view_harmonics,
-                       (const long long*)uniq, n_unique, res, res_harmonics);
+    hipLaunchKernelGGL(smp_unique, dim3(1), dim3(1024), 0, s, picked, n_sample, (long long*)uniq, (long long*)inverse, n_unique, X,
+                       preds, (long long)pred_stride, view_harmonics, res, res_harmonics);
     if (volume)
         if (int e = check_hip(hipMemcpyAsync(volume, total, sizeof(double), hipMemcpyDeviceToDevice, s), "mcr_sample_proxy: volume")) return e;
     MCR_LAUNCH_CHECK("mcr_sample_proxy");

@@ -49,12 +49,12 @@ static size_t al(size_t n_floats) { return (n_floats * sizeof(float) + 255) & ~(
 
 // x <- Encoder(x)  in place.  x [T, E]; scratch h [T, E], qkv [T, 2*dqk + E], ff [T, 2E]
 static void run_encoder(hipStream_t s, const EncW& w, float* x, float* h, float* qkv, float* ff, int64_t S, int L, int E,
-                        int H) {
+                        int H, const int* lens = nullptr) {
     const int64_t T = S * L;
     const int dqk = E / 4, W3 = 2 * dqk + E;
     launch_layernorm(s, x, E, w.n1g, w.n1b, h, E, T, E);                                   // Attention.py:287
     launch_linear(s, h, E, w.qkv.w, w.qkv.b, nullptr, 0, qkv, W3, T, W3, E, ACT_NONE);       // :186-188
-    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E);                                     // :191-198
+    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens);                               // :191-198
     launch_linear(s, h, E, w.out.w, w.out.b, x, E, x, E, T, E, E, ACT_NONE);                 // :201-202 + residual :290
     launch_layernorm(s, x, E, w.n2g, w.n2b, h, E, T, E);                                   // :293
     launch_linear(s, h, E, w.ff1.w, w.ff1.b, nullptr, 0, ff, 2 * E, T, 2 * E, E, ACT_GELU);  // :232
@@ -208,8 +208,8 @@ size_t mcr_scone_vis_workspace_bytes(int64_t B, int64_t N) {
 }
 
 int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* out, int64_t B, int64_t N,
-                          const float* const* weights, int n_weights, void* workspace, size_t workspace_bytes,
-                          void* stream) {
+                          const float* const* weights, int n_weights, const int* lengths, void* workspace,
+                          size_t workspace_bytes, void* stream) {
     MCR_REQUIRE(pts && view_harmonics && out && weights, "mcr_scone_vis_forward: null pointer");
     MCR_REQUIRE(n_weights == VIS_NW, "mcr_scone_vis_forward: expected %d weight pointers, got %d", VIS_NW, n_weights);
     MCR_REQUIRE(B > 0 && N > 0 && B <= 65535, "mcr_scone_vis_forward: bad problem size B=%ld N=%ld", (long)B, (long)N);
@@ -232,9 +232,9 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
     // Embedding: 4 -> 126 GELU -> 126, || cloud-wide max (126) || raw input (4)  = 256   (Attention.py:98-128)
     launch_linear(s, pts, 4, l1.w, l1.b, nullptr, 0, h, VIS_F, T, VIS_F, 4, ACT_GELU);
     launch_linear(s, h, VIS_F, l2.w, l2.b, nullptr, 0, x, VIS_E, T, VIS_F, VIS_F, ACT_NONE);
-    launch_colmax_broadcast(s, x, VIS_E, x + VIS_F, VIS_E, B, (int)N, VIS_F);
+    launch_colmax_broadcast(s, x, VIS_E, x + VIS_F, VIS_E, B, (int)N, VIS_F, lengths);
     launch_copy2d(s, pts, 4, x + 2 * VIS_F, VIS_E, T, 4);
-    for (int e = 0; e < 3; ++e) run_encoder(s, enc[e], x, h, qkv, ff, B, (int)N, VIS_E, 4);     // SconeVis.py:139-140
+    for (int e = 0; e < 3; ++e) run_encoder(s, enc[e], x, h, qkv, ff, B, (int)N, VIS_E, 4, lengths);   // SconeVis.py:139-140
     launch_layernorm(s, x, VIS_E, ng, nb, h, VIS_E, T, VIS_E);                                   // :143
     // fc1 256->192 GELU, || view_harmonics (64), fc2 256->128 GELU, fc3 128->64                  (:146-152)
     launch_linear(s, h, VIS_E, fc1.w, fc1.b, nullptr, 0, ff, VIS_E, T, 192, VIS_E, ACT_GELU);

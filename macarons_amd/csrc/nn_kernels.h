@@ -37,12 +37,14 @@ void launch_layernorm(hipStream_t s, const float* X, int64_t ldx, const float* g
 // Multi-head self-attention core on a packed QKV buffer (Attention.py:8-36,174-198; mask=None, no dropout):
 //   qkv[m, 0:DQK | DQK:2DQK | 2DQK:2DQK+DV], head h owns channels [h*d,(h+1)*d); scores / sqrt(dqk_per_head);
 //   out[m, h*dv:(h+1)*dv].   Sequences are S consecutive blocks of L rows.
+//   lens (optional, device int per sequence): keys = the first min(L, lens[s]) rows (padded variable-length batches).
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
-                      int DQK, int DV);
+                      int DQK, int DV, const int* lens = nullptr);
 
 // Column max over the L rows of each of S sequences, broadcast into a column slice of every row:
 //   Y[(s*L + r)*ldy + c] = max_r' X[(s*L + r')*ldx + c], c < E          (Embedding global feature, Attention.py:117-121)
-void launch_colmax_broadcast(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E);
+void launch_colmax_broadcast(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E,
+                             const int* lens = nullptr);
 
 // PCTransformer tail (SconeOcc.py:123-126): per sequence, max over rows then mean over rows:
 //   Y[s*ldy + c] = max_r X[(s*L+r)*ldx + c],  Y[s*ldy + E + c] = mean_r X[...]

@@ -408,9 +408,13 @@ __global__ __launch_bounds__(64 * KS) void attention_flash_kernel(const float* _
 //   so the per-query rescale factors are fetched across lane groups (4 ds_bpermute per 64 keys).
 // grid = (ceil(L/64), H, S)
 // =====================================================================================================
+// lens (optional, device, one int per sequence): only the first min(L, lens[seq]) rows of a sequence are keys -- the padded
+// SconeVis batches of the sync-free NBV step (the number of unique sampled points never reaches the host); rows beyond it
+// still get an output (never read).
 template <int DQ, int DV>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, long long ldq,
-                                                             float* __restrict__ out, long long ldo, int L, int H) {
+                                                             float* __restrict__ out, long long ldo, int L, int H,
+                                                             const int* __restrict__ lens) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int TK = 64, LDK = DQ + 1, LDV = DV + 4, NT = DV / 16, KQ = DQ / 4;
     __shared__ float s_k[TK * LDK];
@@ -418,6 +422,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
     const int hh = blockIdx.y;
     const long long seq0 = (long long)blockIdx.z * L;
+    const int Lk = lens ? max(1, min(L, __builtin_amdgcn_readfirstlane(lens[blockIdx.z]))) : L;       // number of keys
     const int q0 = blockIdx.x * 64 + wave * 16;
     const int koff = H * DQ + hh * DQ, voff = 2 * H * DQ + hh * DV;
     const float scale = 1.0f / sqrtf((float)DQ);
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         for (int p = 0; p < PT; ++p) {
             const int idx = threadIdx.x + p * 256, r = idx / F4K, c4 = idx - r * F4K;
             stage[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NF4 && t0 + r < L)
+            if (idx < NF4 && t0 + r < Lk)
                 stage[p] = *reinterpret_cast<const float4*>(qkv + (seq0 + t0 + r) * ldq + (c4 < DQ / 4 ? koff + 4 * c4 : voff + 4 * (c4 - DQ / 4)));
         }
     };
@@ -463,11 +468,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         }
     };
     fetch(0);
-    for (int t0 = 0; t0 < L; t0 += TK) {
+    for (int t0 = 0; t0 < Lk; t0 += TK) {
         __syncthreads();                                  // the previous tile is consumed
         commit();
         __syncthreads();
-        if (t0 + TK < L) fetch(t0 + TK);
+        if (t0 + TK < Lk) fetch(t0 + TK);
         // ---- scores of the 64 keys of the tile (all A fragments first: LLVM otherwise issues every ds_read right in
         // front of its MFMA and each one waits out the LDS latency) ----
         const float* kbase = s_k + li * LDK + g;             // K[sub*16 + li][4 sk + g]
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (t0 + sub * 16 + 4 * g + r >= L) st[sub][r] = -__builtin_inff();      // keys past the sequence end
+                if (t0 + sub * 16 + 4 * g + r >= Lk) st[sub][r] = -__builtin_inff();     // keys past the sequence end
                 tmax = fmaxf(tmax, st[sub][r]);
             }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
@@ -553,10 +558,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 }
 
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
-                      int DQK, int DV) {
+                      int DQK, int DV, const int* lens) {
     if (S <= 0 || L <= 0) return;
     const int dq = DQK / H, dv = DV / H;
-    if (L == 16 && H == 4 && dq == 8 && dv == 32) {
+    if (!lens && L == 16 && H == 4 && dq == 8 && dv == 32) {
         constexpr int SPB = 4;
         hipLaunchKernelGGL((attention_small_kernel<16, 4, 8, 32, SPB>), dim3((unsigned)cdiv(S, SPB)), dim3(SPB * 4 * 16), 0,
                            s, qkv, (long long)ldq, out, (long long)ldo, (long long)S);
@@ -567,11 +572,15 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
     static const bool use_mfma = []() { const char* e = getenv("MCR_ATTN_MFMA"); return !(e && e[0] == '0'); }();   // dev A/B knob
     const bool al16 = aligned16(qkv) && ldq % 4 == 0 && (H * dq) % 4 == 0;
     if (use_mfma && al16 && dq == 8 && dv == 32) {
-        hipLaunchKernelGGL((attention_mfma_kernel<8, 32>), grid, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H);
+        hipLaunchKernelGGL((attention_mfma_kernel<8, 32>), grid, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H, lens);
         return;
     }
     if (use_mfma && al16 && dq == 16 && dv == 64) {
-        hipLaunchKernelGGL((attention_mfma_kernel<16, 64>), grid, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H);
+        hipLaunchKernelGGL((attention_mfma_kernel<16, 64>), grid, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H, lens);
+        return;
+    }
+    if (lens) {
+        set_error("launch_attention: per-sequence lengths need the MFMA kernel (16-byte aligned qkv, head dims (8,32) or (16,64))");
         return;
     }
     if (dq == 8 && dv == 32)
@@ -592,15 +601,16 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
 constexpr int POOL_RL = 16;
 template <bool BROADCAST>
 __global__ __launch_bounds__(64 * POOL_RL) void pool_kernel(const float* __restrict__ X, long long ldx, float* __restrict__ Y,
-                                                            long long ldy, int L, int E) {
+                                                            long long ldy, int L, int E, const int* __restrict__ lens) {
     __shared__ float s_max[POOL_RL][64];
     __shared__ float s_sum[POOL_RL][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
     const long long row0 = (long long)blockIdx.x * L;
+    const int Lr = lens ? max(1, min(L, lens[blockIdx.x])) : L;          // rows that take part in the reduction
     float mx = -__builtin_inff(), sm = 0.f;
     if (c < E)
-        for (int r = g; r < L; r += POOL_RL) {
+        for (int r = g; r < Lr; r += POOL_RL) {
             const float v = X[(row0 + r) * ldx + c];
             mx = fmaxf(mx, v);
             sm += v;
@@ -620,20 +630,21 @@ __global__ __launch_bounds__(64 * POOL_RL) void pool_kernel(const float* __restr
         for (int r = g; r < L; r += POOL_RL) Y[(row0 + r) * ldy + c] = mx;
     } else if (g == 0) {
         Y[(long long)blockIdx.x * ldy + c] = mx;
-        Y[(long long)blockIdx.x * ldy + E + c] = sm / (float)L;
+        Y[(long long)blockIdx.x * ldy + E + c] = sm / (float)Lr;
     }
 }
 
-void launch_colmax_broadcast(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E) {
+void launch_colmax_broadcast(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E,
+                             const int* lens) {
     if (S <= 0) return;
     hipLaunchKernelGGL((pool_kernel<true>), dim3((unsigned)S, (unsigned)cdiv(E, 64)), dim3(64 * POOL_RL), 0, s, X, (long long)ldx, Y,
-                       (long long)ldy, L, E);
+                       (long long)ldy, L, E, lens);
 }
 
 void launch_pool_max_avg(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E) {
     if (S <= 0) return;
     hipLaunchKernelGGL((pool_kernel<false>), dim3((unsigned)S, (unsigned)cdiv(E, 64)), dim3(64 * POOL_RL), 0, s, X, (long long)ldx, Y,
-                       (long long)ldy, L, E);
+                       (long long)ldy, L, E, (const int*)nullptr);
 }
 
 __global__ void copy2d_kernel(const float* __restrict__ X, long long ldx, float* __restrict__ Y, long long ldy, long long M,

@@ -28,7 +28,8 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
              view_proj=None, filter_tol=0.01, return_samples=False):
     """pc [1,M,3] surface points, X [1,Q,3] proxy points, X_view [n_view,3] past camera positions, X_cam [C,3]
     candidate cameras (all in the normalised prediction-view space, as the reference feeds its networks).
-    Returns dict(gains [C_local or C], nbv_idx (global camera index, int), max_gain, occ [Q,1], n_unique).
+    Returns dict(gains [C_local or C], nbv_idx (global camera index), max_gain, occ [Q,1], n_unique) -- all device tensors
+    (n_unique: int32 [1]); nothing is read back inside the step, so it runs without a single host synchronisation.
     `occ_perms` / `samples` pin the hidden RNG draws (SconeOcc randperms; sampling uniforms).  `view_proj` [n_view,4,4]
     (full-projection matrices of the past views) switches on the tester's proxy-point filter (testers/shapenet.py:117-122)."""
     world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
@@ -58,16 +59,18 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
             samples = torch.rand(seq_len, 1, device=dev)
             if world > 1:
                 torch.distributed.broadcast(samples, 0, group=group)
-        proxy_points, vh_s, sample_idx = su.sample_proxy_points(X[0], occ, vh, n_sample=seq_len, min_occ=min_occ,
-                                                                return_index=True, samples=samples)
-        n_unique = proxy_points.shape[0]
+        # no host read-back: the unique sampled points stay padded to seq_len rows and their count stays on the device
+        # (SconeVis consumes it as `lengths`); the reference slices on the host (:146-157)
+        proxy_points, vh_s, sample_idx, n_unique = su.sample_proxy_points(X[0], occ, vh, n_sample=seq_len, min_occ=min_occ,
+                                                                          samples=samples, padded=True)
         sampled = (proxy_points, sample_idx)
         # ---- visibility-gain harmonics (:157-160) ----
-        harm = scone_vis(proxy_points[None], view_harmonics=vh_s[None])
+        harm = scone_vis(proxy_points[None], view_harmonics=vh_s[None], lengths=n_unique)
         if true_monte_carlo_sampling:
             proxy_points, harm = proxy_points[sample_idx][None].contiguous(), harm[0][sample_idx][None].contiguous()
-        else:
-            proxy_points = proxy_points[None]
+        else:                                       # score the unique points once each: their count is needed on the host
+            k = int(n_unique)
+            proxy_points, harm = proxy_points[:k][None].contiguous(), harm[:, :k].contiguous()
         # ---- coverage gains over this rank's camera shard + arg-max (:167-172) ----
         C = X_cam.shape[0]
         c0, c1 = mdist.shard_range(C, rank, world)
@@ -79,6 +82,6 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
             max_gain, nbv_idx = best.values, best.indices
     out = {"gains": gains[0], "cam_range": (c0, c1), "nbv_idx": nbv_idx, "max_gain": max_gain, "occ": occ,
            "n_unique": n_unique}
-    if return_samples:                              # the unique sampled proxy points [n_unique,4] and the inverse map [seq_len]
+    if return_samples:                              # the unique sampled proxy points (first n_unique of seq_len rows) and the inverse map [seq_len]
         out["proxy_points"], out["sample_idx"] = sampled
     return out

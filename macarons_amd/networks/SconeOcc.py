@@ -12,7 +12,7 @@ from torch import nn
 
 from .. import ops, _lib
 from .Attention import Embedding, Encoder, _f32c, _inference_only
-from .packing import BlobCache
+from .packing import BlobCache, TableCache
 
 
 class XEmbedding(nn.Module):
@@ -110,6 +110,7 @@ class SconeOcc(nn.Module):
         # fused LDS-resident local transformers (local_pct.hip); set False to run them layer by layer
         self.fused_local = True
         self._blob_caches = [BlobCache() for _ in range(n_scale)]
+        self._table_cache = TableCache()
 
     def _is_default_arch(self):
         return (self.n_scale == 3 and self.k_for_knn == 16 and self.offset and self.x_dim == 3 and self.x_embedding_dim == 512
@@ -165,5 +166,5 @@ class SconeOcc(nn.Module):
             blobs = [c.get(t, variant) for c, t in zip(self._blob_caches, self.local_transformers)]
         else:
             blobs = None
-        res = ops.scone_occ_forward(pc_global, scales, x, view_harmonics, self.weight_table(), blobs)
+        res = ops.scone_occ_forward(pc_global, scales, x, view_harmonics, self._table_cache.get(self, self.weight_table), blobs)
         return res.view(n_clouds, n_sample, self.output_dim)

@@ -14,6 +14,7 @@ from torch import nn
 
 from .. import ops
 from .Attention import Embedding, Encoder, _f32c, _inference_only
+from .packing import TableCache
 
 
 class SconeVis(nn.Module):
@@ -48,6 +49,7 @@ class SconeVis(nn.Module):
         self.fc2 = nn.Linear(4 * n_harmonics, 2 * n_harmonics)
         self.nonlinear2 = nn.GELU()
         self.fc3 = nn.Linear(2 * n_harmonics, n_harmonics)
+        self._table_cache = TableCache()
 
     # ---- the architecture the fused HIP forward implements (the one every call site builds) ----
     def _is_default_arch(self):
@@ -66,8 +68,10 @@ class SconeVis(nn.Module):
             t += [_f32c(fc.weight), _f32c(fc.bias)]
         return t
 
-    def forward(self, pts, mask=None, view_harmonics=None):
-        """pts [n_clouds, seq_len, 4], view_harmonics [n_clouds, seq_len, 64] -> [n_clouds, seq_len, 64]."""
+    def forward(self, pts, mask=None, view_harmonics=None, lengths=None):
+        """pts [n_clouds, seq_len, 4], view_harmonics [n_clouds, seq_len, 64] -> [n_clouds, seq_len, 64].
+        lengths (extension, optional int32 device tensor [n_clouds]): cloud b is its first lengths[b] rows; the rest of the
+        batch is padding (the reference slices on the host instead, which costs a device->host sync per decision)."""
         _inference_only(self, pts)
         if mask is not None:
             raise NotImplementedError("mask is None in every call site of the hot path (SURVEY §8 a6)")
@@ -76,7 +80,7 @@ class SconeVis(nn.Module):
         if view_harmonics is None:
             raise ValueError("view_harmonics is required (view_state_mode='end')")
         n_clouds, seq_len = pts.shape[0], pts.shape[1]
-        res = ops.scone_vis_forward(pts, view_harmonics, self.weight_table())
+        res = ops.scone_vis_forward(pts, view_harmonics, self._table_cache.get(self, self.weight_table), lengths)
         return res.view(n_clouds, seq_len, self.n_harmonics)
 
     def compute_visibilities(self, pts, harmonics, X_cam):

@@ -93,17 +93,45 @@ def pack_local_pct(pct, variant=1):
     return blob
 
 
+def _param_key(module, cache):
+    """Cheap fingerprint of a module's parameters: the in-place version counter of every parameter plus the storage addresses
+    of the first and last one (optimizer steps / load_state_dict bump the versions, .to(device) moves the storage).  The
+    parameter list is collected once per module (host time of the NBV step: walking 172 parameters through nn.Module's
+    generators cost more than the kernels' launch calls)."""
+    plist = cache.get("plist")
+    if plist is None:
+        plist = cache["plist"] = list(module.parameters())
+    return tuple(p._version for p in plist) + (plist[0].data_ptr(), plist[-1].data_ptr(), len(plist)) if plist else ()
+
+
 class BlobCache:
     """Re-pack only when a parameter changed (data_ptr / version / device)."""
 
     def __init__(self):
-        self._key, self._blob = None, None
+        self._key, self._blob, self._c = None, None, {}
 
     def get(self, pct, variant=1):
-        key = (variant,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in pct.parameters())
+        key = (variant,) + _param_key(pct, self._c)
         if key != self._key:
             self._blob, self._key = pack_local_pct(pct, variant), key
         return self._blob
+
+
+class TableCache:
+    """The weight-pointer table of a module (list of contiguous fp32 tensors + the ctypes array handed to the C ABI), rebuilt
+    only when a parameter changed."""
+
+    def __init__(self):
+        self._key, self._val, self._c = None, None, {}
+
+    def get(self, module, build):
+        key = _param_key(module, self._c)
+        if key != self._key:
+            tensors = build()
+            import ctypes
+            self._val = (tensors, (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors]))
+            self._key = key
+        return self._val
 
 
 def _pack_local_pct3(pct):

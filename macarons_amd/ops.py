@@ -170,8 +170,15 @@ def _workspace(device, nbytes):
 
 
 def _ptr_table(tensors):
+    """tensors: a list of tensors, or a (tensors, ready-made ctypes pointer array) pair from networks.packing.TableCache."""
+    if isinstance(tensors, tuple):
+        return tensors[1]
     arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     return arr
+
+
+def _n_weights(tensors):
+    return len(tensors[0]) if isinstance(tensors, tuple) else len(tensors)
 
 
 def pc_transformer_forward(pc, weights, feature_dim):
@@ -186,12 +193,13 @@ def pc_transformer_forward(pc, weights, feature_dim):
     tab = _ptr_table(weights)
     with torch.cuda.device(pc.device):
         check(L_.mcr_pc_transformer_forward(_p(pc), _p(out), c_i64(S), c_i64(L), c_int(feature_dim), tab,
-                                            c_int(len(weights)), _p(ws), c_size(ws.numel()), _stream()),
+                                            c_int(_n_weights(weights)), _p(ws), c_size(ws.numel()), _stream()),
               "mcr_pc_transformer_forward")
     return out
 
 
-def scone_vis_forward(pts, view_harmonics, weights):
+def scone_vis_forward(pts, view_harmonics, weights, lengths=None):
+    """lengths (optional, int32 device tensor [B]): cloud b = its first lengths[b] rows (padded variable-length batch)."""
     pts, view_harmonics = _req(pts, "pts"), _req(view_harmonics, "view_harmonics")
     B, N, d = pts.shape
     if d != 4 or view_harmonics.shape != (B, N, 64):
@@ -202,9 +210,14 @@ def scone_vis_forward(pts, view_harmonics, weights):
     nb = L_.mcr_scone_vis_workspace_bytes(c_i64(B), c_i64(N))
     ws = _workspace(pts.device, nb)
     tab = _ptr_table(weights)
+    if lengths is not None:
+        lengths = _req(lengths, "lengths", torch.int32).reshape(-1)
+        if lengths.numel() != B:
+            raise ValueError(f"lengths must hold one int32 per cloud ({B}), got {lengths.numel()}")
     with torch.cuda.device(pts.device):
-        check(L_.mcr_scone_vis_forward(_p(pts), _p(view_harmonics), _p(out), c_i64(B), c_i64(N), tab, c_int(len(weights)),
-                                       _p(ws), c_size(ws.numel()), _stream()), "mcr_scone_vis_forward")
+        check(L_.mcr_scone_vis_forward(_p(pts), _p(view_harmonics), _p(out), c_i64(B), c_i64(N), tab, c_int(_n_weights(weights)),
+                                       _p(lengths) if lengths is not None else c_vp(0), _p(ws), c_size(ws.numel()), _stream()),
+              "mcr_scone_vis_forward")
     return out
 
 
@@ -238,7 +251,7 @@ def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_bl
     blobs = (ctypes.c_void_p * 3)(*[_req(b, "local_blob").data_ptr() for b in local_blobs]) if local_blobs else None
     with torch.cuda.device(x.device):
         check(L_.mcr_scone_occ_forward(_p(pc_global), c_i64(Lg), sc_ptrs, sc_m, _p(x), _p(view_harmonics), _p(out), c_i64(B),
-                                       c_i64(Q), tab, c_int(len(weights)), blobs, _p(ws), c_size(ws.numel()), _stream()),
+                                       c_i64(Q), tab, c_int(_n_weights(weights)), blobs, _p(ws), c_size(ws.numel()), _stream()),
               "mcr_scone_occ_forward")
     return out
 
@@ -256,9 +269,11 @@ def view_state(pts, X_view, n_elev, n_azim):
     return out
 
 
-def sample_proxy(X, preds, view_harmonics, u, min_occ, return_volume=False):
+def sample_proxy(X, preds, view_harmonics, u, min_occ, return_volume=False, padded=False):
     """(res [n_u,4], res_harmonics [n_u,64], inverse [n_sample] int64, unique original indices [n_u] int64[, volume]);
-    replaces sample_proxy_points (scone_utils.py:1030-1061).  One host sync to read n_u (torch.unique syncs too)."""
+    replaces sample_proxy_points (scone_utils.py:1030-1061).  One host sync to read n_u (torch.unique syncs too) -- unless
+    padded=True: then res / res_harmonics / uniq keep their n_sample rows (zeros beyond n_u) and the count comes back as an
+    int32 device tensor [1] in place of the slicing: (res, res_harmonics, inverse, uniq, n_unique[, volume]), no host sync."""
     X, preds, vh, u = _req(X, "X"), _req(preds, "preds"), _req(view_harmonics, "view_harmonics"), _req(u, "samples")
     P = X.shape[0]
     n = u.numel()
@@ -275,6 +290,8 @@ def sample_proxy(X, preds, view_harmonics, u, min_occ, return_volume=False):
         check(L_.mcr_sample_proxy(_p(X), _p(preds), c_i64(1), _p(vh), c_i64(P), c_f32(float(min_occ)), _p(u), c_int(n),
                                   _p(res), _p(resh), _p(uniq), _p(inv), _p(nu), _p(vol), _p(ws), c_size(ws.numel()), _stream()),
               "mcr_sample_proxy")
+    if padded:
+        return (res, resh, inv, uniq, nu, vol) if return_volume else (res, resh, inv, uniq, nu)
     k = int(nu.item())
     if return_volume:
         return res[:k], resh[:k], inv, uniq[:k], vol

@@ -141,9 +141,10 @@ def filter_proxy_points(view_cameras, X, pc, filter_tol=0.01):
 
 
 def sample_proxy_points(X_world, preds, view_harmonics, n_sample, min_occ, use_occ_to_sample=True, return_index=False,
-                        samples=None):
+                        samples=None, padded=False):
     """scone_utils.py:1030-1076.  `samples` (optional, [n_sample]) pins the uniforms; otherwise they are drawn with
-    torch.rand(n_sample, 1, device=...) like the reference (:1052)."""
+    torch.rand(n_sample, 1, device=...) like the reference (:1052).  padded=True (extension): no host sync -- returns
+    (res [n_sample,4], res_h [n_sample,64], inverse_idx, n_unique int32 device tensor [1]) with zero rows beyond n_unique."""
     if not use_occ_to_sample:
         mask = preds[..., 0] > min_occ
         res_X, res_preds, res_h = X_world[mask][:n_sample], preds[mask][:n_sample], view_harmonics[mask][:n_sample]
@@ -151,5 +152,9 @@ def sample_proxy_points(X_world, preds, view_harmonics, n_sample, min_occ, use_o
         return (res, res_h, None) if return_index else (res, res_h)
     if samples is None:
         samples = torch.rand(n_sample, 1, device=X_world.device)
+    if padded:
+        res, res_h, inverse_idx, _, nu = ops.sample_proxy(X_world, preds.reshape(-1), view_harmonics, samples.reshape(-1), min_occ,
+                                                          padded=True)
+        return res, res_h, inverse_idx, nu
     res, res_h, inverse_idx, _ = ops.sample_proxy(X_world, preds.reshape(-1), view_harmonics, samples.reshape(-1), min_occ)
     return (res, res_h, inverse_idx) if return_index else (res, res_h)

@@ -227,3 +227,23 @@ def test_scone_occ_fused_equals_unfused(dev):
         m.fused_local = False
         y0 = m(pc, x, vh, perms=perms).cpu().numpy()
     assert rel_err(y1, g[f"{tag}_y"]) < TOL and rel_err(y0, g[f"{tag}_y"]) < TOL
+
+
+def test_scone_vis_padded_lengths_equal_sliced(dev):
+    """SconeVis.forward(lengths=...) on a zero/garbage-padded batch == the forward on the sliced clouds: the cloud-wide max of
+    the embedding and the attention keys stop at lengths[b] (this is what lets the NBV step keep the number of unique sampled
+    points on the device)."""
+    from macarons_amd.networks import SconeVis
+    m, _ = _mod(SconeVis, 1, dev)
+    rng = np.random.default_rng(12)
+    N, lens = 700, [700, 333, 64, 1]
+    pts = np.concatenate([rng.uniform(-0.5, 0.5, (4, N, 3)), rng.uniform(0.1, 1.0, (4, N, 1))], -1).astype(np.float32)
+    vh = (rng.standard_normal((4, N, 64)) * 0.3).astype(np.float32)
+    for b, n in enumerate(lens):                         # padding: zeros for one cloud, large garbage for the others
+        pts[b, n:] = 0.0 if b == 1 else 1e3
+        vh[b, n:] = 0.0 if b == 1 else -7.0
+    with torch.no_grad():
+        y = m(T(pts, dev), view_harmonics=T(vh, dev), lengths=torch.tensor(lens, dtype=torch.int32, device=dev)).cpu().numpy()
+        for b, n in enumerate(lens):
+            yb = m(T(pts[b:b + 1, :n], dev), view_harmonics=T(vh[b:b + 1, :n], dev)).cpu().numpy()
+            assert np.array_equal(y[b, :n], yb[0]), (b, n, np.abs(y[b, :n] - yb[0]).max())
