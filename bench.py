@@ -7,21 +7,27 @@ Metric (BASELINE.json): candidate-camera coverage-gain evals/sec (100k pts, 200 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Two quantities are reported:
-  (A) `value`: scorer throughput.  A "step" = one pass of the scorer (SconeVis.compute_coverage_gain semantics) over one synthetic cloud of
-100 000 points x 200 candidate cameras per GPU, inputs already resident in HBM, followed (N>1) by the
-all-gather of each rank's (best gain, camera index).  One (cloud, camera) pair scored = one eval.
-Weak scaling: each rank owns a disjoint shard of 200 candidate cameras of the same cloud (the reference
-scores all cameras on one GPU).
+What one run reports, with no extra flags, at any N:
+  (A)  `value` — the contract line: scorer throughput, WEAK scaling.  A "step" = one pass of the scorer
+       (SconeVis.compute_coverage_gain semantics) over one synthetic cloud of 100 000 points x 200 candidate cameras per GPU,
+       inputs resident in HBM, followed by the arg-max decision record (N > 1: the all-gather of every rank's record).
+       One (cloud, camera) pair scored = one eval.
+  (A') `scorer_strong` — BASELINE config 4: the same cloud x 512 cameras IN TOTAL, block-partitioned over the ranks
+       (512 / N per rank), same decision exchange: strong scaling of the scorer.
+  (B)  `nbv_step` — p50 latency of the full SCONE NBV decision (macarons_amd.nbv.nbv_step: view state + harmonics on Q = 100k
+       proxy points -> SconeOcc vs M = 10 240 surface points -> sample 2048 -> SconeVis -> gains over C = 200 cameras -> arg-max),
+       device-synchronised per iteration, random-init weights; with N GPUs the queries and the cameras are sharded over the ranks
+       (strong scaling of one decision) and the occupancies / records travel over RCCL.
+  `ranks_seen` — how many distinct ranks an RCCL all-gather of the rank ids returned (proof the collective path ran at N).
 
-  (B) `nbv_step`: p50 latency of the full SCONE NBV decision (macarons_amd.nbv.nbv_step: view state + harmonics on
-      Q = 100k proxy points -> SconeOcc vs M = 10 240 surface points -> sample 2048 -> SconeVis -> gains over C = 200
-      cameras -> arg-max), device-synchronised per iteration, random-init weights; with N GPUs the queries and the
-      cameras are sharded (strong scaling of one decision).
-
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel (sh_gain_kernel) algorithmic flop rate vs the fp32 vector peak
-  cpu_baseline — the plain-C port of the reference scorer (oracle/csrc) timed on the host cores
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline              dominant kernel of (A), sh_gain_kernel, timed ALONE with HIP events (K launches of the first stage only):
+                        algorithmic flop per launch / its mean duration vs the fp32 vector peak; the step-level figure
+                        (gain + reduce + decision record per step) sits beside it as `step_*`
+  roofline_nbv_dominant dominant kernel of (B), the fused local transformer: executed matrix-pipe rate vs the fp16 dense peak
+                        (`frac`) and the algorithmic fp32-equivalent rate vs the same pipe (`frac_algorithmic`)
+  cpu_baseline          the plain-C port of the reference scorer (oracle/csrc, pinned to the reference's goldens) on the host cores
+  cpu_baseline_nbv      the numpy restatement of the NBV step (oracle/nbv.py, pinned likewise) on a bounded sample of the queries
 """
 import argparse
 import json
@@ -38,6 +44,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_PAIR = 370.0          # algorithmic flop per (point, camera) pair
 BYTES_PER_POINT = 268.0        # 12 B xyz + 256 B coefficients, read once per cloud
 PEAK_FP32_TFLOPS = 157.3       # MI355X fp32 vector (= fp32 MFMA) peak, MI355X_MICROARCH.md
+PEAK_F16_TFLOPS = 2500.0       # dense fp16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 
 
@@ -74,26 +81,70 @@ def cpu_baseline(pts, harm, cams):
                       f"host has {os.cpu_count()} cores"}, g
 
 
-def pmc_traffic_bytes():
-    """HBM read bytes per launch of the scorer kernel from the committed PMC pass (None if the profile is absent)."""
+def cpu_baseline_nbv(C):
+    """The numpy restatement of one NBV decision (oracle/nbv.py) on a bounded sample: the same surface cloud (M = 10 240), the
+    same C cameras, Q_s = 6000 of the 100 000 proxy points.  The occupancy pass is linear in Q (every query is independent), so
+    the full-size figure is extrapolated from two sample sizes and labelled as such."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import io, contextlib
+    import weights
+    from oracle import nbv as onbv
+    from macarons_amd.networks import SconeVis, SconeOcc
+    with contextlib.redirect_stdout(io.StringIO()):
+        occ, vis = SconeOcc(), SconeVis()
+    sdo = weights.make_state_dict(weights.shapes_of(occ), 2)
+    sdv = weights.make_state_dict(weights.shapes_of(vis), 1)
+    sdo["linear3.bias"] = sdo["linear3.bias"] + np.float32(0.5)
+    rng = np.random.default_rng(4321)
+    M = 10_240
+    d = rng.standard_normal((M, 3))
+    pc = (d / np.linalg.norm(d, axis=1, keepdims=True) * [0.35, 0.25, 0.3]).astype(np.float32)[None]
+    cams = rng.standard_normal((C, 3)).astype(np.float32)
+    cams = (1.5 * cams / np.linalg.norm(cams, axis=1, keepdims=True)).astype(np.float32)
+    u = rng.uniform(0, 1, 2048).astype(np.float32)
+    torch.manual_seed(11)
+    perms = [p.numpy() for p in occ.draw_perms(M)]
+    times = {}
+    for Q in (1500, 6000):
+        X = rng.uniform(-.5, .5, (1, Q, 3)).astype(np.float32)
+        t0 = time.perf_counter()
+        onbv.nbv_step(sdo, sdv, pc, X, cams[:3], cams, perms, u)
+        times[Q] = time.perf_counter() - t0
+    per_q = (times[6000] - times[1500]) / 4500.0
+    fixed = max(times[1500] - 1500 * per_q, 0.0)
+    full = fixed + 100_000 * per_q
+    return {"value": C / times[6000], "unit": "evals/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"numpy restatement of the NBV step (oracle/nbv.py; BLAS threads as numpy picks them, host has "
+                      f"{os.cpu_count()} cores): M=10240 surface points, C={C} cameras, Q_s=6000 of the 100000 proxy points: "
+                      f"{times[6000]:.2f} s (Q_s=1500: {times[1500]:.2f} s)",
+            "sample_step_s": times[6000], "per_query_ms": per_q * 1e3, "fixed_s": fixed,
+            "extrapolated_full_step_s": full, "extrapolated_full_evals_per_s": C / full,
+            "note": "extrapolation = fixed + 100000 x per-query cost from the two sample sizes; not a measurement of the full step"}
+
+
+def pmc_profile(name):
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_scorer_pmc.json")) as f:
-            return float(json.load(f)["hbm_read_bytes_per_launch_corrected"])
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
     except Exception:
         return None
 
 
-def measure_nbv_step(dev, rank, world, args):
-    """(B) p50 latency of one NBV decision at Q=100k / M=10240 / C=200 (sharded over `world` GPUs)."""
+def build_models(dev):
     from macarons_amd.networks import SconeVis, SconeOcc
-    from macarons_amd.nbv import nbv_step, ViewStateGrid
     import io, contextlib
     torch.manual_seed(7)                                   # identical random-init weights on every rank
     with contextlib.redirect_stdout(io.StringIO()):
         occ, vis = SconeOcc(), SconeVis()
     with torch.no_grad():
         occ.linear3.bias += 0.5                            # untrained occupancies must pass min_occ (SURVEY §8c)
-    occ, vis = occ.to(dev).eval(), vis.to(dev).eval()
+    return occ.to(dev).eval(), vis.to(dev).eval()
+
+
+def measure_nbv_step(dev, rank, world, args):
+    """(B) p50 latency of one NBV decision at Q=100k / M=10240 / C=cams, queries and cameras sharded over `world` GPUs."""
+    from macarons_amd.nbv import nbv_step, ViewStateGrid
+    occ, vis = build_models(dev)
     g = torch.Generator(device="cpu").manual_seed(4321)
     Q, M, C = 100_000, 10_240, args.cams
     d = torch.randn(M, 3, generator=g)
@@ -107,8 +158,9 @@ def measure_nbv_step(dev, rank, world, args):
     torch.manual_seed(11)
     perms = [p.to(dev) for p in occ.draw_perms(M)]       # the three randperm draws of SconeOcc.forward, pinned and resident
     group = torch.distributed.group.WORLD if torch.distributed.is_initialized() else None     # shards Q and C over the ranks
+    n_warm = 10
     times = []
-    for it in range(10 + args.nbv_iters):
+    for it in range(n_warm + args.nbv_iters):
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -121,10 +173,11 @@ def measure_nbv_step(dev, rank, world, args):
             tw = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
             dt = float(tw.item())
-        if it >= 10:
+        if it >= n_warm:
             times.append(dt)
     p50 = float(np.median(times))
     return {"p50_ms": p50 * 1e3, "p90_ms": float(np.percentile(times, 90)) * 1e3, "evals_per_s": C / p50, "iters": len(times),
+            "scaling": "strong",
             "config": {"proxy_points": Q, "surface_points": M, "cams": C, "seq_len": 2048, "dtype": "f32",
                        "parallelism": f"query+camera shard x{world}"},
             "algorithmic_TFLOP": 26.5e6 * Q / 1e12 + 0.0037 + 0.0137, "nbv_idx": int(r["nbv_idx"]), "n_unique": int(r["n_unique"])}
@@ -132,9 +185,9 @@ def measure_nbv_step(dev, rank, world, args):
 
 def measure_local_pct(dev):
     """Roofline of the dominant kernel of the NBV step (fused local transformer): HIP events around back-to-back
-    launches on the launch stream.  Default kernel = split-precision bf16x6 (local_pct5.hip): every algorithmic
-    fp32 multiply-add runs as 6 bf16 MFMA multiply-adds, so the matrix pipe executes 6x the algorithmic GEMM flops and
-    is priced against the dense bf16 MFMA peak; the exact-fp32-MFMA kernel (local_pct.hip) is timed beside it."""
+    launches on the launch stream.  Default kernel = two-term fp16 split (local_pct6.hip): every algorithmic fp32 multiply-add
+    runs as 3 fp16 MFMA multiply-adds, so the matrix pipe executes 3x the algorithmic GEMM flops; both the executed rate and the
+    algorithmic (fp32-equivalent) rate are priced against the dense fp16 MFMA peak.  The exact-fp32-MFMA kernel is timed beside."""
     import ctypes
     from macarons_amd import ops, _lib
     from macarons_amd.networks import SconeOcc
@@ -164,18 +217,52 @@ def measure_local_pct(dev):
         out[v] = e0.elapsed_time(e1) / n
     L.mcr_set_local_pct_variant(ctypes.c_int(default_variant))
     ms = out[default_variant]
-    if default_variant in (3, 4, 5):
-        executed = 6.0 * gemm_flops / (ms * 1e-3) / 1e12
-        peak, kern, note = 2500.0, f"local_pct{default_variant}_kernel", "bf16 MFMA dense peak 2.5 PFLOP/s; 6 bf16 MFMAs per exact fp32 product"
+    mult = {6: 3.0, 5: 6.0}.get(default_variant, 1.0)
+    if default_variant in (5, 6):
+        peak = PEAK_F16_TFLOPS
+        kern = f"local_pct{default_variant}_kernel"
+        note = (f"dense fp16/bf16 MFMA peak 2.5 PFLOP/s; {int(mult)} MFMAs per fp32 product (split precision): `frac` = executed "
+                f"matrix-pipe flops / peak, `frac_algorithmic` = algorithmic fp32-equivalent flops / the same peak")
     else:
-        executed = gemm_flops / (ms * 1e-3) / 1e12
         peak, kern, note = PEAK_FP32_TFLOPS, "local_pct_kernel", "fp32 MFMA (v_mfma_f32_32x32x2_f32) peak = 157.3 TFLOP/s"
+    executed = mult * gemm_flops / (ms * 1e-3) / 1e12
+    alg = alg_flops / (ms * 1e-3) / 1e12
     return {"kernel": kern, "bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak,
-            "traffic": None, "device_ms_per_launch": ms, "queries_per_launch": S,
-            "algorithmic_fp32_TFLOPs": alg_flops / (ms * 1e-3) / 1e12, "note": note,
+            "achieved_algorithmic": alg, "frac_algorithmic": alg / peak, "algorithmic_vs_fp32_mfma_peak": alg / PEAK_FP32_TFLOPS,
+            "traffic": None, "device_ms_per_launch": ms, "queries_per_launch": S, "note": note,
             "exact_fp32_mfma_variant": {"kernel": "local_pct_kernel", "device_ms_per_launch": out[1],
                                         "achieved": gemm_flops / (out[1] * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
                                         "frac": gemm_flops / (out[1] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}}
+
+
+def timed_scorer_loop(step, finish, steps, warmup, dev, dist):
+    """W untimed + exactly `steps` timed calls of step(), bracketed by barrier + synchronize on both sides; returns
+    (wall seconds = max over ranks, device ms between HIP events on the launch stream)."""
+    for _ in range(warmup):
+        step()
+    finish(None)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    out = None
+    for _ in range(steps):
+        out = step()
+    out = finish(out)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tw = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    return wall, ev0.elapsed_time(ev1), out
 
 
 def main():
@@ -185,11 +272,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--points", type=int, default=100_000)
     ap.add_argument("--cams", type=int, default=200)
+    ap.add_argument("--strong-cams", type=int, default=512, help="total cameras of the strong-scaling scorer run (config 4)")
     ap.add_argument("--waves-per-simd", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nbv", action="store_true", help="skip the NBV-step latency measurement")
     ap.add_argument("--nbv-iters", type=int, default=50)
-    ap.add_argument("--nbv-multi", action="store_true", help="also time the query/camera-sharded NBV step when --gpus > 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -210,57 +297,94 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from macarons_amd import ops
+    from macarons_amd import dist as mdist
     N, C = args.points, args.cams
-    # every rank: same cloud, its own shard of C cameras out of world*C (weak scaling)
+
+    ranks_seen = 1
+    if dist is not None:                                   # every rank's id through an RCCL all-gather
+        ids = torch.empty(world, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int32, device=dev))
+        ranks_seen = int(torch.unique(ids).numel())
+
+    def scorer_run(pts, harm, cams, cam_offset, steps, warmup):
+        pipe = mdist.PipelinedBest(1, dev, batch=16, depth=3) if dist is not None else None
+
+        def step():
+            gains = ops.sh_coverage_gain(pts, harm, cams, True, args.waves_per_simd)
+            if pipe is not None:                           # records of 16 decisions per all-gather, on a side stream
+                return pipe.submit(gains, cam_offset)
+            return ops.best_record(gains)                  # [B,2] = (max gain, arg-max camera): the decision (torch.max semantics)
+
+        def finish(handle):
+            if pipe is None:
+                return handle
+            pipe.flush()
+            return pipe.result(handle) if handle is not None else None    # the last decision (and all earlier ones) is complete
+        return timed_scorer_loop(step, finish, steps, warmup, dev, dist)
+
+    # ---- (A) weak scaling: every rank its own shard of C cameras out of world*C -------------------------------------------
     pts, harm, cams = make_inputs(N, C, 1234, dev, cam_offset=rank * C, n_cam_total=world * C)
+    wall, dev_ms, _ = scorer_run(pts, harm, cams, rank * C, args.steps, args.warmup)
 
-    pipe = None
-    if use_dist:
-        # the arg-max exchanges are batched (16 decisions per all-gather) and run on a side stream under the next scoring passes
-        from macarons_amd import dist as mdist
-        pipe = mdist.PipelinedBest(1, dev, batch=16, depth=3)
+    # ---- (A') strong scaling, BASELINE config 4: strong_cams cameras in total, block-partitioned ---------------------------
+    Cs = args.strong_cams
+    c0, c1 = mdist.shard_range(Cs, rank, world)
+    _, _, cams_s = make_inputs(N, Cs, 1234, dev)
+    cams_s = cams_s[:, c0:c1].contiguous()
+    s_steps, s_warm = max(20, min(args.steps, 500)), max(5, min(args.warmup, 50))
+    strong = None
+    if c1 > c0:
+        wall_s, _, _ = scorer_run(pts, harm, cams_s, c0, s_steps, s_warm)
+    else:                                                  # more ranks than cameras cannot happen at 512 cameras; keep the barriers aligned
+        wall_s, _, _ = timed_scorer_loop(lambda: None, lambda h: h, s_steps, s_warm, dev, dist)
+    strong = {"metric": f"coverage-gain evals/s, N={N} points x {Cs} cameras in total (BASELINE config 4), strong scaling",
+              "value": Cs * s_steps / wall_s, "unit": "evals/s", "steps": s_steps, "warmup": s_warm,
+              "ms_per_step": wall_s * 1e3 / s_steps, "cams_total": Cs, "cams_this_rank": c1 - c0, "scaling": "strong"}
 
-    def step():
-        gains = ops.sh_coverage_gain(pts, harm, cams, True, args.waves_per_simd)
-        if pipe is not None:
-            return pipe.submit(gains, rank * C)
-        return ops.best_record(gains)                        # [B,2] = (max gain, arg-max camera): the decision (torch.max semantics)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    # ---- dominant kernel alone: sh_gain_kernel (first stage of the scorer), HIP events around back-to-back launches -------
+    kern_ms = None
+    if rank == 0:
+        for _ in range(20):
+            ops.sh_coverage_gain_partials(pts, harm, cams, True, args.waves_per_simd)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nk = 300
+        e0.record()
+        for _ in range(nk):
+            ops.sh_coverage_gain_partials(pts, harm, cams, True, args.waves_per_simd)
+        e1.record()
+        torch.cuda.synchronize()
+        kern_ms = e0.elapsed_time(e1) / nk
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        out = step()
-    if pipe is not None:
-        pipe.flush()
-        out = pipe.result(out)                               # the last decision (and with it all earlier ones) is complete
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        tw = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
-    dev_ms = ev0.elapsed_time(ev1)                 # HIP events on the launch stream (torch current stream)
 
-    # the sharded NBV step at N > 1 is opt-in: the contract line is the scorer step above
-    nbv = measure_nbv_step(dev, rank, world, args) if (not args.no_nbv and (world == 1 or args.nbv_multi)) else None
+    # ---- (B) the NBV step, sharded over the ranks ----------------------------------------------------------------------------
+    nbv = measure_nbv_step(dev, rank, world, args) if not args.no_nbv else None
     lp = measure_local_pct(dev) if (rank == 0 and not args.no_nbv) else None
+    if dist is not None:
+        dist.barrier()
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         evals_per_s = world * C * args.steps / wall
-        kern_ms = dev_ms / args.steps              # per-launch device time of the scorer pass
-        achieved = N * C * FLOP_PER_PAIR / (kern_ms * 1e-3) / 1e12
+        step_ms = dev_ms / args.steps              # device time of one whole step (gain + reduce + decision record)
+        alg_flop = N * C * FLOP_PER_PAIR
+        achieved = alg_flop / (kern_ms * 1e-3) / 1e12
+        pmc = pmc_profile("r02_scorer_pmc.json") or pmc_profile("r01_scorer_pmc.json") or {}
+        valu = (pmc.get("per_dispatch_mean") or {}).get("SQ_INSTS_VALU")
+        roof = {"bound": "valu-fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS, "kernel": "sh_gain_kernel<true>", "device_ms_per_launch": kern_ms,
+                "timing": "HIP events around 300 back-to-back launches of the kernel alone (mcr_sh_coverage_gain_partials)",
+                "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes": N * BYTES_PER_POINT,
+                "traffic": pmc.get("hbm_read_bytes_per_launch_corrected"),
+                "traffic_source": "profiles/*_scorer_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 per MI355X_MICROARCH.md, own pass)",
+                "hbm_algorithmic_GBs": N * BYTES_PER_POINT / (kern_ms * 1e-3) / 1e9,
+                "step_device_ms": step_ms, "step_achieved": alg_flop / (step_ms * 1e-3) / 1e12,
+                "step_frac": alg_flop / (step_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
+        if valu:
+            # wave-level vector instructions issued per launch (PMC) x 2 cycles each (a SIMD retires 32 fp32 lanes per cycle:
+            # 157.3 TFLOP/s = 1024 SIMDs x 2.4 GHz x 64 flop) / (SIMDs x kernel cycles at 2.4 GHz)
+            roof["valu_issue_utilisation"] = valu * 2.0 / (1024 * kern_ms * 1e-3 * 2.4e9)
+            roof["valu_insts_per_launch"] = valu
         res = {
             "metric": "candidate-camera coverage-gain evals/sec (100k pts, 200 cams)",
             "value": evals_per_s, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -269,12 +393,9 @@ def main():
             "config": {"workload": f"scorer: B=1 cloud x N={N} points x C={C} cameras per GPU "
                                    f"(BASELINE headline 100k pts / 200 cams), inputs resident in HBM",
                        "points": N, "cams_per_gpu": C, "parallelism": f"camera-shard x{world}"},
-            "roofline": {"bound": "valu-fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": pmc_traffic_bytes(),
-                         "traffic_source": "profiles/r01_scorer_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 per MI355X_MICROARCH.md, own pass)",
-                         "algorithmic_bytes": N * BYTES_PER_POINT,
-                         "kernel": "sh_gain_kernel<true>", "device_ms_per_launch": kern_ms,
-                         "hbm_algorithmic_GBs": N * BYTES_PER_POINT / (kern_ms * 1e-3) / 1e9},
+            "ranks_seen": ranks_seen,
+            "roofline": roof,
+            "scorer_strong": strong,
         }
         if nbv is not None:
             res["nbv_step"] = nbv
@@ -286,9 +407,16 @@ def main():
             res["cpu_baseline"] = cb
             g_gpu = ops.sh_coverage_gain(pts, harm, cams[:, :n_s].contiguous()).cpu().numpy()
             res["cpu_baseline"]["max_rel_diff_vs_gpu"] = float(np.abs(g_gpu - g_cpu).max() / np.abs(g_cpu).max())
-        print(json.dumps(res))
+            if not args.no_nbv:
+                res["cpu_baseline_nbv"] = cpu_baseline_nbv(C)
+        line = json.dumps(res)
+    else:
+        line = None
     if dist is not None:
-        dist.destroy_process_group()
+        dist.destroy_process_group()       # RCCL prints its version banner to stdout on the way out: keep the JSON the LAST line
+    sys.stdout.flush()
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

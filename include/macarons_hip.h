@@ -37,6 +37,11 @@ size_t mcr_sh_coverage_gain_workspace_bytes(int64_t B, int64_t N, int64_t C);
 int mcr_sh_coverage_gain(const float* pts, int pts_dim, const float* harmonics, const float* cams, float* gains,
                          int64_t B, int64_t N, int64_t C, int use_sigmoid, int waves_per_simd, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* First stage of mcr_sh_coverage_gain alone (sh_gain_kernel: per-(wave tile, camera) partial sums left in `workspace`), so that
+ * the dominant kernel can be timed by itself (bench.py roofline); same arguments minus `gains`. */
+int mcr_sh_coverage_gain_partials(const float* pts, int pts_dim, const float* harmonics, const float* cams, int64_t B, int64_t N,
+                                  int64_t C, int use_sigmoid, int waves_per_simd, void* workspace, size_t workspace_bytes,
+                                  void* stream);
 
 /* Replaces SconeVis.compute_visibilities (SconeVis.py:164-208) == Macarons.compute_visibility_gains
  * (macarons/networks/Macarons.py:138-178): the same without the mean.  vis [B,C,N]. */

@@ -501,29 +501,38 @@ using namespace mcr;
 // ---- arg-max exchange records (multi-GPU camera sharding, testers/shapenet.py:172 = torch.max over cameras) ------------
 // record[b] = (max_c gains[b,c], idx_offset + first arg-max) as two fp32 (camera indices < 2^24 are exact): one 8-byte record
 // per cloud is what the ranks all-gather.  One wave per cloud; ties -> lowest index like torch.max.
+// torch.max ordering: NaN beats every number (the first NaN wins), otherwise the larger value, ties to the lower index.
+__device__ __forceinline__ bool best_before(float v, float i, float bv, float bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn != bn) return vn;
+    if (!vn && v != bv) return v > bv;
+    return i < bi;
+}
+
 __global__ __launch_bounds__(64) void best_record_kernel(const float* __restrict__ gains, int C, long long idx_offset,
                                                          float* __restrict__ rec) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const float* g = gains + (size_t)b * C;
-    float bv = -__builtin_inff();
-    int bi = 0x7fffffff;
-    for (int c = lane; c < C; c += 64) {
+    // start from the lane's first column, so that a row of -inf (or NaN) still yields a valid index like torch.max does
+    float bv = lane < C ? g[lane] : -__builtin_inff();
+    float bi = lane < C ? (float)lane : 3.0e38f;
+    for (int c = lane + 64; c < C; c += 64) {
         const float v = g[c];
-        if (v > bv) { bv = v; bi = c; }                      // strided scan keeps the lowest index per lane
+        if (best_before(v, (float)c, bv, bi)) { bv = v; bi = (float)c; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        const float ov = __shfl_xor(bv, o, 64), oi = __shfl_xor(bi, o, 64);
+        if (best_before(ov, oi, bv, bi)) { bv = ov; bi = oi; }
     }
     if (lane == 0) {
         rec[2 * b] = bv;
-        rec[2 * b + 1] = (float)(idx_offset + bi);
+        rec[2 * b + 1] = (float)idx_offset + bi;               // camera indices < 2^24 are exact in fp32
     }
 }
 
-// recs [world, B, 2] -> (vals[b], idx[b]) of the global arg-max; ties -> lowest camera index.
+// recs [world, B, 2] -> (vals[b], idx[b]) of the global arg-max; ties -> lowest camera index.  A rank with an empty camera shard
+// contributes (-inf, 3e38): it never wins against a rank that scored anything.
 __global__ __launch_bounds__(64) void best_merge_kernel(const float* __restrict__ recs, int world, int B, float* __restrict__ vals,
                                                         long long* __restrict__ idx) {
     const int b = blockIdx.x * 64 + threadIdx.x;
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(64) void best_merge_kernel(const float* __restrict_
     float bv = recs[2 * b], bi = recs[2 * b + 1];
     for (int r = 1; r < world; ++r) {
         const float v = recs[((size_t)r * B + b) * 2], i = recs[((size_t)r * B + b) * 2 + 1];
-        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        if (best_before(v, i, bv, bi)) { bv = v; bi = i; }
     }
     vals[b] = bv;
     idx[b] = (long long)bi;

@@ -255,16 +255,15 @@ size_t mcr_sh_coverage_gain_workspace_bytes(int64_t B, int64_t N, int64_t C) {
     return (size_t)B * (size_t)cdiv(N, MCR_WAVE) * (size_t)C * sizeof(float);
 }
 
-int mcr_sh_coverage_gain(const float* pts, int pts_dim, const float* harmonics, const float* cams, float* gains,
-                         int64_t B, int64_t N, int64_t C, int use_sigmoid, int waves_per_simd, void* workspace,
-                         size_t workspace_bytes, void* stream) {
-    MCR_REQUIRE(pts && harmonics && cams && gains, "mcr_sh_coverage_gain: null pointer");
-    MCR_REQUIRE(pts_dim >= 3, "mcr_sh_coverage_gain: pts_dim must be >= 3 (got %d)", pts_dim);
-    MCR_REQUIRE(B > 0 && N > 0 && C > 0, "mcr_sh_coverage_gain: empty problem B=%ld N=%ld C=%ld", (long)B, (long)N, (long)C);
-    MCR_REQUIRE(C <= 65535 * 64 && N < (1ll << 31) && B <= 65535, "mcr_sh_coverage_gain: problem too large");
-    MCR_REQUIRE(waves_per_simd >= 0 && waves_per_simd <= 16, "mcr_sh_coverage_gain: waves_per_simd out of range");
-    MCR_REQUIRE(workspace && workspace_bytes >= mcr_sh_coverage_gain_workspace_bytes(B, N, C),
-                "mcr_sh_coverage_gain: workspace too small");
+static int sh_gain_impl(const char* who, bool reduce, const float* pts, int pts_dim, const float* harmonics, const float* cams,
+                        float* gains, int64_t B, int64_t N, int64_t C, int use_sigmoid, int waves_per_simd, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    MCR_REQUIRE(pts && harmonics && cams && (gains || !reduce), "%s: null pointer", who);
+    MCR_REQUIRE(pts_dim >= 3, "%s: pts_dim must be >= 3 (got %d)", who, pts_dim);
+    MCR_REQUIRE(B > 0 && N > 0 && C > 0, "%s: empty problem B=%ld N=%ld C=%ld", who, (long)B, (long)N, (long)C);
+    MCR_REQUIRE(C <= 65535 * 64 && N < (1ll << 31) && B <= 65535, "%s: problem too large", who);
+    MCR_REQUIRE(waves_per_simd >= 0 && waves_per_simd <= 16, "%s: waves_per_simd out of range", who);
+    MCR_REQUIRE(workspace && workspace_bytes >= mcr_sh_coverage_gain_workspace_bytes(B, N, C), "%s: workspace too small", who);
     static int cache_sig = 0, cache_relu = 0;
     const int resident = use_sigmoid ? resident_waves_cached(sh_gain_kernel<true>, waves_per_simd, &cache_sig)
                                      : resident_waves_cached(sh_gain_kernel<false>, waves_per_simd, &cache_relu);
@@ -281,10 +280,25 @@ int mcr_sh_coverage_gain(const float* pts, int pts_dim, const float* harmonics, 
         hipLaunchKernelGGL(sh_gain_kernel<false>, grid, dim3(SC_BLOCK), 0, s, pts, pts_dim, harmonics, cams, partial,
                            (int)N, (int)C, n_wtiles, U, W);
     MCR_LAUNCH_CHECK("sh_gain_kernel");
+    if (!reduce) return 0;
     hipLaunchKernelGGL(sh_reduce_kernel, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, partial, gains, n_wtiles, (int)C,
                        1.0f / (float)N);
     MCR_LAUNCH_CHECK("sh_reduce_kernel");
     return 0;
+}
+
+int mcr_sh_coverage_gain(const float* pts, int pts_dim, const float* harmonics, const float* cams, float* gains,
+                         int64_t B, int64_t N, int64_t C, int use_sigmoid, int waves_per_simd, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    return sh_gain_impl("mcr_sh_coverage_gain", true, pts, pts_dim, harmonics, cams, gains, B, N, C, use_sigmoid, waves_per_simd,
+                        workspace, workspace_bytes, stream);
+}
+
+int mcr_sh_coverage_gain_partials(const float* pts, int pts_dim, const float* harmonics, const float* cams, int64_t B, int64_t N,
+                                  int64_t C, int use_sigmoid, int waves_per_simd, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    return sh_gain_impl("mcr_sh_coverage_gain_partials", false, pts, pts_dim, harmonics, cams, nullptr, B, N, C, use_sigmoid,
+                        waves_per_simd, workspace, workspace_bytes, stream);
 }
 
 int mcr_sh_visibilities(const float* pts, int pts_dim, const float* harmonics, const float* cams, float* vis,

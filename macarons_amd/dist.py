@@ -26,7 +26,7 @@ def allgather_argmax(best_vals, best_global_idx, group=None):
     Ties -> lowest camera index (torch.max's first-occurrence rule, testers/shapenet.py:172)."""
     world = dist.get_world_size(group)
     B = best_vals.shape[0]
-    key = (best_vals.device, B, world)
+    key = (best_vals.device, B, world, id(group))
     if key not in _bufs:
         _bufs[key] = (torch.empty(B, 2, dtype=torch.float32, device=best_vals.device),
                       torch.empty(world, B, 2, dtype=torch.float32, device=best_vals.device))
@@ -37,8 +37,9 @@ def allgather_argmax(best_vals, best_global_idx, group=None):
     dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
     vals = recv[:, :, 0]                      # [world, B]
     idx = recv[:, :, 1]
-    vmax = vals.max(dim=0).values             # [B]
-    cand = torch.where(vals == vmax[None], idx, torch.full_like(idx, float("inf")))
+    vmax = vals.max(dim=0).values             # [B]  (NaN if any rank holds one, like torch.max over the full row)
+    same = (vals == vmax[None]) | (torch.isnan(vals) & torch.isnan(vmax)[None])
+    cand = torch.where(same, idx, torch.full_like(idx, float("inf")))
     best_idx = cand.min(dim=0).values
     return vmax, best_idx.to(torch.int64)
 
@@ -61,13 +62,20 @@ def allgather_best(gains, idx_offset, group=None):
     """gains [B, C_local] of this rank's camera shard (global index of column 0 = idx_offset) -> (max_gain [B], nbv_idx [B])
     over all ranks' shards, identical on every rank.  On a HIP device: one record kernel, one all-gather of 8 B per cloud,
     one merge kernel (ops.best_record / ops.best_merge); on CPU tensors (gloo tests of the host logic) plain torch."""
-    if not gains.is_cuda:
+    B = gains.shape[0]
+    if gains.shape[1] == 0:                       # empty camera shard (C < world): join the exchange with a record that cannot win
+        send_v = torch.full((B,), float("-inf"), dtype=torch.float32, device=gains.device)
+        if not gains.is_cuda:
+            return allgather_argmax(send_v, torch.full((B,), 2 ** 24, dtype=torch.int64), group)
+    elif not gains.is_cuda:
         best = torch.max(gains, dim=1)
         return allgather_argmax(best.values, best.indices + idx_offset, group)
     from . import ops
     world = dist.get_world_size(group)
-    B = gains.shape[0]
-    send = ops.best_record(gains, idx_offset)
+    if gains.shape[1] == 0:
+        send = torch.stack((send_v, torch.full_like(send_v, 3.0e38)), dim=1).contiguous()
+    else:
+        send = ops.best_record(gains, idx_offset)
     recv = torch.empty((world, B, 2), dtype=torch.float32, device=gains.device)
     dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
     return ops.best_merge(recv)

@@ -9,6 +9,8 @@ all-gathers the occupancies; sampling and SconeVis (cheap, N <= 2048) run redund
 C candidate cameras are block-partitioned and the only other exchange is the all-gather of each rank's
 (best gain, global camera index).
 """
+import os
+
 import torch
 
 from . import dist as mdist
@@ -32,24 +34,40 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
     (n_unique: int32 [1]); nothing is read back inside the step, so it runs without a single host synchronisation.
     `occ_perms` / `samples` pin the hidden RNG draws (SconeOcc randperms; sampling uniforms).  `view_proj` [n_view,4,4]
     (full-projection matrices of the past views) switches on the tester's proxy-point filter (testers/shapenet.py:117-122)."""
-    world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+    inited = torch.distributed.is_available() and torch.distributed.is_initialized()
+    world = torch.distributed.get_world_size(group) if inited else 1
     rank = torch.distributed.get_rank(group) if world > 1 else 0
+    # the exchange path (broadcast of the hidden draws, all-gathers, record merge) normally needs world > 1; the env knob runs it
+    # through RCCL on a single rank too, so that a one-GPU box can test it end to end
+    sharded = world > 1 or (inited and bool(os.environ.get("MCR_FORCE_DIST_PATH")))
     dev = X.device
     if view_proj is not None:                                                       # testers/shapenet.py:122
         X = su.filter_proxy_points(view_proj, X[0], pc.reshape(-1, 3), filter_tol=filter_tol)[0][None]
     Q = X.shape[1]
+    if Q == 0:
+        raise ValueError("nbv_step: no proxy point left to score (the proxy filter removed every point)")
     with torch.no_grad():
         # ---- view state -> harmonics for this rank's slice of the queries (testers/shapenet.py:126-130) ----
         q0, q1 = mdist.shard_range(Q, rank, world)
         Xl = X[:, q0:q1].contiguous()
-        view_state = su.compute_view_state(Xl, X_view, grid.n_elev, grid.n_azim)
-        vh_l = su.compute_view_harmonics(view_state, grid.base_harmonics, grid.h_polar, grid.h_azim, grid.n_elev, grid.n_azim)
-        # ---- occupancy (:139-144) ----
-        if occ_perms is not None:
-            occ_l = scone_occ(pc, Xl, vh_l, perms=occ_perms).view(-1, 1)
-        else:
-            occ_l = su.compute_occupancy_probability(scone_occ, pc, Xl, vh_l, max_points_per_pass=max_points_per_pass).view(-1, 1)
-        if world > 1:
+        if sharded and occ_perms is None:
+            # one chunk per rank; the hidden randperm draws of SconeOcc.forward come from rank 0's CPU generator and are
+            # broadcast, so every rank sees the same down-sampled clouds (each rank drawing its own would silently diverge)
+            occ_perms = [p.to(dev) for p in scone_occ.draw_perms(pc.shape[1])]
+            for p in occ_perms:
+                torch.distributed.broadcast(p, 0, group=group)
+        if q1 > q0:
+            view_state = su.compute_view_state(Xl, X_view, grid.n_elev, grid.n_azim)
+            vh_l = su.compute_view_harmonics(view_state, grid.base_harmonics, grid.h_polar, grid.h_azim, grid.n_elev, grid.n_azim)
+            # ---- occupancy (:139-144) ----
+            if occ_perms is not None:
+                occ_l = scone_occ(pc, Xl, vh_l, perms=occ_perms).view(-1, 1)
+            else:
+                occ_l = su.compute_occupancy_probability(scone_occ, pc, Xl, vh_l, max_points_per_pass=max_points_per_pass).view(-1, 1)
+        else:                                       # empty query shard (Q < world): no kernels, but the collectives below are joined
+            vh_l = torch.zeros(1, 0, grid.base_harmonics.shape[0], dtype=torch.float32, device=dev)
+            occ_l = torch.zeros(0, 1, dtype=torch.float32, device=dev)
+        if sharded:
             occ = mdist.allgather_rows(occ_l, Q, group)
             vh = mdist.allgather_rows(vh_l[0], Q, group)
         else:
@@ -57,7 +75,7 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
         # ---- occupancy-weighted Monte-Carlo sampling (:146-154); identical on every rank ----
         if samples is None:
             samples = torch.rand(seq_len, 1, device=dev)
-            if world > 1:
+            if sharded:
                 torch.distributed.broadcast(samples, 0, group=group)
         # no host read-back: the unique sampled points stay padded to seq_len rows and their count stays on the device
         # (SconeVis consumes it as `lengths`); the reference slices on the host (:146-157)
@@ -74,8 +92,11 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
         # ---- coverage gains over this rank's camera shard + arg-max (:167-172) ----
         C = X_cam.shape[0]
         c0, c1 = mdist.shard_range(C, rank, world)
-        gains = scone_vis.compute_coverage_gain(proxy_points, harm, X_cam[c0:c1].contiguous().view(1, -1, 3))
-        if world > 1:
+        if c1 > c0:
+            gains = scone_vis.compute_coverage_gain(proxy_points, harm, X_cam[c0:c1].contiguous().view(1, -1, 3))
+        else:                                       # empty camera shard (C < world)
+            gains = torch.zeros(1, 0, dtype=torch.float32, device=dev)
+        if sharded:
             max_gain, nbv_idx = mdist.allgather_best(gains, c0, group)
         else:
             best = torch.max(gains, dim=1)

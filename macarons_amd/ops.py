@@ -49,6 +49,19 @@ def sh_coverage_gain(pts, harmonics, cams, use_sigmoid=True, waves_per_simd=0):
     return gains
 
 
+def sh_coverage_gain_partials(pts, harmonics, cams, use_sigmoid=True, waves_per_simd=0):
+    """First stage of sh_coverage_gain only (sh_gain_kernel; the partial sums stay in the scratch arena): timing hook."""
+    pts, harmonics, cams = _req(pts, "pts"), _req(harmonics, "harmonics"), _req(cams, "X_cam")
+    B, N, P = pts.shape
+    C = cams.shape[1]
+    L = lib()
+    ws = _workspace(pts.device, max(L.mcr_sh_coverage_gain_workspace_bytes(c_i64(B), c_i64(N), c_i64(C)), 4))
+    with torch.cuda.device(pts.device):
+        check(L.mcr_sh_coverage_gain_partials(_p(pts), c_int(P), _p(harmonics), _p(cams), c_i64(B), c_i64(N), c_i64(C),
+                                              c_int(int(bool(use_sigmoid))), c_int(waves_per_simd), _p(ws), c_size(ws.numel()),
+                                              _stream()), "mcr_sh_coverage_gain_partials")
+
+
 def sh_visibilities(pts, harmonics, cams, use_sigmoid=True):
     """vis [B,C,N]; replaces SconeVis.compute_visibilities (SconeVis.py:164-208)."""
     pts, harmonics, cams = _req(pts, "pts"), _req(harmonics, "harmonics"), _req(cams, "X_cam")

@@ -82,6 +82,8 @@ def compute_occupancy_probability(scone_occ, pc, X, view_harmonics, mask=None, m
     p = max_points_per_pass // n_clouds
     q, r = n_sample // p, n_sample % p
     n_loop = q + (1 if r != 0 else 0)
+    if n_loop == 0:                                     # no query point: the reference returns an empty [n_clouds, 0, 1] tensor (:980)
+        return X.new_zeros(n_clouds, 0, 1)
     preds = []
     for i in range(n_loop):
         low, up = i * p, (i + 1) * p

@@ -39,7 +39,20 @@ def _worker(rank, world, port, q):
         q0, q1 = mdist.shard_range(11, rank, world)
         got = mdist.allgather_rows(full[q0:q1].clone(), 11)
         ok2 = torch.equal(got, full)
-        q.put((rank, bool(ok1), bool(ok2), (c0, c1), (q0, q1)))
+        # fewer items than ranks: rank 1 owns an empty shard and still joins both collectives (no hang, right answer)
+        one = torch.tensor([[0.25]])
+        e0, e1 = mdist.shard_range(1, rank, world)
+        v3, i3 = mdist.allgather_best(one[:, e0:e1].contiguous(), e0)
+        ok3 = float(v3[0]) == 0.25 and int(i3[0]) == 0
+        rows = mdist.allgather_rows(torch.full((e1 - e0, 2), 7.0), 1)
+        ok3 = ok3 and rows.shape == (1, 2) and bool((rows == 7.0).all())
+        # a row of -inf / NaN keeps torch.max's answer (first index / first NaN)
+        bad = torch.tensor([[float("-inf")] * 4, [1.0, float("nan"), 3.0, float("nan")]])
+        b0, b1 = mdist.shard_range(4, rank, world)
+        v4, i4 = mdist.allgather_best(bad[:, b0:b1].contiguous(), b0)
+        rb = torch.max(bad, dim=1)
+        ok3 = ok3 and int(i4[0]) == int(rb.indices[0]) and int(i4[1]) == int(rb.indices[1]) and bool(torch.isnan(v4[1]))
+        q.put((rank, bool(ok1), bool(ok2 and ok3), (c0, c1), (q0, q1)))
     finally:
         dist.destroy_process_group()
 

@@ -165,3 +165,40 @@ def test_nbv_step_with_proxy_filter(dev):
     assert 0 < int(mask.sum()) < Q
     b = nbv_step(occ, vis, pc, Xf[None].contiguous(), X_view, cams, grid, occ_perms=perms, samples=u)
     assert int(a["nbv_idx"]) == int(b["nbv_idx"]) and torch.equal(a["gains"], b["gains"]) and a["occ"].shape[0] == int(mask.sum())
+
+
+def test_sharded_step_path_through_rccl_single_rank(dev, monkeypatch):
+    """The exchange path of nbv_step (rank-0 randperm draws broadcast, occupancy / view-harmonics all-gathers, (gain, index)
+    record all-gather + merge) run through RCCL on a one-rank group (MCR_FORCE_DIST_PATH) must reproduce the plain step bit
+    for bit -- incl. the hidden-RNG path (no occ_perms given)."""
+    import socket
+    import torch.distributed as dist
+    from macarons_amd.nbv import nbv_step, ViewStateGrid
+    g = golden("e2e_grid_config1")
+    occ, vis, _, _ = _models(dev)
+    grid = ViewStateGrid(dev)
+    args = (occ, vis, T(g["pc"], dev), T(g["X"], dev), T(g["X_view"], dev), T(g["X_cam"], dev), grid)
+    torch.manual_seed(int(g["seed"]))
+    a = nbv_step(*args, samples=T(g["samples"], dev))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    monkeypatch.setenv("MCR_FORCE_DIST_PATH", "1")
+    try:
+        torch.manual_seed(int(g["seed"]))
+        b = nbv_step(*args, samples=T(g["samples"], dev))
+        assert torch.equal(a["occ"], b["occ"]) and torch.equal(a["gains"], b["gains"])
+        assert int(a["nbv_idx"]) == int(b["nbv_idx"]) == int(g["nbv_idx"]) and float(a["max_gain"]) == float(b["max_gain"])
+        c = nbv_step(*args)                                  # uniforms drawn + broadcast inside
+        assert torch.isfinite(c["gains"]).all() and 0 <= int(c["nbv_idx"]) < 20
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_sharded_step_two_ranks_matches_single_rank(dev):
+    """2 ranks (RCCL over xGMI): query- and camera-sharded nbv_step == the 1-rank step (decision, max gain, occupancies)."""
+    import subprocess, sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(root, "tests", "_two_rank_step.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "TWO_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
