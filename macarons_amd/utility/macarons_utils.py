@@ -168,3 +168,89 @@ def covered_mask(surface_pts, seen_pts, epsilon, a_offsets=None, b_offsets=None)
         a_offsets = torch.tensor([0, surface_pts.shape[0]], dtype=torch.int64, device=dev)
         b_offsets = torch.tensor([0, seen_pts.shape[0]], dtype=torch.int64, device=dev)
     return ops.min_dist_segmented(surface_pts, a_offsets, seen_pts, b_offsets) < epsilon
+
+
+# ---- occupancy field of a scene (SURVEY §8 f4): the per-cell SconeOcc pass of the MACARONS loop ----------------------------------
+def _world_to_view_matrix(prediction_camera):
+    """[4,4] row-vector world -> view matrix (X_view = [x y z 1] M) of a PyTorch3D camera object (its
+    get_world_to_view_transform().get_matrix()) or the matrix itself."""
+    if torch.is_tensor(prediction_camera):
+        return prediction_camera.reshape(4, 4)
+    return prediction_camera.get_world_to_view_transform().get_matrix().reshape(-1, 4, 4)[0]
+
+
+def compute_scene_occupancy_probability_field(params, macarons, camera, surface_scene, proxy_scene, device,
+                                              use_supervision_occ_mask=True, prediction_camera=None,
+                                              use_supervision_occ_instead_of_predicted=False):
+    """macarons_utils.py:1395-1540.  For every grid cell that holds proxy points seen by a camera (and not carved empty): the
+    surface points of its 27-cell neighbourhood and its proxy points go to the prediction camera's view space, centred on the
+    cell and divided by prediction_neighborhood_size x the cell diagonal (one transform kernel each); the view states are
+    rotated into that frame and projected on the harmonics; SconeOcc runs in chunks of 20 000 queries (a fresh global
+    down-sample per chunk, drawn from the CPU generator like upstream); finally the never-seen points are appended with their
+    stored probability and zero harmonics.  Returns (X_world [N,3], view_harmonics [N,64], occ_probs [N,1]) and updates
+    proxy_scene.proxy_proba in place.  `surface_scene` / `proxy_scene`: macarons_amd.utility.scene.Scene or the reference's
+    Scene; `prediction_camera`: a PyTorch3D camera, or the [4,4] world->view matrix."""
+    from . import scone_utils as su
+    X_world = torch.zeros(0, 3, device=device)
+    view_harmonics = torch.zeros(0, params.n_harmonics, device=device)
+    occ_probs = torch.zeros(0, 1, device=device)
+    occ_mask = (proxy_scene.proxy_supervision_occ > 0.)[..., 0]
+    all_fov_mask = (proxy_scene.out_of_field < 1.)[..., 0]
+    seen = occ_mask * all_fov_mask
+    fovs_proxy_points = proxy_scene.proxy_points[seen if use_supervision_occ_mask else all_fov_mask]
+    proxy_scene.proxy_proba[seen] = 0.
+    proxy_cells = proxy_scene.get_englobing_cells(fovs_proxy_points)
+    base_harmonics, h_polar, h_azim = su.get_all_harmonics_under_degree(params.harmonic_degree, params.view_state_n_elev,
+                                                                         params.view_state_n_azim, device)
+    if prediction_camera is None:
+        if camera is None:
+            raise NameError("Both camera and prediction_camera are equal to None.")
+        prediction_camera = camera.fov_camera_0
+    Mv = _world_to_view_matrix(prediction_camera).to(device=device, dtype=torch.float32).contiguous()
+    R = Mv[:3, :3].contiguous()
+    one = torch.ones(1, 1, device=device)
+    for proxy_cell in proxy_cells:
+        cell = proxy_scene.cells[proxy_scene.get_key_from_idx(proxy_cell)]
+        cell_diag = torch.linalg.norm(cell.x_max - cell.x_min)
+        cell_pc_world = surface_scene.get_pt_cloud_from_cells(surface_scene.get_neighboring_cells(proxy_cell), return_features=False)
+        _, cell_X_indices = proxy_scene.get_pt_cloud_from_cells(proxy_cell, return_features=True)
+        cell_X_mask = proxy_scene.get_proxy_mask_from_indices(cell_X_indices)
+        if use_supervision_occ_mask:
+            cell_X_mask = cell_X_mask * occ_mask
+        cell_X_world = proxy_scene.proxy_points[cell_X_mask]
+        if not ((cell_pc_world.shape[0] > 2 * 2 * params.k_for_knn) and (len(cell_X_world) > 0)):
+            continue
+        center = (torch.cat((cell.center.view(1, 3), one), 1) @ Mv)[0, :3].contiguous()       # prediction_box_center (:1471)
+        inv_diag = 1.0 / float(params.prediction_neighborhood_size * cell_diag)
+        cell_pc = ops.transform_points_(cell_pc_world.clone().contiguous(), Mv, center, inv_diag).view(1, -1, 3)
+        cell_X = ops.transform_points_(cell_X_world.clone().contiguous(), Mv, center, inv_diag).view(1, -1, 3)
+        vs = proxy_scene.view_states[cell_X_mask.view(-1).bool()].view(1, cell_X.shape[1], params.n_view_state_cameras)
+        vs = su.move_view_state_to_view_space(vs, R if torch.is_tensor(prediction_camera) else prediction_camera,
+                                              n_elev=params.view_state_n_elev, n_azim=params.view_state_n_azim)
+        cell_vh = su.compute_view_harmonics(vs, base_harmonics, h_polar, h_azim, params.view_state_n_elev, params.view_state_n_azim)
+        if use_supervision_occ_instead_of_predicted:
+            cell_occ = proxy_scene.proxy_supervision_occ[cell_X_mask]
+        else:
+            cell_occ = compute_occupancy_probability(macarons, cell_pc, cell_X, cell_vh, max_points_per_pass=20000).view(-1, 1)
+        X_world = torch.vstack((X_world, cell_X_world.view(-1, 3)))
+        view_harmonics = torch.vstack((view_harmonics, cell_vh.view(-1, params.n_harmonics)))
+        occ_probs = torch.vstack((occ_probs, cell_occ))
+        proxy_scene.proxy_proba[cell_X_mask.view(-1).bool()] = cell_occ
+    oof_mask = (proxy_scene.out_of_field > 0.)[..., 0]
+    oof_X = proxy_scene.proxy_points[oof_mask]
+    X_world = torch.vstack((X_world, oof_X))
+    view_harmonics = torch.vstack((view_harmonics, torch.zeros(len(oof_X), params.n_harmonics, device=device)))
+    occ_probs = torch.vstack((occ_probs, proxy_scene.proxy_proba[oof_mask]))
+    return X_world, view_harmonics, occ_probs
+
+
+def compute_occupancy_probability(macarons, pc, X, view_harmonics, mask=None, max_points_per_pass=20000):
+    """macarons_utils.py:1194-1231: chunked occupancy inference through Macarons.forward(mode='occupancy')."""
+    n_clouds, n_sample = pc.shape[0], X.shape[1]
+    p = max_points_per_pass // n_clouds
+    preds = [torch.zeros(n_clouds, 0, 1, device=X.device)]
+    for low in range(0, n_sample, p):
+        up = min(low + p, n_sample)
+        preds.append(macarons(mode='occupancy', partial_point_cloud=pc, proxy_points=X[:, low:up].contiguous(),
+                              view_harmonics=view_harmonics[:, low:up].contiguous()).view(n_clouds, up - low, -1))
+    return torch.cat(preds, dim=1)

@@ -1,0 +1,150 @@
+"""A uniform grid of capped point sets: the subset of macarons/utility/macarons_utils.py `Scene` (:2588-2830) and `Cell`
+(:2503-2585) that the occupancy-field pass walks -- cell lookup, 27-neighbourhoods, per-cell point / feature
+stores with the admission test of Cell.fill on the MI355X (fp64 nearest-distance kernel), proxy-point state tensors.  Host-side
+bookkeeping in the reference's own dict-of-cells shape (keys like '[i, j, k]'), so that
+macarons_amd.utility.macarons_utils.compute_scene_occupancy_probability_field accepts either these objects or the reference's.
+Everything else of the reference classes (rendering, coverage metrics, collision tests, memory) is out of scope.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import macarons_utils as mu
+
+
+def _key(idx):
+    return str([int(v) for v in idx])
+
+
+class Cell:
+    """One grid cell: axis-aligned box + the points (and optional per-point features) kept in it."""
+
+    def __init__(self, center, l, w, h, capacity, resolution, device, feature_dim=0):
+        half = torch.tensor([[float(l) / 2., float(w) / 2., float(h) / 2.]], device=center.device)
+        self.center, self.l, self.w, self.h = center, l, w, h
+        self.x_min, self.x_max = center - half, center + half
+        if resolution is None and capacity is None:
+            raise NameError("Please choose a capacity or a resolution.")
+        # the largest cross-section of the box sets how many discs of diameter `resolution` fit (macarons_utils.py:2515-2541)
+        l_, w_, h_ = float(l), float(w), float(h)
+        area = max(l_ * math.hypot(w_, h_), w_ * math.hypot(h_, l_), h_ * math.hypot(l_, w_))
+        if resolution is None:
+            resolution = 2 * math.sqrt(area / capacity / math.pi)
+        elif capacity is None:
+            capacity = int(area // (math.pi * (resolution / 2.) ** 2))
+        self.capacity, self.resolution, self.device = capacity, resolution, device
+        self.use_feature, self.feature_dim = feature_dim > 0, feature_dim
+        self.empty()
+
+    def empty(self):
+        self.cell_pts = torch.zeros(0, 3, device=self.device)
+        if self.use_feature:
+            self.cell_features = torch.zeros(0, self.feature_dim, device=self.device)
+
+    def is_empty(self):
+        return self.cell_pts.shape[0] == 0
+
+    def fill(self, pts, features=None, n_point_min=0, perm=None):
+        """Cell.fill (:2551-2577): keep the points strictly inside the box whose fp64 distance to every stored point exceeds
+        the resolution, append, then keep a random `capacity` subset (torch.randperm on the CPU generator, or `perm`)."""
+        inside = (torch.max(pts - self.x_max, dim=-1)[0] < 0.) & (torch.min(pts - self.x_min, dim=-1)[0] > 0.)
+        add = pts[inside]
+        if add.shape[0] <= n_point_min:                 # (the reference tests the two faces one after the other; same outcome)
+            return
+        fts = features[inside] if (self.use_feature and features is not None) else None
+        if self.cell_pts.shape[0] > 0:
+            keep = mu.cell_fill_mask(add.contiguous(), self.cell_pts.contiguous(), self.resolution)
+            add = add[keep]
+            fts = fts[keep] if fts is not None else None
+        self.cell_pts = torch.vstack((self.cell_pts, add))
+        idx = (torch.randperm(len(self.cell_pts)) if perm is None else perm)[:self.capacity].to(self.cell_pts.device)
+        self.cell_pts = self.cell_pts[idx]
+        if fts is not None:
+            self.cell_features = torch.vstack((self.cell_features, fts))[idx]
+
+
+class Scene:
+    def __init__(self, x_min, x_max, grid_l, grid_w, grid_h, cell_capacity, cell_resolution, n_proxy_points, device,
+                 view_state_n_elev=7, view_state_n_azim=2 * 7, feature_dim=0, score_threshold=1.):
+        self.grid_l, self.grid_w, self.grid_h = grid_l, grid_w, grid_h
+        self.x_min, self.x_max = 0. + x_min, 0. + x_max
+        ext = self.x_max - self.x_min
+        self.l, self.w, self.h = ext[0] / grid_l, ext[1] / grid_w, ext[2] / grid_h
+        self.device, self.feature_dim = device, feature_dim
+        self.cells = {}
+        for i in range(grid_l):
+            for j in range(grid_w):
+                for k in range(grid_h):
+                    center = torch.Tensor([self.x_min[0] + (0.5 + i) * self.l, self.x_min[1] + (0.5 + j) * self.w,
+                                           self.x_min[2] + (0.5 + k) * self.h]).to(device)
+                    cell = Cell(center, self.l, self.w, self.h, cell_capacity, cell_resolution, device, feature_dim)
+                    cell_capacity, cell_resolution = cell.capacity, cell.resolution      # derived once, shared by all cells
+                    self.cells[_key((i, j, k))] = cell
+        self.cell_capacity, self.cell_resolution = cell_capacity, cell_resolution
+        self.n_proxy_points = n_proxy_points
+        self.view_state_n_elev, self.view_state_n_azim = view_state_n_elev, view_state_n_azim
+        self.n_view_state_cameras = view_state_n_elev * view_state_n_azim
+        self.score_threshold = score_threshold
+        self.proxy_points = self.proxy_proba = self.proxy_supervision_occ = self.view_states = self.out_of_field = None
+        vol = float(self.l * self.w * self.h) / (n_proxy_points / (grid_l * grid_w * grid_h))
+        self.distance_between_proxy_points = 2 * np.power(3 * vol / (4 * np.pi), 1. / 3.)
+
+    # ---- cell lookup ----
+    def get_cells_for_each_pt(self, pts):
+        step = torch.stack((self.l, self.w, self.h)).to(pts.device).view(1, 3)
+        d = pts - self.x_min.to(pts.device)
+        idx = (d - d % step) / step                                   # utils.floor_divide (non-negative modulo)
+        hi = torch.tensor([self.grid_l - 1, self.grid_w - 1, self.grid_h - 1], device=pts.device, dtype=idx.dtype)
+        return torch.minimum(idx, hi).long().clamp_(min=0)
+
+    def get_englobing_cells(self, pts, list=False):
+        res = torch.unique(self.get_cells_for_each_pt(pts), dim=0)
+        return res.cpu().numpy().tolist() if list else res
+
+    def get_neighboring_cells(self, cell_idx):
+        shift = torch.cartesian_prod(torch.arange(3), torch.arange(3), torch.arange(3)).to(cell_idx.device) - 1
+        hi = torch.tensor([self.grid_l - 1, self.grid_w - 1, self.grid_h - 1], device=cell_idx.device)
+        return torch.unique(torch.minimum((cell_idx + shift).clamp(min=0), hi), dim=0)
+
+    def get_key_from_idx(self, cell_idx):
+        return _key(cell_idx.cpu().numpy().tolist())
+
+    # ---- stores ----
+    def get_pts_in_bounding_box(self, pts, return_mask=True):
+        m = ((pts >= self.x_min.to(pts.device)) & (pts <= self.x_max.to(pts.device))).all(dim=-1)
+        return (pts[m], m) if return_mask else pts[m]
+
+    def fill_cells(self, pts, features=None, n_point_min=0):
+        inside, m = self.get_pts_in_bounding_box(pts)
+        fts = features[m] if features is not None else None
+        for cell_idx in self.get_englobing_cells(inside, list=True):
+            self.cells[_key(cell_idx)].fill(inside, features=fts, n_point_min=n_point_min)
+
+    def get_pt_cloud_from_cells(self, cell_indices, return_features=True):
+        with_fts = return_features and self.feature_dim > 0
+        keys = ([_key(c) for c in cell_indices.cpu().numpy().tolist()] if cell_indices.dim() > 1
+                else [_key(cell_indices.cpu().numpy().tolist())])
+        pts = torch.vstack([torch.zeros(0, 3, device=self.device)] + [self.cells[k].cell_pts for k in keys])
+        if not with_fts:
+            return pts
+        fts = torch.vstack([torch.zeros(0, self.feature_dim, device=self.device)] + [self.cells[k].cell_features for k in keys])
+        return pts, fts
+
+    # ---- proxy points ----
+    def initialize_proxy_points(self, n_proxy_points=None, default_proba_value=0.5):
+        n = self.n_proxy_points if n_proxy_points is None else n_proxy_points
+        dev = self.device
+        self.proxy_points = self.x_min.to(dev) + (self.x_max - self.x_min).to(dev) * torch.rand(n, 3, device=dev)
+        self.proxy_proba = torch.zeros(n, 1, device=dev) + default_proba_value
+        self.proxy_supervision_occ = torch.ones(n, 1, device=dev)
+        self.view_states = torch.zeros(n, self.n_view_state_cameras, device=dev)
+        self.out_of_field = torch.ones(n, 1, device=dev)
+
+    def get_proxy_indices_from_mask(self, proxy_mask):
+        return torch.arange(0, self.n_proxy_points, device=self.device).view(-1, 1)[proxy_mask]
+
+    def get_proxy_mask_from_indices(self, proxy_indices):
+        mask = torch.zeros(self.n_proxy_points, device=self.device).bool()
+        mask[proxy_indices.view(-1).long()] = True
+        return mask

@@ -51,3 +51,60 @@ def compute_partial_point_cloud(depth, mask, Minv, k22, k32, gathering_factor, f
     world = unproject_depth(d, Minv, k22, k32)[keep]
     n = int(len(world) * gathering_factor)
     return world[np.asarray(perm)[:n]]
+
+
+# ---- compute_scene_occupancy_probability_field (macarons_utils.py:1395-1540) on plain arrays ---------------------------------
+def occupancy_field(sd_occ, x_min, x_max, grid, surface_cells, proxy_cells, proxy, sup_occ, out_of_field, view_states, proba,
+                    Mpred, perms, k_for_knn=16, neighborhood=3, chunk=20000, dtype=np.float32):
+    """surface_cells / proxy_cells: {(i,j,k): points [n,3]} / {(i,j,k): proxy indices in storage order}; perms: the randperm
+    draws in the order the reference makes them (3 per chunk per processed cell).  Returns (X_world, view_harmonics, occ_probs,
+    proba_after)."""
+    from . import nets, view_state as V
+    F = np.float32
+    x_min, x_max, proxy = np.asarray(x_min, F), np.asarray(x_max, F), np.asarray(proxy, F)
+    grid = [int(g) for g in grid]
+    step = ((x_max - x_min) / np.array(grid, F)).astype(F)
+    proba = np.asarray(proba, F).copy()
+    occ_mask = np.asarray(sup_occ).reshape(-1) > 0
+    fov_mask = np.asarray(out_of_field).reshape(-1) < 1
+    seen = occ_mask & fov_mask
+    proba[seen] = 0
+    d = proxy[seen] - x_min
+    idx = np.minimum(((d - np.mod(d, step)) / step).astype(np.int64), np.array(grid) - 1).clip(min=0)
+    cells = np.unique(idx, axis=0)                                   # torch.unique(dim=0): lexicographic order
+    base, hp, ha = V.all_harmonics_under_degree(8, 7, 14)
+    Mv = np.asarray(Mpred, F).reshape(4, 4)
+    tf = lambda p: (((p[:, 0:1] * Mv[0, :3] + p[:, 1:2] * Mv[1, :3]) + p[:, 2:3] * Mv[2, :3]) + Mv[3, :3]).astype(F)
+    grid_dirs = (V.view_space_grid(7, 14) @ Mv[:3, :3].T).astype(F)
+    Xs, Hs, Os, pi = [], [], [], 0
+    for c in cells:
+        ci, cj, ck = [int(v) for v in c]
+        neigh = sorted({(min(max(ci + a, 0), grid[0] - 1), min(max(cj + b, 0), grid[1] - 1), min(max(ck + e, 0), grid[2] - 1))
+                        for a in (-1, 0, 1) for b in (-1, 0, 1) for e in (-1, 0, 1)})
+        pcw = np.concatenate([surface_cells[n] for n in neigh if n in surface_cells] or [np.zeros((0, 3), F)])
+        members = np.zeros(len(proxy), bool)
+        members[np.asarray(proxy_cells.get((ci, cj, ck), []), np.int64)] = True
+        cmask = members & occ_mask
+        Xw = proxy[cmask]
+        if not (len(pcw) > 4 * k_for_knn and len(Xw) > 0):
+            continue
+        center_w = (x_min + (np.array([ci, cj, ck], F) + F(0.5)) * step).astype(F)
+        center = tf(center_w[None])[0]
+        diag = F(neighborhood) * np.linalg.norm((step).astype(F)).astype(F)
+        pc = ((tf(pcw) - center) / diag).astype(F)[None]
+        X = ((tf(Xw) - center) / diag).astype(F)[None]
+        vs, _ = V.move_view_state_to_view_space(np.asarray(view_states, F)[cmask][None], grid_dirs, 7, 14)
+        vh = V.compute_view_harmonics(vs, base, hp, ha, 7, 14)
+        occ = []
+        for lo in range(0, X.shape[1], chunk):
+            M = pc.shape[1]
+            ds = int(np.power(M / (16 * 8), 1. / 2)) or 2
+            p3 = [perms[pi][:2048], perms[pi + 1][:M // ds], perms[pi + 2][:(M // ds) // ds]]
+            pi += 3
+            occ.append(nets.scone_occ_forward(sd_occ, pc, X[:, lo:lo + chunk], vh[:, lo:lo + chunk], p3, dtype).reshape(-1, 1))
+        occ = np.concatenate(occ).astype(F)
+        Xs.append(Xw); Hs.append(vh[0]); Os.append(occ)
+        proba[cmask] = occ[:, 0]
+    oof = np.asarray(out_of_field).reshape(-1) > 0
+    Xs.append(proxy[oof]); Hs.append(np.zeros((int(oof.sum()), 64), F)); Os.append(proba[oof][:, None])
+    return np.concatenate(Xs), np.concatenate(Hs), np.concatenate(Os), proba

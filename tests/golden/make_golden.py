@@ -466,10 +466,10 @@ def _grid(a, step=1024.0):
     return (np.round(np.asarray(a, np.float64) * step) / step).astype(np.float32)
 
 
-def _boundary_ties(X, pc, k=16):
+def _boundary_ties(X, pc, k=16, step=1024.0):
     """Mask of the queries whose k-th and (k+1)-th neighbour sit at the same (exact) squared distance."""
-    Xi = np.round(X.astype(np.float64) * 1024).astype(np.int64)
-    Pi = np.round(pc.astype(np.float64) * 1024).astype(np.int64)
+    Xi = np.round(X.astype(np.float64) * step).astype(np.int64)
+    Pi = np.round(pc.astype(np.float64) * step).astype(np.int64)
     bad = np.zeros(len(Xi), bool)
     for lo in range(0, len(Xi), 2048):
         d = ((Xi[lo:lo + 2048, None, :] - Pi[None, :, :]) ** 2).sum(-1)
@@ -842,7 +842,121 @@ def gen_formats():
     print("wrote", out_dir, os.path.getsize(os.path.join(out_dir, "validation_optimal_trajectories_slice.pt")), "bytes slice")
 
 
-GROUPS = {"formats": gen_formats, "e2e_grid": gen_e2e_grid, "fov": gen_fov, "distance": gen_distance, "wrapper": gen_macarons_wrapper, "single_camera": gen_single_camera, "cell": gen_cell, "unproject": gen_unproject, "viewspace": gen_viewspace, "filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
+def gen_occ_field():
+    """compute_scene_occupancy_probability_field (macarons_utils.py:1395-1540) on REAL reference Scene / Cell objects (4 grid
+    cells), a stand-in prediction camera and the reference Macarons wrapper: per cell the 27-neighbourhood surface cloud and the
+    cell's proxy points go to the prediction camera's view space, normalised by 3 x the cell diagonal, view states are rotated,
+    SconeOcc is evaluated (hidden randperm draws captured); then the out-of-field points are appended.  World points sit on a
+    2^-6 grid and the proxy points are redrawn until no query has a k / k+1 neighbour tie in any of its three clouds."""
+    import importlib
+    from types import SimpleNamespace as NS
+    mu = importlib.import_module("macarons.utility.macarons_utils")
+    m = _ref_macarons()
+    rng = np.random.default_rng(131)
+    G = 64.0
+    x_min, x_max = torch.tensor([-8., -4., -8.]), torch.tensor([8., 4., 8.])
+    grid = (2, 1, 2)
+    n_proxy = 3000
+
+    def new_scene(capacity, resolution, feature_dim):
+        return mu.Scene(x_min=x_min, x_max=x_max, grid_l=grid[0], grid_w=grid[1], grid_h=grid[2], cell_capacity=capacity,
+                        cell_resolution=resolution, n_proxy_points=n_proxy, device="cpu", feature_dim=feature_dim)
+    # surface: an ellipsoid shell through all four cells, on the grid
+    d = rng.standard_normal((2600, 3))
+    surf = np.unique(_grid(d / np.linalg.norm(d, axis=1, keepdims=True) * [5.5, 2.8, 5.0] + 0.05 * rng.standard_normal((2600, 3)), G), axis=0)
+    rng.shuffle(surf)
+    torch.manual_seed(4000)
+    surface_scene = new_scene(500, 0.2, 0)
+    surface_scene.fill_cells(t(surf))
+    cell_pts = {k: c.cell_pts.numpy().copy() for k, c in surface_scene.cells.items()}
+    print("  surface cells:", {k: len(v) for k, v in cell_pts.items()})
+    def draw_proxy(n):
+        q = _grid(rng.uniform(-1, 1, (n, 3)) * [7.9, 3.9, 7.9], G)
+        q[q == 0] = 1.0 / G                       # Cell.fill's box tests are strict: a point ON a cell face belongs to no cell
+        return q
+    proxy = draw_proxy(n_proxy)
+    in_fov = rng.random(n_proxy) < 0.7
+    sup_occ = (rng.random((n_proxy, 1)) < 0.8).astype(np.float32)
+    vstates = (rng.random((n_proxy, 98)) < 0.1).astype(np.float32)
+    Rp, Tp, Pp = _scene_cams(np.array([[6., 9., -14.]], np.float32))
+    pred = _StandInCameras(t(Rp), t(Tp), t(Pp), squeeze=True)
+    params = NS(n_harmonics=64, harmonic_degree=8, view_state_n_elev=7, view_state_n_azim=14, k_for_knn=16,
+                prediction_neighborhood_size=3, n_view_state_cameras=98)
+
+    def build_proxy_scene():
+        ps = new_scene(100000, 1e-4, 1)
+        ps.initialize_proxy_points()
+        ps.proxy_points = t(proxy)
+        ps.proxy_supervision_occ = t(sup_occ)
+        ps.view_states = t(vstates)
+        ps.out_of_field = t((~in_fov).astype(np.float32)).view(-1, 1)
+        idx = ps.get_proxy_indices_from_mask(torch.from_numpy(in_fov))
+        torch.manual_seed(4001)
+        ps.fill_cells(t(proxy)[torch.from_numpy(in_fov)], features=idx.view(-1, 1).float())
+        return ps
+    seed = 4002
+    for it in range(60):
+        ps = build_proxy_scene()
+        assert sum(len(c.cell_pts) for c in ps.cells.values()) == int(in_fov.sum()), "a proxy point was refused by Cell.fill"
+        # replay the loop of the function to learn each cell's clouds and the randperm draws it will make
+        occ_mask = (ps.proxy_supervision_occ > 0.)[..., 0]
+        fov_mask = (ps.out_of_field < 1.)[..., 0]
+        cells = ps.get_englobing_cells(ps.proxy_points[occ_mask * fov_mask])
+        torch.manual_seed(seed)
+        bad_idx = []
+        for cell in cells:
+            pcw = surface_scene.get_pt_cloud_from_cells(surface_scene.get_neighboring_cells(cell), return_features=False).numpy()
+            _, ind = ps.get_pt_cloud_from_cells(cell, return_features=True)
+            cmask = ps.get_proxy_mask_from_indices(ind) * occ_mask
+            Xw = ps.proxy_points[cmask].numpy()
+            gi = np.nonzero(cmask.numpy())[0]
+            if not (pcw.shape[0] > 64 and len(Xw) > 0):
+                continue
+            M = len(pcw)
+            ds = int(np.power(M / (16 * 8), 1. / 2)) or 2
+            for lo in range(0, len(Xw), 20000):
+                torch.randperm(M)                              # global down-sample (order of SconeOcc.forward)
+                p1 = torch.randperm(M).numpy()[:M // ds]
+                p2 = torch.randperm(M // ds).numpy()[:(M // ds) // ds]
+                pc1 = pcw[p1]; pc2 = pc1[p2]
+                Xc = Xw[lo:lo + 20000]
+                bad = (_boundary_ties(Xc, pcw, 16, G) | _boundary_ties(Xc, pc1, 16, G) | _boundary_ties(Xc, pc2, 16, G))
+                bad_idx += gi[lo:lo + 20000][bad].tolist()
+        print(f"  occ_field: pass {it}: {len(bad_idx)} proxy points with boundary ties")
+        if not bad_idx:
+            break
+        proxy[bad_idx] = draw_proxy(len(bad_idx))
+    else:
+        raise RuntimeError("no tie-free proxy set found")
+    perms = []
+    real = torch.randperm
+
+    def cap(n, *a, **kw):
+        p_ = real(n, *a, **kw); perms.append(p_.numpy().copy()); return p_
+    proba_before = ps.proxy_proba.numpy().copy()
+    torch.randperm = cap
+    try:
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            Xw_out, vh_out, occ_out = mu.compute_scene_occupancy_probability_field(params, m, None, surface_scene, ps, "cpu",
+                                                                                   prediction_camera=pred)
+    finally:
+        torch.randperm = real
+    out = dict(x_min=x_min.numpy(), x_max=x_max.numpy(), grid=np.array(grid), surface=surf, n_surface_cells=np.int64(len(cell_pts)),
+               proxy=proxy, in_fov=np.packbits(in_fov), sup_occ=sup_occ[:, 0].astype(np.uint8), view_states=np.packbits(vstates.astype(np.uint8), axis=-1),
+               Mpred=pred.Mv.numpy(), Rp=Rp, X_world=Xw_out.numpy(), view_harmonics=vh_out.numpy(), occ_probs=occ_out.numpy(),
+               proxy_proba=ps.proxy_proba.numpy(), proba_before=proba_before, seed=np.int64(seed), n_perms=np.int64(len(perms)))
+    for i, (k, v) in enumerate(sorted(cell_pts.items())):
+        out[f"cellkey_{i}"] = np.array(eval(k))
+        out[f"cellpts_{i}"] = v
+    for i, (k, c) in enumerate(sorted(ps.cells.items())):
+        out[f"pcellkey_{i}"] = np.array(eval(k))
+        out[f"pcellidx_{i}"] = c.cell_features.numpy()[:, 0].astype(np.int32)
+    print(f"  occ_field: {len(Xw_out)} points out ({int(occ_out.shape[0])} probs), {len(perms)} randperm draws")
+    save("occ_field", **out)
+
+
+GROUPS = {"occ_field": gen_occ_field, "formats": gen_formats, "e2e_grid": gen_e2e_grid, "fov": gen_fov, "distance": gen_distance, "wrapper": gen_macarons_wrapper, "single_camera": gen_single_camera, "cell": gen_cell, "unproject": gen_unproject, "viewspace": gen_viewspace, "filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -374,3 +374,36 @@ def test_nbv_oracle_matches_reference_on_grid(name, n_occ):
     harm = nets.scone_vis_forward(sdv, res[None], res_h[None])
     gains = scorer.compute_coverage_gain(res[inv][None], harm[0][inv][None], g["X_cam"][None], True, "trigfree", np.float64)[0]
     assert rel_err(gains, g["gains"]) < 1e-4 and int(np.argmax(gains)) == int(g["nbv_idx"])
+
+
+def _occ_field_inputs(g):
+    n = len(g["proxy"])
+    in_fov = np.unpackbits(g["in_fov"])[:n].astype(bool)
+    vs = np.unpackbits(g["view_states"], axis=-1)[:, :98].astype(np.float32)
+    surface = {tuple(int(v) for v in g[f"cellkey_{i}"]): g[f"cellpts_{i}"] for i in range(int(g["n_surface_cells"]))}
+    proxy_cells = {tuple(int(v) for v in g[f"pcellkey_{i}"]): g[f"pcellidx_{i}"] for i in range(int(g["n_surface_cells"]))}
+    return in_fov, vs, surface, proxy_cells
+
+
+def test_occupancy_field_oracle_matches_reference():
+    """oracle.scene.occupancy_field == compute_scene_occupancy_probability_field (macarons_utils.py:1395-1540) run on real
+    reference Scene / Cell objects: the same points in the same order, rotated view harmonics, occupancies at 1e-4, the updated
+    proxy_proba; the hidden randperm draws replayed from the same seed."""
+    import torch
+    from oracle import scene
+    from macarons_amd.networks import SconeOcc
+    o, sdo = _weights(SconeOcc, 2)
+    sdo["linear3.bias"] = sdo["linear3.bias"] + np.float32(0.5)
+    g = golden("occ_field")
+    in_fov, vs, surface, proxy_cells = _occ_field_inputs(g)
+    torch.manual_seed(int(g["seed"]))
+    perms = []
+    for i in range(int(g["n_perms"]) // 3):                              # every processed cell holds M = 2000 surface points here
+        M = sum(len(v) for v in surface.values())
+        ds = int(np.power(M / (16 * 8), 1. / 2)) or 2
+        perms += [torch.randperm(M).numpy(), torch.randperm(M).numpy(), torch.randperm(M // ds).numpy()]
+    X, H, O, proba = scene.occupancy_field(sdo, g["x_min"], g["x_max"], g["grid"], surface, proxy_cells, g["proxy"], g["sup_occ"],
+                                           (~in_fov).astype(np.float32), vs, g["proba_before"][:, 0], g["Mpred"][0], perms)
+    assert np.array_equal(X, g["X_world"]) and rel_err(H, g["view_harmonics"]) < 1e-5
+    assert np.abs(O - g["occ_probs"]).max() < 1e-4 * np.abs(g["occ_probs"]).max()
+    assert np.abs(proba - g["proxy_proba"][:, 0]).max() < 1e-4 * np.abs(g["occ_probs"]).max()
