@@ -17,11 +17,13 @@ _warned = [False]
 
 
 def _inference_only(module, *tensors):
-    """The HIP path records no autograd graph (training callers are out of this tier)."""
+    """The BLOCK-level modules (Embedding, Encoder, ... called on their own) record no autograd graph; gradients are provided at the
+    entry points the trainers use (SconeVis.forward, SconeOcc.forward, the scorer methods: macarons_amd/autograd.py)."""
     if torch.is_grad_enabled() and not _warned[0]:
         if any(p.requires_grad for p in module.parameters()) or any(getattr(t, "requires_grad", False) for t in tensors):
-            warnings.warn("macarons_amd: the MI355X HIP path is inference-only; no gradients are recorded "
-                          "(wrap calls in torch.no_grad() to silence this).", RuntimeWarning, stacklevel=3)
+            warnings.warn("macarons_amd: this block-level module records no gradients on the MI355X HIP path (SconeVis / SconeOcc "
+                          "forward and the scorer methods do); wrap calls in torch.no_grad() to silence this.", RuntimeWarning,
+                          stacklevel=3)
             _warned[0] = True
 
 

@@ -40,4 +40,4 @@ class Macarons(nn.Module):
         """-> [n_clouds, n_camera_candidates, seq_len]  (Macarons.py:138-178; raises for ReLU like :175-176)."""
         if not self.visibility.use_sigmoid:
             raise NameError("WARNING! ReLU has been used in visibility model.")
-        return ops.sh_visibilities(pts, harmonics, X_cam, True)
+        return self.visibility.compute_visibilities(pts, harmonics, X_cam)

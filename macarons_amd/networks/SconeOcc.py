@@ -10,6 +10,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from .. import autograd as A
 from .. import ops, _lib
 from .Attention import Embedding, Encoder, _f32c, _inference_only
 from .packing import BlobCache, TableCache
@@ -147,7 +148,6 @@ class SconeOcc(nn.Module):
     def forward(self, pc, x, view_harmonics, mask=None, verbose=False, perms=None):
         """pc [n_clouds, M, 3], x [n_clouds, Q, 3], view_harmonics [n_clouds, Q, 64] -> [n_clouds, Q, 1].
         `perms` (optional): the three index tensors draw_perms() would return, to pin the hidden RNG."""
-        _inference_only(self, pc, x)
         if mask is not None:
             raise NotImplementedError("mask is None in every call site of the hot path")
         if not self._is_default_arch():
@@ -166,5 +166,25 @@ class SconeOcc(nn.Module):
             blobs = [c.get(t, variant) for c, t in zip(self._blob_caches, self.local_transformers)]
         else:
             blobs = None
-        res = ops.scone_occ_forward(pc_global, scales, x, view_harmonics, self._table_cache.get(self, self.weight_table), blobs)
+        if A.needs_grad(self, pc, x, view_harmonics):   # trainers: HIP forward, composite-torch backward (autograd.py)
+            pidx = [p.to(dev) for p in perms]
+
+            def clouds(pc_):
+                sc = [pc_.contiguous()]
+                for p in pidx[1:]:
+                    sc.append(sc[-1][:, p].contiguous())
+                return pc_[:, pidx[0]].contiguous(), sc
+
+            def hip(pc_, x_, vh_):
+                g, sc = clouds(pc_)
+                return ops.scone_occ_forward(g, sc, x_, vh_, self._table_cache.get(self, self.weight_table), blobs)
+
+            def composite(pc_, x_, vh_):
+                g, sc = clouds(pc_)
+                with torch.no_grad():
+                    idx = [ops.knn_points(x_.detach().contiguous(), s_.detach(), self.k_for_knn)[2] for s_ in sc]
+                return A.scone_occ(self, g, sc, x_, vh_, idx)
+            res = A.with_torch_backward(hip, composite, (pc, x, view_harmonics), self)
+        else:
+            res = ops.scone_occ_forward(pc_global, scales, x, view_harmonics, self._table_cache.get(self, self.weight_table), blobs)
         return res.view(n_clouds, n_sample, self.output_dim)

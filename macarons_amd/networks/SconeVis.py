@@ -12,8 +12,9 @@ The loss modules (:306-378) are training-only and out of this tier.
 import torch
 from torch import nn
 
+from .. import autograd as A
 from .. import ops
-from .Attention import Embedding, Encoder, _f32c, _inference_only
+from .Attention import Embedding, Encoder, _f32c
 from .packing import TableCache
 
 
@@ -72,7 +73,6 @@ class SconeVis(nn.Module):
         """pts [n_clouds, seq_len, 4], view_harmonics [n_clouds, seq_len, 64] -> [n_clouds, seq_len, 64].
         lengths (extension, optional int32 device tensor [n_clouds]): cloud b is its first lengths[b] rows; the rest of the
         batch is padding (the reference slices on the host instead, which costs a device->host sync per decision)."""
-        _inference_only(self, pts)
         if mask is not None:
             raise NotImplementedError("mask is None in every call site of the hot path (SURVEY §8 a6)")
         if not self._is_default_arch():
@@ -80,18 +80,30 @@ class SconeVis(nn.Module):
         if view_harmonics is None:
             raise ValueError("view_harmonics is required (view_state_mode='end')")
         n_clouds, seq_len = pts.shape[0], pts.shape[1]
-        res = ops.scone_vis_forward(pts, view_harmonics, self._table_cache.get(self, self.weight_table), lengths)
+        hip = lambda p, vh: ops.scone_vis_forward(p, vh, self._table_cache.get(self, self.weight_table), lengths)
+        if A.needs_grad(self, pts, view_harmonics):     # trainers (pretrain_scone_vis.py:224): HIP forward, composite-torch backward
+            res = A.with_torch_backward(hip, lambda p, vh: A.scone_vis(self, p, vh, lengths), (pts, view_harmonics), self)
+        else:
+            res = hip(pts, view_harmonics)
         return res.view(n_clouds, seq_len, self.n_harmonics)
 
     def compute_visibilities(self, pts, harmonics, X_cam):
         """-> [n_clouds, n_camera_candidates, seq_len]   (SconeVis.py:164-208)."""
         self._check_scorer(harmonics)
-        return ops.sh_visibilities(pts, harmonics, X_cam, self.use_sigmoid)
+        sig = self.use_sigmoid
+        hip = lambda p, h, c: ops.sh_visibilities(p, h, c, sig)
+        if A.needs_grad(None, pts, harmonics, X_cam):
+            return A.with_torch_backward(hip, lambda p, h, c: A.visibilities(p, h, c, sig), (pts, harmonics, X_cam))
+        return hip(pts, harmonics, X_cam)
 
     def compute_coverage_gain(self, pts, harmonics, X_cam):
         """-> [n_clouds, n_camera_candidates]   (SconeVis.py:210-252)."""
         self._check_scorer(harmonics)
-        return ops.sh_coverage_gain(pts, harmonics, X_cam, self.use_sigmoid)
+        sig = self.use_sigmoid
+        hip = lambda p, h, c: ops.sh_coverage_gain(p, h, c, sig)
+        if A.needs_grad(None, pts, harmonics, X_cam):
+            return A.with_torch_backward(hip, lambda p, h, c: A.coverage_gain(p, h, c, sig), (pts, harmonics, X_cam))
+        return hip(pts, harmonics, X_cam)
 
     def compute_coverage_gain_multiple(self, pts, harmonics, X_cam, n_cam):
         """Every ordered n_cam-tuple of cameras: mean over points of the max over the tuple (SconeVis.py:254-303)."""

@@ -247,3 +247,65 @@ def test_scone_vis_padded_lengths_equal_sliced(dev):
         for b, n in enumerate(lens):
             yb = m(T(pts[b:b + 1, :n], dev), view_harmonics=T(vh[b:b + 1, :n], dev)).cpu().numpy()
             assert np.array_equal(y[b, :n], yb[0]), (b, n, np.abs(y[b, :n] - yb[0]).max())
+
+
+def test_trainer_gradients_hip_forward_torch_backward(dev):
+    """With gradients enabled the entry points the trainers differentiate (pretrain_scone_vis.py:224, pretrain_scone_occ.py,
+    train_macarons.py:1159) run the HIP forward and a composite-torch backward: the forward value is the HIP one (bit for bit
+    what the no-grad call returns), the composite reproduces it to 1e-4 and the gradients equal autograd through the composite."""
+    from macarons_amd import autograd as A
+    from macarons_amd.networks import SconeVis, SconeOcc
+    vis, _ = _mod(SconeVis, 1, dev)
+    occ, _ = _mod(SconeOcc, 2, dev)
+    rng = np.random.default_rng(21)
+    pts = T(np.concatenate([rng.uniform(-.5, .5, (2, 60, 3)), rng.uniform(.1, 1, (2, 60, 1))], -1).astype(np.float32), dev)
+    vh = T((rng.standard_normal((2, 60, 64)) * 0.3).astype(np.float32), dev)
+    cams = T(rng.standard_normal((2, 7, 3)).astype(np.float32), dev)
+    w = T(rng.standard_normal((2, 7)).astype(np.float32), dev)
+    with torch.no_grad():
+        h_ref = vis(pts, view_harmonics=vh)
+        g_ref = vis.compute_coverage_gain(pts, h_ref, cams)
+    for p in vis.parameters():
+        p.grad = None
+    h = vis(pts, view_harmonics=vh)                            # grad enabled, parameters require grad
+    g = vis.compute_coverage_gain(pts, h, cams)
+    assert torch.equal(h, h_ref) and torch.equal(g, g_ref) and g.requires_grad
+    (g * w).sum().backward()
+    got = {n: p.grad.clone() for n, p in vis.named_parameters()}
+    for p in vis.parameters():
+        p.grad = None
+    hc = A.scone_vis(vis, pts, vh)
+    gc = A.coverage_gain(pts, hc, cams)
+    assert rel_err(hc.detach().cpu().numpy(), h_ref.cpu().numpy()) < 1e-4 and rel_err(gc.detach().cpu().numpy(), g_ref.cpu().numpy()) < 1e-4
+    (gc * w).sum().backward()
+    scale = max(float(p.grad.abs().max()) for p in vis.parameters())
+    for n, p in vis.named_parameters():
+        # relative to the layer's own gradient, floored at 1e-4 of the largest one (w_k.bias has a mathematically ZERO gradient:
+        # softmax ignores a constant added to every key's score, what is left there is rounding noise)
+        ref = p.grad.cpu().numpy()
+        assert got[n] is not None and np.abs(got[n].cpu().numpy() - ref).max() < 1e-3 * max(np.abs(ref).max(), 1e-4 * scale), n
+    # SconeOcc: gradient w.r.t. parameters and the query points
+    pc = T(rng.uniform(-.3, .3, (1, 300, 3)).astype(np.float32), dev)
+    x = T(rng.uniform(-.4, .4, (1, 50, 3)).astype(np.float32), dev).requires_grad_(True)
+    vq = T((rng.standard_normal((1, 50, 64)) * 0.3).astype(np.float32), dev)
+    torch.manual_seed(4)
+    perms = occ.draw_perms(300)
+    with torch.no_grad():
+        y_ref = occ(pc, x.detach(), vq, perms=perms)
+    y = occ(pc, x, vq, perms=perms)
+    assert torch.equal(y, y_ref)
+    y.sum().backward()
+    gx = x.grad.clone()
+    gw = occ.linear2.weight.grad.clone()
+    x.grad = None
+    for p in occ.parameters():
+        p.grad = None
+    from macarons_amd import ops
+    dev_perms = [p.to(dev) for p in perms]
+    scales = [pc, pc[:, dev_perms[1]]]
+    scales.append(scales[1][:, dev_perms[2]])
+    idx = [ops.knn_points(x.detach().contiguous(), s_.contiguous(), 16)[2] for s_ in scales]
+    yc = A.scone_occ(occ, pc[:, dev_perms[0]], scales, x, vq, idx)
+    assert rel_err(yc.detach().cpu().numpy(), y_ref.cpu().numpy()) < 1e-4
+    yc.sum().backward()
+    assert rel_err(gx.cpu().numpy(), x.grad.cpu().numpy()) < 1e-3 and rel_err(gw.cpu().numpy(), occ.linear2.weight.grad.cpu().numpy()) < 1e-3
