@@ -96,7 +96,7 @@ class PipelinedBest:
         mk = lambda *shape, dtype=torch.float32: torch.empty(shape, dtype=dtype, device=device)
         self.slots = [dict(send=mk(batch, B, 2), recv=mk(self.world, batch * B, 2), vals=mk(batch * B),
                            idx=mk(batch * B, dtype=torch.int64), ready=torch.cuda.Event(), done=torch.cuda.Event(),
-                           used=False, fill=0) for _ in range(depth)]
+                           used=False, fill=0, gen=0) for _ in range(depth)]
         self._cur = 0
 
     def submit(self, gains, idx_offset):
@@ -107,9 +107,10 @@ class PipelinedBest:
         j = s["fill"]
         self._ops.best_record(gains, idx_offset, out=s["send"][j])
         s["fill"] = j + 1
+        handle = (s, j, s["gen"])
         if s["fill"] == self.batch:
             self._exchange(s)
-        return (s, j)
+        return handle
 
     def _exchange(self, s):
         n = s["fill"]
@@ -125,6 +126,7 @@ class PipelinedBest:
             self._ops.best_merge(s["recv"], out_vals=s["vals"], out_idx=s["idx"])
             s["done"].record(self.comm)
         s["used"], s["fill"] = True, 0
+        s["gen"] += 1                                # handles of this batch stay valid until the slot is refilled `depth` batches later
         self._cur = (self._cur + 1) % self.depth
 
     def flush(self):
@@ -133,8 +135,11 @@ class PipelinedBest:
 
     def result(self, handle):
         """(max_gain [B], nbv_idx [B]) of one submitted decision; the current stream waits for its batch's exchange."""
-        s, j = handle
-        if s["fill"] > j:
+        s, j, gen = handle
+        if s["gen"] == gen:
             raise RuntimeError("PipelinedBest.result: the decision's batch has not been exchanged yet (call flush())")
+        if s["gen"] != gen + 1:
+            raise RuntimeError("PipelinedBest.result: stale handle -- its slot has been reused by a later batch "
+                               "(read results within depth x batch submits)")
         torch.cuda.current_stream(s["vals"].device).wait_event(s["done"])
         return s["vals"][j * self.B:(j + 1) * self.B], s["idx"][j * self.B:(j + 1) * self.B]

@@ -173,11 +173,15 @@ _ws_cache = {}
 
 
 def _workspace(device, nbytes):
-    """One grow-only scratch buffer per device (the C ABI never allocates)."""
-    key = (device.type, device.index)
+    """One grow-only scratch arena per (device, stream): the C ABI never allocates, and two streams running workspace-using ops
+    concurrently must not share scratch.  A grown arena replaces the old one; the old tensor is freed by torch's caching
+    allocator only after the work queued on its stream (record_stream)."""
+    stream = torch.cuda.current_stream(device)
+    key = (device.type, device.index, stream.cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.1) + 256, dtype=torch.uint8, device=device)
+        buf.record_stream(stream)
         _ws_cache[key] = buf
     return buf
 

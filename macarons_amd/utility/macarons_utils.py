@@ -58,7 +58,8 @@ def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harm
                                       prediction_view_matrices, prediction_box_diag, seq_len=2048, min_occ=0.1,
                                       distance_th=17., samples=None, smooth=False, return_parts=False):
     """The per-neighbour-camera scoring loop of testers/scene.py:434-454 around
-    predict_coverage_gain_for_single_camera (macarons_utils.py:1580-1738), for K cameras:
+    predict_coverage_gain_for_single_camera (macarons_utils.py:1580-1738), for K cameras AT ONCE and without a host
+    synchronisation (the reference runs one SconeVis forward and reads a count back per camera):
       frustum mask (all K at once) -> occupancy-weighted sampling inside each frustum -> prediction-view space ->
       SconeVis -> per-point visibility gains (C = 1) x distance factor -> mean x sum(occ in frustum).
     X_world [P,3], proxy_view_harmonics [P,64], occ_probs [P,1], cameras [K,40], X_cam_world [K,3],
@@ -68,36 +69,45 @@ def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harm
     factored per-point gains [N] and sampled world points [N,4])."""
     K = cameras.shape[0]
     dev = X_world.device
+    S = seq_len
     mask = ops.points_in_fov(X_world, cameras)                                            # :1603
     occ_k = ops.fov_mask_occ(mask, occ_probs.reshape(-1).contiguous())                    # :1606-1613 folded into the sampler
-    gains = torch.zeros(K, dtype=torch.float32, device=dev)
-    parts_vis, parts_world = [], []
+    # ---- sampling inside every frustum (:1624): K independent distributions, nothing read back (padded rows, counts on the device)
+    res, res_h, inv, nu, vol = [], [], [], [], []
     for k in range(K):
-        u = samples[k] if samples is not None else torch.rand(seq_len, device=dev)
-        res, res_h, inv, uniq, vol = ops.sample_proxy(X_world, occ_k[k], proxy_view_harmonics, u.reshape(-1), min_occ,
-                                                      return_volume=True)                 # :1624
-        if res.shape[0] == 0:
-            parts_vis.append(None); parts_world.append(None)
-            continue                                                                      # empty frustum: gain 0 (:1707-1736)
-        world = res[inv].contiguous()                                                     # MC duplicates (:1668-1671)
-        center_w = (res[:, :3].max(dim=0)[0] + res[:, :3].min(dim=0)[0]).view(1, 3) / 2.  # :1631-1633
-        Mv = prediction_view_matrices[k].contiguous()
-        c_view = torch.cat((center_w, torch.ones(1, 1, device=dev)), 1) @ Mv              # prediction_box_center (:1641)
-        center = c_view[0, :3].contiguous()
-        pts = res.clone()
-        ops.transform_points_(pts, Mv, center, 1.0 / prediction_box_diag)                 # :1647-1650
-        cam = X_cam_world[k].view(1, 3).clone()
-        cam4 = torch.cat((cam, torch.ones(1, 1, device=dev)), 1)
-        ops.transform_points_(cam4, Mv, center, 1.0 / prediction_box_diag)                # :1655-1659
-        harm = visibility_model(pts[None], view_harmonics=res_h[None])                    # :1664
-        vis = ops.sh_visibilities(pts[inv][None].contiguous(), harm[0][inv][None].contiguous(),
-                                  cam4[:, :3].reshape(1, 1, 3).contiguous(), True)        # :1683  [1,1,N]
-        g = ops.macarons_gain_(vis.view(1, -1), world[None], X_cam_world[k].view(1, 3).contiguous(),
-                               vol.float(), distance_th, smooth)                          # :1699-1704
-        gains[k] = g[0]
-        parts_vis.append(vis.view(-1)); parts_world.append(world)
+        u = samples[k] if samples is not None else torch.rand(S, device=dev)
+        r, h, i, _, n, v = ops.sample_proxy(X_world, occ_k[k], proxy_view_harmonics, u.reshape(-1), min_occ, return_volume=True,
+                                            padded=True)
+        res.append(r); res_h.append(h); inv.append(i); nu.append(n); vol.append(v)
+    res, res_h, inv = torch.stack(res), torch.stack(res_h), torch.stack(inv)              # [K,S,4] [K,S,64] [K,S]
+    nu, vol = torch.cat(nu), torch.cat(vol).float()                                       # [K] int32, [K]
+    # ---- prediction box: centre of the sampled points' bounding box, in the prediction camera's view space (:1631-1641)
+    valid = (torch.arange(S, device=dev)[None, :] < nu[:, None])[..., None]               # [K,S,1]
+    xyz = res[..., :3]
+    hi = torch.where(valid, xyz, torch.full_like(xyz, float("-inf"))).amax(dim=1)
+    lo = torch.where(valid, xyz, torch.full_like(xyz, float("inf"))).amin(dim=1)
+    center_w = torch.where((nu > 0)[:, None], (hi + lo) / 2., torch.zeros_like(hi))       # empty frustum: any finite centre
+    Mv = prediction_view_matrices.to(device=dev, dtype=torch.float32).contiguous()
+    center = torch.bmm(torch.cat((center_w, torch.ones(K, 1, device=dev)), 1)[:, None, :], Mv)[:, 0, :3].contiguous()
+    pts = res.clone()
+    cam4 = torch.cat((X_cam_world.reshape(K, 3), torch.ones(K, 1, device=dev)), 1).contiguous()
+    inv_diag = 1.0 / prediction_box_diag
+    for k in range(K):                                                                    # one small launch each, no sync
+        ops.transform_points_(pts[k], Mv[k], center[k], inv_diag)                         # :1647-1650
+        ops.transform_points_(cam4[k:k + 1], Mv[k], center[k], inv_diag)                  # :1655-1659
+    # ---- ONE SconeVis forward over the K padded clouds (:1664), ONE scorer launch (C = 1 per cloud, :1683), ONE gain launch
+    harm = visibility_model(pts, view_harmonics=res_h, lengths=nu)
+    gi = inv[..., None]
+    pts_mc = torch.gather(pts, 1, gi.expand(-1, -1, 4)).contiguous()                      # MC duplicates (:1668-1671)
+    harm_mc = torch.gather(harm, 1, gi.expand(-1, -1, 64)).contiguous()
+    world = torch.gather(res, 1, gi.expand(-1, -1, 4)).contiguous()
+    vis = ops.sh_visibilities(pts_mc, harm_mc, cam4[:, None, :3].contiguous(), True).view(K, S)
+    gains = ops.macarons_gain_(vis, world, X_cam_world.reshape(K, 3).contiguous(), vol, distance_th, smooth)     # :1699-1704
+    gains = torch.where(nu > 0, gains, torch.zeros_like(gains))                           # empty frustum: gain 0 (:1707-1736)
     if return_parts:
-        return gains, parts_vis, parts_world
+        n_host = nu.tolist()
+        return (gains, [vis[k] if n_host[k] > 0 else None for k in range(K)],
+                [world[k] if n_host[k] > 0 else None for k in range(K)])
     return gains
 
 
