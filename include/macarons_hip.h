@@ -142,7 +142,8 @@ int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_feat
  *   keeps points with preds > min_occ, draws n_sample points with probability proportional to preds (inverse
  *   CDF in fp64: first i with C_i >= u * C_last), then unique (sorted) + inverse.  Outputs are padded to
  *   n_sample rows (rows >= *n_unique are zero-filled); *n_unique (device int) says how many are valid.  uniq holds
- *   ORIGINAL point indices.  Three launches: block sums + scan of them by the last block to finish, one wave per sample
+ *   ORIGINAL point indices.  view_harmonics may be NULL (then res_harmonics is not written: a caller that only holds a
+ *   shard of the harmonics recomputes the rows of the sampled points from uniq).  Three launches: block sums + scan of them by the last block to finish, one wave per sample
  *   for the search, one block for sort / unique / inverse / gather.
  *   res [n_sample,4] = (X, pred), res_harmonics [n_sample,64].  preds may be strided (pred_stride floats).
  *   volume (optional device double): sum of the kept occupancies (fov_proxy_volume of macarons_utils.py:1620).

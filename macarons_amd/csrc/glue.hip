@@ -243,12 +243,12 @@ __global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__
         const int c = threadIdx.x & 63;
         if (r < nu) {
             const long long i = uniq[r];
-            res_h[(long long)r * 64 + c] = vh[i * 64 + c];
+            if (vh) res_h[(long long)r * 64 + c] = vh[i * 64 + c];
             if (c < 3) res[r * 4 + c] = X[i * 3 + c];
             if (c == 3) res[r * 4 + 3] = preds[i * pred_stride];
         } else {
             uniq[r] = 0;
-            res_h[(long long)r * 64 + c] = 0.f;
+            if (vh) res_h[(long long)r * 64 + c] = 0.f;
             if (c < 4) res[r * 4 + c] = 0.f;
         }
     }
@@ -570,7 +570,7 @@ size_t mcr_sample_proxy_workspace_bytes(int64_t P, int n_sample) {
 int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t P,
                      float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
                      int64_t* inverse, int* n_unique, double* volume, void* workspace, size_t workspace_bytes, void* stream) {
-    MCR_REQUIRE(X && preds && view_harmonics && u && res && res_harmonics && uniq && inverse && n_unique,
+    MCR_REQUIRE(X && preds && u && res && uniq && inverse && n_unique && (res_harmonics || !view_harmonics),
                 "mcr_sample_proxy: null pointer");
     MCR_REQUIRE(P > 0 && n_sample > 0 && n_sample <= SMP_MAX, "mcr_sample_proxy: need 0 < n_sample <= %d", SMP_MAX);
     MCR_REQUIRE(P < (1ll << 49), "mcr_sample_proxy: P too large");

@@ -68,8 +68,10 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
             vh_l = torch.zeros(1, 0, grid.base_harmonics.shape[0], dtype=torch.float32, device=dev)
             occ_l = torch.zeros(0, 1, dtype=torch.float32, device=dev)
         if sharded:
+            # only the occupancies travel (4 B per proxy point); the view harmonics of the <= seq_len sampled points are
+            # recomputed locally below (a row is a function of its own point): all-gathering them would move 256 B per point
             occ = mdist.allgather_rows(occ_l, Q, group)
-            vh = mdist.allgather_rows(vh_l[0], Q, group)
+            vh = None
         else:
             occ, vh = occ_l, vh_l[0]
         # ---- occupancy-weighted Monte-Carlo sampling (:146-154); identical on every rank ----
@@ -79,8 +81,15 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
                 torch.distributed.broadcast(samples, 0, group=group)
         # no host read-back: the unique sampled points stay padded to seq_len rows and their count stays on the device
         # (SconeVis consumes it as `lengths`); the reference slices on the host (:146-157)
-        proxy_points, vh_s, sample_idx, n_unique = su.sample_proxy_points(X[0], occ, vh, n_sample=seq_len, min_occ=min_occ,
-                                                                          samples=samples, padded=True)
+        if vh is not None:
+            proxy_points, vh_s, sample_idx, n_unique = su.sample_proxy_points(X[0], occ, vh, n_sample=seq_len, min_occ=min_occ,
+                                                                              samples=samples, padded=True)
+        else:
+            from . import ops
+            proxy_points, _, sample_idx, _, n_unique = ops.sample_proxy(X[0].contiguous(), occ.reshape(-1), None, samples.reshape(-1),
+                                                                        min_occ, padded=True)
+            vs_s = su.compute_view_state(proxy_points[None, :, :3].contiguous(), X_view, grid.n_elev, grid.n_azim)
+            vh_s = su.compute_view_harmonics(vs_s, grid.base_harmonics, grid.h_polar, grid.h_azim, grid.n_elev, grid.n_azim)[0]
         sampled = (proxy_points, sample_idx)
         # ---- visibility-gain harmonics (:157-160) ----
         harm = scone_vis(proxy_points[None], view_harmonics=vh_s[None], lengths=n_unique)

@@ -291,12 +291,13 @@ def sample_proxy(X, preds, view_harmonics, u, min_occ, return_volume=False, padd
     replaces sample_proxy_points (scone_utils.py:1030-1061).  One host sync to read n_u (torch.unique syncs too) -- unless
     padded=True: then res / res_harmonics / uniq keep their n_sample rows (zeros beyond n_u) and the count comes back as an
     int32 device tensor [1] in place of the slicing: (res, res_harmonics, inverse, uniq, n_unique[, volume]), no host sync."""
-    X, preds, vh, u = _req(X, "X"), _req(preds, "preds"), _req(view_harmonics, "view_harmonics"), _req(u, "samples")
+    X, preds, u = _req(X, "X"), _req(preds, "preds"), _req(u, "samples")
+    vh = _req(view_harmonics, "view_harmonics") if view_harmonics is not None else None    # None: res_harmonics comes back as None
     P = X.shape[0]
     n = u.numel()
     dev = X.device
     res = torch.empty((n, 4), dtype=torch.float32, device=dev)
-    resh = torch.empty((n, 64), dtype=torch.float32, device=dev)
+    resh = torch.empty((n, 64), dtype=torch.float32, device=dev) if vh is not None else None
     uniq = torch.empty(n, dtype=torch.int64, device=dev)
     inv = torch.empty(n, dtype=torch.int64, device=dev)
     nu = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -304,8 +305,9 @@ def sample_proxy(X, preds, view_harmonics, u, min_occ, return_volume=False, padd
     L_ = lib()
     ws = _workspace(dev, L_.mcr_sample_proxy_workspace_bytes(c_i64(P), c_int(n)))
     with torch.cuda.device(dev):
-        check(L_.mcr_sample_proxy(_p(X), _p(preds), c_i64(1), _p(vh), c_i64(P), c_f32(float(min_occ)), _p(u), c_int(n),
-                                  _p(res), _p(resh), _p(uniq), _p(inv), _p(nu), _p(vol), _p(ws), c_size(ws.numel()), _stream()),
+        check(L_.mcr_sample_proxy(_p(X), _p(preds), c_i64(1), _p(vh) if vh is not None else c_vp(0), c_i64(P),
+                                  c_f32(float(min_occ)), _p(u), c_int(n), _p(res), _p(resh) if resh is not None else c_vp(0),
+                                  _p(uniq), _p(inv), _p(nu), _p(vol), _p(ws), c_size(ws.numel()), _stream()),
               "mcr_sample_proxy")
     if padded:
         return (res, resh, inv, uniq, nu, vol) if return_volume else (res, resh, inv, uniq, nu)
