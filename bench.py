@@ -276,6 +276,7 @@ def main():
     ap.add_argument("--waves-per-simd", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nbv", action="store_true", help="skip the NBV-step latency measurement")
+    ap.add_argument("--no-strong", action="store_true", help="skip the config-4 strong-scaling scorer leg (profiling the headline size alone)")
     ap.add_argument("--nbv-iters", type=int, default=50)
     args = ap.parse_args()
 
@@ -333,11 +334,13 @@ def main():
     cams_s = cams_s[:, c0:c1].contiguous()
     s_steps, s_warm = max(20, min(args.steps, 500)), max(5, min(args.warmup, 50))
     strong = None
-    if c1 > c0:
+    if args.no_strong:
+        wall_s = float("nan")
+    elif c1 > c0:
         wall_s, _, _ = scorer_run(pts, harm, cams_s, c0, s_steps, s_warm)
     else:                                                  # more ranks than cameras cannot happen at 512 cameras; keep the barriers aligned
         wall_s, _, _ = timed_scorer_loop(lambda: None, lambda h: h, s_steps, s_warm, dev, dist)
-    strong = {"metric": f"coverage-gain evals/s, N={N} points x {Cs} cameras in total (BASELINE config 4), strong scaling",
+    strong = None if args.no_strong else {"metric": f"coverage-gain evals/s, N={N} points x {Cs} cameras in total (BASELINE config 4), strong scaling",
               "value": Cs * s_steps / wall_s, "unit": "evals/s", "steps": s_steps, "warmup": s_warm,
               "ms_per_step": wall_s * 1e3 / s_steps, "cams_total": Cs, "cams_this_rank": c1 - c0, "scaling": "strong"}
 

@@ -1,12 +1,15 @@
 #!/bin/bash
 # Round profile on the GPU box: bench line, rocprofv3 kernel stats of the same command, PMC passes (own runs, --pmc only)
-# for the scorer and the fused local transformer.  Outputs under gpurun_out/round/ (copy the summaries into profiles/).
+# for the scorer, the fused local transformer and the head GEMM.  Outputs under gpurun_out/round/ (copy the summaries into profiles/).
 R=/root/repo
 OUT=$R/gpurun_out/round
 mkdir -p $OUT
 cd $R && python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats -o bench -- python $R/bench.py --steps 500 --warmup 100 --no-cpu-baseline --nbv-iters 20 > $OUT/kstats.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_scorer -o bench -- python $R/bench.py --steps 500 --warmup 100 --no-cpu-baseline --no-nbv --no-strong > $OUT/kstats_scorer.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/ktrace -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --nbv-iters 20 > /dev/null 2>&1
+python $R/tools/trace_gaps.py $OUT/ktrace/t_kernel_trace.csv > $OUT/nbv_gaps.txt 2>&1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU_TRANS_F32" \
            "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
@@ -28,6 +31,7 @@ if "FETCH_SIZE" in res["per_dispatch_mean"]:
 json.dump(res, open("$OUT/scorer_pmc.json", "w"), indent=1)
 print(json.dumps(res)[:600])
 PY
-VARIANT=5 $R/tools/pmc_local_pct.sh > $OUT/local_pct5_pmc.txt 2>&1
-VARIANT=5 $R/tools/pmc_local_pct_mem.sh >> $OUT/local_pct5_pmc.txt 2>&1
-grep -c . $OUT/local_pct5_pmc.txt
+VARIANT=6 $R/tools/pmc_local_pct.sh > $OUT/local_pct6_pmc.txt 2>&1
+VARIANT=6 $R/tools/pmc_local_pct_mem.sh >> $OUT/local_pct6_pmc.txt 2>&1
+rm -rf $R/gpurun_out/pmc_generic; KERNEL=linear3h_kernel $R/tools/pmc_generic.sh python $R/tools/time_networks.py > $OUT/linear3h_pmc.txt 2>&1
+grep -c . $OUT/local_pct6_pmc.txt $OUT/linear3h_pmc.txt
