@@ -277,7 +277,7 @@ __device__ __forceinline__ void ln_finish(const f32x16 (&x)[2], const float2* __
 
 #ifdef L6_TRACE             // dev only: per-phase timestamps of one workgroup (tools/build_variant.py ... -DL6_TRACE=<block>)
 __device__ long long l6_trace_buf[64];
-#define L6_T() do { if (blockIdx.x == (L6_TRACE) && tid == 0) l6_trace_buf[tp] = clock64(); ++tp; } while (0)
+#define L6_T() do { if (blockIdx.x == (L6_TRACE) && tid == 0) { l6_trace_buf[tp] = clock64(); l6_trace_buf[tp ? 63 : 62] = wall_clock64(); } ++tp; } while (0)
 #else
 #define L6_T() do { } while (0)
 #endif

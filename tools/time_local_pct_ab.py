@@ -23,6 +23,8 @@ for rnd in range(2):
     for v in variants:
         _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(v))
         blob = pack_local_pct(occ.local_transformers[0], v)
+        if os.environ.get("ZERO_BLOB"): blob = torch.zeros_like(blob)      # power experiment: same instruction stream on zero operands
+        if os.environ.get("ZERO_INPUT"): offs = torch.zeros_like(offs)
         for _ in range(3): y = ops.local_pct_forward(offs, blob)
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(20): y = ops.local_pct_forward(offs, blob)

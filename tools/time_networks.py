@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from macarons_amd.networks import SconeVis, SconeOcc
 
 dev = torch.device("cuda:0")
+if os.environ.get("VARIANT"):
+    import ctypes
+    from macarons_amd import _lib
+    _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(int(os.environ["VARIANT"])))
 torch.manual_seed(0)
 vis, occ = SconeVis().to(dev).eval(), SconeOcc().to(dev).eval()
 Q, M = int(os.environ.get("Q", 100000)), int(os.environ.get("M", 10240))

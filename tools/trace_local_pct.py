@@ -11,6 +11,7 @@ L = _lib.lib(); L.mcr_set_local_pct_variant(ctypes.c_int(v))
 with contextlib.redirect_stdout(io.StringIO()):
     occ = SconeOcc().to(dev)
 blob = pack_local_pct(occ.local_transformers[0], v)
+if os.environ.get("ZERO_BLOB"): blob = torch.zeros_like(blob)
 offs = torch.randn(16384, 16, 3, device=dev) * 0.05
 names = ["emb1 product", "emb1 gelu+barrier", "emb2 gemm"]
 for e in range(2):
@@ -25,5 +26,6 @@ for it in range(5):
     d = [buf[i + 1] - buf[i] for i in range(len(names))]
     acc = d if acc is None else [a + b for a, b in zip(acc, d)]
 tot = sum(acc) / 5
+print(f"last launch: {buf[len(names)] - buf[0]} shader ticks in {(buf[63] - buf[62]) * 10} ns (100 MHz wall clock) -> {(buf[len(names)] - buf[0]) / ((buf[63] - buf[62]) * 10):.2f} GHz")
 print(f"total {tot:.0f} ticks")
 for n, a in zip(names, acc): print(f"  {n:22s} {a/5:9.0f}  {100*a/5/tot:5.1f} %")
