@@ -54,7 +54,8 @@ int mcr_sh_visibilities(const float* pts, int pts_dim, const float* harmonics, c
  * (macarons/networks/SconeOcc.py:297-298).
  *   X [B,Q,3] queries, pc [B,M,3] surface points ->
  *   idx [B,Q,k] int64 (ascending distance; ties -> lower index), dists [B,Q,k], pts [B,Q,k,3]
- *   (neighbour coordinates, minus the query if subtract_query).  k in {1,4,8,16}, k <= M. */
+ *   (neighbour coordinates, minus the query if subtract_query).  k in {1,4,8,16}, k <= M.  idx and / or dists may be NULL
+ *   (not written: SconeOcc only consumes the offsets). */
 int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B, int64_t Q,
                    int64_t M, int k, int subtract_query, void* stream);
 
@@ -73,6 +74,12 @@ int mcr_layernorm(const float* X, int64_t ldx, const float* gamma, const float* 
                   void* stream);
 int mcr_attention(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim,
                   int v_dim, void* stream);
+/* Same with a scratch buffer of mcr_attention_workspace_bytes(S, L, n_heads, v_dim) bytes: one or two long sequences (too few
+ * blocks to fill the chip) split their keys over two blocks and merge the partial soft-maxes (results differ from mcr_attention
+ * by summation order only, ~1e-6). */
+size_t mcr_attention_workspace_bytes(int64_t S, int64_t L, int n_heads, int v_dim);
+int mcr_attention_ws(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim,
+                     int v_dim, void* workspace, size_t workspace_bytes, void* stream);
 int mcr_colmax_broadcast(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int64_t L, int E, void* stream);
 int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int64_t L, int E, void* stream);
 

@@ -19,6 +19,17 @@ __device__ __forceinline__ float py_mod(float a, float b) {       // torch.remai
     return m;
 }
 
+// Zero fill by a kernel instead of hipMemsetAsync: inside a captured hipGraph (nbv.GraphedNbvStep) the memset nodes of this
+// ROCm build did not take effect on the second and later replays (view_state accumulated across replays); a kernel node does.
+__global__ void zero_kernel(unsigned* __restrict__ p, long long n_words) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (long long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static void launch_zero(hipStream_t s, void* p, size_t bytes) {       // bytes % 4 == 0, p 4-byte aligned
+    const long long n = (long long)(bytes / 4);
+    if (n <= 0) return;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)std::min<long long>(cdiv(n, 256), 2048)), dim3(256), 0, s, (unsigned*)p, n);
+}
+
 __global__ void view_state_kernel(const float* __restrict__ pts, int pts_dim, const float* __restrict__ X_view,
                                   float* __restrict__ view_state, long long n_points, int n_view, int n_elev, int n_azim) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -183,14 +194,11 @@ __global__ __launch_bounds__(256) void smp_search(const float* __restrict__ pred
     if (lane == 0) picked[sidx] = ans;
 }
 
-// one block: bitonic sort of (picked, sample id), unique, inverse, gather.  n_sample <= SMP_MAX.
-//   res[r] = (X[uniq[r]], pred[uniq[r]]), res_h[r] = vh[uniq[r]] for r < n_unique (scone_utils.py:1060-1061), zeros beyond
+// one block: bitonic sort of (picked, sample id), unique, inverse (scone_utils.py:1060-1061).  n_sample <= SMP_MAX.
 constexpr int SMP_MAX = 4096;
 __global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__ picked, int n_sample,
                                                    long long* __restrict__ uniq, long long* __restrict__ inverse,
-                                                   int* __restrict__ n_unique, const float* __restrict__ X,
-                                                   const float* __restrict__ preds, long long pred_stride,
-                                                   const float* __restrict__ vh, float* __restrict__ res, float* __restrict__ res_h) {
+                                                   int* __restrict__ n_unique) {
     __shared__ long long key[SMP_MAX];
     __shared__ int rank[SMP_MAX];
     int n2 = 1;
@@ -237,20 +245,24 @@ __global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__
         inverse[key[i] & 8191] = r;
     }
     if (threadIdx.x == 0) *n_unique = nu;
-    __syncthreads();                                               // uniq[] (global, written by this block) is complete
-    // gather: 16 rows x 64 columns per pass
-    for (int r = threadIdx.x >> 6; r < n_sample; r += 16) {
-        const int c = threadIdx.x & 63;
-        if (r < nu) {
-            const long long i = uniq[r];
-            if (vh) res_h[(long long)r * 64 + c] = vh[i * 64 + c];
-            if (c < 3) res[r * 4 + c] = X[i * 3 + c];
-            if (c == 3) res[r * 4 + 3] = preds[i * pred_stride];
-        } else {
-            uniq[r] = 0;
-            if (vh) res_h[(long long)r * 64 + c] = 0.f;
-            if (c < 4) res[r * 4 + c] = 0.f;
-        }
+    for (int r = nu + threadIdx.x; r < n_sample; r += 1024) uniq[r] = 0;      // padding rows
+}
+
+// res[r] = (X[uniq[r]], pred[uniq[r]]), res_h[r] = vh[uniq[r]] for r < n_unique, zeros beyond.  grid = ceil(n_sample / 16):
+// 16 rows x 64 columns per block (inside the single sort block this gather was 128 serial passes of dependent loads: 0.2 ms)
+__global__ __launch_bounds__(1024) void smp_gather(const long long* __restrict__ uniq, const int* __restrict__ n_unique, int n_sample,
+                                                   const float* __restrict__ X, const float* __restrict__ preds, long long pred_stride,
+                                                   const float* __restrict__ vh, float* __restrict__ res, float* __restrict__ res_h) {
+    const int r = blockIdx.x * 16 + (threadIdx.x >> 6), c = threadIdx.x & 63;
+    if (r >= n_sample) return;
+    if (r < *n_unique) {
+        const long long i = uniq[r];
+        if (vh) res_h[(long long)r * 64 + c] = vh[i * 64 + c];
+        if (c < 3) res[r * 4 + c] = X[i * 3 + c];
+        if (c == 3) res[r * 4 + 3] = preds[i * pred_stride];
+    } else {
+        if (vh) res_h[(long long)r * 64 + c] = 0.f;
+        if (c < 4) res[r * 4 + c] = 0.f;
     }
 }
 
@@ -554,7 +566,7 @@ int mcr_view_state(const float* pts, int pts_dim, const float* X_view, float* vi
     MCR_REQUIRE(pts_dim >= 3 && n_points > 0 && n_view > 0 && n_elev > 0 && n_azim > 0, "mcr_view_state: bad sizes");
     hipStream_t s = (hipStream_t)stream;
     const size_t bytes = (size_t)n_points * n_elev * n_azim * sizeof(float);
-    if (int e = check_hip(hipMemsetAsync(view_state, 0, bytes, s), "mcr_view_state: memset")) return e;
+    launch_zero(s, view_state, bytes);
     const long long total = (long long)n_points * n_view;
     hipLaunchKernelGGL(view_state_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, pts, pts_dim, X_view, view_state,
                        (long long)n_points, n_view, n_elev, n_azim);
@@ -581,12 +593,13 @@ int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, co
     double* total = block_sums + nb;
     long long* picked = (long long*)(total + 2);
     unsigned* ticket = (unsigned*)(picked + n_sample);          // "last block scans" counter of smp_block_sums, in the caller's scratch
-    if (int e = check_hip(hipMemsetAsync(ticket, 0, sizeof(unsigned), s), "mcr_sample_proxy: ticket")) return e;
+    launch_zero(s, ticket, sizeof(unsigned));
     hipLaunchKernelGGL(smp_block_sums, dim3(nb), dim3(SMP_BLOCK), 0, s, preds, (long long)pred_stride, min_occ, (long long)P, block_sums,
                        nb, total, ticket);
     hipLaunchKernelGGL(smp_search, dim3((unsigned)cdiv(n_sample, 4)), dim3(256), 0, s, preds, (long long)pred_stride, min_occ,
                        (long long)P, block_sums, nb, total, u, n_sample, picked);
-    hipLaunchKernelGGL(smp_unique, dim3(1), dim3(1024), 0, s, picked, n_sample, (long long*)uniq, (long long*)inverse, n_unique, X,
+    hipLaunchKernelGGL(smp_unique, dim3(1), dim3(1024), 0, s, picked, n_sample, (long long*)uniq, (long long*)inverse, n_unique);
+    hipLaunchKernelGGL(smp_gather, dim3((unsigned)cdiv(n_sample, 16)), dim3(1024), 0, s, (const long long*)uniq, n_unique, n_sample, X,
                        preds, (long long)pred_stride, view_harmonics, res, res_harmonics);
     if (volume)
         if (int e = check_hip(hipMemcpyAsync(volume, total, sizeof(double), hipMemcpyDeviceToDevice, s), "mcr_sample_proxy: volume")) return e;

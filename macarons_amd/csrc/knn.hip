@@ -181,8 +181,8 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int w = 0; w < KNN_SPLIT; ++w) head[w] += (best_w == w) ? 1 : 0;
-        out_idx[o + j] = (long long)best_i;
-        out_dist[o + j] = sqrt_cr(best_d);
+        if (out_idx) out_idx[o + j] = (long long)best_i;
+        if (out_dist) out_dist[o + j] = sqrt_cr(best_d);
         const float* p = pcb + (size_t)best_i * 3;
         out_pts[(o + j) * 3 + 0] = OFFSETS ? p[0] - qx : p[0];
         out_pts[(o + j) * 3 + 1] = OFFSETS ? p[1] - qy : p[1];
@@ -205,7 +205,7 @@ using namespace mcr;
 
 extern "C" int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B,
                               int64_t Q, int64_t M, int k, int subtract_query, void* stream) {
-    MCR_REQUIRE(X && pc && idx && dists && pts, "mcr_knn_points: null pointer");
+    MCR_REQUIRE(X && pc && pts, "mcr_knn_points: null pointer");
     MCR_REQUIRE(B > 0 && Q > 0 && M > 0, "mcr_knn_points: empty problem B=%ld Q=%ld M=%ld", (long)B, (long)Q, (long)M);
     MCR_REQUIRE(k <= M, "mcr_knn_points: k=%d exceeds the number of points M=%ld (torch.topk would raise)", k, (long)M);
     MCR_REQUIRE(B <= 65535 && Q < (1ll << 31) && M < (1ll << 31), "mcr_knn_points: problem too large");

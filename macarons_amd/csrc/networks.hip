@@ -54,7 +54,7 @@ static void run_encoder(hipStream_t s, const EncW& w, float* x, float* h, float*
     const int dqk = E / 4, W3 = 2 * dqk + E;
     launch_layernorm(s, x, E, w.n1g, w.n1b, h, E, T, E);                                   // Attention.py:287
     launch_linear(s, h, E, w.qkv.w, w.qkv.b, nullptr, 0, qkv, W3, T, W3, E, ACT_NONE);       // :186-188
-    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens);                               // :191-198
+    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E);       // :191-198 (ff is free here: key-split scratch)
     launch_linear(s, h, E, w.out.w, w.out.b, x, E, x, E, T, E, E, ACT_NONE);                 // :201-202 + residual :290
     launch_layernorm(s, x, E, w.n2g, w.n2b, h, E, T, E);                                   // :293
     launch_linear(s, h, E, w.ff1.w, w.ff1.b, nullptr, 0, ff, 2 * E, T, 2 * E, E, ACT_GELU);  // :232
@@ -129,6 +129,24 @@ int mcr_attention(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_
     MCR_REQUIRE(L == 16 || S <= 65535, "mcr_attention: too many long sequences");
     launch_attention((hipStream_t)stream, qkv, ldq, out, ldo, S, (int)L, n_heads, qk_dim, v_dim);
     MCR_LAUNCH_CHECK("mcr_attention");
+    return 0;
+}
+
+size_t mcr_attention_workspace_bytes(int64_t S, int64_t L, int n_heads, int v_dim) {
+    return attention_split_floats(S, (int)L, n_heads, v_dim) * sizeof(float);
+}
+
+int mcr_attention_ws(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim,
+                     int v_dim, void* workspace, size_t workspace_bytes, void* stream) {
+    MCR_REQUIRE(qkv && out, "mcr_attention_ws: null pointer");
+    MCR_REQUIRE(S > 0 && L > 0, "mcr_attention_ws: empty problem");
+    MCR_REQUIRE(n_heads == 4 && ((qk_dim == 32 && v_dim == 128) || (qk_dim == 64 && v_dim == 256)),
+                "mcr_attention_ws: supported head layouts are 4 heads with (qk,v) = (32,128) or (64,256); got %d heads (%d,%d)",
+                n_heads, qk_dim, v_dim);
+    MCR_REQUIRE(L == 16 || S <= 32767, "mcr_attention_ws: too many long sequences");
+    launch_attention((hipStream_t)stream, qkv, ldq, out, ldo, S, (int)L, n_heads, qk_dim, v_dim, nullptr, (float*)workspace,
+                     workspace ? workspace_bytes / sizeof(float) : 0);
+    MCR_LAUNCH_CHECK("mcr_attention_ws");
     return 0;
 }
 
@@ -317,10 +335,9 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
             for (int64_t b = 0; b < B; ++b) {
                 Arena a = scratch;
                 float* offs = a.f(nq * 16 * 3);
-                float* dist = a.f(nq * 16);
-                int64_t* idx = reinterpret_cast<int64_t*>(a.f(nq * 16 * 2));
                 MCR_REQUIRE(a.ok(), "mcr_scone_occ_forward: workspace overflow (kNN)");
-                if (int e = mcr_knn_points(x + (b * Q + q0) * 3, pc_scale[sc] + b * M_scale[sc] * 3, idx, dist, offs, 1, nq,
+                // only the offsets are consumed (SconeOcc.py:297-298): indices and distances are not written
+                if (int e = mcr_knn_points(x + (b * Q + q0) * 3, pc_scale[sc] + b * M_scale[sc] * 3, nullptr, nullptr, offs, 1, nq,
                                            M_scale[sc], 16, 1, stream))
                     return e;
                 if (local_blobs && local_blobs[sc])      // fused LDS-resident kernel (local_pct.hip)

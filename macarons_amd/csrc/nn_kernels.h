@@ -38,8 +38,10 @@ void launch_layernorm(hipStream_t s, const float* X, int64_t ldx, const float* g
 //   qkv[m, 0:DQK | DQK:2DQK | 2DQK:2DQK+DV], head h owns channels [h*d,(h+1)*d); scores / sqrt(dqk_per_head);
 //   out[m, h*dv:(h+1)*dv].   Sequences are S consecutive blocks of L rows.
 //   lens (optional, device int per sequence): keys = the first min(L, lens[s]) rows (padded variable-length batches).
+// split_ws (optional, attention_split_floats(S, L, H, DV) floats): lets one or two long sequences split their keys over two blocks
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
-                      int DQK, int DV, const int* lens = nullptr);
+                      int DQK, int DV, const int* lens = nullptr, float* split_ws = nullptr, size_t split_ws_floats = 0);
+size_t attention_split_floats(int64_t S, int L, int H, int DV);
 
 // Column max over the L rows of each of S sequences, broadcast into a column slice of every row:
 //   Y[(s*L + r)*ldy + c] = max_r' X[(s*L + r')*ldx + c], c < E          (Embedding global feature, Attention.py:117-121)

@@ -411,18 +411,25 @@ __global__ __launch_bounds__(64 * KS) void attention_flash_kernel(const float* _
 // lens (optional, device, one int per sequence): only the first min(L, lens[seq]) rows of a sequence are keys -- the padded
 // SconeVis batches of the sync-free NBV step (the number of unique sampled points never reaches the host); rows beyond it
 // still get an output (never read).
-template <int DQ, int DV>
+// SPLIT (one or two long sequences: L / 64 * H blocks do not fill the chip): grid.z = 2 * S, the two blocks of a (query tile,
+// head, sequence) take the two halves of the keys and write UNNORMALISED outputs (part 0 -> out, part 1 -> part1 [T, H*DV]) plus
+// their (running max, sum) per query -> ml [2][T][H][2]; attention_combine_kernel merges them.
+template <int DQ, int DV, bool SPLIT>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, long long ldq,
                                                              float* __restrict__ out, long long ldo, int L, int H,
-                                                             const int* __restrict__ lens) {
+                                                             const int* __restrict__ lens, float* __restrict__ part1,
+                                                             float* __restrict__ ml) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int TK = 64, LDK = DQ + 1, LDV = DV + 4, NT = DV / 16, KQ = DQ / 4;
     __shared__ float s_k[TK * LDK];
     __shared__ __attribute__((aligned(16))) float s_v[TK * LDV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
     const int hh = blockIdx.y;
-    const long long seq0 = (long long)blockIdx.z * L;
-    const int Lk = lens ? max(1, min(L, __builtin_amdgcn_readfirstlane(lens[blockIdx.z]))) : L;       // number of keys
+    const int seq = SPLIT ? blockIdx.z >> 1 : blockIdx.z, part = SPLIT ? blockIdx.z & 1 : 0;
+    const long long seq0 = (long long)seq * L;
+    const int Lk_all = lens ? max(1, min(L, __builtin_amdgcn_readfirstlane(lens[seq]))) : L;             // number of keys
+    const int kmid = min(Lk_all, ((Lk_all / 2 + TK - 1) / TK) * TK);                                    // tile-aligned cut
+    const int kb = SPLIT && part ? kmid : 0, Lk = SPLIT && !part ? kmid : Lk_all;                        // this block's keys [kb, Lk)
     const int q0 = blockIdx.x * 64 + wave * 16;
     const int koff = H * DQ + hh * DQ, voff = 2 * H * DQ + hh * DV;
     const float scale = 1.0f / sqrtf((float)DQ);
@@ -467,8 +474,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             }
         }
     };
-    fetch(0);
-    for (int t0 = 0; t0 < Lk; t0 += TK) {
+    fetch(kb);
+    for (int t0 = kb; t0 < Lk; t0 += TK) {
         __syncthreads();                                  // the previous tile is consumed
         commit();
         __syncthreads();
@@ -544,6 +551,24 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     // ---- normalise and write: lane (c = li, g) owns O[q0 + 4g + r][nt*16 + li] ----
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
+    if (SPLIT) {
+        if (g == 0 && q0 + li < L) {
+            float* p = ml + (((long long)part * gridDim.z / 2 * L + seq0 + q0 + li) * H + hh) * 2;
+            p[0] = m; p[1] = l;
+        }
+        float* dst = part ? part1 : out;
+        const long long ld = part ? (long long)H * DV : ldo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + 4 * g + r;
+            if (qi < L) {
+                float* orow = dst + (seq0 + qi) * ld + hh * DV;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) orow[nt * 16 + li] = o[nt][r];
+            }
+        }
+        return;
+    }
     const float inv = 1.0f / l;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -557,8 +582,26 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     }
 }
 
+// out[t, h, :] = (w0 o0 + w1 o1) / (w0 l0 + w1 l1),  w_p = exp(m_p - max(m0, m1)); a part without keys has m = -inf, l = 0
+__global__ void attention_combine_kernel(float* __restrict__ out, long long ldo, const float* __restrict__ part1,
+                                         const float* __restrict__ ml, long long T, int H, int DV) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int E = H * DV;
+    if (idx >= T * E) return;
+    const long long t = idx / E;
+    const int c = (int)(idx - t * E), h = c / DV;
+    const float* p0 = ml + (t * H + h) * 2;
+    const float* p1 = ml + ((T + t) * H + h) * 2;
+    const float m0 = p0[0], l0 = p0[1], m1 = p1[0], l1 = p1[1];
+    const float M = fmaxf(m0, m1);
+    const float w0 = __expf(m0 - M), w1 = l1 > 0.f ? __expf(m1 - M) : 0.f;
+    out[t * ldo + c] = (w0 * out[t * ldo + c] + w1 * part1[t * E + c]) / (w0 * l0 + w1 * l1);
+}
+
+size_t attention_split_floats(int64_t S, int L, int H, int DV) { return (size_t)S * L * DV + (size_t)4 * S * L * H; }
+
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
-                      int DQK, int DV, const int* lens) {
+                      int DQK, int DV, const int* lens, float* split_ws, size_t split_ws_floats) {
     if (S <= 0 || L <= 0) return;
     const int dq = DQK / H, dv = DV / H;
     if (!lens && L == 16 && H == 4 && dq == 8 && dv == 32) {
@@ -571,12 +614,25 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
     dim3 grid((unsigned)cdiv(L, 64), (unsigned)H, (unsigned)S);
     static const bool use_mfma = []() { const char* e = getenv("MCR_ATTN_MFMA"); return !(e && e[0] == '0'); }();   // dev A/B knob
     const bool al16 = aligned16(qkv) && ldq % 4 == 0 && (H * dq) % 4 == 0;
-    if (use_mfma && al16 && dq == 8 && dv == 32) {
-        hipLaunchKernelGGL((attention_mfma_kernel<8, 32>), grid, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H, lens);
-        return;
-    }
-    if (use_mfma && al16 && dq == 16 && dv == 64) {
-        hipLaunchKernelGGL((attention_mfma_kernel<16, 64>), grid, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H, lens);
+    // one or two long sequences leave half the chip idle (L = 2048, 4 heads: 128 blocks): split the keys over two blocks
+    const bool split = split_ws && split_ws_floats >= attention_split_floats(S, L, H, DV) && L >= 512 &&
+                       (int64_t)grid.x * H * S <= 256;
+    if (use_mfma && al16 && ((dq == 8 && dv == 32) || (dq == 16 && dv == 64))) {
+        if (split) {
+            float* part1 = split_ws;
+            float* ml = split_ws + (size_t)S * L * DV;
+            const dim3 g2(grid.x, grid.y, (unsigned)(2 * S));
+            if (dq == 8)
+                hipLaunchKernelGGL((attention_mfma_kernel<8, 32, true>), g2, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H, lens, part1, ml);
+            else
+                hipLaunchKernelGGL((attention_mfma_kernel<16, 64, true>), g2, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H, lens, part1, ml);
+            hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv(S * L * DV, 256)), dim3(256), 0, s, out, (long long)ldo,
+                               (const float*)part1, (const float*)ml, (long long)(S * L), H, dv);
+        } else if (dq == 8) {
+            hipLaunchKernelGGL((attention_mfma_kernel<8, 32, false>), grid, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H, lens, (float*)nullptr, (float*)nullptr);
+        } else {
+            hipLaunchKernelGGL((attention_mfma_kernel<16, 64, false>), grid, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H, lens, (float*)nullptr, (float*)nullptr);
+        }
         return;
     }
     if (lens) {

@@ -115,3 +115,54 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
     if return_samples:                              # the unique sampled proxy points (first n_unique of seq_len rows) and the inverse map [seq_len]
         out["proxy_points"], out["sample_idx"] = sampled
     return out
+
+
+class GraphedNbvStep:
+    """One NBV decision captured in a hipGraph (torch.cuda.CUDAGraph) and replayed: the ~60 kernel launches of the sync-free
+    `nbv_step` cost one graph launch, which removes the launch gaps between the many small kernels (single-GPU path only: the
+    RCCL exchange is not captured).
+
+    The step's host-side randomness cannot live inside a graph, so it becomes an input: every call draws SconeOcc's three
+    `torch.randperm` (CPU generator, the reference's order) and the `seq_len` sampling uniforms (device generator) exactly as
+    the eager step would, copies them and the scene tensors into the static input buffers, and replays.  Shapes are fixed at
+    construction.  Returns the same dict as `nbv_step` (static output tensors: clone what must survive the next call)."""
+
+    def __init__(self, scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1, warmup=2):
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            raise RuntimeError("GraphedNbvStep captures the single-GPU step; use nbv_step under torchrun")
+        self.occ, self.vis, self.grid, self.seq_len, self.min_occ = scone_occ, scone_vis, grid, seq_len, min_occ
+        dev = X.device
+        self._in = {"pc": pc.clone(), "X": X.clone(), "X_view": X_view.clone(), "X_cam": X_cam.clone(),
+                    "samples": torch.empty(seq_len, 1, device=dev),
+                    "perms": [p.to(dev) for p in scone_occ.draw_perms(pc.shape[1])]}
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                  # warm-up on the capture stream: weight tables, blobs and arenas get built
+            for _ in range(max(1, warmup)):
+                self._run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self._out = self._run()
+        torch.cuda.synchronize(dev)
+
+    def _run(self):
+        i = self._in
+        return nbv_step(self.occ, self.vis, i["pc"], i["X"], i["X_view"], i["X_cam"], self.grid, seq_len=self.seq_len,
+                        min_occ=self.min_occ, occ_perms=i["perms"], samples=i["samples"], return_samples=True)
+
+    def __call__(self, pc=None, X=None, X_view=None, X_cam=None, occ_perms=None, samples=None):
+        i = self._in
+        for name, t in (("pc", pc), ("X", X), ("X_view", X_view), ("X_cam", X_cam)):
+            if t is not None:
+                i[name].copy_(t)
+        perms = occ_perms if occ_perms is not None else self.occ.draw_perms(i["pc"].shape[1])
+        for dst, src in zip(i["perms"], perms):
+            dst.copy_(src, non_blocking=True)
+        if samples is not None:
+            i["samples"].copy_(samples.reshape(self.seq_len, 1))
+        else:
+            i["samples"].uniform_()                     # == torch.rand(seq_len, 1, device=dev) of the eager step
+        self.graph.replay()
+        return self._out

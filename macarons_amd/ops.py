@@ -133,16 +133,22 @@ def layernorm(x, weight, bias):
     return y.reshape(*lead, E)
 
 
-def attention_packed(qkv, n_heads, qk_dim, v_dim):
-    """qkv [S, L, 2*qk_dim + v_dim] -> [S, L, v_dim]; attention() + head split/merge of Attention.py:8-36,174-198."""
+def attention_packed(qkv, n_heads, qk_dim, v_dim, split=True):
+    """qkv [S, L, 2*qk_dim + v_dim] -> [S, L, v_dim]; attention() + head split/merge of Attention.py:8-36,174-198.
+    split=True hands the kernel a scratch buffer so that one or two long sequences can split their keys over two blocks."""
     qkv = _req(qkv, "qkv")
     S, L, W = qkv.shape
     if W != 2 * qk_dim + v_dim:
         raise ValueError("packed qkv width mismatch")
     out = torch.empty((S, L, v_dim), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        check(lib().mcr_attention(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads),
-                                  c_int(qk_dim), c_int(v_dim), _stream()), "mcr_attention")
+        if split and L >= 512:
+            ws = _workspace(qkv.device, int(lib().mcr_attention_workspace_bytes(c_i64(S), c_i64(L), c_int(n_heads), c_int(v_dim))))
+            check(lib().mcr_attention_ws(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads),
+                                         c_int(qk_dim), c_int(v_dim), _p(ws), ctypes.c_size_t(ws.numel()), _stream()), "mcr_attention_ws")
+        else:
+            check(lib().mcr_attention(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads),
+                                      c_int(qk_dim), c_int(v_dim), _stream()), "mcr_attention")
     return out
 
 

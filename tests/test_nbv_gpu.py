@@ -202,3 +202,35 @@ def test_sharded_step_two_ranks_matches_single_rank(dev):
     r = subprocess.run([_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", os.path.join(root, "tests", "_two_rank_step.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "TWO_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_graph_captured_step_equals_eager(dev):
+    """GraphedNbvStep (the whole decision as one hipGraph replay) returns exactly what the eager sync-free step returns for the same
+    hidden draws, on a first scene and after the inputs are replaced."""
+    from macarons_amd.nbv import nbv_step, GraphedNbvStep, ViewStateGrid
+    occ, vis, _, _ = _models(dev)
+    gen = torch.Generator().manual_seed(3)
+    grid = ViewStateGrid(dev)
+
+    def scene(M=4096, Q=20_000, C=64):
+        pc = (torch.rand(1, M, 3, generator=gen) - 0.5).to(dev)
+        X = (torch.rand(1, Q, 3, generator=gen) - 0.5).to(dev)
+        cams = torch.randn(C, 3, generator=gen)
+        return pc, X, (1.5 * cams / cams.norm(dim=1, keepdim=True)).to(dev)
+
+    pc, X, cams = scene()
+    g = GraphedNbvStep(occ, vis, pc, X, cams[:3].contiguous(), cams, grid)
+    for trial in range(2):
+        if trial:
+            pc, X, cams = scene()
+        perms = occ.draw_perms(pc.shape[1])
+        u = torch.rand(2048, generator=gen).to(dev)
+        a = nbv_step(occ, vis, pc, X, cams[:3].contiguous(), cams, grid, occ_perms=perms, samples=u, return_samples=True)
+        b = g(pc, X, cams[:3].contiguous(), cams, occ_perms=perms, samples=u)
+        torch.cuda.synchronize()
+        for k in ("gains", "occ", "nbv_idx", "max_gain", "n_unique", "proxy_points", "sample_idx"):
+            assert torch.equal(a[k], b[k]), k
+    # without pinned draws the wrapper draws them itself (fresh perms, fresh uniforms): still a valid decision
+    c = g()
+    torch.cuda.synchronize()
+    assert torch.isfinite(c["gains"]).all() and int(c["nbv_idx"]) == int(torch.argmax(c["gains"]))

@@ -230,7 +230,7 @@ def test_scone_occ_fused_equals_unfused(dev):
 
 
 def test_scone_vis_padded_lengths_equal_sliced(dev):
-    """SconeVis.forward(lengths=...) on a zero/garbage-padded batch == the forward on the sliced clouds: the cloud-wide max of
+    """SconeVis.forward(lengths=...) on a zero/garbage-padded batch == the forward on the sliced clouds (to rounding): the cloud-wide max of
     the embedding and the attention keys stop at lengths[b] (this is what lets the NBV step keep the number of unique sampled
     points on the device)."""
     from macarons_amd.networks import SconeVis
@@ -246,7 +246,8 @@ def test_scone_vis_padded_lengths_equal_sliced(dev):
         y = m(T(pts, dev), view_harmonics=T(vh, dev), lengths=torch.tensor(lens, dtype=torch.int32, device=dev)).cpu().numpy()
         for b, n in enumerate(lens):
             yb = m(T(pts[b:b + 1, :n], dev), view_harmonics=T(vh[b:b + 1, :n], dev)).cpu().numpy()
-            assert np.array_equal(y[b, :n], yb[0]), (b, n, np.abs(y[b, :n] - yb[0]).max())
+            # same arithmetic, but a long padded batch may split its attention keys over two blocks (different summation order)
+            assert np.abs(y[b, :n] - yb[0]).max() <= 2e-5 * np.abs(yb[0]).max(), (b, n, np.abs(y[b, :n] - yb[0]).max())
 
 
 def test_trainer_gradients_hip_forward_torch_backward(dev):
