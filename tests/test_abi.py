@@ -46,3 +46,16 @@ def test_ops_refuse_cpu_tensors():
     from macarons_amd import ops
     with pytest.raises(_lib.MacaronsHipError):
         ops.sh_coverage_gain(torch.zeros(1, 4, 4), torch.zeros(1, 4, 64), torch.zeros(1, 2, 3))
+
+
+def test_torch_ops_registered_without_cpu_fallback():
+    """torch.ops.macarons.* (SURVEY 8b's operator list) exists after importing macarons_amd.torch_ops and has no CPU kernel."""
+    import pytest
+    import torch
+    import macarons_amd.torch_ops as t
+    assert t.registered() == sorted(["sh_coverage_gain", "sh_visibilities", "knn_gather_offset", "points_in_fov", "view_state",
+                                     "view_harmonics", "sample_proxy", "scone_vis_forward", "scone_occ_forward"])
+    for name in t.registered():
+        assert hasattr(torch.ops.macarons, name)
+    with pytest.raises(NotImplementedError):
+        torch.ops.macarons.sh_coverage_gain(torch.zeros(1, 4, 3), torch.zeros(1, 4, 64), torch.zeros(1, 2, 3), True)

@@ -310,3 +310,24 @@ def test_trainer_gradients_hip_forward_torch_backward(dev):
     assert rel_err(yc.detach().cpu().numpy(), y_ref.cpu().numpy()) < 1e-4
     yc.sum().backward()
     assert rel_err(gx.cpu().numpy(), x.grad.cpu().numpy()) < 1e-3 and rel_err(gw.cpu().numpy(), occ.linear2.weight.grad.cpu().numpy()) < 1e-3
+
+
+def test_torch_ops_namespace_matches_module_path(dev):
+    """torch.ops.macarons.* forwards to the same C ABI as the module surface: identical tensors."""
+    import macarons_amd.torch_ops  # noqa: F401  (registers the operators)
+    from macarons_amd import ops
+    from macarons_amd.networks import SconeVis
+    rng = np.random.default_rng(21)
+    pts = T(np.concatenate([rng.uniform(-.5, .5, (1, 300, 3)), rng.uniform(.1, 1, (1, 300, 1))], -1).astype(np.float32), dev)
+    harm = T((rng.standard_normal((1, 300, 64)) * 0.5).astype(np.float32), dev)
+    cams = T(rng.standard_normal((1, 9, 3)).astype(np.float32), dev)
+    assert torch.equal(torch.ops.macarons.sh_coverage_gain(pts, harm, cams, True), ops.sh_coverage_gain(pts, harm, cams, True))
+    assert torch.equal(torch.ops.macarons.sh_visibilities(pts, harm, cams, False), ops.sh_visibilities(pts, harm, cams, False))
+    X, pc = T(rng.uniform(-.5, .5, (1, 70, 3)).astype(np.float32), dev), T(rng.uniform(-.5, .5, (1, 99, 3)).astype(np.float32), dev)
+    for a, b in zip(torch.ops.macarons.knn_gather_offset(X, pc, 16), ops.knn_points(X, pc, 16, True)):
+        assert torch.equal(a, b)
+    assert torch.equal(torch.ops.macarons.view_state(X, cams[0, :3].contiguous(), 7, 14), ops.view_state(X, cams[0, :3].contiguous(), 7, 14))
+    m, _ = _mod(SconeVis, 1, dev)
+    with torch.no_grad():
+        y = torch.ops.macarons.scone_vis_forward(pts, harm, m.weight_table())
+        assert torch.equal(y, m(pts, view_harmonics=harm))
