@@ -189,6 +189,13 @@ __device__ __forceinline__ f32x4 gelu4(const f32x4 v, float sc) {
     return f32x4{l3_gelu(v[0] * sc), l3_gelu(v[1] * sc), l3_gelu(v[2] * sc), l3_gelu(v[3] * sc)};
 }
 
+#ifdef L8_TRACE             // dev only: per-group timestamps of one wave (tools/build_variant.py ... -DL8_TRACE=<block>, tools/trace_local_pct8.py)
+__device__ long long l8_trace_buf[160];
+#define L8_T() do { if (blockIdx.x == (L8_TRACE) && tid == 0) { l8_trace_buf[tp] = clock64(); } ++tp; } while (0)
+#else
+#define L8_T() do { } while (0)
+#endif
+
 // grid = ceil(S / NW); S sequences of 16 offsets [S,16,3]; features[s*ld_feat + 0:256] = max(128) || avg(128)
 #ifndef L8_NW
 #define L8_NW 8              // waves = queries per workgroup: every weight byte fetched from L2 serves NW queries
@@ -222,9 +229,12 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void local_pct8_kernel(co
         return Grp{b + opaque(lane), reinterpret_cast<const float*>(b)};
     };
     // end of group g: my DMA of group g+1 has landed (vmcnt), everybody's has and everybody is done reading group g (barrier) ...
+    int tp = 0; (void)tp;
     auto sync_next = [&]() {
+        L8_T();                                            // work of group g done
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        L8_T();                                            // barrier passed
         ++g;
     };
     // ... and group g+2 goes into the buffer just retired (issued AFTER the first fragment reads of the new group)
@@ -506,6 +516,10 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 2 : 1) void local_pct8_kernel(co
 }
 
 }  // namespace v8
+
+#ifdef L8_TRACE
+extern "C" int mcr_dev_read_trace8(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(v8::l8_trace_buf), sizeof(long long) * 160); }
+#endif
 
 void launch_local_pct8(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob) {
     if (S <= 0) return;
