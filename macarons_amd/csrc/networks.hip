@@ -10,6 +10,7 @@
 // Only the reference's default architecture hyper-parameters are implemented on the HIP path (every call site
 // uses them); the Python host classes refuse other configurations loudly.
 #include "nn_kernels.h"
+#include <cstdlib>
 #include <algorithm>
 
 namespace mcr {
@@ -172,7 +173,11 @@ int mcr_local_pct8_blob_floats(void) { return local_pct8_blob_floats(); }
 
 // 1: local_pct.hip exact-fp32 MFMA; 5: local_pct5.hip split-precision bf16 hi/mid/lo (6 MFMAs per product, whole fp32
 // range); 6 (default): local_pct6.hip two-term fp16 split (3 MFMAs per product).  Each has its own blob format.
-static int g_local_pct_variant = 6;
+static int g_local_pct_variant = []() {                 // env MCR_LOCAL_PCT_VARIANT picks the start-up value (testing: whole suites on a variant)
+    const char* e = getenv("MCR_LOCAL_PCT_VARIANT");
+    const int v = e ? atoi(e) : 6;
+    return (v == 1 || v == 5 || v == 6 || v == 8) ? v : 6;
+}();
 int mcr_set_local_pct_variant(int v) {
     MCR_REQUIRE(v == 1 || v == 5 || v == 6 || v == 8, "mcr_set_local_pct_variant: variant must be 1, 5, 6 or 8 (got %d)", v);
     g_local_pct_variant = v;
