@@ -665,12 +665,26 @@ __global__ __launch_bounds__(64 * POOL_RL) void pool_kernel(const float* __restr
     const long long row0 = (long long)blockIdx.x * L;
     const int Lr = lens ? max(1, min(L, lens[blockIdx.x])) : L;          // rows that take part in the reduction
     float mx = -__builtin_inff(), sm = 0.f;
-    if (c < E)
-        for (int r = g; r < Lr; r += POOL_RL) {
+    if (c < E) {
+        // 8 rows in flight per thread (a one-row loop is a chain of exposed load latencies: 128 of them at L = 2048); the sum
+        // keeps its row order
+        int r = g;
+        for (; r + 7 * POOL_RL < Lr; r += 8 * POOL_RL) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = X[(row0 + r + j * POOL_RL) * ldx + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                mx = fmaxf(mx, v[j]);
+                sm += v[j];
+            }
+        }
+        for (; r < Lr; r += POOL_RL) {
             const float v = X[(row0 + r) * ldx + c];
             mx = fmaxf(mx, v);
             sm += v;
         }
+    }
     s_max[g][cl] = mx;
     s_sum[g][cl] = sm;
     __syncthreads();
