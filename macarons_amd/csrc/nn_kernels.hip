@@ -146,6 +146,33 @@ __global__ __launch_bounds__(256, NT == 8 ? 2 : 1) void linear_kernel(const floa
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// K <= 4 (the xyz embeddings 3 -> 128 over all queries): a thread owns 4 consecutive outputs of one row.  The fmaf chain in
+// ascending k from 0, then + bias, is bit for bit what the zero-padded fp32 MFMA path returns (the fp32 MFMA is an exact fmaf
+// chain); that path spent 69 us on 100k x 128 outputs, this one is bound by its 51 MB of stores.
+__global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ W,
+                                                            long long ldw, const float* __restrict__ bias,
+                                                            const float* __restrict__ R, long long ldr, float* __restrict__ Y,
+                                                            long long ldy, long long M, int N, int K, int act) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = N >> 2;
+    if (idx >= M * n4) return;
+    const long long m = idx / n4;
+    const int n = (int)(idx - m * n4) * 4;
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) x[k] = X[m * ldx + k];
+    float y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(x[k], W[(long long)(n + j) * ldw + k], acc);
+        acc += bias ? bias[n + j] : 0.f;
+        if (act == ACT_GELU) acc = gelu_erf(acc);
+        if (R) acc += R[m * ldr + n + j];
+        y[j] = acc;
+    }
+    *reinterpret_cast<float4*>(Y + m * ldy + n) = make_float4(y[0], y[1], y[2], y[3]);
+}
+
 void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R,
                    int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int act, const float* row_bias,
                    int64_t rows_per_group, int64_t ldw) {
@@ -154,6 +181,11 @@ void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, c
     static const bool use_split = []() { const char* e = getenv("MCR_LINEAR3"); return !(e && e[0] == '0'); }();   // dev A/B knob
     if (use_split && linear3_applicable(X, ldx, W, ldw, M, N, K)) {
         launch_linear3(s, X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, act, row_bias, rows_per_group, ldw);
+        return;
+    }
+    if (K <= 4 && N % 4 == 0 && ldy % 4 == 0 && aligned16(Y) && !row_bias && M * (N / 4) >= 65536) {
+        hipLaunchKernelGGL(linear_smallk_kernel, dim3((unsigned)cdiv(M * (N / 4), 256)), dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw,
+                           bias, R, (long long)ldr, Y, (long long)ldy, (long long)M, N, K, act);
         return;
     }
     const int vec_x = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
