@@ -17,7 +17,7 @@ names = ["emb1 product", "emb1 gelu+barrier", "emb2 gemm"]
 for e in range(2):
     names += [f"e{e} prev epilogue", f"e{e} norm1 partial+barrier", f"e{e} norm1 finish+barrier", f"e{e} qkv gemm", f"e{e} barrier", f"e{e} qkv put+barrier",
               f"e{e} attention", f"e{e} bias+barrier", f"e{e} out gemm", f"e{e} res+norm2 partial+barrier", f"e{e} norm2 finish+barrier", f"e{e} ff1a gemm",
-              f"e{e} gelu a+barrier", f"e{e} ff2a gemm", f"e{e} ff1b gemm", f"e{e} barrier", f"e{e} gelu b+barrier", f"e{e} ff2b gemm"]
+              f"e{e} ff1b gemm + gelu a", f"e{e} barrier", f"e{e} ff2a gemm + gelu b", f"e{e} barrier", f"e{e} (spare)", f"e{e} ff2b gemm"]
 names += ["epilogue", "final norm+lin0", "pool"]
 acc = None
 for it in range(5):
