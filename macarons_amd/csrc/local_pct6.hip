@@ -247,14 +247,12 @@ __device__ __forceinline__ void put_planes(uint4* __restrict__ buf, int nt, int 
         __builtin_amdgcn_sched_barrier(0);         // one quad at a time: interleaving all 32 GELUs of an epilogue spills
     }
 }
-// one quad (g) of put_planes: 4 consecutive features of one token, split and stored
+// one quad (g) of put_planes: 4 consecutive features of one token, split and stored; `row` = (lane & 31) * 32 + (lane >> 5) and
+// `key` = lane & 15 are computed once per product by the caller
 template <class Fn>
-__device__ __forceinline__ void put_quad(uint4* __restrict__ buf, int nt, int mt, int g, const f32x16& t, int lane_, Fn f) {
-    const int lane = opaque(lane_);
-    const int j = lane & 31, h = lane >> 5, key = j & 15;
+__device__ __forceinline__ void put_quad(uint4* __restrict__ buf, int nt, int mt, int g, const f32x16& t, int row, int key, Fn f) {
     uint2* b2 = reinterpret_cast<uint2*>(buf);
-    const int base = (mt * 32 + j) * 32 + h;
-    put4(b2, base + (((4 * nt + g) ^ key) << 1), f(t[4 * g]), f(t[4 * g + 1]), f(t[4 * g + 2]), f(t[4 * g + 3]));
+    put4(b2, mt * 1024 + row + (((4 * nt + g) ^ key) << 1), f(t[4 * g]), f(t[4 * g + 1]), f(t[4 * g + 2]), f(t[4 * g + 3]));
 }
 // fp32 tile with row stride LD floats: features (4 floats = one chunk) chunk0 + 2 g + h of token 32 mt + j, ds_write_b128
 template <class Fn>
@@ -550,10 +548,11 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
         f32x16 accb[2];
         init_bias(accb[0], ev + 192 + 128 + 128, wave, lane);
         init_bias(accb[1], ev + 192 + 128 + 128, wave, lane);
+        const int pq_lane = opaque(lane), pq_row = (pq_lane & 31) * 32 + (pq_lane >> 5), pq_key = pq_lane & 15;
         {
             const float sc = es[2];
             gemm_with<8>(accb, P, ring, wptr(w_ff1b, wave, 8, lane), lane, [&](int s_) {
-                put_quad(H, wave, s_ >> 2, s_ & 3, acc[s_ >> 2], lane, [&](float v) { return l3_gelu(v * sc); });
+                put_quad(H, wave, s_ >> 2, s_ & 3, acc[s_ >> 2], pq_row, pq_key, [&](float v) { return l3_gelu(v * sc); });
             });
         }
         L6_T();                                    // ff1b gemm + gelu a
@@ -565,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
         {
             const float sc = es[3];
             gemm_with<8>(xres, H, ring, wptr(w_ff2a, wave, 8, lane), lane, [&](int s_) {
-                put_quad(P, wave, s_ >> 2, s_ & 3, accb[s_ >> 2], lane, [&](float v) { return l3_gelu(v * sc); });
+                put_quad(P, wave, s_ >> 2, s_ & 3, accb[s_ >> 2], pq_row, pq_key, [&](float v) { return l3_gelu(v * sc); });
             });
         }
         L6_T();                                    // ff2a gemm + gelu b
