@@ -50,12 +50,27 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
         # ---- view state -> harmonics for this rank's slice of the queries (testers/shapenet.py:126-130) ----
         q0, q1 = mdist.shard_range(Q, rank, world)
         Xl = X[:, q0:q1].contiguous()
-        if sharded and occ_perms is None:
-            # one chunk per rank; the hidden randperm draws of SconeOcc.forward come from rank 0's CPU generator and are
-            # broadcast, so every rank sees the same down-sampled clouds (each rank drawing its own would silently diverge)
-            occ_perms = [p.to(dev) for p in scone_occ.draw_perms(pc.shape[1])]
-            for p in occ_perms:
-                torch.distributed.broadcast(p, 0, group=group)
+        if sharded and (occ_perms is None or samples is None):
+            # one chunk per rank; the hidden draws (SconeOcc.forward's three randperms from the CPU generator, the sampling
+            # uniforms from the device generator) are rank 0's and reach the others in ONE broadcast (the uniforms travel
+            # bit-cast inside the int64 buffer): every rank drawing its own would silently diverge
+            draw_perms, draw_u = occ_perms is None, samples is None
+            if draw_perms:
+                occ_perms = [p.to(dev) for p in scone_occ.draw_perms(pc.shape[1])]
+            if draw_u:
+                samples = torch.rand(seq_len + (seq_len & 1), 1, device=dev)          # even count: whole int64 words
+            parts = ([p.reshape(-1) for p in occ_perms] if draw_perms else []) + ([samples.reshape(-1).view(torch.int64)] if draw_u else [])
+            buf = torch.cat(parts)
+            torch.distributed.broadcast(buf, 0, group=group)
+            off = 0
+            if draw_perms:
+                out = []
+                for p in occ_perms:
+                    out.append(buf[off:off + p.numel()].reshape(p.shape))
+                    off += p.numel()
+                occ_perms = out
+            if draw_u:
+                samples = buf[off:].view(torch.float32).reshape(-1, 1)[:seq_len]
         if q1 > q0:
             view_state = su.compute_view_state(Xl, X_view, grid.n_elev, grid.n_azim)
             vh_l = su.compute_view_harmonics(view_state, grid.base_harmonics, grid.h_polar, grid.h_azim, grid.n_elev, grid.n_azim)
@@ -75,10 +90,8 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
         else:
             occ, vh = occ_l, vh_l[0]
         # ---- occupancy-weighted Monte-Carlo sampling (:146-154); identical on every rank ----
-        if samples is None:
+        if samples is None:                          # (the sharded path drew and broadcast them above)
             samples = torch.rand(seq_len, 1, device=dev)
-            if sharded:
-                torch.distributed.broadcast(samples, 0, group=group)
         # no host read-back: the unique sampled points stay padded to seq_len rows and their count stays on the device
         # (SconeVis consumes it as `lengths`); the reference slices on the host (:146-157)
         if vh is not None:
