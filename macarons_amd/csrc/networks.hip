@@ -284,11 +284,32 @@ size_t mcr_scone_occ_workspace_bytes(int64_t B, int64_t Q, int64_t Lg) {
     size_t glob = pct_ws_bytes(B * Lg);
     size_t head = al(B * Q * 1344) + al(B * Q * 512) + al(B * Q * 256) + al(B * 512) * 2;
     head += linear3h_planes_bytes(512, 1344);        // split weight planes of the largest head layer (reused layer after layer)
-    return std::max(local, glob) + head + 8192;
+    return local + glob + head + 8192;          // local and global paths run concurrently (two streams): disjoint scratch
 }
 
 int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B, int64_t Q, int64_t M,
                    int k, int subtract_query, void* stream);
+
+// The global feature (a chain of ~20 small launches on 2048 tokens, ~0.3 ms of mostly latency) depends on nothing the local
+// path produces and is needed only by the first head layer: it runs on a side stream beside the kNN / local-transformer
+// launches (fork / join by events, so a captured graph keeps the structure).  MCR_OCC_OVERLAP=0 puts it back on the caller's stream.
+struct OccSide { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static OccSide* occ_side() {
+    static const bool on = []() { const char* e = getenv("MCR_OCC_OVERLAP"); return !(e && e[0] == '0'); }();
+    if (!on) return nullptr;
+    static OccSide table[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    OccSide& x = table[dev & 63];
+    if (!x.s) {
+        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
+            x.s = nullptr;
+            return nullptr;
+        }
+    }
+    return &x;
+}
 
 int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const* pc_scale, const int64_t* M_scale,
                           const float* x, const float* view_harmonics, float* out, int64_t B, int64_t Q,
@@ -319,16 +340,27 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     float* gfeat = head.f(B * 512);
     float* gbias = head.f(B * 512);
     void* wplanes = head.f(linear3h_planes_bytes(512, 1344) / sizeof(float));
-    Arena scratch{(char*)workspace + head.off, workspace_bytes - head.off, 0};
+    const size_t glob_bytes = pct_ws_bytes(B * Lg);
+    Arena garena{(char*)workspace + head.off, glob_bytes, 0};
+    Arena scratch{(char*)workspace + head.off + glob_bytes, workspace_bytes - head.off - glob_bytes, 0};
 
-    // ---- global feature (SconeOcc.py:269-277) ----
+    // ---- global feature (SconeOcc.py:269-277), on the side stream ----
+    OccSide* side = occ_side();
+    hipStream_t gs = s;
+    if (side && hipEventRecord(side->fork, s) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess) gs = side->s;
+    else side = nullptr;
     {
-        Arena a = scratch;
-        run_pct(s, wg, pc_global, gfeat, 512, B, (int)Lg, 256, a);
-        MCR_REQUIRE(a.ok(), "mcr_scone_occ_forward: workspace overflow (global)");
+        run_pct(gs, wg, pc_global, gfeat, 512, B, (int)Lg, 256, garena);
+        MCR_REQUIRE(garena.ok(), "mcr_scone_occ_forward: workspace overflow (global)");
         // its contribution to linear1: gbias[b, n] = sum_k gfeat[b, k] * W1[n, k]  (columns 0..511 of linear1.weight)
-        launch_linear(s, gfeat, 512, lin1.w, nullptr, nullptr, 0, gbias, 512, B, 512, 512, ACT_NONE, nullptr, 0, 1856);
+        launch_linear(gs, gfeat, 512, lin1.w, nullptr, nullptr, 0, gbias, 512, B, 512, 512, ACT_NONE, nullptr, 0, 1856);
     }
+    // every way out of this function joins the side stream again (error returns included: a dangling fork would poison a capture)
+    struct SideJoin {
+        OccSide* side; hipStream_t s; bool joined;
+        ~SideJoin() { if (side && !joined) (void)hipStreamWaitEvent(s, side->join, 0); }
+    } side_join{side, s, false};
+    if (side) MCR_REQUIRE(hipEventRecord(side->join, side->s) == hipSuccess, "mcr_scone_occ_forward: side stream (record)");
     // ---- local multi-scale neighbourhood features (SconeOcc.py:290-311) ----
     // fused path: one kNN + one LDS-resident transformer launch per (cloud, scale) over ALL queries (nothing but
     // the [Q,16,3] offsets is materialised); layer-by-layer path: chunked over queries to bound its workspace.
@@ -370,6 +402,10 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     big_linear(h1, 256, xe3.w, 256, xe3.b, feat + 768, FEAT, T, 512, 256, nullptr, 0);
     launch_copy2d(s, view_harmonics, 64, feat + 1280, FEAT, T, 64);
     // ---- head MLP 1856 -> 512 -> 256 -> 1, GELU after every layer incl. the last (SconeOcc.py:334-345) ----
+    if (side) {
+        side_join.joined = true;
+        MCR_REQUIRE(hipStreamWaitEvent(s, side->join, 0) == hipSuccess, "mcr_scone_occ_forward: side stream (join)");
+    }
     big_linear(feat, FEAT, lin1.w + 512, 1856, lin1.b, h1, 512, T, 512, FEAT, gbias, Q);
     big_linear(h1, 512, lin2.w, 512, lin2.b, h2, 256, T, 256, 512, nullptr, 0);
     launch_linear(s, h2, 256, lin3.w, lin3.b, nullptr, 0, out, 1, T, 1, 256, ACT_GELU);
