@@ -81,6 +81,33 @@ def allgather_best(gains, idx_offset, group=None):
     return ops.best_merge(recv)
 
 
+def broadcast_draws(int_tensors, uniforms=None, src=0, group=None):
+    """Rank `src`'s hidden random draws reach every rank in ONE broadcast.  `int_tensors`: list of int64 tensors (SconeOcc's
+    randperm index tensors), `uniforms`: optional float32 tensor (the sampling uniforms); every rank passes tensors of the same
+    shapes (its own draws), the returned ones hold rank src's values.  The float32 values travel bit-cast inside the int64
+    buffer (an odd count is padded by one word)."""
+    parts = [t.reshape(-1) for t in int_tensors]
+    if any(t.dtype != torch.int64 for t in parts):
+        raise TypeError("broadcast_draws: index tensors must be int64")
+    n_u = 0
+    if uniforms is not None:
+        u = uniforms.reshape(-1).to(torch.float32)
+        n_u = u.numel()
+        if n_u & 1:
+            u = torch.cat((u, u.new_zeros(1)))
+        parts.append(u.contiguous().view(torch.int64))
+    if not parts:
+        return [], None
+    buf = torch.cat(parts)
+    torch.distributed.broadcast(buf, src, group=group)
+    out, off = [], 0
+    for t in int_tensors:
+        out.append(buf[off:off + t.numel()].reshape(t.shape))
+        off += t.numel()
+    u_out = buf[off:].view(torch.float32)[:n_u].reshape(uniforms.shape) if uniforms is not None else None
+    return out, u_out
+
+
 class PipelinedBest:
     """Arg-max exchange for a stream of decisions, sized for xGMI: the record kernel of every decision runs on the scoring
     stream, and once `batch` decisions have accumulated ONE all-gather (8 B x batch x clouds per rank) and ONE merge run on a

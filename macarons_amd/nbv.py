@@ -58,19 +58,12 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
             if draw_perms:
                 occ_perms = [p.to(dev) for p in scone_occ.draw_perms(pc.shape[1])]
             if draw_u:
-                samples = torch.rand(seq_len + (seq_len & 1), 1, device=dev)          # even count: whole int64 words
-            parts = ([p.reshape(-1) for p in occ_perms] if draw_perms else []) + ([samples.reshape(-1).view(torch.int64)] if draw_u else [])
-            buf = torch.cat(parts)
-            torch.distributed.broadcast(buf, 0, group=group)
-            off = 0
+                samples = torch.rand(seq_len, 1, device=dev)
+            got_p, got_u = mdist.broadcast_draws(occ_perms if draw_perms else [], samples if draw_u else None, 0, group)
             if draw_perms:
-                out = []
-                for p in occ_perms:
-                    out.append(buf[off:off + p.numel()].reshape(p.shape))
-                    off += p.numel()
-                occ_perms = out
+                occ_perms = got_p
             if draw_u:
-                samples = buf[off:].view(torch.float32).reshape(-1, 1)[:seq_len]
+                samples = got_u
         if q1 > q0:
             view_state = su.compute_view_state(Xl, X_view, grid.n_elev, grid.n_azim)
             vh_l = su.compute_view_harmonics(view_state, grid.base_harmonics, grid.h_polar, grid.h_azim, grid.n_elev, grid.n_azim)

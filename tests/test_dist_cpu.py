@@ -52,6 +52,18 @@ def _worker(rank, world, port, q):
         v4, i4 = mdist.allgather_best(bad[:, b0:b1].contiguous(), b0)
         rb = torch.max(bad, dim=1)
         ok3 = ok3 and int(i4[0]) == int(rb.indices[0]) and int(i4[1]) == int(rb.indices[1]) and bool(torch.isnan(v4[1]))
+        # hidden draws: every rank draws its own randperms / uniforms, rank 0's reach everybody in one broadcast (odd and even counts)
+        g = torch.Generator().manual_seed(100 + rank)
+        perms = [torch.randperm(50, generator=g)[:20], torch.randperm(7, generator=g), torch.randperm(9, generator=g)[:3]]
+        g0 = torch.Generator().manual_seed(100)
+        want = [torch.randperm(50, generator=g0)[:20], torch.randperm(7, generator=g0), torch.randperm(9, generator=g0)[:3]]
+        for n_u in (8, 5):
+            u = torch.rand(n_u, 1, generator=torch.Generator().manual_seed(7 + rank))
+            u0 = torch.rand(n_u, 1, generator=torch.Generator().manual_seed(7))
+            got_p, got_u = mdist.broadcast_draws(perms, u)
+            ok3 = ok3 and all(torch.equal(a, b) for a, b in zip(got_p, want)) and torch.equal(got_u, u0) and got_u.shape == (n_u, 1)
+        only_p, none_u = mdist.broadcast_draws(perms, None)
+        ok3 = ok3 and none_u is None and all(torch.equal(a, b) for a, b in zip(only_p, want))
         q.put((rank, bool(ok1), bool(ok2 and ok3), (c0, c1), (q0, q1)))
     finally:
         dist.destroy_process_group()
