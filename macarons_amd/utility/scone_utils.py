@@ -14,34 +14,38 @@ from .CustomGeometry import get_cartesian_coords, get_spherical_coords
 from .spherical_harmonics import get_spherical_harmonics
 
 
+def _lattice(n_elev, n_azim, elev_span, azim_span):
+    """The (elevation-major) direction lattice both helpers below share: row i sits at -span/2 + (i + 1) / (n_elev + 1) * span,
+    column j at azim_span * j / n_azim.  Evaluated in float64 in the reference's operation order and rounded to float32 once,
+    so the values are the reference's bit for bit (scone_utils.py:724-727, 765-771)."""
+    rows = (torch.arange(n_elev, dtype=torch.float64) + 1.0) / (n_elev + 1) * elev_span - elev_span / 2
+    cols = azim_span * torch.arange(n_azim, dtype=torch.float64) / n_azim
+    return rows.repeat_interleave(n_azim).float(), cols.repeat(n_elev).float()
+
+
 def get_all_harmonics_under_degree(degree, n_elev, n_azim, device):
     """-> (z [degree^2, n_elev*n_azim], h_polar, h_azim); elevation-major grid (scone_utils.py:714-738)."""
-    h_elev = torch.Tensor([-np.pi / 2 + (i + 1) / (n_elev + 1) * np.pi for i in range(n_elev) for j in range(n_azim)]).to(device)
+    h_elev, h_azim = (t.to(device) for t in _lattice(n_elev, n_azim, np.pi, 2 * np.pi))
     h_polar = -h_elev + np.pi / 2
-    h_azim = torch.Tensor([2 * np.pi * j / n_azim for i in range(n_elev) for j in range(n_azim)]).to(device)
     z = torch.cat([get_spherical_harmonics(l, h_polar, h_azim) for l in range(degree)], dim=-1)
     return z.transpose(dim0=0, dim1=1).contiguous(), h_polar, h_azim
 
 
 def get_cameras_on_sphere(params=None, device="cpu", pole_cameras=False, n_elev=None, n_azim=None, camera_dist=None):
-    """(X_cam [n,3], dist, elev, azim) on the reference's lattice (scone_utils.py:741-785)."""
+    """(X_cam [n,3], dist, elev, azim): candidate cameras on the reference's sphere lattice, optionally with the two near-pole
+    cameras at +-89.9 degrees in front and behind (scone_utils.py:741-785)."""
     if n_elev is None or n_azim is None:
-        n_elev, n_azim, n_camera = params.n_camera_elev, params.n_camera_azim, params.n_camera
-    else:
-        n_camera = n_elev * n_azim + (2 if pole_cameras else 0)
+        n_elev, n_azim = params.n_camera_elev, params.n_camera_azim
     if camera_dist is None:
         camera_dist = params.camera_dist
-    candidate_dist = torch.Tensor([camera_dist for _ in range(n_camera)]).to(device)
-    candidate_elev = [-90. + (i + 1) / (n_elev + 1) * 180. for i in range(n_elev) for j in range(n_azim)]
-    candidate_azim = [360. * j / n_azim for i in range(n_elev) for j in range(n_azim)]
+    elev, azim = _lattice(n_elev, n_azim, 180.0, 360.0)
     if pole_cameras:
-        candidate_elev = [-89.9] + candidate_elev + [89.9]
-        candidate_azim = [0.] + candidate_azim + [0.]
-    candidate_elev = torch.Tensor(candidate_elev).to(device)
-    candidate_azim = torch.Tensor(candidate_azim).to(device)
-    X_cam = get_cartesian_coords(r=candidate_dist.view(-1, 1), elev=candidate_elev.view(-1, 1),
-                                 azim=candidate_azim.view(-1, 1), in_degrees=True)
-    return X_cam, candidate_dist, candidate_elev, candidate_azim
+        elev = torch.cat((elev.new_tensor([-89.9]), elev, elev.new_tensor([89.9])))
+        azim = torch.cat((azim.new_zeros(1), azim, azim.new_zeros(1)))
+    elev, azim = elev.to(device), azim.to(device)
+    dist = torch.full_like(elev, float(camera_dist))
+    X_cam = get_cartesian_coords(r=dist.view(-1, 1), elev=elev.view(-1, 1), azim=azim.view(-1, 1), in_degrees=True)
+    return X_cam, dist, elev, azim
 
 
 def normalize_points_in_prediction_box(points, prediction_box_center, prediction_box_diag):

@@ -407,3 +407,22 @@ def test_occupancy_field_oracle_matches_reference():
     assert np.array_equal(X, g["X_world"]) and rel_err(H, g["view_harmonics"]) < 1e-5
     assert np.abs(O - g["occ_probs"]).max() < 1e-4 * np.abs(g["occ_probs"]).max()
     assert np.abs(proba - g["proxy_proba"][:, 0]).max() < 1e-4 * np.abs(g["occ_probs"]).max()
+
+
+def test_direction_lattices_bit_exact():
+    """get_cameras_on_sphere / get_all_harmonics_under_degree build their lattices vectorised; the float32 values must equal the
+    reference's per-element formulas (scone_utils.py:724-727, 765-771) bit for bit."""
+    import math
+    import torch
+    from macarons_amd.utility import scone_utils as su
+    for n_e, n_a in ((4, 5), (10, 10), (10, 20), (16, 32), (7, 14)):
+        X, dist, elev, azim = su.get_cameras_on_sphere(n_elev=n_e, n_azim=n_a, camera_dist=1.5)
+        want_e = torch.tensor([-90. + (i + 1) / (n_e + 1) * 180. for i in range(n_e) for _ in range(n_a)], dtype=torch.float32)
+        want_a = torch.tensor([360. * j / n_a for _ in range(n_e) for j in range(n_a)], dtype=torch.float32)
+        assert torch.equal(elev, want_e) and torch.equal(azim, want_a) and bool((dist == 1.5).all()) and X.shape == (n_e * n_a, 3)
+        _, h_polar, h_azim = su.get_all_harmonics_under_degree(2, n_e, n_a, "cpu")
+        he = torch.tensor([-math.pi / 2 + (i + 1) / (n_e + 1) * math.pi for i in range(n_e) for _ in range(n_a)], dtype=torch.float32)
+        ha = torch.tensor([2 * math.pi * j / n_a for _ in range(n_e) for j in range(n_a)], dtype=torch.float32)
+        assert torch.equal(h_polar, -he + math.pi / 2) and torch.equal(h_azim, ha)
+    X, dist, elev, azim = su.get_cameras_on_sphere(n_elev=4, n_azim=5, camera_dist=2.0, pole_cameras=True)
+    assert X.shape == (22, 3) and float(elev[0]) == np.float32(-89.9) and float(elev[-1]) == np.float32(89.9) and float(azim[0]) == 0.0
