@@ -236,8 +236,8 @@ def measure_local_pct(dev):
         out[v] = e0.elapsed_time(e1) / n
     L.mcr_set_local_pct_variant(ctypes.c_int(default_variant))
     ms = out[default_variant]
-    mult = {6: 3.0, 8: 3.0, 5: 6.0}.get(default_variant, 1.0)
-    if default_variant in (5, 6, 8):
+    mult = {6: 3.0, 5: 6.0}.get(default_variant, 1.0)
+    if default_variant in (5, 6):
         peak = PEAK_F16_TFLOPS
         kern = f"local_pct{default_variant}_kernel"
         note = (f"dense fp16/bf16 MFMA peak 2.5 PFLOP/s; {int(mult)} MFMAs per fp32 product (split precision): `frac` = executed "
@@ -249,7 +249,7 @@ def measure_local_pct(dev):
     # what the fp16 matrix pipe sustains on this part with non-zero operands: every SIMD issuing v_mfma_f32_32x32x16_f16 back to
     # back reaches 2.43 PFLOP/s (2.40 GHz) on all-zero operands but 1.79 PFLOP/s on random ones -- the clock is managed down to
     # 1.76 GHz by the operand data (tools/experiments/mfma_power.hip)
-    sustained = 1790.0 if default_variant in (5, 6, 8) else None
+    sustained = 1790.0 if default_variant in (5, 6) else None
     return {"kernel": kern, "bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak,
             "peak_sustained_random_operands": sustained, "frac_of_sustained": (executed / sustained) if sustained else None,
             "achieved_algorithmic": alg, "frac_algorithmic": alg / peak, "algorithmic_vs_fp32_mfma_peak": alg / PEAK_FP32_TFLOPS,

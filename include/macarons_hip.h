@@ -129,7 +129,6 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
 int mcr_local_pct_blob_floats(void);
 int mcr_local_pct3_blob_floats(void);
 int mcr_local_pct6_blob_floats(void);
-int mcr_local_pct8_blob_floats(void);
 /* Kernel variant behind mcr_local_pct_forward / the fused path of mcr_scone_occ_forward.  The blob must have been packed
  * for the selected variant (macarons_amd/networks/packing.py):
  *   1: exact-fp32 MFMA, one workgroup/CU (local_pct.hip; mcr_local_pct_blob_floats() floats);

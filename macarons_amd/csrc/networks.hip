@@ -169,17 +169,16 @@ int mcr_get_local_pct_variant(void);
 int mcr_local_pct_blob_floats(void) { return local_pct_blob_floats(); }
 int mcr_local_pct3_blob_floats(void) { return local_pct3_blob_floats(); }
 int mcr_local_pct6_blob_floats(void) { return local_pct6_blob_floats(); }
-int mcr_local_pct8_blob_floats(void) { return local_pct8_blob_floats(); }
 
 // 1: local_pct.hip exact-fp32 MFMA; 5: local_pct5.hip split-precision bf16 hi/mid/lo (6 MFMAs per product, whole fp32
 // range); 6 (default): local_pct6.hip two-term fp16 split (3 MFMAs per product).  Each has its own blob format.
 static int g_local_pct_variant = []() {                 // env MCR_LOCAL_PCT_VARIANT picks the start-up value (testing: whole suites on a variant)
     const char* e = getenv("MCR_LOCAL_PCT_VARIANT");
     const int v = e ? atoi(e) : 6;
-    return (v == 1 || v == 5 || v == 6 || v == 8) ? v : 6;
+    return (v == 1 || v == 5 || v == 6) ? v : 6;
 }();
 int mcr_set_local_pct_variant(int v) {
-    MCR_REQUIRE(v == 1 || v == 5 || v == 6 || v == 8, "mcr_set_local_pct_variant: variant must be 1, 5, 6 or 8 (got %d)", v);
+    MCR_REQUIRE(v == 1 || v == 5 || v == 6, "mcr_set_local_pct_variant: variant must be 1, 5 or 6 (got %d)", v);
     g_local_pct_variant = v;
     return 0;
 }
@@ -187,8 +186,7 @@ int mcr_get_local_pct_variant(void) { return g_local_pct_variant; }
 static void run_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld, int64_t S, const float* blob) {
     if (g_local_pct_variant == 1) launch_local_pct(s, offs, feat, ld, S, blob);
     else if (g_local_pct_variant == 5) launch_local_pct5(s, offs, feat, ld, S, blob);
-    else if (g_local_pct_variant == 6) launch_local_pct6(s, offs, feat, ld, S, blob);
-    else launch_local_pct8(s, offs, feat, ld, S, blob);
+    else launch_local_pct6(s, offs, feat, ld, S, blob);
 }
 
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,
@@ -387,7 +385,7 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     }
     // the large layers run on the split-precision matrix path of the selected variant (6: fp16 x 3 with the weights split once per
     // call into `wplanes`; otherwise launch_linear's own routing: bf16 x 6 / exact fp32 MFMA)
-    const bool f16 = g_local_pct_variant >= 6;
+    const bool f16 = g_local_pct_variant == 6;
     auto big_linear = [&](const float* X_, int64_t ldx, const float* W_, int64_t ldw, const float* b_, float* Y_, int64_t ldy, int64_t M_,
                           int N_, int K_, const float* rb, int64_t rpg) {
         if (f16 && linear3h_applicable(X_, ldx, W_, ldw, M_, N_, K_))

@@ -63,7 +63,5 @@ void launch_local_pct6(hipStream_t s, const float* offs, float* feat, int64_t ld
 int local_pct_blob_floats();
 int local_pct3_blob_floats();
 int local_pct6_blob_floats();
-void launch_local_pct8(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);   // register-resident, weight stream blob
-int local_pct8_blob_floats();
 
 }  // namespace mcr

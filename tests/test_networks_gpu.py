@@ -166,10 +166,10 @@ def test_scone_occ_chunking_and_batch(dev):
     assert rel_err(y[:, sel], ref) < TOL
 
 
-@pytest.mark.parametrize("variant", [1, 5, 6, 8])
+@pytest.mark.parametrize("variant", [1, 5, 6])
 def test_fused_local_transformer(dev, variant):
     """Fused local transformer kernels (1: exact-fp32 MFMA, 5: split-precision bf16 hi/mid/lo x 6 MFMAs, 6: two-term fp16
-    split x 3 MFMAs, the default; 8: the same arithmetic, register-resident, one wave per query) vs the layer-by-layer HIP path and the fp64 oracle.  All must be fp32-class: 2e-5, far
+    split x 3 MFMAs, the default) vs the layer-by-layer HIP path and the fp64 oracle.  All must be fp32-class: 2e-5, far
     inside the 1e-4 bar."""
     import ctypes
     from macarons_amd import ops, _lib
@@ -206,10 +206,10 @@ def test_split_precision_is_exact_split(dev):
     prev = _lib.lib().mcr_get_local_pct_variant()
     try:
         out = {}
-        for v in (1, 5, 6, 8):
+        for v in (1, 5, 6):
             _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(v))
             out[v] = ops.local_pct_forward(T(offs, dev), pack_local_pct(m.local_transformers[1], v)).cpu().numpy()
-        assert rel_err(out[5], out[1]) < 5e-6 and rel_err(out[6], out[1]) < 5e-6 and rel_err(out[8], out[1]) < 5e-6
+        assert rel_err(out[5], out[1]) < 5e-6 and rel_err(out[6], out[1]) < 5e-6
     finally:
         _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(prev))
 

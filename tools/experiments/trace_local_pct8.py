@@ -1,6 +1,6 @@
 """Dev: per-group cycle stamps of one wave of local_pct8 (lib built with -DL8_TRACE=<block>): work and barrier wait per group."""
 import sys, os, torch, io, contextlib, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from macarons_amd import ops, _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_libs", f"libmacarons_hip_{os.environ['MCR_DEV_LIB']}.so")
 from macarons_amd.networks import SconeOcc
