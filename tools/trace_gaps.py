@@ -1,4 +1,4 @@
-"""Dev: GPU idle time inside one NBV step from a rocprofv3 kernel trace (csv): sum of gaps between consecutive kernels.
+"""Dev: GPU idle time inside one NBV step from a rocprofv3 kernel trace (csv): the holes in the union of the kernel intervals.
     cd /tmp && rocprofv3 --kernel-trace --output-format csv -d out -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --nbv-iters 20
     python tools/trace_gaps.py out/t_kernel_trace.csv"""
 import csv, sys
@@ -8,9 +8,19 @@ starts = [i for i, r in enumerate(rows) if "view_state_kernel" in r[2]]
 res = []
 for a, b in zip(starts[10:-1], starts[11:]):
     seg = rows[a:b]
-    busy = sum(e - s for s, e, _ in seg)
-    span = seg[-1][1] - seg[0][0]
-    gaps = sorted(((seg[i + 1][0] - seg[i][1], seg[i][2][:40], seg[i + 1][2][:40]) for i in range(len(seg) - 1)), reverse=True)
+    # kernels of the step may overlap (SconeOcc's global branch runs on a side stream): busy = length of the UNION of the
+    # kernel intervals, gaps = the holes of that union
+    span = max(e for _, e, _ in seg) - seg[0][0]
+    busy, gaps, cur_end, last = 0, [], seg[0][0], seg[0][2]
+    for s_, e_, n_ in seg:
+        if s_ > cur_end:
+            gaps.append((s_ - cur_end, last[:40], n_[:40]))
+            busy += e_ - s_
+        else:
+            busy += max(0, e_ - cur_end)
+        if e_ > cur_end:
+            cur_end, last = e_, n_
+    gaps.sort(reverse=True)
     res.append((span, busy, gaps[:6], len(seg)))
 res.sort(key=lambda x: x[0])
 span, busy, gaps, n = res[len(res) // 2]
