@@ -113,6 +113,16 @@ class SconeOcc(nn.Module):
         self._blob_caches = [BlobCache() for _ in range(n_scale)]
         self._table_cache = TableCache()
 
+    def invalidate_weight_caches(self):
+        """Drop every derived weight image (pointer table, packed local-transformer blobs, stacked QKV, split head planes): call
+        after editing parameters in a way no fingerprint can see (in place through `p.data`, see packing._param_key)."""
+        self._table_cache.invalidate()
+        for c in self._blob_caches:
+            c.invalidate()
+        for m in self.modules():
+            if hasattr(m, "_packed"):
+                m._packed = None
+
     def _is_default_arch(self):
         return (self.n_scale == 3 and self.k_for_knn == 16 and self.offset and self.x_dim == 3 and self.x_embedding_dim == 512
                 and self.global_feature_dim == 512 and self.local_feature_dim == 256 and self.n_harmonics == 64

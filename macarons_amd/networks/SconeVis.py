@@ -52,6 +52,13 @@ class SconeVis(nn.Module):
         self.fc3 = nn.Linear(2 * n_harmonics, n_harmonics)
         self._table_cache = TableCache()
 
+    def invalidate_weight_caches(self):
+        """Drop the derived weight images (pointer table, stacked QKV); see packing._param_key for when this is needed."""
+        self._table_cache.invalidate()
+        for m in self.modules():
+            if hasattr(m, "_packed"):
+                m._packed = None
+
     # ---- the architecture the fused HIP forward implements (the one every call site builds) ----
     def _is_default_arch(self):
         return (self.pts_dim == 4 and self.pts_embedding_dim == 256 and self.n_heads == 4 and self.n_code == 3

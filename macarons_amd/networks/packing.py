@@ -94,14 +94,28 @@ def pack_local_pct(pct, variant=1):
 
 
 def _param_key(module, cache):
-    """Cheap fingerprint of a module's parameters: the in-place version counter of every parameter plus the storage addresses
-    of the first and last one (optimizer steps / load_state_dict bump the versions, .to(device) moves the storage).  The
-    parameter list is collected once per module (host time of the NBV step: walking 172 parameters through nn.Module's
-    generators cost more than the kernels' launch calls)."""
-    plist = cache.get("plist")
-    if plist is None:
-        plist = cache["plist"] = list(module.parameters())
-    return tuple(p._version for p in plist) + (plist[0].data_ptr(), plist[-1].data_ptr(), len(plist)) if plist else ()
+    """Fingerprint of a module's parameters: (identity, storage address, in-place version counter) of EVERY parameter, read from
+    the live `_parameters` dicts on each call.  It therefore sees optimizer steps and load_state_dict (version), .to(device) and
+    `p.data = new` (address), `layer.weight = nn.Parameter(...)` and load_state_dict(assign=True) (identity).  Only the list of
+    sub-modules is collected once (walking nn.Module's recursive generators on every call cost more host time than the launches
+    of an NBV step; add_module after the first forward needs invalidate()).  What no fingerprint can see is an in-place edit
+    through a detached alias (`p.data.mul_()`): the pointer tables still read the live storage, but derived images (packed
+    blobs, stacked QKV, split planes) need `invalidate_weight_caches()` after such an edit."""
+    mods = cache.get("mods")
+    if mods is None:
+        mods = cache["mods"] = [m for m in module.modules() if m._parameters]
+    key = [cache.get("epoch", 0)]
+    for m in mods:
+        for p in m._parameters.values():
+            if p is not None:
+                key += (id(p), p.data_ptr(), p._version)
+    return tuple(key)
+
+
+def invalidate(cache):
+    """Forget the sub-module list and force the next key to differ (explicit invalidation hook)."""
+    cache.pop("mods", None)
+    cache["epoch"] = cache.get("epoch", 0) + 1
 
 
 class BlobCache:
@@ -109,6 +123,9 @@ class BlobCache:
 
     def __init__(self):
         self._key, self._blob, self._c = None, None, {}
+
+    def invalidate(self):
+        invalidate(self._c)
 
     def get(self, pct, variant=1):
         key = (variant,) + _param_key(pct, self._c)
@@ -123,6 +140,9 @@ class TableCache:
 
     def __init__(self):
         self._key, self._val, self._c = None, None, {}
+
+    def invalidate(self):
+        invalidate(self._c)
 
     def get(self, module, build):
         key = _param_key(module, self._c)

@@ -22,3 +22,33 @@ def test_blob_sizes_match_the_kernels():
     assert pack_local_pct(pct, 1).numel() == L.mcr_local_pct_blob_floats()
     assert pack_local_pct(pct, 5).numel() == L.mcr_local_pct3_blob_floats()
     assert pack_local_pct(pct, 6).numel() == L.mcr_local_pct6_blob_floats()
+
+
+def test_param_fingerprint_sees_every_kind_of_weight_change():
+    """The cache key of the derived weight images must change on: optimizer-style in-place updates, `p.data = new`,
+    load_state_dict(assign=True), parameter replacement -- on ANY parameter, not just the first / last."""
+    from macarons_amd.networks.packing import _param_key, invalidate
+    pct = _pct()
+    cache = {}
+    k0 = _param_key(pct, cache)
+    assert _param_key(pct, cache) == k0                                   # stable when nothing changed
+    mid = pct.encoders[0].ff.linear1                                      # a parameter in the middle of the list
+    with torch.no_grad():
+        mid.weight.add_(1.0)
+    k1 = _param_key(pct, cache)
+    assert k1 != k0
+    mid.weight.data = mid.weight.data.clone()
+    k2 = _param_key(pct, cache)
+    assert k2 != k1
+    mid.weight = torch.nn.Parameter(mid.weight.detach().clone())
+    k3 = _param_key(pct, cache)
+    assert k3 != k2
+    sd = {k: v.clone() for k, v in pct.state_dict().items()}
+    pct.load_state_dict(sd, assign=True)
+    k4 = _param_key(pct, cache)
+    assert k4 != k3
+    pct.load_state_dict(sd)                                               # copy_ in place: versions bump
+    k5 = _param_key(pct, cache)
+    assert k5 != k4
+    invalidate(cache)
+    assert _param_key(pct, cache) != k5
