@@ -163,10 +163,27 @@ int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_feat
  *   vis [B,C,N] -> gains [B, C^n_cam] over ordered tuples in torch.cartesian_prod order, n_cam in {2,3}. */
 int mcr_view_state(const float* pts, int pts_dim, const float* X_view, float* view_state, int64_t n_points, int n_view,
                    int n_elev, int n_azim, void* stream);
+/* Batched / in-place form.  n_clouds clouds of pts_per_cloud points each; cloud c is binned against ITS OWN view positions
+ * X_view[c] ([n_clouds, n_view, 3]: every object of a scene batch has its own trajectory, testers/shapenet.py:33-37).
+ * accumulate != 0: view_state is not cleared first -- bins are OR'ed into the caller's 0/1 table, which is what the reference's
+ * `view_states[mask] += compute_view_state(...)` followed by torch.heaviside(., 0) does (macarons_utils.py:2867-2877); with
+ * rows != NULL (device int64 [n_clouds*pts_per_cloud], needs accumulate) point p updates row rows[p] of the table, i.e. the
+ * masked in-place update of the scene-wide state table in one launch. */
+int mcr_view_state_batched(const float* pts, int pts_dim, const float* X_view, float* view_state, int64_t n_clouds,
+                           int64_t pts_per_cloud, int n_view, int n_elev, int n_azim, const int64_t* rows, int accumulate,
+                           void* stream);
 size_t mcr_sample_proxy_workspace_bytes(int64_t P, int n_sample);
 int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t P,
                      float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
                      int64_t* inverse, int* n_unique, double* volume, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for B independent clouds in one launch sequence (a scene batch: every tensor gains a leading B; preds is
+ * [B, P] with element stride pred_stride; u [B, n_sample]; n_unique int[B]; volume double[B] or NULL): every cloud draws from its
+ * own CDF with its own uniforms, exactly as B calls of mcr_sample_proxy would. */
+size_t mcr_sample_proxy_batched_workspace_bytes(int64_t B, int64_t P, int n_sample);
+int mcr_sample_proxy_batched(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t B,
+                             int64_t P, float min_occ, const float* u, int n_sample, float* res, float* res_harmonics,
+                             int64_t* uniq, int64_t* inverse, int* n_unique, double* volume, void* workspace,
+                             size_t workspace_bytes, void* stream);
 int mcr_points_in_fov(const float* pts, int64_t P, const float* cameras, int n_cam, unsigned char* mask, void* stream);
 /* filter_proxy_points (macarons/utility/scone_utils.py:1001-1027; call site testers/shapenet.py:122): mask[p] = 1 iff in every
  * view v the projection ([x y z 1] * proj[v])[:2] / w of X[p] lies strictly inside the bounding box of the projected surface

@@ -30,16 +30,20 @@ static void launch_zero(hipStream_t s, void* p, size_t bytes) {       // bytes %
     hipLaunchKernelGGL(zero_kernel, dim3((unsigned)std::min<long long>(cdiv(n, 256), 2048)), dim3(256), 0, s, (unsigned*)p, n);
 }
 
+// Cloud c = p / pts_per_cloud reads its own view positions X_view[c] ([n_clouds, n_view, 3]); `rows` (optional) redirects point p to
+// row rows[p] of view_state (the in-place update of a scene-wide state table, macarons_utils.py:2867-2877).
 __global__ void view_state_kernel(const float* __restrict__ pts, int pts_dim, const float* __restrict__ X_view,
-                                  float* __restrict__ view_state, long long n_points, int n_view, int n_elev, int n_azim) {
+                                  float* __restrict__ view_state, long long n_points, long long pts_per_cloud, int n_view, int n_elev,
+                                  int n_azim, const long long* __restrict__ rows) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_points * n_view) return;
     const long long p = gid / n_view;
     const int v = (int)(gid - p * n_view);
+    const float* xv = X_view + (p / pts_per_cloud) * (3ll * n_view) + 3 * v;
     const float PI = 3.14159265358979323846f;
-    const float x = X_view[3 * v + 0] - pts[p * pts_dim + 0];
-    const float y = X_view[3 * v + 1] - pts[p * pts_dim + 1];
-    const float z = X_view[3 * v + 2] - pts[p * pts_dim + 2];
+    const float x = xv[0] - pts[p * pts_dim + 0];
+    const float y = xv[1] - pts[p * pts_dim + 1];
+    const float z = xv[2] - pts[p * pts_dim + 2];
     // get_spherical_coords (CustomGeometry.py:27-45)
     const float r = sqrtf(x * x + y * y + z * z);
     const float yr = y / r;
@@ -68,7 +72,7 @@ __global__ void view_state_kernel(const float* __restrict__ pts, int pts_dim, co
     const int nb = n_elev * n_azim;
     idx %= nb;
     if (idx < 0) idx += nb;                                            // Python % on a negative product
-    view_state[p * nb + idx] = 1.0f;                                   // idempotent (scone_utils.py:857-858)
+    view_state[(rows ? rows[p] : p) * nb + idx] = 1.0f;                // idempotent (scone_utils.py:857-858)
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -80,10 +84,16 @@ constexpr int SMP_BLOCK = 256;
 
 __global__ __launch_bounds__(SMP_BLOCK) void smp_block_sums(const float* __restrict__ preds, long long pred_stride,
                                                             float min_occ, long long P, double* __restrict__ block_sums,
-                                                            int n_blocks, double* __restrict__ total, unsigned* __restrict__ done) {
+                                                            int n_blocks, double* __restrict__ total, unsigned* __restrict__ done,
+                                                            long long ws_stride) {
     __shared__ double s[SMP_BLOCK];
     __shared__ double carry;
     __shared__ bool last;
+    // cloud blockIdx.y: its own occupancies and its own slice of the scratch (ws_stride bytes apart)
+    preds += (long long)blockIdx.y * P * pred_stride;
+    block_sums = (double*)((char*)block_sums + blockIdx.y * ws_stride);
+    total = (double*)((char*)total + blockIdx.y * ws_stride);
+    done = (unsigned*)((char*)done + blockIdx.y * ws_stride);
     const long long i = (long long)blockIdx.x * SMP_BLOCK + threadIdx.x;
     double v = 0.0;
     if (i < P) {
@@ -129,9 +139,15 @@ __global__ __launch_bounds__(SMP_BLOCK) void smp_block_sums(const float* __restr
 // block, the search moves on to the next block (and ends on the last kept point overall).
 __global__ __launch_bounds__(256) void smp_search(const float* __restrict__ preds, long long pred_stride, float min_occ, long long P,
                                                   const double* __restrict__ block_off, int n_blocks, const double* __restrict__ total,
-                                                  const float* __restrict__ u, int n_sample, long long* __restrict__ picked) {
+                                                  const float* __restrict__ u, int n_sample, long long* __restrict__ picked,
+                                                  long long ws_stride) {
     const int sidx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (sidx >= n_sample) return;
+    preds += (long long)blockIdx.y * P * pred_stride;
+    u += (long long)blockIdx.y * n_sample;
+    block_off = (const double*)((const char*)block_off + blockIdx.y * ws_stride);
+    total = (const double*)((const char*)total + blockIdx.y * ws_stride);
+    picked = (long long*)((char*)picked + blockIdx.y * ws_stride);
     const double target = (double)u[sidx] * (*total);
     int lo = 0, hi = n_blocks - 1;                 // last block whose exclusive offset < target (or 0)
     while (lo < hi) {
@@ -198,9 +214,15 @@ __global__ __launch_bounds__(256) void smp_search(const float* __restrict__ pred
 constexpr int SMP_MAX = 4096;
 __global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__ picked, int n_sample,
                                                    long long* __restrict__ uniq, long long* __restrict__ inverse,
-                                                   int* __restrict__ n_unique) {
+                                                   int* __restrict__ n_unique, long long ws_stride,
+                                                   const double* __restrict__ total, double* __restrict__ volume) {
     __shared__ long long key[SMP_MAX];
     __shared__ int rank[SMP_MAX];
+    picked = (const long long*)((const char*)picked + blockIdx.x * ws_stride);     // one block per cloud
+    if (volume && threadIdx.x == 0) volume[blockIdx.x] = *(const double*)((const char*)total + blockIdx.x * ws_stride);
+    uniq += (long long)blockIdx.x * n_sample;
+    inverse += (long long)blockIdx.x * n_sample;
+    n_unique += blockIdx.x;
     int n2 = 1;
     while (n2 < n_sample) n2 <<= 1;
     for (int i = threadIdx.x; i < n2; i += 1024)
@@ -252,9 +274,14 @@ __global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__
 // 16 rows x 64 columns per block (inside the single sort block this gather was 128 serial passes of dependent loads: 0.2 ms)
 __global__ __launch_bounds__(1024) void smp_gather(const long long* __restrict__ uniq, const int* __restrict__ n_unique, int n_sample,
                                                    const float* __restrict__ X, const float* __restrict__ preds, long long pred_stride,
-                                                   const float* __restrict__ vh, float* __restrict__ res, float* __restrict__ res_h) {
+                                                   const float* __restrict__ vh, float* __restrict__ res, float* __restrict__ res_h,
+                                                   long long P) {
     const int r = blockIdx.x * 16 + (threadIdx.x >> 6), c = threadIdx.x & 63;
     if (r >= n_sample) return;
+    const long long b = blockIdx.y;
+    uniq += b * n_sample; n_unique += b; X += b * P * 3; preds += b * P * pred_stride;
+    if (vh) { vh += b * P * 64; res_h += b * n_sample * 64; }
+    res += b * n_sample * 4;
     if (r < *n_unique) {
         const long long i = uniq[r];
         if (vh) res_h[(long long)r * 64 + c] = vh[i * 64 + c];
@@ -560,51 +587,77 @@ __global__ __launch_bounds__(64) void best_merge_kernel(const float* __restrict_
 
 extern "C" {
 
-int mcr_view_state(const float* pts, int pts_dim, const float* X_view, float* view_state, int64_t n_points, int n_view,
-                   int n_elev, int n_azim, void* stream) {
-    MCR_REQUIRE(pts && X_view && view_state, "mcr_view_state: null pointer");
-    MCR_REQUIRE(pts_dim >= 3 && n_points > 0 && n_view > 0 && n_elev > 0 && n_azim > 0, "mcr_view_state: bad sizes");
+static int view_state_impl(const char* who, const float* pts, int pts_dim, const float* X_view, float* view_state, int64_t n_clouds,
+                           int64_t pts_per_cloud, int n_view, int n_elev, int n_azim, const int64_t* rows, int accumulate,
+                           void* stream) {
+    MCR_REQUIRE(pts && X_view && view_state, "%s: null pointer", who);
+    MCR_REQUIRE(pts_dim >= 3 && n_clouds > 0 && pts_per_cloud > 0 && n_view > 0 && n_elev > 0 && n_azim > 0, "%s: bad sizes", who);
+    MCR_REQUIRE(!rows || accumulate, "%s: a row index needs accumulate != 0 (the table is the caller's state)", who);
     hipStream_t s = (hipStream_t)stream;
-    const size_t bytes = (size_t)n_points * n_elev * n_azim * sizeof(float);
-    launch_zero(s, view_state, bytes);
-    const long long total = (long long)n_points * n_view;
+    const long long n_points = (long long)n_clouds * pts_per_cloud;
+    if (!accumulate) launch_zero(s, view_state, (size_t)n_points * n_elev * n_azim * sizeof(float));
+    const long long total = n_points * n_view;
     hipLaunchKernelGGL(view_state_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, pts, pts_dim, X_view, view_state,
-                       (long long)n_points, n_view, n_elev, n_azim);
+                       n_points, (long long)pts_per_cloud, n_view, n_elev, n_azim, (const long long*)rows);
     MCR_LAUNCH_CHECK("view_state_kernel");
     return 0;
 }
 
-size_t mcr_sample_proxy_workspace_bytes(int64_t P, int n_sample) {
-    return (size_t)(cdiv(P, SMP_BLOCK) + 2) * sizeof(double) + (size_t)n_sample * sizeof(long long) + 512;
+int mcr_view_state(const float* pts, int pts_dim, const float* X_view, float* view_state, int64_t n_points, int n_view,
+                   int n_elev, int n_azim, void* stream) {
+    return view_state_impl("mcr_view_state", pts, pts_dim, X_view, view_state, 1, n_points, n_view, n_elev, n_azim, nullptr, 0, stream);
 }
 
+int mcr_view_state_batched(const float* pts, int pts_dim, const float* X_view, float* view_state, int64_t n_clouds,
+                           int64_t pts_per_cloud, int n_view, int n_elev, int n_azim, const int64_t* rows, int accumulate,
+                           void* stream) {
+    return view_state_impl("mcr_view_state_batched", pts, pts_dim, X_view, view_state, n_clouds, pts_per_cloud, n_view, n_elev, n_azim,
+                           rows, accumulate, stream);
+}
 
-int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t P,
-                     float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
-                     int64_t* inverse, int* n_unique, double* volume, void* workspace, size_t workspace_bytes, void* stream) {
+// per-cloud scratch slice: [block sums (nb) | total (2)] doubles, picked[n_sample] int64, ticket (+ padding)
+static size_t smp_slice_bytes(int64_t P, int n_sample) {
+    return (size_t)(cdiv(P, SMP_BLOCK) + 2) * sizeof(double) + (size_t)n_sample * sizeof(long long) + 64;
+}
+
+size_t mcr_sample_proxy_workspace_bytes(int64_t P, int n_sample) { return smp_slice_bytes(P, n_sample) + 448; }
+size_t mcr_sample_proxy_batched_workspace_bytes(int64_t B, int64_t P, int n_sample) { return (size_t)B * smp_slice_bytes(P, n_sample) + 448; }
+
+int mcr_sample_proxy_batched(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t B, int64_t P,
+                             float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
+                             int64_t* inverse, int* n_unique, double* volume, void* workspace, size_t workspace_bytes, void* stream) {
     MCR_REQUIRE(X && preds && u && res && uniq && inverse && n_unique && (res_harmonics || !view_harmonics),
                 "mcr_sample_proxy: null pointer");
-    MCR_REQUIRE(P > 0 && n_sample > 0 && n_sample <= SMP_MAX, "mcr_sample_proxy: need 0 < n_sample <= %d", SMP_MAX);
+    MCR_REQUIRE(B > 0 && B <= 65535 && P > 0 && n_sample > 0 && n_sample <= SMP_MAX, "mcr_sample_proxy: need 0 < n_sample <= %d, 0 < B <= 65535",
+                SMP_MAX);
     MCR_REQUIRE(P < (1ll << 49), "mcr_sample_proxy: P too large");
-    MCR_REQUIRE(workspace && workspace_bytes >= mcr_sample_proxy_workspace_bytes(P, n_sample), "mcr_sample_proxy: workspace too small");
+    MCR_REQUIRE(workspace && workspace_bytes >= mcr_sample_proxy_batched_workspace_bytes(B, P, n_sample), "mcr_sample_proxy: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int nb = (int)cdiv(P, SMP_BLOCK);
+    const long long stride = (long long)smp_slice_bytes(P, n_sample);
     double* block_sums = (double*)workspace;
     double* total = block_sums + nb;
     long long* picked = (long long*)(total + 2);
     unsigned* ticket = (unsigned*)(picked + n_sample);          // "last block scans" counter of smp_block_sums, in the caller's scratch
-    launch_zero(s, ticket, sizeof(unsigned));
-    hipLaunchKernelGGL(smp_block_sums, dim3(nb), dim3(SMP_BLOCK), 0, s, preds, (long long)pred_stride, min_occ, (long long)P, block_sums,
-                       nb, total, ticket);
-    hipLaunchKernelGGL(smp_search, dim3((unsigned)cdiv(n_sample, 4)), dim3(256), 0, s, preds, (long long)pred_stride, min_occ,
-                       (long long)P, block_sums, nb, total, u, n_sample, picked);
-    hipLaunchKernelGGL(smp_unique, dim3(1), dim3(1024), 0, s, picked, n_sample, (long long*)uniq, (long long*)inverse, n_unique);
-    hipLaunchKernelGGL(smp_gather, dim3((unsigned)cdiv(n_sample, 16)), dim3(1024), 0, s, (const long long*)uniq, n_unique, n_sample, X,
-                       preds, (long long)pred_stride, view_harmonics, res, res_harmonics);
-    if (volume)
-        if (int e = check_hip(hipMemcpyAsync(volume, total, sizeof(double), hipMemcpyDeviceToDevice, s), "mcr_sample_proxy: volume")) return e;
+    if (B == 1) launch_zero(s, ticket, sizeof(unsigned));
+    else launch_zero(s, workspace, (size_t)B * stride);
+    hipLaunchKernelGGL(smp_block_sums, dim3(nb, (unsigned)B), dim3(SMP_BLOCK), 0, s, preds, (long long)pred_stride, min_occ, (long long)P,
+                       block_sums, nb, total, ticket, stride);
+    hipLaunchKernelGGL(smp_search, dim3((unsigned)cdiv(n_sample, 4), (unsigned)B), dim3(256), 0, s, preds, (long long)pred_stride, min_occ,
+                       (long long)P, block_sums, nb, total, u, n_sample, picked, stride);
+    hipLaunchKernelGGL(smp_unique, dim3((unsigned)B), dim3(1024), 0, s, picked, n_sample, (long long*)uniq, (long long*)inverse, n_unique,
+                       stride, total, volume);
+    hipLaunchKernelGGL(smp_gather, dim3((unsigned)cdiv(n_sample, 16), (unsigned)B), dim3(1024), 0, s, (const long long*)uniq, n_unique,
+                       n_sample, X, preds, (long long)pred_stride, view_harmonics, res, res_harmonics, (long long)P);
     MCR_LAUNCH_CHECK("mcr_sample_proxy");
     return 0;
+}
+
+int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t P,
+                     float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
+                     int64_t* inverse, int* n_unique, double* volume, void* workspace, size_t workspace_bytes, void* stream) {
+    return mcr_sample_proxy_batched(X, preds, pred_stride, view_harmonics, 1, P, min_occ, u, n_sample, res, res_harmonics, uniq, inverse,
+                                    n_unique, volume, workspace, workspace_bytes, stream);
 }
 
 int mcr_points_in_fov(const float* pts, int64_t P, const float* cameras, int n_cam, unsigned char* mask, void* stream) {

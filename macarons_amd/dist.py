@@ -17,6 +17,34 @@ def shard_range(n_items, rank, world):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def _host_staged(t, group):
+    """gloo has no device transport worth relying on: when the group's backend is gloo and the tensor lives on a HIP device
+    (world-size-2 tests of the sharded step with two processes on ONE GPU -- RCCL refuses duplicate devices), the collective
+    runs on a host copy.  RCCL groups (the product path) never take this branch."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_gather_into(recv, send, group=None):
+    """dist.all_gather_into_tensor(recv, send) on flat tensors, host-staged for (gloo, device tensor)."""
+    if _host_staged(send, group):
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(r, send.cpu(), group=group)
+        recv.copy_(r)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+
+
+def broadcast(buf, src, group=None):
+    """dist.broadcast(buf, src) (`src` = rank inside `group`), host-staged for (gloo, device tensor)."""
+    gsrc = dist.get_global_rank(group, src) if group is not None else src
+    if _host_staged(buf, group):
+        h = buf.cpu()
+        dist.broadcast(h, gsrc, group=group)
+        buf.copy_(h)
+    else:
+        dist.broadcast(buf, gsrc, group=group)
+
+
 _bufs = {}
 
 
@@ -34,7 +62,7 @@ def allgather_argmax(best_vals, best_global_idx, group=None):
     send[:, 0] = best_vals
     # camera indices < 2^24 are exact in fp32: one 8-byte record per cloud, one collective
     send[:, 1] = best_global_idx.to(torch.float32)
-    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    all_gather_into(recv.view(-1), send.view(-1), group)
     vals = recv[:, :, 0]                      # [world, B]
     idx = recv[:, :, 1]
     vmax = vals.max(dim=0).values             # [B]  (NaN if any rank holds one, like torch.max over the full row)
@@ -54,7 +82,7 @@ def allgather_rows(local, n_total, group=None):
     send = local.new_zeros((m,) + tuple(tail))
     send[:local.shape[0]] = local
     recv = local.new_empty((world * m,) + tuple(tail))
-    dist.all_gather_into_tensor(recv, send, group=group)
+    all_gather_into(recv, send, group)
     return torch.cat([recv[r * m: r * m + (b - a)] for r, (a, b) in enumerate(sizes)], dim=0)
 
 
@@ -77,7 +105,7 @@ def allgather_best(gains, idx_offset, group=None):
     else:
         send = ops.best_record(gains, idx_offset)
     recv = torch.empty((world, B, 2), dtype=torch.float32, device=gains.device)
-    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    all_gather_into(recv.view(-1), send.view(-1), group)
     return ops.best_merge(recv)
 
 
@@ -99,7 +127,7 @@ def broadcast_draws(int_tensors, uniforms=None, src=0, group=None):
     if not parts:
         return [], None
     buf = torch.cat(parts)
-    torch.distributed.broadcast(buf, src, group=group)
+    broadcast(buf, src, group)
     out, off = [], 0
     for t in int_tensors:
         out.append(buf[off:off + t.numel()].reshape(t.shape))

@@ -34,6 +34,12 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
     (n_unique: int32 [1]); nothing is read back inside the step, so it runs without a single host synchronisation.
     `occ_perms` / `samples` pin the hidden RNG draws (SconeOcc randperms; sampling uniforms).  `view_proj` [n_view,4,4]
     (full-projection matrices of the past views) switches on the tester's proxy-point filter (testers/shapenet.py:117-122)."""
+    if X.shape[0] > 1:                              # a scene batch: nbv_step_batch (B independent decisions, SURVEY §8e sharding rule)
+        if view_proj is not None or max_points_per_pass < X.shape[1] * X.shape[0]:
+            raise NotImplementedError("nbv_step: the proxy filter / multi-chunk occupancy pass are single-cloud options")
+        return nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=seq_len, min_occ=min_occ,
+                              true_monte_carlo_sampling=true_monte_carlo_sampling, occ_perms=occ_perms, samples=samples,
+                              group=group, return_samples=return_samples)
     inited = torch.distributed.is_available() and torch.distributed.is_initialized()
     world = torch.distributed.get_world_size(group) if inited else 1
     rank = torch.distributed.get_rank(group) if world > 1 else 0
@@ -120,6 +126,101 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
            "n_unique": n_unique}
     if return_samples:                              # the unique sampled proxy points (first n_unique of seq_len rows) and the inverse map [seq_len]
         out["proxy_points"], out["sample_idx"] = sampled
+    return out
+
+
+def draw_batch(scone_occ, B, M, seq_len, device):
+    """The hidden draws of B single-cloud decisions made one after the other (testers/shapenet.py:33-37 loops the objects of a
+    batch): per cloud SconeOcc's three randperms from the CPU generator, then its seq_len sampling uniforms from the device
+    generator.  -> (perms: three int64 tensors [B, n_i], samples [B, seq_len])."""
+    per_cloud = [scone_occ.draw_perms(M) for _ in range(B)]
+    perms = [torch.stack([pc_[i] for pc_ in per_cloud]).to(device) for i in range(3)]
+    samples = torch.stack([torch.rand(seq_len, 1, device=device).view(-1) for _ in range(B)])
+    return perms, samples
+
+
+def nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1, true_monte_carlo_sampling=True,
+                   occ_perms=None, samples=None, group=None, return_samples=False):
+    """B independent NBV decisions (a scene batch: BASELINE config 3 = 8 objects x 32k proxy points x 200 cameras) in ONE launch
+    sequence.  pc [B,M,3], X [B,Q,3], X_view [B,n_view,3] (every object has its own trajectory) or [n_view,3], X_cam [C,3] or
+    [B,C,3].  occ_perms: three int64 tensors [B, n_i] (or 1-D, shared), samples [B, seq_len]; None = draw_batch().  Cloud b's
+    result equals nbv_step(pc[b:b+1], X[b:b+1], X_view[b], X_cam[b], occ_perms=[p[b] ...], samples=samples[b]).
+
+    Sharding over the ranks of `group` (block-partition the flattened scene-batch x camera product):
+      B >= world: the CLOUDS are sharded -- every rank runs whole decisions for its clouds (nothing replicated, no data-path
+                  collective) and the only exchange is the all-gather of one 8-byte (gain, camera) record per cloud;
+      B <  world: clouds replicated, the Q queries of the occupancy pass and the C cameras are sharded as in nbv_step
+                  (all-gather of the occupancies, then of the per-rank records).
+    Returns dict(gains [B_local, C_local], cloud_range, cam_range, max_gain [B], nbv_idx [B] int64, occ [B_local, Q, 1],
+    n_unique int32 [B_local]); device tensors, no host synchronisation inside."""
+    from . import ops
+    inited = torch.distributed.is_available() and torch.distributed.is_initialized()
+    world = torch.distributed.get_world_size(group) if inited else 1
+    rank = torch.distributed.get_rank(group) if world > 1 else 0
+    dev = X.device
+    B, Q, M, C = X.shape[0], X.shape[1], pc.shape[1], X_cam.shape[-2]
+    if pc.shape[0] != B:
+        raise ValueError("nbv_step_batch: pc and X must hold the same number of clouds")
+    by_cloud = world > 1 and B >= world
+    with torch.no_grad():
+        # ---- hidden draws: rank 0's, for ALL clouds, in one broadcast ----
+        if occ_perms is None or samples is None:
+            dp, du = draw_batch(scone_occ, B, M, seq_len, dev)
+            if world > 1:
+                got_p, got_u = mdist.broadcast_draws(dp if occ_perms is None else [], du if samples is None else None, 0, group)
+                dp, du = (got_p if occ_perms is None else dp), (got_u if samples is None else du)
+            occ_perms = dp if occ_perms is None else occ_perms
+            samples = du if samples is None else samples
+        samples = samples.reshape(B, seq_len).to(dev)
+        occ_perms = [p.to(dev) for p in occ_perms]
+        b0, b1 = mdist.shard_range(B, rank, world) if by_cloud else (0, B)
+        q0, q1 = (0, Q) if (by_cloud or world == 1) else mdist.shard_range(Q, rank, world)
+        c0, c1 = (0, C) if (by_cloud or world == 1) else mdist.shard_range(C, rank, world)
+        Bl = b1 - b0
+        pc_l, X_b = pc[b0:b1].contiguous(), X[b0:b1].contiguous()
+        Xv_l = X_view[b0:b1].contiguous() if X_view.dim() == 3 else X_view
+        perms_l = [p[b0:b1] if p.dim() == 2 else p for p in occ_perms]
+        u_l = samples[b0:b1].contiguous()
+        vs_of = lambda pts: su.compute_view_harmonics(su.compute_view_state(pts, Xv_l, grid.n_elev, grid.n_azim), grid.base_harmonics,
+                                                      grid.h_polar, grid.h_azim, grid.n_elev, grid.n_azim)
+        # ---- view harmonics + occupancy of this rank's (clouds, queries) block ----
+        if q1 > q0:
+            Xl = X_b[:, q0:q1].contiguous()
+            vh_l = vs_of(Xl)
+            occ_l = scone_occ(pc_l, Xl, vh_l, perms=perms_l).view(Bl, q1 - q0)
+        else:
+            vh_l, occ_l = None, torch.zeros(Bl, 0, dtype=torch.float32, device=dev)
+        if q1 - q0 < Q:                               # query-sharded: only the occupancies travel (4 B per proxy point and cloud)
+            occ = mdist.allgather_rows(occ_l.t().contiguous(), Q, group).t().contiguous()
+            vh_l = None
+        else:
+            occ = occ_l
+        # ---- sampling (per cloud, own uniforms), SconeVis on the padded unique sets ----
+        res, resh, inv, uniq, nu, _ = ops.sample_proxy_batched(X_b, occ, vh_l, u_l, min_occ)
+        if resh is None:                              # harmonics of the sampled points recomputed locally (a row depends on its point only)
+            resh = vs_of(res[..., :3].contiguous())
+        harm = scone_vis(res, view_harmonics=resh, lengths=nu)
+        if true_monte_carlo_sampling:
+            pts_s = torch.gather(res, 1, inv[..., None].expand(-1, -1, 4))
+            harm_s = torch.gather(harm, 1, inv[..., None].expand(-1, -1, 64))
+        else:
+            raise NotImplementedError("nbv_step_batch scores the Monte-Carlo multiset (true_monte_carlo_sampling=True)")
+        # ---- gains over this rank's cameras, arg-max exchange ----
+        cams = X_cam[b0:b1] if X_cam.dim() == 3 else X_cam[None].expand(Bl, -1, -1)
+        cams = cams[:, c0:c1].contiguous()
+        gains = scone_vis.compute_coverage_gain(pts_s, harm_s, cams) if c1 > c0 else torch.zeros(Bl, 0, dtype=torch.float32, device=dev)
+        if by_cloud:
+            rec = mdist.allgather_rows(ops.best_record(gains, 0), B, group)
+            max_gain, nbv_idx = rec[:, 0].contiguous(), rec[:, 1].to(torch.int64)
+        elif world > 1:
+            max_gain, nbv_idx = mdist.allgather_best(gains, c0, group)
+        else:
+            rec = ops.best_record(gains, 0)
+            max_gain, nbv_idx = rec[:, 0].contiguous(), rec[:, 1].to(torch.int64)
+    out = {"gains": gains, "cloud_range": (b0, b1), "cam_range": (c0, c1), "max_gain": max_gain, "nbv_idx": nbv_idx,
+           "occ": occ.view(Bl, Q, 1), "n_unique": nu}
+    if return_samples:
+        out["proxy_points"], out["sample_idx"] = res, inv
     return out
 
 

@@ -155,9 +155,19 @@ class SconeOcc(nn.Module):
             m = m // ds
         return perms
 
+    @staticmethod
+    def _take(pc, p):
+        """pc[:, p] for a shared 1-D index (SconeOcc.py:269, :311) or, extension, a per-cloud [n_clouds, n] index (a scene batch in
+        which every object keeps the draws its own single-cloud call would have made)."""
+        p = p.to(pc.device)
+        if p.dim() == 1:
+            return pc[:, p].contiguous()
+        return torch.gather(pc, 1, p[..., None].expand(-1, -1, pc.shape[-1])).contiguous()
+
     def forward(self, pc, x, view_harmonics, mask=None, verbose=False, perms=None):
         """pc [n_clouds, M, 3], x [n_clouds, Q, 3], view_harmonics [n_clouds, Q, 64] -> [n_clouds, Q, 1].
-        `perms` (optional): the three index tensors draw_perms() would return, to pin the hidden RNG."""
+        `perms` (optional): the three index tensors draw_perms() would return, to pin the hidden RNG; each either 1-D (shared by
+        the clouds, as the reference draws them) or [n_clouds, n] (one draw per cloud)."""
         if mask is not None:
             raise NotImplementedError("mask is None in every call site of the hot path")
         if not self._is_default_arch():
@@ -167,10 +177,10 @@ class SconeOcc(nn.Module):
         if perms is None:
             perms = self.draw_perms(full_seq_len)
         dev = pc.device
-        pc_global = pc[:, perms[0].to(dev)].contiguous()                              # SconeOcc.py:269
+        pc_global = self._take(pc, perms[0])                                          # SconeOcc.py:269
         scales = [pc.contiguous()]
         for p in perms[1:]:
-            scales.append(scales[-1][:, p.to(dev)].contiguous())                      # :311
+            scales.append(self._take(scales[-1], p))                                  # :311
         if self.fused_local:
             variant = _lib.lib().mcr_get_local_pct_variant()
             blobs = [c.get(t, variant) for c, t in zip(self._blob_caches, self.local_transformers)]
@@ -182,8 +192,8 @@ class SconeOcc(nn.Module):
             def clouds(pc_):
                 sc = [pc_.contiguous()]
                 for p in pidx[1:]:
-                    sc.append(sc[-1][:, p].contiguous())
-                return pc_[:, pidx[0]].contiguous(), sc
+                    sc.append(self._take(sc[-1], p))
+                return self._take(pc_, pidx[0]), sc
 
             def hip(pc_, x_, vh_):
                 g, sc = clouds(pc_)

@@ -142,7 +142,7 @@ def attention_packed(qkv, n_heads, qk_dim, v_dim, split=True):
         raise ValueError("packed qkv width mismatch")
     out = torch.empty((S, L, v_dim), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        if split and L >= 512:
+        if split and L >= 512 and -(-L // 64) * n_heads * S <= 256:      # the kernel's own key-split predicate (launch_attention)
             ws = _workspace(qkv.device, int(lib().mcr_attention_workspace_bytes(c_i64(S), c_i64(L), c_int(n_heads), c_int(v_dim))))
             check(lib().mcr_attention_ws(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads),
                                          c_int(qk_dim), c_int(v_dim), _p(ws), ctypes.c_size_t(ws.numel()), _stream()), "mcr_attention_ws")
@@ -281,15 +281,69 @@ def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_bl
 
 # ---- glue (SURVEY §8f) -----------------------------------------------------------------------------------
 def view_state(pts, X_view, n_elev, n_azim):
-    """[n_clouds, seq_len, n_elev*n_azim] fp32 0/1; replaces compute_view_state (scone_utils.py:799-860)."""
+    """[n_clouds, seq_len, n_elev*n_azim] fp32 0/1; replaces compute_view_state (scone_utils.py:799-860).
+    X_view [n_view,3] (shared by all clouds, as the reference) or [n_clouds,n_view,3] (every cloud of a scene batch against its
+    own past camera positions)."""
     pts, X_view = _req(pts, "pts"), _req(X_view, "X_view")
     B, Q, d = pts.shape
-    V = X_view.shape[0]
     out = torch.empty((B, Q, n_elev * n_azim), dtype=torch.float32, device=pts.device)
     with torch.cuda.device(pts.device):
-        check(lib().mcr_view_state(_p(pts), c_int(d), _p(X_view), _p(out), c_i64(B * Q), c_int(V), c_int(n_elev),
-                                   c_int(n_azim), _stream()), "mcr_view_state")
+        if X_view.dim() == 3:
+            if X_view.shape[0] != B:
+                raise ValueError(f"per-cloud X_view must be [n_clouds={B}, n_view, 3], got {tuple(X_view.shape)}")
+            check(lib().mcr_view_state_batched(_p(pts), c_int(d), _p(X_view), _p(out), c_i64(B), c_i64(Q), c_int(X_view.shape[1]),
+                                               c_int(n_elev), c_int(n_azim), c_vp(0), c_int(0), _stream()), "mcr_view_state_batched")
+        else:
+            check(lib().mcr_view_state(_p(pts), c_int(d), _p(X_view), _p(out), c_i64(B * Q), c_int(X_view.shape[0]), c_int(n_elev),
+                                       c_int(n_azim), _stream()), "mcr_view_state")
     return out
+
+
+def view_state_update_(table, rows, pts, X_view, n_elev, n_azim):
+    """In place: table [P_total, n_elev*n_azim] (0/1 fp32) gets, in row rows[i], the bins of the directions from pts[i] to every
+    X_view position OR'ed in: `view_states[mask] += compute_view_state(...)` followed by torch.heaviside(., 0)
+    (macarons_utils.py:2867-2877) as one launch.  rows: int64 device tensor [n] (None: row i <- point i)."""
+    table, pts, X_view = _req(table, "view_states"), _req(pts, "pts"), _req(X_view, "X_view")
+    n, d = pts.shape
+    if table.shape[-1] != n_elev * n_azim:
+        raise ValueError("view-state table width does not match the lattice")
+    if n == 0:
+        return table
+    r = _req(rows, "rows", torch.int64) if rows is not None else None
+    if r is not None and r.numel() != n:
+        raise ValueError("rows must hold one table row per point")
+    with torch.cuda.device(pts.device):
+        check(lib().mcr_view_state_batched(_p(pts), c_int(d), _p(X_view), _p(table), c_i64(1), c_i64(n), c_int(X_view.shape[0]),
+                                           c_int(n_elev), c_int(n_azim), _p(r) if r is not None else c_vp(0), c_int(1), _stream()),
+              "mcr_view_state_batched")
+    return table
+
+
+def sample_proxy_batched(X, preds, view_harmonics, u, min_occ):
+    """B clouds at once, no host sync: X [B,P,3], preds [B,P], view_harmonics [B,P,64] or None, u [B,n] ->
+    (res [B,n,4], res_harmonics [B,n,64] | None, inverse [B,n] int64, uniq [B,n] int64, n_unique int32 [B], volume fp64 [B]);
+    rows beyond n_unique[b] are zero.  Cloud b is sampled exactly as sample_proxy(X[b], preds[b], ...) would."""
+    X, preds, u = _req(X, "X"), _req(preds, "preds"), _req(u, "samples")
+    vh = _req(view_harmonics, "view_harmonics") if view_harmonics is not None else None
+    B, P = X.shape[0], X.shape[1]
+    n = u.shape[-1]
+    if preds.numel() != B * P or u.numel() != B * n:
+        raise ValueError("sample_proxy_batched: preds must be [B,P] and samples [B,n]")
+    dev = X.device
+    res = torch.empty((B, n, 4), dtype=torch.float32, device=dev)
+    resh = torch.empty((B, n, 64), dtype=torch.float32, device=dev) if vh is not None else None
+    uniq = torch.empty((B, n), dtype=torch.int64, device=dev)
+    inv = torch.empty((B, n), dtype=torch.int64, device=dev)
+    nu = torch.empty(B, dtype=torch.int32, device=dev)
+    vol = torch.empty(B, dtype=torch.float64, device=dev)
+    L_ = lib()
+    ws = _workspace(dev, L_.mcr_sample_proxy_batched_workspace_bytes(c_i64(B), c_i64(P), c_int(n)))
+    with torch.cuda.device(dev):
+        check(L_.mcr_sample_proxy_batched(_p(X), _p(preds), c_i64(1), _p(vh) if vh is not None else c_vp(0), c_i64(B), c_i64(P),
+                                          c_f32(float(min_occ)), _p(u), c_int(n), _p(res), _p(resh) if resh is not None else c_vp(0),
+                                          _p(uniq), _p(inv), _p(nu), _p(vol), _p(ws), c_size(ws.numel()), _stream()),
+              "mcr_sample_proxy_batched")
+    return res, resh, inv, uniq, nu, vol
 
 
 def sample_proxy(X, preds, view_harmonics, u, min_occ, return_volume=False, padded=False):

@@ -1,4 +1,8 @@
-"""Helper of tests/test_nbv_gpu.py::test_sharded_step_two_ranks_matches_single_rank (launched with torch.distributed.run, 2 ranks)."""
+"""Helper of tests/test_nbv_gpu.py: the sharded NBV step on TWO ranks (launched with torch.distributed.run, 2 processes).
+
+MCR_TEST_BACKEND = nccl (two GPUs, RCCL) or gloo (both ranks on cuda:0 of a one-GPU box: RCCL refuses duplicate devices, so the
+collectives run host-staged -- macarons_amd/dist.py -- while every kernel still runs on the GPU).  Every rank first computes the
+1-rank answers (no process group yet), then the 2-rank ones, and compares bit for bit."""
 import os
 import sys
 
@@ -14,13 +18,34 @@ from conftest import golden  # noqa: E402
 import weights  # noqa: E402
 
 
+def batch_scene(g, B, dev):
+    """B different grid clouds out of one golden: cloud b has its axes rotated cyclically b times (stays on the 2^-10 grid), its
+    own past views, hidden draws and uniforms."""
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    roll = lambda a, b: np.roll(a, b, axis=-1)
+    pc = T(np.stack([roll(g["pc"][0], b) for b in range(B)]))
+    X = T(np.stack([roll(g["X"][0], b) for b in range(B)]))
+    cams = g["X_cam"]
+    X_view = T(np.stack([cams[[b % len(cams), (3 * b + 1) % len(cams)]] for b in range(B)]))
+    gen = torch.Generator().manual_seed(77)
+    M = pc.shape[1]
+    perms = [torch.stack([torch.randperm(M, generator=gen)[:2048] for _ in range(B)])]
+    ds = max(2, int(np.power(M / 128, 0.5)))
+    m = M
+    for _ in range(2):
+        perms.append(torch.stack([torch.randperm(m, generator=gen)[:m // ds] for _ in range(B)]))
+        m //= ds
+    u = torch.rand(B, 2048, generator=gen).to(dev)
+    return pc, X, X_view, T(cams), perms, u
+
+
 def main():
     rank, lr = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
-    torch.cuda.set_device(lr)
-    dev = torch.device("cuda", lr)
-    dist.init_process_group("nccl", device_id=dev)
+    backend = os.environ.get("MCR_TEST_BACKEND", "nccl")
+    dev = torch.device("cuda", lr if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
     from macarons_amd.networks import SconeVis, SconeOcc
-    from macarons_amd.nbv import nbv_step, ViewStateGrid
+    from macarons_amd.nbv import nbv_step, nbv_step_batch, ViewStateGrid
     occ, vis = SconeOcc(), SconeVis()
     sdo = weights.make_state_dict(weights.shapes_of(occ), 2)
     sdv = weights.make_state_dict(weights.shapes_of(vis), 1)
@@ -28,18 +53,73 @@ def main():
     occ.load_state_dict({k: torch.from_numpy(v) for k, v in sdo.items()})
     vis.load_state_dict({k: torch.from_numpy(v) for k, v in sdv.items()})
     occ, vis = occ.to(dev).eval(), vis.to(dev).eval()
-    g = golden("e2e_grid_config2")
+    grid = ViewStateGrid(dev)
     T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
-    perms = [torch.from_numpy(g[f"perm{i}"].astype(np.int64)) for i in range(3)]
-    r = nbv_step(occ, vis, T(g["pc"]), T(g["X"]), T(g["X_view"]), T(g["X_cam"]), ViewStateGrid(dev), occ_perms=perms, samples=T(g["samples"]))
-    ok = int(r["nbv_idx"]) == int(g["nbv_idx"])
-    ok = ok and float(np.abs(r["occ"].cpu().numpy() - g["occ"]).max()) < 1e-4 * float(np.abs(g["occ"]).max())
+    g2, g1 = golden("e2e_grid_config2"), golden("e2e_grid_config1")
+    P = lambda g: [torch.from_numpy(g[f"perm{i}"].astype(np.int64)) for i in range(3)]
+    a2 = (occ, vis, T(g2["pc"]), T(g2["X"]), T(g2["X_view"]), T(g2["X_cam"]), grid)
+    tiny = (occ, vis, T(g1["pc"]), T(g1["X"][:, :1]), T(g1["X_view"]), T(g1["X_cam"][:1]), grid)       # Q = 1 < world, C = 1 < world
+    pcb, Xb, Xvb, camb, permb, ub = batch_scene(g1, 3, dev)
+    ab = (occ, vis, pcb, Xb, Xvb, camb, grid)
+
+    # ---- 1-rank answers (torch.distributed not initialised: the plain path) ----
+    s_full = nbv_step(*a2, occ_perms=P(g2), samples=T(g2["samples"]))
+    s_tiny = nbv_step(*tiny, occ_perms=P(g1), samples=T(g1["samples"]))
+    s_b3 = nbv_step_batch(*ab, occ_perms=permb, samples=ub)
+    s_b1 = nbv_step_batch(occ, vis, pcb[:1], Xb[:1], Xvb[:1], camb, grid, occ_perms=[p[:1] for p in permb], samples=ub[:1])
+    torch.cuda.synchronize()
+
+    dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    fails = []
+
+    def expect(cond, what):
+        if not bool(cond):
+            fails.append(what)
+
+    # A: query- and camera-sharded single-cloud step (config-2 shape) == the 1-rank step, bit for bit; == the reference golden at 1e-4
+    r = nbv_step(*a2, occ_perms=P(g2), samples=T(g2["samples"]))
     c0, c1 = r["cam_range"]
-    ok = ok and float(np.abs(r["gains"].cpu().numpy() - g["gains"][c0:c1]).max()) < 1e-4 * float(np.abs(g["gains"]).max())
-    t = torch.tensor([int(ok)], device=dev)
+    expect((c0, c1) == ((0, 50) if rank == 0 else (50, 100)), "A cam_range")
+    expect(torch.equal(r["occ"], s_full["occ"]), "A occ")
+    expect(torch.equal(r["gains"], s_full["gains"][c0:c1]), "A gains")
+    expect(torch.equal(r["max_gain"], s_full["max_gain"]) and int(r["nbv_idx"]) == int(s_full["nbv_idx"]) == int(g2["nbv_idx"]), "A decision")
+    expect(float(np.abs(r["gains"].cpu().numpy() - g2["gains"][c0:c1]).max()) < 1e-4 * float(np.abs(g2["gains"]).max()), "A golden")
+    # B: fewer queries and cameras than ranks: rank 1 holds empty shards but joins every collective
+    r = nbv_step(*tiny, occ_perms=P(g1), samples=T(g1["samples"]))
+    expect(r["cam_range"] == ((0, 1) if rank == 0 else (1, 1)), "B cam_range")
+    expect(torch.equal(r["occ"], s_tiny["occ"]) and torch.equal(r["max_gain"], s_tiny["max_gain"]) and int(r["nbv_idx"]) == 0, "B decision")
+    # C: scene batch, B = 3 >= world: clouds sharded (2 + 1), one record all-gather
+    r = nbv_step_batch(*ab, occ_perms=permb, samples=ub)
+    b0, b1 = r["cloud_range"]
+    expect((b0, b1) == ((0, 2) if rank == 0 else (2, 3)) and r["cam_range"] == (0, camb.shape[0]), "C ranges")
+    expect(torch.equal(r["occ"], s_b3["occ"][b0:b1]) and torch.equal(r["gains"], s_b3["gains"][b0:b1]), "C own clouds")
+    expect(torch.equal(r["max_gain"], s_b3["max_gain"]) and torch.equal(r["nbv_idx"], s_b3["nbv_idx"]), "C decisions")
+    # D: scene batch smaller than the world (B = 1 < 2): replicated cloud, queries and cameras sharded
+    r = nbv_step_batch(occ, vis, pcb[:1], Xb[:1], Xvb[:1], camb, grid, occ_perms=[p[:1] for p in permb], samples=ub[:1])
+    c0, c1 = r["cam_range"]
+    expect(r["cloud_range"] == (0, 1) and (c0, c1) == ((0, 10) if rank == 0 else (10, 20)), "D ranges")
+    expect(torch.equal(r["occ"], s_b1["occ"]) and torch.equal(r["gains"], s_b1["gains"][:, c0:c1]), "D shards")
+    expect(torch.equal(r["max_gain"], s_b1["max_gain"]) and torch.equal(r["nbv_idx"], s_b1["nbv_idx"]), "D decision")
+    expect(torch.equal(s_b1["max_gain"], s_b3["max_gain"][:1]) and torch.equal(s_b1["occ"], s_b3["occ"][:1]), "D batch-of-1 == first of 3")
+    # E: hidden draws (nothing pinned): rank 0's reach rank 1 -> identical decisions on both ranks, single-cloud and batch
+    torch.manual_seed(100 + rank)                                        # the ranks' own generators disagree on purpose
+    r1 = nbv_step(*a2)
+    r2 = nbv_step_batch(*ab)
+    mine = torch.cat((r1["max_gain"].view(-1), r1["nbv_idx"].view(-1).float(), r2["max_gain"], r2["nbv_idx"].float(),
+                      r1["occ"].sum().view(1)))
+    mine = mine if backend == "nccl" else mine.cpu()
+    both = [torch.empty_like(mine) for _ in range(2)]
+    dist.all_gather(both, mine)
+    expect(torch.equal(both[0], both[1]), "E ranks agree under hidden draws")
+
+    t = torch.tensor([0 if fails else 1])
+    if backend == "nccl":
+        t = t.to(dev)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if fails:
+        print(f"rank {rank} FAILED: {fails}", flush=True)
     if rank == 0 and int(t) == 1:
-        print("TWO_RANK_OK")
+        print("TWO_RANK_OK", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if int(t) == 1 else 1)
 
