@@ -226,6 +226,23 @@ int mcr_macarons_gain(float* vis, const float* pts_world, int pts_dim, const flo
  * mcr_unproject_depth (K12): Camera.project_depth_in_3D / utils.project_depth_back_to_3D (macarons_utils.py:2339-2360,
  *   utils.py:1458-1487): depth [n_cam,H,W] -> world [n_cam,H*W,3]; each camera = 18 floats: inverse full projection
  *   matrix (row-major, row-vector convention) + k22, k32 of the projection matrix (scaled-depth conversion). */
+/* mcr_signed_distance_to_depth: Camera.get_signed_distance_to_depth_maps (macarons_utils.py:2451-2500) for one camera / depth
+ *   map: sgn[i] = z_view(pts[i]) - bilinear(depth)(projection of pts[i]), grid_sample(bilinear, border, align_corners=False)
+ *   semantics; camera = 32 floats M_view[16] | M_full_projection[16] (row-major, row-vector convention); depth [H,W];
+ *   mask [H,W] bytes or NULL: pixels with mask == 0 count as `fill` (the reference writes 1.1 zfar there, :2479).
+ * mcr_proxy_scene_update: the proxy-point bookkeeping of one MACARONS step after a new depth map (testers/scene.py:402-418:
+ *   signed distances, Scene.update_proxy_view_states :2817-2877, update_proxy_supervision_occ :2888-2912,
+ *   update_proxy_out_of_field :2879-2886) fused in one pass over the P proxy points; fov_mask [P] bytes selects the points in
+ *   the current frustum (mcr_points_in_fov); X_cam = 3 device floats (the camera centre); per-point state tensors are updated
+ *   in place: view_states [P, n_elev*n_azim] (0/1; the bin towards the camera is OR'ed in where the signed distance is below
+ *   distance_to_surface), n_inside / n_behind / supervision_occ / out_of_field [P].  sgn [P] (optional) receives the signed
+ *   distances of the masked points. */
+int mcr_signed_distance_to_depth(const float* pts, int64_t n, const float* camera, const float* depth, const unsigned char* mask,
+                                 int H, int W, float fill, float* sgn, void* stream);
+int mcr_proxy_scene_update(const float* proxy_points, int64_t P, const unsigned char* fov_mask, const float* camera, const float* depth,
+                           const unsigned char* depth_mask, int H, int W, float fill, const float* X_cam, float distance_to_surface,
+                           float tol, float score_threshold, int n_elev, int n_azim, float* view_states, float* n_inside,
+                           float* n_behind, float* supervision_occ, float* out_of_field, float* sgn, void* stream);
 int mcr_min_dist_segmented(const float* A, const int64_t* a_offsets, const float* B, const int64_t* b_offsets, int64_t n_segments,
                            int64_t max_a_per_segment, double* dmin, void* stream);
 int mcr_unproject_depth(const float* depth, int H, int W, const float* cameras, int64_t n_cam, float* world, void* stream);

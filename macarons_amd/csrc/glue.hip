@@ -30,21 +30,10 @@ static void launch_zero(hipStream_t s, void* p, size_t bytes) {       // bytes %
     hipLaunchKernelGGL(zero_kernel, dim3((unsigned)std::min<long long>(cdiv(n, 256), 2048)), dim3(256), 0, s, (unsigned*)p, n);
 }
 
-// Cloud c = p / pts_per_cloud reads its own view positions X_view[c] ([n_clouds, n_view, 3]); `rows` (optional) redirects point p to
-// row rows[p] of view_state (the in-place update of a scene-wide state table, macarons_utils.py:2867-2877).
-__global__ void view_state_kernel(const float* __restrict__ pts, int pts_dim, const float* __restrict__ X_view,
-                                  float* __restrict__ view_state, long long n_points, long long pts_per_cloud, int n_view, int n_elev,
-                                  int n_azim, const long long* __restrict__ rows) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n_points * n_view) return;
-    const long long p = gid / n_view;
-    const int v = (int)(gid - p * n_view);
-    const float* xv = X_view + (p / pts_per_cloud) * (3ll * n_view) + 3 * v;
+// Bin of the direction (x, y, z) on the n_elev x n_azim lattice: get_spherical_coords (CustomGeometry.py:27-45) followed by the
+// index arithmetic of compute_view_state (scone_utils.py:830-849), literally, in fp32.
+__device__ __forceinline__ long long view_state_bin(float x, float y, float z, int n_elev, int n_azim) {
     const float PI = 3.14159265358979323846f;
-    const float x = xv[0] - pts[p * pts_dim + 0];
-    const float y = xv[1] - pts[p * pts_dim + 1];
-    const float z = xv[2] - pts[p * pts_dim + 2];
-    // get_spherical_coords (CustomGeometry.py:27-45)
     const float r = sqrtf(x * x + y * y + z * z);
     const float yr = y / r;
     float elev = asinf(yr);
@@ -72,7 +61,22 @@ __global__ void view_state_kernel(const float* __restrict__ pts, int pts_dim, co
     const int nb = n_elev * n_azim;
     idx %= nb;
     if (idx < 0) idx += nb;                                            // Python % on a negative product
-    view_state[(rows ? rows[p] : p) * nb + idx] = 1.0f;                // idempotent (scone_utils.py:857-858)
+    return idx;
+}
+
+// Cloud c = p / pts_per_cloud reads its own view positions X_view[c] ([n_clouds, n_view, 3]); `rows` (optional) redirects point p to
+// row rows[p] of view_state (the in-place update of a scene-wide state table, macarons_utils.py:2867-2877).
+__global__ void view_state_kernel(const float* __restrict__ pts, int pts_dim, const float* __restrict__ X_view,
+                                  float* __restrict__ view_state, long long n_points, long long pts_per_cloud, int n_view, int n_elev,
+                                  int n_azim, const long long* __restrict__ rows) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_points * n_view) return;
+    const long long p = gid / n_view;
+    const int v = (int)(gid - p * n_view);
+    const float* xv = X_view + (p / pts_per_cloud) * (3ll * n_view) + 3 * v;
+    const long long idx = view_state_bin(xv[0] - pts[p * pts_dim + 0], xv[1] - pts[p * pts_dim + 1], xv[2] - pts[p * pts_dim + 2],
+                                         n_elev, n_azim);
+    view_state[(rows ? rows[p] : p) * (long long)(n_elev * n_azim) + idx] = 1.0f;      // idempotent (scone_utils.py:857-858)
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -320,6 +324,73 @@ __global__ void fov_kernel(const float* __restrict__ pts, long long P, const flo
     mask[gid] = m ? 1 : 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Signed distance of world points to the surface a depth map delimits (Camera.get_signed_distance_to_depth_maps,
+// macarons_utils.py:2451-2500): z of the point in the camera's view space minus the depth map sampled at the point's projection
+// with torch.nn.functional.grid_sample(mode='bilinear', padding_mode='border', align_corners=False); pixels outside `mask`
+// count as `fill` (= 1.1 zfar, :2479).  cam = M_view[16] | M_full_projection[16] (row-vector convention).
+__device__ __forceinline__ float depth_at(const float* __restrict__ depth, const unsigned char* __restrict__ mask, int W, int ix, int iy,
+                                          float fill) {
+    const long long i = (long long)iy * W + ix;
+    return (mask && !mask[i]) ? fill : depth[i];
+}
+__device__ __forceinline__ float signed_distance(const float* __restrict__ cam, const float* __restrict__ depth,
+                                                 const unsigned char* __restrict__ mask, int H, int W, float fill, float x, float y, float z) {
+    const float zw = ((x * cam[3] + y * cam[7]) + z * cam[11]) + cam[15];
+    const float zv = (((x * cam[2] + y * cam[6]) + z * cam[10]) + cam[14]) / zw;                     // get_points_zbuf (:2448)
+    const float* Mp = cam + 16;
+    const float pw = ((x * Mp[3] + y * Mp[7]) + z * Mp[11]) + Mp[15];
+    const float px = (((x * Mp[0] + y * Mp[4]) + z * Mp[8]) + Mp[12]) / pw;
+    const float py = (((x * Mp[1] + y * Mp[5]) + z * Mp[9]) + Mp[13]) / pw;
+    const float factor = -(float)min(H, W);                                                           // :2484-2487
+    const float gx = factor / (float)W * px, gy = factor / (float)H * py;
+    // grid_sample: unnormalise (align_corners=False), clip to the border, bilinear
+    float fx = ((gx + 1.f) * (float)W - 1.f) / 2.f, fy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    fx = fminf((float)(W - 1), fmaxf(fx, 0.f));
+    fy = fminf((float)(H - 1), fmaxf(fy, 0.f));
+    const float x0 = floorf(fx), y0 = floorf(fy);
+    const int ix0 = (int)x0, iy0 = (int)y0, ix1 = ix0 + 1, iy1 = iy0 + 1;
+    const float w_nw = (x0 + 1.f - fx) * (y0 + 1.f - fy), w_ne = (fx - x0) * (y0 + 1.f - fy);
+    const float w_sw = (x0 + 1.f - fx) * (fy - y0), w_se = (fx - x0) * (fy - y0);
+    float acc = depth_at(depth, mask, W, ix0, iy0, fill) * w_nw;
+    if (ix1 < W) acc += depth_at(depth, mask, W, ix1, iy0, fill) * w_ne;
+    if (iy1 < H) acc += depth_at(depth, mask, W, ix0, iy1, fill) * w_sw;
+    if (ix1 < W && iy1 < H) acc += depth_at(depth, mask, W, ix1, iy1, fill) * w_se;
+    return zv - acc;
+}
+__global__ void signed_distance_kernel(const float* __restrict__ pts, long long n, const float* __restrict__ cam,
+                                       const float* __restrict__ depth, const unsigned char* __restrict__ mask, int H, int W, float fill,
+                                       float* __restrict__ out) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    out[p] = signed_distance(cam, depth, mask, H, W, fill, pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]);
+}
+
+// One pass over the scene's proxy points after a new depth map (testers/scene.py:402-418 = Camera.get_signed_distance_to_depth_maps
+// + Scene.update_proxy_view_states + update_proxy_supervision_occ + update_proxy_out_of_field, macarons_utils.py:2817-2912), for
+// the points whose fov_mask is set: signed distance d to the depth map; if d < distance_to_surface the bin of the direction to
+// the camera is OR'ed into the point's view state; n_inside += 1, n_behind += (d >= -tol), supervision_occ = (n_behind / n_inside
+// >= score_threshold); out_of_field = 0.  sgn (optional) receives d (untouched where the mask is clear).
+__global__ void proxy_update_kernel(const float* __restrict__ pts, long long P, const unsigned char* __restrict__ fov_mask,
+                                    const float* __restrict__ cam, const float* __restrict__ depth, const unsigned char* __restrict__ dmask,
+                                    int H, int W, float fill, const float* __restrict__ X_cam, float distance_to_surface, float tol,
+                                    float score_threshold, int n_elev, int n_azim, float* __restrict__ view_states,
+                                    float* __restrict__ n_inside, float* __restrict__ n_behind, float* __restrict__ sup_occ,
+                                    float* __restrict__ out_of_field, float* __restrict__ sgn) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P || !fov_mask[p]) return;
+    const float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
+    const float d = signed_distance(cam, depth, dmask, H, W, fill, x, y, z);
+    if (sgn) sgn[p] = d;
+    if (d < distance_to_surface)
+        view_states[p * (long long)(n_elev * n_azim) + view_state_bin(X_cam[0] - x, X_cam[1] - y, X_cam[2] - z, n_elev, n_azim)] = 1.0f;
+    const float ni = n_inside[p] + 1.f, nbh = n_behind[p] + (d >= -tol ? 1.f : 0.f);
+    n_inside[p] = ni;
+    n_behind[p] = nbh;
+    sup_occ[p] = (nbh / ni >= score_threshold) ? 1.f : 0.f;
+    out_of_field[p] = 0.f;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // filter_proxy_points (macarons/utility/scone_utils.py:1001-1027): keep the proxy points whose projection falls, in EVERY
@@ -665,6 +736,30 @@ int mcr_points_in_fov(const float* pts, int64_t P, const float* cameras, int n_c
     hipLaunchKernelGGL(fov_kernel, dim3((unsigned)cdiv(P * n_cam, 256)), dim3(256), 0, (hipStream_t)stream, pts, (long long)P,
                        cameras, n_cam, mask);
     MCR_LAUNCH_CHECK("fov_kernel");
+    return 0;
+}
+
+int mcr_signed_distance_to_depth(const float* pts, int64_t n, const float* camera, const float* depth, const unsigned char* mask,
+                                 int H, int W, float fill, float* sgn, void* stream) {
+    MCR_REQUIRE(pts && camera && depth && sgn, "mcr_signed_distance_to_depth: null pointer");
+    MCR_REQUIRE(n > 0 && H > 0 && W > 0, "mcr_signed_distance_to_depth: empty problem");
+    hipLaunchKernelGGL(signed_distance_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, (long long)n, camera,
+                       depth, mask, H, W, fill, sgn);
+    MCR_LAUNCH_CHECK("signed_distance_kernel");
+    return 0;
+}
+
+int mcr_proxy_scene_update(const float* proxy_points, int64_t P, const unsigned char* fov_mask, const float* camera, const float* depth,
+                           const unsigned char* depth_mask, int H, int W, float fill, const float* X_cam, float distance_to_surface,
+                           float tol, float score_threshold, int n_elev, int n_azim, float* view_states, float* n_inside,
+                           float* n_behind, float* supervision_occ, float* out_of_field, float* sgn, void* stream) {
+    MCR_REQUIRE(proxy_points && fov_mask && camera && depth && X_cam && view_states && n_inside && n_behind && supervision_occ &&
+                out_of_field, "mcr_proxy_scene_update: null pointer");
+    MCR_REQUIRE(P > 0 && H > 0 && W > 0 && n_elev > 0 && n_azim > 0, "mcr_proxy_scene_update: bad sizes");
+    hipLaunchKernelGGL(proxy_update_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, proxy_points, (long long)P,
+                       fov_mask, camera, depth, depth_mask, H, W, fill, X_cam, distance_to_surface, tol,
+                       score_threshold, n_elev, n_azim, view_states, n_inside, n_behind, supervision_occ, out_of_field, sgn);
+    MCR_LAUNCH_CHECK("proxy_update_kernel");
     return 0;
 }
 

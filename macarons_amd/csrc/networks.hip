@@ -54,12 +54,13 @@ static void run_encoder(hipStream_t s, const EncW& w, float* x, float* h, float*
     const int64_t T = S * L;
     const int dqk = E / 4, W3 = 2 * dqk + E;
     launch_layernorm(s, x, E, w.n1g, w.n1b, h, E, T, E);                                   // Attention.py:287
-    launch_linear(s, h, E, w.qkv.w, w.qkv.b, nullptr, 0, qkv, W3, T, W3, E, ACT_NONE);       // :186-188
-    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E);       // :191-198 (ff is free here: key-split scratch)
-    launch_linear(s, h, E, w.out.w, w.out.b, x, E, x, E, T, E, E, ACT_NONE);                 // :201-202 + residual :290
+    // every GEMM of the networks routes (fp32 vs split precision) on the rows of ONE sequence, not on T: see launch_linear
+    launch_linear(s, h, E, w.qkv.w, w.qkv.b, nullptr, 0, qkv, W3, T, W3, E, ACT_NONE, nullptr, 0, 0, L);       // :186-188
+    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, /*split_by_length=*/true);   // :191-198 (ff is free here: key-split scratch)
+    launch_linear(s, h, E, w.out.w, w.out.b, x, E, x, E, T, E, E, ACT_NONE, nullptr, 0, 0, L);                 // :201-202 + residual :290
     launch_layernorm(s, x, E, w.n2g, w.n2b, h, E, T, E);                                   // :293
-    launch_linear(s, h, E, w.ff1.w, w.ff1.b, nullptr, 0, ff, 2 * E, T, 2 * E, E, ACT_GELU);  // :232
-    launch_linear(s, ff, 2 * E, w.ff2.w, w.ff2.b, x, E, x, E, T, E, 2 * E, ACT_NONE);        // :235 + residual :298
+    launch_linear(s, h, E, w.ff1.w, w.ff1.b, nullptr, 0, ff, 2 * E, T, 2 * E, E, ACT_GELU, nullptr, 0, 0, L);  // :232
+    launch_linear(s, ff, 2 * E, w.ff2.w, w.ff2.b, x, E, x, E, T, E, 2 * E, ACT_NONE, nullptr, 0, 0, L);        // :235 + residual :298
 }
 
 // ---- PCTransformer (SconeOcc.py:45-130): S sequences of L points (pts_dim 3), E = 128, 2 encoders, 4 heads ----
@@ -85,12 +86,12 @@ static void run_pct(hipStream_t s, const PctW& w, const float* pc, float* feat, 
     float* qkv = a.f(T * (PCT_E + 64));
     float* ff = a.f(T * 2 * PCT_E);
     // Embedding (Attention.py:98-128): linear1 3->125, GELU, linear2 125->125, concat raw input -> 128
-    launch_linear(s, pc, 3, w.l1.w, w.l1.b, nullptr, 0, h, PCT_INNER, T, PCT_INNER, 3, ACT_GELU);
-    launch_linear(s, h, PCT_INNER, w.l2.w, w.l2.b, nullptr, 0, x, PCT_E, T, PCT_INNER, PCT_INNER, ACT_NONE);
+    launch_linear(s, pc, 3, w.l1.w, w.l1.b, nullptr, 0, h, PCT_INNER, T, PCT_INNER, 3, ACT_GELU, nullptr, 0, 0, L);
+    launch_linear(s, h, PCT_INNER, w.l2.w, w.l2.b, nullptr, 0, x, PCT_E, T, PCT_INNER, PCT_INNER, ACT_NONE, nullptr, 0, 0, L);
     launch_copy2d(s, pc, 3, x + PCT_INNER, PCT_E, T, 3);
     for (int e = 0; e < 2; ++e) run_encoder(s, w.enc[e], x, h, qkv, ff, S, L, PCT_E, 4);
     launch_layernorm(s, x, PCT_E, w.ng, w.nb, h, PCT_E, T, PCT_E);                          // SconeOcc.py:119
-    launch_linear(s, h, PCT_E, w.lin0.w, w.lin0.b, nullptr, 0, ff, half, T, half, PCT_E, ACT_NONE);   // :122
+    launch_linear(s, h, PCT_E, w.lin0.w, w.lin0.b, nullptr, 0, ff, half, T, half, PCT_E, ACT_NONE, nullptr, 0, 0, L);   // :122
     launch_pool_max_avg(s, ff, half, feat, ld_feat, S, L, half);                             // :124-126
 }
 
@@ -253,17 +254,17 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
     float* qkv = a.f(T * (VIS_E + 128));
     float* ff = a.f(T * 2 * VIS_E);
     // Embedding: 4 -> 126 GELU -> 126, || cloud-wide max (126) || raw input (4)  = 256   (Attention.py:98-128)
-    launch_linear(s, pts, 4, l1.w, l1.b, nullptr, 0, h, VIS_F, T, VIS_F, 4, ACT_GELU);
-    launch_linear(s, h, VIS_F, l2.w, l2.b, nullptr, 0, x, VIS_E, T, VIS_F, VIS_F, ACT_NONE);
+    launch_linear(s, pts, 4, l1.w, l1.b, nullptr, 0, h, VIS_F, T, VIS_F, 4, ACT_GELU, nullptr, 0, 0, N);
+    launch_linear(s, h, VIS_F, l2.w, l2.b, nullptr, 0, x, VIS_E, T, VIS_F, VIS_F, ACT_NONE, nullptr, 0, 0, N);
     launch_colmax_broadcast(s, x, VIS_E, x + VIS_F, VIS_E, B, (int)N, VIS_F, lengths);
     launch_copy2d(s, pts, 4, x + 2 * VIS_F, VIS_E, T, 4);
     for (int e = 0; e < 3; ++e) run_encoder(s, enc[e], x, h, qkv, ff, B, (int)N, VIS_E, 4, lengths);   // SconeVis.py:139-140
     launch_layernorm(s, x, VIS_E, ng, nb, h, VIS_E, T, VIS_E);                                   // :143
     // fc1 256->192 GELU, || view_harmonics (64), fc2 256->128 GELU, fc3 128->64                  (:146-152)
-    launch_linear(s, h, VIS_E, fc1.w, fc1.b, nullptr, 0, ff, VIS_E, T, 192, VIS_E, ACT_GELU);
+    launch_linear(s, h, VIS_E, fc1.w, fc1.b, nullptr, 0, ff, VIS_E, T, 192, VIS_E, ACT_GELU, nullptr, 0, 0, N);
     launch_copy2d(s, view_harmonics, 64, ff + 192, VIS_E, T, 64);
-    launch_linear(s, ff, VIS_E, fc2.w, fc2.b, nullptr, 0, h, 128, T, 128, VIS_E, ACT_GELU);
-    launch_linear(s, h, 128, fc3.w, fc3.b, nullptr, 0, out, 64, T, 64, 128, ACT_NONE);
+    launch_linear(s, ff, VIS_E, fc2.w, fc2.b, nullptr, 0, h, 128, T, 128, VIS_E, ACT_GELU, nullptr, 0, 0, N);
+    launch_linear(s, h, 128, fc3.w, fc3.b, nullptr, 0, out, 64, T, 64, 128, ACT_NONE, nullptr, 0, 0, N);
     MCR_LAUNCH_CHECK("mcr_scone_vis_forward");
     return 0;
 }
@@ -351,7 +352,7 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
         run_pct(gs, wg, pc_global, gfeat, 512, B, (int)Lg, 256, garena);
         MCR_REQUIRE(garena.ok(), "mcr_scone_occ_forward: workspace overflow (global)");
         // its contribution to linear1: gbias[b, n] = sum_k gfeat[b, k] * W1[n, k]  (columns 0..511 of linear1.weight)
-        launch_linear(gs, gfeat, 512, lin1.w, nullptr, nullptr, 0, gbias, 512, B, 512, 512, ACT_NONE, nullptr, 0, 1856);
+        launch_linear(gs, gfeat, 512, lin1.w, nullptr, nullptr, 0, gbias, 512, B, 512, 512, ACT_NONE, nullptr, 0, 1856, 1);
     }
     // every way out of this function joins the side stream again (error returns included: a dangling fork would poison a capture)
     struct SideJoin {
@@ -385,17 +386,24 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     }
     // the large layers run on the split-precision matrix path of the selected variant (6: fp16 x 3 with the weights split once per
     // call into `wplanes`; otherwise launch_linear's own routing: bf16 x 6 / exact fp32 MFMA)
-    const bool f16 = g_local_pct_variant == 6;
+    // The large layers run on the matrix path of the selected variant -- 6: fp16 x 3 with the weights split once per call into
+    // `wplanes`; 5: bf16 x 6 (exact hi/mid/lo); 1: exact fp32 MFMA -- chosen by the variant and the layer alone, never by the
+    // number of rows: a query's occupancy must not depend on how many other queries share the launch (query shards of the
+    // multi-GPU step, chunks, scene batches and the single call agree bit for bit).
+    const int variant = g_local_pct_variant;
+    const int64_t ANY_M = (int64_t)1 << 40;
     auto big_linear = [&](const float* X_, int64_t ldx, const float* W_, int64_t ldw, const float* b_, float* Y_, int64_t ldy, int64_t M_,
                           int N_, int K_, const float* rb, int64_t rpg) {
-        if (f16 && linear3h_applicable(X_, ldx, W_, ldw, M_, N_, K_))
+        if (variant == 6 && linear3h_applicable(X_, ldx, W_, ldw, ANY_M, N_, K_))
             launch_linear3h(s, X_, ldx, W_, ldw, wplanes, b_, nullptr, 0, Y_, ldy, M_, N_, K_, ACT_GELU, rb, rpg);
+        else if (variant != 1 && linear3_applicable(X_, ldx, W_, ldw, ANY_M, N_, K_))
+            launch_linear3(s, X_, ldx, W_, b_, nullptr, 0, Y_, ldy, M_, N_, K_, ACT_GELU, rb, rpg, ldw);
         else
-            launch_linear(s, X_, ldx, W_, b_, nullptr, 0, Y_, ldy, M_, N_, K_, ACT_GELU, rb, rpg, ldw);
+            launch_linear(s, X_, ldx, W_, b_, nullptr, 0, Y_, ldy, M_, N_, K_, ACT_GELU, rb, rpg, ldw, /*route_rows=*/1);
     };
     // ---- x embedding 3 -> 128 -> 256 -> 512, GELU each (SconeOcc.py:35-42) ----
     const int64_t T = B * Q;
-    launch_linear(s, x, 3, xe1.w, xe1.b, nullptr, 0, h2, 128, T, 128, 3, ACT_GELU);
+    launch_linear(s, x, 3, xe1.w, xe1.b, nullptr, 0, h2, 128, T, 128, 3, ACT_GELU, nullptr, 0, 0, 1);
     big_linear(h2, 128, xe2.w, 128, xe2.b, h1, 256, T, 256, 128, nullptr, 0);
     big_linear(h1, 256, xe3.w, 256, xe3.b, feat + 768, FEAT, T, 512, 256, nullptr, 0);
     launch_copy2d(s, view_harmonics, 64, feat + 1280, FEAT, T, 64);
@@ -406,7 +414,7 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     }
     big_linear(feat, FEAT, lin1.w + 512, 1856, lin1.b, h1, 512, T, 512, FEAT, gbias, Q);
     big_linear(h1, 512, lin2.w, 512, lin2.b, h2, 256, T, 256, 512, nullptr, 0);
-    launch_linear(s, h2, 256, lin3.w, lin3.b, nullptr, 0, out, 1, T, 1, 256, ACT_GELU);
+    launch_linear(s, h2, 256, lin3.w, lin3.b, nullptr, 0, out, 1, T, 1, 256, ACT_GELU, nullptr, 0, 0, 1);
     MCR_LAUNCH_CHECK("mcr_scone_occ_forward");
     return 0;
 }

@@ -11,9 +11,13 @@ enum Act { ACT_NONE = 0, ACT_GELU = 1 };
 // nn.Linear semantics (W is [N,K] row-major).  fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-fp32 products.
 // row_bias (optional): extra bias per group of rows, row_bias[(m / rows_per_group) * N + n]  (used to fold the
 // per-cloud global feature of SconeOcc into the head's first layer without materialising the concat).
+// route_rows (0 = M): the row count the fp32 / split-precision routing decision is taken on.  The networks pass the rows of ONE
+// cloud / sequence, so that a cloud's numerics do not depend on how many other clouds share the launch (a scene batch, a
+// query shard of a multi-GPU step and the single-cloud call then agree bit for bit); the tiling (nt) may still follow M: every
+// fp32 tiling accumulates k in the same order.
 void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R,
                    int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int act,
-                   const float* row_bias = nullptr, int64_t rows_per_group = 0, int64_t ldw = 0);
+                   const float* row_bias = nullptr, int64_t rows_per_group = 0, int64_t ldw = 0, int64_t route_rows = 0);
 
 // Split-precision (exact bf16 hi/mid/lo, six MFMAs per product) variant for the large GEMMs (linear3.hip); launch_linear
 // routes to it when linear3_applicable().
@@ -39,8 +43,11 @@ void launch_layernorm(hipStream_t s, const float* X, int64_t ldx, const float* g
 //   out[m, h*dv:(h+1)*dv].   Sequences are S consecutive blocks of L rows.
 //   lens (optional, device int per sequence): keys = the first min(L, lens[s]) rows (padded variable-length batches).
 // split_ws (optional, attention_split_floats(S, L, H, DV) floats): lets one or two long sequences split their keys over two blocks
+// (L >= 512 and at most 256 blocks otherwise); split_by_length: split whenever L >= 512, whatever S -- the networks use this so
+// that a cloud's result does not depend on how many clouds share the launch (the two forms differ by summation order, ~1e-6).
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
-                      int DQK, int DV, const int* lens = nullptr, float* split_ws = nullptr, size_t split_ws_floats = 0);
+                      int DQK, int DV, const int* lens = nullptr, float* split_ws = nullptr, size_t split_ws_floats = 0,
+                      bool split_by_length = false);
 size_t attention_split_floats(int64_t S, int L, int H, int DV);
 
 // Column max over the L rows of each of S sequences, broadcast into a column slice of every row:

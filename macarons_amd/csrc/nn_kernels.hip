@@ -175,11 +175,11 @@ __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restr
 
 void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R,
                    int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int act, const float* row_bias,
-                   int64_t rows_per_group, int64_t ldw) {
+                   int64_t rows_per_group, int64_t ldw, int64_t route_rows) {
     if (M <= 0 || N <= 0) return;
     if (ldw == 0) ldw = K;
     static const bool use_split = []() { const char* e = getenv("MCR_LINEAR3"); return !(e && e[0] == '0'); }();   // dev A/B knob
-    if (use_split && linear3_applicable(X, ldx, W, ldw, M, N, K)) {
+    if (use_split && linear3_applicable(X, ldx, W, ldw, route_rows > 0 ? route_rows : M, N, K)) {
         launch_linear3(s, X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, act, row_bias, rows_per_group, ldw);
         return;
     }
@@ -191,13 +191,18 @@ void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, c
     const int vec_x = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
     const int vec_w = (K % 4 == 0) && (ldw % 4 == 0) && aligned16(W);
     const long long mb = cdiv(M, LIN_BM);
+    // The K-chunk depth fixes the summation order (the two lane halves of the 32x32x2 MFMA own the two halves of a chunk), so it
+    // is chosen on the ROUTING rows (one cloud), never on M: deep 128-wide chunks when one cloud's problem is a latency chain
+    // (few blocks), 32-wide otherwise.  The column tile nt only groups independent accumulators and may follow M.
+    const long long mb_r = cdiv(route_rows > 0 ? route_rows : M, LIN_BM);
+    const bool deep_k = K >= 128 && K % 4 == 0 && mb_r * cdiv(N, 64) <= 512;
     // widest column tile (X is then read once), but never wider than N, and narrower when the problem is too
     // small to give every CU a few blocks otherwise
-    int nt = 8;
+    int nt = deep_k ? 2 : 8;
     while (nt > 1 && (nt / 2) * 32 >= N) nt >>= 1;
     while (nt > 1 && mb * cdiv(N, nt * 32) < 512) nt >>= 1;
     dim3 grid((unsigned)mb, (unsigned)cdiv(N, nt * 32));
-    if (nt <= 2 && K >= 128 && K % 4 == 0 && mb * cdiv(N, nt * 32) <= 512) {      // small problem: latency chain, deep K chunks
+    if (deep_k) {
         if (nt == 2)
             hipLaunchKernelGGL((linear_kernel<2, 128>), grid, dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw, bias, row_bias,
                                (long long)(rows_per_group > 0 ? rows_per_group : 1), R, (long long)ldr, Y, (long long)ldy, (long long)M,
@@ -633,7 +638,7 @@ __global__ void attention_combine_kernel(float* __restrict__ out, long long ldo,
 size_t attention_split_floats(int64_t S, int L, int H, int DV) { return (size_t)S * L * DV + (size_t)4 * S * L * H; }
 
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
-                      int DQK, int DV, const int* lens, float* split_ws, size_t split_ws_floats) {
+                      int DQK, int DV, const int* lens, float* split_ws, size_t split_ws_floats, bool split_by_length) {
     if (S <= 0 || L <= 0) return;
     const int dq = DQK / H, dv = DV / H;
     if (!lens && L == 16 && H == 4 && dq == 8 && dv == 32) {
@@ -648,7 +653,7 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
     const bool al16 = aligned16(qkv) && ldq % 4 == 0 && (H * dq) % 4 == 0;
     // one or two long sequences leave half the chip idle (L = 2048, 4 heads: 128 blocks): split the keys over two blocks
     const bool split = split_ws && split_ws_floats >= attention_split_floats(S, L, H, DV) && L >= 512 &&
-                       (int64_t)grid.x * H * S <= 256;
+                       2 * S <= 65535 && (split_by_length || (int64_t)grid.x * H * S <= 256);
     if (use_mfma && al16 && ((dq == 8 && dv == 32) || (dq == 16 && dv == 64))) {
         if (split) {
             float* part1 = split_ws;
