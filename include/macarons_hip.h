@@ -184,6 +184,13 @@ int mcr_sample_proxy_batched(const float* X, const float* preds, int64_t pred_st
                              int64_t P, float min_occ, const float* u, int n_sample, float* res, float* res_harmonics,
                              int64_t* uniq, int64_t* inverse, int* n_unique, double* volume, void* workspace,
                              size_t workspace_bytes, void* stream);
+/* B distributions over ONE shared point set: X [P,3] and view_harmonics [P,64] are common, only preds [B,P] and u [B,n_sample]
+ * differ -- the K neighbour cameras of a MACARONS decision, each sampling the scene's proxy points inside its own frustum
+ * (preds = mcr_fov_mask_occ rows; macarons_utils.py:1603-1624).  Workspace as for the batched form. */
+int mcr_sample_proxy_shared(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t B,
+                            int64_t P, float min_occ, const float* u, int n_sample, float* res, float* res_harmonics,
+                            int64_t* uniq, int64_t* inverse, int* n_unique, double* volume, void* workspace,
+                            size_t workspace_bytes, void* stream);
 int mcr_points_in_fov(const float* pts, int64_t P, const float* cameras, int n_cam, unsigned char* mask, void* stream);
 /* filter_proxy_points (macarons/utility/scone_utils.py:1001-1027; call site testers/shapenet.py:122): mask[p] = 1 iff in every
  * view v the projection ([x y z 1] * proj[v])[:2] / w of X[p] lies strictly inside the bounding box of the projected surface
@@ -216,6 +223,11 @@ int mcr_fov_mask_occ(const unsigned char* mask, const float* occ, int64_t occ_st
                      void* stream);
 int mcr_transform_points(float* pts, int pts_dim, int64_t n, const float* M_view, const float* center, float inv_diag,
                          void* stream);
+/* All clouds in one launch: cloud c (pts_per_cloud consecutive rows, or, with cloud_of != NULL, the n_points rows whose
+ * cloud_of[i] == c -- ragged clouds) uses M_view[c] (16 floats), center[c] (3 floats) and inv_diag[c]: the K neighbour cameras'
+ * sampled sets, or the per-cell clouds of the occupancy-field pass, go to their prediction spaces together. */
+int mcr_transform_points_batched(float* pts, int pts_dim, int64_t n_clouds, int64_t pts_per_cloud, const float* M_view,
+                                 const float* center, const float* inv_diag, const int* cloud_of, int64_t n_points, void* stream);
 int mcr_macarons_gain(float* vis, const float* pts_world, int pts_dim, const float* cam_world, const float* volume,
                       float distance_th, int factor_mode, int64_t B, int64_t N, float* gains, void* stream);
 

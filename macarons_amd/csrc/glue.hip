@@ -279,12 +279,13 @@ __global__ __launch_bounds__(1024) void smp_unique(const long long* __restrict__
 __global__ __launch_bounds__(1024) void smp_gather(const long long* __restrict__ uniq, const int* __restrict__ n_unique, int n_sample,
                                                    const float* __restrict__ X, const float* __restrict__ preds, long long pred_stride,
                                                    const float* __restrict__ vh, float* __restrict__ res, float* __restrict__ res_h,
-                                                   long long P) {
+                                                   long long P, int shared_points) {
     const int r = blockIdx.x * 16 + (threadIdx.x >> 6), c = threadIdx.x & 63;
     if (r >= n_sample) return;
     const long long b = blockIdx.y;
-    uniq += b * n_sample; n_unique += b; X += b * P * 3; preds += b * P * pred_stride;
-    if (vh) { vh += b * P * 64; res_h += b * n_sample * 64; }
+    uniq += b * n_sample; n_unique += b; preds += b * P * pred_stride;
+    if (!shared_points) X += b * P * 3;
+    if (vh) { if (!shared_points) vh += b * P * 64; res_h += b * n_sample * 64; }
     res += b * n_sample * 4;
     if (r < *n_unique) {
         const long long i = uniq[r];
@@ -502,10 +503,15 @@ __global__ void fov_mask_occ_kernel(const unsigned char* __restrict__ mask, cons
 
 // in place: pts[i, :3] = ((pts[i, :3] 1) * M_view - center) * inv_diag     (world -> normalised prediction-view space,
 // macarons_utils.py:1641-1660); row stride pts_dim
+// batched form: point i belongs to cloud i / pts_per_cloud (or cloud_of[i]) with its own matrix (16 floats), centre (3) and scale
 __global__ void transform_points_kernel(float* __restrict__ pts, int pts_dim, long long n, const float* __restrict__ M,
-                                        const float* __restrict__ center, float inv_diag) {
+                                        const float* __restrict__ center, float inv_diag, long long pts_per_cloud,
+                                        const float* __restrict__ inv_diag_c, const int* __restrict__ cloud_of) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const long long c = cloud_of ? (long long)cloud_of[i] : i / pts_per_cloud;
+    M += c * 16; center += c * 3;
+    if (inv_diag_c) inv_diag = inv_diag_c[c];
     float* p = pts + i * pts_dim;
     const float x = p[0], y = p[1], z = p[2];
     p[0] = ((((x * M[0] + y * M[4]) + z * M[8]) + M[12]) - center[0]) * inv_diag;
@@ -694,9 +700,10 @@ static size_t smp_slice_bytes(int64_t P, int n_sample) {
 size_t mcr_sample_proxy_workspace_bytes(int64_t P, int n_sample) { return smp_slice_bytes(P, n_sample) + 448; }
 size_t mcr_sample_proxy_batched_workspace_bytes(int64_t B, int64_t P, int n_sample) { return (size_t)B * smp_slice_bytes(P, n_sample) + 448; }
 
-int mcr_sample_proxy_batched(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t B, int64_t P,
+static int sample_proxy_impl(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t B, int64_t P,
                              float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
-                             int64_t* inverse, int* n_unique, double* volume, void* workspace, size_t workspace_bytes, void* stream) {
+                             int64_t* inverse, int* n_unique, double* volume, void* workspace, size_t workspace_bytes, void* stream,
+                             int shared_points) {
     MCR_REQUIRE(X && preds && u && res && uniq && inverse && n_unique && (res_harmonics || !view_harmonics),
                 "mcr_sample_proxy: null pointer");
     MCR_REQUIRE(B > 0 && B <= 65535 && P > 0 && n_sample > 0 && n_sample <= SMP_MAX, "mcr_sample_proxy: need 0 < n_sample <= %d, 0 < B <= 65535",
@@ -719,9 +726,23 @@ int mcr_sample_proxy_batched(const float* X, const float* preds, int64_t pred_st
     hipLaunchKernelGGL(smp_unique, dim3((unsigned)B), dim3(1024), 0, s, picked, n_sample, (long long*)uniq, (long long*)inverse, n_unique,
                        stride, total, volume);
     hipLaunchKernelGGL(smp_gather, dim3((unsigned)cdiv(n_sample, 16), (unsigned)B), dim3(1024), 0, s, (const long long*)uniq, n_unique,
-                       n_sample, X, preds, (long long)pred_stride, view_harmonics, res, res_harmonics, (long long)P);
+                       n_sample, X, preds, (long long)pred_stride, view_harmonics, res, res_harmonics, (long long)P, shared_points);
     MCR_LAUNCH_CHECK("mcr_sample_proxy");
     return 0;
+}
+
+int mcr_sample_proxy_batched(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t B, int64_t P,
+                             float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
+                             int64_t* inverse, int* n_unique, double* volume, void* workspace, size_t workspace_bytes, void* stream) {
+    return sample_proxy_impl(X, preds, pred_stride, view_harmonics, B, P, min_occ, u, n_sample, res, res_harmonics, uniq, inverse,
+                             n_unique, volume, workspace, workspace_bytes, stream, 0);
+}
+
+int mcr_sample_proxy_shared(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t B, int64_t P,
+                            float min_occ, const float* u, int n_sample, float* res, float* res_harmonics, int64_t* uniq,
+                            int64_t* inverse, int* n_unique, double* volume, void* workspace, size_t workspace_bytes, void* stream) {
+    return sample_proxy_impl(X, preds, pred_stride, view_harmonics, B, P, min_occ, u, n_sample, res, res_harmonics, uniq, inverse,
+                             n_unique, volume, workspace, workspace_bytes, stream, 1);
 }
 
 int mcr_sample_proxy(const float* X, const float* preds, int64_t pred_stride, const float* view_harmonics, int64_t P,
@@ -795,7 +816,18 @@ int mcr_transform_points(float* pts, int pts_dim, int64_t n, const float* M_view
                          void* stream) {
     MCR_REQUIRE(pts && M_view && center && pts_dim >= 3 && n > 0, "mcr_transform_points: bad arguments");
     hipLaunchKernelGGL(transform_points_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, pts_dim,
-                       (long long)n, M_view, center, inv_diag);
+                       (long long)n, M_view, center, inv_diag, (long long)n, (const float*)nullptr, (const int*)nullptr);
+    MCR_LAUNCH_CHECK("transform_points_kernel");
+    return 0;
+}
+
+int mcr_transform_points_batched(float* pts, int pts_dim, int64_t n_clouds, int64_t pts_per_cloud, const float* M_view,
+                                 const float* center, const float* inv_diag, const int* cloud_of, int64_t n_points, void* stream) {
+    MCR_REQUIRE(pts && M_view && center && inv_diag && pts_dim >= 3 && n_clouds > 0, "mcr_transform_points_batched: bad arguments");
+    const long long n = cloud_of ? (long long)n_points : (long long)n_clouds * pts_per_cloud;
+    MCR_REQUIRE(n > 0 && (cloud_of || pts_per_cloud > 0), "mcr_transform_points_batched: empty problem");
+    hipLaunchKernelGGL(transform_points_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, pts_dim, n, M_view,
+                       center, 0.f, (long long)(cloud_of ? 1 : pts_per_cloud), inv_diag, cloud_of);
     MCR_LAUNCH_CHECK("transform_points_kernel");
     return 0;
 }

@@ -319,13 +319,37 @@ def view_state_update_(table, rows, pts, X_view, n_elev, n_azim):
     return table
 
 
+def transform_points_batched_(pts, M_view, center, inv_diag, cloud_of=None):
+    """In place, all clouds in one launch: pts [K,S,d] (or, with cloud_of int32 [n], ragged rows [n,d]); M_view [K,4,4],
+    center [K,3], inv_diag [K]:  pts[..., :3] <- (([x y z 1] M_view[c])[:3] - center[c]) * inv_diag[c]."""
+    pts = _req(pts, "pts")
+    M_view, center, inv_diag = _req(M_view, "M_view"), _req(center, "center"), _req(inv_diag, "inv_diag")
+    K = M_view.shape[0]
+    d = pts.shape[-1]
+    if cloud_of is not None:
+        cloud_of = _req(cloud_of, "cloud_of", torch.int32)
+        n, per = pts.shape[0], 0
+    else:
+        n, per = 0, pts.shape[1]
+        if pts.shape[0] != K:
+            raise ValueError("transform_points_batched_: one matrix per cloud")
+    if pts.numel() == 0:
+        return pts
+    with torch.cuda.device(pts.device):
+        check(lib().mcr_transform_points_batched(_p(pts), c_int(d), c_i64(K), c_i64(per), _p(M_view), _p(center), _p(inv_diag),
+                                                 _p(cloud_of) if cloud_of is not None else c_vp(0), c_i64(n), _stream()),
+              "mcr_transform_points_batched")
+    return pts
+
+
 def sample_proxy_batched(X, preds, view_harmonics, u, min_occ):
     """B clouds at once, no host sync: X [B,P,3], preds [B,P], view_harmonics [B,P,64] or None, u [B,n] ->
     (res [B,n,4], res_harmonics [B,n,64] | None, inverse [B,n] int64, uniq [B,n] int64, n_unique int32 [B], volume fp64 [B]);
     rows beyond n_unique[b] are zero.  Cloud b is sampled exactly as sample_proxy(X[b], preds[b], ...) would."""
     X, preds, u = _req(X, "X"), _req(preds, "preds"), _req(u, "samples")
     vh = _req(view_harmonics, "view_harmonics") if view_harmonics is not None else None
-    B, P = X.shape[0], X.shape[1]
+    shared = X.dim() == 2                          # X [P,3] / view_harmonics [P,64] common to the B distributions (preds [B,P])
+    B, P = (preds.shape[0], X.shape[0]) if shared else (X.shape[0], X.shape[1])
     n = u.shape[-1]
     if preds.numel() != B * P or u.numel() != B * n:
         raise ValueError("sample_proxy_batched: preds must be [B,P] and samples [B,n]")
@@ -339,7 +363,8 @@ def sample_proxy_batched(X, preds, view_harmonics, u, min_occ):
     L_ = lib()
     ws = _workspace(dev, L_.mcr_sample_proxy_batched_workspace_bytes(c_i64(B), c_i64(P), c_int(n)))
     with torch.cuda.device(dev):
-        check(L_.mcr_sample_proxy_batched(_p(X), _p(preds), c_i64(1), _p(vh) if vh is not None else c_vp(0), c_i64(B), c_i64(P),
+        fn = L_.mcr_sample_proxy_shared if shared else L_.mcr_sample_proxy_batched
+        check(fn(_p(X), _p(preds), c_i64(1), _p(vh) if vh is not None else c_vp(0), c_i64(B), c_i64(P),
                                           c_f32(float(min_occ)), _p(u), c_int(n), _p(res), _p(resh) if resh is not None else c_vp(0),
                                           _p(uniq), _p(inv), _p(nu), _p(vol), _p(ws), c_size(ws.numel()), _stream()),
               "mcr_sample_proxy_batched")
@@ -515,3 +540,46 @@ def unproject_depth(depth, cameras):
         check(lib().mcr_unproject_depth(_p(depth), c_int(H), c_int(W), _p(cameras), c_i64(n), _p(out), _stream()),
               "mcr_unproject_depth")
     return out
+
+
+def signed_distance_to_depth(pts, camera, depth, mask=None, fill=0.0):
+    """pts [n,3], camera: >= 32 floats (M_view[16] | M_full_projection[16], the head of a points_in_fov record), depth [H,W],
+    mask [H,W] bool/uint8 or None -> signed distances [n]; replaces Camera.get_signed_distance_to_depth_maps
+    (macarons_utils.py:2451-2500) for one camera (pixels outside the mask count as `fill` = 1.1 zfar)."""
+    pts, camera, depth = _req(pts, "pts"), _req(camera, "camera"), _req(depth, "depth")
+    H, W = depth.shape[-2], depth.shape[-1]
+    n = pts.shape[0]
+    out = torch.empty(n, dtype=torch.float32, device=pts.device)
+    if n == 0:
+        return out
+    m = mask.to(torch.uint8).contiguous() if mask is not None else None
+    with torch.cuda.device(pts.device):
+        check(lib().mcr_signed_distance_to_depth(_p(pts), c_i64(n), _p(camera), _p(depth), _p(m) if m is not None else c_vp(0),
+                                                 c_int(H), c_int(W), c_f32(float(fill)), _p(out), _stream()),
+              "mcr_signed_distance_to_depth")
+    return out
+
+
+def proxy_scene_update_(proxy_points, fov_mask, camera, depth, depth_mask, fill, X_cam, distance_to_surface, tol, score_threshold,
+                        n_elev, n_azim, view_states, n_inside, n_behind, supervision_occ, out_of_field, return_sgn=False):
+    """The proxy-point bookkeeping of one MACARONS step (testers/scene.py:402-418) fused in one pass, in place on the state
+    tensors (see mcr_proxy_scene_update).  fov_mask [P] bool/uint8; returns the signed distances [P] if asked (0 outside the mask)."""
+    pp = _req(proxy_points, "proxy_points")
+    P = pp.shape[0]
+    fm = fov_mask.to(torch.uint8).contiguous()
+    dm = depth_mask.to(torch.uint8).contiguous() if depth_mask is not None else None
+    depth = _req(depth, "depth")
+    H, W = depth.shape[-2], depth.shape[-1]
+    for name, t in (("view_states", view_states), ("n_inside", n_inside), ("n_behind", n_behind), ("supervision_occ", supervision_occ),
+                    ("out_of_field", out_of_field)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError(f"{name} must be a contiguous fp32 device tensor (updated in place)")
+    sgn = torch.zeros(P, dtype=torch.float32, device=pp.device) if return_sgn else None
+    with torch.cuda.device(pp.device):
+        check(lib().mcr_proxy_scene_update(_p(pp), c_i64(P), _p(fm), _p(_req(camera, "camera")), _p(depth),
+                                           _p(dm) if dm is not None else c_vp(0), c_int(H), c_int(W), c_f32(float(fill)),
+                                           _p(_req(X_cam, "X_cam")), c_f32(float(distance_to_surface)), c_f32(float(tol)),
+                                           c_f32(float(score_threshold)), c_int(n_elev), c_int(n_azim), _p(view_states), _p(n_inside),
+                                           _p(n_behind), _p(supervision_occ), _p(out_of_field), _p(sgn) if sgn is not None else c_vp(0),
+                                           _stream()), "mcr_proxy_scene_update")
+    return sgn

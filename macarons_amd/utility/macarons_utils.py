@@ -72,15 +72,14 @@ def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harm
     S = seq_len
     mask = ops.points_in_fov(X_world, cameras)                                            # :1603
     occ_k = ops.fov_mask_occ(mask, occ_probs.reshape(-1).contiguous())                    # :1606-1613 folded into the sampler
-    # ---- sampling inside every frustum (:1624): K independent distributions, nothing read back (padded rows, counts on the device)
-    res, res_h, inv, nu, vol = [], [], [], [], []
-    for k in range(K):
-        u = samples[k] if samples is not None else torch.rand(S, device=dev)
-        r, h, i, _, n, v = ops.sample_proxy(X_world, occ_k[k], proxy_view_harmonics, u.reshape(-1), min_occ, return_volume=True,
-                                            padded=True)
-        res.append(r); res_h.append(h); inv.append(i); nu.append(n); vol.append(v)
-    res, res_h, inv = torch.stack(res), torch.stack(res_h), torch.stack(inv)              # [K,S,4] [K,S,64] [K,S]
-    nu, vol = torch.cat(nu), torch.cat(vol).float()                                       # [K] int32, [K]
+    # ---- sampling inside every frustum (:1624): K distributions over the ONE shared point set in one launch sequence, nothing
+    # read back (padded rows, counts on the device).  Uniforms: one torch.rand(S, 1) per camera in order, as K calls would draw.
+    if samples is None:
+        u = torch.stack([torch.rand(S, 1, device=dev).view(-1) for _ in range(K)])
+    else:
+        u = torch.stack([torch.as_tensor(x, device=dev).reshape(-1) for x in samples]).float()
+    res, res_h, inv, _, nu, vol = ops.sample_proxy_batched(X_world, occ_k, proxy_view_harmonics, u.contiguous(), min_occ)
+    vol = vol.float()                                                                      # [K,S,4] [K,S,64] [K,S]; [K] int32, [K]
     # ---- prediction box: centre of the sampled points' bounding box, in the prediction camera's view space (:1631-1641)
     valid = (torch.arange(S, device=dev)[None, :] < nu[:, None])[..., None]               # [K,S,1]
     xyz = res[..., :3]
@@ -91,10 +90,9 @@ def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harm
     center = torch.bmm(torch.cat((center_w, torch.ones(K, 1, device=dev)), 1)[:, None, :], Mv)[:, 0, :3].contiguous()
     pts = res.clone()
     cam4 = torch.cat((X_cam_world.reshape(K, 3), torch.ones(K, 1, device=dev)), 1).contiguous()
-    inv_diag = 1.0 / prediction_box_diag
-    for k in range(K):                                                                    # one small launch each, no sync
-        ops.transform_points_(pts[k], Mv[k], center[k], inv_diag)                         # :1647-1650
-        ops.transform_points_(cam4[k:k + 1], Mv[k], center[k], inv_diag)                  # :1655-1659
+    inv_diag = torch.full((K,), 1.0 / prediction_box_diag, dtype=torch.float32, device=dev)
+    ops.transform_points_batched_(pts, Mv, center, inv_diag)                               # :1647-1650, all cameras in one launch
+    ops.transform_points_batched_(cam4.view(K, 1, 4), Mv, center, inv_diag)                # :1655-1659
     # ---- ONE SconeVis forward over the K padded clouds (:1664), ONE scorer launch (C = 1 per cloud, :1683), ONE gain launch
     harm = visibility_model(pts, view_harmonics=res_h, lengths=nu)
     gi = inv[..., None]
@@ -109,6 +107,70 @@ def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harm
         return (gains, [vis[k] if n_host[k] > 0 else None for k in range(K)],
                 [world[k] if n_host[k] > 0 else None for k in range(K)])
     return gains
+
+
+class SceneCamera:
+    """What one MACARONS decision reads of the reference's Camera / PyTorch3D objects (which stay outside the kernels):
+    the 40-float record of mcr_points_in_fov (world->view matrix, full projection matrix, NDC bounds, centre, sensor range), the
+    camera centre X_cam [1,3], zfar and the field of view in degrees."""
+
+    def __init__(self, record, X_cam, zfar, fov=60.0):
+        self.record, self.X_cam, self.zfar = record.reshape(40).contiguous(), X_cam.reshape(1, 3).contiguous(), float(zfar)
+        self.fov = torch.tensor([float(fov)])
+
+    @property
+    def M_view(self):
+        return self.record[:16].view(4, 4)
+
+
+def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, depth, depth_mask, neighbor_records, X_neighbors,
+                          device, samples=None, return_signed_distances=False):
+    """One next-best-view decision of the MACARONS loop after the depth map of the current pose is known -- the body of
+    testers/scene.py:391-454 (everything between the depth network and the move to the chosen pose):
+      1. proxy points in the current frustum (Camera.get_points_in_fov :391), registered in the proxy grid (:394-395);
+      2. signed distances to the depth map, view-state OR, supervision occupancy, out-of-field flags (:397-415) -- one fused pass;
+      3. surface features reset (:418); occupancy-probability field over the seen cells (:421-425);
+      4. coverage gain of every valid neighbour pose (:434-450), all cameras in one launch sequence; first strict maximum (:452-454).
+    camera: SceneCamera of the current pose (it is also the prediction camera, fov_camera_0 of :305); depth [H,W] (+ optional
+    leading/trailing singleton dims), depth_mask like depth; neighbor_records [K,40], X_neighbors [K,3].
+    Returns dict(next_idx (device int64: index into the neighbour list), gains [K], fov_mask [P] bool, X_world, view_harmonics,
+    occ_probs).  The scene objects are updated in place like upstream.  Nothing but the occupancy-field pass (cell bookkeeping on
+    the host, as upstream) synchronises with the host."""
+    H, W = params.image_height, params.image_width
+    depth2 = depth.reshape(H, W).contiguous().float()
+    dmask2 = depth_mask.reshape(H, W) if depth_mask is not None else None
+    rec = camera.record.to(device)
+    # 1 ---- proxy points in the current field of view, registered in their grid cells with their index as feature
+    fov_mask = ops.points_in_fov(proxy_scene.proxy_points, rec.view(1, 40))[0]
+    fov_idx = proxy_scene.get_proxy_indices_from_mask(fov_mask)
+    proxy_scene.fill_cells(proxy_scene.proxy_points[fov_mask], features=fov_idx.view(-1, 1).float())
+    # 2 ---- carve with the depth map: signed distance, view states, supervision occupancy, out-of-field, one launch
+    sgn = proxy_scene.update_from_depth(fov_mask, rec, camera.X_cam.to(device), depth2, dmask2, fill=1.1 * camera.zfar,
+                                        tol=params.carving_tolerance, return_signed_distances=return_signed_distances)
+    surface_scene.set_all_features_to_value(value=1.)
+    # 3 ---- occupancy probability field, in the current camera's view space
+    Mv = camera.M_view.to(device)
+    X_world, view_harmonics, occ_probs = compute_scene_occupancy_probability_field(params, macarons, None, surface_scene, proxy_scene,
+                                                                                   device, prediction_camera=Mv)
+    # 4 ---- neighbours
+    K = neighbor_records.shape[0]
+    th = params.distance_factor_th
+    smooth = th == 'smooth'
+    if th is None or smooth:
+        th = sensor_distance_threshold(params, camera, surface_scene.cell_resolution)
+    vis_model = macarons.visibility                 # `macarons` = the SCONE part (Macarons.scone upstream): .occupancy / .visibility
+    diag = torch.linalg.norm(proxy_scene.x_max - proxy_scene.x_min).item()
+    gains = predict_coverage_gain_for_cameras(vis_model, X_world, view_harmonics, occ_probs, neighbor_records.to(device),
+                                              X_neighbors.to(device), Mv.reshape(1, 4, 4).expand(K, -1, -1), diag,
+                                              seq_len=params.seq_len, min_occ=params.min_occ_for_proxy_points, distance_th=float(th),
+                                              samples=samples, smooth=smooth)
+    # `if coverage_gain > max_coverage_gain` from -1: the first strict maximum (a NaN gain never wins upstream; here it would)
+    rec_best = ops.best_record(gains.view(1, K), 0)
+    out = {"next_idx": rec_best[0, 1].to(torch.int64), "max_gain": rec_best[0, 0], "gains": gains, "fov_mask": fov_mask,
+           "X_world": X_world, "view_harmonics": view_harmonics, "occ_probs": occ_probs}
+    if return_signed_distances:
+        out["signed_distances"] = sgn              # [P], 0 outside the frustum
+    return out
 
 
 # ---- scene-side point bookkeeping (SURVEY §8f row 4) -----------------------------------------------------------
@@ -170,14 +232,19 @@ def cell_fill_mask(pts_to_add, cell_pts, resolution, a_offsets=None, b_offsets=N
     return ops.min_dist_segmented(pts_to_add, a_offsets, cell_pts, b_offsets) > resolution
 
 
-def covered_mask(surface_pts, seen_pts, epsilon, a_offsets=None, b_offsets=None):
+def covered_mask(surface_pts, seen_pts, epsilon, a_offsets=None, b_offsets=None, fp32_compare=False):
     """heaviside(epsilon - min cdist, 0) of camera_coverage_gain / scene_coverage (macarons_utils.py:3022-3024,
-    3049-3051): a surface point is covered iff some seen point lies strictly within epsilon (fp64)."""
+    3049-3051): a surface point is covered iff some seen point lies strictly within epsilon.  The nearest distance is fp64;
+    scene_coverage compares it in fp64, camera_coverage_gain rounds it to fp32 first (`.float()`, :3022) and subtracts it from
+    epsilon in fp32 (fp32_compare=True)."""
     dev = surface_pts.device
     if a_offsets is None:
         a_offsets = torch.tensor([0, surface_pts.shape[0]], dtype=torch.int64, device=dev)
         b_offsets = torch.tensor([0, seen_pts.shape[0]], dtype=torch.int64, device=dev)
-    return ops.min_dist_segmented(surface_pts, a_offsets, seen_pts, b_offsets) < epsilon
+    d = ops.min_dist_segmented(surface_pts, a_offsets, seen_pts, b_offsets)
+    if fp32_compare:
+        return (epsilon - d.float()) > 0.
+    return (epsilon - d) > 0.
 
 
 # ---- occupancy field of a scene (SURVEY §8 f4): the per-cell SconeOcc pass of the MACARONS loop ----------------------------------

@@ -140,6 +140,8 @@ class Scene:
         self.proxy_supervision_occ = torch.ones(n, 1, device=dev)
         self.view_states = torch.zeros(n, self.n_view_state_cameras, device=dev)
         self.out_of_field = torch.ones(n, 1, device=dev)
+        self.proxy_n_inside_fov = torch.zeros(n, 1, device=dev)
+        self.proxy_n_behind_depth = torch.zeros(n, 1, device=dev)
 
     def get_proxy_indices_from_mask(self, proxy_mask):
         return torch.arange(0, self.n_proxy_points, device=self.device).view(-1, 1)[proxy_mask]
@@ -148,3 +150,85 @@ class Scene:
         mask = torch.zeros(self.n_proxy_points, device=self.device).bool()
         mask[proxy_indices.view(-1).long()] = True
         return mask
+
+    # ---- proxy-point state updates of one MACARONS step (macarons_utils.py:2817-2912) ----
+    def update_proxy_view_states(self, camera, proxy_mask, signed_distances=None, distance_to_surface=None, X_cam=None):
+        """:2817-2877: OR the bin of the direction towards the camera into the view state of the masked points (only those
+        whose signed distance is below `distance_to_surface`, default 3 x the proxy spacing, when distances are given): the
+        reference's `+=` followed by torch.heaviside(., 0) as ONE in-place launch on the state table."""
+        from .. import ops
+        update_mask = proxy_mask
+        if signed_distances is not None:
+            if distance_to_surface is None:
+                distance_to_surface = 3 * self.distance_between_proxy_points
+            update_mask = torch.zeros_like(proxy_mask).bool()
+            update_mask[proxy_mask] = signed_distances.view(-1) < distance_to_surface
+        if X_cam is None:
+            X_cam = camera.X_cam
+        rows = torch.nonzero(update_mask.view(-1)).view(-1)
+        ops.view_state_update_(self.view_states, rows, self.proxy_points[rows].contiguous(), X_cam.reshape(-1, 3).contiguous(),
+                               self.view_state_n_elev, self.view_state_n_azim)
+
+    def update_proxy_out_of_field(self, fov_proxy_mask):
+        self.out_of_field[fov_proxy_mask] = 0.                                                       # :2879-2886
+
+    def update_proxy_supervision_occ(self, proxy_mask, signed_distances, tol=0.):
+        self.proxy_n_inside_fov[proxy_mask] += 1                                                     # :2908-2912
+        self.proxy_n_behind_depth[proxy_mask] += (signed_distances.view(-1, 1) >= -tol).float()
+        self.proxy_supervision_occ[proxy_mask] = ((self.proxy_n_behind_depth[proxy_mask] / self.proxy_n_inside_fov[proxy_mask])
+                                                  >= self.score_threshold).float()
+
+    def update_from_depth(self, fov_proxy_mask, camera_record, X_cam, depth, depth_mask, fill, tol=0., distance_to_surface=None,
+                          return_signed_distances=False):
+        """The four calls above + Camera.get_signed_distance_to_depth_maps (testers/scene.py:402-418) as one fused pass over the
+        proxy points (ops.proxy_scene_update_): nothing is compacted, nothing returns to the host."""
+        from .. import ops
+        if distance_to_surface is None:
+            distance_to_surface = 3 * self.distance_between_proxy_points
+        return ops.proxy_scene_update_(self.proxy_points, fov_proxy_mask, camera_record, depth, depth_mask, fill, X_cam,
+                                       distance_to_surface, tol, self.score_threshold, self.view_state_n_elev, self.view_state_n_azim,
+                                       self.view_states, self.proxy_n_inside_fov, self.proxy_n_behind_depth, self.proxy_supervision_occ,
+                                       self.out_of_field, return_sgn=return_signed_distances)
+
+    def set_all_features_to_value(self, value):
+        for cell in self.cells.values():                                                             # :2931-2941
+            if self.feature_dim > 0 and len(cell.cell_features) > 0:
+                cell.cell_features = torch.zeros_like(cell.cell_features) + value
+
+    # ---- coverage metrics (macarons_utils.py:2987-3056): one segmented fp64 nearest-distance launch over all cells ----
+    def _csr(self, clouds):
+        off = torch.zeros(len(clouds) + 1, dtype=torch.int64)
+        off[1:] = torch.cumsum(torch.tensor([c.shape[0] for c in clouds], dtype=torch.int64), 0)
+        pts = torch.vstack([torch.zeros(0, 3, device=self.device)] + list(clouds)).contiguous()
+        return pts, off.to(self.device)
+
+    def scene_coverage(self, recovered_scene, surface_epsilon=None):
+        """(:3031-3056) fraction of this scene's points that have a point of `recovered_scene` (same grid, same cell) strictly
+        within epsilon (fp64), and the number of points.  -> (coverage tensor, n_gt_pts)."""
+        epsilon = 2. * self.cell_resolution if surface_epsilon is None else surface_epsilon
+        keys = [k for k, c in self.cells.items() if len(c.cell_pts) > 0]
+        n_gt = sum(len(self.cells[k].cell_pts) for k in keys)
+        both = [k for k in keys if len(recovered_scene.cells[k].cell_pts) > 0]
+        if not both:
+            return torch.zeros((), dtype=torch.float64, device=self.device) / max(n_gt, 1), n_gt
+        A, a_off = self._csr([self.cells[k].cell_pts for k in both])
+        B, b_off = self._csr([recovered_scene.cells[k].cell_pts for k in both])
+        covered = mu.covered_mask(A, B, epsilon, a_off, b_off)
+        return covered.sum().double() / n_gt, n_gt
+
+    def camera_coverage_gain(self, part_pc, surface_epsilon=None, surface_epsilon_factor=None):
+        """(:2987-3029) number of not-yet-covered surface points (cell feature 0) of the cells the partial cloud touches that
+        have a point of the WHOLE in-box partial cloud within epsilon (distance rounded to fp32 before the compare, as
+        upstream's `.float()`)."""
+        epsilon = self.cell_resolution if surface_epsilon is None else surface_epsilon
+        if surface_epsilon_factor is not None:
+            epsilon = epsilon * surface_epsilon_factor
+        inside = self.get_pts_in_bounding_box(part_pc, return_mask=False)
+        cells = [self.cells[_key(c)] for c in self.get_englobing_cells(inside, list=True)]
+        cells = [c for c in cells if len(c.cell_pts) > 0]
+        if not cells or len(inside) == 0:
+            return 0.
+        A, _ = self._csr([c.cell_pts for c in cells])
+        seen = torch.cat([c.cell_features.view(-1) for c in cells])
+        covered = mu.covered_mask(A, inside.contiguous(), epsilon, fp32_compare=True)
+        return (covered.float() * (1. - seen)).sum()

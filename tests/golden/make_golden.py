@@ -562,7 +562,7 @@ def _stub_renderer(H=256, W=456):
     return NS(rasterizer=NS(raster_settings=NS(image_size=(H, W))))
 
 
-def _ref_camera(mu, H=256, W=456):
+def _ref_camera(mu, H=256, W=456):  # noqa: E302
     """A REAL reference Camera (macarons_utils.py:1852): only its renderer is a stub that carries the image size, so the NDC
     tables and bounds (:1929-1938) are the reference's own arithmetic."""
     return mu.Camera(x_min=torch.tensor([-40., -40., -40.]), x_max=torch.tensor([40., 40., 40.]), pose_l=2, pose_w=2, pose_h=2,
@@ -956,7 +956,218 @@ def gen_occ_field():
     save("occ_field", **out)
 
 
-GROUPS = {"occ_field": gen_occ_field, "formats": gen_formats, "e2e_grid": gen_e2e_grid, "fov": gen_fov, "distance": gen_distance, "wrapper": gen_macarons_wrapper, "single_camera": gen_single_camera, "cell": gen_cell, "unproject": gen_unproject, "viewspace": gen_viewspace, "filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
+def _look_at_target(eyes, ats):
+    """World->view rotations / translations of cameras at `eyes` looking at `ats` (up = +Y), pytorch3d's look_at as published."""
+    R, T = [], []
+    for e, a in zip(np.asarray(eyes, np.float32), np.asarray(ats, np.float32)):
+        r, _ = _look_at((e - a)[None])
+        R.append(r[0]); T.append(-(r[0].T @ e))
+    return np.stack(R).astype(np.float32), np.stack(T).astype(np.float32)
+
+
+def _ellipsoid_depth(ndc_x, ndc_y, eye, R, axes, fov_deg=60.0):
+    """View-space depth of the ellipsoid sum((x/axes)^2) = 1 along the ray of every pixel (its NDC coordinates from the
+    reference Camera's own tables), and the hit mask.  R = world->view rotation (columns = camera axes)."""
+    s = 1.0 / np.tan(np.deg2rad(fov_deg) / 2)
+    d_view = np.stack([ndc_x.astype(np.float64) / s, ndc_y.astype(np.float64) / s, np.ones_like(ndc_x, np.float64)], -1)
+    d = d_view @ R.astype(np.float64).T
+    o = np.asarray(eye, np.float64)
+    ax = np.asarray(axes, np.float64)
+    A = ((d / ax) ** 2).sum(-1)
+    B = 2 * ((o / ax) * (d / ax)).sum(-1)
+    C = ((o / ax) ** 2).sum() - 1
+    disc = B * B - 4 * A * C
+    hit = disc > 0
+    tt = (-B - np.sqrt(np.where(hit, disc, 0.0))) / (2 * A)
+    hit &= tt > 0
+    return np.where(hit, tt, -1.0).astype(np.float32), hit
+
+
+def gen_decision():
+    """TWO consecutive next-best-view decisions of the MACARONS loop (testers/scene.py:391-454, everything between the depth
+    network and the move to the next pose) driven on REAL reference Scene / Cell / Camera objects with stand-in FoV cameras and
+    analytic depth maps of the surface (an ellipsoid shell): frustum of the proxy points, proxy-cell registration, signed
+    distances to the depth map (grid_sample), view-state / supervision-occupancy / out-of-field updates, surface feature
+    reset, occupancy-probability field, coverage gain of five neighbour poses (one with an empty frustum), first strict
+    maximum.  The second decision runs on the state the first left behind (view states accumulate, counters grow, stored
+    proxy points are refused by Cell.fill).  World points sit on the 2^-6 grid; proxy points are redrawn until no query has
+    a k / k+1 neighbour tie and no signed distance sits within 2e-3 of a threshold."""
+    import importlib
+    from types import SimpleNamespace as NS
+    mu = importlib.import_module("macarons.utility.macarons_utils")
+    m = _ref_macarons()
+    rng = np.random.default_rng(141)
+    G = 64.0
+    H, W = 64, 114
+    x_min, x_max = torch.tensor([-8., -4., -8.]), torch.tensor([8., 4., 8.])
+    grid = (2, 1, 2)
+    n_proxy = 4000
+    axes = np.array([5.5, 2.8, 5.0])
+    zfar = 500.
+    params = NS(n_harmonics=64, harmonic_degree=8, view_state_n_elev=7, view_state_n_azim=14, k_for_knn=16,
+                prediction_neighborhood_size=3, n_view_state_cameras=98, sensor_range=40., min_occ_for_proxy_points=0.1, seq_len=2048,
+                use_occ_to_sample_proxy_points=True, jz=False, ddp=False, distance_factor_th=17., image_height=H, image_width=W,
+                carving_tolerance=0.05)
+
+    def new_scene(capacity, resolution, feature_dim):
+        return mu.Scene(x_min=x_min, x_max=x_max, grid_l=grid[0], grid_w=grid[1], grid_h=grid[2], cell_capacity=capacity,
+                        cell_resolution=resolution, n_proxy_points=n_proxy, device="cpu", feature_dim=feature_dim)
+    d = rng.standard_normal((2600, 3))
+    surf = np.unique(_grid(d / np.linalg.norm(d, axis=1, keepdims=True) * axes + 0.05 * rng.standard_normal((2600, 3)), G), axis=0)
+    rng.shuffle(surf)
+
+    def draw_proxy(n):
+        q = _grid(rng.uniform(-1, 1, (n, 3)) * [7.9, 3.9, 7.9], G)
+        q[q == 0] = 1.0 / G
+        return q
+    proxy = draw_proxy(n_proxy)
+    # the two poses of the trajectory and, per decision, five neighbour poses (the last one looks away from the scene)
+    eyes = np.array([[13., 5., -11.], [-12., 6., -9.]], np.float32)
+    Rc, Tc = _look_at_target(eyes, np.zeros((2, 3)))
+    Pc = np.broadcast_to(_fov_projection(60.0, 1.0, zfar), (2, 4, 4)).copy()
+    n_eyes = np.array([[[11., 5., -13.], [14., 3., -8.], [13., 8., -11.], [9., 5., -6.], [30., 0., 0.]],
+                       [[-10., 6., -12.], [-14., 4., -6.], [-12., 9., -9.], [-8., 4., -5.], [-30., 0., 0.]]], np.float32)
+    n_ats = np.zeros((2, 5, 3), np.float32)
+    n_ats[0, 4], n_ats[1, 4] = [90., 0., 0.], [-90., 0., 0.]
+    cam = _ref_camera(mu, H, W)
+    depth, dmask = [], []
+    for c in range(2):
+        dd, hh = _ellipsoid_depth(cam.ndc_x_tab.numpy(), cam.ndc_y_tab.numpy(), eyes[c], Rc[c], axes)
+        depth.append(dd); dmask.append(hh)
+    dts = None
+
+    def tie_scan(ps, surface_scene):
+        """Replay compute_scene_occupancy_probability_field's cell loop (and the randperm draws SconeOcc will make) on the
+        current state; returns the proxy indices that have a k / k+1 tie in one of their three clouds.  RNG state untouched."""
+        state = torch.get_rng_state()
+        occ_mask = (ps.proxy_supervision_occ > 0.)[..., 0]
+        fov_mask = (ps.out_of_field < 1.)[..., 0]
+        cells = ps.get_englobing_cells(ps.proxy_points[occ_mask * fov_mask])
+        bad_idx = []
+        for cell in cells:
+            pcw = surface_scene.get_pt_cloud_from_cells(surface_scene.get_neighboring_cells(cell), return_features=False).numpy()
+            _, ind = ps.get_pt_cloud_from_cells(cell, return_features=True)
+            cmask = ps.get_proxy_mask_from_indices(ind) * occ_mask
+            Xw = ps.proxy_points[cmask].numpy()
+            gi = np.nonzero(cmask.numpy())[0]
+            if not (pcw.shape[0] > 64 and len(Xw) > 0):
+                continue
+            M = len(pcw)
+            ds = int(np.power(M / (16 * 8), 1. / 2)) or 2
+            for lo in range(0, len(Xw), 20000):
+                torch.randperm(M)
+                p1 = torch.randperm(M).numpy()[:M // ds]
+                p2 = torch.randperm(M // ds).numpy()[:(M // ds) // ds]
+                pc1 = pcw[p1]; pc2 = pc1[p2]
+                Xc = Xw[lo:lo + 20000]
+                bad = (_boundary_ties(Xc, pcw, 16, G) | _boundary_ties(Xc, pc1, 16, G) | _boundary_ties(Xc, pc2, 16, G))
+                bad_idx += gi[lo:lo + 20000][bad].tolist()
+        torch.set_rng_state(state)
+        return bad_idx
+
+    real_rand = torch.rand
+    for it in range(80):
+        torch.manual_seed(5000)
+        surface_scene = new_scene(500, 0.2, 1)
+        surface_scene.fill_cells(t(surf), features=torch.zeros(len(surf), 1))
+        surf_cells = {k: c.cell_pts.numpy().copy() for k, c in surface_scene.cells.items()}
+        ps = new_scene(100000, 1e-4, 1)
+        ps.initialize_proxy_points()
+        ps.proxy_points = t(proxy)
+        dts = 3 * ps.distance_between_proxy_points
+        out, bad_idx = {}, []
+        for c in range(2):
+            cam.fov_camera = _StandInCameras(t(Rc[c:c + 1]), t(Tc[c:c + 1]), t(Pc[c:c + 1]), squeeze=True)
+            cam.X_cam = t(eyes[c:c + 1])
+            cam.fov_camera_0 = cam.fov_camera                                               # testers/scene.py:305
+            dmap, dm = t(depth[c]).view(1, H, W, 1), torch.from_numpy(dmask[c]).view(1, H, W, 1)
+            torch.manual_seed(5100 + c)
+            # ---- testers/scene.py:391-418
+            fov_pts, fov_mask = cam.get_points_in_fov(ps.proxy_points, return_mask=True, fov_camera=None, fov_range=params.sensor_range)
+            fov_idx = ps.get_proxy_indices_from_mask(fov_mask)
+            ps.fill_cells(fov_pts, features=fov_idx.view(-1, 1))
+            sgn = cam.get_signed_distance_to_depth_maps(pts=fov_pts, depth_maps=dmap, mask=dm, fov_camera=None)
+            ps.update_proxy_view_states(cam, fov_mask, signed_distances=sgn, distance_to_surface=None, X_cam=None)
+            ps.update_proxy_supervision_occ(fov_mask, sgn, tol=params.carving_tolerance)
+            ps.update_proxy_out_of_field(fov_mask)
+            surface_scene.set_all_features_to_value(value=1.)
+            sg = sgn.view(-1).numpy()
+            near = (np.abs(sg - dts) < 2e-3) | (np.abs(sg + params.carving_tolerance) < 2e-3)
+            bad_idx += np.nonzero(fov_mask.numpy())[0][near].tolist()
+            bad_idx += tie_scan(ps, surface_scene)
+            out[f"fov_mask_{c}"] = np.packbits(fov_mask.numpy())
+            out[f"sgn_{c}"] = sg.copy()
+            out[f"view_states_{c}"] = np.packbits(ps.view_states.numpy().astype(np.uint8), axis=-1)
+            out[f"sup_occ_{c}"] = ps.proxy_supervision_occ.numpy()[:, 0].astype(np.uint8)
+            out[f"oof_{c}"] = ps.out_of_field.numpy()[:, 0].astype(np.uint8)
+            out[f"n_inside_{c}"] = ps.proxy_n_inside_fov.numpy()[:, 0].astype(np.uint8)
+            out[f"n_behind_{c}"] = ps.proxy_n_behind_depth.numpy()[:, 0].astype(np.uint8)
+            # ---- :421-425
+            with torch.no_grad():
+                X_world, vh, occ = mu.compute_scene_occupancy_probability_field(params, m, cam, surface_scene, ps, "cpu")
+            out[f"X_world_{c}"], out[f"vh_{c}"], out[f"occ_{c}"] = X_world.numpy(), vh.numpy()[::5].copy(), occ.numpy()
+            out[f"proxy_proba_{c}"] = ps.proxy_proba.numpy().copy()
+            # ---- :434-454 on five neighbour poses
+            Rn, Tn = _look_at_target(n_eyes[c], n_ats[c])
+            Pn = np.broadcast_to(_fov_projection(60.0, 1.0, zfar), (5, 4, 4)).copy()
+            alln = _StandInCameras(t(Rn), t(Tn), t(Pn))
+            out[f"nMview_{c}"], out[f"nMfull_{c}"] = alln.Mv.numpy(), alln.get_full_projection_transform().M.numpy()
+            max_gain, next_idx, gains, us = -1., 0, [], []
+            for k in range(5):
+                fn = _StandInCameras(t(Rn[k:k + 1]), t(Tn[k:k + 1]), t(Pn[k:k + 1]), squeeze=True)
+                drawn = []
+
+                def cap(*a, **kw):
+                    r_ = real_rand(*a, **kw); drawn.append(r_.numpy().copy()); return r_
+                torch.rand = cap
+                try:
+                    with torch.no_grad():
+                        _, _, _, cg = mu.predict_coverage_gain_for_single_camera(
+                            params=params, macarons=m, proxy_scene=ps, surface_scene=surface_scene, X_world=X_world,
+                            proxy_view_harmonics=vh, occ_probs=occ, camera=cam, X_cam_world=t(n_eyes[c, k:k + 1]), fov_camera=fn)
+                finally:
+                    torch.rand = real_rand
+                gains.append(float(cg.view(-1)[0]))
+                us.append(drawn[0].reshape(-1) if drawn else np.zeros(2048, np.float32))
+                if cg.shape[0] > 0 and cg > max_gain:
+                    max_gain, next_idx = cg, k
+            out[f"gains_{c}"], out[f"next_idx_{c}"], out[f"u_{c}"] = np.array(gains, np.float32), np.int64(next_idx), np.stack(us)
+            print(f"  decision {c}: {int(fov_mask.sum())} proxy points in fov, field {len(X_world)} points, gains {np.round(gains, 4)}, next {next_idx}")
+        bad_idx = sorted(set(bad_idx))
+        print(f"  decision golden: pass {it}: {len(bad_idx)} proxy points to redraw")
+        if not bad_idx:
+            break
+        proxy[bad_idx] = draw_proxy(len(bad_idx))
+    else:
+        raise RuntimeError("no tie-free proxy set found")
+    allc = _StandInCameras(t(Rc), t(Tc), t(Pc))
+    out.update(x_min=x_min.numpy(), x_max=x_max.numpy(), grid=np.array(grid), surface=surf, proxy=proxy, eyes=eyes, n_eyes=n_eyes,
+               Mview=allc.Mv.numpy(), Mfull=allc.get_full_projection_transform().M.numpy(),
+               ndc=np.array([cam.min_ndc_x, cam.max_ndc_x, cam.min_ndc_y, cam.max_ndc_y], np.float32), depth=np.stack(depth),
+               dmask=np.packbits(np.stack(dmask)), hw=np.array([H, W]), zfar=np.float32(zfar), dts=np.float64(dts),
+               box_diag=np.float32(torch.linalg.norm(ps.x_max - ps.x_min).item()))
+    for i, (k, v) in enumerate(sorted(surf_cells.items())):
+        out[f"cellkey_{i}"] = np.array(eval(k))
+        out[f"cellpts_{i}"] = v
+    out["n_surface_cells"] = np.int64(len(surf_cells))
+    # coverage metrics on the final state (macarons_utils.py:2987-3056): the surface scene as ground truth, a "recovered" scene
+    # filled with a noisy subset, and the gain a partial cloud would bring
+    rec = new_scene(500, 0.2, 1)
+    part = _grid(surf[:900] + 0.08 * rng.standard_normal((900, 3)), G)
+    torch.manual_seed(5200)
+    rec.fill_cells(t(part), features=torch.zeros(len(part), 1))
+    cov, n_gt = surface_scene.scene_coverage(rec, surface_epsilon=0.25)
+    surface_scene.set_all_features_to_value(value=0.)
+    for k_, c_ in surface_scene.cells.items():                                  # half of the points already covered
+        c_.cell_features[::2] = 1.
+    part2 = _grid(surf[600:1500] + 0.05 * rng.standard_normal((900, 3)), G)
+    cg = surface_scene.camera_coverage_gain(t(part2), surface_epsilon=0.2)
+    out.update(cov_part=part, cov_value=np.float64(cov), cov_n=np.int64(n_gt), cov_part2=part2, cov_gain=np.float64(cg), cov_seed=np.int64(5200))
+    print(f"  coverage {float(cov):.4f} of {n_gt}; camera coverage gain {float(cg)}")
+    save("macarons_decision", **out)
+
+
+GROUPS = {"decision": gen_decision, "occ_field": gen_occ_field, "formats": gen_formats, "e2e_grid": gen_e2e_grid, "fov": gen_fov, "distance": gen_distance, "wrapper": gen_macarons_wrapper, "single_camera": gen_single_camera, "cell": gen_cell, "unproject": gen_unproject, "viewspace": gen_viewspace, "filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

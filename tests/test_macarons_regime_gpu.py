@@ -177,3 +177,95 @@ def test_scene_occupancy_field_matches_reference(dev):
     s2.fill_cells(T(g["surface"], dev))
     for i in range(int(g["n_surface_cells"])):
         assert np.array_equal(s2.cells[str([int(v) for v in g[f"cellkey_{i}"]])].cell_pts.cpu().numpy(), g[f"cellpts_{i}"]), i
+
+
+def _decision_scenes(g, dev):
+    from macarons_amd.utility.scene import Scene
+    n = len(g["proxy"])
+    x_min, x_max, grid = T(g["x_min"], dev), T(g["x_max"], dev), [int(v) for v in g["grid"]]
+    surface = Scene(x_min, x_max, *grid, cell_capacity=500, cell_resolution=0.2, n_proxy_points=n, device=dev, feature_dim=1)
+    torch.manual_seed(5000)
+    surface.fill_cells(T(g["surface"], dev), features=torch.zeros(len(g["surface"]), 1, device=dev))
+    for i in range(int(g["n_surface_cells"])):                 # Scene.fill_cells reproduces the reference's cells (randperm from the seed)
+        assert np.array_equal(surface.cells[str([int(v) for v in g[f"cellkey_{i}"]])].cell_pts.cpu().numpy(), g[f"cellpts_{i}"]), i
+    proxy = Scene(x_min, x_max, *grid, cell_capacity=100000, cell_resolution=1e-4, n_proxy_points=n, device=dev, feature_dim=1)
+    proxy.initialize_proxy_points()
+    proxy.proxy_points = T(g["proxy"], dev)
+    return surface, proxy
+
+
+def test_macarons_decision_matches_reference(dev):
+    """Two consecutive NBV decisions of the MACARONS loop (config 5 minus the depth network; testers/scene.py:391-454) through
+    macarons_utils.macarons_nbv_decision on macarons_amd Scene objects vs the golden the REFERENCE's own tester body produced on
+    its Scene / Cell / Camera objects (make_golden.py: gen_decision): frustum mask, view states (OR-accumulated over the two
+    poses), supervision occupancy, counters and out-of-field flags bit-exact; signed distances 2e-4 (abs, depths up to 550);
+    occupancy field points in identical order, harmonics 1e-5, probabilities 1e-4; the five neighbour gains 1e-4; the chosen
+    neighbour."""
+    from macarons_amd.utility import macarons_utils as mu
+    g = golden("macarons_decision")
+    m = _models(dev)
+    surface, proxy = _decision_scenes(g, dev)
+    H, W = int(g["hw"][0]), int(g["hw"][1])
+    n = len(g["proxy"])
+    params = NS(n_harmonics=64, harmonic_degree=8, view_state_n_elev=7, view_state_n_azim=14, k_for_knn=16,
+                prediction_neighborhood_size=3, n_view_state_cameras=98, sensor_range=40., min_occ_for_proxy_points=0.1, seq_len=2048,
+                distance_factor_th=17., image_height=H, image_width=W, carving_tolerance=0.05)
+    assert abs(3 * proxy.distance_between_proxy_points - float(g["dts"])) < 1e-12
+    dmask = np.unpackbits(g["dmask"])[:2 * H * W].reshape(2, H, W).astype(bool)
+    for c in range(2):
+        cam = mu.SceneCamera(mu.camera_record(g["Mview"][c], g["Mfull"][c], g["ndc"], g["eyes"][c], params.sensor_range).to(dev),
+                             T(g["eyes"][c:c + 1], dev), float(g["zfar"]))
+        nrec = torch.stack([mu.camera_record(g[f"nMview_{c}"][k], g[f"nMfull_{c}"][k], g["ndc"], g["n_eyes"][c, k], params.sensor_range)
+                            for k in range(5)]).to(dev)
+        torch.manual_seed(5100 + c)
+        with torch.no_grad():
+            r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, T(g["depth"][c], dev), T(dmask[c], dev), nrec,
+                                         T(g["n_eyes"][c], dev), dev, samples=T(g[f"u_{c}"], dev), return_signed_distances=True)
+        fov = np.unpackbits(g[f"fov_mask_{c}"])[:n].astype(bool)
+        assert np.array_equal(r["fov_mask"].cpu().numpy(), fov), c
+        assert np.abs(r["signed_distances"].cpu().numpy()[fov] - g[f"sgn_{c}"]).max() < 2e-4, c
+        assert np.array_equal(proxy.view_states.cpu().numpy().astype(np.uint8), np.unpackbits(g[f"view_states_{c}"], axis=-1)[:, :98]), c
+        assert np.array_equal(proxy.proxy_supervision_occ.cpu().numpy()[:, 0].astype(np.uint8), g[f"sup_occ_{c}"]), c
+        assert np.array_equal(proxy.out_of_field.cpu().numpy()[:, 0].astype(np.uint8), g[f"oof_{c}"]), c
+        assert np.array_equal(proxy.proxy_n_inside_fov.cpu().numpy()[:, 0].astype(np.uint8), g[f"n_inside_{c}"]), c
+        assert np.array_equal(proxy.proxy_n_behind_depth.cpu().numpy()[:, 0].astype(np.uint8), g[f"n_behind_{c}"]), c
+        assert np.array_equal(r["X_world"].cpu().numpy(), g[f"X_world_{c}"]), c
+        assert rel_err(r["view_harmonics"].cpu().numpy()[::5], g[f"vh_{c}"]) < 1e-5, c
+        scale = np.abs(g[f"occ_{c}"]).max()
+        assert np.abs(r["occ_probs"].cpu().numpy() - g[f"occ_{c}"]).max() < 1e-4 * scale, c
+        assert np.abs(proxy.proxy_proba.cpu().numpy() - g[f"proxy_proba_{c}"]).max() < 1e-4 * scale, c
+        assert rel_err(r["gains"].cpu().numpy(), g[f"gains_{c}"]) < 1e-4, c
+        assert int(r["next_idx"]) == int(g[f"next_idx_{c}"]), c
+    # the unfused state-update methods (Scene.update_proxy_view_states / _supervision_occ / _out_of_field + the signed-distance
+    # op) give the same state as the fused pass: redo decision 0's update on a fresh scene
+    from macarons_amd import ops
+    _, fresh = _decision_scenes(g, dev)
+    rec = mu.camera_record(g["Mview"][0], g["Mfull"][0], g["ndc"], g["eyes"][0], params.sensor_range).to(dev)
+    fm = ops.points_in_fov(fresh.proxy_points, rec.view(1, 40))[0]
+    sgn = ops.signed_distance_to_depth(fresh.proxy_points[fm].contiguous(), rec, T(g["depth"][0], dev), T(dmask[0], dev), 1.1 * float(g["zfar"]))
+    assert np.abs(sgn.cpu().numpy() - g["sgn_0"]).max() < 2e-4
+    fresh.update_proxy_view_states(NS(X_cam=T(g["eyes"][0:1], dev)), fm, signed_distances=sgn)
+    fresh.update_proxy_supervision_occ(fm, sgn, tol=params.carving_tolerance)
+    fresh.update_proxy_out_of_field(fm)
+    assert np.array_equal(fresh.view_states.cpu().numpy().astype(np.uint8), np.unpackbits(g["view_states_0"], axis=-1)[:, :98])
+    assert np.array_equal(fresh.proxy_supervision_occ.cpu().numpy()[:, 0].astype(np.uint8), g["sup_occ_0"])
+    assert np.array_equal(fresh.out_of_field.cpu().numpy()[:, 0].astype(np.uint8), g["oof_0"])
+
+
+def test_coverage_metrics_match_reference(dev):
+    """Scene.scene_coverage / Scene.camera_coverage_gain (macarons_utils.py:2987-3056: fp64 nearest distance against epsilon, per
+    cell / against the whole in-box partial cloud) vs the values the reference's methods returned on its own Scene objects."""
+    from macarons_amd.utility.scene import Scene
+    g = golden("macarons_decision")
+    surface, _ = _decision_scenes(g, dev)
+    x_min, x_max, grid = T(g["x_min"], dev), T(g["x_max"], dev), [int(v) for v in g["grid"]]
+    rec = Scene(x_min, x_max, *grid, cell_capacity=500, cell_resolution=0.2, n_proxy_points=len(g["proxy"]), device=dev, feature_dim=1)
+    torch.manual_seed(int(g["cov_seed"]))
+    rec.fill_cells(T(g["cov_part"], dev), features=torch.zeros(len(g["cov_part"]), 1, device=dev))
+    cov, n_gt = surface.scene_coverage(rec, surface_epsilon=0.25)
+    assert n_gt == int(g["cov_n"]) and float(cov) == float(g["cov_value"])
+    surface.set_all_features_to_value(0.)
+    for c in surface.cells.values():
+        c.cell_features[::2] = 1.
+    gain = surface.camera_coverage_gain(T(g["cov_part2"], dev), surface_epsilon=0.2)
+    assert float(gain) == float(g["cov_gain"])
