@@ -87,7 +87,8 @@ class Scene:
         self.n_view_state_cameras = view_state_n_elev * view_state_n_azim
         self.score_threshold = score_threshold
         self.proxy_points = self.proxy_proba = self.proxy_supervision_occ = self.view_states = self.out_of_field = None
-        vol = float(self.l * self.w * self.h) / (n_proxy_points / (grid_l * grid_w * grid_h))
+        # the volume per proxy point is an fp32 tensor division upstream (:2670-2674), the cube root a float64 numpy one
+        vol = ((self.l * self.w * self.h) / (n_proxy_points / (grid_l * grid_h * grid_w))).item()
         self.distance_between_proxy_points = 2 * np.power(3 * vol / (4 * np.pi), 1. / 3.)
 
     # ---- cell lookup ----

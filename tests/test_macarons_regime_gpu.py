@@ -198,7 +198,7 @@ def test_macarons_decision_matches_reference(dev):
     """Two consecutive NBV decisions of the MACARONS loop (config 5 minus the depth network; testers/scene.py:391-454) through
     macarons_utils.macarons_nbv_decision on macarons_amd Scene objects vs the golden the REFERENCE's own tester body produced on
     its Scene / Cell / Camera objects (make_golden.py: gen_decision): frustum mask, view states (OR-accumulated over the two
-    poses), supervision occupancy, counters and out-of-field flags bit-exact; signed distances 2e-4 (abs, depths up to 550);
+    poses), supervision occupancy, counters and out-of-field flags bit-exact; signed distances 1e-5 of the 550 fill depth;
     occupancy field points in identical order, harmonics 1e-5, probabilities 1e-4; the five neighbour gains 1e-4; the chosen
     neighbour."""
     from macarons_amd.utility import macarons_utils as mu
@@ -223,7 +223,8 @@ def test_macarons_decision_matches_reference(dev):
                                          T(g["n_eyes"][c], dev), dev, samples=T(g[f"u_{c}"], dev), return_signed_distances=True)
         fov = np.unpackbits(g[f"fov_mask_{c}"])[:n].astype(bool)
         assert np.array_equal(r["fov_mask"].cpu().numpy(), fov), c
-        assert np.abs(r["signed_distances"].cpu().numpy()[fov] - g[f"sgn_{c}"]).max() < 2e-4, c
+        # bilinear weights come from pixel coordinates up to W = 114 (fp32 ulp 8e-6) and blend depths with the 1.1 zfar = 550 fill
+        assert np.abs(r["signed_distances"].cpu().numpy()[fov] - g[f"sgn_{c}"]).max() < 1e-5 * np.abs(g[f"sgn_{c}"]).max(), c
         assert np.array_equal(proxy.view_states.cpu().numpy().astype(np.uint8), np.unpackbits(g[f"view_states_{c}"], axis=-1)[:, :98]), c
         assert np.array_equal(proxy.proxy_supervision_occ.cpu().numpy()[:, 0].astype(np.uint8), g[f"sup_occ_{c}"]), c
         assert np.array_equal(proxy.out_of_field.cpu().numpy()[:, 0].astype(np.uint8), g[f"oof_{c}"]), c
@@ -243,7 +244,7 @@ def test_macarons_decision_matches_reference(dev):
     rec = mu.camera_record(g["Mview"][0], g["Mfull"][0], g["ndc"], g["eyes"][0], params.sensor_range).to(dev)
     fm = ops.points_in_fov(fresh.proxy_points, rec.view(1, 40))[0]
     sgn = ops.signed_distance_to_depth(fresh.proxy_points[fm].contiguous(), rec, T(g["depth"][0], dev), T(dmask[0], dev), 1.1 * float(g["zfar"]))
-    assert np.abs(sgn.cpu().numpy() - g["sgn_0"]).max() < 2e-4
+    assert np.abs(sgn.cpu().numpy() - g["sgn_0"]).max() < 1e-5 * np.abs(g["sgn_0"]).max()
     fresh.update_proxy_view_states(NS(X_cam=T(g["eyes"][0:1], dev)), fm, signed_distances=sgn)
     fresh.update_proxy_supervision_occ(fm, sgn, tol=params.carving_tolerance)
     fresh.update_proxy_out_of_field(fm)
