@@ -67,6 +67,7 @@ def cpu_baseline(pts, harm, cams):
     from oracle import cport
     p, h, c = pts.cpu().numpy(), harm.cpu().numpy(), cams.cpu().numpy()
     N, C_sample = p.shape[1], c.shape[1]
+    cport.set_threads(os.cpu_count() or 1)                # every host core (work items = camera x point chunk: 2600 at the headline size)
     cport.coverage_gain(p[:, :256], h[:, :256], c)        # warm-up / build
     reps, t0 = 0, time.perf_counter()
     while True:                                           # ~10 s of CPU work, at least one full pass
@@ -78,7 +79,7 @@ def cpu_baseline(pts, harm, cams):
     return {"value": reps * C_sample / dt, "unit": "evals/s", "cores": int(nthreads), "kind": "port",
             "sample": f"C port (oracle/csrc/scorer_port.c, OpenMP) of the reference scorer on the same cloud: "
                       f"N={N} points x {C_sample} cameras x {reps} passes, {dt:.2f} s wall; "
-                      f"host has {os.cpu_count()} cores"}, g
+                      f"`cores` = omp_get_num_threads() inside the parallel region; host has {os.cpu_count()} cores"}, g
 
 
 def cpu_baseline_nbv(C):
@@ -105,6 +106,14 @@ def cpu_baseline_nbv(C):
     torch.manual_seed(11)
     perms = [p.numpy() for p in occ.draw_perms(M)]
     times = {}
+    # numpy's BLAS / OpenMP pools: ask for every host core and report what the pools say they run with
+    blas_threads = None
+    try:
+        from threadpoolctl import threadpool_limits, threadpool_info
+        threadpool_limits(limits=os.cpu_count() or 1)
+        blas_threads = {i.get("internal_api", i.get("user_api", "?")): int(i.get("num_threads", 0)) for i in threadpool_info()}
+    except Exception:
+        pass
     for Q in (1500, 6000):
         X = rng.uniform(-.5, .5, (1, Q, 3)).astype(np.float32)
         t0 = time.perf_counter()
@@ -113,9 +122,10 @@ def cpu_baseline_nbv(C):
     per_q = (times[6000] - times[1500]) / 4500.0
     fixed = max(times[1500] - 1500 * per_q, 0.0)
     full = fixed + 100_000 * per_q
-    return {"value": C / times[6000], "unit": "evals/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"numpy restatement of the NBV step (oracle/nbv.py; BLAS threads as numpy picks them, host has "
-                      f"{os.cpu_count()} cores): M=10240 surface points, C={C} cameras, Q_s=6000 of the 100000 proxy points: "
+    cores = max(blas_threads.values()) if blas_threads else int(torch.get_num_threads())
+    return {"value": C / times[6000], "unit": "evals/s", "cores": int(cores), "thread_pools": blas_threads, "kind": "port",
+            "sample": f"numpy restatement of the NBV step (oracle/nbv.py; `cores` = the largest thread pool numpy's BLAS / OpenMP "
+                      f"libraries report after asking for all {os.cpu_count()} host cores): M=10240 surface points, C={C} cameras, Q_s=6000 of the 100000 proxy points: "
                       f"{times[6000]:.2f} s (Q_s=1500: {times[1500]:.2f} s)",
             "sample_step_s": times[6000], "per_query_ms": per_q * 1e3, "fixed_s": fixed,
             "extrapolated_full_step_s": full, "extrapolated_full_evals_per_s": C / full,
@@ -195,11 +205,152 @@ def measure_nbv_step(dev, rank, world, args):
                      "same_gains_as_eager": bool(torch.equal(rg["gains"], r["gains"]))}
         except Exception as e:                               # capture is an optimisation: report, never fail the bench on it
             graph = {"error": repr(e)[:200]}
+    # the same step on the other numerics of the matrix path (1: exact fp32 MFMA, 5: bf16 hi/mid/lo x6, 6: fp16 hi/lo x3 = default)
+    by_variant = None
+    if world == 1:
+        import ctypes
+        from macarons_amd import _lib
+        L = _lib.lib()
+        default_variant = L.mcr_get_local_pct_variant()
+        by_variant = {}
+        for v in (1, 5, 6):
+            L.mcr_set_local_pct_variant(ctypes.c_int(v))
+            tv = []
+            for it in range(3 + 8):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rv = nbv_step(occ, vis, pc, X, X_view, cams, grid, occ_perms=perms, samples=u)
+                int(rv["nbv_idx"])
+                torch.cuda.synchronize()
+                if it >= 3:
+                    tv.append(time.perf_counter() - t0)
+            by_variant[str(v)] = {"p50_ms": float(np.median(tv)) * 1e3, "same_decision_as_default": int(rv["nbv_idx"]) == int(r["nbv_idx"]),
+                                  "max_rel_gain_diff_vs_default": float((rv["gains"] - r["gains"]).abs().max() / r["gains"].abs().max())}
+        L.mcr_set_local_pct_variant(ctypes.c_int(default_variant))
     return {"p50_ms": p50 * 1e3, "p90_ms": float(np.percentile(times, 90)) * 1e3, "evals_per_s": C / p50, "iters": len(times),
-            "hipgraph_replay": graph, "scaling": "strong",
-            "config": {"proxy_points": Q, "surface_points": M, "cams": C, "seq_len": 2048, "dtype": "f32",
+            "hipgraph_replay": graph, "scaling": "strong", "by_variant": by_variant,
+            "config": {"proxy_points": Q, "surface_points": M, "cams": C, "seq_len": 2048,
+                       "dtype": "f32 (matrix products of the local transformers and the head as fp16 hi/lo split, 22-bit significands, "
+                                "fp32 accumulation; everything else fp32); by_variant: 1 = exact fp32 MFMA, 5 = bf16 x6",
                        "parallelism": f"query+camera shard x{world}"},
             "algorithmic_TFLOP": 26.5e6 * Q / 1e12 + 0.0037 + 0.0137, "nbv_idx": int(r["nbv_idx"]), "n_unique": int(r["n_unique"])}
+
+
+def measure_nbv_batch(dev, rank, world, args):
+    """BASELINE config 3: a scene batch of 8 objects x 32 768 proxy points (M = 4096 surface points each) x 200 cameras as ONE
+    launch sequence (nbv.nbv_step_batch); with N >= 2 GPUs the clouds are sharded over the ranks (8 / N each, no data-path
+    collective, one all-gather of the 8-byte records).  p50 latency of the 8 decisions, evals/s = 8 x 200 / p50."""
+    from macarons_amd.nbv import nbv_step_batch, draw_batch, ViewStateGrid
+    occ, vis = build_models(dev)
+    B, M, Q, C = 8, 4096, 32768, args.cams
+    g = torch.Generator(device="cpu").manual_seed(977)
+    d = torch.randn(B, M, 3, generator=g)
+    pc = (d / d.norm(dim=-1, keepdim=True) * torch.tensor([0.35, 0.25, 0.3]) + 0.002 * torch.randn(B, M, 3, generator=g)).to(dev)
+    X = (torch.rand(B, Q, 3, generator=g) - 0.5).to(dev)
+    cams = torch.randn(C, 3, generator=g)
+    cams = (1.5 * cams / cams.norm(dim=1, keepdim=True)).to(dev)
+    X_view = torch.stack([cams[torch.randperm(C, generator=g)[:3]] for _ in range(B)]).contiguous()
+    grid = ViewStateGrid(dev)
+    torch.manual_seed(13)
+    perms, u = draw_batch(occ, B, M, 2048, dev)
+    group = torch.distributed.group.WORLD if torch.distributed.is_initialized() else None
+    times = []
+    for it in range(3 + 15):
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        r = nbv_step_batch(occ, vis, pc, X, X_view, cams, grid, occ_perms=perms, samples=u, group=group)
+        r["nbv_idx"].tolist()                              # the 8 decisions reach the host
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tw = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tw.item())
+        if it >= 3:
+            times.append(dt)
+    p50 = float(np.median(times))
+    return {"p50_ms": p50 * 1e3, "evals_per_s": B * C / p50, "decisions_per_s": B / p50, "iters": len(times), "scaling": "strong",
+            "config": {"workload": "BASELINE config 3: batch of 8 objects x 32768 proxy points (4096 surface points) x 200 cameras",
+                       "clouds": B, "proxy_points": Q, "surface_points": M, "cams": C, "dtype": "f32 (fp16 hi/lo split matrix path)",
+                       "parallelism": f"cloud shard x{world}" if world <= B else f"query+camera shard x{world}"},
+            "nbv_idx": r["nbv_idx"].tolist()}
+
+
+def measure_macarons_step(dev):
+    """BASELINE config 5 minus the depth network: p50 latency of one MACARONS next-best-view decision
+    (macarons_utils.macarons_nbv_decision = testers/scene.py:391-454) on a synthetic scene of liberty's proportions: 3 x 8 x 3
+    grid, 100 000 proxy points, surface = an ellipsoid shell (capacity 1000 points per cell), 256 x 456 analytic depth maps,
+    30 neighbour cameras, seq_len 2048.  The poses cycle through three positions (the state keeps evolving as in a trajectory)."""
+    from types import SimpleNamespace as NS
+    from macarons_amd.networks import Macarons
+    from macarons_amd.utility import macarons_utils as mu
+    from macarons_amd.utility.scene import Scene
+    occ, vis = build_models(dev)
+    m = Macarons(None, occ, vis).to(dev).eval()
+    H, W, zfar, P, K = 256, 456, 500., 100_000, 30
+    rng = np.random.default_rng(55)
+    x_min, x_max = torch.tensor([-21., -40., -21.], device=dev), torch.tensor([21., 40., 21.], device=dev)
+    axes = np.array([9., 30., 9.])
+    surface = Scene(x_min, x_max, 3, 8, 3, cell_capacity=1000, cell_resolution=0.5, n_proxy_points=P, device=dev, feature_dim=1)
+    proxy = Scene(x_min, x_max, 3, 8, 3, cell_capacity=100000, cell_resolution=0.001, n_proxy_points=P, device=dev, feature_dim=1,
+                  score_threshold=0.95)
+    d = rng.standard_normal((60000, 3))
+    surf = torch.from_numpy((d / np.linalg.norm(d, axis=1, keepdims=True) * axes).astype(np.float32)).to(dev)
+    torch.manual_seed(3)
+    surface.fill_cells(surf, features=torch.zeros(len(surf), 1, device=dev))
+    proxy.initialize_proxy_points()
+    params = NS(n_harmonics=64, harmonic_degree=8, view_state_n_elev=7, view_state_n_azim=14, k_for_knn=16,
+                prediction_neighborhood_size=3, n_view_state_cameras=98, sensor_range=70., min_occ_for_proxy_points=0.1, seq_len=2048,
+                distance_factor_th=17., image_height=H, image_width=W, carving_tolerance=10.0)
+    s = 1.0 / np.tan(np.deg2rad(60.0) / 2)
+    Pm = np.array([[s, 0, 0, 0], [0, s, 0, 0], [0, 0, zfar / (zfar - 1), 1], [0, 0, -zfar / (zfar - 1), 0]], np.float32)
+    jj, ii = np.meshgrid(np.arange(W), np.arange(H))
+    ndc_x = W / H - jj / (H - 1) * 2.0                      # the reference Camera's NDC tables (macarons_utils.py:1921-1928)
+    ndc_y = 1.0 - ii / (H - 1) * 2.0
+    ndc = np.array([ndc_x[-1, -1], ndc_x[0, 0], ndc_y[-1, -1], ndc_y[0, 0]], np.float32)
+
+    def look_at(eye, at):
+        z = (at - eye) / np.linalg.norm(at - eye); x = np.cross([0., 1., 0.], z); x /= np.linalg.norm(x); y = np.cross(z, x)
+        R = np.stack([x, y, z], -1)
+        Mv = np.eye(4); Mv[:3, :3] = R; Mv[3, :3] = -(R.T @ eye)
+        return R, Mv.astype(np.float32)
+
+    def pose(eye, at):
+        R, Mv = look_at(np.asarray(eye, float), np.asarray(at, float))
+        dv = np.stack([ndc_x / s, ndc_y / s, np.ones_like(ndc_x)], -1) @ R.T
+        o = np.asarray(eye, float)
+        A = ((dv / axes) ** 2).sum(-1); Bq = 2 * ((o / axes) * (dv / axes)).sum(-1); Cq = ((o / axes) ** 2).sum() - 1
+        disc = Bq * Bq - 4 * A * Cq
+        hit = disc > 0
+        tt = (-Bq - np.sqrt(np.where(hit, disc, 0))) / (2 * A)
+        hit &= tt > 0
+        cam = mu.SceneCamera(mu.camera_record(Mv, Mv @ Pm, ndc, eye, params.sensor_range).to(dev),
+                             torch.tensor([eye], dtype=torch.float32, device=dev), zfar)
+        ne = np.asarray(eye, float) + rng.uniform(-6, 6, (K, 3))
+        recs = torch.stack([mu.camera_record(mv_, mv_ @ Pm, ndc, e_, params.sensor_range)
+                            for e_, mv_ in ((e_, look_at(e_, np.asarray(at, float) + rng.uniform(-4, 4, 3))[1]) for e_ in ne)]).to(dev)
+        return (cam, torch.from_numpy(np.where(hit, tt, -1.0).astype(np.float32)).to(dev), torch.from_numpy(hit).to(dev), recs,
+                torch.from_numpy(ne.astype(np.float32)).to(dev))
+    poses = [pose([34., 10., -30.], [0., 5., 0.]), pose([-36., -8., -26.], [0., -10., 0.]), pose([30., 25., 32.], [0., 20., 0.])]
+    times, info = [], None
+    for it in range(2 + 9):
+        cam, depth, dmask, recs, ne = poses[it % 3]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, depth, dmask, recs, ne, dev)
+        nxt = int(r["next_idx"])
+        torch.cuda.synchronize()
+        if it >= 2:
+            times.append(time.perf_counter() - t0)
+        info = {"field_points": int(r["X_world"].shape[0]), "proxy_in_fov": int(r["fov_mask"].sum()), "next_idx": nxt}
+    p50 = float(np.median(times))
+    return {"p50_ms": p50 * 1e3, "evals_per_s": K / p50, "iters": len(times), "last": info,
+            "config": {"workload": "MACARONS decision (BASELINE config 5 minus the depth network): 100000 proxy points, 3x8x3 grid, "
+                                   "30 neighbour cameras, 256x456 depth map, seq_len 2048", "cams": K, "proxy_points": P,
+                       "note": "the per-cell occupancy pass keeps upstream's host-side cell loop"}}
 
 
 def measure_local_pct(dev):
@@ -386,7 +537,14 @@ def main():
 
     # ---- (B) the NBV step, sharded over the ranks ----------------------------------------------------------------------------
     nbv = measure_nbv_step(dev, rank, world, args) if not args.no_nbv else None
+    nbv_batch = measure_nbv_batch(dev, rank, world, args) if not args.no_nbv else None
     lp = measure_local_pct(dev) if (rank == 0 and not args.no_nbv) else None
+    mac = None
+    if rank == 0 and not args.no_nbv:
+        try:
+            mac = measure_macarons_step(dev)
+        except Exception as e:                              # an extra leg: reported, never fatal for the contract line
+            mac = {"error": repr(e)[:300]}
     if dist is not None:
         dist.barrier()
 
@@ -426,6 +584,10 @@ def main():
         }
         if nbv is not None:
             res["nbv_step"] = nbv
+        if nbv_batch is not None:
+            res["nbv_batch"] = nbv_batch
+        if mac is not None:
+            res["macarons_step"] = mac
         if lp is not None:
             res["roofline_nbv_dominant"] = lp
         if not args.no_cpu_baseline and world == 1:

@@ -32,6 +32,11 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def set_threads(n):
+    """OpenMP threads of the following calls (0: OpenMP's default)."""
+    lib().scorer_port_set_threads(ctypes.c_int(int(n)))
+
+
 def coverage_gain(pts, harmonics, cams, use_sigmoid=True):
     """C port of SconeVis.compute_coverage_gain. Returns (gains [B,C], n_threads)."""
     pts, harmonics, cams = _f(pts), _f(harmonics), _f(cams)

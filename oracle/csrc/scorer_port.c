@@ -14,6 +14,7 @@
 #include <stddef.h>
 #ifdef _OPENMP
 #include <omp.h>
+#include <stdlib.h>
 #endif
 
 #define LMAX 8
@@ -72,29 +73,51 @@ static inline float pair_value(float dx, float dy, float dz, const float* h, int
     return use_sigmoid ? 1.f / (1.f + expf(-z)) : (z > 0.f ? z : 0.f);
 }
 
-/* gains[B,C];  returns number of threads used */
+/* Thread count of the next calls (0 = leave OpenMP's default).  The benchmark asks for every host core. */
+static int g_threads = 0;
+void scorer_port_set_threads(int n) { g_threads = n; }
+
+/* gains[B,C];  returns the number of threads the parallel region actually ran with.
+ * Work items = (cloud-camera pair, chunk of CHUNK points): 200 cameras alone would leave most of a 256-core host idle.  Every
+ * chunk keeps the blocked fp32 sums (1024 points, like torch.sum) in a double; a pair's chunks are added in order. */
+#define CHUNK 8192
 int scorer_port_coverage_gain(const float* pts, int pts_dim, const float* harm, const float* cams, float* gains,
                               int64_t B, int64_t N, int64_t C, int use_sigmoid) {
     init_tables();
     int nthreads = 1;
+    const int64_t BC = B * C, NCH = (N + CHUNK - 1) / CHUNK;
+    double* part = (double*)malloc((size_t)(BC * NCH) * sizeof(double));
+    if (!part) return -1;
 #ifdef _OPENMP
-    nthreads = omp_get_max_threads();
+    if (g_threads > 0) omp_set_num_threads(g_threads);
 #endif
-    const int64_t BC = B * C;
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int64_t bc = 0; bc < BC; ++bc) {
-        const int64_t b = bc / C;
-        const float* cam = cams + bc * 3;
-        double acc = 0.0;
-        float accf = 0.f;
-        for (int64_t n = 0; n < N; ++n) {
-            const float* p = pts + (b * N + n) * pts_dim;
-            accf += pair_value(cam[0] - p[0], cam[1] - p[1], cam[2] - p[2], harm + (b * N + n) * 64, use_sigmoid);
-            if ((n & 1023) == 1023) { acc += accf; accf = 0.f; }   /* blocked fp32 sum (torch.sum is blocked too) */
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+#pragma omp single
+        nthreads = omp_get_num_threads();
+#endif
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t w = 0; w < BC * NCH; ++w) {
+            const int64_t bc = w / NCH, ch = w - bc * NCH, b = bc / C;
+            const float* cam = cams + bc * 3;
+            const int64_t n0 = ch * CHUNK, n1 = n0 + CHUNK < N ? n0 + CHUNK : N;
+            double acc = 0.0;
+            float accf = 0.f;
+            for (int64_t n = n0; n < n1; ++n) {
+                const float* p = pts + (b * N + n) * pts_dim;
+                accf += pair_value(cam[0] - p[0], cam[1] - p[1], cam[2] - p[2], harm + (b * N + n) * 64, use_sigmoid);
+                if ((n & 1023) == 1023) { acc += accf; accf = 0.f; }   /* blocked fp32 sum (torch.sum is blocked too) */
+            }
+            part[w] = acc + accf;
         }
-        acc += accf;
+    }
+    for (int64_t bc = 0; bc < BC; ++bc) {
+        double acc = 0.0;
+        for (int64_t ch = 0; ch < NCH; ++ch) acc += part[bc * NCH + ch];
         gains[bc] = (float)(acc / (double)N);
     }
+    free(part);
     return nthreads;
 }
 
