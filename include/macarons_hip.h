@@ -105,7 +105,14 @@ int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t
  * mcr_scone_occ_forward: SconeOcc.forward (macarons/networks/SconeOcc.py:250-347) given the clouds the reference
  *   would obtain from its torch.randperm draws (:269, :311), which the HOST performs so the RNG stream matches:
  *   pc_global [B,Lg,3]; pc_scale[i] [B,M_scale[i],3] for the 3 neighbourhood scales; x [B,Q,3];
- *   view_harmonics [B,Q,64] -> out [B,Q,1].  pc_scale / M_scale are HOST arrays of 3 entries. */
+ *   view_harmonics [B,Q,64] -> out [B,Q,1].  pc_scale / M_scale are HOST arrays of 3 entries.
+ *   head_planes / head_inv_scales (optional, HOST arrays of 4; variant 6 only): the fp16 hi/lo planes of the four large head
+ *   matrices -- x_embedding.linear2 [256,128], x_embedding.linear3 [512,256], linear1[:, 512:1856] [512,1344], linear2
+ *   [256,512] -- each times a power of two 2^e, laid out [plane][n][K/8][8 fp16], and 2^-e (networks/packing.py:
+ *   pack_head_planes); NULL: the kernel splits the weights itself on every call (fixed 2^8 scale: needs |w| < 255).
+ *   range_flag (optional, DEVICE int, cleared by the caller): set to 1 when an occupancy comes out non-finite -- on the fp16
+ *   split path (variant 6, |activation| < 65504) that is what an out-of-range activation turns into; the host mirror then
+ *   re-runs the call on variant 5 (whole fp32 range). */
 size_t mcr_pc_transformer_workspace_bytes(int64_t S, int64_t L);
 int mcr_pc_transformer_forward(const float* pc, float* features, int64_t S, int64_t L, int feature_dim,
                                const float* const* weights, int n_weights, void* workspace, size_t workspace_bytes,
@@ -117,7 +124,8 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
 size_t mcr_scone_occ_workspace_bytes(int64_t B, int64_t Q, int64_t Lg);
 int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const* pc_scale, const int64_t* M_scale,
                           const float* x, const float* view_harmonics, float* out, int64_t B, int64_t Q,
-                          const float* const* weights, int n_weights, const float* const* local_blobs, void* workspace,
+                          const float* const* weights, int n_weights, const float* const* local_blobs,
+                          const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
                           size_t workspace_bytes, void* stream);
 
 /* Fused per-query local PCTransformer (the FLOP majority of SconeOcc.forward, SconeOcc.py:293-304 + :104-130):

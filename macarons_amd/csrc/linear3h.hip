@@ -36,7 +36,8 @@ __global__ void split_weights_kernel(const float* __restrict__ W, long long ldw,
 __global__ __launch_bounds__(256, 3) void linear3h_kernel(const float* __restrict__ X, long long ldx, const uint4* __restrict__ Wp,
                                                          const float* __restrict__ bias, const float* __restrict__ row_bias,
                                                          long long rows_per_group, const float* __restrict__ R, long long ldr,
-                                                         float* __restrict__ Y, long long ldy, long long M, int N, int K, int act) {
+                                                         float* __restrict__ Y, long long ldy, long long M, int N, int K, int act,
+                                                         float wscale_inv) {
     __shared__ __attribute__((aligned(16))) uint4 As[2][LH_BM * 4];
     __shared__ __attribute__((aligned(16))) uint4 Bs[2][LH_BN * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, 3) void linear3h_kernel(const float* __restric
         for (int r = 0; r < 16; ++r) {
             const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m >= M) continue;
-            float y = fmaf(acc[t][r], LH_WSCALE_INV, bn);
+            float y = fmaf(acc[t][r], wscale_inv, bn);
             if (row_bias) y += row_bias[(m / rows_per_group) * N + n];
             if (act == ACT_GELU) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
             if (R) y += R[m * ldr + n];
@@ -129,17 +130,21 @@ bool linear3h_applicable(const float* X, int64_t ldx, const float* W, int64_t ld
 }
 size_t linear3h_planes_bytes(int N, int K) { return ((size_t)2 * N * (K / 8) * sizeof(uint4) + 255) & ~(size_t)255; }
 
-// planes: scratch of linear3h_planes_bytes(N, K) bytes (16-byte aligned) that receives the split weights
+// planes: scratch of linear3h_planes_bytes(N, K) bytes (16-byte aligned) that receives the split weights -- or, with
+// presplit_inv_scale > 0, planes the HOST already built (networks/packing.py: pack_head_planes, cached per parameter version;
+// fp16 hi/lo of W * 2^e with e chosen per matrix like the local-transformer blobs): no split launch, the epilogue multiplies by
+// presplit_inv_scale = 2^-e.
 void launch_linear3h(hipStream_t s, const float* X, int64_t ldx, const float* W, int64_t ldw, void* planes, const float* bias,
                      const float* R, int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int act, const float* row_bias,
-                     int64_t rows_per_group) {
+                     int64_t rows_per_group, float presplit_inv_scale) {
     const int K8 = K / 8;
     uint4* Wp = reinterpret_cast<uint4*>(planes);
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)cdiv((int64_t)N * K8, 256)), dim3(256), 0, s, W, (long long)ldw, Wp, N, K8);
+    if (!(presplit_inv_scale > 0.f))
+        hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)cdiv((int64_t)N * K8, 256)), dim3(256), 0, s, W, (long long)ldw, Wp, N, K8);
     dim3 grid((unsigned)cdiv(M, LH_BM), (unsigned)cdiv(N, LH_BN));
     hipLaunchKernelGGL(linear3h_kernel, grid, dim3(256), 0, s, X, (long long)ldx, Wp, bias, row_bias,
                        (long long)(rows_per_group > 0 ? rows_per_group : 1), R, (long long)ldr, Y, (long long)ldy, (long long)M, N,
-                       K, act);
+                       K, act, presplit_inv_scale > 0.f ? presplit_inv_scale : LH_WSCALE_INV);
 }
 
 }  // namespace mcr

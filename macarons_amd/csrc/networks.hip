@@ -95,6 +95,17 @@ static void run_pct(hipStream_t s, const PctW& w, const float* pc, float* feat, 
     launch_pool_max_avg(s, ff, half, feat, ld_feat, S, L, half);                             // :124-126
 }
 
+// *flag |= 1 if any of x[0..n) is inf / NaN (the flag is the caller's: cleared by the caller, OR'ed here)
+__global__ void nonfinite_flag_kernel(const float* __restrict__ x, long long n, int* __restrict__ flag) {
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        bad |= !(fabsf(x[i]) <= 3.4028234663852886e38f);
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+static void launch_nonfinite_flag(hipStream_t s, const float* x, int64_t n, int* flag) {
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 1024)), dim3(256), 0, s, x, (long long)n, flag);
+}
+
 }  // namespace mcr
 
 using namespace mcr;
@@ -312,9 +323,11 @@ static OccSide* occ_side() {
 
 int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const* pc_scale, const int64_t* M_scale,
                           const float* x, const float* view_harmonics, float* out, int64_t B, int64_t Q,
-                          const float* const* weights, int n_weights, const float* const* local_blobs, void* workspace,
+                          const float* const* weights, int n_weights, const float* const* local_blobs,
+                          const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
                           size_t workspace_bytes, void* stream) {
     MCR_REQUIRE(pc_global && pc_scale && M_scale && x && view_harmonics && out && weights, "mcr_scone_occ_forward: null pointer");
+    MCR_REQUIRE(!head_planes || head_inv_scales, "mcr_scone_occ_forward: head_planes need head_inv_scales");
     MCR_REQUIRE(n_weights == OCC_NW, "mcr_scone_occ_forward: expected %d weight pointers, got %d", OCC_NW, n_weights);
     MCR_REQUIRE(B > 0 && Q > 0 && Lg > 0 && B <= 65535, "mcr_scone_occ_forward: bad problem size");
     MCR_REQUIRE(workspace && workspace_bytes >= mcr_scone_occ_workspace_bytes(B, Q, Lg), "mcr_scone_occ_forward: workspace too small");
@@ -392,11 +405,15 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     // multi-GPU step, chunks, scene batches and the single call agree bit for bit).
     const int variant = g_local_pct_variant;
     const int64_t ANY_M = (int64_t)1 << 40;
-    auto big_linear = [&](const float* X_, int64_t ldx, const float* W_, int64_t ldw, const float* b_, float* Y_, int64_t ldy, int64_t M_,
-                          int N_, int K_, const float* rb, int64_t rpg) {
-        if (variant == 6 && linear3h_applicable(X_, ldx, W_, ldw, ANY_M, N_, K_))
-            launch_linear3h(s, X_, ldx, W_, ldw, wplanes, b_, nullptr, 0, Y_, ldy, M_, N_, K_, ACT_GELU, rb, rpg);
-        else if (variant != 1 && linear3_applicable(X_, ldx, W_, ldw, ANY_M, N_, K_))
+    // which: 0 xe2, 1 xe3, 2 lin1 (columns 512..1855), 3 lin2 -- the order of the host's pre-split planes (variant 6)
+    auto big_linear = [&](int which, const float* X_, int64_t ldx, const float* W_, int64_t ldw, const float* b_, float* Y_, int64_t ldy,
+                          int64_t M_, int N_, int K_, const float* rb, int64_t rpg) {
+        if (variant == 6 && linear3h_applicable(X_, ldx, W_, ldw, ANY_M, N_, K_)) {
+            const bool pre = head_planes && head_planes[which] && head_inv_scales[which] > 0.f;
+            launch_linear3h(s, X_, ldx, W_, ldw, pre ? const_cast<void*>(head_planes[which]) : wplanes, b_, nullptr, 0, Y_, ldy, M_, N_, K_,
+                            ACT_GELU, rb, rpg, pre ? head_inv_scales[which] : 0.f);
+        }
+        else if (variant == 5 && linear3_applicable(X_, ldx, W_, ldw, ANY_M, N_, K_))
             launch_linear3(s, X_, ldx, W_, b_, nullptr, 0, Y_, ldy, M_, N_, K_, ACT_GELU, rb, rpg, ldw);
         else
             launch_linear(s, X_, ldx, W_, b_, nullptr, 0, Y_, ldy, M_, N_, K_, ACT_GELU, rb, rpg, ldw, /*route_rows=*/1);
@@ -404,17 +421,21 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     // ---- x embedding 3 -> 128 -> 256 -> 512, GELU each (SconeOcc.py:35-42) ----
     const int64_t T = B * Q;
     launch_linear(s, x, 3, xe1.w, xe1.b, nullptr, 0, h2, 128, T, 128, 3, ACT_GELU, nullptr, 0, 0, 1);
-    big_linear(h2, 128, xe2.w, 128, xe2.b, h1, 256, T, 256, 128, nullptr, 0);
-    big_linear(h1, 256, xe3.w, 256, xe3.b, feat + 768, FEAT, T, 512, 256, nullptr, 0);
+    big_linear(0, h2, 128, xe2.w, 128, xe2.b, h1, 256, T, 256, 128, nullptr, 0);
+    big_linear(1, h1, 256, xe3.w, 256, xe3.b, feat + 768, FEAT, T, 512, 256, nullptr, 0);
     launch_copy2d(s, view_harmonics, 64, feat + 1280, FEAT, T, 64);
     // ---- head MLP 1856 -> 512 -> 256 -> 1, GELU after every layer incl. the last (SconeOcc.py:334-345) ----
     if (side) {
         side_join.joined = true;
         MCR_REQUIRE(hipStreamWaitEvent(s, side->join, 0) == hipSuccess, "mcr_scone_occ_forward: side stream (join)");
     }
-    big_linear(feat, FEAT, lin1.w + 512, 1856, lin1.b, h1, 512, T, 512, FEAT, gbias, Q);
-    big_linear(h1, 512, lin2.w, 512, lin2.b, h2, 256, T, 256, 512, nullptr, 0);
+    big_linear(2, feat, FEAT, lin1.w + 512, 1856, lin1.b, h1, 512, T, 512, FEAT, gbias, Q);
+    big_linear(3, h1, 512, lin2.w, 512, lin2.b, h2, 256, T, 256, 512, nullptr, 0);
     launch_linear(s, h2, 256, lin3.w, lin3.b, nullptr, 0, out, 1, T, 1, 256, ACT_GELU, nullptr, 0, 0, 1);
+    // range guard of the fp16 split path: an activation beyond the fp16 range (|x| >= 65520) becomes inf in its high plane and
+    // reaches the output as a non-finite occupancy (inf - inf in the accumulators, NaN through LayerNorm / soft-max / the mean
+    // pooling); the caller re-runs on the full-range variant 5 when the flag comes back set
+    if (range_flag) launch_nonfinite_flag(s, out, T, range_flag);
     MCR_LAUNCH_CHECK("mcr_scone_occ_forward");
     return 0;
 }

@@ -32,7 +32,7 @@ bool linear3h_applicable(const float* X, int64_t ldx, const float* W, int64_t ld
 size_t linear3h_planes_bytes(int N, int K);
 void launch_linear3h(hipStream_t s, const float* X, int64_t ldx, const float* W, int64_t ldw, void* planes, const float* bias,
                      const float* R, int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int act, const float* row_bias,
-                     int64_t rows_per_group);
+                     int64_t rows_per_group, float presplit_inv_scale = 0.f);
 
 // Row LayerNorm (eps 1e-5, affine): Y[m, :E] = (X[m, :E] - mean) * rstd * g + b     (Attention.py:274,292)
 void launch_layernorm(hipStream_t s, const float* X, int64_t ldx, const float* g, const float* b, float* Y, int64_t ldy,

@@ -45,6 +45,17 @@ def broadcast(buf, src, group=None):
         dist.broadcast(buf, gsrc, group=group)
 
 
+def all_reduce_max(t, group=None):
+    """MAX all-reduce of a small tensor (the range-guard flag of the sharded step); returns the reduced tensor."""
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        return h
+    t = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
 _bufs = {}
 
 

@@ -25,21 +25,78 @@ class ViewStateGrid:
         self.base_harmonics, self.h_polar, self.h_azim = su.get_all_harmonics_under_degree(degree, n_elev, n_azim, device)
 
 
+def _guarded(impl, scone_occ, range_guard, group, draws):
+    """Run one decision with SconeOcc's range check deferred to the END of the step (the step itself stays free of host
+    synchronisation); if the flag comes back set (an activation left the fp16 range of the default matrix path, SconeOcc.range_guard)
+    the decision is repeated on variant 5 with the SAME hidden draws.  `draws()` pins the draws before the first attempt when
+    the caller did not.  With several ranks the flag is all-reduced first: every rank repeats, or none."""
+    from . import _lib
+    L = _lib.lib()
+    capturing = torch.cuda.is_current_stream_capturing()
+    prev = scone_occ.range_guard
+    guard = range_guard and prev != "off" and L.mcr_get_local_pct_variant() == 6
+    scone_occ.range_guard = "defer" if (guard or prev != "off") else "off"
+    try:
+        scone_occ.clear_range_flag()
+        kw = draws() if (guard and not capturing) else {}
+        out = impl(**kw)
+        flag = scone_occ.range_flag() if L.mcr_get_local_pct_variant() == 6 else None
+        out["range_flag"] = flag
+        if guard and not capturing and flag is not None:
+            world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+            if world > 1:
+                flag = mdist.all_reduce_max(flag, group)
+            if int(flag):                                  # the one read-back, after the last kernel of the decision was queued
+                L.mcr_set_local_pct_variant(5)
+                try:
+                    out = impl(**kw)
+                finally:
+                    L.mcr_set_local_pct_variant(6)
+                out["range_flag"], out["fallback_variant"] = None, 5
+    finally:
+        scone_occ.range_guard = prev
+    return out
+
+
 def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1,
              max_points_per_pass=300000, true_monte_carlo_sampling=True, occ_perms=None, samples=None, group=None,
-             view_proj=None, filter_tol=0.01, return_samples=False):
+             view_proj=None, filter_tol=0.01, return_samples=False, range_guard=True):
+    """One decision; see _nbv_step for the arguments.  range_guard: check once, at the end of the step, whether an activation left
+    the fp16 range of the default matrix path and repeat the decision on the full-range variant 5 if so (dict key
+    `fallback_variant`); False: no read-back at all, the device flag is returned as `range_flag` for the caller to look at."""
+    if X.shape[0] > 1:                              # a scene batch: nbv_step_batch (B independent decisions, SURVEY §8e sharding rule)
+        if view_proj is not None or max_points_per_pass < X.shape[1] * X.shape[0]:
+            raise NotImplementedError("nbv_step: the proxy filter / multi-chunk occupancy pass are single-cloud options")
+        return nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=seq_len, min_occ=min_occ,
+                              true_monte_carlo_sampling=true_monte_carlo_sampling, occ_perms=occ_perms, samples=samples,
+                              group=group, return_samples=return_samples, range_guard=range_guard)
+    fixed = dict(occ_perms=occ_perms, samples=samples)
+
+    def draws():                                    # a repeat must see the first attempt's draws: pin them up front (one chunk)
+        if fixed["occ_perms"] is None and X.shape[1] <= max_points_per_pass and view_proj is None:
+            fixed["occ_perms"] = scone_occ.draw_perms(pc.shape[1])
+        if fixed["samples"] is None:
+            fixed["samples"] = torch.rand(seq_len, 1, device=X.device)
+        return {}
+
+    def impl():
+        return _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len, min_occ, max_points_per_pass,
+                         true_monte_carlo_sampling, fixed["occ_perms"], fixed["samples"], group, view_proj, filter_tol, return_samples)
+    inited = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if inited and torch.distributed.get_world_size(group) > 1:
+        draws = lambda: {}                          # noqa: E731  (sharded: rank 0's draws are broadcast inside the step; a repeat redraws)
+    return _guarded(impl, scone_occ, range_guard, group, draws)
+
+
+def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1,
+              max_points_per_pass=300000, true_monte_carlo_sampling=True, occ_perms=None, samples=None, group=None,
+              view_proj=None, filter_tol=0.01, return_samples=False):
     """pc [1,M,3] surface points, X [1,Q,3] proxy points, X_view [n_view,3] past camera positions, X_cam [C,3]
     candidate cameras (all in the normalised prediction-view space, as the reference feeds its networks).
     Returns dict(gains [C_local or C], nbv_idx (global camera index), max_gain, occ [Q,1], n_unique) -- all device tensors
     (n_unique: int32 [1]); nothing is read back inside the step, so it runs without a single host synchronisation.
     `occ_perms` / `samples` pin the hidden RNG draws (SconeOcc randperms; sampling uniforms).  `view_proj` [n_view,4,4]
     (full-projection matrices of the past views) switches on the tester's proxy-point filter (testers/shapenet.py:117-122)."""
-    if X.shape[0] > 1:                              # a scene batch: nbv_step_batch (B independent decisions, SURVEY §8e sharding rule)
-        if view_proj is not None or max_points_per_pass < X.shape[1] * X.shape[0]:
-            raise NotImplementedError("nbv_step: the proxy filter / multi-chunk occupancy pass are single-cloud options")
-        return nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=seq_len, min_occ=min_occ,
-                              true_monte_carlo_sampling=true_monte_carlo_sampling, occ_perms=occ_perms, samples=samples,
-                              group=group, return_samples=return_samples)
     inited = torch.distributed.is_available() and torch.distributed.is_initialized()
     world = torch.distributed.get_world_size(group) if inited else 1
     rank = torch.distributed.get_rank(group) if world > 1 else 0
@@ -140,7 +197,27 @@ def draw_batch(scone_occ, B, M, seq_len, device):
 
 
 def nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1, true_monte_carlo_sampling=True,
-                   occ_perms=None, samples=None, group=None, return_samples=False):
+                   occ_perms=None, samples=None, group=None, return_samples=False, range_guard=True):
+    """B independent decisions in one launch sequence; see _nbv_step_batch.  range_guard as in nbv_step."""
+    fixed = dict(occ_perms=occ_perms, samples=samples)
+    inited = torch.distributed.is_available() and torch.distributed.is_initialized()
+    world = torch.distributed.get_world_size(group) if inited else 1
+
+    def draws():
+        if world == 1 and (fixed["occ_perms"] is None or fixed["samples"] is None):
+            dp, du = draw_batch(scone_occ, X.shape[0], pc.shape[1], seq_len, X.device)
+            fixed["occ_perms"] = dp if fixed["occ_perms"] is None else fixed["occ_perms"]
+            fixed["samples"] = du if fixed["samples"] is None else fixed["samples"]
+        return {}
+
+    def impl():
+        return _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len, min_occ, true_monte_carlo_sampling,
+                               fixed["occ_perms"], fixed["samples"], group, return_samples)
+    return _guarded(impl, scone_occ, range_guard, group, draws)
+
+
+def _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1, true_monte_carlo_sampling=True,
+                    occ_perms=None, samples=None, group=None, return_samples=False):
     """B independent NBV decisions (a scene batch: BASELINE config 3 = 8 objects x 32k proxy points x 200 cameras) in ONE launch
     sequence.  pc [B,M,3], X [B,Q,3], X_view [B,n_view,3] (every object has its own trajectory) or [n_view,3], X_cam [C,3] or
     [B,C,3].  occ_perms: three int64 tensors [B, n_i] (or 1-D, shared), samples [B, seq_len]; None = draw_batch().  Cloud b's
@@ -257,7 +334,7 @@ class GraphedNbvStep:
     def _run(self):
         i = self._in
         return nbv_step(self.occ, self.vis, i["pc"], i["X"], i["X_view"], i["X_cam"], self.grid, seq_len=self.seq_len,
-                        min_occ=self.min_occ, occ_perms=i["perms"], samples=i["samples"], return_samples=True)
+                        min_occ=self.min_occ, occ_perms=i["perms"], samples=i["samples"], return_samples=True, range_guard=False)
 
     def __call__(self, pc=None, X=None, X_view=None, X_cam=None, occ_perms=None, samples=None):
         i = self._in

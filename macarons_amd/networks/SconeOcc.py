@@ -13,7 +13,7 @@ from torch import nn
 from .. import autograd as A
 from .. import ops, _lib
 from .Attention import Embedding, Encoder, _f32c, _inference_only
-from .packing import BlobCache, TableCache
+from .packing import BlobCache, HeadPlaneCache, TableCache
 
 
 class XEmbedding(nn.Module):
@@ -112,11 +112,30 @@ class SconeOcc(nn.Module):
         self.fused_local = True
         self._blob_caches = [BlobCache() for _ in range(n_scale)]
         self._table_cache = TableCache()
+        self._head_cache = HeadPlaneCache()
+        # Range guard of the default numerics (variant 6: matrix products on fp16 hi/lo planes, valid for |activation| < 65504;
+        # the reference is plain fp32, Attention.py:98-128): the kernels flag a non-finite occupancy -- what an out-of-range
+        # activation turns into -- and the forward is repeated on variant 5 (bf16 hi/mid/lo, the whole fp32 range).
+        #   "sync"  (default) read the flag after every forward (one 4-byte read-back) and repeat at once;
+        #   "defer" leave it in range_flag() for the caller (nbv_step checks it once, at the end of the decision);
+        #   "off"   no check.
+        self.range_guard = "sync"
+        self._range_flag = None
+
+    def range_flag(self):
+        """int32 device tensor [1]: 1 if a forward since clear_range_flag() produced a non-finite occupancy (None before the first
+        guarded forward)."""
+        return self._range_flag
+
+    def clear_range_flag(self):
+        if self._range_flag is not None:
+            self._range_flag.zero_()
 
     def invalidate_weight_caches(self):
         """Drop every derived weight image (pointer table, packed local-transformer blobs, stacked QKV, split head planes): call
         after editing parameters in a way no fingerprint can see (in place through `p.data`, see packing._param_key)."""
         self._table_cache.invalidate()
+        self._head_cache.invalidate()
         for c in self._blob_caches:
             c.invalidate()
         for m in self.modules():
@@ -181,11 +200,21 @@ class SconeOcc(nn.Module):
         scales = [pc.contiguous()]
         for p in perms[1:]:
             scales.append(self._take(scales[-1], p))                                  # :311
-        if self.fused_local:
-            variant = _lib.lib().mcr_get_local_pct_variant()
-            blobs = [c.get(t, variant) for c, t in zip(self._blob_caches, self.local_transformers)]
-        else:
-            blobs = None
+        L = _lib.lib()
+        variant = L.mcr_get_local_pct_variant()
+
+        def run(variant, pc_global, scales, x_, vh_, flag):
+            blobs = [c.get(t, variant) for c, t in zip(self._blob_caches, self.local_transformers)] if self.fused_local else None
+            head = self._head_cache.get(self) if variant == 6 else None
+            return ops.scone_occ_forward(pc_global, scales, x_, vh_, self._table_cache.get(self, self.weight_table), blobs, head, flag)
+
+        flag = None
+        if variant == 6 and self.range_guard != "off":
+            if self._range_flag is None or self._range_flag.device != dev:
+                self._range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            elif self.range_guard == "sync":
+                self._range_flag.zero_()
+            flag = self._range_flag
         if A.needs_grad(self, pc, x, view_harmonics):   # trainers: HIP forward, composite-torch backward (autograd.py)
             pidx = [p.to(dev) for p in perms]
 
@@ -197,7 +226,7 @@ class SconeOcc(nn.Module):
 
             def hip(pc_, x_, vh_):
                 g, sc = clouds(pc_)
-                return ops.scone_occ_forward(g, sc, x_, vh_, self._table_cache.get(self, self.weight_table), blobs)
+                return run(variant, g, sc, x_, vh_, None)
 
             def composite(pc_, x_, vh_):
                 g, sc = clouds(pc_)
@@ -206,5 +235,11 @@ class SconeOcc(nn.Module):
                 return A.scone_occ(self, g, sc, x_, vh_, idx)
             res = A.with_torch_backward(hip, composite, (pc, x, view_harmonics), self)
         else:
-            res = ops.scone_occ_forward(pc_global, scales, x, view_harmonics, self._table_cache.get(self, self.weight_table), blobs)
+            res = run(variant, pc_global, scales, x, view_harmonics, flag)
+            if flag is not None and self.range_guard == "sync" and int(flag):      # out of the fp16 range: the full-range path
+                L.mcr_set_local_pct_variant(5)
+                try:
+                    res = run(5, pc_global, scales, x, view_harmonics, None)
+                finally:
+                    L.mcr_set_local_pct_variant(variant)
         return res.view(n_clouds, n_sample, self.output_dim)

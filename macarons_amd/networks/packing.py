@@ -250,3 +250,43 @@ def _pack_local_pct6(pct):
         raise RuntimeError(f"packed local transformer (v6) has {blob.numel()} floats, kernel expects {expect}")
     return blob
 
+
+
+def pack_head_planes(W):
+    """[N, K] fp32 (K % 8 == 0) -> (planes, inv_scale): fp16 hi / lo planes of W * 2^e in the layout linear3h.hip reads,
+    [plane][n][K/8][8 fp16] (returned as an int32 tensor, 4 words per 8 weights), and 2^-e.  e is chosen per matrix like the
+    local-transformer blobs (_pow2_scale: max |W| lands in [2^13, 2^14)), so neither large nor small weights leave the fp16
+    planes' normal range -- the kernel's own per-call split uses a fixed 2^8 and needs |w| < 255."""
+    with torch.no_grad():
+        W = W.detach().float().contiguous()
+        N, K = W.shape
+        assert K % 8 == 0
+        sc = _pow2_scale(W)
+        Ws = W * sc
+        hi = Ws.to(torch.float16)
+        lo = (Ws - hi.float()).to(torch.float16)
+        planes = torch.stack((hi, lo), 0).contiguous().view(torch.int32)        # [2, N, K/2] int32 = [2][N][K/8][4 words]
+    return planes, 1.0 / sc
+
+
+class HeadPlaneCache:
+    """The pre-split planes of SconeOcc's four large head matrices (x_embedding.linear2 / linear3, linear1[:, 512:], linear2),
+    rebuilt when a parameter changes.  get() -> (tensors kept alive, ctypes void* array[4], ctypes float array[4])."""
+
+    def __init__(self):
+        self._key, self._val, self._c = None, None, {}
+
+    def invalidate(self):
+        invalidate(self._c)
+
+    def get(self, occ):
+        key = _param_key(occ, self._c)
+        if key != self._key:
+            import ctypes
+            g = occ.global_feature_dim
+            mats = [occ.x_embedding.linear2.weight, occ.x_embedding.linear3.weight, occ.linear1.weight[:, g:], occ.linear2.weight]
+            packed = [pack_head_planes(W) for W in mats]
+            self._val = ([p for p, _ in packed], (ctypes.c_void_p * 4)(*[p.data_ptr() for p, _ in packed]),
+                         (ctypes.c_float * 4)(*[inv for _, inv in packed]))
+            self._key = key
+        return self._val

@@ -257,7 +257,9 @@ def local_pct_forward(offsets, blob):
     return out
 
 
-def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_blobs=None):
+def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_blobs=None, head_planes=None, range_flag=None):
+    """head_planes: packing.HeadPlaneCache.get() triple (pre-split fp16 planes of the head matrices, variant 6) or None;
+    range_flag: int32 device tensor [1] the call ORs 1 into when an occupancy comes out non-finite (or None)."""
     pc_global, x, view_harmonics = _req(pc_global, "pc_global"), _req(x, "x"), _req(view_harmonics, "view_harmonics")
     pc_scales = [_req(p, "pc_scale") for p in pc_scales]
     B, Lg, _ = pc_global.shape
@@ -274,7 +276,11 @@ def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_bl
     blobs = (ctypes.c_void_p * 3)(*[_req(b, "local_blob").data_ptr() for b in local_blobs]) if local_blobs else None
     with torch.cuda.device(x.device):
         check(L_.mcr_scone_occ_forward(_p(pc_global), c_i64(Lg), sc_ptrs, sc_m, _p(x), _p(view_harmonics), _p(out), c_i64(B),
-                                       c_i64(Q), tab, c_int(_n_weights(weights)), blobs, _p(ws), c_size(ws.numel()), _stream()),
+                                       c_i64(Q), tab, c_int(_n_weights(weights)), blobs,
+                                       head_planes[1] if head_planes is not None else None,
+                                       head_planes[2] if head_planes is not None else None,
+                                       _p(_req(range_flag, "range_flag", torch.int32)) if range_flag is not None else c_vp(0),
+                                       _p(ws), c_size(ws.numel()), _stream()),
               "mcr_scone_occ_forward")
     return out
 

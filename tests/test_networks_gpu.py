@@ -214,6 +214,56 @@ def test_split_precision_is_exact_split(dev):
         _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(prev))
 
 
+@pytest.mark.parametrize("where", ["local_ff", "head"])
+def test_range_guard_falls_back_to_full_range_variant(dev, where):
+    """The default matrix path (variant 6: fp16 hi/lo planes) needs |activation| < 65504; the reference is plain fp32
+    (Attention.py:98-128).  With weights scaled by 2^16 activations leave that range: variant 6 ALONE returns garbage (non-finite
+    occupancies) and raises the device flag; the guarded forward (range_guard="sync", the default) repeats on variant 5 and matches
+    the fp64 oracle; nbv_step checks the same flag once at the end of the decision."""
+    from macarons_amd.networks import SconeOcc, SconeVis
+    from macarons_amd.nbv import nbv_step, ViewStateGrid
+    m, sd = _mod(SconeOcc, 2, dev)
+    sd = {k: v.copy() for k, v in sd.items()}
+    keys = (["local_transformers.1.encoders.0.ff.linear1.weight", "local_transformers.1.encoders.0.ff.linear1.bias"] if where == "local_ff"
+            else ["linear1.weight", "linear1.bias", "x_embedding.linear2.weight", "x_embedding.linear2.bias"])
+    for k in keys:
+        sd[k] = sd[k] * np.float32(65536.0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    g = golden("scone_occ")
+    tag = "m1024_q300"
+    perms = [torch.from_numpy(g[f"{tag}_perm{i}"].astype(np.int64)) for i in range(3)]
+    pc, x, vh = T(g[f"{tag}_pc"], dev), T(g[f"{tag}_x"], dev), T(g[f"{tag}_vh"], dev)
+    ref = nets.scone_occ_forward(sd, g[f"{tag}_pc"], g[f"{tag}_x"], g[f"{tag}_vh"], [p.numpy() for p in perms], np.float64)
+    with torch.no_grad():
+        m.range_guard = "off"
+        y6 = m(pc, x, vh, perms=perms).cpu().numpy()
+        assert not np.isfinite(y6).all()                                 # variant 6 alone: out of range
+        m.range_guard = "defer"
+        m.clear_range_flag()
+        m(pc, x, vh, perms=perms)
+        assert int(m.range_flag()) == 1                                  # ... and says so
+        m.range_guard = "sync"
+        y = m(pc, x, vh, perms=perms).cpu().numpy()
+    assert np.isfinite(y).all() and rel_err(y, ref) < 1e-4               # guarded: repeated on variant 5
+    # an in-range model leaves the flag clear
+    m2, _ = _mod(SconeOcc, 2, dev)
+    with torch.no_grad():
+        m2.range_guard = "defer"
+        m2(pc, x, vh, perms=perms)
+    assert int(m2.range_flag()) == 0
+    # the whole decision: one deferred check at the end, repeat on variant 5
+    vis, _ = _mod(SconeVis, 1, dev)
+    with torch.no_grad():
+        m.linear3.bias += 0.5
+    gg = golden("e2e_grid_config1")
+    a = (m, vis, T(gg["pc"], dev), T(gg["X"], dev), T(gg["X_view"], dev), T(gg["X_cam"], dev), ViewStateGrid(dev))
+    p2 = [torch.from_numpy(gg[f"perm{i}"].astype(np.int64)) for i in range(3)]
+    r = nbv_step(*a, occ_perms=p2, samples=T(gg["samples"], dev))
+    assert r.get("fallback_variant") == 5 and torch.isfinite(r["occ"]).all() and torch.isfinite(r["gains"]).all()
+    r0 = nbv_step(*a, occ_perms=p2, samples=T(gg["samples"], dev), range_guard=False)
+    assert int(r0["range_flag"]) == 1 and "fallback_variant" not in r0
+
+
 def test_scone_occ_fused_equals_unfused(dev):
     from macarons_amd.networks import SconeOcc
     m, sd = _mod(SconeOcc, 2, dev)
