@@ -726,6 +726,29 @@ def gen_single_camera():
         out[f"vis_{c}"] = vg.numpy()
         out[f"world_{c}"] = pw.numpy()
         if drawn:
+            # the same per-point gains from the reference's modules run in FLOAT64 on the SAME sampled set (the fp32 run's own
+            # asin -> cos -> acos chain is off by up to 6e-4 near the poles): the unique sampled points (SconeVis is
+            # permutation-equivariant, so their order is free), prediction-view normalisation, SconeVis, compute_visibility_gains,
+            # distance factor -- all in double
+            import copy
+            md = copy.deepcopy(m).double()
+            uq, inv = torch.unique(pw[0], dim=0, return_inverse=True)
+            vh_u = torch.zeros(len(uq), 64, dtype=torch.float64)
+            vh_u[inv] = vhs[0].double()
+            Mp = pred.Mv[0].double()
+            tf = lambda p: torch.cat((p, torch.ones(len(p), 1, dtype=torch.float64)), 1) @ Mp
+            ptsd = uq.double().clone()
+            ctr = tf(((ptsd[:, :3].max(0)[0] + ptsd[:, :3].min(0)[0]) / 2.).view(1, 3))[:, :3]
+            diag = torch.linalg.norm(proxy_scene.x_max - proxy_scene.x_min).item()
+            ptsd[:, :3] = (tf(ptsd[:, :3])[:, :3] - ctr) / diag
+            Xc = ((tf(t(eyes[c:c + 1], torch.float64))[:, :3] - ctr) / diag)[None]
+            with torch.no_grad():
+                hd = md(mode='visibility', proxy_points=ptsd[None], view_harmonics=vh_u[None])
+                vg64 = md.compute_visibility_gains(pts=ptsd[inv][None], harmonics=hd[0][inv][None], X_cam=Xc)
+                fac = mu.get_distance_factor_threshold(pw[0, :, :3].double(), t(eyes[c:c + 1], torch.float64), distance_th=17.)
+            out[f"vis64_{c}"] = (vg64 * fac.view(1, 1, -1)).numpy()
+            print(f"    fp64 per-point run: max |fp32 - fp64| = {float((vg.double() - vg64 * fac.view(1, 1, -1)).abs().max()):.2e}")
+        if drawn:
             out[f"u_{c}"] = drawn[0].reshape(-1)
         print(f"  camera {c}: gain {cg.numpy().ravel()}  sampled {pw.shape}")
     # the 'smooth' and None distance-factor branches on camera 0 (same uniforms)

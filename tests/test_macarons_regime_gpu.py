@@ -80,7 +80,10 @@ def test_single_camera_gain_matches_reference(dev):
         ref = float(g[f"gain_{c}"].ravel()[0])
         assert abs(gains[c] - ref) < 1e-4 * ref, (c, gains[c], ref)
         assert np.array_equal(world[c].cpu().numpy(), g[f"world_{c}"][0])
-        assert np.abs(vis[c].cpu().numpy() - g[f"vis_{c}"][0, 0]).max() < 2e-3     # reference fp32 trig conditioning
+        # per-point gains vs the reference's modules run in float64 on the same sampled set (its fp32 run is itself off by up to
+        # 6e-4: asin -> cos -> acos near the poles)
+        assert np.abs(vis[c].cpu().numpy() - g[f"vis64_{c}"][0, 0]).max() < 2e-5
+        assert np.abs(vis[c].cpu().numpy() - g[f"vis_{c}"][0, 0]).max() < 2e-3
     assert gains[3] == 0.0 and float(g["gain_3"].ravel()[0]) == 0.0
     # the two other distance-factor branches (:1686-1698)
     params, fc = NS(image_height=256, image_width=456), NS(fov=torch.tensor([60.0]))
