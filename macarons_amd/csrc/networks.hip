@@ -12,6 +12,9 @@
 #include "nn_kernels.h"
 #include <cstdlib>
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace mcr {
 
@@ -304,13 +307,17 @@ int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, 
 // path produces and is needed only by the first head layer: it runs on a side stream beside the kNN / local-transformer
 // launches (fork / join by events, so a captured graph keeps the structure).  MCR_OCC_OVERLAP=0 puts it back on the caller's stream.
 struct OccSide { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-static OccSide* occ_side() {
+// One side stream + fork / join event pair per (device, CALLER stream): two host streams (or threads) running SconeOcc
+// concurrently never share an event pair; creation is serialised.
+static OccSide* occ_side(hipStream_t caller) {
     static const bool on = []() { const char* e = getenv("MCR_OCC_OVERLAP"); return !(e && e[0] == '0'); }();
     if (!on) return nullptr;
-    static OccSide table[64];
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, OccSide> table;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    OccSide& x = table[dev & 63];
+    std::lock_guard<std::mutex> lock(mu);
+    OccSide& x = table[std::make_pair(dev, caller)];
     if (!x.s) {
         if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
@@ -357,22 +364,31 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     Arena scratch{(char*)workspace + head.off + glob_bytes, workspace_bytes - head.off - glob_bytes, 0};
 
     // ---- global feature (SconeOcc.py:269-277), on the side stream ----
-    OccSide* side = occ_side();
+    OccSide* side = occ_side(s);
     hipStream_t gs = s;
     if (side && hipEventRecord(side->fork, s) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess) gs = side->s;
     else side = nullptr;
+    // every way out of this function joins the side stream again (error returns included: a dangling fork would poison a capture and
+    // let side-stream work outlive the caller's workspace): the guard exists before anything is queued on the side stream, and on an
+    // early return it records the join itself
+    struct SideJoin {
+        OccSide* side; hipStream_t s; bool recorded, joined;
+        ~SideJoin() {
+            if (!side || joined) return;
+            if (!recorded) (void)hipEventRecord(side->join, side->s);
+            (void)hipStreamWaitEvent(s, side->join, 0);
+        }
+    } side_join{side, s, false, false};
     {
         run_pct(gs, wg, pc_global, gfeat, 512, B, (int)Lg, 256, garena);
         MCR_REQUIRE(garena.ok(), "mcr_scone_occ_forward: workspace overflow (global)");
         // its contribution to linear1: gbias[b, n] = sum_k gfeat[b, k] * W1[n, k]  (columns 0..511 of linear1.weight)
         launch_linear(gs, gfeat, 512, lin1.w, nullptr, nullptr, 0, gbias, 512, B, 512, 512, ACT_NONE, nullptr, 0, 1856, 1);
     }
-    // every way out of this function joins the side stream again (error returns included: a dangling fork would poison a capture)
-    struct SideJoin {
-        OccSide* side; hipStream_t s; bool joined;
-        ~SideJoin() { if (side && !joined) (void)hipStreamWaitEvent(s, side->join, 0); }
-    } side_join{side, s, false};
-    if (side) MCR_REQUIRE(hipEventRecord(side->join, side->s) == hipSuccess, "mcr_scone_occ_forward: side stream (record)");
+    if (side) {
+        MCR_REQUIRE(hipEventRecord(side->join, side->s) == hipSuccess, "mcr_scone_occ_forward: side stream (record)");
+        side_join.recorded = true;
+    }
     // ---- local multi-scale neighbourhood features (SconeOcc.py:290-311) ----
     // fused path: one kNN + one LDS-resident transformer launch per (cloud, scale) over ALL queries (nothing but
     // the [Q,16,3] offsets is materialised); layer-by-layer path: chunked over queries to bound its workspace.

@@ -174,11 +174,16 @@ def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, mi
             gains = scone_vis.compute_coverage_gain(proxy_points, harm, X_cam[c0:c1].contiguous().view(1, -1, 3))
         else:                                       # empty camera shard (C < world)
             gains = torch.zeros(1, 0, dtype=torch.float32, device=dev)
+        # no proxy point above min_occ: nothing was sampled (the kernels then score one zero row): the reference fails on the empty
+        # sample (scone_utils.py:1052-1061); here the decision says so on the device: gains NaN, nbv_idx -1
+        empty = n_unique.view(1, 1) < 1
+        gains = torch.where(empty, torch.full_like(gains, float("nan")), gains)
         if sharded:
             max_gain, nbv_idx = mdist.allgather_best(gains, c0, group)
         else:
             best = torch.max(gains, dim=1)
             max_gain, nbv_idx = best.values, best.indices
+        nbv_idx = torch.where(empty.view(-1), torch.full_like(nbv_idx, -1), nbv_idx)
     out = {"gains": gains[0], "cam_range": (c0, c1), "nbv_idx": nbv_idx, "max_gain": max_gain, "occ": occ,
            "n_unique": n_unique}
     if return_samples:                              # the unique sampled proxy points (first n_unique of seq_len rows) and the inverse map [seq_len]
@@ -286,6 +291,7 @@ def _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=20
         cams = X_cam[b0:b1] if X_cam.dim() == 3 else X_cam[None].expand(Bl, -1, -1)
         cams = cams[:, c0:c1].contiguous()
         gains = scone_vis.compute_coverage_gain(pts_s, harm_s, cams) if c1 > c0 else torch.zeros(Bl, 0, dtype=torch.float32, device=dev)
+        gains = torch.where(nu.view(-1, 1) < 1, torch.full_like(gains, float("nan")), gains)      # nothing sampled: NaN gains, index -1
         if by_cloud:
             rec = mdist.allgather_rows(ops.best_record(gains, 0), B, group)
             max_gain, nbv_idx = rec[:, 0].contiguous(), rec[:, 1].to(torch.int64)
@@ -294,6 +300,10 @@ def _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=20
         else:
             rec = ops.best_record(gains, 0)
             max_gain, nbv_idx = rec[:, 0].contiguous(), rec[:, 1].to(torch.int64)
+        if not by_cloud:                              # (cloud-sharded: a rank only knows its own clouds' counts; the NaN max_gain marks the others)
+            nbv_idx = torch.where(nu < 1, torch.full_like(nbv_idx, -1), nbv_idx)
+        else:
+            nbv_idx = torch.where(torch.isnan(max_gain), torch.full_like(nbv_idx, -1), nbv_idx)
     out = {"gains": gains, "cloud_range": (b0, b1), "cam_range": (c0, c1), "max_gain": max_gain, "nbv_idx": nbv_idx,
            "occ": occ.view(Bl, Q, 1), "n_unique": nu}
     if return_samples:

@@ -260,6 +260,21 @@ def test_batch_step_equals_single_cloud_steps(dev, B, M, Q, C):
     assert torch.equal(r3["gains"], r["gains"]) and torch.equal(r3["nbv_idx"], r["nbv_idx"])
 
 
+def test_nothing_to_sample_is_reported_on_the_device(dev):
+    """No proxy point above min_occ: the reference fails on the empty sample (scone_utils.py:1052-1061); the sync-free step
+    answers NaN gains / nbv_idx -1 / n_unique 0 instead of a plausible-looking decision from the padding row."""
+    from macarons_amd.nbv import nbv_step, nbv_step_batch, ViewStateGrid
+    g = golden("e2e_grid_config1")
+    occ, vis, _, _ = _models(dev)
+    grid = ViewStateGrid(dev)
+    perms = [torch.from_numpy(g[f"perm{i}"].astype(np.int64)) for i in range(3)]
+    a = (occ, vis, T(g["pc"], dev), T(g["X"], dev), T(g["X_view"], dev), T(g["X_cam"], dev), grid)
+    r = nbv_step(*a, occ_perms=perms, samples=T(g["samples"], dev), min_occ=10.0)
+    assert int(r["n_unique"]) == 0 and int(r["nbv_idx"]) == -1 and torch.isnan(r["gains"]).all() and torch.isnan(r["max_gain"]).all()
+    rb = nbv_step_batch(occ, vis, a[2], a[3], a[4], a[5], grid, occ_perms=perms, samples=T(g["samples"], dev).view(1, -1), min_occ=10.0)
+    assert int(rb["n_unique"][0]) == 0 and int(rb["nbv_idx"][0]) == -1 and torch.isnan(rb["gains"]).all()
+
+
 def test_graph_captured_step_equals_eager(dev):
     """GraphedNbvStep (the whole decision as one hipGraph replay) returns exactly what the eager sync-free step returns for the same
     hidden draws, on a first scene and after the inputs are replaced."""
