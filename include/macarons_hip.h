@@ -128,6 +128,24 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
                           const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Ragged SconeOcc: J independent SconeOcc.forward calls ("jobs" = one surface cloud + one chunk of queries, all of different
+ * sizes: the per-cell passes of compute_scene_occupancy_probability_field, macarons/utility/macarons_utils.py:1395-1540, which
+ * upstream runs one after the other from a Python loop over the grid cells) in ONE launch sequence.
+ *   pc_global [J,Lg,3]: job j's global down-sample (its first global_len[j] rows; the rest padding), global_len DEVICE int[J];
+ *   pc_scale[s] (HOST array of 3 device pointers): the neighbourhood clouds of scale s of all jobs back to back, job j =
+ *     rows [scale_off[s][j], scale_off[s][j+1]) (scale_off: HOST array of 3 DEVICE int64[J+1]); every job needs >= 16 points per scale;
+ *   x [T,3], view_harmonics [T,64]: the queries of all jobs back to back, sorted by job; row_job DEVICE int[T];
+ *   knn_blocks DEVICE int[n_blocks*4] = (job, first row, rows <= mcr_knn_rows_per_block(), 0) per workgroup of the segmented
+ *     kNN, covering every row exactly once;  out [T].  Needs the fused local-transformer blobs; other arguments as above. */
+int mcr_knn_rows_per_block(void);
+size_t mcr_scone_occ_ragged_workspace_bytes(int64_t J, int64_t T, int64_t Lg);
+int mcr_scone_occ_forward_ragged(const float* pc_global, const int* global_len, int64_t Lg, const float* const* pc_scale,
+                                 const int64_t* const* scale_off, const float* x, const float* view_harmonics, const int* row_job,
+                                 const int* knn_blocks, int64_t n_blocks, float* out, int64_t J, int64_t T,
+                                 const float* const* weights, int n_weights, const float* const* local_blobs,
+                                 const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
 /* Fused per-query local PCTransformer (the FLOP majority of SconeOcc.forward, SconeOcc.py:293-304 + :104-130):
  *   offsets [S,16,3] (kNN neighbours minus the query) -> features[s*ld_features + 0:256] = max(128) || avg(128).
  * `blob`: 16-byte-aligned device image of ONE local transformer's parameters, mcr_local_pct_blob_floats() floats,

@@ -72,7 +72,8 @@ __device__ __forceinline__ float knn_d2(float qx, float qy, float qz, const floa
 template <int K, bool OFFSETS>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict__ X, const float* __restrict__ pc,
                                                         long long* __restrict__ out_idx, float* __restrict__ out_dist,
-                                                        float* __restrict__ out_pts, int Q, int M) {
+                                                        float* __restrict__ out_pts, int Q, int M, const int4* __restrict__ blocks,
+                                                        const long long* __restrict__ pc_off) {
     // 40 KB: [tile 24 KB][queue distances 8 KB][queue indices 8 KB]; the first 32 KB are reused as the merge buffer
     __shared__ __attribute__((aligned(16))) char smem[KNN_TILE * 16 + 2 * KNN_QCAP * KNN_BLOCK * 4];
     float4* s_pc = reinterpret_cast<float4*>(smem);
@@ -83,11 +84,21 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
     const int lane = threadIdx.x & (MCR_WAVE - 1);
     const int wave = threadIdx.x / MCR_WAVE;
     const int qt = wave / KNN_SPLIT, part = wave % KNN_SPLIT;
-    const int q = (blockIdx.x * KNN_QT + qt) * MCR_WAVE + lane;
-    const bool valid = q < Q;
-    const float* xq = X + ((size_t)b * Q + (valid ? q : Q - 1)) * 3;
-    const float qx = xq[0], qy = xq[1], qz = xq[2];
+    // segmented form (blocks != NULL): workgroup i serves queries [blocks[i].y, blocks[i].y + blocks[i].z) (at most 128 rows of X,
+    // all of job blocks[i].x) against that job's own candidate cloud pc[pc_off[job] .. pc_off[job + 1]) -- many clouds of different
+    // sizes in one launch (the per-cell clouds of the occupancy-field pass); neighbour indices are relative to the job's cloud
+    int q_first = blockIdx.x * KNN_QT * MCR_WAVE, q_end = Q;
     const float* pcb = pc + (size_t)b * M * 3;
+    if (blocks) {
+        const int4 bk = blocks[blockIdx.x];
+        q_first = bk.y; q_end = bk.y + bk.z;
+        pcb = pc + (size_t)pc_off[bk.x] * 3;
+        M = (int)(pc_off[bk.x + 1] - pc_off[bk.x]);
+    }
+    const int q = q_first + qt * MCR_WAVE + lane;
+    const bool valid = q < q_end;
+    const float* xq = X + ((size_t)b * Q + (valid ? q : q_end - 1)) * 3;
+    const float qx = xq[0], qy = xq[1], qz = xq[2];
 
     float bd[K];
     int bi[K];
@@ -192,16 +203,29 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
 
 template <int K>
 static void launch_knn(bool offsets, dim3 grid, hipStream_t s, const float* X, const float* pc, long long* idx, float* dist,
-                       float* pts, int Q, int M) {
+                       float* pts, int Q, int M, const int4* blocks = nullptr, const long long* pc_off = nullptr) {
     if (offsets)
-        hipLaunchKernelGGL((knn_kernel<K, true>), grid, dim3(KNN_BLOCK), 0, s, X, pc, idx, dist, pts, Q, M);
+        hipLaunchKernelGGL((knn_kernel<K, true>), grid, dim3(KNN_BLOCK), 0, s, X, pc, idx, dist, pts, Q, M, blocks, pc_off);
     else
-        hipLaunchKernelGGL((knn_kernel<K, false>), grid, dim3(KNN_BLOCK), 0, s, X, pc, idx, dist, pts, Q, M);
+        hipLaunchKernelGGL((knn_kernel<K, false>), grid, dim3(KNN_BLOCK), 0, s, X, pc, idx, dist, pts, Q, M, blocks, pc_off);
 }
 
 }  // namespace mcr
 
 using namespace mcr;
+
+// Segmented k = 16 search with the query offsets (SconeOcc's use): n_blocks workgroups, workgroup i = blocks[i] = (job, first query
+// row, number of rows <= 128, 0); job j's candidates are pc[pc_off[j] .. pc_off[j+1]).  Every job needs >= 16 candidates.
+namespace mcr {
+void launch_knn16_segmented(hipStream_t s, const float* X, const float* pc, const long long* pc_off, const int* blocks,
+                            int64_t n_blocks, int64_t T, float* offsets_out) {
+    if (n_blocks <= 0) return;
+    launch_knn<16>(true, dim3((unsigned)n_blocks, 1), s, X, pc, nullptr, nullptr, offsets_out, (int)T, 0,
+                   reinterpret_cast<const int4*>(blocks), pc_off);
+}
+constexpr int knn_block_rows() { return MCR_WAVE * KNN_QT; }
+int knn_rows_per_block() { return knn_block_rows(); }
+}  // namespace mcr
 
 extern "C" int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B,
                               int64_t Q, int64_t M, int k, int subtract_query, void* stream) {

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256, L3G_NT == 8 ? 2 : (L3G_NT == 4 ? 3 : 4)) void 
                                                         long long ldw, const float* __restrict__ bias,
                                                         const float* __restrict__ row_bias, long long rows_per_group,
                                                         const float* __restrict__ R, long long ldr, float* __restrict__ Y,
-                                                        long long ldy, long long M, int N, int K, int act) {
+                                                        long long ldy, long long M, int N, int K, int act,
+                                                        const int* __restrict__ row_group) {
     __shared__ __attribute__((aligned(16))) uint4 As[3][L3G_BM * 4];
     __shared__ __attribute__((aligned(16))) uint4 Bs[3][L3G_BN * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, L3G_NT == 8 ? 2 : (L3G_NT == 4 ? 3 : 4)) void 
             const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m >= M) continue;
             float y = acc[t][r] + bn;
-            if (row_bias) y += row_bias[(m / rows_per_group) * N + n];
+            if (row_bias) y += row_bias[(row_group ? (long long)row_group[m] : m / rows_per_group) * N + n];
             if (act == ACT_GELU) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
             if (R) y += R[m * ldr + n];
             Y[m * ldy + n] = y;
@@ -132,11 +133,11 @@ bool linear3_applicable(const float* X, int64_t ldx, const float* W, int64_t ldw
 
 void launch_linear3(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R, int64_t ldr,
                     float* Y, int64_t ldy, int64_t M, int N, int K, int act, const float* row_bias, int64_t rows_per_group,
-                    int64_t ldw) {
+                    int64_t ldw, const int* row_group) {
     dim3 grid((unsigned)cdiv(M, L3G_BM), (unsigned)cdiv(N, L3G_BN));
     hipLaunchKernelGGL(linear3_kernel, grid, dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw, bias, row_bias,
                        (long long)(rows_per_group > 0 ? rows_per_group : 1), R, (long long)ldr, Y, (long long)ldy, (long long)M,
-                       N, K, act);
+                       N, K, act, row_group);
 }
 
 }  // namespace mcr

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, 3) void linear3h_kernel(const float* __restric
                                                          const float* __restrict__ bias, const float* __restrict__ row_bias,
                                                          long long rows_per_group, const float* __restrict__ R, long long ldr,
                                                          float* __restrict__ Y, long long ldy, long long M, int N, int K, int act,
-                                                         float wscale_inv) {
+                                                         float wscale_inv, const int* __restrict__ row_group) {
     __shared__ __attribute__((aligned(16))) uint4 As[2][LH_BM * 4];
     __shared__ __attribute__((aligned(16))) uint4 Bs[2][LH_BN * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 3) void linear3h_kernel(const float* __restric
             const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m >= M) continue;
             float y = fmaf(acc[t][r], wscale_inv, bn);
-            if (row_bias) y += row_bias[(m / rows_per_group) * N + n];
+            if (row_bias) y += row_bias[(row_group ? (long long)row_group[m] : m / rows_per_group) * N + n];
             if (act == ACT_GELU) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
             if (R) y += R[m * ldr + n];
             Y[m * ldy + n] = y;
@@ -136,7 +136,7 @@ size_t linear3h_planes_bytes(int N, int K) { return ((size_t)2 * N * (K / 8) * s
 // presplit_inv_scale = 2^-e.
 void launch_linear3h(hipStream_t s, const float* X, int64_t ldx, const float* W, int64_t ldw, void* planes, const float* bias,
                      const float* R, int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int act, const float* row_bias,
-                     int64_t rows_per_group, float presplit_inv_scale) {
+                     int64_t rows_per_group, float presplit_inv_scale, const int* row_group) {
     const int K8 = K / 8;
     uint4* Wp = reinterpret_cast<uint4*>(planes);
     if (!(presplit_inv_scale > 0.f))
@@ -144,7 +144,7 @@ void launch_linear3h(hipStream_t s, const float* X, int64_t ldx, const float* W,
     dim3 grid((unsigned)cdiv(M, LH_BM), (unsigned)cdiv(N, LH_BN));
     hipLaunchKernelGGL(linear3h_kernel, grid, dim3(256), 0, s, X, (long long)ldx, Wp, bias, row_bias,
                        (long long)(rows_per_group > 0 ? rows_per_group : 1), R, (long long)ldr, Y, (long long)ldy, (long long)M, N,
-                       K, act, presplit_inv_scale > 0.f ? presplit_inv_scale : LH_WSCALE_INV);
+                       K, act, presplit_inv_scale > 0.f ? presplit_inv_scale : LH_WSCALE_INV, row_group);
 }
 
 }  // namespace mcr

@@ -81,8 +81,10 @@ static size_t pct_ws_bytes(int64_t T) {
     return al(T * PCT_E) * 2 + al(T * (PCT_E + 64)) + al(T * 2 * PCT_E);
 }
 // feat[s*ld_feat + 0 : feature_dim] ; feature_dim = 2 * half (max || avg)
+// lens (optional, device int per sequence): sequence s consists of its first lens[s] rows (zero-padded batch of clouds of
+// different sizes): attention keys and the pooling stop there
 static void run_pct(hipStream_t s, const PctW& w, const float* pc, float* feat, int64_t ld_feat, int64_t S, int L, int half,
-                    Arena& a) {
+                    Arena& a, const int* lens = nullptr) {
     const int64_t T = S * L;
     float* x = a.f(T * PCT_E);
     float* h = a.f(T * PCT_E);
@@ -92,10 +94,10 @@ static void run_pct(hipStream_t s, const PctW& w, const float* pc, float* feat, 
     launch_linear(s, pc, 3, w.l1.w, w.l1.b, nullptr, 0, h, PCT_INNER, T, PCT_INNER, 3, ACT_GELU, nullptr, 0, 0, L);
     launch_linear(s, h, PCT_INNER, w.l2.w, w.l2.b, nullptr, 0, x, PCT_E, T, PCT_INNER, PCT_INNER, ACT_NONE, nullptr, 0, 0, L);
     launch_copy2d(s, pc, 3, x + PCT_INNER, PCT_E, T, 3);
-    for (int e = 0; e < 2; ++e) run_encoder(s, w.enc[e], x, h, qkv, ff, S, L, PCT_E, 4);
+    for (int e = 0; e < 2; ++e) run_encoder(s, w.enc[e], x, h, qkv, ff, S, L, PCT_E, 4, lens);
     launch_layernorm(s, x, PCT_E, w.ng, w.nb, h, PCT_E, T, PCT_E);                          // SconeOcc.py:119
     launch_linear(s, h, PCT_E, w.lin0.w, w.lin0.b, nullptr, 0, ff, half, T, half, PCT_E, ACT_NONE, nullptr, 0, 0, L);   // :122
-    launch_pool_max_avg(s, ff, half, feat, ld_feat, S, L, half);                             // :124-126
+    launch_pool_max_avg(s, ff, half, feat, ld_feat, S, L, half, lens);                       // :124-126
 }
 
 // *flag |= 1 if any of x[0..n) is inf / NaN (the flag is the caller's: cleared by the caller, OR'ed here)
@@ -453,6 +455,111 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     // pooling); the caller re-runs on the full-range variant 5 when the flag comes back set
     if (range_flag) launch_nonfinite_flag(s, out, T, range_flag);
     MCR_LAUNCH_CHECK("mcr_scone_occ_forward");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ragged SconeOcc: J independent SconeOcc.forward calls ("jobs": one surface cloud + one chunk of queries each, clouds and
+// chunks of different sizes -- the per-cell passes of compute_scene_occupancy_probability_field, macarons_utils.py:1395-1540)
+// as ONE launch sequence.  Job j: global cloud pc_global[j] (Lg rows, the first global_len[j] valid), neighbourhood clouds
+// pc_scale[s][scale_off[s][j] .. scale_off[s][j+1]), queries = the rows r of x with row_job[r] == j (rows sorted by job).
+// knn_blocks: n_blocks x int4 (job, first row, rows <= mcr_knn_rows_per_block(), 0) covering every row once.
+size_t mcr_scone_occ_ragged_workspace_bytes(int64_t J, int64_t T, int64_t Lg) {
+    size_t local = al(T * 16 * 3) + 1024;
+    size_t glob = pct_ws_bytes(J * Lg);
+    size_t head = al(T * 1344) + al(T * 512) + al(T * 256) + al(J * 512) * 2 + linear3h_planes_bytes(512, 1344);
+    return local + glob + head + 8192;
+}
+int mcr_knn_rows_per_block(void) { return knn_rows_per_block(); }
+
+int mcr_scone_occ_forward_ragged(const float* pc_global, const int* global_len, int64_t Lg, const float* const* pc_scale,
+                                 const int64_t* const* scale_off, const float* x, const float* view_harmonics, const int* row_job,
+                                 const int* knn_blocks, int64_t n_blocks, float* out, int64_t J, int64_t T,
+                                 const float* const* weights, int n_weights, const float* const* local_blobs,
+                                 const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    MCR_REQUIRE(pc_global && global_len && pc_scale && scale_off && x && view_harmonics && row_job && knn_blocks && out && weights,
+                "mcr_scone_occ_forward_ragged: null pointer");
+    MCR_REQUIRE(n_weights == OCC_NW, "mcr_scone_occ_forward_ragged: expected %d weight pointers, got %d", OCC_NW, n_weights);
+    MCR_REQUIRE(J > 0 && T > 0 && Lg > 0 && J <= 32767 && n_blocks > 0, "mcr_scone_occ_forward_ragged: bad problem size");
+    MCR_REQUIRE(local_blobs && local_blobs[0] && local_blobs[1] && local_blobs[2],
+                "mcr_scone_occ_forward_ragged: needs the fused local-transformer blobs");
+    MCR_REQUIRE(!head_planes || head_inv_scales, "mcr_scone_occ_forward_ragged: head_planes need head_inv_scales");
+    MCR_REQUIRE(workspace && workspace_bytes >= mcr_scone_occ_ragged_workspace_bytes(J, T, Lg), "mcr_scone_occ_forward_ragged: workspace too small");
+    for (int i = 0; i < n_weights; ++i) MCR_REQUIRE(weights[i], "mcr_scone_occ_forward_ragged: weight %d is null", i);
+    for (int i = 0; i < 3; ++i) MCR_REQUIRE(pc_scale[i] && scale_off[i], "mcr_scone_occ_forward_ragged: scale %d is null", i);
+    hipStream_t s = (hipStream_t)stream;
+    const float* const* p = weights;
+    const PctW wg = read_pct(p);
+    for (int i = 0; i < 3; ++i) (void)read_pct(p);
+    LinW xe1{p[0], p[1]}, xe2{p[2], p[3]}, xe3{p[4], p[5]};
+    p += 6;
+    LinW lin1{p[0], p[1]}, lin2{p[2], p[3]}, lin3{p[4], p[5]};
+
+    Arena head{(char*)workspace, workspace_bytes, 0};
+    constexpr int FEAT = 1344;
+    float* feat = head.f(T * FEAT);
+    float* h1 = head.f(T * 512);
+    float* h2 = head.f(T * 256);
+    float* gfeat = head.f(J * 512);
+    float* gbias = head.f(J * 512);
+    void* wplanes = head.f(linear3h_planes_bytes(512, 1344) / sizeof(float));
+    const size_t glob_bytes = pct_ws_bytes(J * Lg);
+    Arena garena{(char*)workspace + head.off, glob_bytes, 0};
+    Arena scratch{(char*)workspace + head.off + glob_bytes, workspace_bytes - head.off - glob_bytes, 0};
+
+    OccSide* side = occ_side(s);
+    hipStream_t gs = s;
+    if (side && hipEventRecord(side->fork, s) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess) gs = side->s;
+    else side = nullptr;
+    struct SideJoin {
+        OccSide* side; hipStream_t s; bool recorded, joined;
+        ~SideJoin() {
+            if (!side || joined) return;
+            if (!recorded) (void)hipEventRecord(side->join, side->s);
+            (void)hipStreamWaitEvent(s, side->join, 0);
+        }
+    } side_join{side, s, false, false};
+    run_pct(gs, wg, pc_global, gfeat, 512, J, (int)Lg, 256, garena, global_len);
+    MCR_REQUIRE(garena.ok(), "mcr_scone_occ_forward_ragged: workspace overflow (global)");
+    launch_linear(gs, gfeat, 512, lin1.w, nullptr, nullptr, 0, gbias, 512, J, 512, 512, ACT_NONE, nullptr, 0, 1856, 1);
+    if (side) {
+        MCR_REQUIRE(hipEventRecord(side->join, side->s) == hipSuccess, "mcr_scone_occ_forward_ragged: side stream (record)");
+        side_join.recorded = true;
+    }
+    // ---- local features: one segmented kNN + one fused transformer launch per scale over ALL rows ----
+    float* offs = scratch.f(T * 16 * 3);
+    MCR_REQUIRE(scratch.ok(), "mcr_scone_occ_forward_ragged: workspace overflow (kNN)");
+    for (int sc = 0; sc < 3; ++sc) {
+        launch_knn16_segmented(s, x, pc_scale[sc], (const long long*)scale_off[sc], knn_blocks, n_blocks, T, offs);
+        run_local_pct(s, offs, feat + sc * 256, FEAT, T, local_blobs[sc]);
+    }
+    const int variant = g_local_pct_variant;
+    const int64_t ANY_M = (int64_t)1 << 40;
+    auto big_linear = [&](int which, const float* X_, int64_t ldx, const float* W_, int64_t ldw, const float* b_, float* Y_, int64_t ldy,
+                          int64_t M_, int N_, int K_, const float* rb, const int* rg) {
+        if (variant == 6 && linear3h_applicable(X_, ldx, W_, ldw, ANY_M, N_, K_)) {
+            const bool pre = head_planes && head_planes[which] && head_inv_scales[which] > 0.f;
+            launch_linear3h(s, X_, ldx, W_, ldw, pre ? const_cast<void*>(head_planes[which]) : wplanes, b_, nullptr, 0, Y_, ldy, M_, N_, K_,
+                            ACT_GELU, rb, 0, pre ? head_inv_scales[which] : 0.f, rg);
+        } else if (variant == 5 && linear3_applicable(X_, ldx, W_, ldw, ANY_M, N_, K_))
+            launch_linear3(s, X_, ldx, W_, b_, nullptr, 0, Y_, ldy, M_, N_, K_, ACT_GELU, rb, 0, ldw, rg);
+        else
+            launch_linear(s, X_, ldx, W_, b_, nullptr, 0, Y_, ldy, M_, N_, K_, ACT_GELU, rb, 0, ldw, /*route_rows=*/1, rg);
+    };
+    launch_linear(s, x, 3, xe1.w, xe1.b, nullptr, 0, h2, 128, T, 128, 3, ACT_GELU, nullptr, 0, 0, 1);
+    big_linear(0, h2, 128, xe2.w, 128, xe2.b, h1, 256, T, 256, 128, nullptr, nullptr);
+    big_linear(1, h1, 256, xe3.w, 256, xe3.b, feat + 768, FEAT, T, 512, 256, nullptr, nullptr);
+    launch_copy2d(s, view_harmonics, 64, feat + 1280, FEAT, T, 64);
+    if (side) {
+        side_join.joined = true;
+        MCR_REQUIRE(hipStreamWaitEvent(s, side->join, 0) == hipSuccess, "mcr_scone_occ_forward_ragged: side stream (join)");
+    }
+    big_linear(2, feat, FEAT, lin1.w + 512, 1856, lin1.b, h1, 512, T, 512, FEAT, gbias, row_job);
+    big_linear(3, h1, 512, lin2.w, 512, lin2.b, h2, 256, T, 256, 512, nullptr, nullptr);
+    launch_linear(s, h2, 256, lin3.w, lin3.b, nullptr, 0, out, 1, T, 1, 256, ACT_GELU, nullptr, 0, 0, 1);
+    if (range_flag) launch_nonfinite_flag(s, out, T, range_flag);
+    MCR_LAUNCH_CHECK("mcr_scone_occ_forward_ragged");
     return 0;
 }
 

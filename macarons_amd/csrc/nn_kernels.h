@@ -17,14 +17,15 @@ enum Act { ACT_NONE = 0, ACT_GELU = 1 };
 // fp32 tiling accumulates k in the same order.
 void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R,
                    int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int act,
-                   const float* row_bias = nullptr, int64_t rows_per_group = 0, int64_t ldw = 0, int64_t route_rows = 0);
+                   const float* row_bias = nullptr, int64_t rows_per_group = 0, int64_t ldw = 0, int64_t route_rows = 0,
+                   const int* row_group = nullptr);   // row_group (optional, device int per row): the row_bias group of row m instead of m / rows_per_group
 
 // Split-precision (exact bf16 hi/mid/lo, six MFMAs per product) variant for the large GEMMs (linear3.hip); launch_linear
 // routes to it when linear3_applicable().
 bool linear3_applicable(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int N, int K);
 void launch_linear3(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R, int64_t ldr,
                     float* Y, int64_t ldy, int64_t M, int N, int K, int act, const float* row_bias, int64_t rows_per_group,
-                    int64_t ldw);
+                    int64_t ldw, const int* row_group = nullptr);
 
 // Two-term fp16 split variant (linear3h.hip, three MFMAs per product): the weights are split once per call into `planes`
 // (linear3h_planes_bytes(N, K) bytes of scratch).  Range |x| < 65504, |w| < 255.
@@ -32,7 +33,7 @@ bool linear3h_applicable(const float* X, int64_t ldx, const float* W, int64_t ld
 size_t linear3h_planes_bytes(int N, int K);
 void launch_linear3h(hipStream_t s, const float* X, int64_t ldx, const float* W, int64_t ldw, void* planes, const float* bias,
                      const float* R, int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int act, const float* row_bias,
-                     int64_t rows_per_group, float presplit_inv_scale = 0.f);
+                     int64_t rows_per_group, float presplit_inv_scale = 0.f, const int* row_group = nullptr);
 
 // Row LayerNorm (eps 1e-5, affine): Y[m, :E] = (X[m, :E] - mean) * rstd * g + b     (Attention.py:274,292)
 void launch_layernorm(hipStream_t s, const float* X, int64_t ldx, const float* g, const float* b, float* Y, int64_t ldy,
@@ -57,7 +58,8 @@ void launch_colmax_broadcast(hipStream_t s, const float* X, int64_t ldx, float* 
 
 // PCTransformer tail (SconeOcc.py:123-126): per sequence, max over rows then mean over rows:
 //   Y[s*ldy + c] = max_r X[(s*L+r)*ldx + c],  Y[s*ldy + E + c] = mean_r X[...]
-void launch_pool_max_avg(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E);
+void launch_pool_max_avg(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E,
+                         const int* lens = nullptr);   // lens: rows of sequence s that take part (padded batches)
 
 // Strided 2-D copy: Y[m*ldy + c] = X[m*ldx + c], c < E
 void launch_copy2d(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t M, int E);
@@ -67,6 +69,10 @@ void launch_copy2d(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t
 void launch_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);
 void launch_local_pct5(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);   // bf16 hi/mid/lo blob
 void launch_local_pct6(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);   // fp16 hi/lo blob
+// segmented kNN-16 with query offsets (knn.hip): see launch_knn16_segmented there
+void launch_knn16_segmented(hipStream_t s, const float* X, const float* pc, const long long* pc_off, const int* blocks,
+                            int64_t n_blocks, int64_t T, float* offsets_out);
+int knn_rows_per_block();
 int local_pct_blob_floats();
 int local_pct3_blob_floats();
 int local_pct6_blob_floats();

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, NT == 8 ? 2 : 1) void linear_kernel(const floa
                                                      const float* __restrict__ bias, const float* __restrict__ row_bias,
                                                      long long rows_per_group, const float* __restrict__ R, long long ldr,
                                                      float* __restrict__ Y, long long ldy, long long M, int N, int K,
-                                                     int act, int vec_x, int vec_w) {
+                                                     int act, int vec_x, int vec_w, const int* __restrict__ row_group) {
     constexpr int LIN_LD = LIN_BK + 4, F4 = LIN_BK / 4, RA = F4 / 2, RB = NT * F4 / 8;     // float4 per row; per-thread staging counts
     __shared__ __attribute__((aligned(16))) float As[LIN_BM * LIN_LD];
     __shared__ __attribute__((aligned(16))) float Bs[NT * 32 * LIN_LD];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, NT == 8 ? 2 : 1) void linear_kernel(const floa
             const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m >= M) continue;
             float y = acc[t][r] + bn;
-            if (row_bias) y += row_bias[(m / rows_per_group) * N + n];
+            if (row_bias) y += row_bias[(row_group ? (long long)row_group[m] : m / rows_per_group) * N + n];
             if (act == ACT_GELU) y = gelu_erf(y);
             if (R) y += R[m * ldr + n];
             Y[m * ldy + n] = y;
@@ -175,12 +175,12 @@ __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restr
 
 void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R,
                    int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int act, const float* row_bias,
-                   int64_t rows_per_group, int64_t ldw, int64_t route_rows) {
+                   int64_t rows_per_group, int64_t ldw, int64_t route_rows, const int* row_group) {
     if (M <= 0 || N <= 0) return;
     if (ldw == 0) ldw = K;
     static const bool use_split = []() { const char* e = getenv("MCR_LINEAR3"); return !(e && e[0] == '0'); }();   // dev A/B knob
     if (use_split && linear3_applicable(X, ldx, W, ldw, route_rows > 0 ? route_rows : M, N, K)) {
-        launch_linear3(s, X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, act, row_bias, rows_per_group, ldw);
+        launch_linear3(s, X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, act, row_bias, rows_per_group, ldw, row_group);
         return;
     }
     if (K <= 4 && N % 4 == 0 && ldy % 4 == 0 && aligned16(Y) && !row_bias && M * (N / 4) >= 65536) {
@@ -206,17 +206,17 @@ void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, c
         if (nt == 2)
             hipLaunchKernelGGL((linear_kernel<2, 128>), grid, dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw, bias, row_bias,
                                (long long)(rows_per_group > 0 ? rows_per_group : 1), R, (long long)ldr, Y, (long long)ldy, (long long)M,
-                               N, K, act, vec_x, vec_w);
+                               N, K, act, vec_x, vec_w, row_group);
         else
             hipLaunchKernelGGL((linear_kernel<1, 128>), grid, dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw, bias, row_bias,
                                (long long)(rows_per_group > 0 ? rows_per_group : 1), R, (long long)ldr, Y, (long long)ldy, (long long)M,
-                               N, K, act, vec_x, vec_w);
+                               N, K, act, vec_x, vec_w, row_group);
         return;
     }
 #define MCR_LIN(NT)                                                                                                   \
     hipLaunchKernelGGL((linear_kernel<NT>), grid, dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw, bias, row_bias, \
                        (long long)(rows_per_group > 0 ? rows_per_group : 1), R, (long long)ldr, Y, (long long)ldy,       \
-                       (long long)M, N, K, act, vec_x, vec_w)
+                       (long long)M, N, K, act, vec_x, vec_w, row_group)
     switch (nt) {
         case 8: MCR_LIN(8); break;
         case 4: MCR_LIN(4); break;
@@ -748,10 +748,10 @@ void launch_colmax_broadcast(hipStream_t s, const float* X, int64_t ldx, float* 
                        (long long)ldy, L, E, lens);
 }
 
-void launch_pool_max_avg(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E) {
+void launch_pool_max_avg(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E, const int* lens) {
     if (S <= 0) return;
     hipLaunchKernelGGL((pool_kernel<false>), dim3((unsigned)S, (unsigned)cdiv(E, 64)), dim3(64 * POOL_RL), 0, s, X, (long long)ldx, Y,
-                       (long long)ldy, L, E, (const int*)nullptr);
+                       (long long)ldy, L, E, lens);
 }
 
 __global__ void copy2d_kernel(const float* __restrict__ X, long long ldx, float* __restrict__ Y, long long ldy, long long M,

@@ -183,6 +183,78 @@ class SconeOcc(nn.Module):
             return pc[:, p].contiguous()
         return torch.gather(pc, 1, p[..., None].expand(-1, -1, pc.shape[-1])).contiguous()
 
+    def forward_ragged(self, pc, cloud_sizes, x, view_harmonics, query_sizes, perms=None):
+        """J forward() calls of different sizes as ONE launch sequence (extension; the reference calls forward once per grid cell and
+        chunk from a Python loop, macarons_utils.py:1395-1540).  Job j: surface cloud = the next cloud_sizes[j] rows of pc [sum M, 3],
+        queries = the next query_sizes[j] rows of x [T,3] / view_harmonics [T,64] (host lists).  perms: per job the three index
+        tensors draw_perms(cloud_sizes[j]) returns; None = drawn here in job order on the CPU generator, exactly the draws J
+        sequential forward() calls would make.  -> [T,1].  Inference only (no autograd graph)."""
+        if not self._is_default_arch() or not self.fused_local:
+            raise NotImplementedError("forward_ragged implements the default architecture on the fused local-transformer path")
+        dev = x.device
+        J = len(cloud_sizes)
+        if perms is None:
+            perms = [self.draw_perms(int(m)) for m in cloud_sizes]
+        L = _lib.lib()
+        # ---- index arrays of the down-sampled clouds, built on the host from the draws, ONE upload
+        Lg = self.seq_len
+        off0 = np.concatenate(([0], np.cumsum(cloud_sizes))).astype(np.int64)
+        g_idx = np.zeros((J, Lg), np.int64)
+        g_len = np.zeros(J, np.int32)
+        idx1, idx2, off1, off2 = [], [], [0], [0]
+        for j, (p0, p1, p2) in enumerate(perms):
+            p0, p1, p2 = (np.asarray(p0, dtype=np.int64), np.asarray(p1, dtype=np.int64), np.asarray(p2, dtype=np.int64))
+            n0 = min(len(p0), Lg)
+            g_idx[j, :n0] = off0[j] + p0[:n0]
+            g_idx[j, n0:] = off0[j]                                  # padding rows: any valid point (masked by global_len)
+            g_len[j] = n0
+            idx1.append(off0[j] + p1)
+            idx2.append(off1[-1] + p2)                               # scale 2 indexes scale 1's rows (SconeOcc.py:311)
+            off1.append(off1[-1] + len(p1))
+            off2.append(off2[-1] + len(p2))
+        rows = int(L.mcr_knn_rows_per_block())
+        blocks, row_job, r0 = [], np.empty(int(sum(query_sizes)), np.int32), 0
+        for j, q in enumerate(query_sizes):
+            row_job[r0:r0 + q] = j
+            for b0 in range(0, q, rows):
+                blocks.append((j, r0 + b0, min(rows, q - b0), 0))
+            r0 += q
+        ints = np.concatenate([g_idx.reshape(-1), np.concatenate(idx1), np.concatenate(idx2), off0, np.asarray(off1, np.int64),
+                               np.asarray(off2, np.int64), g_len.astype(np.int64), row_job.astype(np.int64),
+                               np.asarray(blocks, np.int64).reshape(-1)])
+        d = torch.from_numpy(ints).to(dev, non_blocking=True)
+        cut, o = [], 0
+        for n in (J * Lg, off1[-1], off2[-1], J + 1, J + 1, J + 1, J, len(row_job), 4 * len(blocks)):
+            cut.append(d[o:o + n]); o += n
+        pc = pc.contiguous()
+        pc_global = pc[cut[0]].view(J, Lg, 3)
+        pc1 = pc[cut[1]]
+        pc2 = pc1[cut[2]]
+        variant = L.mcr_get_local_pct_variant()
+
+        def run(variant, flag):
+            blobs = [c.get(t, variant) for c, t in zip(self._blob_caches, self.local_transformers)]
+            head = self._head_cache.get(self) if variant == 6 else None
+            return ops.scone_occ_forward_ragged(pc_global, cut[6].to(torch.int32), [pc, pc1, pc2], [cut[3], cut[4], cut[5]], x, view_harmonics,
+                                                cut[7].to(torch.int32), cut[8].to(torch.int32).view(-1, 4),
+                                                self._table_cache.get(self, self.weight_table), blobs, head, flag)
+        flag = None
+        if variant == 6 and self.range_guard != "off":
+            if self._range_flag is None or self._range_flag.device != dev:
+                self._range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            elif self.range_guard == "sync":
+                self._range_flag.zero_()
+            flag = self._range_flag
+        with torch.no_grad():
+            res = run(variant, flag)
+            if flag is not None and self.range_guard == "sync" and int(flag):
+                L.mcr_set_local_pct_variant(5)
+                try:
+                    res = run(5, None)
+                finally:
+                    L.mcr_set_local_pct_variant(variant)
+        return res
+
     def forward(self, pc, x, view_harmonics, mask=None, verbose=False, perms=None):
         """pc [n_clouds, M, 3], x [n_clouds, Q, 3], view_harmonics [n_clouds, Q, 64] -> [n_clouds, Q, 1].
         `perms` (optional): the three index tensors draw_perms() would return, to pin the hidden RNG; each either 1-D (shared by

@@ -285,6 +285,39 @@ def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_bl
     return out
 
 
+def scone_occ_forward_ragged(pc_global, global_len, pc_scales, scale_offsets, x, view_harmonics, row_job, knn_blocks, weights,
+                             local_blobs, head_planes=None, range_flag=None):
+    """J SconeOcc jobs of different sizes in one launch sequence (mcr_scone_occ_forward_ragged).  pc_global [J,Lg,3],
+    global_len int32 [J], pc_scales: 3 ragged clouds [sum M_s,3], scale_offsets: 3 int64 [J+1], x [T,3], view_harmonics [T,64],
+    row_job int32 [T], knn_blocks int32 [n_blocks,4] -> out [T,1]."""
+    pc_global, x, view_harmonics = _req(pc_global, "pc_global"), _req(x, "x"), _req(view_harmonics, "view_harmonics")
+    global_len, row_job = _req(global_len, "global_len", torch.int32), _req(row_job, "row_job", torch.int32)
+    knn_blocks = _req(knn_blocks, "knn_blocks", torch.int32)
+    pc_scales = [_req(p, "pc_scale") for p in pc_scales]
+    scale_offsets = [_req(o, "scale_offsets", torch.int64) for o in scale_offsets]
+    J, Lg = pc_global.shape[0], pc_global.shape[1]
+    T = x.shape[0]
+    if x.shape != (T, 3) or view_harmonics.shape != (T, 64) or row_job.numel() != T or global_len.numel() != J:
+        raise ValueError("scone_occ_forward_ragged: x [T,3], view_harmonics [T,64], row_job [T], global_len [J]")
+    if any(o.numel() != J + 1 for o in scale_offsets) or knn_blocks.dim() != 2 or knn_blocks.shape[1] != 4:
+        raise ValueError("scone_occ_forward_ragged: scale_offsets must be [J+1], knn_blocks [n_blocks,4]")
+    L_ = lib()
+    out = torch.empty((T, 1), dtype=torch.float32, device=x.device)
+    ws = _workspace(x.device, L_.mcr_scone_occ_ragged_workspace_bytes(c_i64(J), c_i64(T), c_i64(Lg)))
+    sc_ptrs = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in pc_scales])
+    off_ptrs = (ctypes.c_void_p * 3)(*[o.data_ptr() for o in scale_offsets])
+    blobs = (ctypes.c_void_p * 3)(*[_req(b, "local_blob").data_ptr() for b in local_blobs])
+    with torch.cuda.device(x.device):
+        check(L_.mcr_scone_occ_forward_ragged(_p(pc_global), _p(global_len), c_i64(Lg), sc_ptrs, off_ptrs, _p(x), _p(view_harmonics),
+                                              _p(row_job), _p(knn_blocks), c_i64(knn_blocks.shape[0]), _p(out), c_i64(J), c_i64(T),
+                                              _ptr_table(weights), c_int(_n_weights(weights)), blobs,
+                                              head_planes[1] if head_planes is not None else None,
+                                              head_planes[2] if head_planes is not None else None,
+                                              _p(_req(range_flag, "range_flag", torch.int32)) if range_flag is not None else c_vp(0),
+                                              _p(ws), c_size(ws.numel()), _stream()), "mcr_scone_occ_forward_ragged")
+    return out
+
+
 # ---- glue (SURVEY §8f) -----------------------------------------------------------------------------------
 def view_state(pts, X_view, n_elev, n_azim):
     """[n_clouds, seq_len, n_elev*n_azim] fp32 0/1; replaces compute_view_state (scone_utils.py:799-860).

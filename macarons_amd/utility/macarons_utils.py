@@ -256,68 +256,148 @@ def _world_to_view_matrix(prediction_camera):
     return prediction_camera.get_world_to_view_transform().get_matrix().reshape(-1, 4, 4)[0]
 
 
+def _lin(idx3, gw, gh):
+    return (idx3[..., 0] * gw + idx3[..., 1]) * gh + idx3[..., 2]
+
+
 def compute_scene_occupancy_probability_field(params, macarons, camera, surface_scene, proxy_scene, device,
                                               use_supervision_occ_mask=True, prediction_camera=None,
-                                              use_supervision_occ_instead_of_predicted=False):
-    """macarons_utils.py:1395-1540.  For every grid cell that holds proxy points seen by a camera (and not carved empty): the
-    surface points of its 27-cell neighbourhood and its proxy points go to the prediction camera's view space, centred on the
-    cell and divided by prediction_neighborhood_size x the cell diagonal (one transform kernel each); the view states are
-    rotated into that frame and projected on the harmonics; SconeOcc runs in chunks of 20 000 queries (a fresh global
-    down-sample per chunk, drawn from the CPU generator like upstream); finally the never-seen points are appended with their
-    stored probability and zero harmonics.  Returns (X_world [N,3], view_harmonics [N,64], occ_probs [N,1]) and updates
-    proxy_scene.proxy_proba in place.  `surface_scene` / `proxy_scene`: macarons_amd.utility.scene.Scene or the reference's
-    Scene; `prediction_camera`: a PyTorch3D camera, or the [4,4] world->view matrix."""
+                                              use_supervision_occ_instead_of_predicted=False, chunk=20000):
+    """Occupancy probability of every proxy point the cameras have seen (macarons_utils.py:1395-1540), as ONE batched pass.
+
+    Upstream walks the grid cells that hold seen proxy points from Python: per cell it gathers the surface points of the 27-cell
+    neighbourhood and the cell's registered proxy points, moves both to the prediction camera's view space (centred on the cell,
+    scaled by prediction_neighborhood_size x the cell diagonal), rotates the view states into that frame, and calls the occupancy
+    network in chunks of 20 000 queries.  Here the cells are SEGMENTS of flat device arrays: one stable sort groups the selected
+    proxy points by cell, one gather builds every cell's surface cloud, one launch each transforms clouds / queries with a per-row
+    cell id, one gather + one product give the view harmonics, and all (cell, chunk) jobs go through SconeOcc.forward_ragged
+    together.  The host learns two integers per cell (visited?, how many selected points) in a single read-back; the hidden draws
+    of the network are made job by job on the CPU generator, i.e. exactly the draws of the cell loop.
+    Returns (X_world [N,3], view_harmonics [N,64], occ_probs [N,1]) in upstream's order (cells in lexicographic order, points by
+    index, then the never-seen points with their stored probability) and updates proxy_scene.proxy_proba in place.
+    `surface_scene` / `proxy_scene`: macarons_amd.utility.scene.Scene or objects with the reference Scene's attributes;
+    `prediction_camera`: a PyTorch3D-like camera, or the [4,4] world->view matrix."""
     from . import scone_utils as su
-    X_world = torch.zeros(0, 3, device=device)
-    view_harmonics = torch.zeros(0, params.n_harmonics, device=device)
-    occ_probs = torch.zeros(0, 1, device=device)
-    occ_mask = (proxy_scene.proxy_supervision_occ > 0.)[..., 0]
-    all_fov_mask = (proxy_scene.out_of_field < 1.)[..., 0]
-    seen = occ_mask * all_fov_mask
-    fovs_proxy_points = proxy_scene.proxy_points[seen if use_supervision_occ_mask else all_fov_mask]
-    proxy_scene.proxy_proba[seen] = 0.
-    proxy_cells = proxy_scene.get_englobing_cells(fovs_proxy_points)
-    base_harmonics, h_polar, h_azim = su.get_all_harmonics_under_degree(params.harmonic_degree, params.view_state_n_elev,
-                                                                         params.view_state_n_azim, device)
+    ps, ss = proxy_scene, surface_scene
+    gl, gw, gh = ps.grid_l, ps.grid_w, ps.grid_h
+    n_cells = gl * gw * gh
+    P = ps.proxy_points.shape[0]
+    nh = params.n_harmonics
+    occ_mask = (ps.proxy_supervision_occ > 0.)[..., 0]
+    seen = occ_mask & (ps.out_of_field < 1.)[..., 0]
+    visit_pts = seen if use_supervision_occ_mask else (ps.out_of_field < 1.)[..., 0]
+    ps.proxy_proba.masked_fill_(seen.view(-1, 1), 0.)                                            # :1431
     if prediction_camera is None:
         if camera is None:
             raise NameError("Both camera and prediction_camera are equal to None.")
         prediction_camera = camera.fov_camera_0
     Mv = _world_to_view_matrix(prediction_camera).to(device=device, dtype=torch.float32).contiguous()
-    R = Mv[:3, :3].contiguous()
-    one = torch.ones(1, 1, device=device)
-    for proxy_cell in proxy_cells:
-        cell = proxy_scene.cells[proxy_scene.get_key_from_idx(proxy_cell)]
-        cell_diag = torch.linalg.norm(cell.x_max - cell.x_min)
-        cell_pc_world = surface_scene.get_pt_cloud_from_cells(surface_scene.get_neighboring_cells(proxy_cell), return_features=False)
-        _, cell_X_indices = proxy_scene.get_pt_cloud_from_cells(proxy_cell, return_features=True)
-        cell_X_mask = proxy_scene.get_proxy_mask_from_indices(cell_X_indices)
-        if use_supervision_occ_mask:
-            cell_X_mask = cell_X_mask * occ_mask
-        cell_X_world = proxy_scene.proxy_points[cell_X_mask]
-        if not ((cell_pc_world.shape[0] > 2 * 2 * params.k_for_knn) and (len(cell_X_world) > 0)):
+    # ---- per proxy point: the cell its coordinates fall in (which cells are visited, :1434) and the cell whose store holds it
+    cell_by_pos = _lin(ps.get_cells_for_each_pt(ps.proxy_points), gw, gh)
+    keys = sorted(ps.cells.keys(), key=lambda k: tuple(int(v) for v in k.strip("[]").split(",")))     # lexicographic = linear id order
+    lin_of = {k: (lambda t: (t[0] * gw + t[1]) * gh + t[2])(tuple(int(v) for v in k.strip("[]").split(","))) for k in keys}
+    stored_cell = torch.full((P,), -1, dtype=torch.int64, device=device)
+    for k in keys:
+        c = ps.cells[k]
+        if c.cell_pts.shape[0] > 0:
+            stored_cell[c.cell_features[:, 0].long()] = lin_of[k]
+    sel = stored_cell >= 0
+    if use_supervision_occ_mask:
+        sel = sel & occ_mask
+    big = torch.full_like(stored_cell, n_cells)
+    visit = torch.zeros(n_cells + 1, dtype=torch.int64, device=device).scatter_(0, torch.where(visit_pts, cell_by_pos, big), 1)
+    counts = torch.zeros(n_cells + 1, dtype=torch.int64, device=device).scatter_add_(0, torch.where(sel, stored_cell, big),
+                                                                                   torch.ones_like(stored_cell))
+    host = torch.stack((visit[:n_cells], counts[:n_cells])).cpu().numpy()                        # the one read-back of the pass
+    # ---- host: which cells run, their surface neighbourhoods (sizes are tensor shapes: no read-back), the (cell, chunk) jobs
+    s_keys = sorted(ss.cells.keys(), key=lambda k: lin_of.get(k, 0))
+    s_len = {lin_of[k]: int(ss.cells[k].cell_pts.shape[0]) for k in s_keys}
+    s_start, o = {}, 0
+    for k in s_keys:
+        s_start[lin_of[k]] = o
+        o += s_len[lin_of[k]]
+
+    def neighbours(c):
+        i, j, k = c // (gw * gh), (c // gh) % gw, c % gh
+        out = {(min(max(i + a, 0), gl - 1) * gw + min(max(j + b, 0), gw - 1)) * gh + min(max(k + d, 0), gh - 1)
+               for a in (-1, 0, 1) for b in (-1, 0, 1) for d in (-1, 0, 1)}
+        return sorted(out)
+    jobs, seg_src, seg_len = [], [], []                 # job = (cell, number of queries); surface segments in job order
+    valid_cell = torch.zeros(n_cells + 1, dtype=torch.bool)
+    for c in range(n_cells):
+        if not host[0, c]:
             continue
-        center = (torch.cat((cell.center.view(1, 3), one), 1) @ Mv)[0, :3].contiguous()       # prediction_box_center (:1471)
-        inv_diag = 1.0 / float(params.prediction_neighborhood_size * cell_diag)
-        cell_pc = ops.transform_points_(cell_pc_world.clone().contiguous(), Mv, center, inv_diag).view(1, -1, 3)
-        cell_X = ops.transform_points_(cell_X_world.clone().contiguous(), Mv, center, inv_diag).view(1, -1, 3)
-        vs = proxy_scene.view_states[cell_X_mask.view(-1).bool()].view(1, cell_X.shape[1], params.n_view_state_cameras)
-        vs = su.move_view_state_to_view_space(vs, R if torch.is_tensor(prediction_camera) else prediction_camera,
+        nb = [n for n in neighbours(c) if s_len[n] > 0]
+        m_c = sum(s_len[n] for n in nb)
+        q_c = int(host[1, c])
+        if not (m_c > 2 * 2 * params.k_for_knn and q_c > 0):
+            continue
+        valid_cell[c] = True
+        for lo in range(0, q_c, chunk):
+            jobs.append((c, min(chunk, q_c - lo), m_c))
+            seg_src += [s_start[n] for n in nb]
+            seg_len += [s_len[n] for n in nb]
+    X_parts, H_parts, O_parts = [], [], []
+    if jobs:
+        J = len(jobs)
+        T = sum(q for _, q, _ in jobs)
+        tot = sum(seg_len)
+        # ---- selected proxy points grouped by cell (stable: ascending index inside a cell)
+        key = torch.where(sel & valid_cell.to(device)[stored_cell.clamp(min=0)], stored_cell, big)
+        rows = torch.sort(key, stable=True).indices[:T]
+        X_sel = ps.proxy_points[rows]
+        # ---- every job's surface cloud in one gather
+        ints = torch.tensor([seg_src, seg_len, [c for c, _, _ in jobs] + [0] * (len(seg_src) - J),
+                             [q for _, q, _ in jobs] + [0] * (len(seg_src) - J), [m for _, _, m in jobs] + [0] * (len(seg_src) - J)],
+                            dtype=torch.int64).to(device)
+        src, ln = ints[0], ints[1]
+        dst = torch.cumsum(ln, 0) - ln
+        gather = torch.arange(tot, device=device) + torch.repeat_interleave(src - dst, ln, output_size=tot)
+        S_all = torch.cat([ss.cells[k].cell_pts for k in s_keys if ss.cells[k].cell_pts.shape[0] > 0], dim=0)
+        pc_all = S_all[gather].contiguous()
+        job_cell, job_q, job_m = ints[2, :J], ints[3, :J], ints[4, :J]
+        jid = torch.arange(J, device=device)
+        cloud_of = torch.repeat_interleave(jid, job_m, output_size=tot).to(torch.int32)
+        row_job = torch.repeat_interleave(jid, job_q, output_size=T).to(torch.int32)
+        # ---- prediction boxes: cell centres in view space, 1 / (neighbourhood size x cell diagonal)   (:1468-1478)
+        by_lin = {lin_of[k]: ps.cells[k] for k in keys}
+        cells_in_order = [by_lin[c] for c, _, _ in jobs]
+        centers_w = torch.stack([c.center.reshape(3) for c in cells_in_order]).to(device)
+        diag = torch.linalg.norm(torch.stack([c.x_max.reshape(3) for c in cells_in_order])
+                                 - torch.stack([c.x_min.reshape(3) for c in cells_in_order]), dim=1).to(device)
+        centers = (torch.cat((centers_w, torch.ones(J, 1, device=device)), 1) @ Mv)[:, :3].contiguous()
+        inv_diag = (1.0 / (params.prediction_neighborhood_size * diag)).float().contiguous()
+        MvJ = Mv.reshape(1, 16).expand(J, -1).contiguous()
+        ops.transform_points_batched_(pc_all, MvJ, centers, inv_diag, cloud_of=cloud_of)
+        X_q = ops.transform_points_batched_(X_sel.clone().contiguous(), MvJ, centers, inv_diag, cloud_of=row_job)
+        # ---- view states -> prediction frame -> harmonics, all rows at once   (:1486-1497)
+        vs = ps.view_states[rows].view(1, T, params.n_view_state_cameras)
+        vs = su.move_view_state_to_view_space(vs, Mv[:3, :3].contiguous() if torch.is_tensor(prediction_camera) else prediction_camera,
                                               n_elev=params.view_state_n_elev, n_azim=params.view_state_n_azim)
-        cell_vh = su.compute_view_harmonics(vs, base_harmonics, h_polar, h_azim, params.view_state_n_elev, params.view_state_n_azim)
+        base_harmonics, h_polar, h_azim = su.get_all_harmonics_under_degree(params.harmonic_degree, params.view_state_n_elev,
+                                                                             params.view_state_n_azim, device)
+        vh = su.compute_view_harmonics(vs, base_harmonics, h_polar, h_azim, params.view_state_n_elev, params.view_state_n_azim)[0]
+        # ---- occupancy of all jobs
         if use_supervision_occ_instead_of_predicted:
-            cell_occ = proxy_scene.proxy_supervision_occ[cell_X_mask]
+            occ = ps.proxy_supervision_occ[rows]
         else:
-            cell_occ = compute_occupancy_probability(macarons, cell_pc, cell_X, cell_vh, max_points_per_pass=20000).view(-1, 1)
-        X_world = torch.vstack((X_world, cell_X_world.view(-1, 3)))
-        view_harmonics = torch.vstack((view_harmonics, cell_vh.view(-1, params.n_harmonics)))
-        occ_probs = torch.vstack((occ_probs, cell_occ))
-        proxy_scene.proxy_proba[cell_X_mask.view(-1).bool()] = cell_occ
-    oof_mask = (proxy_scene.out_of_field > 0.)[..., 0]
-    oof_X = proxy_scene.proxy_points[oof_mask]
-    X_world = torch.vstack((X_world, oof_X))
-    view_harmonics = torch.vstack((view_harmonics, torch.zeros(len(oof_X), params.n_harmonics, device=device)))
-    occ_probs = torch.vstack((occ_probs, proxy_scene.proxy_proba[oof_mask]))
+            occ_net = getattr(macarons, "occupancy", macarons)
+            if hasattr(occ_net, "forward_ragged"):
+                occ = occ_net.forward_ragged(pc_all, [m for _, _, m in jobs], X_q, vh, [q for _, q, _ in jobs]).view(-1, 1)
+            else:                                       # any other module with the reference's call signature: job by job
+                outs, r0, p0 = [], 0, 0
+                for _, q, m in jobs:
+                    outs.append(macarons(mode='occupancy', partial_point_cloud=pc_all[p0:p0 + m][None], proxy_points=X_q[r0:r0 + q][None],
+                                         view_harmonics=vh[r0:r0 + q][None]).view(-1, 1))
+                    r0, p0 = r0 + q, p0 + m
+                occ = torch.cat(outs)
+        ps.proxy_proba[rows] = occ                                                                # :1525
+        X_parts, H_parts, O_parts = [X_sel], [vh], [occ]
+    oof_mask = (ps.out_of_field > 0.)[..., 0]
+    oof_X = ps.proxy_points[oof_mask]
+    X_world = torch.cat(X_parts + [oof_X])
+    view_harmonics = torch.cat(H_parts + [torch.zeros(len(oof_X), nh, device=device)])
+    occ_probs = torch.cat(O_parts + [ps.proxy_proba[oof_mask]])
     return X_world, view_harmonics, occ_probs
 
 
