@@ -553,7 +553,7 @@ def macarons_gain_(vis, pts_world, cam_world, volume, distance_th, smooth=False)
 
 
 # ---- scene-side bookkeeping ---------------------------------------------------------------
-def min_dist_segmented(A, a_offsets, B, b_offsets):
+def min_dist_segmented(A, a_offsets, B, b_offsets, max_a=None):
     """fp64 distance of every A point to the nearest B point of its segment (grid cell); +inf for empty B segments.
     Replaces torch.min(torch.cdist(a.double(), b.double())) (macarons_utils.py:2566, 3022, 3049)."""
     A, B = _req(A, "A"), _req(B, "B")
@@ -561,9 +561,12 @@ def min_dist_segmented(A, a_offsets, B, b_offsets):
     b_off = _req(b_offsets, "b_offsets", torch.int64)
     nseg = a_off.numel() - 1
     out = torch.empty(A.shape[0], dtype=torch.float64, device=A.device)
-    max_a = int((a_off[1:] - a_off[:-1]).max().item()) if nseg > 0 else 0
-    if max_a == 0:
+    if max_a is None:                                 # (an upper bound of the largest A segment avoids this read-back: it only sizes the grid)
+        max_a = int((a_off[1:] - a_off[:-1]).max().item()) if nseg > 0 else 0
+    if max_a == 0 or A.shape[0] == 0:
         return out
+    if B.shape[0] == 0:                                  # every segment's B is empty
+        return out.fill_(float("inf"))
     with torch.cuda.device(A.device):
         check(lib().mcr_min_dist_segmented(_p(A), _p(a_off), _p(B), _p(b_off), c_i64(nseg), c_i64(max_a), _p(out), _stream()),
               "mcr_min_dist_segmented")

@@ -116,11 +116,78 @@ class Scene:
         m = ((pts >= self.x_min.to(pts.device)) & (pts <= self.x_max.to(pts.device))).all(dim=-1)
         return (pts[m], m) if return_mask else pts[m]
 
+    def _cell_table(self):
+        """Cells in linear-id (= lexicographic key) order and their box bounds as [n_cells, 3] device tables."""
+        t = getattr(self, "_table", None)
+        if t is None:
+            order = [self.cells[_key((i, j, k))] for i in range(self.grid_l) for j in range(self.grid_w) for k in range(self.grid_h)]
+            lo = torch.stack([c.x_min.reshape(3) for c in order]).to(self.device)
+            hi = torch.stack([c.x_max.reshape(3) for c in order]).to(self.device)
+            t = self._table = (order, lo, hi)
+        return t
+
     def fill_cells(self, pts, features=None, n_point_min=0):
-        inside, m = self.get_pts_in_bounding_box(pts)
-        fts = features[m] if features is not None else None
-        for cell_idx in self.get_englobing_cells(inside, list=True):
-            self.cells[_key(cell_idx)].fill(inside, features=fts, n_point_min=n_point_min)
+        """Scene.fill_cells (macarons_utils.py:2727-2737) over Cell.fill (:2551-2577) for ALL touched cells at once: upstream loops
+        the cells from Python, each testing every point against its box and its store.  Here one stable sort groups the points by
+        cell (floor rule, then the strict box test of that cell), ONE segmented fp64 nearest-distance launch runs every cell's
+        admission test against its own store, a second stable sort compacts the admitted points, and the host -- after reading
+        two integers per cell -- draws each touched cell's torch.randperm on the CPU generator in cell order (the reference's
+        draws) and turns them into one gather.  A point exactly on a cell face belongs to no cell, as upstream."""
+        from .. import ops
+        dev = self.device
+        N = pts.shape[0]
+        if N == 0:
+            return
+        cells, lo, hi = self._cell_table()
+        n_cells = len(cells)
+        with_fts = self.feature_dim > 0 and features is not None
+        cid = (self.get_cells_for_each_pt(pts) * torch.tensor([self.grid_w * self.grid_h, self.grid_h, 1], device=pts.device)).sum(-1)
+        ok = ((pts >= self.x_min.to(dev)) & (pts <= self.x_max.to(dev))).all(-1)                  # get_pts_in_bounding_box
+        ok = ok & (torch.max(pts - hi[cid], dim=-1)[0] < 0.) & (torch.min(pts - lo[cid], dim=-1)[0] > 0.)      # Cell.fill's box masks
+        big = torch.full_like(cid, n_cells)
+        key = torch.where(ok, cid, big)
+        order = torch.sort(key, stable=True).indices
+        key_s = key[order]
+        ones = torch.ones_like(key)
+        cand = torch.zeros(n_cells + 1, dtype=torch.int64, device=dev).scatter_add_(0, key, ones)
+        a_off = torch.zeros(n_cells + 1, dtype=torch.int64, device=dev)
+        a_off[1:] = torch.cumsum(cand[:n_cells], 0)
+        b_len = [int(c.cell_pts.shape[0]) for c in cells]
+        b_off_h = np.concatenate(([0], np.cumsum(b_len))).astype(np.int64)
+        B_all = torch.cat([c.cell_pts for c in cells if c.cell_pts.shape[0] > 0] + [torch.zeros(0, 3, device=dev)])
+        A_s = pts[order].contiguous()
+        d = ops.min_dist_segmented(A_s, a_off, B_all.contiguous(), torch.from_numpy(b_off_h).to(dev), max_a=N)
+        admit = (d > cells[0].resolution) & (key_s < n_cells) & (cand[key_s] > n_point_min)       # fp64 compare (:2566-2567)
+        key2 = torch.where(admit, key_s, big)
+        order2 = torch.sort(key2, stable=True).indices
+        adm = torch.zeros(n_cells + 1, dtype=torch.int64, device=dev).scatter_add_(0, key2, ones)
+        host = torch.stack((cand[:n_cells], adm[:n_cells])).cpu().numpy()                         # the one read-back
+        n_adm = int(host[1].sum())
+        add_pts = A_s[order2[:n_adm]]
+        src = torch.cat((B_all, add_pts))
+        if with_fts:
+            F_all = torch.cat([c.cell_features for c in cells if c.cell_pts.shape[0] > 0] + [torch.zeros(0, self.feature_dim, device=dev)])
+            src_f = torch.cat((F_all, features[order][order2[:n_adm]].to(F_all.dtype).view(-1, self.feature_dim)))
+        adm_off = np.concatenate(([0], np.cumsum(host[1])))
+        gidx, touched = [], []
+        for c in range(n_cells):
+            if host[0, c] <= n_point_min:
+                continue                                  # Cell.fill returns before the random subset (:2562): no draw
+            comb = np.concatenate((np.arange(b_off_h[c], b_off_h[c + 1]), b_off_h[-1] + np.arange(adm_off[c], adm_off[c + 1])))
+            perm = torch.randperm(len(comb))[:cells[c].capacity].numpy()                          # :2573, CPU generator, cell order
+            gidx.append(comb[perm])
+            touched.append((c, len(perm)))
+        if not touched:
+            return
+        g = torch.from_numpy(np.concatenate(gidx)).to(dev)
+        new_pts = src[g]
+        new_fts = src_f[g] if with_fts else None
+        o = 0
+        for c, n in touched:
+            cells[c].cell_pts = new_pts[o:o + n]
+            if with_fts:
+                cells[c].cell_features = new_fts[o:o + n]
+            o += n
 
     def get_pt_cloud_from_cells(self, cell_indices, return_features=True):
         with_fts = return_features and self.feature_dim > 0
