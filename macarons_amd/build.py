@@ -86,6 +86,43 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+TORCH_LIB_PATH = os.path.join(PKG_DIR, "libmacarons_torch.so")
+TORCH_SRC = os.path.join(PKG_DIR, "csrc_torch", "macarons_torch.cpp")
+
+
+def build_torch_ops(force=False, verbose=False):
+    """libmacarons_torch.so: the C++ TORCH_LIBRARY extension (torch.ops.macarons.*) over the C ABI; host code only, compiled with
+    hipcc against the installed torch's headers and linked to libmacarons_hip.so next to it."""
+    import torch
+    tdir = os.path.dirname(torch.__file__)
+    h = hashlib.sha256()
+    for p in (TORCH_SRC, os.path.join(os.path.dirname(PKG_DIR), "include", "macarons_hip.h")):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(torch.__version__.encode())
+    stamp = TORCH_LIB_PATH + ".stamp"
+    if not force and os.path.exists(TORCH_LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == h.hexdigest():
+        return TORCH_LIB_PATH
+    cmd = [hipcc_path(), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-w",
+           "-I", os.path.join(tdir, "include"), "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
+           "-I", "/opt/rocm/include", "-I", os.path.join(os.path.dirname(PKG_DIR), "include"), TORCH_SRC, "-o", TORCH_LIB_PATH,
+           "-L", os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-L", PKG_DIR, "-lmacarons_hip",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(tdir, "lib")]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {TORCH_SRC}:\n{r.stdout.decode()}")
+    for tmp in glob.glob(TORCH_LIB_PATH + ".*"):
+        if tmp != stamp:
+            os.remove(tmp)
+    with open(stamp, "w") as f:
+        f.write(h.hexdigest())
+    return TORCH_LIB_PATH
+
+
 if __name__ == "__main__":
     p = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
     print(p)
+    print(build_torch_ops(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

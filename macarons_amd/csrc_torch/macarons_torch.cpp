@@ -1,0 +1,197 @@
+// torch.ops.macarons.* -- the operator layer SURVEY §8(b) asks for below the Python class boundary, as a C++ TORCH_LIBRARY
+// extension: at::Tensor in / out, launches on c10::hip::getCurrentHIPStream(), errors through TORCH_CHECK.  Every operator is a
+// thin shim over the C ABI of include/macarons_hip.h (libmacarons_hip.so, linked): validation, output / scratch allocation
+// through torch's caching allocator, one call.  Registered on the CUDA (= HIP on ROCm) dispatch key only: there is no CPU kernel.
+// Reference op sequences (file:line, upstream tree) are cited per operator in include/macarons_hip.h.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGuard.h>
+#include <torch/library.h>
+
+#include <vector>
+
+#include "macarons_hip.h"
+
+namespace {
+
+void* stream_of(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+at::Tensor f32(const at::Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda(), "macarons::", name, " must live on a HIP device (the MI355X hot path has no CPU fallback)");
+    TORCH_CHECK(t.scalar_type() == at::kFloat, "macarons::", name, " must be float32");
+    return t.contiguous();
+}
+void ok(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed: ", mcr_last_error()); }
+at::Tensor scratch(const at::Tensor& like, size_t bytes) {
+    return at::empty({(int64_t)std::max<size_t>(bytes, 16)}, like.options().dtype(at::kByte));
+}
+std::vector<const float*> pointers(const c10::List<at::Tensor>& ts, std::vector<at::Tensor>& keep, const char* name) {
+    std::vector<const float*> p;
+    for (const at::Tensor& t : ts) {
+        keep.push_back(f32(t, name));
+        p.push_back(keep.back().data_ptr<float>());
+    }
+    return p;
+}
+
+// SconeVis.compute_coverage_gain (SconeVis.py:210-252): pts [B,N,3|4], harmonics [B,N,64], cams [B,C,3] -> [B,C]
+at::Tensor sh_coverage_gain(const at::Tensor& pts_, const at::Tensor& harm_, const at::Tensor& cams_, bool use_sigmoid) {
+    const at::Tensor pts = f32(pts_, "pts"), harm = f32(harm_, "harmonics"), cams = f32(cams_, "cams");
+    TORCH_CHECK(pts.dim() == 3 && harm.dim() == 3 && cams.dim() == 3, "sh_coverage_gain: pts [B,N,P], harmonics [B,N,64], cams [B,C,3]");
+    const int64_t B = pts.size(0), N = pts.size(1), P = pts.size(2), C = cams.size(1);
+    TORCH_CHECK(harm.size(0) == B && harm.size(1) == N && harm.size(2) == 64 && cams.size(0) == B && cams.size(2) == 3,
+                "sh_coverage_gain: shape mismatch");
+    c10::hip::HIPGuard guard(pts.device());
+    at::Tensor gains = at::empty({B, C}, pts.options());
+    at::Tensor ws = scratch(pts, mcr_sh_coverage_gain_workspace_bytes(B, N, C));
+    ok(mcr_sh_coverage_gain(pts.data_ptr<float>(), (int)P, harm.data_ptr<float>(), cams.data_ptr<float>(), gains.data_ptr<float>(), B, N, C,
+                            use_sigmoid ? 1 : 0, 0, ws.data_ptr(), (size_t)ws.numel(), stream_of(pts)), "mcr_sh_coverage_gain");
+    return gains;
+}
+
+// SconeVis.compute_visibilities (SconeVis.py:164-208) -> [B,C,N]
+at::Tensor sh_visibilities(const at::Tensor& pts_, const at::Tensor& harm_, const at::Tensor& cams_, bool use_sigmoid) {
+    const at::Tensor pts = f32(pts_, "pts"), harm = f32(harm_, "harmonics"), cams = f32(cams_, "cams");
+    TORCH_CHECK(pts.dim() == 3 && harm.dim() == 3 && cams.dim() == 3, "sh_visibilities: pts [B,N,P], harmonics [B,N,64], cams [B,C,3]");
+    const int64_t B = pts.size(0), N = pts.size(1), P = pts.size(2), C = cams.size(1);
+    TORCH_CHECK(harm.size(0) == B && harm.size(1) == N && harm.size(2) == 64 && cams.size(0) == B && cams.size(2) == 3,
+                "sh_visibilities: shape mismatch");
+    c10::hip::HIPGuard guard(pts.device());
+    at::Tensor vis = at::empty({B, C, N}, pts.options());
+    ok(mcr_sh_visibilities(pts.data_ptr<float>(), (int)P, harm.data_ptr<float>(), cams.data_ptr<float>(), vis.data_ptr<float>(), B, N, C,
+                           use_sigmoid ? 1 : 0, stream_of(pts)), "mcr_sh_visibilities");
+    return vis;
+}
+
+// get_knn_points + the offset step (utils.py:1497-1509, SconeOcc.py:297-298) -> (offsets [B,Q,k,3], dists [B,Q,k], idx int64)
+std::tuple<at::Tensor, at::Tensor, at::Tensor> knn_gather_offset(const at::Tensor& x_, const at::Tensor& pc_, int64_t k) {
+    const at::Tensor x = f32(x_, "x"), pc = f32(pc_, "pc");
+    TORCH_CHECK(x.dim() == 3 && pc.dim() == 3 && x.size(2) == 3 && pc.size(2) == 3 && pc.size(0) == x.size(0), "knn_gather_offset: x [B,Q,3], pc [B,M,3]");
+    const int64_t B = x.size(0), Q = x.size(1), M = pc.size(1);
+    c10::hip::HIPGuard guard(x.device());
+    at::Tensor idx = at::empty({B, Q, k}, x.options().dtype(at::kLong)), d = at::empty({B, Q, k}, x.options()), pts = at::empty({B, Q, k, 3}, x.options());
+    ok(mcr_knn_points(x.data_ptr<float>(), pc.data_ptr<float>(), idx.data_ptr<int64_t>(), d.data_ptr<float>(), pts.data_ptr<float>(), B, Q, M,
+                      (int)k, 1, stream_of(x)), "mcr_knn_points");
+    return {pts, d, idx};
+}
+
+// Camera.get_points_in_fov (macarons_utils.py:2400-2435): pts [P,3], camera records [n_cam,40] -> bool [n_cam,P]
+at::Tensor points_in_fov(const at::Tensor& pts_, const at::Tensor& cams_) {
+    const at::Tensor pts = f32(pts_, "pts"), cams = f32(cams_, "cameras");
+    TORCH_CHECK(pts.dim() == 2 && pts.size(1) == 3 && cams.dim() == 2 && cams.size(1) == 40, "points_in_fov: pts [P,3], cameras [n_cam,40]");
+    c10::hip::HIPGuard guard(pts.device());
+    at::Tensor mask = at::empty({cams.size(0), pts.size(0)}, pts.options().dtype(at::kByte));
+    ok(mcr_points_in_fov(pts.data_ptr<float>(), pts.size(0), cams.data_ptr<float>(), (int)cams.size(0), mask.data_ptr<uint8_t>(), stream_of(pts)),
+       "mcr_points_in_fov");
+    return mask.to(at::kBool);
+}
+
+// compute_view_state (scone_utils.py:799-860) -> [B,Q,n_elev*n_azim]
+at::Tensor view_state(const at::Tensor& pts_, const at::Tensor& xv_, int64_t n_elev, int64_t n_azim) {
+    const at::Tensor pts = f32(pts_, "pts"), xv = f32(xv_, "X_view");
+    TORCH_CHECK(pts.dim() == 3 && pts.size(2) >= 3 && xv.dim() == 2 && xv.size(1) == 3, "view_state: pts [B,Q,>=3], X_view [n_view,3]");
+    c10::hip::HIPGuard guard(pts.device());
+    at::Tensor out = at::empty({pts.size(0), pts.size(1), n_elev * n_azim}, pts.options());
+    ok(mcr_view_state(pts.data_ptr<float>(), (int)pts.size(2), xv.data_ptr<float>(), out.data_ptr<float>(), pts.size(0) * pts.size(1),
+                      (int)xv.size(0), (int)n_elev, (int)n_azim, stream_of(pts)), "mcr_view_state");
+    return out;
+}
+
+// compute_view_harmonics (scone_utils.py:934-960) as one product with the constant [n_harmonics, n_bins] matrix
+at::Tensor view_harmonics(const at::Tensor& vs_, const at::Tensor& mat_) {
+    const at::Tensor vs = f32(vs_, "view_state"), mat = f32(mat_, "matrix");
+    TORCH_CHECK(mat.dim() == 2 && vs.size(-1) == mat.size(1), "view_harmonics: view_state [..., n_bins], matrix [n_harmonics, n_bins]");
+    const int64_t K = mat.size(1), N = mat.size(0), M = vs.numel() / K;
+    c10::hip::HIPGuard guard(vs.device());
+    std::vector<int64_t> shape(vs.sizes().begin(), vs.sizes().end());
+    shape.back() = N;
+    at::Tensor out = at::empty(shape, vs.options());
+    ok(mcr_linear(vs.data_ptr<float>(), K, mat.data_ptr<float>(), nullptr, nullptr, N, out.data_ptr<float>(), N, M, (int)N, (int)K, 0,
+                  stream_of(vs)), "mcr_linear");
+    return out;
+}
+
+// sample_proxy_points (scone_utils.py:1030-1061) -> (points+occupancy [n_u,4], harmonics [n_u,64], inverse [n], unique idx [n_u]);
+// one host read-back of the unique count (the reference's torch.unique synchronises at the same point)
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> sample_proxy(const at::Tensor& X_, const at::Tensor& probs_, const at::Tensor& vh_,
+                                                                        const at::Tensor& u_, double min_occ) {
+    const at::Tensor X = f32(X_, "X"), probs = f32(probs_, "probs"), vh = f32(vh_, "view_harmonics"), u = f32(u_, "u");
+    TORCH_CHECK(X.dim() == 2 && X.size(1) == 3 && probs.numel() == X.size(0) && vh.dim() == 2 && vh.size(0) == X.size(0) && vh.size(1) == 64,
+                "sample_proxy: X [P,3], probs [P], view_harmonics [P,64]");
+    const int64_t P = X.size(0), n = u.numel();
+    c10::hip::HIPGuard guard(X.device());
+    at::Tensor res = at::empty({n, 4}, X.options()), resh = at::empty({n, 64}, X.options());
+    at::Tensor uniq = at::empty({n}, X.options().dtype(at::kLong)), inv = at::empty({n}, X.options().dtype(at::kLong));
+    at::Tensor nu = at::zeros({1}, X.options().dtype(at::kInt));
+    at::Tensor ws = scratch(X, mcr_sample_proxy_workspace_bytes(P, (int)n));
+    ok(mcr_sample_proxy(X.data_ptr<float>(), probs.data_ptr<float>(), 1, vh.data_ptr<float>(), P, (float)min_occ, u.data_ptr<float>(), (int)n,
+                        res.data_ptr<float>(), resh.data_ptr<float>(), uniq.data_ptr<int64_t>(), inv.data_ptr<int64_t>(), nu.data_ptr<int>(),
+                        nullptr, ws.data_ptr(), (size_t)ws.numel(), stream_of(X)), "mcr_sample_proxy");
+    const int64_t k = nu.item<int>();
+    return {res.narrow(0, 0, k), resh.narrow(0, 0, k), inv, uniq.narrow(0, 0, k)};
+}
+
+// SconeVis.forward (SconeVis.py:121-162): pts [B,N,4], view_harmonics [B,N,64], the 48 weight tensors -> [B,N,64]
+at::Tensor scone_vis_forward(const at::Tensor& pts_, const at::Tensor& vh_, c10::List<at::Tensor> weights) {
+    const at::Tensor pts = f32(pts_, "pts"), vh = f32(vh_, "view_harmonics");
+    TORCH_CHECK(pts.dim() == 3 && pts.size(2) == 4 && vh.dim() == 3 && vh.size(0) == pts.size(0) && vh.size(1) == pts.size(1) && vh.size(2) == 64,
+                "scone_vis_forward: pts [B,N,4], view_harmonics [B,N,64]");
+    const int64_t B = pts.size(0), N = pts.size(1);
+    std::vector<at::Tensor> keep;
+    const std::vector<const float*> w = pointers(weights, keep, "weights");
+    c10::hip::HIPGuard guard(pts.device());
+    at::Tensor out = at::empty({B, N, 64}, pts.options());
+    at::Tensor ws = scratch(pts, mcr_scone_vis_workspace_bytes(B, N));
+    ok(mcr_scone_vis_forward(pts.data_ptr<float>(), vh.data_ptr<float>(), out.data_ptr<float>(), B, N, w.data(), (int)w.size(), nullptr,
+                             ws.data_ptr(), (size_t)ws.numel(), stream_of(pts)), "mcr_scone_vis_forward");
+    return out;
+}
+
+// SconeOcc.forward (SconeOcc.py:250-347) after the three down-sampling draws: pc_global [B,Lg,3], the three scale clouds,
+// x [B,Q,3], view_harmonics [B,Q,64], the 140 weight tensors, the three packed local-transformer blobs (may be empty) -> [B,Q,1]
+at::Tensor scone_occ_forward(const at::Tensor& pcg_, c10::List<at::Tensor> pc_scales, const at::Tensor& x_, const at::Tensor& vh_,
+                             c10::List<at::Tensor> weights, c10::List<at::Tensor> local_blobs) {
+    const at::Tensor pcg = f32(pcg_, "pc_global"), x = f32(x_, "x"), vh = f32(vh_, "view_harmonics");
+    TORCH_CHECK(pc_scales.size() == 3, "scone_occ_forward: three scale clouds");
+    TORCH_CHECK(x.dim() == 3 && x.size(2) == 3 && vh.dim() == 3 && vh.size(2) == 64 && pcg.dim() == 3, "scone_occ_forward: x [B,Q,3], view_harmonics [B,Q,64]");
+    const int64_t B = x.size(0), Q = x.size(1), Lg = pcg.size(1);
+    std::vector<at::Tensor> keep;
+    const std::vector<const float*> sc = pointers(pc_scales, keep, "pc_scales"), w = pointers(weights, keep, "weights"),
+                                    bl = pointers(local_blobs, keep, "local_blobs");
+    TORCH_CHECK(bl.empty() || bl.size() == 3, "scone_occ_forward: local_blobs must be empty or hold the three packed transformers");
+    int64_t Ms[3];
+    for (int i = 0; i < 3; ++i) Ms[i] = keep[i].size(1);
+    c10::hip::HIPGuard guard(x.device());
+    at::Tensor out = at::empty({B, Q, 1}, x.options());
+    at::Tensor ws = scratch(x, mcr_scone_occ_workspace_bytes(B, Q, Lg));
+    ok(mcr_scone_occ_forward(pcg.data_ptr<float>(), Lg, sc.data(), Ms, x.data_ptr<float>(), vh.data_ptr<float>(), out.data_ptr<float>(), B, Q,
+                             w.data(), (int)w.size(), bl.empty() ? nullptr : bl.data(), nullptr, nullptr, nullptr, ws.data_ptr(),
+                             (size_t)ws.numel(), stream_of(x)), "mcr_scone_occ_forward");
+    return out;
+}
+
+}  // namespace
+
+TORCH_LIBRARY(macarons, m) {
+    m.def("sh_coverage_gain(Tensor pts, Tensor harmonics, Tensor cams, bool use_sigmoid) -> Tensor");
+    m.def("sh_visibilities(Tensor pts, Tensor harmonics, Tensor cams, bool use_sigmoid) -> Tensor");
+    m.def("knn_gather_offset(Tensor x, Tensor pc, int k) -> (Tensor, Tensor, Tensor)");
+    m.def("points_in_fov(Tensor pts, Tensor cameras) -> Tensor");
+    m.def("view_state(Tensor pts, Tensor X_view, int n_elev, int n_azim) -> Tensor");
+    m.def("view_harmonics(Tensor view_state, Tensor matrix) -> Tensor");
+    m.def("sample_proxy(Tensor X, Tensor probs, Tensor view_harmonics, Tensor u, float min_occ) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("scone_vis_forward(Tensor pts, Tensor view_harmonics, Tensor[] weights) -> Tensor");
+    m.def("scone_occ_forward(Tensor pc_global, Tensor[] pc_scales, Tensor x, Tensor view_harmonics, Tensor[] weights, Tensor[] local_blobs) -> Tensor");
+}
+
+TORCH_LIBRARY_IMPL(macarons, CUDA, m) {
+    m.impl("sh_coverage_gain", &sh_coverage_gain);
+    m.impl("sh_visibilities", &sh_visibilities);
+    m.impl("knn_gather_offset", &knn_gather_offset);
+    m.impl("points_in_fov", &points_in_fov);
+    m.impl("view_state", &view_state);
+    m.impl("view_harmonics", &view_harmonics);
+    m.impl("sample_proxy", &sample_proxy);
+    m.impl("scone_vis_forward", &scone_vis_forward);
+    m.impl("scone_occ_forward", &scone_occ_forward);
+}

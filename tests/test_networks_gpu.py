@@ -411,3 +411,35 @@ def test_torch_ops_namespace_matches_module_path(dev):
     with torch.no_grad():
         y = torch.ops.macarons.scone_vis_forward(pts, harm, m.weight_table())
         assert torch.equal(y, m(pts, view_harmonics=harm))
+    # the rest of the operator list (C++ TORCH_LIBRARY shims over the same C ABI): frustum, harmonics product, sampler, SconeOcc
+    from macarons_amd.networks import SconeOcc
+    from macarons_amd.networks.packing import pack_local_pct
+    from macarons_amd import _lib
+    from macarons_amd.utility.macarons_utils import camera_record
+    g = golden("fov_camera")
+    recs = torch.stack([camera_record(g["Mview"][c], g["Mfull"][c], g["ndc"], g["center"][c], 40.0) for c in range(2)]).to(dev)
+    P3 = T(g["pts"][:5000], dev)
+    assert torch.equal(torch.ops.macarons.points_in_fov(P3, recs), ops.points_in_fov(P3, recs))
+    vs = ops.view_state(X, cams[0, :3].contiguous(), 7, 14)
+    mat = T(rng.standard_normal((64, 98)).astype(np.float32), dev)
+    assert torch.equal(torch.ops.macarons.view_harmonics(vs, mat), ops.linear(vs, mat))
+    Xp, pr = T(rng.uniform(-.5, .5, (900, 3)).astype(np.float32), dev), T(rng.uniform(0, 1, 900).astype(np.float32), dev)
+    vh = T((rng.standard_normal((900, 64)) * .3).astype(np.float32), dev)
+    u = T(rng.uniform(0, 1, 256).astype(np.float32), dev)
+    for a, b in zip(torch.ops.macarons.sample_proxy(Xp, pr, vh, u, 0.1), ops.sample_proxy(Xp, pr, vh, u, 0.1)):
+        assert torch.equal(a, b)
+    occ, _ = _mod(SconeOcc, 2, dev)
+    torch.manual_seed(2)
+    perms = occ.draw_perms(99)
+    xq, vq = T(rng.uniform(-.5, .5, (1, 70, 3)).astype(np.float32), dev), T((rng.standard_normal((1, 70, 64)) * .3).astype(np.float32), dev)
+    pcg = pc[:, perms[0].to(dev)].contiguous()
+    scales = [pc, pc[:, perms[1].to(dev)].contiguous()]
+    scales.append(scales[1][:, perms[2].to(dev)].contiguous())
+    blobs = [pack_local_pct(t_, _lib.lib().mcr_get_local_pct_variant()) for t_ in occ.local_transformers]
+    with torch.no_grad():
+        yo = torch.ops.macarons.scone_occ_forward(pcg, scales, xq, vq, occ.weight_table(), blobs)
+        occ.range_guard = "off"
+        ref = occ(pc, xq, vq, perms=perms)
+    assert rel_err(yo.cpu().numpy(), ref.cpu().numpy()) < 2e-6        # (the module passes host-split head planes, the operator lets the kernel split)
+    with pytest.raises(RuntimeError):
+        torch.ops.macarons.sh_coverage_gain(pts, harm[:, :10], cams, True)           # TORCH_CHECK on a shape mismatch
