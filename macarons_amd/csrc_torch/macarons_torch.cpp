@@ -1,11 +1,12 @@
 // torch.ops.macarons.* -- the operator layer SURVEY §8(b) asks for below the Python class boundary, as a C++ TORCH_LIBRARY
-// extension: at::Tensor in / out, launches on c10::hip::getCurrentHIPStream(), errors through TORCH_CHECK.  Every operator is a
+// extension: at::Tensor in / out, launches on torch's current HIP stream (c10::hip::getCurrentHIPStream...()), errors through TORCH_CHECK.  Every operator is a
 // thin shim over the C ABI of include/macarons_hip.h (libmacarons_hip.so, linked): validation, output / scratch allocation
 // through torch's caching allocator, one call.  Registered on the CUDA (= HIP on ROCm) dispatch key only: there is no CPU kernel.
 // Reference op sequences (file:line, upstream tree) are cited per operator in include/macarons_hip.h.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+// torch on ROCm keeps the device type "cuda": the guard / stream accessors are the Masquerading-As-CUDA flavours of c10::hip
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
 #include <vector>
@@ -14,7 +15,7 @@
 
 namespace {
 
-void* stream_of(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+void* stream_of(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 at::Tensor f32(const at::Tensor& t, const char* name) {
     TORCH_CHECK(t.is_cuda(), "macarons::", name, " must live on a HIP device (the MI355X hot path has no CPU fallback)");
@@ -41,7 +42,7 @@ at::Tensor sh_coverage_gain(const at::Tensor& pts_, const at::Tensor& harm_, con
     const int64_t B = pts.size(0), N = pts.size(1), P = pts.size(2), C = cams.size(1);
     TORCH_CHECK(harm.size(0) == B && harm.size(1) == N && harm.size(2) == 64 && cams.size(0) == B && cams.size(2) == 3,
                 "sh_coverage_gain: shape mismatch");
-    c10::hip::HIPGuard guard(pts.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(pts.device());
     at::Tensor gains = at::empty({B, C}, pts.options());
     at::Tensor ws = scratch(pts, mcr_sh_coverage_gain_workspace_bytes(B, N, C));
     ok(mcr_sh_coverage_gain(pts.data_ptr<float>(), (int)P, harm.data_ptr<float>(), cams.data_ptr<float>(), gains.data_ptr<float>(), B, N, C,
@@ -56,7 +57,7 @@ at::Tensor sh_visibilities(const at::Tensor& pts_, const at::Tensor& harm_, cons
     const int64_t B = pts.size(0), N = pts.size(1), P = pts.size(2), C = cams.size(1);
     TORCH_CHECK(harm.size(0) == B && harm.size(1) == N && harm.size(2) == 64 && cams.size(0) == B && cams.size(2) == 3,
                 "sh_visibilities: shape mismatch");
-    c10::hip::HIPGuard guard(pts.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(pts.device());
     at::Tensor vis = at::empty({B, C, N}, pts.options());
     ok(mcr_sh_visibilities(pts.data_ptr<float>(), (int)P, harm.data_ptr<float>(), cams.data_ptr<float>(), vis.data_ptr<float>(), B, N, C,
                            use_sigmoid ? 1 : 0, stream_of(pts)), "mcr_sh_visibilities");
@@ -68,7 +69,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> knn_gather_offset(const at::Tenso
     const at::Tensor x = f32(x_, "x"), pc = f32(pc_, "pc");
     TORCH_CHECK(x.dim() == 3 && pc.dim() == 3 && x.size(2) == 3 && pc.size(2) == 3 && pc.size(0) == x.size(0), "knn_gather_offset: x [B,Q,3], pc [B,M,3]");
     const int64_t B = x.size(0), Q = x.size(1), M = pc.size(1);
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     at::Tensor idx = at::empty({B, Q, k}, x.options().dtype(at::kLong)), d = at::empty({B, Q, k}, x.options()), pts = at::empty({B, Q, k, 3}, x.options());
     ok(mcr_knn_points(x.data_ptr<float>(), pc.data_ptr<float>(), idx.data_ptr<int64_t>(), d.data_ptr<float>(), pts.data_ptr<float>(), B, Q, M,
                       (int)k, 1, stream_of(x)), "mcr_knn_points");
@@ -79,7 +80,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> knn_gather_offset(const at::Tenso
 at::Tensor points_in_fov(const at::Tensor& pts_, const at::Tensor& cams_) {
     const at::Tensor pts = f32(pts_, "pts"), cams = f32(cams_, "cameras");
     TORCH_CHECK(pts.dim() == 2 && pts.size(1) == 3 && cams.dim() == 2 && cams.size(1) == 40, "points_in_fov: pts [P,3], cameras [n_cam,40]");
-    c10::hip::HIPGuard guard(pts.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(pts.device());
     at::Tensor mask = at::empty({cams.size(0), pts.size(0)}, pts.options().dtype(at::kByte));
     ok(mcr_points_in_fov(pts.data_ptr<float>(), pts.size(0), cams.data_ptr<float>(), (int)cams.size(0), mask.data_ptr<uint8_t>(), stream_of(pts)),
        "mcr_points_in_fov");
@@ -90,7 +91,7 @@ at::Tensor points_in_fov(const at::Tensor& pts_, const at::Tensor& cams_) {
 at::Tensor view_state(const at::Tensor& pts_, const at::Tensor& xv_, int64_t n_elev, int64_t n_azim) {
     const at::Tensor pts = f32(pts_, "pts"), xv = f32(xv_, "X_view");
     TORCH_CHECK(pts.dim() == 3 && pts.size(2) >= 3 && xv.dim() == 2 && xv.size(1) == 3, "view_state: pts [B,Q,>=3], X_view [n_view,3]");
-    c10::hip::HIPGuard guard(pts.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(pts.device());
     at::Tensor out = at::empty({pts.size(0), pts.size(1), n_elev * n_azim}, pts.options());
     ok(mcr_view_state(pts.data_ptr<float>(), (int)pts.size(2), xv.data_ptr<float>(), out.data_ptr<float>(), pts.size(0) * pts.size(1),
                       (int)xv.size(0), (int)n_elev, (int)n_azim, stream_of(pts)), "mcr_view_state");
@@ -102,7 +103,7 @@ at::Tensor view_harmonics(const at::Tensor& vs_, const at::Tensor& mat_) {
     const at::Tensor vs = f32(vs_, "view_state"), mat = f32(mat_, "matrix");
     TORCH_CHECK(mat.dim() == 2 && vs.size(-1) == mat.size(1), "view_harmonics: view_state [..., n_bins], matrix [n_harmonics, n_bins]");
     const int64_t K = mat.size(1), N = mat.size(0), M = vs.numel() / K;
-    c10::hip::HIPGuard guard(vs.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(vs.device());
     std::vector<int64_t> shape(vs.sizes().begin(), vs.sizes().end());
     shape.back() = N;
     at::Tensor out = at::empty(shape, vs.options());
@@ -119,7 +120,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> sample_proxy(const at
     TORCH_CHECK(X.dim() == 2 && X.size(1) == 3 && probs.numel() == X.size(0) && vh.dim() == 2 && vh.size(0) == X.size(0) && vh.size(1) == 64,
                 "sample_proxy: X [P,3], probs [P], view_harmonics [P,64]");
     const int64_t P = X.size(0), n = u.numel();
-    c10::hip::HIPGuard guard(X.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(X.device());
     at::Tensor res = at::empty({n, 4}, X.options()), resh = at::empty({n, 64}, X.options());
     at::Tensor uniq = at::empty({n}, X.options().dtype(at::kLong)), inv = at::empty({n}, X.options().dtype(at::kLong));
     at::Tensor nu = at::zeros({1}, X.options().dtype(at::kInt));
@@ -139,7 +140,7 @@ at::Tensor scone_vis_forward(const at::Tensor& pts_, const at::Tensor& vh_, c10:
     const int64_t B = pts.size(0), N = pts.size(1);
     std::vector<at::Tensor> keep;
     const std::vector<const float*> w = pointers(weights, keep, "weights");
-    c10::hip::HIPGuard guard(pts.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(pts.device());
     at::Tensor out = at::empty({B, N, 64}, pts.options());
     at::Tensor ws = scratch(pts, mcr_scone_vis_workspace_bytes(B, N));
     ok(mcr_scone_vis_forward(pts.data_ptr<float>(), vh.data_ptr<float>(), out.data_ptr<float>(), B, N, w.data(), (int)w.size(), nullptr,
@@ -161,7 +162,7 @@ at::Tensor scone_occ_forward(const at::Tensor& pcg_, c10::List<at::Tensor> pc_sc
     TORCH_CHECK(bl.empty() || bl.size() == 3, "scone_occ_forward: local_blobs must be empty or hold the three packed transformers");
     int64_t Ms[3];
     for (int i = 0; i < 3; ++i) Ms[i] = keep[i].size(1);
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     at::Tensor out = at::empty({B, Q, 1}, x.options());
     at::Tensor ws = scratch(x, mcr_scone_occ_workspace_bytes(B, Q, Lg));
     ok(mcr_scone_occ_forward(pcg.data_ptr<float>(), Lg, sc.data(), Ms, x.data_ptr<float>(), vh.data_ptr<float>(), out.data_ptr<float>(), B, Q,
