@@ -130,6 +130,12 @@ bool linear3h_applicable(const float* X, int64_t ldx, const float* W, int64_t ld
 }
 size_t linear3h_planes_bytes(int N, int K) { return ((size_t)2 * N * (K / 8) * sizeof(uint4) + 255) & ~(size_t)255; }
 
+void launch_split_weights(hipStream_t s, const float* W, int64_t ldw, void* planes, int N, int K) {
+    const int K8 = K / 8;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)cdiv((int64_t)N * K8, 256)), dim3(256), 0, s, W, (long long)ldw,
+                       reinterpret_cast<uint4*>(planes), N, K8);
+}
+
 // planes: scratch of linear3h_planes_bytes(N, K) bytes (16-byte aligned) that receives the split weights -- or, with
 // presplit_inv_scale > 0, planes the HOST already built (networks/packing.py: pack_head_planes, cached per parameter version;
 // fp16 hi/lo of W * 2^e with e chosen per matrix like the local-transformer blobs): no split launch, the epilogue multiplies by

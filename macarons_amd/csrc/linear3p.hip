@@ -1,0 +1,233 @@
+// K4-planes — nn.Linear on the two-term fp16 split with BOTH operands already stored as fp16 hi/lo planes in HBM (the SconeOcc
+// head, SconeOcc.py:320-347, variant 6): three MFMAs per fp32 product like linear3h.hip, but nothing is split inside the GEMM.
+//
+// linear3h re-split every activation tile in each of its N/128 column blocks (4x for the 1344 -> 512 layer) and staged both
+// operands through registers; here every activation is split ONCE where it is produced (the local transformers' pooled
+// features, the epilogues of the previous layers) and both operands travel HBM -> LDS by global_load_lds_dwordx4: no staging
+// registers, no ds_write pass, no vector work in the K loop besides the MFMAs' fragment reads.
+//
+// Operands: X planes Xh / Xl [M][ldx] fp16 (row-major), W planes Wh / Wl [N][ldw] fp16 (W times a power of two 2^e, built by
+// networks/packing.py: pack_head_planes, or by split_weights_kernel).  Evaluated TRANSPOSED, D^T[n][m] = W[n][:] . X[m][:] (W
+// tile = MFMA A operand), so a lane ends up with 4 CONSECUTIVE features n of one row m per register quad: the epilogue adds the
+// bias (and the per-group row bias), applies the exact-erf GELU and stores either fp32 (float4 per quad) or, split again, the
+// next layer's planes (8 bytes per plane and quad).
+//
+// Block = 8 waves = 128 features x 256 rows (wave w: features 32 (w & 3).., rows 128 (w >> 2)..), K in chunks of 32, THREE LDS
+// stages of 48 KB (Xh, Xl: 256 rows; Wh, Wl: 128 rows) = 144 KB, one block per CU.  The DMA runs two chunks ahead: iteration k waits
+// (counted: s_waitcnt vmcnt(6) = the six DMA instructions of chunk k+1 may stay in flight), passes ONE raw s_barrier, queues
+// chunk k+2 into the stage chunk k-1 just left, and multiplies chunk k -- a __syncthreads() would drain the DMA queue at every
+// barrier (hipcc puts vmcnt(0) in front of it) and the 128 x 128 / two-stage form of this kernel spent half its time waiting
+// for L2 round trips (616 TFLOP/s executed on the 1344 -> 512 layer).  The DMA's LDS image is lane-linear, so the XOR swizzle of
+// the 16-byte chunks (by (row >> 2) & 3: conflict-free ds_read_b128 fragment reads) is applied on the SOURCE address: LDS
+// position (row, c) receives the row's chunk c ^ ((row >> 2) & 3).
+#include "lp_split.h"
+
+namespace mcr {
+
+constexpr int LP_TN = 128, LP_TM = 256, LP_BK = 32;       // features / activation rows per block, k per chunk
+constexpr int LP_XC = LP_TM * 4, LP_WC = LP_TN * 4;       // 16-byte chunks per X / W tile and plane
+constexpr int LP_STAGE = 2 * LP_XC + 2 * LP_WC;           // chunks per stage (Xh | Xl | Wh | Wl) = 3072 = 48 KB
+constexpr int LP_STAGES = 3;
+constexpr int LP_LDS_BYTES = LP_STAGES * LP_STAGE * 16;   // 147 456
+
+typedef const __attribute__((address_space(1))) void* lp_gptr;
+typedef __attribute__((address_space(3))) void* lp_lptr;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read(unsigned addr) {           // ds_read_b128 the compiler's wait-count pass does not see
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ f32x16 mfma_u(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <bool PLANES_OUT>
+__global__ __launch_bounds__(512, 1) void linear3p_kernel(const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, long long ldx,
+                                                          const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, long long ldw,
+                                                          const float* __restrict__ bias, const float* __restrict__ row_bias,
+                                                          long long rows_per_group, const int* __restrict__ row_group,
+                                                          float* __restrict__ Y, _Float16* __restrict__ Yh, _Float16* __restrict__ Yl,
+                                                          long long ldy, long long M, int N, int K, int act, float wscale_inv) {
+    extern __shared__ __attribute__((aligned(16))) uint4 S[];                     // [stage][Xh 1024 | Xl 1024 | Wh 512 | Wl 512]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wm = wave >> 2;
+    // XCD-aware block order: workgroup b runs on XCD b % 8 (its own L2).  The N / 128 column blocks of one 256-row block read the
+    // SAME activation rows: they get consecutive slots of ONE XCD, so the rows come from HBM once and from that L2 afterwards
+    // (with the plain (row block, column block) grid the 1344 -> 512 layer fetched its 537 MB of activations four times).
+    const int ncb = (N + LP_TN - 1) / LP_TN;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const long long rb = (long long)(q / ncb) * 8 + xcd;
+    const long long m0 = rb * LP_TM;
+    if (m0 >= M) return;                                   // (the grid is padded to whole groups of 8 row blocks)
+    const int n0 = (q % ncb) * LP_TN;
+    const int i = lane & 31, h = lane >> 5;
+
+    // ---- DMA addressing: per stage this wave moves X chunk groups 2 wave, 2 wave + 1 (64 chunks = 16 rows each) of both X planes and
+    // W chunk group `wave` of both W planes.  LDS position p = group * 64 + lane = (row = p >> 2, c = p & 3) takes the source
+    // chunk c ^ ((row >> 2) & 3) of that row.
+    const _Float16 *sx[2][2], *sw[2];                      // this lane's sources at k = 0: [group][plane], [plane]
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int p = (2 * wave + g) * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+        const long long xr = min(m0 + row, M - 1);         // rows beyond the matrix repeat its last row (results discarded)
+        sx[g][0] = Xh + xr * ldx + c * 8; sx[g][1] = Xl + xr * ldx + c * 8;
+    }
+    {
+        const int p = wave * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+        const long long wr = min((long long)n0 + row, (long long)N - 1);
+        sw[0] = Wh + wr * ldw + c * 8; sw[1] = Wl + wr * ldw + c * 8;
+    }
+    auto stage = [&](int st, int k0) {                     // 6 DMA instructions per wave
+        uint4* b = S + st * LP_STAGE;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                __builtin_amdgcn_global_load_lds((lp_gptr)(sx[g][pl] + k0), (lp_lptr)(b + pl * LP_XC + (2 * wave + g) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((lp_gptr)(sw[pl] + k0), (lp_lptr)(b + 2 * LP_XC + pl * LP_WC + wave * 64), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // Fragment reads are inline-asm ds_read_b128 with hand-counted lgkmcnt waits: hipcc cannot prove that a C++ LDS read of stage
+    // kc does not alias the DMA it has just queued into stage kc+2 (run-time stage indices) and puts s_waitcnt vmcnt(0) in front of
+    // the first read of every chunk -- which drains the whole DMA pipeline (measured: 2.8 us per chunk against 0.7 us of MFMAs).
+    // Byte addresses: row r of a tile, k16-step s, lane half h -> ((r * 4 + ((2 s + h) ^ ((r >> 2) & 3))) * 16; the tile / plane
+    // offsets are immediates.  ((32 t + i) >> 2) & 3 == (i >> 2) & 3 for every 32-row tile.
+    const int key = (i >> 2) & 3;
+    const unsigned lds0 = (unsigned)(size_t)((lp_lptr)S);
+    unsigned ax[2], aw[2];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+        const int cs = (2 * s_ + h) ^ key;
+        ax[s_] = lds0 + (unsigned)(((wm * 128 + i) * 4 + cs) * 16);
+        aw[s_] = lds0 + (unsigned)((2 * LP_XC + (wn * 32 + i) * 4 + cs) * 16);
+    }
+    const int n_chunks = K / LP_BK;
+    stage(0, 0);
+    if (n_chunks > 1) stage(1, LP_BK);
+    for (int kc = 0; kc < n_chunks; ++kc) {
+        // chunk kc has landed (my share: the counted wait; everybody's: the barrier) and everybody is done reading chunk kc - 1
+        if (kc + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kc + 2 < n_chunks) stage((kc + 2) % LP_STAGES, (kc + 2) * LP_BK);
+        const unsigned sb = (unsigned)((kc % LP_STAGES) * LP_STAGE * 16);
+        u32x4 w_hi[2], w_lo[2], x_hi[2][4], x_lo[2][4];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            const unsigned pw = aw[s_] + sb, px = ax[s_] + sb;
+            w_hi[s_] = lds_read<0>(pw); w_lo[s_] = lds_read<LP_WC * 16>(pw);
+            x_hi[s_][0] = lds_read<0 * 2048>(px); x_lo[s_][0] = lds_read<LP_XC * 16 + 0 * 2048>(px);
+            x_hi[s_][1] = lds_read<1 * 2048>(px); x_lo[s_][1] = lds_read<LP_XC * 16 + 1 * 2048>(px);
+            x_hi[s_][2] = lds_read<2 * 2048>(px); x_lo[s_][2] = lds_read<LP_XC * 16 + 2 * 2048>(px);
+            x_hi[s_][3] = lds_read<3 * 2048>(px); x_lo[s_][3] = lds_read<LP_XC * 16 + 3 * 2048>(px);
+        }
+        // the first k16-step's ten fragments are back when at most the second step's ten reads are outstanding (LDS returns in order)
+        asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(w_hi[0]), "+v"(w_lo[0]), "+v"(x_hi[0][0]), "+v"(x_lo[0][0]), "+v"(x_hi[0][1]), "+v"(x_lo[0][1]),
+                     "+v"(x_hi[0][2]), "+v"(x_lo[0][2]), "+v"(x_hi[0][3]), "+v"(x_lo[0][3]));
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            if (s_ == 1)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w_hi[1]), "+v"(w_lo[1]), "+v"(x_hi[1][0]), "+v"(x_lo[1][0]), "+v"(x_hi[1][1]),
+                             "+v"(x_lo[1][1]), "+v"(x_hi[1][2]), "+v"(x_lo[1][2]), "+v"(x_hi[1][3]), "+v"(x_lo[1][3]));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma_u(w_lo[s_], x_hi[s_][t], acc[t]);          // smallest terms first; 4 independent chains
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma_u(w_hi[s_], x_lo[s_][t], acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma_u(w_hi[s_], x_hi[s_][t], acc[t]);
+        }
+    }
+    // ---- epilogue: lane (j, h) of tile t holds features n = n0 + 32 wn + 8 g + 4 h + e (register 4 g + e) of row m0 + 128 wm + 32 t + j
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const long long m = m0 + wm * 128 + t * 32 + i;
+        if (m >= M) continue;
+        const long long grp = row_bias ? (row_group ? (long long)row_group[m] : m / rows_per_group) : 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * 32 + 8 * g + 4 * h;
+            if (n >= N) continue;                          // N % 4 == 0: a quad is in or out as a whole
+            float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_bias) {
+                const float4 rb = *reinterpret_cast<const float4*>(row_bias + grp * N + n);
+                b4.x += rb.x; b4.y += rb.y; b4.z += rb.z; b4.w += rb.w;
+            }
+            float y[4] = {fmaf(acc[t][4 * g], wscale_inv, b4.x), fmaf(acc[t][4 * g + 1], wscale_inv, b4.y),
+                          fmaf(acc[t][4 * g + 2], wscale_inv, b4.z), fmaf(acc[t][4 * g + 3], wscale_inv, b4.w)};
+            if (act == ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = 0.5f * y[e] * (1.f + erff(y[e] * 0.70710678118654752440f));
+            }
+            if (PLANES_OUT) {
+                uint2 hi, lo;
+                split2h(y[0], y[1], hi.x, lo.x);
+                split2h(y[2], y[3], hi.y, lo.y);
+                *reinterpret_cast<uint2*>(Yh + m * ldy + n) = hi;
+                *reinterpret_cast<uint2*>(Yl + m * ldy + n) = lo;
+            } else {
+                *reinterpret_cast<float4*>(Y + m * ldy + n) = make_float4(y[0], y[1], y[2], y[3]);
+            }
+        }
+    }
+}
+
+// fp32 rows -> fp16 hi/lo planes: P[m][col0 + c] for c < E (E % 4 == 0); one thread per 4 consecutive values
+__global__ void split_to_planes_kernel(const float* __restrict__ X, long long ldx, _Float16* __restrict__ Ph, _Float16* __restrict__ Pl,
+                                       long long ldp, long long M, int E4) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * E4) return;
+    const long long m = idx / E4;
+    const int c = (int)(idx - m * E4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(X + m * ldx + c);
+    uint2 hi, lo;
+    split2h(v.x, v.y, hi.x, lo.x);
+    split2h(v.z, v.w, hi.y, lo.y);
+    *reinterpret_cast<uint2*>(Ph + m * ldp + c) = hi;
+    *reinterpret_cast<uint2*>(Pl + m * ldp + c) = lo;
+}
+
+bool linear3p_applicable(int N, int K, int64_t ldx, int64_t ldw, int64_t ldy) {
+    return K % LP_BK == 0 && K >= LP_BK && N % 4 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 4 == 0;
+}
+
+// Y (fp32, ldy floats) or Yh / Yl (fp16 planes, ldy halves) = act(X W^T * wscale_inv + bias (+ row bias)); exactly one of Y, Yh is set
+void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
+                     const float* bias, float* Y, void* Yh, void* Yl, int64_t ldy, int64_t M, int N, int K, int act, float wscale_inv,
+                     const float* row_bias, int64_t rows_per_group, const int* row_group) {
+    if (M <= 0 || N <= 0) return;
+    static const bool lds_ok = []() {                     // 144 KB of dynamic LDS: opt in once per kernel
+        return hipFuncSetAttribute((const void*)linear3p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)linear3p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES) == hipSuccess;
+    }();
+    if (!lds_ok) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LP_LDS_BYTES); return; }
+    dim3 grid((unsigned)(cdiv(cdiv(M, LP_TM), 8) * 8 * cdiv(N, LP_TN)));          // 1-D: see the XCD-aware block order in the kernel
+    const long long rpg = rows_per_group > 0 ? rows_per_group : 1;
+    if (Yh)
+        hipLaunchKernelGGL((linear3p_kernel<true>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
+                           (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group, (float*)nullptr,
+                           (_Float16*)Yh, (_Float16*)Yl, (long long)ldy, (long long)M, N, K, act, wscale_inv);
+    else
+        hipLaunchKernelGGL((linear3p_kernel<false>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
+                           (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group, Y,
+                           (_Float16*)nullptr, (_Float16*)nullptr, (long long)ldy, (long long)M, N, K, act, wscale_inv);
+}
+
+void launch_split_to_planes(hipStream_t s, const float* X, int64_t ldx, void* Ph, void* Pl, int64_t ldp, int64_t M, int E) {
+    if (M <= 0 || E <= 0) return;
+    const int E4 = E / 4;
+    hipLaunchKernelGGL(split_to_planes_kernel, dim3((unsigned)cdiv(M * E4, 256)), dim3(256), 0, s, X, (long long)ldx, (_Float16*)Ph,
+                       (_Float16*)Pl, (long long)ldp, (long long)M, E4);
+}
+
+}  // namespace mcr

@@ -332,9 +332,12 @@ __device__ long long l6_trace_buf[64];
 #endif
 
 // grid = ceil(S / 4); S sequences of 16 offsets [S,16,3]; features[s*ld_feat + 0:256] = max(128) || avg(128)
+// feat_h != NULL: the pooled features go out as fp16 hi / lo planes (feat_h / feat_l, row stride ld_feat halves) instead of fp32:
+// the head GEMM (linear3p.hip) reads ready-made planes
 __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restrict__ offs, float* __restrict__ feat,
                                                           long long ld_feat, long long S,
-                                                          const float* __restrict__ blob) {
+                                                          const float* __restrict__ blob, _Float16* __restrict__ feat_h,
+                                                          _Float16* __restrict__ feat_l) {
     __shared__ __attribute__((aligned(16))) uint4 P[2 * 64 * 16];
     __shared__ __attribute__((aligned(16))) uint4 H[2 * 64 * 16];
     __shared__ __attribute__((aligned(16))) float2 St[4 * 64];
@@ -613,8 +616,19 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
                 mx = fmaxf(mx, v);
                 sm += v;
             }
-            feat[(s0 + q) * ld_feat + c] = mx;
-            feat[(s0 + q) * ld_feat + 128 + c] = sm * (1.0f / 16.f);
+            const float av = sm * (1.0f / 16.f);
+            if (feat_h) {
+                unsigned hi, lo;
+                split2h(mx, av, hi, lo);
+                const long long o2 = (s0 + q) * ld_feat + c;
+                feat_h[o2] = __builtin_bit_cast(_Float16, (unsigned short)(hi & 0xffffu));
+                feat_h[o2 + 128] = __builtin_bit_cast(_Float16, (unsigned short)(hi >> 16));
+                feat_l[o2] = __builtin_bit_cast(_Float16, (unsigned short)(lo & 0xffffu));
+                feat_l[o2 + 128] = __builtin_bit_cast(_Float16, (unsigned short)(lo >> 16));
+            } else {
+                feat[(s0 + q) * ld_feat + c] = mx;
+                feat[(s0 + q) * ld_feat + 128 + c] = av;
+            }
         }
     }
     L6_T();
@@ -626,10 +640,11 @@ __global__ __launch_bounds__(256, 2) void local_pct6_kernel(const float* __restr
 extern "C" int mcr_dev_read_trace(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(v6::l6_trace_buf), sizeof(long long) * 64); }
 #endif
 
-void launch_local_pct6(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob) {
+void launch_local_pct6(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob, void* feat_h,
+                       void* feat_l) {
     if (S <= 0) return;
     hipLaunchKernelGGL(v6::local_pct6_kernel, dim3((unsigned)cdiv(S, L3_QPB)), dim3(256), 0, s, offs, feat, (long long)ld_feat,
-                       (long long)S, blob);
+                       (long long)S, blob, (_Float16*)feat_h, (_Float16*)feat_l);
 }
 
 int local_pct6_blob_floats() { return L6_BLOB_FLOATS; }

@@ -111,6 +111,55 @@ static void launch_nonfinite_flag(hipStream_t s, const float* x, int64_t n, int*
     hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 1024)), dim3(256), 0, s, x, (long long)n, flag);
 }
 
+// ---- SconeOcc head on fp16 hi/lo planes end to end (variant 6; linear3p.hip): every activation is split once where it is produced
+// (local_pct6's pooled features, the GEMM epilogues), every operand reaches LDS by DMA.  Scratch (the caller's regions, same
+// bytes as the fp32 layout): featP = planes [2][T][1344] fp16, h1P = [2][T][512] fp16 (first used as [2][T][256] for the
+// x-embedding), h2 = fp32 [T][256] (first half first used for xe1's fp32 output, second half for its planes).
+struct HeadScratch { _Float16* featP; _Float16* h1P; float* h2; void* wplanes; };
+static void head_planes_weights(hipStream_t s, int which, const float* W, int64_t ldw, int N, int K, const void* const* head_planes,
+                                const float* head_inv_scales, void* wplanes, const _Float16*& Wh, const _Float16*& Wl, float& inv) {
+    if (head_planes && head_planes[which] && head_inv_scales[which] > 0.f) {
+        Wh = (const _Float16*)head_planes[which];
+        inv = head_inv_scales[which];
+    } else {                                              // no host planes: split here (fixed 2^8 scale, |w| < 255)
+        launch_split_weights(s, W, ldw, wplanes, N, K);
+        Wh = (const _Float16*)wplanes;
+        inv = 1.0f / 256.0f;
+    }
+    Wl = Wh + (size_t)N * K;
+}
+template <class Join>
+static void run_head_planes(hipStream_t s, const float* x, const float* view_harmonics, int64_t T, const LinW& xe1, const LinW& xe2,
+                            const LinW& xe3, const LinW& lin1, const LinW& lin2, const LinW& lin3, const float* gbias,
+                            int64_t rows_per_group, const int* row_group, const void* const* head_planes, const float* head_inv_scales,
+                            const HeadScratch& w, float* out, Join join) {
+    _Float16 *fh = w.featP, *fl = w.featP + (size_t)T * 1344;
+    _Float16 *hh = w.h1P;
+    float* x1 = w.h2;                                                        // fp32 [T][128]
+    _Float16* x1h = reinterpret_cast<_Float16*>(w.h2 + (size_t)T * 128);     // planes [2][T][128]
+    _Float16* x1l = x1h + (size_t)T * 128;
+    const _Float16 *Wh, *Wl;
+    float inv;
+    // x embedding 3 -> 128 -> 256 -> 512, GELU each (SconeOcc.py:35-42)
+    launch_linear(s, x, 3, xe1.w, xe1.b, nullptr, 0, x1, 128, T, 128, 3, ACT_GELU, nullptr, 0, 0, 1);
+    launch_split_to_planes(s, x1, 128, x1h, x1l, 128, T, 128);
+    head_planes_weights(s, 0, xe2.w, 128, 256, 128, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
+    launch_linear3p(s, x1h, x1l, 128, Wh, Wl, 128, xe2.b, nullptr, hh, hh + (size_t)T * 256, 256, T, 256, 128, ACT_GELU, inv, nullptr, 0, nullptr);
+    head_planes_weights(s, 1, xe3.w, 256, 512, 256, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
+    launch_linear3p(s, hh, hh + (size_t)T * 256, 256, Wh, Wl, 256, xe3.b, nullptr, fh + 768, fl + 768, 1344, T, 512, 256, ACT_GELU, inv, nullptr, 0,
+                    nullptr);
+    launch_split_to_planes(s, view_harmonics, 64, fh + 1280, fl + 1280, 1344, T, 64);
+    join();                                               // the global feature (side stream) is needed from here on
+    // head MLP 1856 -> 512 -> 256 -> 1, GELU after every layer incl. the last (SconeOcc.py:334-345); the global 512 columns are gbias
+    head_planes_weights(s, 2, lin1.w + 512, 1856, 512, 1344, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
+    launch_linear3p(s, fh, fl, 1344, Wh, Wl, 1344, lin1.b, nullptr, hh, hh + (size_t)T * 512, 512, T, 512, 1344, ACT_GELU, inv, gbias,
+                    rows_per_group, row_group);
+    head_planes_weights(s, 3, lin2.w, 512, 256, 512, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
+    launch_linear3p(s, hh, hh + (size_t)T * 512, 512, Wh, Wl, 512, lin2.b, w.h2, nullptr, nullptr, 256, T, 256, 512, ACT_GELU, inv, nullptr, 0,
+                    nullptr);
+    launch_linear(s, w.h2, 256, lin3.w, lin3.b, nullptr, 0, out, 1, T, 1, 256, ACT_GELU, nullptr, 0, 0, 1);
+}
+
 }  // namespace mcr
 
 using namespace mcr;
@@ -200,10 +249,11 @@ int mcr_set_local_pct_variant(int v) {
     return 0;
 }
 int mcr_get_local_pct_variant(void) { return g_local_pct_variant; }
-static void run_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld, int64_t S, const float* blob) {
+static void run_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld, int64_t S, const float* blob,
+                          void* feat_h = nullptr, void* feat_l = nullptr) {
     if (g_local_pct_variant == 1) launch_local_pct(s, offs, feat, ld, S, blob);
     else if (g_local_pct_variant == 5) launch_local_pct5(s, offs, feat, ld, S, blob);
-    else launch_local_pct6(s, offs, feat, ld, S, blob);
+    else launch_local_pct6(s, offs, feat, ld, S, blob, feat_h, feat_l);       // planes out (variant 6 only) when feat_h is set
 }
 
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,
@@ -396,6 +446,12 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     // the [Q,16,3] offsets is materialised); layer-by-layer path: chunked over queries to bound its workspace.
     const bool fused_all = local_blobs && local_blobs[0] && local_blobs[1] && local_blobs[2];
     const int64_t qc = fused_all ? Q : std::min<int64_t>(Q, OCC_CHUNK);
+    // variant 6 with all three fused transformers: the head runs on fp16 hi/lo planes end to end (run_head_planes); the feature
+    // buffer then holds planes [2][T][1344] fp16 instead of fp32 [T][1344] (MCR_HEAD_PLANES=0: the fp32-input linear3h path)
+    static const bool planes_on = []() { const char* e = getenv("MCR_HEAD_PLANES"); return !(e && e[0] == '0'); }();
+    const bool planes = planes_on && fused_all && g_local_pct_variant == 6;
+    _Float16* featP = reinterpret_cast<_Float16*>(feat);
+    const int64_t Tall = B * Q;
     for (int sc = 0; sc < 3; ++sc) {
         for (int64_t q0 = 0; q0 < Q; q0 += qc) {
             const int64_t nq = std::min<int64_t>(qc, Q - q0);
@@ -407,7 +463,10 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
                 if (int e = mcr_knn_points(x + (b * Q + q0) * 3, pc_scale[sc] + b * M_scale[sc] * 3, nullptr, nullptr, offs, 1, nq,
                                            M_scale[sc], 16, 1, stream))
                     return e;
-                if (local_blobs && local_blobs[sc])      // fused LDS-resident kernel (local_pct.hip)
+                if (planes)
+                    run_local_pct(s, offs, nullptr, FEAT, nq, local_blobs[sc], featP + (b * Q + q0) * FEAT + sc * 256,
+                                  featP + Tall * FEAT + (b * Q + q0) * FEAT + sc * 256);
+                else if (local_blobs && local_blobs[sc])      // fused LDS-resident kernel (local_pct.hip)
                     run_local_pct(s, offs, feat + (b * Q + q0) * FEAT + sc * 256, FEAT, nq, local_blobs[sc]);
                 else                                      // layer-by-layer path through HBM
                     run_pct(s, wl[sc], offs, feat + (b * Q + q0) * FEAT + sc * 256, FEAT, nq, 16, 128, a);
@@ -436,8 +495,22 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
         else
             launch_linear(s, X_, ldx, W_, b_, nullptr, 0, Y_, ldy, M_, N_, K_, ACT_GELU, rb, rpg, ldw, /*route_rows=*/1);
     };
-    // ---- x embedding 3 -> 128 -> 256 -> 512, GELU each (SconeOcc.py:35-42) ----
     const int64_t T = B * Q;
+    if (planes) {
+        bool join_failed = false;
+        run_head_planes(s, x, view_harmonics, T, xe1, xe2, xe3, lin1, lin2, lin3, gbias, Q, nullptr, head_planes, head_inv_scales,
+                        HeadScratch{featP, reinterpret_cast<_Float16*>(h1), h2, wplanes}, out, [&]() {
+                            if (side) {
+                                side_join.joined = true;
+                                join_failed = hipStreamWaitEvent(s, side->join, 0) != hipSuccess;
+                            }
+                        });
+        MCR_REQUIRE(!join_failed, "mcr_scone_occ_forward: side stream (join)");
+        if (range_flag) launch_nonfinite_flag(s, out, T, range_flag);
+        MCR_LAUNCH_CHECK("mcr_scone_occ_forward");
+        return 0;
+    }
+    // ---- x embedding 3 -> 128 -> 256 -> 512, GELU each (SconeOcc.py:35-42) ----
     launch_linear(s, x, 3, xe1.w, xe1.b, nullptr, 0, h2, 128, T, 128, 3, ACT_GELU, nullptr, 0, 0, 1);
     big_linear(0, h2, 128, xe2.w, 128, xe2.b, h1, 256, T, 256, 128, nullptr, 0);
     big_linear(1, h1, 256, xe3.w, 256, xe3.b, feat + 768, FEAT, T, 512, 256, nullptr, 0);
@@ -530,9 +603,27 @@ int mcr_scone_occ_forward_ragged(const float* pc_global, const int* global_len, 
     // ---- local features: one segmented kNN + one fused transformer launch per scale over ALL rows ----
     float* offs = scratch.f(T * 16 * 3);
     MCR_REQUIRE(scratch.ok(), "mcr_scone_occ_forward_ragged: workspace overflow (kNN)");
+    static const bool planes_on = []() { const char* e = getenv("MCR_HEAD_PLANES"); return !(e && e[0] == '0'); }();
+    const bool planes = planes_on && g_local_pct_variant == 6;
+    _Float16* featP = reinterpret_cast<_Float16*>(feat);
     for (int sc = 0; sc < 3; ++sc) {
         launch_knn16_segmented(s, x, pc_scale[sc], (const long long*)scale_off[sc], knn_blocks, n_blocks, T, offs);
-        run_local_pct(s, offs, feat + sc * 256, FEAT, T, local_blobs[sc]);
+        if (planes) run_local_pct(s, offs, nullptr, FEAT, T, local_blobs[sc], featP + sc * 256, featP + T * FEAT + sc * 256);
+        else run_local_pct(s, offs, feat + sc * 256, FEAT, T, local_blobs[sc]);
+    }
+    if (planes) {
+        bool join_failed = false;
+        run_head_planes(s, x, view_harmonics, T, xe1, xe2, xe3, lin1, lin2, lin3, gbias, 0, row_job, head_planes, head_inv_scales,
+                        HeadScratch{featP, reinterpret_cast<_Float16*>(h1), h2, wplanes}, out, [&]() {
+                            if (side) {
+                                side_join.joined = true;
+                                join_failed = hipStreamWaitEvent(s, side->join, 0) != hipSuccess;
+                            }
+                        });
+        MCR_REQUIRE(!join_failed, "mcr_scone_occ_forward_ragged: side stream (join)");
+        if (range_flag) launch_nonfinite_flag(s, out, T, range_flag);
+        MCR_LAUNCH_CHECK("mcr_scone_occ_forward_ragged");
+        return 0;
     }
     const int variant = g_local_pct_variant;
     const int64_t ANY_M = (int64_t)1 << 40;

@@ -68,7 +68,17 @@ void launch_copy2d(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t
 // `blob` is the host-packed parameter image of one local transformer (local_pct_blob_floats() floats).
 void launch_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);
 void launch_local_pct5(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);   // bf16 hi/mid/lo blob
-void launch_local_pct6(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);   // fp16 hi/lo blob
+// fp16 hi/lo blob; feat_h / feat_l (optional): write the features as fp16 hi/lo planes (row stride ld_feat halves) instead of fp32
+void launch_local_pct6(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob,
+                       void* feat_h = nullptr, void* feat_l = nullptr);
+
+// Head GEMM on operands that already are fp16 hi/lo planes in HBM (linear3p.hip): Y fp32 or Yh / Yl planes = act(X W^T 2^-e + bias ...)
+bool linear3p_applicable(int N, int K, int64_t ldx, int64_t ldw, int64_t ldy);
+void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
+                     const float* bias, float* Y, void* Yh, void* Yl, int64_t ldy, int64_t M, int N, int K, int act, float wscale_inv,
+                     const float* row_bias, int64_t rows_per_group, const int* row_group);
+void launch_split_to_planes(hipStream_t s, const float* X, int64_t ldx, void* Ph, void* Pl, int64_t ldp, int64_t M, int E);
+void launch_split_weights(hipStream_t s, const float* W, int64_t ldw, void* planes, int N, int K);   // linear3h.hip: [2][N][K] fp16 of W * 2^8
 // segmented kNN-16 with query offsets (knn.hip): see launch_knn16_segmented there
 void launch_knn16_segmented(hipStream_t s, const float* X, const float* pc, const long long* pc_off, const int* blocks,
                             int64_t n_blocks, int64_t T, float* offsets_out);
