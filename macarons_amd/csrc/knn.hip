@@ -16,6 +16,7 @@
 //   ascending by (d2, index): ties go to the lower index;  dists = sqrt(d2), correctly rounded.
 // MCR_HIPCC_FLAGS: -ffp-contract=off
 #include "common.h"
+#include <cstdlib>
 
 namespace mcr {
 
@@ -201,9 +202,202 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// K1-mfma: the same search with the distances on the matrix pipe.  A wave owns 32 queries; for 32 candidates at a time two
+// v_mfma_f32_32x32x2_f32 evaluate  s[c][q] = |p_c|^2 - 2 x_q . p_c  (A row c = (p.x, p.y, p.z, |p|^2), B column q =
+// (-2x.x, -2x.y, -2x.z, 1); the fp32 MFMA is bit for bit a k-ordered fmaf chain) -- 1024 candidate-query pairs per 128 pipe
+// cycles, 3.7x the vector form (11 instructions per 64 pairs), and the vector ALU is left with the selection.  Lane (q, h) gets 16
+// of the 32 candidates (rows (r & 3) + 8 (r >> 2) + 4 h) of ITS query, so a query's list is kept in two halves (merged at the
+// end, like the two-wave split of the vector kernel).  s + |x|^2 is NOT the convention's distance (different rounding): it only
+// FILTERS.  A candidate passes when s < tau - |x|^2 + eps (tau = the lane's current, possibly stale, k-th EXACT distance; eps =
+// 2^-20 (|x| + max|p|)^2 covers both forms' rounding 16 times over, so no true neighbour is ever rejected); its index goes to
+// the lane's LDS queue; at a flush the exact (dx^2 + dy^2) + dz^2 is recomputed from the coordinates and inserted with the same
+// strict compare -- the output is bit-identical to the vector kernel's (and oracle/knn.py's).
+constexpr int KM_TILE = 1024;      // candidates per LDS tile (SoA x | y | z | |p|^2: 16 KB)
+constexpr int KM_QCAP = 32;        // queued candidate indices per lane (32 KB as [slot][thread])
+
+template <int K, bool OFFSETS>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_mfma_kernel(const float* __restrict__ X, const float* __restrict__ pc,
+                                                             long long* __restrict__ out_idx, float* __restrict__ out_dist,
+                                                             float* __restrict__ out_pts, int Q, int M, const int4* __restrict__ blocks,
+                                                             const long long* __restrict__ pc_off) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    __shared__ __attribute__((aligned(16))) float s_p[4][KM_TILE];           // x | y | z | |p|^2
+    __shared__ int s_q[KM_QCAP * KNN_BLOCK];                                  // queue; reused as the merge buffer
+    __shared__ unsigned s_pmax;
+    static_assert(2 * K * 128 * 2 <= KM_QCAP * KNN_BLOCK, "merge buffer does not fit");
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & (MCR_WAVE - 1), wave = threadIdx.x / MCR_WAVE;
+    const int j = lane & 31, h = lane >> 5;
+    int q_first = blockIdx.x * 128, q_end = Q;
+    const float* pcb = pc + (size_t)b * M * 3;
+    if (blocks) {                                  // segmented form: see knn_kernel
+        const int4 bk = blocks[blockIdx.x];
+        q_first = bk.y; q_end = bk.y + bk.z;
+        pcb = pc + (size_t)pc_off[bk.x] * 3;
+        M = (int)(pc_off[bk.x + 1] - pc_off[bk.x]);
+    }
+    const int q = q_first + wave * 32 + j;
+    const bool valid = q < q_end;
+    const float* xq = X + ((size_t)b * Q + (valid ? q : q_end - 1)) * 3;
+    const float qx = xq[0], qy = xq[1], qz = xq[2];
+    const float q2 = (qx * qx + qy * qy) + qz * qz, qn = sqrtf(q2);
+    const float b0 = h ? -2.f * qy : -2.f * qx, b1 = h ? 1.f : -2.f * qz;
+
+    float bd[K];
+    int bi[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) { bd[r] = __builtin_inff(); bi[r] = 0x7fffffff; }
+    float tau = __builtin_inff(), thr = __builtin_inff(), eps = 0.f;
+    int cnt = 0, t0 = 0;
+    int* qi = s_q + threadIdx.x;
+    auto flush = [&]() {                           // exact distances of the queued candidates (their tile is still in LDS), insertion
+        int maxc = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
+        for (int sidx = 0; sidx < maxc; ++sidx)
+            if (sidx < cnt) {
+                const int idx = qi[sidx * KNN_BLOCK], li = idx - t0;
+                const float d = knn_d2(qx, qy, qz, make_float4(s_p[0][li], s_p[1][li], s_p[2][li], 0.f));
+                knn_insert<K>(bd, bi, d, idx);
+            }
+        tau = bd[K - 1];
+        thr = (tau - q2) + eps;
+        cnt = 0;
+    };
+    for (t0 = 0; t0 < M; t0 += KM_TILE) {
+        const int nt = min(KM_TILE, M - t0);
+        const int nt_pad = (nt + 31) & ~31;
+        __syncthreads();                           // the previous tile (fragments and flushes) is done with
+        if (threadIdx.x == 0) s_pmax = 0u;
+        __syncthreads();
+        float pm = 0.f;
+        for (int i = threadIdx.x; i < nt_pad; i += KNN_BLOCK) {
+            float x = 3e18f, y = 3e18f, z = 3e18f;                            // padding: far away, never passes the filter
+            if (i < nt) { const float* p = pcb + (size_t)(t0 + i) * 3; x = p[0]; y = p[1]; z = p[2]; }
+            const float pn = (x * x + y * y) + z * z;
+            s_p[0][i] = x; s_p[1][i] = y; s_p[2][i] = z; s_p[3][i] = pn;
+            if (i < nt) pm = fmaxf(pm, pn);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o, 64));
+        if (lane == 0) atomicMax(&s_pmax, __builtin_bit_cast(unsigned, pm));  // non-negative floats order like their bit patterns
+        __syncthreads();
+        {
+            const float pmax = sqrtf(__builtin_bit_cast(float, s_pmax)), e = qn + pmax;
+            eps = 9.5367431640625e-07f * (e * e);                             // 2^-20 (|x| + max |p|)^2
+            thr = (tau - q2) + eps;
+        }
+        const float* a0p = s_p[h ? 1 : 0] + j;
+        const float* a1p = s_p[h ? 3 : 2] + j;
+        for (int c0 = 0; c0 < nt_pad; c0 += 32) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0p[c0], b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1p[c0], b1, acc, 0, 0, 0);
+            float m = fminf(fminf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) m = fminf(fminf(m, acc[r]), acc[r + 1]);
+            m = fminf(m, acc[15]);
+            if (__any(m < thr)) {
+                // Some lane of the wave passes in nearly every tile (64 lanes x 16 candidates), so this path has to be cheap: sixteen
+                // predicated pushes cost ~12 instructions each (exec-mask juggling per branch: 0.36 of the kernel's 0.64 ms at Q = 100k,
+                // M = 10 240).  Instead: the lane's 16-bit mask of passing candidates, branch-free, then one push per SET BIT in a loop
+                // that runs as long as any lane has bits left (typically one or two rounds).
+                unsigned mask = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mask |= (acc[r] < thr ? 1u : 0u) << r;
+                const int base = t0 + c0 + 4 * h;
+                while (__any(mask != 0u)) {
+                    if (mask != 0u) {
+                        const int r = __builtin_ctz(mask);
+                        qi[cnt * KNN_BLOCK] = base + (r & 3) + 8 * (r >> 2);
+                        ++cnt;
+                        mask &= mask - 1;
+                    }
+                }
+                if (__any(cnt > KM_QCAP - 16)) flush();
+            }
+        }
+        flush();
+    }
+    // ---- merge of the two half lists of every query (lexicographic on (d2, index)) ----------------------------
+    __syncthreads();
+    float* m_d = reinterpret_cast<float*>(s_q);                         // [half][K][128 queries of the block]
+    int* m_i = s_q + 2 * K * 128;
+    const int ql = wave * 32 + j;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        m_d[(h * K + r) * 128 + ql] = bd[r];
+        m_i[(h * K + r) * 128 + ql] = bi[r];
+    }
+    __syncthreads();
+    // every lane takes part from here on (the staging below has barriers); the merge itself runs on the h == 0 lanes
+    int head[2] = {0, 0};
+    const size_t o = ((size_t)b * Q + q) * K;
+    int mi[K];                                     // merged neighbour indices of this lane's query (h == 0 lanes)
+    if (h == 0) {
+        for (int r = 0; r < K; ++r) {
+            float best_d = __builtin_inff();
+            int best_i = 0x7fffffff, best_w = 0;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int hd = head[w] < K ? head[w] : K - 1;
+                const float d = head[w] < K ? m_d[(w * K + hd) * 128 + ql] : __builtin_inff();
+                const int id = head[w] < K ? m_i[(w * K + hd) * 128 + ql] : 0x7fffffff;
+                const bool better = d < best_d || (d == best_d && id < best_i);
+                best_d = better ? d : best_d;
+                best_i = better ? id : best_i;
+                best_w = better ? w : best_w;
+            }
+            head[0] += best_w == 0 ? 1 : 0;
+            head[1] += best_w == 1 ? 1 : 0;
+            mi[r] = best_i;
+            if (valid) {
+                if (out_idx) out_idx[o + r] = (long long)best_i;
+                if (out_dist) out_dist[o + r] = sqrt_cr(best_d);
+            }
+        }
+    }
+    // ---- the neighbour coordinates leave through LDS: a block's 128 queries x K x 3 floats are ONE contiguous range of out_pts,
+    // written as whole 16-byte chunks by all 256 threads (a lane storing its own 48 floats 12 bytes at a time at a 192-byte
+    // stride was ~65 us of every launch: more than the whole search at M = 126)
+    __syncthreads();                               // the merge buffer is read: s_p / s_q may be reused
+    float* st = reinterpret_cast<float*>(s_q);     // [128 queries][K][3]  (K = 16: 24 KB <= 32 KB)
+    if (h == 0) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int id = mi[r] == 0x7fffffff ? 0 : mi[r];
+            const float* p = pcb + (size_t)id * 3;
+            st[(ql * K + r) * 3 + 0] = OFFSETS ? p[0] - qx : p[0];
+            st[(ql * K + r) * 3 + 1] = OFFSETS ? p[1] - qy : p[1];
+            st[(ql * K + r) * 3 + 2] = OFFSETS ? p[2] - qz : p[2];
+        }
+    }
+    __syncthreads();
+    const int n_valid = max(0, min(128, q_end - q_first));                      // queries of this block
+    const int n_f = n_valid * K * 3;
+    float* dst = out_pts + ((size_t)b * Q + q_first) * K * 3;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        for (int c = threadIdx.x; c * 4 + 3 < n_f; c += KNN_BLOCK) reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(st)[c];
+        for (int e = (n_f & ~3) + threadIdx.x; e < n_f; e += KNN_BLOCK) dst[e] = st[e];
+    } else {
+        for (int e = threadIdx.x; e < n_f; e += KNN_BLOCK) dst[e] = st[e];
+    }
+}
+
 template <int K>
 static void launch_knn(bool offsets, dim3 grid, hipStream_t s, const float* X, const float* pc, long long* idx, float* dist,
                        float* pts, int Q, int M, const int4* blocks = nullptr, const long long* pc_off = nullptr) {
+    static const bool use_mfma = []() { const char* e = getenv("MCR_KNN_MFMA"); return !(e && e[0] == '0'); }();   // dev A/B knob
+    if (use_mfma) {                                // distances on the matrix pipe (bit-identical results); same grid: 128 queries per block
+        if (offsets)
+            hipLaunchKernelGGL((knn_mfma_kernel<K, true>), grid, dim3(KNN_BLOCK), 0, s, X, pc, idx, dist, pts, Q, M, blocks, pc_off);
+        else
+            hipLaunchKernelGGL((knn_mfma_kernel<K, false>), grid, dim3(KNN_BLOCK), 0, s, X, pc, idx, dist, pts, Q, M, blocks, pc_off);
+        return;
+    }
     if (offsets)
         hipLaunchKernelGGL((knn_kernel<K, true>), grid, dim3(KNN_BLOCK), 0, s, X, pc, idx, dist, pts, Q, M, blocks, pc_off);
     else
