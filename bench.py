@@ -67,16 +67,23 @@ def cpu_baseline(pts, harm, cams):
     from oracle import cport
     p, h, c = pts.cpu().numpy(), harm.cpu().numpy(), cams.cpu().numpy()
     N, C_sample = p.shape[1], c.shape[1]
-    cport.set_threads(os.cpu_count() or 1)                # every host core (work items = camera x point chunk: 2600 at the headline size)
     cport.coverage_gain(p[:, :256], h[:, :256], c)        # warm-up / build
-    reps, t0 = 0, time.perf_counter()
-    while True:                                           # ~10 s of CPU work, at least one full pass
-        g, nthreads = cport.coverage_gain(p, h, c)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > 10.0 or reps >= 50:
-            break
-    return {"value": reps * C_sample / dt, "unit": "evals/s", "cores": int(nthreads), "kind": "port",
+    # every host core, and one thread per physical core (SMT siblings share the FP units: 256 threads measured SLOWER than 128 on
+    # the 2 x 64-core host); ~5 s of CPU work each, the better one is the baseline, both are reported
+    runs = []
+    for nt_req in sorted({os.cpu_count() or 1, max(1, (os.cpu_count() or 2) // 2)}, reverse=True):
+        cport.set_threads(nt_req)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            g, nthreads = cport.coverage_gain(p, h, c)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > 5.0 or reps >= 50:
+                break
+        runs.append({"threads": int(nthreads), "evals_per_s": reps * C_sample / dt, "passes": reps, "wall_s": dt})
+    best = max(runs, key=lambda r_: r_["evals_per_s"])
+    reps, dt, nthreads = best["passes"], best["wall_s"], best["threads"]
+    return {"value": best["evals_per_s"], "unit": "evals/s", "cores": int(nthreads), "thread_sweep": runs, "kind": "port",
             "sample": f"C port (oracle/csrc/scorer_port.c, OpenMP) of the reference scorer on the same cloud: "
                       f"N={N} points x {C_sample} cameras x {reps} passes, {dt:.2f} s wall; "
                       f"`cores` = omp_get_num_threads() inside the parallel region; host has {os.cpu_count()} cores"}, g
@@ -176,7 +183,7 @@ def measure_nbv_step(dev, rank, world, args):
             torch.distributed.barrier()
         t0 = time.perf_counter()
         r = nbv_step(occ, vis, pc, X, X_view, cams, grid, occ_perms=perms, samples=u, group=group)
-        int(r["nbv_idx"])                                  # the decision reaches the host
+        int(r["host"]["nbv_idx"][0]) if "host" in r else int(r["nbv_idx"])     # the decision reaches the host (with the range flag: one read-back)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:

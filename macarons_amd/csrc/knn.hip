@@ -250,6 +250,10 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_mfma_kernel(const float* __rest
     for (int r = 0; r < K; ++r) { bd[r] = __builtin_inff(); bi[r] = 0x7fffffff; }
     float tau = __builtin_inff(), thr = __builtin_inff(), eps = 0.f;
     int cnt = 0, t0 = 0;
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    asm volatile("" : "+v"(zero));                 // keep it in registers (not rematerialised as 16 moves per tile)
     int* qi = s_q + threadIdx.x;
     auto flush = [&]() {                           // exact distances of the queued candidates (their tile is still in LDS), insertion
         int maxc = cnt;
@@ -291,30 +295,26 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_mfma_kernel(const float* __rest
         const float* a0p = s_p[h ? 1 : 0] + j;
         const float* a1p = s_p[h ? 3 : 2] + j;
         for (int c0 = 0; c0 < nt_pad; c0 += 32) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0p[c0], b0, acc, 0, 0, 0);
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0p[c0], b0, zero, 0, 0, 0);     // C = a register set that stays zero
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1p[c0], b1, acc, 0, 0, 0);
-            float m = fminf(fminf(acc[0], acc[1]), acc[2]);
+            // Some lane of the wave passes in nearly every tile (64 lanes x 16 candidates), so the per-tile selection has to be cheap.
+            // The lane's 16-bit mask of passing candidates is built branch-free from the SIGN of s - thr, two instructions per
+            // candidate (v_sub_f32, v_alignbit_b32 shifting the sign bit in; bit 15 - r = candidate r; s == thr may pass as -0:
+            // harmless, the exact compare follows); then one push per SET BIT in a loop that runs while any lane has bits left
+            // (one or two rounds).  Sixteen predicated pushes cost ~12 instructions each (exec-mask juggling per branch): 0.36 of
+            // 0.64 ms at Q = 100k, M = 10 240.
+            unsigned mask = 0;
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) m = fminf(fminf(m, acc[r]), acc[r + 1]);
-            m = fminf(m, acc[15]);
-            if (__any(m < thr)) {
-                // Some lane of the wave passes in nearly every tile (64 lanes x 16 candidates), so this path has to be cheap: sixteen
-                // predicated pushes cost ~12 instructions each (exec-mask juggling per branch: 0.36 of the kernel's 0.64 ms at Q = 100k,
-                // M = 10 240).  Instead: the lane's 16-bit mask of passing candidates, branch-free, then one push per SET BIT in a loop
-                // that runs as long as any lane has bits left (typically one or two rounds).
-                unsigned mask = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mask |= (acc[r] < thr ? 1u : 0u) << r;
+            for (int r = 0; r < 16; ++r)
+                mask = __builtin_amdgcn_alignbit(mask, __builtin_bit_cast(unsigned, acc[r] - thr), 31);
+            if (__any(mask != 0u)) {
                 const int base = t0 + c0 + 4 * h;
                 while (__any(mask != 0u)) {
                     if (mask != 0u) {
-                        const int r = __builtin_ctz(mask);
+                        const int pbit = 31 - __builtin_clz(mask), r = 15 - pbit;    // highest bit = lowest candidate first: ties keep index order
                         qi[cnt * KNN_BLOCK] = base + (r & 3) + 8 * (r >> 2);
                         ++cnt;
-                        mask &= mask - 1;
+                        mask &= ~(1u << pbit);
                     }
                 }
                 if (__any(cnt > KM_QCAP - 16)) flush();

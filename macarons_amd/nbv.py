@@ -46,13 +46,20 @@ def _guarded(impl, scone_occ, range_guard, group, draws):
             world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
             if world > 1:
                 flag = mdist.all_reduce_max(flag, group)
-            if int(flag):                                  # the one read-back, after the last kernel of the decision was queued
+            # the one read-back, after the last kernel of the decision was queued; the decision itself rides along (a caller that
+            # wants the camera index on the host reads out["host"]["nbv_idx"] instead of paying a second device->host round trip)
+            both = torch.cat((flag.to(out["nbv_idx"].device).view(-1).to(torch.float64), out["nbv_idx"].view(-1).to(torch.float64),
+                              out["max_gain"].view(-1).to(torch.float64))).cpu()
+            n_dec = out["nbv_idx"].numel()
+            out["host"] = {"nbv_idx": both[1:1 + n_dec].to(torch.int64), "max_gain": both[1 + n_dec:].to(torch.float32)}
+            if int(both[0]):
                 L.mcr_set_local_pct_variant(5)
                 try:
                     out = impl(**kw)
                 finally:
                     L.mcr_set_local_pct_variant(6)
                 out["range_flag"], out["fallback_variant"] = None, 5
+                out.pop("host", None)
     finally:
         scone_occ.range_guard = prev
     return out

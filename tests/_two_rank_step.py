@@ -101,6 +101,21 @@ def main():
     expect(torch.equal(r["occ"], s_b1["occ"]) and torch.equal(r["gains"], s_b1["gains"][:, c0:c1]), "D shards")
     expect(torch.equal(r["max_gain"], s_b1["max_gain"]) and torch.equal(r["nbv_idx"], s_b1["nbv_idx"]), "D decision")
     expect(torch.equal(s_b1["max_gain"], s_b3["max_gain"][:1]) and torch.equal(s_b1["occ"], s_b3["occ"][:1]), "D batch-of-1 == first of 3")
+    # F: BASELINE config 4's scorer shape on two ranks: 100 000 points x 512 cameras, 256 cameras per rank, the decision through the
+    # record exchange == the 1-rank arg-max over all 512
+    from macarons_amd import ops
+    from macarons_amd import dist as mdist
+    gen = torch.Generator().manual_seed(404)
+    pts4 = torch.cat([torch.rand(1, 100_000, 3, generator=gen) - 0.5, 0.1 + 0.9 * torch.rand(1, 100_000, 1, generator=gen)], -1).to(dev)
+    harm4 = (torch.randn(1, 100_000, 64, generator=gen) * 0.5).to(dev)
+    cams4 = torch.randn(1, 512, 3, generator=gen)
+    cams4 = (1.5 * cams4 / cams4.norm(dim=-1, keepdim=True)).to(dev)
+    full = ops.sh_coverage_gain(pts4, harm4, cams4)
+    c0, c1 = mdist.shard_range(512, rank, 2)
+    mine4 = ops.sh_coverage_gain(pts4, harm4, cams4[:, c0:c1].contiguous())
+    v4, i4 = mdist.allgather_best(mine4, c0)
+    ref4 = torch.max(full, dim=1)
+    expect(torch.equal(mine4, full[:, c0:c1]) and torch.equal(v4, ref4.values) and torch.equal(i4, ref4.indices), "F config-4 scorer shards")
     # E: hidden draws (nothing pinned): rank 0's reach rank 1 -> identical decisions on both ranks, single-cloud and batch
     torch.manual_seed(100 + rank)                                        # the ranks' own generators disagree on purpose
     r1 = nbv_step(*a2)

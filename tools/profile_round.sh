@@ -1,15 +1,18 @@
 #!/bin/bash
-# Round profile on the GPU box: bench line, rocprofv3 kernel stats of the same command, PMC passes (own runs, --pmc only)
-# for the scorer, the fused local transformer and the head GEMM.  Outputs under gpurun_out/round/ (copy the summaries into profiles/).
+# Round profile on the GPU box: bench line, rocprofv3 kernel stats of the same command, per-kernel time inside the median NBV step,
+# PMC passes (own runs, --pmc only) for the scorer, the fused local transformer, the head GEMM and the kNN, power telemetry.
+# Outputs under gpurun_out/round/ (copy the summaries into profiles/ with the round's prefix).
 R=/root/repo
 OUT=$R/gpurun_out/round
 mkdir -p $OUT
 cd $R && python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats -o bench -- python $R/bench.py --steps 500 --warmup 100 --no-cpu-baseline --nbv-iters 20 > $OUT/kstats.log 2>&1
+timeout -s KILL 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats -o bench -- python $R/bench.py --steps 500 --warmup 100 --no-cpu-baseline --nbv-iters 20 > $OUT/kstats.log 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_scorer -o bench -- python $R/bench.py --steps 500 --warmup 100 --no-cpu-baseline --no-nbv --no-strong > $OUT/kstats_scorer.log 2>&1
-timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/ktrace -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --nbv-iters 20 > /dev/null 2>&1
-python $R/tools/trace_gaps.py $OUT/ktrace/t_kernel_trace.csv > $OUT/nbv_gaps.txt 2>&1
+rm -rf $OUT/ktrace; timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/ktrace -o t -- python $R/tools/run_nbv_steps.py 40 > $OUT/ktrace.log 2>&1
+T=$(find $OUT/ktrace -name "*kernel_trace.csv" | head -1)
+python $R/tools/step_breakdown.py $T > $OUT/nbv_step_breakdown.txt 2>&1
+python $R/tools/trace_gaps.py $T > $OUT/nbv_gaps.txt 2>&1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU_TRANS_F32" \
            "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
@@ -33,5 +36,7 @@ print(json.dumps(res)[:600])
 PY
 VARIANT=6 $R/tools/pmc_local_pct.sh > $OUT/local_pct6_pmc.txt 2>&1
 VARIANT=6 $R/tools/pmc_local_pct_mem.sh >> $OUT/local_pct6_pmc.txt 2>&1
-rm -rf $R/gpurun_out/pmc_generic; KERNEL=linear3h_kernel $R/tools/pmc_generic.sh python $R/tools/time_networks.py > $OUT/linear3h_pmc.txt 2>&1
-grep -c . $OUT/local_pct6_pmc.txt $OUT/linear3h_pmc.txt
+rm -rf $R/gpurun_out/pmc_generic; KERNEL=linear3p_kernel $R/tools/pmc_generic.sh python $R/tools/run_nbv_steps.py 12 > $OUT/linear3p_pmc.txt 2>&1
+rm -rf $R/gpurun_out/pmc_generic; MS=10240 KERNEL=knn_mfma_kernel $R/tools/pmc_generic.sh python $R/tools/time_knn.py > $OUT/knn_pmc.txt 2>&1
+cd $R && python tools/power_trace.py > $OUT/power_trace.txt 2>&1
+grep -c . $OUT/local_pct6_pmc.txt $OUT/linear3p_pmc.txt $OUT/knn_pmc.txt $OUT/power_trace.txt
