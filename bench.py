@@ -422,6 +422,15 @@ def timed_scorer_loop(step, finish, steps, warmup, dev, dist):
     (wall seconds = max over ranks, device ms between HIP events on the launch stream)."""
     for _ in range(warmup):
         step()
+    # The W warm-up steps of a short run (the driver's --steps 20 --warmup 5 = 0.3 ms of GPU work) end before the shader clock has
+    # left its idle state: keep issuing UNTIMED steps until the GPU has been busy for ~50 ms, so that the K timed steps measure the
+    # kernel and not the clock ramp (a 2000-step run is unaffected: its warm-up is long enough anyway)
+    t_w = time.perf_counter()
+    torch.cuda.synchronize()
+    while time.perf_counter() - t_w < 0.05:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
     finish(None)
     torch.cuda.synchronize()
     if dist is not None:
