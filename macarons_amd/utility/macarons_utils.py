@@ -260,6 +260,36 @@ def _lin(idx3, gw, gh):
     return (idx3[..., 0] * gw + idx3[..., 1]) * gh + idx3[..., 2]
 
 
+def _grid_tables(scene, device):
+    """What never changes for a scene grid, built once and kept on the scene object: the cell keys in linear-id (= lexicographic)
+    order, key -> linear id, every cell's 27-neighbourhood (clamped, unique, sorted: get_neighboring_cells), and device tables of
+    the cell centres and box diagonals."""
+    tab = getattr(scene, "_mcr_grid_tables", None)
+    if tab is not None and tab["device"] == str(device):
+        return tab
+    gl, gw, gh = scene.grid_l, scene.grid_w, scene.grid_h
+    parse = lambda k: tuple(int(v) for v in k.strip("[]").split(","))
+    keys = sorted(scene.cells.keys(), key=parse)
+    lin_of = {k: (parse(k)[0] * gw + parse(k)[1]) * gh + parse(k)[2] for k in keys}
+    by_lin = {lin_of[k]: scene.cells[k] for k in keys}
+    n_cells = gl * gw * gh
+
+    def neigh(c):
+        i, j, k = c // (gw * gh), (c // gh) % gw, c % gh
+        return sorted({(min(max(i + a, 0), gl - 1) * gw + min(max(j + b, 0), gw - 1)) * gh + min(max(k + d, 0), gh - 1)
+                       for a in (-1, 0, 1) for b in (-1, 0, 1) for d in (-1, 0, 1)})
+    order = [by_lin[c] for c in range(n_cells)]
+    centers = torch.stack([c.center.reshape(3) for c in order]).to(device)
+    diag = torch.linalg.norm(torch.stack([c.x_max.reshape(3) for c in order]) - torch.stack([c.x_min.reshape(3) for c in order]), dim=1).to(device)
+    tab = {"device": str(device), "keys": keys, "lin_of": lin_of, "neighbours": [neigh(c) for c in range(n_cells)], "centers": centers,
+           "diag": diag}
+    try:
+        scene._mcr_grid_tables = tab
+    except Exception:
+        pass
+    return tab
+
+
 def compute_scene_occupancy_probability_field(params, macarons, camera, surface_scene, proxy_scene, device,
                                               use_supervision_occ_mask=True, prediction_camera=None,
                                               use_supervision_occ_instead_of_predicted=False, chunk=20000):
@@ -294,13 +324,15 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
     Mv = _world_to_view_matrix(prediction_camera).to(device=device, dtype=torch.float32).contiguous()
     # ---- per proxy point: the cell its coordinates fall in (which cells are visited, :1434) and the cell whose store holds it
     cell_by_pos = _lin(ps.get_cells_for_each_pt(ps.proxy_points), gw, gh)
-    keys = sorted(ps.cells.keys(), key=lambda k: tuple(int(v) for v in k.strip("[]").split(",")))     # lexicographic = linear id order
-    lin_of = {k: (lambda t: (t[0] * gw + t[1]) * gh + t[2])(tuple(int(v) for v in k.strip("[]").split(","))) for k in keys}
+    tab = _grid_tables(ps, device)                       # static per scene: cells in linear-id order, their centres / diagonals, 27-neighbourhoods
+    keys, lin_of = tab["keys"], tab["lin_of"]
     stored_cell = torch.full((P,), -1, dtype=torch.int64, device=device)
-    for k in keys:
-        c = ps.cells[k]
-        if c.cell_pts.shape[0] > 0:
-            stored_cell[c.cell_features[:, 0].long()] = lin_of[k]
+    filled = [k for k in keys if ps.cells[k].cell_pts.shape[0] > 0]
+    if filled:                                           # every stored index -> its cell, three launches for the whole grid
+        idx_all = torch.cat([ps.cells[k].cell_features[:, 0] for k in filled]).long()
+        lens = torch.tensor([ps.cells[k].cell_pts.shape[0] for k in filled], dtype=torch.int64)
+        lins = torch.tensor([lin_of[k] for k in filled], dtype=torch.int64)
+        stored_cell[idx_all] = torch.repeat_interleave(lins, lens).to(device)
     sel = stored_cell >= 0
     if use_supervision_occ_mask:
         sel = sel & occ_mask
@@ -310,18 +342,14 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
                                                                                    torch.ones_like(stored_cell))
     host = torch.stack((visit[:n_cells], counts[:n_cells])).cpu().numpy()                        # the one read-back of the pass
     # ---- host: which cells run, their surface neighbourhoods (sizes are tensor shapes: no read-back), the (cell, chunk) jobs
-    s_keys = sorted(ss.cells.keys(), key=lambda k: lin_of.get(k, 0))
+    s_keys = keys if set(ss.cells.keys()) == set(keys) else sorted(ss.cells.keys(), key=lambda k: lin_of.get(k, 0))
     s_len = {lin_of[k]: int(ss.cells[k].cell_pts.shape[0]) for k in s_keys}
     s_start, o = {}, 0
     for k in s_keys:
         s_start[lin_of[k]] = o
         o += s_len[lin_of[k]]
 
-    def neighbours(c):
-        i, j, k = c // (gw * gh), (c // gh) % gw, c % gh
-        out = {(min(max(i + a, 0), gl - 1) * gw + min(max(j + b, 0), gw - 1)) * gh + min(max(k + d, 0), gh - 1)
-               for a in (-1, 0, 1) for b in (-1, 0, 1) for d in (-1, 0, 1)}
-        return sorted(out)
+    neighbours = tab["neighbours"].__getitem__
     jobs, seg_src, seg_len = [], [], []                 # job = (cell, number of queries); surface segments in job order
     valid_cell = torch.zeros(n_cells + 1, dtype=torch.bool)
     for c in range(n_cells):
@@ -360,11 +388,7 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
         cloud_of = torch.repeat_interleave(jid, job_m, output_size=tot).to(torch.int32)
         row_job = torch.repeat_interleave(jid, job_q, output_size=T).to(torch.int32)
         # ---- prediction boxes: cell centres in view space, 1 / (neighbourhood size x cell diagonal)   (:1468-1478)
-        by_lin = {lin_of[k]: ps.cells[k] for k in keys}
-        cells_in_order = [by_lin[c] for c, _, _ in jobs]
-        centers_w = torch.stack([c.center.reshape(3) for c in cells_in_order]).to(device)
-        diag = torch.linalg.norm(torch.stack([c.x_max.reshape(3) for c in cells_in_order])
-                                 - torch.stack([c.x_min.reshape(3) for c in cells_in_order]), dim=1).to(device)
+        centers_w, diag = tab["centers"][job_cell], tab["diag"][job_cell]               # per job, gathered from the per-scene tables
         centers = (torch.cat((centers_w, torch.ones(J, 1, device=device)), 1) @ Mv)[:, :3].contiguous()
         inv_diag = (1.0 / (params.prediction_neighborhood_size * diag)).float().contiguous()
         MvJ = Mv.reshape(1, 16).expand(J, -1).contiguous()

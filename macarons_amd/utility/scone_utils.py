@@ -23,8 +23,20 @@ def _lattice(n_elev, n_azim, elev_span, azim_span):
     return rows.repeat_interleave(n_azim).float(), cols.repeat(n_elev).float()
 
 
+_harm_tables = {}
+
+
 def get_all_harmonics_under_degree(degree, n_elev, n_azim, device):
-    """-> (z [degree^2, n_elev*n_azim], h_polar, h_azim); elevation-major grid (scone_utils.py:714-738)."""
+    """-> (z [degree^2, n_elev*n_azim], h_polar, h_azim); elevation-major grid (scone_utils.py:714-738).  The lattice is a constant
+    of (degree, n_elev, n_azim): built once per device (upstream rebuilds it -- ~70 small launches -- on every call)."""
+    key = (degree, n_elev, n_azim, str(device))
+    hit = _harm_tables.get(key)
+    if hit is None:
+        hit = _harm_tables[key] = _all_harmonics_under_degree(degree, n_elev, n_azim, device)
+    return hit
+
+
+def _all_harmonics_under_degree(degree, n_elev, n_azim, device):
     h_elev, h_azim = (t.to(device) for t in _lattice(n_elev, n_azim, np.pi, 2 * np.pi))
     h_polar = -h_elev + np.pi / 2
     z = torch.cat([get_spherical_harmonics(l, h_polar, h_azim) for l in range(degree)], dim=-1)
