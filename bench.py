@@ -622,6 +622,12 @@ def main():
     sys.stdout.flush()
     if line is not None:
         print(line, flush=True)
+    if dist is not None:
+        # librccl prints its version banner to stdout when the process winds down (after destroy_process_group, on every rank):
+        # leave without running the exit handlers so that rank 0's JSON stays the LAST line of the job's output
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
