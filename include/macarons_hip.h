@@ -59,6 +59,15 @@ int mcr_sh_visibilities(const float* pts, int pts_dim, const float* harmonics, c
 int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B, int64_t Q,
                    int64_t M, int k, int subtract_query, void* stream);
 
+/* The same search with a scratch buffer (mcr_knn_grid_workspace_bytes(B, Q, M) bytes, device): for k = 16 and 1024 <= M <= 16384 the
+ * candidates are counting-sorted into a 16^3 Morton grid, the queries into a 32^3 one, and a wave visits only the 32-candidate
+ * sub-tiles whose bounding box can still hold one of its queries' 16 nearest points -- outputs IDENTICAL to mcr_knn_points (same
+ * exact fp32 distances, same (distance, index) order); any other shape runs mcr_knn_points itself.  Nothing upstream corresponds to
+ * the pruning: torch.cdist + topk (utils.py:1497-1509) is brute force. */
+size_t mcr_knn_grid_workspace_bytes(int64_t B, int64_t Q, int64_t M);
+int mcr_knn_points_grid(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B, int64_t Q, int64_t M,
+                        int k, int subtract_query, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K4/K5 building blocks (macarons/networks/Attention.py) -------------------------------------------
  * mcr_linear: nn.Linear (+ optional exact-erf GELU, + optional residual add):
  *   Y[m*ldy+n] = act(sum_k X[m*ldx+k] * W[n*K+k] + bias[n]) + residual[m*ldr+n]     (Attention.py:98-103,186-188,232-235)

@@ -15,7 +15,8 @@
 //   d2 = (dx*dx + dy*dy) + dz*dz in fp32 with every product and sum rounded (no FMA contraction),
 //   ascending by (d2, index): ties go to the lower index;  dists = sqrt(d2), correctly rounded.
 // MCR_HIPCC_FLAGS: -ffp-contract=off
-#include "common.h"
+#include "nn_kernels.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace mcr {
@@ -387,6 +388,528 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_mfma_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// K1-grid (default for 1024 <= M <= 16384, k = 16): the same exact search, but a wave only LOOKS at the candidates near its queries.
+//
+// The brute-force kernels evaluate all Q M pairs (1.02 G at Q = 100k, M = 10 240) although a query's 16 neighbours sit within
+// ~7 % of the cloud's extent.  Here (i) the candidates are counting-sorted by the Hilbert index of their cell in a 16^3 grid over
+// the cloud's bounding box (kg_build_cloud_kernel: one workgroup per cloud, LDS counters) into an array of float4 (x, y, z, original
+// index), cut into SUB-TILES of 32 consecutive candidates with their bounding boxes; (ii) the queries are counting-sorted the same
+// way on a 32^3 grid over THEIR bounding box (kg_q*: once per SconeOcc forward, shared by the three scales), so that a wave's 32
+// queries are neighbours in space; (iii) a wave computes the box of its queries, seeds its lists from the four sub-tiles nearest
+// to it, and then visits only sub-tiles whose box-to-box lower bound lb does not exceed R^2 = the largest current 16th distance
+// among its queries (three rounds, lb <= R^2/8, <= 0.4 R^2, <= R^2, the lists -- and R -- tightening in between).  A sub-tile is
+// processed like the brute-force MFMA kernel processes 32 candidates (two v_mfma_f32_32x32x2_f32 filter, exact recompute + insert
+// at the flush).  Candidates no longer arrive in index order: list entries are 64-bit keys (d2 bits << 32 | index), compared
+// lexicographically -- the documented convention (ascending (d2, index)) without relying on the scan order.
+//
+// Exactness: a candidate in a skipped sub-tile has (real) distance^2 >= lb > R^2 >= the true 16th distance of every query of
+// the wave (any 16 candidates bound it from above); lb is compared after a relative guard of 1e-5 (its own fp32 rounding is
+// ~2e-7).  Everything that is visited goes through the same filter + exact fp32 (dx^2 + dy^2) + dz^2 + insert as before, so the
+// output is bit-identical to knn_kernel / knn_mfma_kernel and oracle/knn.py (tests/test_knn_gpu.py, incl. heavy ties).
+constexpr int KG_GP_BITS = 4, KG_GQ_BITS = 5, KG_GP = 1 << KG_GP_BITS, KG_GQ = 1 << KG_GQ_BITS;      // cells per axis: candidate grid, query grid
+constexpr int KG_MIN_M = 1024, KG_MAX_M = 16384;
+constexpr int KG_BUILD_BLOCK = 1024;
+
+struct KgCloud { float lo[3], inv[3]; float pmax2; int n_sub; };       // one per cloud (32 bytes)
+#ifdef KG_DEBUG
+__device__ unsigned kg_trace[8192 * 16];          // per wave (blockIdx.x < 8192): [0..3] sub-tiles, insert rounds, flushes, -; [8..] cycles per phase
+#define KG_COUNT(i, v) do { if (lane == 0 && blockIdx.x < 8192) kg_trace[blockIdx.x * 16 + (i)] = (unsigned)(v); } while (0)
+#define KG_LOCAL(...) __VA_ARGS__
+#define KG_T0() unsigned long long kg_t = __builtin_readcyclecounter()
+#define KG_T(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); KG_COUNT(8 + i, n_ - kg_t); kg_t = n_; } while (0)
+#else
+#define KG_COUNT(i, v) do { } while (0)
+#define KG_LOCAL(...)
+#define KG_T0() do { } while (0)
+#define KG_T(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ unsigned kg_spread3(unsigned v) {            // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ __forceinline__ int kg_cell(float p, float lo, float inv, int G) {
+    const int c = (int)((p - lo) * inv);
+    return min(max(c, 0), G - 1);
+}
+// Hilbert index of cell (cx, cy, cz) in a (2^BITS)^3 grid (Skilling's transpose construction): consecutive indices are
+// face-adjacent cells, so 32 consecutive sorted queries / candidates always form one compact snake.  (A Morton order jumps across
+// the grid at every block boundary: 1 % of the waves straddled a jump, owned a box spanning both sides and ran 3-8x longer than
+// the median wave.)
+template <int BITS>
+__device__ __forceinline__ unsigned kg_hilbert(unsigned x0, unsigned x1, unsigned x2) {
+    unsigned X[3] = {x0, x1, x2};
+#pragma unroll
+    for (unsigned Q = 1u << (BITS - 1); Q > 1; Q >>= 1) {
+        const unsigned P = Q - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const unsigned t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    unsigned t = 0;
+#pragma unroll
+    for (unsigned Q = 1u << (BITS - 1); Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    return (kg_spread3(X[0] ^ t) << 2) | (kg_spread3(X[1] ^ t) << 1) | kg_spread3(X[2] ^ t);
+}
+template <int BITS>
+__device__ __forceinline__ unsigned kg_code(float x, float y, float z, const float* lo, const float* inv) {
+    constexpr int G = 1 << BITS;
+    return kg_hilbert<BITS>((unsigned)kg_cell(x, lo[0], inv[0], G), (unsigned)kg_cell(y, lo[1], inv[1], G), (unsigned)kg_cell(z, lo[2], inv[2], G));
+}
+__device__ __forceinline__ int kg_ord(float f) {                        // float -> int with the same order
+    const int i = __builtin_bit_cast(int, f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float kg_unord(int i) { return __builtin_bit_cast(float, i >= 0 ? i : i ^ 0x7fffffff); }
+
+// exclusive scan of n = per * KG_BUILD_BLOCK ints in place (LDS or global), by one workgroup of KG_BUILD_BLOCK threads
+template <int PER>
+__device__ __forceinline__ void kg_block_scan(int* v, int* s_wave /* [16] */) {      // v 16-byte aligned, PER % 4 == 0
+    static_assert(PER % 4 == 0, "whole int4 per thread");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int4* v4 = reinterpret_cast<int4*>(v) + tid * (PER / 4);
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int e = 0; e < PER / 4; ++e) {
+        const int4 x = v4[e];
+        loc[4 * e] = sum; sum += x.x; loc[4 * e + 1] = sum; sum += x.y; loc[4 * e + 2] = sum; sum += x.z; loc[4 * e + 3] = sum; sum += x.w;
+    }
+    int inc = sum;                                 // inclusive wave scan of the thread sums
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_wave[w];
+    base += inc - sum;
+#pragma unroll
+    for (int e = 0; e < PER / 4; ++e) v4[e] = make_int4(base + loc[4 * e], base + loc[4 * e + 1], base + loc[4 * e + 2], base + loc[4 * e + 3]);
+    __syncthreads();
+}
+
+// one workgroup per cloud (of up to three candidate sets x B clouds in one launch): bounding box, counting sort by Hilbert cell,
+// padded float4 array, sub-tile boxes
+struct KgBuildArgs {
+    const float* pc[3]; float4* cand[3]; float4* boxes[3]; KgCloud* hdr[3];
+    int M[3]; int B;
+};
+__global__ __launch_bounds__(KG_BUILD_BLOCK) void kg_build_cloud_kernel(const KgBuildArgs args) {
+    __shared__ __attribute__((aligned(16))) int s_cnt[KG_GP * KG_GP * KG_GP];
+    __shared__ float s_red[7][16];
+    __shared__ int s_wave[16];
+    __shared__ float s_lo[3], s_inv[3];
+    const int which = blockIdx.x / args.B, b = blockIdx.x - which * args.B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = args.M[which], Mpad = (M + 31) & ~31, n_sub = Mpad / 32;
+    const float* pcb = args.pc[which] + (size_t)b * M * 3;
+    float4* cb = args.cand[which] + (size_t)b * Mpad;
+    float4* bb = args.boxes[which] + (size_t)b * n_sub * 2;
+    KgCloud* hdr = args.hdr[which] + b;
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()}, pm = 0.f;
+    for (int i = tid; i < M; i += KG_BUILD_BLOCK) {
+        const float x = pcb[(size_t)i * 3], y = pcb[(size_t)i * 3 + 1], z = pcb[(size_t)i * 3 + 2];
+        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+        mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+        pm = fmaxf(pm, (x * x + y * y) + z * z);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
+        pm = fmaxf(pm, __shfl_xor(pm, o, 64));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s_red[a][wave] = mn[a]; s_red[3 + a][wave] = mx[a]; }
+        s_red[6][wave] = pm;
+    }
+    for (int i = tid; i < KG_GP * KG_GP * KG_GP; i += KG_BUILD_BLOCK) s_cnt[i] = 0;
+    __syncthreads();
+    if (tid < 3) {
+        float lo = s_red[tid][0], hi = s_red[3 + tid][0];
+        for (int w = 1; w < 16; ++w) { lo = fminf(lo, s_red[tid][w]); hi = fmaxf(hi, s_red[3 + tid][w]); }
+        const float ext = hi - lo;
+        s_lo[tid] = lo;
+        s_inv[tid] = (ext > 0.f && ext < __builtin_inff()) ? (float)KG_GP / ext : 0.f;
+        hdr->lo[tid] = s_lo[tid]; hdr->inv[tid] = s_inv[tid];
+    }
+    if (tid == 3) {
+        float p = s_red[6][0];
+        for (int w = 1; w < 16; ++w) p = fmaxf(p, s_red[6][w]);
+        hdr->pmax2 = p;
+        hdr->n_sub = n_sub;
+    }
+    __syncthreads();
+    for (int i = tid; i < M; i += KG_BUILD_BLOCK)
+        atomicAdd(&s_cnt[kg_code<KG_GP_BITS>(pcb[(size_t)i * 3], pcb[(size_t)i * 3 + 1], pcb[(size_t)i * 3 + 2], s_lo, s_inv)], 1);
+    __syncthreads();
+    kg_block_scan<KG_GP * KG_GP * KG_GP / KG_BUILD_BLOCK>(s_cnt, s_wave);
+    for (int i = tid; i < M; i += KG_BUILD_BLOCK) {
+        const float x = pcb[(size_t)i * 3], y = pcb[(size_t)i * 3 + 1], z = pcb[(size_t)i * 3 + 2];
+        const int pos = atomicAdd(&s_cnt[kg_code<KG_GP_BITS>(x, y, z, s_lo, s_inv)], 1);
+        cb[pos] = make_float4(x, y, z, __builtin_bit_cast(float, i));
+    }
+    for (int i = M + tid; i < Mpad; i += KG_BUILD_BLOCK) cb[i] = make_float4(3e18f, 3e18f, 3e18f, __builtin_bit_cast(float, 0x7fffffff));
+    __syncthreads();                               // the sorted array (written by this workgroup) is visible to it
+    // sub-tile boxes: one half wave per sub-tile, lane = candidate (padding rows stay out of the box)
+    const int j = lane & 31, h = lane >> 5;
+    for (int t = wave * 2 + h; t < ((n_sub + 1) & ~1); t += 32) {
+        float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        if (t < n_sub && t * 32 + j < M) {
+            const float4 p = cb[t * 32 + j];
+            lo[0] = hi[0] = p.x; lo[1] = hi[1] = p.y; lo[2] = hi[2] = p.z;
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+        if (j == 0 && t < n_sub) {
+            bb[2 * t] = make_float4(lo[0], lo[1], lo[2], 0.f);
+            bb[2 * t + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        }
+    }
+}
+
+// ---- query order: qperm[b][sorted position] = query row, sorted by the Hilbert index of the query's cell (32^3 over the queries' box)
+constexpr int KG_QCELLS = KG_GQ * KG_GQ * KG_GQ;
+__global__ void kg_qinit_kernel(int* __restrict__ hist, int* __restrict__ qbox) {     // grid (KG_QCELLS / 1024, B)
+    const int b = blockIdx.y;
+    hist[(size_t)b * KG_QCELLS + blockIdx.x * 1024 + threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 6) qbox[b * 8 + threadIdx.x] = threadIdx.x < 3 ? 0x7fffffff : (int)0x80000000;
+}
+__global__ __launch_bounds__(256) void kg_qbbox_kernel(const float* __restrict__ X, int Q, int* __restrict__ qbox) {      // grid (blocks, B)
+    __shared__ float s_red[6][4];
+    const int b = blockIdx.y;
+    const float* xb = X + (size_t)b * Q * 3;
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Q; i += gridDim.x * 256)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = xb[(size_t)i * 3 + a]; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64)); }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s_red[a][threadIdx.x >> 6] = mn[a]; s_red[3 + a][threadIdx.x >> 6] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&qbox[b * 8 + threadIdx.x], kg_ord(fminf(fminf(s_red[threadIdx.x][0], s_red[threadIdx.x][1]), fminf(s_red[threadIdx.x][2], s_red[threadIdx.x][3]))));
+    else if (threadIdx.x < 6) atomicMax(&qbox[b * 8 + threadIdx.x], kg_ord(fmaxf(fmaxf(s_red[threadIdx.x][0], s_red[threadIdx.x][1]), fmaxf(s_red[threadIdx.x][2], s_red[threadIdx.x][3]))));
+}
+__global__ __launch_bounds__(256) void kg_qcell_kernel(const float* __restrict__ X, int Q, const int* __restrict__ qbox, int* __restrict__ hist,
+                                                       int* __restrict__ code, int* __restrict__ rank) {                 // grid (ceil(Q/256), B)
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Q) return;
+    float lo[3], inv[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = kg_unord(qbox[b * 8 + a]);
+        const float ext = kg_unord(qbox[b * 8 + 3 + a]) - lo[a];
+        inv[a] = (ext > 0.f && ext < __builtin_inff()) ? (float)KG_GQ / ext : 0.f;
+    }
+    const float* x = X + ((size_t)b * Q + i) * 3;
+    const int c = (int)kg_code<KG_GQ_BITS>(x[0], x[1], x[2], lo, inv);
+    code[(size_t)b * Q + i] = c;
+    rank[(size_t)b * Q + i] = atomicAdd(&hist[(size_t)b * KG_QCELLS + c], 1);
+}
+__global__ __launch_bounds__(KG_BUILD_BLOCK) void kg_qscan_kernel(int* __restrict__ hist) {                               // grid (B)
+    __shared__ int s_wave[16];
+    kg_block_scan<KG_QCELLS / KG_BUILD_BLOCK>(hist + (size_t)blockIdx.x * KG_QCELLS, s_wave);
+}
+__global__ __launch_bounds__(256) void kg_qscatter_kernel(int Q, const int* __restrict__ hist, const int* __restrict__ code,
+                                                          const int* __restrict__ rank, int* __restrict__ qperm) {          // grid (ceil(Q/256), B)
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Q) return;
+    qperm[(size_t)b * Q + hist[(size_t)b * KG_QCELLS + code[(size_t)b * Q + i]] + rank[(size_t)b * Q + i]] = i;
+}
+
+// Insert key = (d2 bits << 32 | index) into the ascending list of 64-bit keys held as (hi = d2 bits, lo = index) register pairs.
+// With c_j = (k < key_j) (one 64-bit compare per slot, kept in scalar registers): slot j takes key_{j-1} if c_{j-1}, k if c_j only,
+// else stays.  The high words do not need the masks: hi'_j = med3(hi_{j-1}, k_hi, hi_j) (the list is sorted; on a tie of the high
+// words the candidates for the slot have equal high words anyway) -- 16 compares + 16 v_med3_u32 + 32 v_cndmask per insertion
+// (the plain select form compiled to two compares, four selects and two wait states per slot).
+__device__ __forceinline__ unsigned kg_umed3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <int K>
+__device__ __forceinline__ void kg_insert(unsigned (&khi)[K], unsigned (&klo)[K], unsigned hi, unsigned lo) {
+    const unsigned long long k = ((unsigned long long)hi << 32) | lo;
+    bool c[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) c[j] = k < (((unsigned long long)khi[j] << 32) | klo[j]);
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) {
+        klo[j] = c[j - 1] ? klo[j - 1] : (c[j] ? lo : klo[j]);
+        khi[j] = kg_umed3(khi[j - 1], hi, khi[j]);
+    }
+    klo[0] = c[0] ? lo : klo[0];
+    khi[0] = min(khi[0], hi);
+}
+
+// grid = (ceil(Q / 32), B); ONE wave per workgroup = 32 queries (sorted positions), lane (j, h) as in knn_mfma_kernel: waves
+// never wait for each other (their work differs by 2x with the geometry) and leave the CU as they finish.  Everything a wave touches
+// repeatedly sits in its 9 KB of LDS: the lower bounds of all sub-tiles (computed once), a ring of the last KG_RING sub-tiles it
+// filtered (a flush re-reads candidate coordinates from LDS, not from L2) and the queue of accepted ring positions; the next
+// sub-tile's 32 candidates are requested from L2 before the current one is filtered.
+constexpr int KG_RING = 6;                         // sub-tiles between two flushes at most
+constexpr int KG_ROUNDS = 6;                       // visiting rounds: sub-tiles in (roughly) increasing distance from the wave's queries
+__device__ __forceinline__ float kg_round_frac(int r) { return r == 0 ? 0.02f : (r == 1 ? 0.06f : (r == 2 ? 0.15f : (r == 3 ? 0.3f : 0.55f))); }
+constexpr int KG_MAX_SUB = KG_MAX_M / 32;          // 512
+constexpr int KG_LDS_LB = KG_MAX_SUB * 4, KG_LDS_RING = KG_RING * 32 * 16, KG_LDS_QUEUE = KM_QCAP * 64 * 2;
+constexpr int KG_LDS_BYTES = KG_LDS_LB + KG_LDS_RING + KG_LDS_QUEUE;            // 2 + 3 + 4 KB
+
+template <int K, bool OFFSETS>
+__global__ __launch_bounds__(64, 4) void knn_grid_kernel(const float* __restrict__ X, const float* __restrict__ pc, long long pc_stride,
+                                                         const int* __restrict__ qperm, const float4* __restrict__ cand,
+                                                         const float4* __restrict__ boxes, const KgCloud* __restrict__ hdr,
+                                                         long long cand_stride, long long box_stride, int n_sub,
+                                                         long long* __restrict__ out_idx, float* __restrict__ out_dist,
+                                                         float* __restrict__ out_pts, int Q) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    __shared__ __attribute__((aligned(16))) char s_mem[KG_LDS_BYTES];         // [lb | ring | queue]; reused as the merge buffer / output staging
+    __shared__ int s_row[32];
+    static_assert(2 * K * 32 * 8 <= KG_LDS_BYTES && 32 * K * 3 * 4 <= KG_LDS_BYTES, "merge / staging buffers do not fit");
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    KG_T0();
+    KG_LOCAL(int dbg_tiles = 0; int dbg_rounds = 0; int dbg_flushes = 0; int dbg_mine = 0);
+    float* s_lb = reinterpret_cast<float*>(s_mem);
+    float4* s_ring = reinterpret_cast<float4*>(s_mem + KG_LDS_LB);
+    unsigned short* qi = reinterpret_cast<unsigned short*>(s_mem + KG_LDS_LB + KG_LDS_RING) + lane;       // [slot][lane]
+    const float4* cb = cand + (size_t)b * cand_stride;
+    const float4* bb = boxes + (size_t)b * box_stride;
+    const float* pcb = pc + (size_t)b * pc_stride;
+    const float pmax2 = hdr[b].pmax2;              // (needed late: the load overlaps the set-up)
+    const int sp = blockIdx.x * 32 + j;
+    const bool valid = sp < Q;
+    const int q = qperm[(size_t)b * Q + (valid ? sp : Q - 1)];       // a lane without a query repeats the last one
+    const float* xq = X + ((size_t)b * Q + q) * 3;
+    const float qx = xq[0], qy = xq[1], qz = xq[2];
+    // the boxes of the wave's queries, one per group of 8 consecutive sorted positions: a wave whose 32 queries straddle a jump of the
+    // Morton curve would otherwise own a box spanning both sides (measured: 1 % of the waves visited 3-8x the sub-tiles of the
+    // median wave and the kernel waited for them)
+    float glo[4][3], ghi[4][3];
+    {
+        float lo[3] = {qx, qy, qz}, hi[3] = {qx, qy, qz};
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                glo[g][a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo[a]), g * 8));
+                ghi[g][a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi[a]), g * 8));
+            }
+    }
+    KG_T(0);
+    // ---- lower bounds of all sub-tiles (guarded: see the header), once; the nearest one seeds the lists
+    float best = __builtin_inff();
+    int best_t = 0;
+    auto lower_bound = [&](const float4 tl, const float4 th) -> float {        // min over the four query boxes of the box-to-box distance^2
+        float m = __builtin_inff();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float gx = fmaxf(0.f, fmaxf(tl.x - ghi[g][0], glo[g][0] - th.x));
+            const float gy = fmaxf(0.f, fmaxf(tl.y - ghi[g][1], glo[g][1] - th.y));
+            const float gz = fmaxf(0.f, fmaxf(tl.z - ghi[g][2], glo[g][2] - th.z));
+            m = fminf(m, (gx * gx + gy * gy) + gz * gz);
+        }
+        return m * 0.99999f;
+    };
+    for (int t0 = 0; t0 < n_sub; t0 += 256) {      // four independent box loads in flight
+        float4 tl[4], th[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = min(t0 + u * 64 + lane, n_sub - 1);
+            tl[u] = bb[2 * t]; th[u] = bb[2 * t + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * 64 + lane;
+            if (t < n_sub) {
+                const float lb = lower_bound(tl[u], th[u]);
+                s_lb[t] = lb;
+                if (lb < best) { best = lb; best_t = t; }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int ot = __shfl_xor(best_t, o, 64);
+        if (ob < best || (ob == best && ot < best_t)) { best = ob; best_t = ot; }
+    }
+    KG_T(1);
+    const float q2 = (qx * qx + qy * qy) + qz * qz, qn = sqrtf(q2);
+    const float b0 = h ? -2.f * qy : -2.f * qx, b1 = h ? 1.f : -2.f * qz;
+    float eps;
+    {
+        const float e = qn + sqrtf(pmax2);
+        eps = 9.5367431640625e-07f * (e * e);                         // 2^-20 (|x| + max |p|)^2
+    }
+    unsigned khi[K], klo[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) { khi[r] = 0x7f800000u; klo[r] = 0x7fffffffu; }      // (+inf, no index)
+    float tau = __builtin_inff(), thr = __builtin_inff(), R2 = __builtin_inff();
+    int cnt = 0, staged = 0;
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    asm volatile("" : "+v"(zero));
+    auto flush = [&]() {                           // exact distances of the queued candidates (ring positions), insertion, new thresholds
+        int maxc = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
+        KG_LOCAL(dbg_rounds += maxc; dbg_flushes += 1; dbg_mine += cnt);
+        for (int sidx = 0; sidx < maxc; ++sidx)
+            if (sidx < cnt) {
+                const float4 p = s_ring[qi[sidx * 64]];
+                const float d = knn_d2(qx, qy, qz, p);
+                kg_insert<K>(khi, klo, __builtin_bit_cast(unsigned, d), __builtin_bit_cast(unsigned, p.w));
+            }
+        tau = __builtin_bit_cast(float, khi[K - 1]);
+        thr = (tau - q2) + eps;
+        cnt = 0; staged = 0;
+        float tq = fminf(tau, __shfl_xor(tau, 32, 64));              // either half list bounds the query's 16th distance
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) tq = fmaxf(tq, __shfl_xor(tq, o, 64));
+        R2 = tq;
+    };
+    auto fetch = [&](int t) -> float4 { return cb[t * 32 + j]; };
+    auto process = [&](const float4 p) {           // p = candidate j of the sub-tile (both lane halves hold it)
+        KG_LOCAL(dbg_tiles += 1);
+        if (h == 0) s_ring[staged * 32 + j] = p;
+        const float pn = (p.x * p.x + p.y * p.y) + p.z * p.z;
+        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? p.y : p.x, b0, zero, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? pn : p.z, b1, acc, 0, 0, 0);
+        unsigned mask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            mask = __builtin_amdgcn_alignbit(mask, __builtin_bit_cast(unsigned, acc[r] - thr), 31);
+        const int base = staged * 32 + 4 * h;
+        while (__any(mask != 0u)) {
+            if (mask != 0u) {
+                const int pbit = 31 - __builtin_clz(mask), r = 15 - pbit;
+                qi[cnt * 64] = (unsigned short)(base + (r & 3) + 8 * (r >> 2));
+                ++cnt;
+                mask &= ~(1u << pbit);
+            }
+        }
+        ++staged;
+        __builtin_amdgcn_wave_barrier();           // (the ring rows written above are read by other lanes of this wave in flush)
+        if (staged == KG_RING || __any(cnt > KM_QCAP - 16)) flush();
+    };
+
+    // ---- seed: the nearest sub-tile fills both half lists (16 candidates each)
+    const int s0 = best_t;
+    process(fetch(s0));
+    // ---- rounds: sub-tiles with prev < lb <= limit (limit fixed per round: no sub-tile is visited twice); a sub-tile is dropped
+    // for good when the bound R2 has tightened below its lb by the time it comes up
+    float prev = -1.f;
+    KG_T(2);
+#pragma unroll 1
+    for (int round = 0; round < KG_ROUNDS; ++round) {
+        flush();
+        const float limit = round == KG_ROUNDS - 1 ? R2 : kg_round_frac(round) * R2;
+        if (!(limit > prev)) continue;
+        int c = -64;
+        unsigned long long m = 0;
+        auto next = [&]() -> int {                 // next sub-tile of this round, -1 at the end
+            while (m == 0) {
+                c += 64;
+                if (c >= n_sub) return -1;
+                const int t = c + lane;
+                const bool ok = t < n_sub && t != s0;
+                const float lb = ok ? s_lb[t] : __builtin_inff();
+                m = __ballot(ok && lb > prev && lb <= limit && !(lb > R2));
+            }
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            return c + bit;
+        };
+        int t_cur = next();
+        float4 p_cur = fetch(max(t_cur, 0));
+        while (t_cur >= 0) {
+            const int t_nxt = next();
+            const float4 p_nxt = fetch(max(t_nxt, 0));
+            if (!(s_lb[t_cur] > R2)) process(p_cur);
+            t_cur = t_nxt;
+            p_cur = p_nxt;
+        }
+        prev = limit;
+    }
+    flush();
+    KG_T(3);
+    KG_LOCAL(KG_COUNT(0, dbg_tiles); KG_COUNT(1, dbg_rounds); KG_COUNT(2, dbg_flushes);
+             int mx_ = dbg_mine, sm_ = dbg_mine;
+             for (int o_ = 32; o_ > 0; o_ >>= 1) { mx_ = max(mx_, __shfl_xor(mx_, o_, 64)); sm_ += __shfl_xor(sm_, o_, 64); }
+             KG_COUNT(3, mx_); KG_COUNT(4, sm_ / 64));
+    // ---- merge of the two half lists of every query (a one-wave workgroup: the barriers only order the LDS traffic)
+    __syncthreads();
+    unsigned long long* m_k = reinterpret_cast<unsigned long long*>(s_mem);     // [half][K][32 queries]: 8 KB
+#pragma unroll
+    for (int r = 0; r < K; ++r) m_k[(h * K + r) * 32 + j] = ((unsigned long long)khi[r] << 32) | klo[r];
+    if (h == 0) s_row[j] = valid ? q : -1;
+    __syncthreads();
+    int head[2] = {0, 0};
+    const size_t o = ((size_t)b * Q + q) * K;
+    int mi[K];
+    if (h == 0) {
+        for (int r = 0; r < K; ++r) {
+            const unsigned long long k0 = head[0] < K ? m_k[(0 * K + min(head[0], K - 1)) * 32 + j] : ~0ull;
+            const unsigned long long k1 = head[1] < K ? m_k[(1 * K + min(head[1], K - 1)) * 32 + j] : ~0ull;
+            const bool first = k0 <= k1;           // equal only for two empty slots
+            const unsigned long long kb = first ? k0 : k1;
+            head[0] += first ? 1 : 0;
+            head[1] += first ? 0 : 1;
+            mi[r] = (int)(unsigned)kb;
+            if (valid) {
+                if (out_idx) out_idx[o + r] = (long long)mi[r];
+                if (out_dist) out_dist[o + r] = sqrt_cr(__builtin_bit_cast(float, (unsigned)(kb >> 32)));
+            }
+        }
+    }
+    // ---- neighbour coordinates through LDS; a query's K x 3 floats are one contiguous, 16-byte aligned run of out_pts
+    __syncthreads();
+    float* st = reinterpret_cast<float*>(s_mem);   // [32 queries][K][3]
+    if (h == 0) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int id = mi[r] == 0x7fffffff ? 0 : mi[r];
+            const float* p = pcb + (size_t)id * 3;
+            st[(j * K + r) * 3 + 0] = OFFSETS ? p[0] - qx : p[0];
+            st[(j * K + r) * 3 + 1] = OFFSETS ? p[1] - qy : p[1];
+            st[(j * K + r) * 3 + 2] = OFFSETS ? p[2] - qz : p[2];
+        }
+    }
+    __syncthreads();
+    static_assert((K * 3) % 4 == 0, "a query's output row must be whole 16-byte chunks");
+    constexpr int CH = K * 3 / 4;                  // chunks per query row
+    float* dst = out_pts + (size_t)b * Q * K * 3;
+    const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    for (int c = lane; c < 32 * CH; c += 64) {
+        const int row = c / CH, ch = c - row * CH, qr = s_row[row];
+        if (qr < 0) continue;
+        float* d = dst + (size_t)qr * K * 3 + ch * 4;
+        const float4 v = reinterpret_cast<const float4*>(st)[c];
+        if (aligned) *reinterpret_cast<float4*>(d) = v;
+        else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+    }
+    KG_T(4);
+}
+
 template <int K>
 static void launch_knn(bool offsets, dim3 grid, hipStream_t s, const float* X, const float* pc, long long* idx, float* dist,
                        float* pts, int Q, int M, const int4* blocks = nullptr, const long long* pc_off = nullptr) {
@@ -421,6 +944,81 @@ constexpr int knn_block_rows() { return MCR_WAVE * KNN_QT; }
 int knn_rows_per_block() { return knn_block_rows(); }
 }  // namespace mcr
 
+namespace mcr {
+static inline size_t kg_al(size_t n) { return (n + 255) & ~(size_t)255; }
+bool knn_grid_applicable(int64_t M, int k) {
+    static const bool on = []() { const char* e = getenv("MCR_KNN_GRID"); return !(e && e[0] == '0'); }();      // dev A/B knob
+    return on && k == 16 && M >= KG_MIN_M && M <= KG_MAX_M;
+}
+size_t knn_grid_query_bytes(int64_t B, int64_t Q) {
+    return kg_al(B * 8 * 4) + kg_al((size_t)B * KG_QCELLS * 4) + 3 * kg_al((size_t)B * Q * 4);
+}
+size_t knn_grid_cloud_bytes(int64_t B, int64_t M) {
+    const size_t Mpad = (M + 31) & ~(size_t)31;
+    return kg_al(B * sizeof(KgCloud)) + kg_al(B * Mpad * 16) + kg_al(B * (Mpad / 32) * 32);
+}
+// qperm [B][Q] (device, inside ws): the queries of every cloud in the order the grid kernel walks them
+const int* knn_grid_order_queries(hipStream_t s, const float* X, int64_t B, int64_t Q, void* ws) {
+    char* w = (char*)ws;
+    int* qbox = (int*)w; w += kg_al(B * 8 * 4);
+    int* hist = (int*)w; w += kg_al((size_t)B * KG_QCELLS * 4);
+    int* code = (int*)w; w += kg_al((size_t)B * Q * 4);
+    int* rank = (int*)w; w += kg_al((size_t)B * Q * 4);
+    int* qperm = (int*)w;
+    hipLaunchKernelGGL(kg_qinit_kernel, dim3(KG_QCELLS / 1024, (unsigned)B), dim3(1024), 0, s, hist, qbox);
+    hipLaunchKernelGGL(kg_qbbox_kernel, dim3((unsigned)std::min<int64_t>(cdiv(Q, 1024), 64), (unsigned)B), dim3(256), 0, s, X, (int)Q, qbox);
+    hipLaunchKernelGGL(kg_qcell_kernel, dim3((unsigned)cdiv(Q, 256), (unsigned)B), dim3(256), 0, s, X, (int)Q, qbox, hist, code, rank);
+    hipLaunchKernelGGL(kg_qscan_kernel, dim3((unsigned)B), dim3(KG_BUILD_BLOCK), 0, s, hist);
+    hipLaunchKernelGGL(kg_qscatter_kernel, dim3((unsigned)cdiv(Q, 256), (unsigned)B), dim3(256), 0, s, (int)Q, hist, code, rank, qperm);
+    return qperm;
+}
+// n <= 3 candidate sets (the scales of one SconeOcc forward) of B clouds each, in ONE launch; set i needs knn_grid_cloud_bytes(B, M[i])
+// bytes at ws[i]
+void knn_grid_build_clouds(hipStream_t s, int n, const float* const* pc, const int64_t* M, int64_t B, void* const* ws, KnnGridCloud* out) {
+    KgBuildArgs args{};
+    args.B = (int)B;
+    for (int i = 0; i < n; ++i) {
+        const int64_t Mpad = (M[i] + 31) & ~(int64_t)31;
+        char* w = (char*)ws[i];
+        KnnGridCloud& c = out[i];
+        c.hdr = w; w += kg_al(B * sizeof(KgCloud));
+        c.cand = w; w += kg_al(B * Mpad * 16);
+        c.boxes = w;
+        c.cand_stride = Mpad; c.box_stride = Mpad / 32 * 2;
+        args.pc[i] = pc[i]; args.cand[i] = (float4*)c.cand; args.boxes[i] = (float4*)c.boxes; args.hdr[i] = (KgCloud*)c.hdr; args.M[i] = (int)M[i];
+    }
+    if (n > 0) hipLaunchKernelGGL(kg_build_cloud_kernel, dim3((unsigned)(n * B)), dim3(KG_BUILD_BLOCK), 0, s, args);
+}
+KnnGridCloud knn_grid_build_cloud(hipStream_t s, const float* pc, int64_t B, int64_t M, void* ws) {
+    KnnGridCloud c;
+    knn_grid_build_clouds(s, 1, &pc, &M, B, &ws, &c);
+    return c;
+}
+// clouds b_first .. b_first + n_b - 1 of a batch whose INPUT arrays are laid out [B][...]; idx / dist / pts: the outputs of these n_b
+// clouds, as mcr_knn_points writes them (k = 16)
+void launch_knn16_grid(hipStream_t s, const float* X, const float* pc, int64_t M, const int* qperm, const KnnGridCloud& c, int64_t b_first,
+                       int64_t n_b, int64_t Q, int64_t* idx, float* dist, float* pts, bool offsets) {
+    if (n_b <= 0 || Q <= 0) return;
+    const float* Xb = X + b_first * Q * 3;
+    const float* pcb = pc + b_first * M * 3;
+    const int* qp = qperm + b_first * Q;
+    const float4* cand = (const float4*)c.cand + b_first * c.cand_stride;
+    const float4* boxes = (const float4*)c.boxes + b_first * c.box_stride;
+    const KgCloud* hdr = (const KgCloud*)c.hdr + b_first;
+    long long* i64 = (long long*)idx;             // the outputs are those of cloud b_first already
+    float* d = dist;
+    float* o = pts;
+    dim3 grid((unsigned)cdiv(Q, 32), (unsigned)n_b);
+    const int n_sub = (int)(c.cand_stride / 32);
+    if (offsets)
+        hipLaunchKernelGGL((knn_grid_kernel<16, true>), grid, dim3(64), 0, s, Xb, pcb, (long long)(M * 3), qp, cand, boxes, hdr,
+                           (long long)c.cand_stride, (long long)c.box_stride, n_sub, i64, d, o, (int)Q);
+    else
+        hipLaunchKernelGGL((knn_grid_kernel<16, false>), grid, dim3(64), 0, s, Xb, pcb, (long long)(M * 3), qp, cand, boxes, hdr,
+                           (long long)c.cand_stride, (long long)c.box_stride, n_sub, i64, d, o, (int)Q);
+}
+}  // namespace mcr
+
 extern "C" int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B,
                               int64_t Q, int64_t M, int k, int subtract_query, void* stream) {
     MCR_REQUIRE(X && pc && pts, "mcr_knn_points: null pointer");
@@ -441,3 +1039,29 @@ extern "C" int mcr_knn_points(const float* X, const float* pc, int64_t* idx, flo
     MCR_LAUNCH_CHECK("knn_kernel");
     return 0;
 }
+
+extern "C" size_t mcr_knn_grid_workspace_bytes(int64_t B, int64_t Q, int64_t M) {
+    return knn_grid_query_bytes(B, Q) + knn_grid_cloud_bytes(B, M) + 512;
+}
+
+// mcr_knn_points with a scratch buffer: the grid-pruned search where it applies (k = 16, 1024 <= M <= 16384), the brute-force
+// kernels otherwise -- identical outputs either way.
+extern "C" int mcr_knn_points_grid(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B, int64_t Q, int64_t M,
+                                   int k, int subtract_query, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!knn_grid_applicable(M, k)) return mcr_knn_points(X, pc, idx, dists, pts, B, Q, M, k, subtract_query, stream);
+    MCR_REQUIRE(X && pc && pts, "mcr_knn_points_grid: null pointer");
+    MCR_REQUIRE(B > 0 && Q > 0 && B <= 65535 && Q < (1ll << 31), "mcr_knn_points_grid: bad problem size B=%ld Q=%ld", (long)B, (long)Q);
+    MCR_REQUIRE(workspace && workspace_bytes >= mcr_knn_grid_workspace_bytes(B, Q, M), "mcr_knn_points_grid: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int* qperm = knn_grid_order_queries(s, X, B, Q, workspace);
+    const KnnGridCloud c = knn_grid_build_cloud(s, pc, B, M, (char*)workspace + knn_grid_query_bytes(B, Q));
+    launch_knn16_grid(s, X, pc, M, qperm, c, 0, B, Q, idx, dists, pts, subtract_query != 0);
+    MCR_LAUNCH_CHECK("knn_grid_kernel");
+    return 0;
+}
+
+#ifdef KG_DEBUG
+extern "C" int mcr_knn_grid_debug(unsigned* out) {      // out[8192 * 16]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(kg_trace), sizeof(unsigned) * 8192 * 16) == hipSuccess ? 0 : 1;
+}
+#endif

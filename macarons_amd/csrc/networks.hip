@@ -349,7 +349,9 @@ size_t mcr_scone_occ_workspace_bytes(int64_t B, int64_t Q, int64_t Lg) {
     size_t glob = pct_ws_bytes(B * Lg);
     size_t head = al(B * Q * 1344) + al(B * Q * 512) + al(B * Q * 256) + al(B * 512) * 2;
     head += linear3h_planes_bytes(512, 1344);        // split weight planes of the largest head layer (reused layer after layer)
-    return local + glob + head + 8192;          // local and global paths run concurrently (two streams): disjoint scratch
+    // grid-pruned kNN (knn.hip: K1-grid): the query order of all clouds + one sorted candidate copy (the largest admissible cloud)
+    const size_t knn_grid = knn_grid_query_bytes(B, Q) + 3 * knn_grid_cloud_bytes(B, 16384) + 1024;
+    return local + glob + head + knn_grid + 8192;          // local and global paths run concurrently (two streams): disjoint scratch
 }
 
 int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B, int64_t Q, int64_t M,
@@ -411,6 +413,9 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     float* gfeat = head.f(B * 512);
     float* gbias = head.f(B * 512);
     void* wplanes = head.f(linear3h_planes_bytes(512, 1344) / sizeof(float));
+    const size_t knn_q_bytes = knn_grid_query_bytes(B, Q), knn_c_bytes = knn_grid_cloud_bytes(B, 16384);
+    char* knn_q_ws = (char*)head.f((knn_q_bytes + 3) / 4);
+    char* knn_c_ws = (char*)head.f((3 * knn_c_bytes + 3) / 4);
     const size_t glob_bytes = pct_ws_bytes(B * Lg);
     Arena garena{(char*)workspace + head.off, glob_bytes, 0};
     Arena scratch{(char*)workspace + head.off + glob_bytes, workspace_bytes - head.off - glob_bytes, 0};
@@ -452,7 +457,27 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     const bool planes = planes_on && fused_all && g_local_pct_variant == 6;
     _Float16* featP = reinterpret_cast<_Float16*>(feat);
     const int64_t Tall = B * Q;
+    // grid-pruned kNN for the scales it applies to (whole-Q launches only): ONE query order for all three scales
+    const int* knn_qperm = nullptr;
+    KnnGridCloud knn_clouds[3]{};
+    int knn_slot[3] = {-1, -1, -1};
+    if (qc == Q) {
+        const float* g_pc[3]; int64_t g_M[3]; void* g_ws[3];
+        int n_grid = 0;
+        for (int sc = 0; sc < 3; ++sc)
+            if (knn_grid_applicable(M_scale[sc], 16)) {
+                g_pc[n_grid] = pc_scale[sc]; g_M[n_grid] = M_scale[sc]; g_ws[n_grid] = knn_c_ws + n_grid * knn_c_bytes;
+                knn_slot[sc] = n_grid++;
+            }
+        if (n_grid) {
+            knn_qperm = knn_grid_order_queries(s, x, B, Q, knn_q_ws);
+            knn_grid_build_clouds(s, n_grid, g_pc, g_M, B, g_ws, knn_clouds);
+            MCR_LAUNCH_CHECK("knn grid preparation");
+        }
+    }
     for (int sc = 0; sc < 3; ++sc) {
+        const bool grid_knn = knn_slot[sc] >= 0;
+        const KnnGridCloud knn_cloud = grid_knn ? knn_clouds[knn_slot[sc]] : KnnGridCloud{};
         for (int64_t q0 = 0; q0 < Q; q0 += qc) {
             const int64_t nq = std::min<int64_t>(qc, Q - q0);
             for (int64_t b = 0; b < B; ++b) {
@@ -460,8 +485,11 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
                 float* offs = a.f(nq * 16 * 3);
                 MCR_REQUIRE(a.ok(), "mcr_scone_occ_forward: workspace overflow (kNN)");
                 // only the offsets are consumed (SconeOcc.py:297-298): indices and distances are not written
-                if (int e = mcr_knn_points(x + (b * Q + q0) * 3, pc_scale[sc] + b * M_scale[sc] * 3, nullptr, nullptr, offs, 1, nq,
-                                           M_scale[sc], 16, 1, stream))
+                if (grid_knn) {
+                    launch_knn16_grid(s, x, pc_scale[sc], M_scale[sc], knn_qperm, knn_cloud, b, 1, Q, nullptr, nullptr, offs, true);
+                    MCR_LAUNCH_CHECK("knn_grid_kernel");
+                } else if (int e = mcr_knn_points(x + (b * Q + q0) * 3, pc_scale[sc] + b * M_scale[sc] * 3, nullptr, nullptr, offs, 1, nq,
+                                                  M_scale[sc], 16, 1, stream))
                     return e;
                 if (planes)
                     run_local_pct(s, offs, nullptr, FEAT, nq, local_blobs[sc], featP + (b * Q + q0) * FEAT + sc * 256,

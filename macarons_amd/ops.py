@@ -91,8 +91,11 @@ def knn_points(X, pc, k, subtract_query=False):
     dists = torch.empty((B, Q, k), dtype=torch.float32, device=X.device)
     pts = torch.empty((B, Q, k, 3), dtype=torch.float32, device=X.device)
     with torch.cuda.device(X.device):
-        check(lib().mcr_knn_points(_p(X), _p(pc), _p(idx), _p(dists), _p(pts), c_i64(B), c_i64(Q), c_i64(M), c_int(k),
-                                   c_int(int(bool(subtract_query))), _stream()), "mcr_knn_points")
+        nb = int(lib().mcr_knn_grid_workspace_bytes(c_i64(B), c_i64(Q), c_i64(M)))
+        ws = _workspace(X.device, nb)
+        check(lib().mcr_knn_points_grid(_p(X), _p(pc), _p(idx), _p(dists), _p(pts), c_i64(B), c_i64(Q), c_i64(M), c_int(k),
+                                        c_int(int(bool(subtract_query))), _p(ws), ctypes.c_size_t(ws.numel()), _stream()),
+              "mcr_knn_points_grid")
     return pts, dists, idx
 
 

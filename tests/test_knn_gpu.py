@@ -62,3 +62,56 @@ def test_large_properties(dev):
     assert np.array_equal(i[:, sel], io) and np.array_equal(d[:, sel], do) and np.array_equal(p[:, sel], po)
     # offsets consistent with indices
     assert np.array_equal(p, pc[0][i[0]][None] - X[:, :, None, :])
+
+
+def _grid_cases():
+    """Clouds and query sets that stress the grid-pruned search (K1-grid, knn.hip): the output must stay that of the brute-force
+    convention whatever the geometry does to the pruning."""
+    rng = np.random.default_rng(11)
+    u = lambda *s: rng.uniform(-.5, .5, s).astype(np.float32)
+    cases = {}
+    cases["uniform"] = (u(1, 3000, 3), u(1, 4096, 3))
+    # heavy ties: both sets on a coarse lattice (dozens of candidates at exactly the 16th distance)
+    lat = lambda n: (rng.integers(0, 9, (1, n, 3)) / 8.0 - 0.5).astype(np.float32)
+    cases["lattice_ties"] = (lat(1500), lat(3000))
+    # a surface-like cloud (thin spherical shell) with queries filling the box: most queries are far from every candidate
+    d = rng.normal(size=(1, 5000, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    cases["shell_far_queries"] = (u(1, 2500, 3) * 3.0, (0.3 * d).astype(np.float32))
+    # two tight clusters far apart + queries between them (the seed sub-tiles are far from the true neighbours of some queries)
+    c = np.concatenate([u(1, 1200, 3) * 0.01 + 5.0, u(1, 1200, 3) * 0.01 - 5.0], axis=1)
+    cases["two_clusters"] = (np.concatenate([u(1, 700, 3) * 12.0, c[:, ::7] + 1e-3], axis=1).astype(np.float32), c.astype(np.float32))
+    # degenerate boxes: every candidate identical (all cells collapse), then a planar cloud (zero extent on one axis)
+    cases["all_identical"] = (u(1, 300, 3), np.full((1, 1100, 3), 0.25, np.float32))
+    flat = u(1, 2048, 3); flat[..., 2] = 0.125
+    cases["planar"] = (u(1, 1000, 3), flat)
+    # not a multiple of 32 candidates / of 128 queries, a batch of clouds, a cloud far from the origin (filter guard band)
+    cases["ragged_batch"] = (u(3, 333, 3), u(3, 1031, 3))
+    cases["offset_origin"] = (u(1, 777, 3) + 100.0, u(1, 2000, 3) + 100.0)
+    cases["one_query"] = (u(1, 1, 3), u(1, 1024, 3))
+    return cases
+
+
+@pytest.mark.parametrize("name", list(_grid_cases()))
+def test_grid_pruned_search_is_exact(dev, name):
+    X, pc = _grid_cases()[name]
+    p, d, i = _run(dev, X, pc, 16, sub=True)
+    po, do, io = knn.knn_offsets(X, pc, 16)
+    assert np.array_equal(i, io), name
+    assert np.array_equal(d, do) and np.array_equal(p, po), name
+
+
+def test_grid_pruned_equals_brute_force_kernels(dev, monkeypatch):
+    """Same call through mcr_knn_points (brute force, MFMA filter) and mcr_knn_points_grid: bit-identical outputs at the step's size."""
+    import ctypes
+    from macarons_amd import ops
+    from macarons_amd._lib import lib, check, c_i64, c_int
+    rng = np.random.default_rng(3)
+    X = torch.from_numpy(rng.uniform(-.5, .5, (2, 20_000, 3)).astype(np.float32)).to(dev)
+    pc = torch.from_numpy(rng.normal(0, .2, (2, 10_240, 3)).astype(np.float32)).to(dev)
+    p1, d1, i1 = ops.knn_points(X, pc, 16, True)
+    i0 = torch.empty_like(i1); d0 = torch.empty_like(d1); p0 = torch.empty_like(p1)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    check(lib().mcr_knn_points(ptr(X), ptr(pc), ptr(i0), ptr(d0), ptr(p0), c_i64(2), c_i64(20_000), c_i64(10_240), c_int(16), c_int(1),
+                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "mcr_knn_points")
+    torch.cuda.synchronize()
+    assert torch.equal(i0, i1) and torch.equal(d0, d1) and torch.equal(p0, p1)
