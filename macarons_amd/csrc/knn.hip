@@ -661,26 +661,118 @@ __device__ __forceinline__ void kg_insert(unsigned (&khi)[K], unsigned (&klo)[K]
 // repeatedly sits in its 9 KB of LDS: the lower bounds of all sub-tiles (computed once), a ring of the last KG_RING sub-tiles it
 // filtered (a flush re-reads candidate coordinates from LDS, not from L2) and the queue of accepted ring positions; the next
 // sub-tile's 32 candidates are requested from L2 before the current one is filtered.
+//
+// Heavy groups.  Queries far from the cloud (the middle of a hollow object) have hundreds of sub-tiles within their 16th distance: a
+// few waves out of thousands then run 5-8x longer than the median one and the launch waits for them (measured on an ellipsoid
+// shell: mean 45 sub-tiles per wave, the heaviest 313; kernel 520 us for 100 us of average work).  A wave that finds more than
+// KG_HEAVY sub-tiles behind it and in the band of the next visiting round therefore PARKS its group: it stores its lists, its lower bounds and the band's
+// lower limit in a slot of the scratch buffer and exits.  A second launch (MODE 1) gives every parked group KG_SPLIT waves, each
+// taking every KG_SPLIT-th remaining sub-tile with the parked 16th distances as its starting thresholds (so it only keeps genuine
+// improvements); the eight waves are ONE workgroup and fold their lists pairwise through LDS (three steps of 16 insertions), wave
+// 0 adds the parked lists and writes the group's output.  The launch has a fixed grid and exits at once for unused slots: no host
+// round trip.  A group that finds no free slot simply carries on.
 constexpr int KG_RING = 6;                         // sub-tiles between two flushes at most
 constexpr int KG_ROUNDS = 6;                       // visiting rounds: sub-tiles in (roughly) increasing distance from the wave's queries
 __device__ __forceinline__ float kg_round_frac(int r) { return r == 0 ? 0.02f : (r == 1 ? 0.06f : (r == 2 ? 0.15f : (r == 3 ? 0.3f : 0.55f))); }
 constexpr int KG_MAX_SUB = KG_MAX_M / 32;          // 512
 constexpr int KG_LDS_LB = KG_MAX_SUB * 4, KG_LDS_RING = KG_RING * 32 * 16, KG_LDS_QUEUE = KM_QCAP * 64 * 2;
 constexpr int KG_LDS_BYTES = KG_LDS_LB + KG_LDS_RING + KG_LDS_QUEUE;            // 2 + 3 + 4 KB
+constexpr int KG_HEAVY = 80, KG_SPLIT = 8, KG_MAXDEF = 384;
+// scratch of one parked group: header | lower bounds | its lists [half][K = 16][32 queries] as 64-bit keys
+struct KgSlot { int group, b; float prev; int seed; };
+constexpr size_t KG_SLOT_LISTS = 2 * 16 * 32 * 8;                                // 8 KB
+constexpr size_t KG_SLOT_BYTES = 256 + KG_MAX_SUB * 4 + KG_SLOT_LISTS;
+__device__ __forceinline__ KgSlot* kg_slot_hdr(char* scratch, int slot) { return reinterpret_cast<KgSlot*>(scratch + (size_t)slot * KG_SLOT_BYTES); }
+__device__ __forceinline__ float* kg_slot_lb(char* scratch, int slot) { return reinterpret_cast<float*>(scratch + (size_t)slot * KG_SLOT_BYTES + 256); }
+__device__ __forceinline__ unsigned long long* kg_slot_lists(char* scratch, int slot) {
+    return reinterpret_cast<unsigned long long*>(scratch + (size_t)slot * KG_SLOT_BYTES + 256 + KG_MAX_SUB * 4);
+}
 
-template <int K, bool OFFSETS>
-__global__ __launch_bounds__(64, 4) void knn_grid_kernel(const float* __restrict__ X, const float* __restrict__ pc, long long pc_stride,
+// the end of a group's search: merge the two half lists of every query, write indices / distances / neighbour coordinates
+template <int K, bool OFFSETS, bool BLOCK_IS_WAVE>
+__device__ __forceinline__ void kg_output(const unsigned (&khi)[K], const unsigned (&klo)[K], char* s_mem, int* s_row, int lane, int b, int Q,
+                                          int q, bool valid, float qx, float qy, float qz, const float* pcb, long long* out_idx,
+                                          float* out_dist, float* out_pts) {
+    const int j = lane & 31, h = lane >> 5;
+    auto sync = [&]() { if (BLOCK_IS_WAVE) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } };
+    sync();                                        // (one wave: the barriers only order the LDS traffic)
+    unsigned long long* m_k = reinterpret_cast<unsigned long long*>(s_mem);     // [half][K][32 queries]: 8 KB
+#pragma unroll
+    for (int r = 0; r < K; ++r) m_k[(h * K + r) * 32 + j] = ((unsigned long long)khi[r] << 32) | klo[r];
+    if (h == 0) s_row[j] = valid ? q : -1;
+    sync();
+    int head[2] = {0, 0};
+    const size_t o = ((size_t)b * Q + q) * K;
+    int mi[K];
+    if (h == 0) {
+        for (int r = 0; r < K; ++r) {
+            const unsigned long long k0 = head[0] < K ? m_k[(0 * K + min(head[0], K - 1)) * 32 + j] : ~0ull;
+            const unsigned long long k1 = head[1] < K ? m_k[(1 * K + min(head[1], K - 1)) * 32 + j] : ~0ull;
+            const bool first = k0 <= k1;           // equal only for two empty slots
+            const unsigned long long kb = first ? k0 : k1;
+            head[0] += first ? 1 : 0;
+            head[1] += first ? 0 : 1;
+            mi[r] = (int)(unsigned)kb;
+            if (valid) {
+                if (out_idx) out_idx[o + r] = (long long)mi[r];
+                if (out_dist) out_dist[o + r] = sqrt_cr(__builtin_bit_cast(float, (unsigned)(kb >> 32)));
+            }
+        }
+    }
+    // neighbour coordinates through LDS; a query's K x 3 floats are one contiguous, 16-byte aligned run of out_pts
+    sync();
+    float* st = reinterpret_cast<float*>(s_mem);   // [32 queries][K][3]
+    if (h == 0) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int id = mi[r] == 0x7fffffff ? 0 : mi[r];
+            const float* p = pcb + (size_t)id * 3;
+            st[(j * K + r) * 3 + 0] = OFFSETS ? p[0] - qx : p[0];
+            st[(j * K + r) * 3 + 1] = OFFSETS ? p[1] - qy : p[1];
+            st[(j * K + r) * 3 + 2] = OFFSETS ? p[2] - qz : p[2];
+        }
+    }
+    sync();
+    static_assert((K * 3) % 4 == 0, "a query's output row must be whole 16-byte chunks");
+    constexpr int CH = K * 3 / 4;                  // chunks per query row
+    float* dst = out_pts + (size_t)b * Q * K * 3;
+    const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    for (int c = lane; c < 32 * CH; c += 64) {
+        const int row = c / CH, ch = c - row * CH, qr = s_row[row];
+        if (qr < 0) continue;
+        float* d = dst + (size_t)qr * K * 3 + ch * 4;
+        const float4 v = reinterpret_cast<const float4*>(st)[c];
+        if (aligned) *reinterpret_cast<float4*>(d) = v;
+        else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+    }
+}
+
+// MODE 0: grid (ceil(Q / 32), B) x 64 threads, the search proper.  MODE 1: grid (KG_MAXDEF) x 512 threads: wave `part` of parked
+// group `slot`.
+template <int K, bool OFFSETS, int MODE>
+__global__ __launch_bounds__(MODE ? 64 * KG_SPLIT : 64, MODE ? 2 : 4) void knn_grid_kernel(const float* __restrict__ X, const float* __restrict__ pc, long long pc_stride,
                                                          const int* __restrict__ qperm, const float4* __restrict__ cand,
                                                          const float4* __restrict__ boxes, const KgCloud* __restrict__ hdr,
                                                          long long cand_stride, long long box_stride, int n_sub,
                                                          long long* __restrict__ out_idx, float* __restrict__ out_dist,
-                                                         float* __restrict__ out_pts, int Q) {
+                                                         float* __restrict__ out_pts, int Q, int* __restrict__ def_count,
+                                                         char* __restrict__ def_scratch) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
-    __shared__ __attribute__((aligned(16))) char s_mem[KG_LDS_BYTES];         // [lb | ring | queue]; reused as the merge buffer / output staging
+    __shared__ __attribute__((aligned(16))) char s_all[(MODE ? KG_SPLIT : 1) * KG_LDS_BYTES];     // per wave: [lb | ring | queue]; reused for merges / staging
     __shared__ int s_row[32];
     static_assert(2 * K * 32 * 8 <= KG_LDS_BYTES && 32 * K * 3 * 4 <= KG_LDS_BYTES, "merge / staging buffers do not fit");
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    static_assert(K == 16, "the parked-group scratch layout is written for k = 16");
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int part = MODE ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    char* s_mem = s_all + part * KG_LDS_BYTES;
+    int b = blockIdx.y, group = blockIdx.x, slot = 0;
+    float prev = -1.f;
+    if (MODE == 1) {
+        slot = blockIdx.x;
+        if (slot >= min(*def_count, KG_MAXDEF)) return;
+        const KgSlot* sl = kg_slot_hdr(def_scratch, slot);
+        group = sl->group; b = sl->b; prev = sl->prev;
+    }
     KG_T0();
     KG_LOCAL(int dbg_tiles = 0; int dbg_rounds = 0; int dbg_flushes = 0; int dbg_mine = 0);
     float* s_lb = reinterpret_cast<float*>(s_mem);
@@ -690,66 +782,75 @@ __global__ __launch_bounds__(64, 4) void knn_grid_kernel(const float* __restrict
     const float4* bb = boxes + (size_t)b * box_stride;
     const float* pcb = pc + (size_t)b * pc_stride;
     const float pmax2 = hdr[b].pmax2;              // (needed late: the load overlaps the set-up)
-    const int sp = blockIdx.x * 32 + j;
+    const int sp = group * 32 + j;
     const bool valid = sp < Q;
     const int q = qperm[(size_t)b * Q + (valid ? sp : Q - 1)];       // a lane without a query repeats the last one
     const float* xq = X + ((size_t)b * Q + q) * 3;
     const float qx = xq[0], qy = xq[1], qz = xq[2];
-    // the boxes of the wave's queries, one per group of 8 consecutive sorted positions: a wave whose 32 queries straddle a jump of the
-    // Morton curve would otherwise own a box spanning both sides (measured: 1 % of the waves visited 3-8x the sub-tiles of the
-    // median wave and the kernel waited for them)
-    float glo[4][3], ghi[4][3];
-    {
-        float lo[3] = {qx, qy, qz}, hi[3] = {qx, qy, qz};
-#pragma unroll
-        for (int o = 4; o > 0; o >>= 1)
-#pragma unroll
-            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                glo[g][a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo[a]), g * 8));
-                ghi[g][a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi[a]), g * 8));
-            }
-    }
+    float tau_parked = __builtin_inff();           // MODE 1: the query's 16th distance when its group was parked
+    int s0 = -1;                                   // MODE 0: the seed sub-tile
     KG_T(0);
-    // ---- lower bounds of all sub-tiles (guarded: see the header), once; the nearest one seeds the lists
-    float best = __builtin_inff();
-    int best_t = 0;
-    auto lower_bound = [&](const float4 tl, const float4 th) -> float {        // min over the four query boxes of the box-to-box distance^2
-        float m = __builtin_inff();
+    if (MODE == 0) {
+        // the boxes of the wave's queries, one per group of 8 consecutive sorted positions (tighter than one box of all 32)
+        float glo[4][3], ghi[4][3];
+        {
+            float lo[3] = {qx, qy, qz}, hi[3] = {qx, qy, qz};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float gx = fmaxf(0.f, fmaxf(tl.x - ghi[g][0], glo[g][0] - th.x));
-            const float gy = fmaxf(0.f, fmaxf(tl.y - ghi[g][1], glo[g][1] - th.y));
-            const float gz = fmaxf(0.f, fmaxf(tl.z - ghi[g][2], glo[g][2] - th.z));
-            m = fminf(m, (gx * gx + gy * gy) + gz * gz);
+            for (int o = 4; o > 0; o >>= 1)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    glo[g][a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo[a]), g * 8));
+                    ghi[g][a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi[a]), g * 8));
+                }
         }
-        return m * 0.99999f;
-    };
-    for (int t0 = 0; t0 < n_sub; t0 += 256) {      // four independent box loads in flight
-        float4 tl[4], th[4];
+        // ---- lower bounds of all sub-tiles (guarded: see the header), once; the nearest one seeds the lists
+        float best = __builtin_inff();
+        int best_t = 0;
+        auto lower_bound = [&](const float4 tl, const float4 th) -> float {        // min over the four query boxes of the box-to-box distance^2
+            float m = __builtin_inff();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = min(t0 + u * 64 + lane, n_sub - 1);
-            tl[u] = bb[2 * t]; th[u] = bb[2 * t + 1];
-        }
+            for (int g = 0; g < 4; ++g) {
+                const float gx = fmaxf(0.f, fmaxf(tl.x - ghi[g][0], glo[g][0] - th.x));
+                const float gy = fmaxf(0.f, fmaxf(tl.y - ghi[g][1], glo[g][1] - th.y));
+                const float gz = fmaxf(0.f, fmaxf(tl.z - ghi[g][2], glo[g][2] - th.z));
+                m = fminf(m, (gx * gx + gy * gy) + gz * gz);
+            }
+            return m * 0.99999f;
+        };
+        for (int t0 = 0; t0 < n_sub; t0 += 256) {      // four independent box loads in flight
+            float4 tl[4], th[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = t0 + u * 64 + lane;
-            if (t < n_sub) {
-                const float lb = lower_bound(tl[u], th[u]);
-                s_lb[t] = lb;
-                if (lb < best) { best = lb; best_t = t; }
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(t0 + u * 64 + lane, n_sub - 1);
+                tl[u] = bb[2 * t]; th[u] = bb[2 * t + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u * 64 + lane;
+                if (t < n_sub) {
+                    const float lb = lower_bound(tl[u], th[u]);
+                    s_lb[t] = lb;
+                    if (lb < best) { best = lb; best_t = t; }
+                }
             }
         }
-    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64);
-        const int ot = __shfl_xor(best_t, o, 64);
-        if (ob < best || (ob == best && ot < best_t)) { best = ob; best_t = ot; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int ot = __shfl_xor(best_t, o, 64);
+            if (ob < best || (ob == best && ot < best_t)) { best = ob; best_t = ot; }
+        }
+        s0 = best_t;
+    } else {
+        const float* lbp = kg_slot_lb(def_scratch, slot);
+        for (int t = lane; t < n_sub; t += 64) s_lb[t] = lbp[t];
+        const unsigned long long* L = kg_slot_lists(def_scratch, slot);
+        const unsigned t0_ = (unsigned)(L[(0 * K + K - 1) * 32 + j] >> 32), t1_ = (unsigned)(L[(1 * K + K - 1) * 32 + j] >> 32);
+        tau_parked = __builtin_bit_cast(float, min(t0_, t1_));
     }
     KG_T(1);
     const float q2 = (qx * qx + qy * qy) + qz * qz, qn = sqrtf(q2);
@@ -762,8 +863,8 @@ __global__ __launch_bounds__(64, 4) void knn_grid_kernel(const float* __restrict
     unsigned khi[K], klo[K];
 #pragma unroll
     for (int r = 0; r < K; ++r) { khi[r] = 0x7f800000u; klo[r] = 0x7fffffffu; }      // (+inf, no index)
-    float tau = __builtin_inff(), thr = __builtin_inff(), R2 = __builtin_inff();
-    int cnt = 0, staged = 0;
+    float tau = tau_parked, thr = __builtin_inff(), R2 = __builtin_inff();
+    int cnt = 0, staged = 0, visited = 0;
     f32x16 zero;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero[r] = 0.f;
@@ -779,7 +880,7 @@ __global__ __launch_bounds__(64, 4) void knn_grid_kernel(const float* __restrict
                 const float d = knn_d2(qx, qy, qz, p);
                 kg_insert<K>(khi, klo, __builtin_bit_cast(unsigned, d), __builtin_bit_cast(unsigned, p.w));
             }
-        tau = __builtin_bit_cast(float, khi[K - 1]);
+        tau = fminf(__builtin_bit_cast(float, khi[K - 1]), tau_parked);
         thr = (tau - q2) + eps;
         cnt = 0; staged = 0;
         float tq = fminf(tau, __shfl_xor(tau, 32, 64));              // either half list bounds the query's 16th distance
@@ -807,37 +908,29 @@ __global__ __launch_bounds__(64, 4) void knn_grid_kernel(const float* __restrict
                 mask &= ~(1u << pbit);
             }
         }
-        ++staged;
+        ++staged; ++visited;
         __builtin_amdgcn_wave_barrier();           // (the ring rows written above are read by other lanes of this wave in flush)
         if (staged == KG_RING || __any(cnt > KM_QCAP - 16)) flush();
     };
-
-    // ---- seed: the nearest sub-tile fills both half lists (16 candidates each)
-    const int s0 = best_t;
-    process(fetch(s0));
-    // ---- rounds: sub-tiles with prev < lb <= limit (limit fixed per round: no sub-tile is visited twice); a sub-tile is dropped
-    // for good when the bound R2 has tightened below its lb by the time it comes up
-    float prev = -1.f;
-    KG_T(2);
-#pragma unroll 1
-    for (int round = 0; round < KG_ROUNDS; ++round) {
-        flush();
-        const float limit = round == KG_ROUNDS - 1 ? R2 : kg_round_frac(round) * R2;
-        if (!(limit > prev)) continue;
-        int c = -64;
+    // one pass over the sub-tiles with lower < lb <= upper (never the seed); take(ordinal) says whether this wave visits the ordinal-th
+    // of them; a sub-tile whose lb exceeds the CURRENT bound R2 when it comes up is dropped
+    auto visit = [&](const float lower, const float upper, auto take) {
+        int c = -64, seen = 0;
         unsigned long long m = 0;
-        auto next = [&]() -> int {                 // next sub-tile of this round, -1 at the end
-            while (m == 0) {
-                c += 64;
-                if (c >= n_sub) return -1;
-                const int t = c + lane;
-                const bool ok = t < n_sub && t != s0;
-                const float lb = ok ? s_lb[t] : __builtin_inff();
-                m = __ballot(ok && lb > prev && lb <= limit && !(lb > R2));
+        auto next = [&]() -> int {                 // next sub-tile of the pass, -1 at the end
+            for (;;) {
+                while (m == 0) {
+                    c += 64;
+                    if (c >= n_sub) return -1;
+                    const int t = c + lane;
+                    const bool ok = t < n_sub && t != s0;
+                    const float lb = ok ? s_lb[t] : __builtin_inff();
+                    m = __ballot(ok && lb > lower && lb <= upper);
+                }
+                const int bit = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (take(seen++)) return c + bit;
             }
-            const int bit = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            return c + bit;
         };
         int t_cur = next();
         float4 p_cur = fetch(max(t_cur, 0));
@@ -848,66 +941,80 @@ __global__ __launch_bounds__(64, 4) void knn_grid_kernel(const float* __restrict
             t_cur = t_nxt;
             p_cur = p_nxt;
         }
-        prev = limit;
-    }
-    flush();
-    KG_T(3);
-    KG_LOCAL(KG_COUNT(0, dbg_tiles); KG_COUNT(1, dbg_rounds); KG_COUNT(2, dbg_flushes);
-             int mx_ = dbg_mine, sm_ = dbg_mine;
-             for (int o_ = 32; o_ > 0; o_ >>= 1) { mx_ = max(mx_, __shfl_xor(mx_, o_, 64)); sm_ += __shfl_xor(sm_, o_, 64); }
-             KG_COUNT(3, mx_); KG_COUNT(4, sm_ / 64));
-    // ---- merge of the two half lists of every query (a one-wave workgroup: the barriers only order the LDS traffic)
-    __syncthreads();
-    unsigned long long* m_k = reinterpret_cast<unsigned long long*>(s_mem);     // [half][K][32 queries]: 8 KB
+    };
+    KG_T(2);
+    if (MODE == 0) {
+        process(fetch(s0));                        // the seed fills both half lists (16 candidates each)
+        // ---- rounds: sub-tiles with prev < lb <= limit (limit fixed per round: no sub-tile is visited twice)
+#pragma unroll 1
+        for (int round = 0; round < KG_ROUNDS; ++round) {
+            flush();
+            const float limit = round == KG_ROUNDS - 1 ? R2 : kg_round_frac(round) * R2;
+            if (!(limit > prev)) continue;
+            if (def_count) {                       // heavy so far + the band ahead: park the group (see the header)
+                int band = 0;
+                for (int c = 0; c < n_sub; c += 64) {
+                    const int t = c + lane;
+                    const float lb = t < n_sub && t != s0 ? s_lb[t] : __builtin_inff();
+                    band += __popcll(__ballot(lb > prev && lb <= limit));
+                }
+                if (visited + band > KG_HEAVY) {
+                    int sl = 0;
+                    if (lane == 0) sl = atomicAdd(def_count, 1);
+                    sl = __builtin_amdgcn_readfirstlane(sl);
+                    if (sl < KG_MAXDEF) {
+                        KgSlot* hd = kg_slot_hdr(def_scratch, sl);
+                        if (lane == 0) { hd->group = group; hd->b = b; hd->prev = prev; hd->seed = s0; }
+                        float* lbp = kg_slot_lb(def_scratch, sl);
+                        for (int t = lane; t < n_sub; t += 64) lbp[t] = s_lb[t];
+                        unsigned long long* L = kg_slot_lists(def_scratch, sl);
 #pragma unroll
-    for (int r = 0; r < K; ++r) m_k[(h * K + r) * 32 + j] = ((unsigned long long)khi[r] << 32) | klo[r];
-    if (h == 0) s_row[j] = valid ? q : -1;
-    __syncthreads();
-    int head[2] = {0, 0};
-    const size_t o = ((size_t)b * Q + q) * K;
-    int mi[K];
-    if (h == 0) {
-        for (int r = 0; r < K; ++r) {
-            const unsigned long long k0 = head[0] < K ? m_k[(0 * K + min(head[0], K - 1)) * 32 + j] : ~0ull;
-            const unsigned long long k1 = head[1] < K ? m_k[(1 * K + min(head[1], K - 1)) * 32 + j] : ~0ull;
-            const bool first = k0 <= k1;           // equal only for two empty slots
-            const unsigned long long kb = first ? k0 : k1;
-            head[0] += first ? 1 : 0;
-            head[1] += first ? 0 : 1;
-            mi[r] = (int)(unsigned)kb;
-            if (valid) {
-                if (out_idx) out_idx[o + r] = (long long)mi[r];
-                if (out_dist) out_dist[o + r] = sqrt_cr(__builtin_bit_cast(float, (unsigned)(kb >> 32)));
+                        for (int r = 0; r < K; ++r) L[(h * K + r) * 32 + j] = ((unsigned long long)khi[r] << 32) | klo[r];
+                        return;
+                    }
+                }
             }
+            visit(prev, limit, [](int) { return true; });
+            prev = limit;
         }
-    }
-    // ---- neighbour coordinates through LDS; a query's K x 3 floats are one contiguous, 16-byte aligned run of out_pts
-    __syncthreads();
-    float* st = reinterpret_cast<float*>(s_mem);   // [32 queries][K][3]
-    if (h == 0) {
+        flush();
+        KG_T(3);
+        KG_LOCAL(KG_COUNT(0, dbg_tiles); KG_COUNT(1, dbg_rounds); KG_COUNT(2, dbg_flushes);
+                 int mx_ = dbg_mine, sm_ = dbg_mine;
+                 for (int o_ = 32; o_ > 0; o_ >>= 1) { mx_ = max(mx_, __shfl_xor(mx_, o_, 64)); sm_ += __shfl_xor(sm_, o_, 64); }
+                 KG_COUNT(3, mx_); KG_COUNT(4, sm_ / 64));
+        kg_output<K, OFFSETS, true>(khi, klo, s_mem, s_row, lane, b, Q, q, valid, qx, qy, qz, pcb, out_idx, out_dist, out_pts);
+        KG_T(4);
+    } else {
+        s0 = kg_slot_hdr(def_scratch, slot)->seed; // (the parked wave's seed: already in its lists)
+        flush();                                   // thresholds from the parked 16th distances
+        const float upper = R2;
+        visit(prev, upper, [&](int ordinal) { return ordinal % KG_SPLIT == part; });
+        flush();
+        // ---- fold the KG_SPLIT list sets pairwise: waves [n, 2n) hand theirs to waves [0, n) through LDS; every step inserts at most
+        // K keys per lane (ascending: stop when no lane's entry beats its 16th any more)
+        auto absorb = [&](const unsigned long long* src) {       // src: [half][K][32 queries]
+            for (int r = 0; r < K; ++r) {
+                const unsigned long long k = src[(h * K + r) * 32 + j];
+                if (!__any(k < (((unsigned long long)khi[K - 1] << 32) | klo[K - 1]))) break;
+                kg_insert<K>(khi, klo, (unsigned)(k >> 32), (unsigned)k);
+            }
+        };
+#pragma unroll 1
+        for (int n = KG_SPLIT / 2; n >= 1; n >>= 1) {
+            __syncthreads();                       // every wave is out of its own LDS area (search / previous step)
+            if (part >= n && part < 2 * n) {
+                unsigned long long* dst = reinterpret_cast<unsigned long long*>(s_all + (part - n) * KG_LDS_BYTES);
 #pragma unroll
-        for (int r = 0; r < K; ++r) {
-            const int id = mi[r] == 0x7fffffff ? 0 : mi[r];
-            const float* p = pcb + (size_t)id * 3;
-            st[(j * K + r) * 3 + 0] = OFFSETS ? p[0] - qx : p[0];
-            st[(j * K + r) * 3 + 1] = OFFSETS ? p[1] - qy : p[1];
-            st[(j * K + r) * 3 + 2] = OFFSETS ? p[2] - qz : p[2];
+                for (int r = 0; r < K; ++r) dst[(h * K + r) * 32 + j] = ((unsigned long long)khi[r] << 32) | klo[r];
+            }
+            __syncthreads();
+            if (part < n) absorb(reinterpret_cast<const unsigned long long*>(s_mem));
         }
+        if (part != 0) return;                     // (no barrier below involves the other waves: kg_output's are wave-local in effect)
+        absorb(kg_slot_lists(def_scratch, slot));
+        kg_output<K, OFFSETS, false>(khi, klo, s_mem, s_row, lane, b, Q, q, valid, qx, qy, qz, pcb, out_idx, out_dist, out_pts);
     }
-    __syncthreads();
-    static_assert((K * 3) % 4 == 0, "a query's output row must be whole 16-byte chunks");
-    constexpr int CH = K * 3 / 4;                  // chunks per query row
-    float* dst = out_pts + (size_t)b * Q * K * 3;
-    const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
-    for (int c = lane; c < 32 * CH; c += 64) {
-        const int row = c / CH, ch = c - row * CH, qr = s_row[row];
-        if (qr < 0) continue;
-        float* d = dst + (size_t)qr * K * 3 + ch * 4;
-        const float4 v = reinterpret_cast<const float4*>(st)[c];
-        if (aligned) *reinterpret_cast<float4*>(d) = v;
-        else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
-    }
-    KG_T(4);
 }
 
 template <int K>
@@ -958,7 +1065,8 @@ size_t knn_grid_cloud_bytes(int64_t B, int64_t M) {
     return kg_al(B * sizeof(KgCloud)) + kg_al(B * Mpad * 16) + kg_al(B * (Mpad / 32) * 32);
 }
 // qperm [B][Q] (device, inside ws): the queries of every cloud in the order the grid kernel walks them
-const int* knn_grid_order_queries(hipStream_t s, const float* X, int64_t B, int64_t Q, void* ws) {
+const int* knn_grid_order_queries(hipStream_t s, const float* X, int64_t B, int64_t Q, void* ws, void* park_ws) {
+    if (park_ws) (void)hipMemsetAsync(park_ws, 0, 256, s);         // the parked-group counters of the launches that will use this order
     char* w = (char*)ws;
     int* qbox = (int*)w; w += kg_al(B * 8 * 4);
     int* hist = (int*)w; w += kg_al((size_t)B * KG_QCELLS * 4);
@@ -994,10 +1102,13 @@ KnnGridCloud knn_grid_build_cloud(hipStream_t s, const float* pc, int64_t B, int
     knn_grid_build_clouds(s, 1, &pc, &M, B, &ws, &c);
     return c;
 }
+// scratch of the parked groups: one counter per launch (`launch` < 64; zeroed by knn_grid_order_queries) + KG_MAXDEF slots (re-used by
+// consecutive launches on the stream)
+size_t knn_grid_park_bytes() { return 256 + (size_t)KG_MAXDEF * KG_SLOT_BYTES; }
 // clouds b_first .. b_first + n_b - 1 of a batch whose INPUT arrays are laid out [B][...]; idx / dist / pts: the outputs of these n_b
-// clouds, as mcr_knn_points writes them (k = 16)
+// clouds, as mcr_knn_points writes them (k = 16).  park_ws (knn_grid_park_bytes(), may be NULL: no parking) + the launch's ordinal
 void launch_knn16_grid(hipStream_t s, const float* X, const float* pc, int64_t M, const int* qperm, const KnnGridCloud& c, int64_t b_first,
-                       int64_t n_b, int64_t Q, int64_t* idx, float* dist, float* pts, bool offsets) {
+                       int64_t n_b, int64_t Q, int64_t* idx, float* dist, float* pts, bool offsets, void* park_ws, int launch) {
     if (n_b <= 0 || Q <= 0) return;
     const float* Xb = X + b_first * Q * 3;
     const float* pcb = pc + b_first * M * 3;
@@ -1008,14 +1119,22 @@ void launch_knn16_grid(hipStream_t s, const float* X, const float* pc, int64_t M
     long long* i64 = (long long*)idx;             // the outputs are those of cloud b_first already
     float* d = dist;
     float* o = pts;
+    static const bool park_on = []() { const char* e = getenv("MCR_KNN_PARK"); return !(e && e[0] == '0'); }();          // dev A/B knob
+    int* def_count = park_ws && park_on && launch >= 0 && launch < 64 ? (int*)park_ws + launch : nullptr;
+    char* def_scratch = park_ws ? (char*)park_ws + 256 : nullptr;
     dim3 grid((unsigned)cdiv(Q, 32), (unsigned)n_b);
     const int n_sub = (int)(c.cand_stride / 32);
-    if (offsets)
-        hipLaunchKernelGGL((knn_grid_kernel<16, true>), grid, dim3(64), 0, s, Xb, pcb, (long long)(M * 3), qp, cand, boxes, hdr,
-                           (long long)c.cand_stride, (long long)c.box_stride, n_sub, i64, d, o, (int)Q);
-    else
-        hipLaunchKernelGGL((knn_grid_kernel<16, false>), grid, dim3(64), 0, s, Xb, pcb, (long long)(M * 3), qp, cand, boxes, hdr,
-                           (long long)c.cand_stride, (long long)c.box_stride, n_sub, i64, d, o, (int)Q);
+#define KG_LAUNCH(OFF)                                                                                                                     \
+    do {                                                                                                                                   \
+        hipLaunchKernelGGL((knn_grid_kernel<16, OFF, 0>), grid, dim3(64), 0, s, Xb, pcb, (long long)(M * 3), qp, cand, boxes, hdr,         \
+                           (long long)c.cand_stride, (long long)c.box_stride, n_sub, i64, d, o, (int)Q, def_count, def_scratch);           \
+        if (def_count)                                                                                                                     \
+            hipLaunchKernelGGL((knn_grid_kernel<16, OFF, 1>), dim3(KG_MAXDEF), dim3(64 * KG_SPLIT), 0, s, Xb, pcb, (long long)(M * 3), qp, cand,  \
+                               boxes, hdr, (long long)c.cand_stride, (long long)c.box_stride, n_sub, i64, d, o, (int)Q, def_count, def_scratch); \
+    } while (0)
+    if (offsets) KG_LAUNCH(true);
+    else KG_LAUNCH(false);
+#undef KG_LAUNCH
 }
 }  // namespace mcr
 
@@ -1041,7 +1160,7 @@ extern "C" int mcr_knn_points(const float* X, const float* pc, int64_t* idx, flo
 }
 
 extern "C" size_t mcr_knn_grid_workspace_bytes(int64_t B, int64_t Q, int64_t M) {
-    return knn_grid_query_bytes(B, Q) + knn_grid_cloud_bytes(B, M) + 512;
+    return knn_grid_query_bytes(B, Q) + knn_grid_cloud_bytes(B, M) + knn_grid_park_bytes() + 512;
 }
 
 // mcr_knn_points with a scratch buffer: the grid-pruned search where it applies (k = 16, 1024 <= M <= 16384), the brute-force
@@ -1053,9 +1172,10 @@ extern "C" int mcr_knn_points_grid(const float* X, const float* pc, int64_t* idx
     MCR_REQUIRE(B > 0 && Q > 0 && B <= 65535 && Q < (1ll << 31), "mcr_knn_points_grid: bad problem size B=%ld Q=%ld", (long)B, (long)Q);
     MCR_REQUIRE(workspace && workspace_bytes >= mcr_knn_grid_workspace_bytes(B, Q, M), "mcr_knn_points_grid: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    const int* qperm = knn_grid_order_queries(s, X, B, Q, workspace);
+    char* park = (char*)workspace + knn_grid_query_bytes(B, Q) + knn_grid_cloud_bytes(B, M);
+    const int* qperm = knn_grid_order_queries(s, X, B, Q, workspace, park);
     const KnnGridCloud c = knn_grid_build_cloud(s, pc, B, M, (char*)workspace + knn_grid_query_bytes(B, Q));
-    launch_knn16_grid(s, X, pc, M, qperm, c, 0, B, Q, idx, dists, pts, subtract_query != 0);
+    launch_knn16_grid(s, X, pc, M, qperm, c, 0, B, Q, idx, dists, pts, subtract_query != 0, park, 0);
     MCR_LAUNCH_CHECK("knn_grid_kernel");
     return 0;
 }

@@ -350,7 +350,7 @@ size_t mcr_scone_occ_workspace_bytes(int64_t B, int64_t Q, int64_t Lg) {
     size_t head = al(B * Q * 1344) + al(B * Q * 512) + al(B * Q * 256) + al(B * 512) * 2;
     head += linear3h_planes_bytes(512, 1344);        // split weight planes of the largest head layer (reused layer after layer)
     // grid-pruned kNN (knn.hip: K1-grid): the query order of all clouds + one sorted candidate copy (the largest admissible cloud)
-    const size_t knn_grid = knn_grid_query_bytes(B, Q) + 3 * knn_grid_cloud_bytes(B, 16384) + 1024;
+    const size_t knn_grid = knn_grid_query_bytes(B, Q) + 3 * knn_grid_cloud_bytes(B, 16384) + knn_grid_park_bytes() + 1024;
     return local + glob + head + knn_grid + 8192;          // local and global paths run concurrently (two streams): disjoint scratch
 }
 
@@ -416,6 +416,7 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     const size_t knn_q_bytes = knn_grid_query_bytes(B, Q), knn_c_bytes = knn_grid_cloud_bytes(B, 16384);
     char* knn_q_ws = (char*)head.f((knn_q_bytes + 3) / 4);
     char* knn_c_ws = (char*)head.f((3 * knn_c_bytes + 3) / 4);
+    char* knn_park_ws = (char*)head.f((knn_grid_park_bytes() + 3) / 4);
     const size_t glob_bytes = pct_ws_bytes(B * Lg);
     Arena garena{(char*)workspace + head.off, glob_bytes, 0};
     Arena scratch{(char*)workspace + head.off + glob_bytes, workspace_bytes - head.off - glob_bytes, 0};
@@ -470,7 +471,7 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
                 knn_slot[sc] = n_grid++;
             }
         if (n_grid) {
-            knn_qperm = knn_grid_order_queries(s, x, B, Q, knn_q_ws);
+            knn_qperm = knn_grid_order_queries(s, x, B, Q, knn_q_ws, knn_park_ws);
             knn_grid_build_clouds(s, n_grid, g_pc, g_M, B, g_ws, knn_clouds);
             MCR_LAUNCH_CHECK("knn grid preparation");
         }
@@ -486,7 +487,8 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
                 MCR_REQUIRE(a.ok(), "mcr_scone_occ_forward: workspace overflow (kNN)");
                 // only the offsets are consumed (SconeOcc.py:297-298): indices and distances are not written
                 if (grid_knn) {
-                    launch_knn16_grid(s, x, pc_scale[sc], M_scale[sc], knn_qperm, knn_cloud, b, 1, Q, nullptr, nullptr, offs, true);
+                    launch_knn16_grid(s, x, pc_scale[sc], M_scale[sc], knn_qperm, knn_cloud, b, 1, Q, nullptr, nullptr, offs, true, knn_park_ws,
+                                      (int)(sc * B + b));
                     MCR_LAUNCH_CHECK("knn_grid_kernel");
                 } else if (int e = mcr_knn_points(x + (b * Q + q0) * 3, pc_scale[sc] + b * M_scale[sc] * 3, nullptr, nullptr, offs, 1, nq,
                                                   M_scale[sc], 16, 1, stream))

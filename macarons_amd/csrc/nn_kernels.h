@@ -88,11 +88,12 @@ struct KnnGridCloud { const void* cand; const void* boxes; const void* hdr; int6
 bool knn_grid_applicable(int64_t M, int k);
 size_t knn_grid_query_bytes(int64_t B, int64_t Q);
 size_t knn_grid_cloud_bytes(int64_t B, int64_t M);
-const int* knn_grid_order_queries(hipStream_t s, const float* X, int64_t B, int64_t Q, void* ws);
+size_t knn_grid_park_bytes();
+const int* knn_grid_order_queries(hipStream_t s, const float* X, int64_t B, int64_t Q, void* ws, void* park_ws);
 KnnGridCloud knn_grid_build_cloud(hipStream_t s, const float* pc, int64_t B, int64_t M, void* ws);
 void knn_grid_build_clouds(hipStream_t s, int n, const float* const* pc, const int64_t* M, int64_t B, void* const* ws, KnnGridCloud* out);
 void launch_knn16_grid(hipStream_t s, const float* X, const float* pc, int64_t M, const int* qperm, const KnnGridCloud& c, int64_t b_first,
-                       int64_t n_b, int64_t Q, int64_t* idx, float* dist, float* pts, bool offsets);
+                       int64_t n_b, int64_t Q, int64_t* idx, float* dist, float* pts, bool offsets, void* park_ws, int launch);
 int local_pct_blob_floats();
 int local_pct3_blob_floats();
 int local_pct6_blob_floats();
