@@ -13,7 +13,7 @@ from torch import nn
 from .. import autograd as A
 from .. import ops, _lib
 from .Attention import Embedding, Encoder, _f32c, _inference_only
-from .packing import BlobCache, HeadPlaneCache, TableCache
+from .packing import BlobCache, HeadPlaneCache, TableCache, param_key, invalidate as _invalidate_key
 
 
 class XEmbedding(nn.Module):
@@ -113,6 +113,7 @@ class SconeOcc(nn.Module):
         self._blob_caches = [BlobCache() for _ in range(n_scale)]
         self._table_cache = TableCache()
         self._head_cache = HeadPlaneCache()
+        self._key_cache = {}
         # Range guard of the default numerics (variant 6: matrix products on fp16 hi/lo planes, valid for |activation| < 65504;
         # the reference is plain fp32, Attention.py:98-128): the kernels flag a non-finite occupancy -- what an out-of-range
         # activation turns into -- and the forward is repeated on variant 5 (bf16 hi/mid/lo, the whole fp32 range).
@@ -134,6 +135,7 @@ class SconeOcc(nn.Module):
     def invalidate_weight_caches(self):
         """Drop every derived weight image (pointer table, packed local-transformer blobs, stacked QKV, split head planes): call
         after editing parameters in a way no fingerprint can see (in place through `p.data`, see packing._param_key)."""
+        _invalidate_key(self._key_cache)                             # the shared per-forward fingerprint: every cache below rebuilds
         self._table_cache.invalidate()
         self._head_cache.invalidate()
         for c in self._blob_caches:
@@ -233,11 +235,12 @@ class SconeOcc(nn.Module):
         variant = L.mcr_get_local_pct_variant()
 
         def run(variant, flag):
-            blobs = [c.get(t, variant) for c, t in zip(self._blob_caches, self.local_transformers)]
-            head = self._head_cache.get(self) if variant == 6 else None
+            key = param_key(self, self._key_cache)                  # one fingerprint of the parameters for every derived image
+            blobs = [c.get(t, variant, key) for c, t in zip(self._blob_caches, self.local_transformers)]
+            head = self._head_cache.get(self, key) if variant == 6 else None
             return ops.scone_occ_forward_ragged(pc_global, cut[6].to(torch.int32), [pc, pc1, pc2], [cut[3], cut[4], cut[5]], x, view_harmonics,
                                                 cut[7].to(torch.int32), cut[8].to(torch.int32).view(-1, 4),
-                                                self._table_cache.get(self, self.weight_table), blobs, head, flag)
+                                                self._table_cache.get(self, self.weight_table, key), blobs, head, flag)
         flag = None
         if variant == 6 and self.range_guard != "off":
             if self._range_flag is None or self._range_flag.device != dev:
@@ -276,9 +279,10 @@ class SconeOcc(nn.Module):
         variant = L.mcr_get_local_pct_variant()
 
         def run(variant, pc_global, scales, x_, vh_, flag):
-            blobs = [c.get(t, variant) for c, t in zip(self._blob_caches, self.local_transformers)] if self.fused_local else None
-            head = self._head_cache.get(self) if variant == 6 else None
-            return ops.scone_occ_forward(pc_global, scales, x_, vh_, self._table_cache.get(self, self.weight_table), blobs, head, flag)
+            key = param_key(self, self._key_cache)                  # one fingerprint of the parameters for every derived image
+            blobs = [c.get(t, variant, key) for c, t in zip(self._blob_caches, self.local_transformers)] if self.fused_local else None
+            head = self._head_cache.get(self, key) if variant == 6 else None
+            return ops.scone_occ_forward(pc_global, scales, x_, vh_, self._table_cache.get(self, self.weight_table, key), blobs, head, flag)
 
         flag = None
         if variant == 6 and self.range_guard != "off":

@@ -112,6 +112,11 @@ def _param_key(module, cache):
     return tuple(key)
 
 
+def param_key(module, cache):
+    """Public form of the fingerprint: one key per forward, shared by all derived-image caches of the module."""
+    return _param_key(module, cache)
+
+
 def invalidate(cache):
     """Forget the sub-module list and force the next key to differ (explicit invalidation hook)."""
     cache.pop("mods", None)
@@ -127,8 +132,11 @@ class BlobCache:
     def invalidate(self):
         invalidate(self._c)
 
-    def get(self, pct, variant=1):
-        key = (variant,) + _param_key(pct, self._c)
+    def get(self, pct, variant=1, key=None):
+        """key: a fingerprint that covers at least pct's parameters (the owner's whole-module key, taken once per forward: the three
+        local transformers, the pointer table and the head planes of a SconeOcc otherwise fingerprint ~400 parameters per call,
+        ~150 us of host time in front of the first launch)."""
+        key = (variant,) + (key if key is not None else _param_key(pct, self._c))
         if key != self._key:
             self._blob, self._key = pack_local_pct(pct, variant), key
         return self._blob
@@ -144,8 +152,8 @@ class TableCache:
     def invalidate(self):
         invalidate(self._c)
 
-    def get(self, module, build):
-        key = _param_key(module, self._c)
+    def get(self, module, build, key=None):
+        key = key if key is not None else _param_key(module, self._c)
         if key != self._key:
             tensors = build()
             import ctypes
@@ -279,8 +287,8 @@ class HeadPlaneCache:
     def invalidate(self):
         invalidate(self._c)
 
-    def get(self, occ):
-        key = _param_key(occ, self._c)
+    def get(self, occ, key=None):
+        key = key if key is not None else _param_key(occ, self._c)
         if key != self._key:
             import ctypes
             g = occ.global_feature_dim

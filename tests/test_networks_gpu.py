@@ -148,6 +148,50 @@ def test_scone_occ_forward(dev):
             assert np.array_equal(y, y2)
 
 
+def test_weight_caches_follow_parameter_changes(dev):
+    """The derived weight images (packed local-transformer blobs, pointer table, head planes) share one fingerprint per forward:
+    every kind of parameter change an optimizer or a checkpoint load makes must reach all of them, and an edit no fingerprint can
+    see (in place through .data) must reach them through invalidate_weight_caches()."""
+    from macarons_amd.networks import SconeOcc
+    m, sd = _mod(SconeOcc, 2, dev)
+    g = golden("scone_occ")
+    tag = "m1024_q300"
+    perms = [torch.from_numpy(g[f"{tag}_perm{i}"].astype(np.int64)) for i in range(3)]
+    pc, x, vh = T(g[f"{tag}_pc"], dev), T(g[f"{tag}_x"], dev), T(g[f"{tag}_vh"], dev)
+
+    def expected(edit):                            # a freshly built module with the same edit: no cache history
+        r, _ = _mod(SconeOcc, 2, dev)
+        with torch.no_grad():
+            edit(r)
+            return r(pc, x, vh, perms=perms)
+
+    with torch.no_grad():
+        y0 = m(pc, x, vh, perms=perms)
+        # (a) in-place update as an optimizer does it (version counter): blob of local transformer 1, head planes, table
+        def step(r):
+            r.local_transformers[1].linear0.weight.mul_(1.25)
+            r.linear2.weight.add_(0.01)
+            r.linear3.bias.add_(0.1)
+        step(m)
+        y1 = m(pc, x, vh, perms=perms)
+        assert not torch.equal(y1, y0) and torch.equal(y1, expected(step))
+        # (b) a new Parameter object (identity) and new storage (load_state_dict(assign=True)-like)
+        def swap(r):
+            step(r)
+            r.x_embedding.linear2.weight = torch.nn.Parameter(r.x_embedding.linear2.weight.detach().clone() * 0.5)
+        m.x_embedding.linear2.weight = torch.nn.Parameter(m.x_embedding.linear2.weight.detach().clone() * 0.5)
+        y2 = m(pc, x, vh, perms=perms)
+        assert not torch.equal(y2, y1) and torch.equal(y2, expected(swap))
+        # (c) in place through .data: invisible to the fingerprint (documented) until the caches are invalidated
+        def hidden(r):
+            swap(r)
+            r.local_transformers[0].linear0.weight.data.mul_(1.5)
+        m.local_transformers[0].linear0.weight.data.mul_(1.5)
+        m.invalidate_weight_caches()
+        y3 = m(pc, x, vh, perms=perms)
+        assert not torch.equal(y3, y2) and torch.equal(y3, expected(hidden))
+
+
 def test_scone_occ_chunking_and_batch(dev):
     """Q larger than one chunk and B > 1 against the oracle on a sample of queries."""
     from macarons_amd.networks import SconeOcc
