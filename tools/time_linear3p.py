@@ -2,6 +2,9 @@
 event pair around SconeOcc.forward minus nothing -- use with rocprofv3 --kernel-trace, or MCR_L3P_KO knock-outs (128-tile kernel)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from macarons_amd import _lib
+if os.environ.get("MCR_DEV_LIB"):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_libs", f"libmacarons_hip_{os.environ['MCR_DEV_LIB']}.so")
 import bench
 dev = torch.device("cuda:0")
 occ, vis = bench.build_models(dev)
