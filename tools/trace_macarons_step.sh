@@ -1,0 +1,34 @@
+#!/bin/bash
+# Dev: GPU busy / idle inside one MACARONS decision (kernel trace of bench.measure_macarons_step): decisions are delimited by the
+# fused depth update (proxy_update_kernel)
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/mtrace; timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/mtrace -o t -- python -c "
+import sys; sys.path.insert(0, '/root/repo')
+import torch, bench
+print(bench.measure_macarons_step(torch.device('cuda:0'))['p50_ms'])" > /tmp/mtrace.log 2>&1
+tail -1 /tmp/mtrace.log
+python - <<'PY'
+import csv, glob, collections
+f = glob.glob("/tmp/mtrace/**/t_kernel_trace.csv", recursive=True)[0]
+rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
+starts = [i for i, r in enumerate(rows) if "proxy_update_kernel" in r[2]]
+res = []
+for a, b in zip(starts[3:-1], starts[4:]):
+    seg = rows[a:b]
+    span = max(e for _, e, _ in seg) - seg[0][0]
+    busy, gaps, cur_end, last = 0, [], seg[0][0], seg[0][2]
+    for s_, e_, n_ in seg:
+        if s_ > cur_end:
+            gaps.append((s_ - cur_end, last[:48], n_[:48])); busy += e_ - s_
+        else:
+            busy += max(0, e_ - cur_end)
+        if e_ > cur_end: cur_end, last = e_, n_
+    res.append((span, busy, sorted(gaps, reverse=True)[:12], len(seg), seg))
+res.sort(key=lambda x: x[0])
+span, busy, gaps, n, seg = res[len(res) // 2]
+print(f"median decision: {n} kernels, span {span/1e6:.3f} ms, busy {busy/1e6:.3f} ms, idle {(span-busy)/1e6:.3f} ms")
+for g, a, b in gaps: print(f"  gap {g/1e3:8.1f} us  after {a}  before {b}")
+agg = collections.defaultdict(lambda: [0, 0])
+for s_, e_, n_ in seg: agg[n_[:60]][0] += e_ - s_; agg[n_[:60]][1] += 1
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]: print(f"  {v[0]/1e3:9.1f} us x{v[1]:4d}  {k}")
+PY
