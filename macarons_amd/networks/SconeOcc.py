@@ -197,6 +197,7 @@ class SconeOcc(nn.Module):
         J = len(cloud_sizes)
         if perms is None:
             perms = [self.draw_perms(int(m)) for m in cloud_sizes]
+        self.last_ragged_perms = perms                                 # (a caller that repeats the pass on another variant re-uses the draws)
         L = _lib.lib()
         # ---- index arrays of the down-sampled clouds, built on the host from the draws, ONE upload
         Lg = self.seq_len

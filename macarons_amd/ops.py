@@ -470,13 +470,32 @@ def coverage_gain_multiple(pts, harmonics, cams, n_cam, use_sigmoid=True):
     return out, n_idx
 
 
+def h2d(data, dtype, device):
+    """Host data (list / numpy array / CPU tensor) -> device tensor WITHOUT stalling the host: a `.to(device)` from pageable memory
+    is a stream-ordered blocking copy, i.e. the host waits for every kernel queued before it (the glue of a MACARONS decision did
+    that ~15 times per decision).  Staged through PyTorch's cached pinned allocator and copied asynchronously instead."""
+    t = data if torch.is_tensor(data) else torch.as_tensor(data)
+    t = t.to(dtype) if t.dtype != dtype else t
+    device = torch.device(device)
+    if device.type != "cuda" or t.device.type != "cpu":
+        return t.to(device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
 def gather_columns(x, idx):
-    """x [..., V] fp32, idx [V] integer (values in [0, V)) -> x[..., idx] (torch.gather along the last dim with one index row)."""
+    """x [..., V] fp32, idx [V] integer (values in [0, V)) -> x[..., idx] (torch.gather along the last dim with one index row).
+    A host idx is range-checked on the host and uploaded without a stall; a device idx is trusted (checking it would read it
+    back)."""
     x = _req(x, "x")
     V = x.shape[-1]
-    idx = idx.to(device=x.device, dtype=torch.int32).contiguous()
-    if idx.numel() != V or int(idx.min()) < 0 or int(idx.max()) >= V:
-        raise ValueError("gather_columns: idx must hold V indices in [0, V)")
+    if idx.device.type == "cpu":
+        if idx.numel() != V or int(idx.min()) < 0 or int(idx.max()) >= V:
+            raise ValueError("gather_columns: idx must hold V indices in [0, V)")
+        idx = h2d(idx, torch.int32, x.device)
+    else:
+        if idx.numel() != V:
+            raise ValueError("gather_columns: idx must hold V indices in [0, V)")
+        idx = idx.to(device=x.device, dtype=torch.int32).contiguous()
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
         check(lib().mcr_gather_columns(_p(x), _p(idx), _p(out), c_i64(x.numel() // V), c_int(V), _stream()), "mcr_gather_columns")

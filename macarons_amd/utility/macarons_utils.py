@@ -56,7 +56,7 @@ def get_distance_factor_smooth(params, pts, X_cam, fov_camera, cell_resolution):
 
 def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harmonics, occ_probs, cameras, X_cam_world,
                                       prediction_view_matrices, prediction_box_diag, seq_len=2048, min_occ=0.1,
-                                      distance_th=17., samples=None, smooth=False, return_parts=False):
+                                      distance_th=17., samples=None, smooth=False, return_parts=False, record=None):
     """The per-neighbour-camera scoring loop of testers/scene.py:434-454 around
     predict_coverage_gain_for_single_camera (macarons_utils.py:1580-1738), for K cameras AT ONCE and without a host
     synchronisation (the reference runs one SconeVis forward and reads a count back per camera):
@@ -76,8 +76,12 @@ def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harm
     # read back (padded rows, counts on the device).  Uniforms: one torch.rand(S, 1) per camera in order, as K calls would draw.
     if samples is None:
         u = torch.stack([torch.rand(S, 1, device=dev).view(-1) for _ in range(K)])
+    elif torch.is_tensor(samples):
+        u = samples.to(dev).reshape(K, S).float()
     else:
         u = torch.stack([torch.as_tensor(x, device=dev).reshape(-1) for x in samples]).float()
+    if record is not None:
+        record["samples"] = u                                                               # (a re-run must see the same uniforms)
     res, res_h, inv, _, nu, vol = ops.sample_proxy_batched(X_world, occ_k, proxy_view_harmonics, u.contiguous(), min_occ)
     vol = vol.float()                                                                      # [K,S,4] [K,S,64] [K,S]; [K] int32, [K]
     # ---- prediction box: centre of the sampled points' bounding box, in the prediction camera's view space (:1631-1641)
@@ -124,7 +128,7 @@ class SceneCamera:
 
 
 def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, depth, depth_mask, neighbor_records, X_neighbors,
-                          device, samples=None, return_signed_distances=False):
+                          device, samples=None, return_signed_distances=False, range_guard=True):
     """One next-best-view decision of the MACARONS loop after the depth map of the current pose is known -- the body of
     testers/scene.py:391-454 (everything between the depth network and the move to the chosen pose):
       1. proxy points in the current frustum (Camera.get_points_in_fov :391), registered in the proxy grid (:394-395);
@@ -134,40 +138,85 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     camera: SceneCamera of the current pose (it is also the prediction camera, fov_camera_0 of :305); depth [H,W] (+ optional
     leading/trailing singleton dims), depth_mask like depth; neighbor_records [K,40], X_neighbors [K,3].
     Returns dict(next_idx (device int64: index into the neighbour list), gains [K], fov_mask [P] bool, X_world, view_harmonics,
-    occ_probs).  The scene objects are updated in place like upstream.  Nothing but the occupancy-field pass (cell bookkeeping on
-    the host, as upstream) synchronises with the host."""
+    occ_probs).  The scene objects are updated in place like upstream.  Host synchronisations: the cell counts of the occupancy-field
+    pass (cell bookkeeping on the host, as upstream), fill_cells' one, and -- range_guard=True -- the range flag of the fp16-split
+    path, read once at the end (range_guard=False: the caller checks macarons.occupancy.range_flag() itself)."""
     H, W = params.image_height, params.image_width
     depth2 = depth.reshape(H, W).contiguous().float()
     dmask2 = depth_mask.reshape(H, W) if depth_mask is not None else None
-    rec = camera.record.to(device)
+    rec = ops.h2d(camera.record, torch.float32, device)
     # 1 ---- proxy points in the current field of view, registered in their grid cells with their index as feature
     fov_mask = ops.points_in_fov(proxy_scene.proxy_points, rec.view(1, 40))[0]
     fov_idx = proxy_scene.get_proxy_indices_from_mask(fov_mask)
-    proxy_scene.fill_cells(proxy_scene.proxy_points[fov_mask], features=fov_idx.view(-1, 1).float())
+    proxy_scene.fill_cells(proxy_scene.proxy_points[fov_idx.view(-1)], features=fov_idx.view(-1, 1).float())   # (index, not mask: one read-back less)
     # 2 ---- carve with the depth map: signed distance, view states, supervision occupancy, out-of-field, one launch
-    sgn = proxy_scene.update_from_depth(fov_mask, rec, camera.X_cam.to(device), depth2, dmask2, fill=1.1 * camera.zfar,
+    sgn = proxy_scene.update_from_depth(fov_mask, rec, ops.h2d(camera.X_cam, torch.float32, device), depth2, dmask2, fill=1.1 * camera.zfar,
                                         tol=params.carving_tolerance, return_signed_distances=return_signed_distances)
     surface_scene.set_all_features_to_value(value=1.)
-    # 3 ---- occupancy probability field, in the current camera's view space
-    Mv = camera.M_view.to(device)
-    X_world, view_harmonics, occ_probs = compute_scene_occupancy_probability_field(params, macarons, None, surface_scene, proxy_scene,
-                                                                                   device, prediction_camera=Mv)
-    # 4 ---- neighbours
+    # 3 ---- occupancy probability field, in the current camera's view space; 4 ---- neighbours.
+    # The range check of the fp16-split path (SconeOcc.range_guard) is DEFERRED to one read-back at the very end: checked inside
+    # the occupancy pass it stalls the host until the pass has run, and the ~200 small launches of the glue behind it then start
+    # on an idle GPU (kernel trace of one decision: 9 of 22 ms idle).  On a set flag steps 3-4 are repeated on the full-range
+    # variant with the SAME hidden draws (cell permutations, sampling uniforms).
+    Mv_field = camera.M_view                          # where the caller keeps it: a host matrix is used on the host, uploaded without a stall
+    Mv = ops.h2d(Mv_field, torch.float32, device)
     K = neighbor_records.shape[0]
     th = params.distance_factor_th
     smooth = th == 'smooth'
     if th is None or smooth:
         th = sensor_distance_threshold(params, camera, surface_scene.cell_resolution)
     vis_model = macarons.visibility                 # `macarons` = the SCONE part (Macarons.scone upstream): .occupancy / .visibility
-    diag = torch.linalg.norm(proxy_scene.x_max - proxy_scene.x_min).item()
-    gains = predict_coverage_gain_for_cameras(vis_model, X_world, view_harmonics, occ_probs, neighbor_records.to(device),
-                                              X_neighbors.to(device), Mv.reshape(1, 4, 4).expand(K, -1, -1), diag,
-                                              seq_len=params.seq_len, min_occ=params.min_occ_for_proxy_points, distance_th=float(th),
-                                              samples=samples, smooth=smooth)
+    diag = getattr(proxy_scene, "_mcr_box_diag", None)      # a constant of the scene: read back once, not once per decision
+    if diag is None:
+        diag = torch.linalg.norm(proxy_scene.x_max - proxy_scene.x_min).item()
+        try:
+            proxy_scene._mcr_box_diag = diag
+        except Exception:
+            pass
+    occ_net = getattr(macarons, "occupancy", macarons)
+    nrec, xn = ops.h2d(neighbor_records, torch.float32, device), ops.h2d(X_neighbors, torch.float32, device)
+
+    def field_and_gains(ragged_perms, smp, record):
+        X_world, view_harmonics, occ_probs = compute_scene_occupancy_probability_field(params, macarons, None, surface_scene, proxy_scene,
+                                                                                       device, prediction_camera=Mv_field, ragged_perms=ragged_perms)
+        gains = predict_coverage_gain_for_cameras(vis_model, X_world, view_harmonics, occ_probs, nrec, xn,
+                                                  Mv.reshape(1, 4, 4).expand(K, -1, -1), diag, seq_len=params.seq_len,
+                                                  min_occ=params.min_occ_for_proxy_points, distance_th=float(th), samples=smp,
+                                                  smooth=smooth, record=record)
+        return X_world, view_harmonics, occ_probs, gains
+
+    deferred = range_guard and getattr(occ_net, "range_guard", None) == "sync" and hasattr(occ_net, "forward_ragged")
+    record = {}
+    if deferred:
+        occ_net.range_guard = "defer"
+        occ_net.clear_range_flag()
+    try:
+        X_world, view_harmonics, occ_probs, gains = field_and_gains(None, samples, record)
+        fallback = None
+        if deferred:
+            flag = occ_net.range_flag()
+            if flag is not None and int(flag):      # the one read-back; out of the fp16 range: repeat on the full-range variant
+                from .. import _lib
+                import ctypes
+                L = _lib.lib()
+                v0 = L.mcr_get_local_pct_variant()
+                L.mcr_set_local_pct_variant(ctypes.c_int(5))
+                try:
+                    X_world, view_harmonics, occ_probs, gains = field_and_gains(getattr(occ_net, "last_ragged_perms", None),
+                                                                                record.get("samples"), None)
+                finally:
+                    L.mcr_set_local_pct_variant(ctypes.c_int(v0))
+                occ_net.clear_range_flag()
+                fallback = 5
+    finally:
+        if deferred:
+            occ_net.range_guard = "sync"
     # `if coverage_gain > max_coverage_gain` from -1: the first strict maximum (a NaN gain never wins upstream; here it would)
     rec_best = ops.best_record(gains.view(1, K), 0)
     out = {"next_idx": rec_best[0, 1].to(torch.int64), "max_gain": rec_best[0, 0], "gains": gains, "fov_mask": fov_mask,
            "X_world": X_world, "view_harmonics": view_harmonics, "occ_probs": occ_probs}
+    if fallback:
+        out["fallback_variant"] = fallback
     if return_signed_distances:
         out["signed_distances"] = sgn              # [P], 0 outside the frustum
     return out
@@ -292,7 +341,7 @@ def _grid_tables(scene, device):
 
 def compute_scene_occupancy_probability_field(params, macarons, camera, surface_scene, proxy_scene, device,
                                               use_supervision_occ_mask=True, prediction_camera=None,
-                                              use_supervision_occ_instead_of_predicted=False, chunk=20000):
+                                              use_supervision_occ_instead_of_predicted=False, chunk=20000, ragged_perms=None):
     """Occupancy probability of every proxy point the cameras have seen (macarons_utils.py:1395-1540), as ONE batched pass.
 
     Upstream walks the grid cells that hold seen proxy points from Python: per cell it gathers the surface points of the 27-cell
@@ -321,7 +370,9 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
         if camera is None:
             raise NameError("Both camera and prediction_camera are equal to None.")
         prediction_camera = camera.fov_camera_0
-    Mv = _world_to_view_matrix(prediction_camera).to(device=device, dtype=torch.float32).contiguous()
+    Mv_any = _world_to_view_matrix(prediction_camera)
+    Mv_host = Mv_any.detach().to(torch.float32) if Mv_any.device.type == "cpu" else None     # (a host matrix stays usable on the host)
+    Mv = ops.h2d(Mv_host, torch.float32, device).contiguous() if Mv_host is not None else Mv_any.to(device=device, dtype=torch.float32).contiguous()
     # ---- per proxy point: the cell its coordinates fall in (which cells are visited, :1434) and the cell whose store holds it
     cell_by_pos = _lin(ps.get_cells_for_each_pt(ps.proxy_points), gw, gh)
     tab = _grid_tables(ps, device)                       # static per scene: cells in linear-id order, their centres / diagonals, 27-neighbourhoods
@@ -332,7 +383,7 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
         idx_all = torch.cat([ps.cells[k].cell_features[:, 0] for k in filled]).long()
         lens = torch.tensor([ps.cells[k].cell_pts.shape[0] for k in filled], dtype=torch.int64)
         lins = torch.tensor([lin_of[k] for k in filled], dtype=torch.int64)
-        stored_cell[idx_all] = torch.repeat_interleave(lins, lens).to(device)
+        stored_cell[idx_all] = ops.h2d(torch.repeat_interleave(lins, lens), torch.int64, device)
     sel = stored_cell >= 0
     if use_supervision_occ_mask:
         sel = sel & occ_mask
@@ -371,13 +422,13 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
         T = sum(q for _, q, _ in jobs)
         tot = sum(seg_len)
         # ---- selected proxy points grouped by cell (stable: ascending index inside a cell)
-        key = torch.where(sel & valid_cell.to(device)[stored_cell.clamp(min=0)], stored_cell, big)
+        key = torch.where(sel & ops.h2d(valid_cell, torch.bool, device)[stored_cell.clamp(min=0)], stored_cell, big)
         rows = torch.sort(key, stable=True).indices[:T]
         X_sel = ps.proxy_points[rows]
         # ---- every job's surface cloud in one gather
-        ints = torch.tensor([seg_src, seg_len, [c for c, _, _ in jobs] + [0] * (len(seg_src) - J),
-                             [q for _, q, _ in jobs] + [0] * (len(seg_src) - J), [m for _, _, m in jobs] + [0] * (len(seg_src) - J)],
-                            dtype=torch.int64).to(device)
+        ints = ops.h2d(torch.tensor([seg_src, seg_len, [c for c, _, _ in jobs] + [0] * (len(seg_src) - J),
+                                     [q for _, q, _ in jobs] + [0] * (len(seg_src) - J), [m for _, _, m in jobs] + [0] * (len(seg_src) - J)],
+                                    dtype=torch.int64), torch.int64, device)
         src, ln = ints[0], ints[1]
         dst = torch.cumsum(ln, 0) - ln
         gather = torch.arange(tot, device=device) + torch.repeat_interleave(src - dst, ln, output_size=tot)
@@ -396,7 +447,8 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
         X_q = ops.transform_points_batched_(X_sel.clone().contiguous(), MvJ, centers, inv_diag, cloud_of=row_job)
         # ---- view states -> prediction frame -> harmonics, all rows at once   (:1486-1497)
         vs = ps.view_states[rows].view(1, T, params.n_view_state_cameras)
-        vs = su.move_view_state_to_view_space(vs, Mv[:3, :3].contiguous() if torch.is_tensor(prediction_camera) else prediction_camera,
+        vs = su.move_view_state_to_view_space(vs, ((Mv_host if Mv_host is not None else Mv)[:3, :3].contiguous()
+                                                   if torch.is_tensor(prediction_camera) else prediction_camera),
                                               n_elev=params.view_state_n_elev, n_azim=params.view_state_n_azim)
         base_harmonics, h_polar, h_azim = su.get_all_harmonics_under_degree(params.harmonic_degree, params.view_state_n_elev,
                                                                              params.view_state_n_azim, device)
@@ -407,7 +459,7 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
         else:
             occ_net = getattr(macarons, "occupancy", macarons)
             if hasattr(occ_net, "forward_ragged"):
-                occ = occ_net.forward_ragged(pc_all, [m for _, _, m in jobs], X_q, vh, [q for _, q, _ in jobs]).view(-1, 1)
+                occ = occ_net.forward_ragged(pc_all, [m for _, _, m in jobs], X_q, vh, [q for _, q, _ in jobs], perms=ragged_perms).view(-1, 1)
             else:                                       # any other module with the reference's call signature: job by job
                 outs, r0, p0 = [], 0, 0
                 for _, q, m in jobs:
@@ -417,11 +469,11 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
                 occ = torch.cat(outs)
         ps.proxy_proba[rows] = occ                                                                # :1525
         X_parts, H_parts, O_parts = [X_sel], [vh], [occ]
-    oof_mask = (ps.out_of_field > 0.)[..., 0]
-    oof_X = ps.proxy_points[oof_mask]
+    oof_idx = torch.nonzero((ps.out_of_field > 0.)[..., 0]).view(-1)                          # (one read-back for both gathers)
+    oof_X = ps.proxy_points[oof_idx]
     X_world = torch.cat(X_parts + [oof_X])
     view_harmonics = torch.cat(H_parts + [torch.zeros(len(oof_X), nh, device=device)])
-    occ_probs = torch.cat(O_parts + [ps.proxy_proba[oof_mask]])
+    occ_probs = torch.cat(O_parts + [ps.proxy_proba[oof_idx]])
     return X_world, view_harmonics, occ_probs
 
 

@@ -92,12 +92,25 @@ class Scene:
         self.distance_between_proxy_points = 2 * np.power(3 * vol / (4 * np.pi), 1. / 3.)
 
     # ---- cell lookup ----
+    def _consts(self, device):
+        """Small per-device constants of the grid (built once: creating them from Python lists on every call is a blocking
+        host-to-device copy each)."""
+        c = getattr(self, "_dev_consts", None)
+        if c is None or c["device"] != str(device):
+            c = {"device": str(device),
+                 "step": torch.stack((self.l, self.w, self.h)).to(device).view(1, 3),
+                 "x_min": self.x_min.to(device), "x_max": self.x_max.to(device),
+                 "hi": torch.tensor([self.grid_l - 1, self.grid_w - 1, self.grid_h - 1], device=device, dtype=torch.float32),
+                 "lin": torch.tensor([self.grid_w * self.grid_h, self.grid_h, 1], device=device)}
+            self._dev_consts = c
+        return c
+
     def get_cells_for_each_pt(self, pts):
-        step = torch.stack((self.l, self.w, self.h)).to(pts.device).view(1, 3)
-        d = pts - self.x_min.to(pts.device)
+        c = self._consts(pts.device)
+        step = c["step"]
+        d = pts - c["x_min"]
         idx = (d - d % step) / step                                   # utils.floor_divide (non-negative modulo)
-        hi = torch.tensor([self.grid_l - 1, self.grid_w - 1, self.grid_h - 1], device=pts.device, dtype=idx.dtype)
-        return torch.minimum(idx, hi).long().clamp_(min=0)
+        return torch.minimum(idx, c["hi"].to(idx.dtype)).long().clamp_(min=0)
 
     def get_englobing_cells(self, pts, list=False):
         res = torch.unique(self.get_cells_for_each_pt(pts), dim=0)
@@ -141,7 +154,7 @@ class Scene:
         cells, lo, hi = self._cell_table()
         n_cells = len(cells)
         with_fts = self.feature_dim > 0 and features is not None
-        cid = (self.get_cells_for_each_pt(pts) * torch.tensor([self.grid_w * self.grid_h, self.grid_h, 1], device=pts.device)).sum(-1)
+        cid = (self.get_cells_for_each_pt(pts) * self._consts(pts.device)["lin"]).sum(-1)
         ok = ((pts >= self.x_min.to(dev)) & (pts <= self.x_max.to(dev))).all(-1)                  # get_pts_in_bounding_box
         ok = ok & (torch.max(pts - hi[cid], dim=-1)[0] < 0.) & (torch.min(pts - lo[cid], dim=-1)[0] > 0.)      # Cell.fill's box masks
         big = torch.full_like(cid, n_cells)
@@ -156,7 +169,7 @@ class Scene:
         b_off_h = np.concatenate(([0], np.cumsum(b_len))).astype(np.int64)
         B_all = torch.cat([c.cell_pts for c in cells if c.cell_pts.shape[0] > 0] + [torch.zeros(0, 3, device=dev)])
         A_s = pts[order].contiguous()
-        d = ops.min_dist_segmented(A_s, a_off, B_all.contiguous(), torch.from_numpy(b_off_h).to(dev), max_a=N)
+        d = ops.min_dist_segmented(A_s, a_off, B_all.contiguous(), ops.h2d(b_off_h, torch.int64, dev), max_a=N)
         admit = (d > cells[0].resolution) & (key_s < n_cells) & (cand[key_s] > n_point_min)       # fp64 compare (:2566-2567)
         key2 = torch.where(admit, key_s, big)
         order2 = torch.sort(key2, stable=True).indices
@@ -179,7 +192,7 @@ class Scene:
             touched.append((c, len(perm)))
         if not touched:
             return
-        g = torch.from_numpy(np.concatenate(gidx)).to(dev)
+        g = ops.h2d(np.concatenate(gidx), torch.int64, dev)
         new_pts = src[g]
         new_fts = src_f[g] if with_fts else None
         o = 0

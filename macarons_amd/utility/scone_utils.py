@@ -132,7 +132,8 @@ def move_view_state_to_view_space(view_state, fov_camera, n_elev, n_azim):
     n_elev*n_azim] -> same shape, column v taken from the bin the v-th grid direction lands in after the inverse
     world-to-view transform.  `fov_camera`: the reference's camera object (its get_world_to_view_transform().inverse()
     .transform_points and get_camera_center are called exactly as the reference does; PyTorch3D stays outside the kernels)
-    or the 3x3 world-to-view rotation R of the row-vector convention X_view = X_world R + T."""
+    or the 3x3 world-to-view rotation R of the row-vector convention X_view = X_world R + T (a CPU tensor costs nothing; a device
+    tensor is read back)."""
     n_view = n_elev * n_azim
     elev = torch.Tensor([-90. + (i + 1) / (n_elev + 1) * 180. for i in range(n_elev) for j in range(n_azim)])
     azim = torch.Tensor([360. * j / n_azim for i in range(n_elev) for j in range(n_azim)])

@@ -256,6 +256,51 @@ def test_macarons_decision_matches_reference(dev):
     assert np.array_equal(fresh.out_of_field.cpu().numpy()[:, 0].astype(np.uint8), g["oof_0"])
 
 
+def test_macarons_decision_range_guard_is_deferred_and_falls_back(dev):
+    """The fp16-split range check of a MACARONS decision is read once at the end (no stall inside the occupancy pass); with weights
+    that overflow the fp16 range the decision is repeated on the full-range variant with the same hidden draws: it reports
+    fallback_variant = 5 and equals, bit for bit, the decision of a model that runs on variant 5 from the start."""
+    import ctypes
+    from macarons_amd import _lib
+    from macarons_amd.utility import macarons_utils as mu
+    g = golden("macarons_decision")
+    H, W = int(g["hw"][0]), int(g["hw"][1])
+    params = NS(n_harmonics=64, harmonic_degree=8, view_state_n_elev=7, view_state_n_azim=14, k_for_knn=16,
+                prediction_neighborhood_size=3, n_view_state_cameras=98, sensor_range=40., min_occ_for_proxy_points=0.1, seq_len=2048,
+                distance_factor_th=17., image_height=H, image_width=W, carving_tolerance=0.05)
+    dmask = np.unpackbits(g["dmask"])[:2 * H * W].reshape(2, H, W).astype(bool)
+    L = _lib.lib()
+
+    def decide(force_variant):
+        m = _models(dev)
+        with torch.no_grad():
+            for lin in (m.occupancy.linear1, m.occupancy.x_embedding.linear2):     # activations beyond 65504 in the head
+                lin.weight.mul_(65536.); lin.bias.mul_(65536.)                      # (the recipe of test_range_guard_falls_back_...)
+        surface, proxy = _decision_scenes(g, dev)
+        cam = mu.SceneCamera(mu.camera_record(g["Mview"][0], g["Mfull"][0], g["ndc"], g["eyes"][0], params.sensor_range).to(dev),
+                             T(g["eyes"][0:1], dev), float(g["zfar"]))
+        nrec = torch.stack([mu.camera_record(g["nMview_0"][k], g["nMfull_0"][k], g["ndc"], g["n_eyes"][0, k], params.sensor_range)
+                            for k in range(5)]).to(dev)
+        v0 = L.mcr_get_local_pct_variant()
+        if force_variant:
+            L.mcr_set_local_pct_variant(ctypes.c_int(force_variant))
+        try:
+            torch.manual_seed(5100)
+            with torch.no_grad():
+                r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, T(g["depth"][0], dev), T(dmask[0], dev), nrec,
+                                             T(g["n_eyes"][0], dev), dev, samples=T(g["u_0"], dev))
+            assert m.occupancy.range_guard == "sync"                    # restored
+        finally:
+            L.mcr_set_local_pct_variant(ctypes.c_int(v0))
+        return r
+
+    if L.mcr_get_local_pct_variant() != 6:
+        pytest.skip("the range guard belongs to variant 6")
+    a, b = decide(None), decide(5)
+    assert a.get("fallback_variant") == 5 and "fallback_variant" not in b
+    assert torch.equal(a["occ_probs"], b["occ_probs"]) and torch.equal(a["gains"], b["gains"]) and int(a["next_idx"]) == int(b["next_idx"])
+
+
 def test_coverage_metrics_match_reference(dev):
     """Scene.scene_coverage / Scene.camera_coverage_gain (macarons_utils.py:2987-3056: fp64 nearest distance against epsilon, per
     cell / against the whole in-box partial cloud) vs the values the reference's methods returned on its own Scene objects."""
