@@ -18,20 +18,21 @@
 namespace mcr {
 
 constexpr int L3G_BM = 128, L3G_BK = 32;
-#ifndef L3G_NT_N
-#define L3G_NT_N 4
-#endif
-constexpr int L3G_NT = L3G_NT_N, L3G_BN = 32 * L3G_NT;      // 8: 72 KB LDS, 2 blocks/CU; 4: 48 KB, 3 blocks/CU; 2: 36 KB, 4 blocks/CU
+// column tiles per wave: 4 (128 columns, 48 KB LDS, 3 blocks/CU) for the big layers; 2 and 1 (64 / 32 columns) give a 2048-row
+// problem enough blocks.  The tile width only groups independent accumulators: every output element sees the same k order and the
+// same six products per k16 step whatever L3G_NT is, so the result does not depend on it (nor on M).
 
 // uint4 index of chunk c (8 bf16) of row `row` in a plane image [rows][4 chunks]
 __device__ __forceinline__ int l3g_chunk(int row, int c) { return row * 4 + (c ^ ((row >> 2) & 3)); }
 
-__global__ __launch_bounds__(256, L3G_NT == 8 ? 2 : (L3G_NT == 4 ? 3 : 4)) void linear3_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ W,
+template <int L3G_NT>
+__global__ __launch_bounds__(256, L3G_NT == 4 ? 3 : 4) void linear3_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ W,
                                                         long long ldw, const float* __restrict__ bias,
                                                         const float* __restrict__ row_bias, long long rows_per_group,
                                                         const float* __restrict__ R, long long ldr, float* __restrict__ Y,
                                                         long long ldy, long long M, int N, int K, int act,
                                                         const int* __restrict__ row_group) {
+    constexpr int L3G_BN = 32 * L3G_NT;
     __shared__ __attribute__((aligned(16))) uint4 As[3][L3G_BM * 4];
     __shared__ __attribute__((aligned(16))) uint4 Bs[3][L3G_BN * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(256, L3G_NT == 8 ? 2 : (L3G_NT == 4 ? 3 : 4)) void 
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // staging: a thread owns 16-byte plane chunks = 8 consecutive k of one row: 2 chunks of A, 4 of W per K-chunk
-    float4 ra[2][2], rb[L3G_NT / 2][2];
+    constexpr int WR = (L3G_NT + 1) / 2;           // W chunk groups of 256 threads (NT = 1: the first 128 threads of one group)
+    float4 ra[2][2], rb[WR][2];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -59,10 +61,10 @@ __global__ __launch_bounds__(256, L3G_NT == 8 ? 2 : (L3G_NT == 4 ? 3 : 4)) void 
             }
         }
 #pragma unroll
-        for (int r = 0; r < L3G_NT / 2; ++r) {
+        for (int r = 0; r < WR; ++r) {
             const int idx = tid + r * 256, row = idx >> 2, c = idx & 3;
             rb[r][0] = rb[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n0 + row < N && k0 + c * 8 < K) {
+            if (row < L3G_BN && n0 + row < N && k0 + c * 8 < K) {
                 const float* p = W + (long long)(n0 + row) * ldw + k0 + c * 8;
                 rb[r][0] = *reinterpret_cast<const float4*>(p);
                 rb[r][1] = *reinterpret_cast<const float4*>(p + 4);
@@ -79,10 +81,12 @@ __global__ __launch_bounds__(256, L3G_NT == 8 ? 2 : (L3G_NT == 4 ? 3 : 4)) void 
             As[0][l3g_chunk(row, c)] = sp.hi; As[1][l3g_chunk(row, c)] = sp.mid; As[2][l3g_chunk(row, c)] = sp.lo;
         }
 #pragma unroll
-        for (int r = 0; r < L3G_NT / 2; ++r) {
+        for (int r = 0; r < WR; ++r) {
             const int idx = tid + r * 256, row = idx >> 2, c = idx & 3;
-            const Split3 sp = split8(rb[r][0], rb[r][1]);
-            Bs[0][l3g_chunk(row, c)] = sp.hi; Bs[1][l3g_chunk(row, c)] = sp.mid; Bs[2][l3g_chunk(row, c)] = sp.lo;
+            if (row < L3G_BN) {
+                const Split3 sp = split8(rb[r][0], rb[r][1]);
+                Bs[0][l3g_chunk(row, c)] = sp.hi; Bs[1][l3g_chunk(row, c)] = sp.mid; Bs[2][l3g_chunk(row, c)] = sp.lo;
+            }
         }
         __syncthreads();
         if (k0 + L3G_BK < K) fetch(k0 + L3G_BK);       // in flight during the MFMA phase
@@ -125,19 +129,30 @@ __global__ __launch_bounds__(256, L3G_NT == 8 ? 2 : (L3G_NT == 4 ? 3 : 4)) void 
 }
 
 // true when the split-precision kernel applies: 16-byte aligned rows of 8-float groups, a problem big enough to fill the chip
-bool linear3_applicable(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int N, int K) {
+constexpr int L3G_BN_BIG = 128;
+bool linear3_shape_ok(const float* X, int64_t ldx, const float* W, int64_t ldw, int N, int K) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    return K % 8 == 0 && K >= 64 && ldx % 4 == 0 && ldw % 4 == 0 && al(X) && al(W) && N >= 128 &&
-           cdiv(M, L3G_BM) * cdiv(N, L3G_BN) >= 256;
+    return K % 8 == 0 && K >= 64 && ldx % 4 == 0 && ldw % 4 == 0 && al(X) && al(W) && N >= 128;
+}
+bool linear3_applicable(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int N, int K) {
+    return linear3_shape_ok(X, ldx, W, ldw, N, K) && cdiv(M, L3G_BM) * cdiv(N, L3G_BN_BIG) >= 256;
 }
 
 void launch_linear3(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R, int64_t ldr,
                     float* Y, int64_t ldy, int64_t M, int N, int K, int act, const float* row_bias, int64_t rows_per_group,
                     int64_t ldw, const int* row_group) {
-    dim3 grid((unsigned)cdiv(M, L3G_BM), (unsigned)cdiv(N, L3G_BN));
-    hipLaunchKernelGGL(linear3_kernel, grid, dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw, bias, row_bias,
-                       (long long)(rows_per_group > 0 ? rows_per_group : 1), R, (long long)ldr, Y, (long long)ldy, (long long)M,
-                       N, K, act, row_group);
+    const int64_t mb = cdiv(M, L3G_BM);
+    const long long rpg = rows_per_group > 0 ? rows_per_group : 1;
+    // widest column tile that still gives the chip ~2 blocks per CU (performance only: see the note on L3G_NT above)
+    int nt = 4;
+    while (nt > 1 && mb * cdiv(N, nt * 32) < 512) nt >>= 1;
+#define MCR_L3(NT)                                                                                                              \
+    hipLaunchKernelGGL((linear3_kernel<NT>), dim3((unsigned)mb, (unsigned)cdiv(N, NT * 32)), dim3(256), 0, s, X, (long long)ldx, W, \
+                       (long long)ldw, bias, row_bias, rpg, R, (long long)ldr, Y, (long long)ldy, (long long)M, N, K, act, row_group)
+    if (nt == 4) MCR_L3(4);
+    else if (nt == 2) MCR_L3(2);
+    else MCR_L3(1);
+#undef MCR_L3
 }
 
 }  // namespace mcr

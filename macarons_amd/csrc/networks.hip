@@ -51,6 +51,24 @@ struct Arena {
 };
 static size_t al(size_t n_floats) { return (n_floats * sizeof(float) + 255) & ~(size_t)255; }
 
+// 1: local_pct.hip exact-fp32 MFMA; 5: local_pct5.hip split-precision bf16 hi/mid/lo (6 MFMAs per product, whole fp32
+// range); 6 (default): local_pct6.hip two-term fp16 split (3 MFMAs per product).  Each has its own blob format.
+static int g_local_pct_variant = []() {                 // env MCR_LOCAL_PCT_VARIANT picks the start-up value (testing: whole suites on a variant)
+    const char* e = getenv("MCR_LOCAL_PCT_VARIANT");
+    const int v = e ? atoi(e) : 6;
+    return (v == 1 || v == 5 || v == 6) ? v : 6;
+}();
+// rows-per-sequence argument of launch_linear for the encoders of the 2048-token networks (SconeVis, SconeOcc's global
+// transformer): on the split-precision variants (5, 6) their GEMMs take the split-precision kernel for EVERY launch size (negative
+// argument = "choose on the layer's shape"; its column-tile width follows the launch, which does not change a single bit) -- one
+// sequence costs the same as on the fp32 kernels, 8 or 30 sequences in one launch (scene batch, the neighbour cameras of a MACARONS
+// decision) run 1.3x faster, and a sequence's result still does not depend on how many share the launch.  Variant 1 = exact fp32
+// everywhere.  MCR_SMALL_SPLIT=0: the fp32 small-problem kernels on every variant (A/B).
+static inline int64_t seq_route(int64_t L) {
+    static const bool on = []() { const char* e = getenv("MCR_SMALL_SPLIT"); return !(e && e[0] == '0'); }();
+    return on && g_local_pct_variant >= 5 ? -L : L;
+}
+
 // x <- Encoder(x)  in place.  x [T, E]; scratch h [T, E], qkv [T, 2*dqk + E], ff [T, 2E]
 static void run_encoder(hipStream_t s, const EncW& w, float* x, float* h, float* qkv, float* ff, int64_t S, int L, int E,
                         int H, const int* lens = nullptr) {
@@ -58,12 +76,12 @@ static void run_encoder(hipStream_t s, const EncW& w, float* x, float* h, float*
     const int dqk = E / 4, W3 = 2 * dqk + E;
     launch_layernorm(s, x, E, w.n1g, w.n1b, h, E, T, E);                                   // Attention.py:287
     // every GEMM of the networks routes (fp32 vs split precision) on the rows of ONE sequence, not on T: see launch_linear
-    launch_linear(s, h, E, w.qkv.w, w.qkv.b, nullptr, 0, qkv, W3, T, W3, E, ACT_NONE, nullptr, 0, 0, L);       // :186-188
+    launch_linear(s, h, E, w.qkv.w, w.qkv.b, nullptr, 0, qkv, W3, T, W3, E, ACT_NONE, nullptr, 0, 0, seq_route(L));       // :186-188
     launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, /*split_by_length=*/true);   // :191-198 (ff is free here: key-split scratch)
-    launch_linear(s, h, E, w.out.w, w.out.b, x, E, x, E, T, E, E, ACT_NONE, nullptr, 0, 0, L);                 // :201-202 + residual :290
+    launch_linear(s, h, E, w.out.w, w.out.b, x, E, x, E, T, E, E, ACT_NONE, nullptr, 0, 0, seq_route(L));                 // :201-202 + residual :290
     launch_layernorm(s, x, E, w.n2g, w.n2b, h, E, T, E);                                   // :293
-    launch_linear(s, h, E, w.ff1.w, w.ff1.b, nullptr, 0, ff, 2 * E, T, 2 * E, E, ACT_GELU, nullptr, 0, 0, L);  // :232
-    launch_linear(s, ff, 2 * E, w.ff2.w, w.ff2.b, x, E, x, E, T, E, 2 * E, ACT_NONE, nullptr, 0, 0, L);        // :235 + residual :298
+    launch_linear(s, h, E, w.ff1.w, w.ff1.b, nullptr, 0, ff, 2 * E, T, 2 * E, E, ACT_GELU, nullptr, 0, 0, seq_route(L));  // :232
+    launch_linear(s, ff, 2 * E, w.ff2.w, w.ff2.b, x, E, x, E, T, E, 2 * E, ACT_NONE, nullptr, 0, 0, seq_route(L));        // :235 + residual :298
 }
 
 // ---- PCTransformer (SconeOcc.py:45-130): S sequences of L points (pts_dim 3), E = 128, 2 encoders, 4 heads ----
@@ -236,13 +254,6 @@ int mcr_local_pct_blob_floats(void) { return local_pct_blob_floats(); }
 int mcr_local_pct3_blob_floats(void) { return local_pct3_blob_floats(); }
 int mcr_local_pct6_blob_floats(void) { return local_pct6_blob_floats(); }
 
-// 1: local_pct.hip exact-fp32 MFMA; 5: local_pct5.hip split-precision bf16 hi/mid/lo (6 MFMAs per product, whole fp32
-// range); 6 (default): local_pct6.hip two-term fp16 split (3 MFMAs per product).  Each has its own blob format.
-static int g_local_pct_variant = []() {                 // env MCR_LOCAL_PCT_VARIANT picks the start-up value (testing: whole suites on a variant)
-    const char* e = getenv("MCR_LOCAL_PCT_VARIANT");
-    const int v = e ? atoi(e) : 6;
-    return (v == 1 || v == 5 || v == 6) ? v : 6;
-}();
 int mcr_set_local_pct_variant(int v) {
     MCR_REQUIRE(v == 1 || v == 5 || v == 6, "mcr_set_local_pct_variant: variant must be 1, 5 or 6 (got %d)", v);
     g_local_pct_variant = v;

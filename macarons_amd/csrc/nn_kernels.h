@@ -22,6 +22,7 @@ void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, c
 
 // Split-precision (exact bf16 hi/mid/lo, six MFMAs per product) variant for the large GEMMs (linear3.hip); launch_linear
 // routes to it when linear3_applicable().
+bool linear3_shape_ok(const float* X, int64_t ldx, const float* W, int64_t ldw, int N, int K);
 bool linear3_applicable(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int N, int K);
 void launch_linear3(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R, int64_t ldr,
                     float* Y, int64_t ldy, int64_t M, int N, int K, int act, const float* row_bias, int64_t rows_per_group,

@@ -179,7 +179,12 @@ void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, c
     if (M <= 0 || N <= 0) return;
     if (ldw == 0) ldw = K;
     static const bool use_split = []() { const char* e = getenv("MCR_LINEAR3"); return !(e && e[0] == '0'); }();   // dev A/B knob
-    if (use_split && linear3_applicable(X, ldx, W, ldw, route_rows > 0 ? route_rows : M, N, K)) {
+    // route_rows < 0: "one sequence of -route_rows rows, matrix path chosen on the layer's SHAPE alone" (the 2048-token encoders
+    // on the split-precision variants: a batch of 30 sequences and a single one take the same kernel family, whose column-tile
+    // width -- performance only -- follows M)
+    const bool by_shape = route_rows < 0;
+    if (by_shape) route_rows = -route_rows;
+    if (use_split && (by_shape ? linear3_shape_ok(X, ldx, W, ldw, N, K) : linear3_applicable(X, ldx, W, ldw, route_rows > 0 ? route_rows : M, N, K))) {
         launch_linear3(s, X, ldx, W, bias, R, ldr, Y, ldy, M, N, K, act, row_bias, rows_per_group, ldw, row_group);
         return;
     }

@@ -266,6 +266,9 @@ def test_range_guard_falls_back_to_full_range_variant(dev, where):
     the fp64 oracle; nbv_step checks the same flag once at the end of the decision."""
     from macarons_amd.networks import SconeOcc, SconeVis
     from macarons_amd.nbv import nbv_step, ViewStateGrid
+    from macarons_amd import _lib
+    if _lib.lib().mcr_get_local_pct_variant() != 6:
+        pytest.skip("the range guard belongs to variant 6 (suite running on another variant)")
     m, sd = _mod(SconeOcc, 2, dev)
     sd = {k: v.copy() for k, v in sd.items()}
     keys = (["local_transformers.1.encoders.0.ff.linear1.weight", "local_transformers.1.encoders.0.ff.linear1.bias"] if where == "local_ff"
