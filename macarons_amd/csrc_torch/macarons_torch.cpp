@@ -71,8 +71,9 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> knn_gather_offset(const at::Tenso
     const int64_t B = x.size(0), Q = x.size(1), M = pc.size(1);
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     at::Tensor idx = at::empty({B, Q, k}, x.options().dtype(at::kLong)), d = at::empty({B, Q, k}, x.options()), pts = at::empty({B, Q, k, 3}, x.options());
-    ok(mcr_knn_points(x.data_ptr<float>(), pc.data_ptr<float>(), idx.data_ptr<int64_t>(), d.data_ptr<float>(), pts.data_ptr<float>(), B, Q, M,
-                      (int)k, 1, stream_of(x)), "mcr_knn_points");
+    at::Tensor ws = scratch(x, mcr_knn_grid_workspace_bytes(B, Q, M));                   // grid-pruned search where it applies
+    ok(mcr_knn_points_grid(x.data_ptr<float>(), pc.data_ptr<float>(), idx.data_ptr<int64_t>(), d.data_ptr<float>(), pts.data_ptr<float>(), B, Q, M,
+                           (int)k, 1, ws.data_ptr(), (size_t)ws.numel(), stream_of(x)), "mcr_knn_points_grid");
     return {pts, d, idx};
 }
 
