@@ -24,9 +24,13 @@
 
 namespace mcr {
 
-constexpr int LP_TN = 128, LP_TM = 256, LP_BK = 32;       // features / activation rows per block, k per chunk
-constexpr int LP_XC = LP_TM * 4, LP_WC = LP_TN * 4;       // 16-byte chunks per X / W tile and plane
-constexpr int LP_STAGE = 2 * LP_XC + 2 * LP_WC;           // chunks per stage (Xh | Xl | Wh | Wl) = 3072 = 48 KB
+constexpr int LP_BK = 32;                                 // k per chunk
+// output modes: fp32 rows, fp16 hi/lo planes (128 features x 256 rows per block), or LP_DOT: 256 features x 128 rows per block --
+// the block then owns ALL 256 outputs of its rows and the epilogue reduces them against a vector: out[m] = act2(act(y[m][:]) . v +
+// c), the last two layers of the SconeOcc head (512 -> 256 -> 1) in one launch: the 256-wide activations (102 MB at T = 100k) are
+// neither written nor read back, and the 256 -> 1 layer costs no launch of its own.
+constexpr int LP_F32 = 0, LP_PLANES = 1, LP_DOT = 2;
+constexpr int LP_STAGE = 2 * 256 * 4 + 2 * 128 * 4;       // chunks per stage (Xh | Xl | Wh | Wl) = 3072 = 48 KB in either tile shape
 constexpr int LP_STAGES = 3;
 constexpr int LP_LDS_BYTES = LP_STAGES * LP_STAGE * 16;   // 147 456
 
@@ -44,17 +48,22 @@ __device__ __forceinline__ f32x16 mfma_u(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <bool PLANES_OUT>
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void linear3p_kernel(const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, long long ldx,
                                                           const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, long long ldw,
                                                           const float* __restrict__ bias, const float* __restrict__ row_bias,
                                                           long long rows_per_group, const int* __restrict__ row_group,
                                                           float* __restrict__ Y, _Float16* __restrict__ Yh, _Float16* __restrict__ Yl,
-                                                          long long ldy, long long M, int N, int K, int act, float wscale_inv) {
-    extern __shared__ __attribute__((aligned(16))) uint4 S[];                     // [stage][Xh 1024 | Xl 1024 | Wh 512 | Wl 512]
+                                                          long long ldy, long long M, int N, int K, int act, float wscale_inv,
+                                                          const float* __restrict__ dot_v, const float* __restrict__ dot_c, int act2) {
+    constexpr int LP_TN = MODE == LP_DOT ? 256 : 128, LP_TM = MODE == LP_DOT ? 128 : 256;     // features / activation rows per block
+    constexpr int LP_XC = LP_TM * 4, LP_WC = LP_TN * 4;                                       // 16-byte chunks per X / W tile and plane
+    constexpr int GX = LP_TM / 128, GW = LP_TN / 128;                                         // DMA chunk groups (64 chunks) per wave and plane
+    constexpr bool PLANES_OUT = MODE == LP_PLANES;
+    extern __shared__ __attribute__((aligned(16))) uint4 S[];                     // [stage][Xh | Xl | Wh | Wl]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 3, wm = wave >> 2;
+    const int wn = MODE == LP_DOT ? wave : (wave & 3), wm = MODE == LP_DOT ? 0 : (wave >> 2);   // the wave's 32 features x 128 rows
     // XCD-aware block order: workgroup b runs on XCD b % 8 (its own L2).  The N / 128 column blocks of one 256-row block read the
     // SAME activation rows: they get consecutive slots of ONE XCD, so the rows come from HBM once and from that L2 afterwards
     // (with the plain (row block, column block) grid the 1344 -> 512 layer fetched its 537 MB of activations four times).
@@ -69,26 +78,29 @@ __global__ __launch_bounds__(512, 1) void linear3p_kernel(const _Float16* __rest
     // ---- DMA addressing: per stage this wave moves X chunk groups 2 wave, 2 wave + 1 (64 chunks = 16 rows each) of both X planes and
     // W chunk group `wave` of both W planes.  LDS position p = group * 64 + lane = (row = p >> 2, c = p & 3) takes the source
     // chunk c ^ ((row >> 2) & 3) of that row.
-    const _Float16 *sx[2][2], *sw[2];                      // this lane's sources at k = 0: [group][plane], [plane]
+    const _Float16 *sx[GX][2], *sw[GW][2];                 // this lane's sources at k = 0: [group][plane]
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int p = (2 * wave + g) * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+    for (int g = 0; g < GX; ++g) {
+        const int p = (GX * wave + g) * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
         const long long xr = min(m0 + row, M - 1);         // rows beyond the matrix repeat its last row (results discarded)
         sx[g][0] = Xh + xr * ldx + c * 8; sx[g][1] = Xl + xr * ldx + c * 8;
     }
-    {
-        const int p = wave * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+#pragma unroll
+    for (int g = 0; g < GW; ++g) {
+        const int p = (GW * wave + g) * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
         const long long wr = min((long long)n0 + row, (long long)N - 1);
-        sw[0] = Wh + wr * ldw + c * 8; sw[1] = Wl + wr * ldw + c * 8;
+        sw[g][0] = Wh + wr * ldw + c * 8; sw[g][1] = Wl + wr * ldw + c * 8;
     }
     auto stage = [&](int st, int k0) {                     // 6 DMA instructions per wave
         uint4* b = S + st * LP_STAGE;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
-                __builtin_amdgcn_global_load_lds((lp_gptr)(sx[g][pl] + k0), (lp_lptr)(b + pl * LP_XC + (2 * wave + g) * 64), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((lp_gptr)(sw[pl] + k0), (lp_lptr)(b + 2 * LP_XC + pl * LP_WC + wave * 64), 16, 0, 0);
+            for (int g = 0; g < GX; ++g)
+                __builtin_amdgcn_global_load_lds((lp_gptr)(sx[g][pl] + k0), (lp_lptr)(b + pl * LP_XC + (GX * wave + g) * 64), 16, 0, 0);
+#pragma unroll
+            for (int g = 0; g < GW; ++g)
+                __builtin_amdgcn_global_load_lds((lp_gptr)(sw[g][pl] + k0), (lp_lptr)(b + 2 * LP_XC + pl * LP_WC + (GW * wave + g) * 64), 16, 0, 0);
         }
     };
 
@@ -148,6 +160,46 @@ __global__ __launch_bounds__(512, 1) void linear3p_kernel(const _Float16* __rest
             for (int t = 0; t < 4; ++t) acc[t] = mfma_u(w_hi[s_], x_hi[s_][t], acc[t]);
         }
     }
+    if (MODE == LP_DOT) {
+        // ---- epilogue of the dot form: lane (j, h) of tile t holds features 32 wn + 8 g + 4 h + e of row m0 + 32 t + j.  Per row: the
+        // wave's 32 features against v (16 in-lane terms in register order, then the other lane half), the eight waves through LDS in
+        // wave order -- one fixed summation order whatever M is.
+        float part[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = wn * 32 + 8 * g + 4 * h;
+                const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v4 = *reinterpret_cast<const float4*>(dot_v + n);
+                float y[4] = {fmaf(acc[t][4 * g], wscale_inv, b4.x), fmaf(acc[t][4 * g + 1], wscale_inv, b4.y),
+                              fmaf(acc[t][4 * g + 2], wscale_inv, b4.z), fmaf(acc[t][4 * g + 3], wscale_inv, b4.w)};
+                if (act == ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = 0.5f * y[e] * (1.f + erff(y[e] * 0.70710678118654752440f));
+                }
+                sacc = fmaf(y[0], v4.x, sacc); sacc = fmaf(y[1], v4.y, sacc); sacc = fmaf(y[2], v4.z, sacc); sacc = fmaf(y[3], v4.w, sacc);
+            }
+            part[t] = sacc + __shfl_xor(sacc, 32, 64);     // (a + b == b + a: both halves hold the same value)
+        }
+        __syncthreads();                                   // every wave is done with the stages: the LDS is free
+        float* red = reinterpret_cast<float*>(S);          // [8 waves][128 rows]
+        if (h == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) red[wave * 128 + t * 32 + i] = part[t];
+        }
+        __syncthreads();
+        if (tid < 128 && m0 + tid < M) {
+            float y = red[tid];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) y += red[w * 128 + tid];
+            y += dot_c ? dot_c[0] : 0.f;
+            if (act2 == ACT_GELU) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+            Y[m0 + tid] = y;
+        }
+        return;
+    }
     // ---- epilogue: lane (j, h) of tile t holds features n = n0 + 32 wn + 8 g + 4 h + e (register 4 g + e) of row m0 + 128 wm + 32 t + j
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -201,26 +253,44 @@ bool linear3p_applicable(int N, int K, int64_t ldx, int64_t ldw, int64_t ldy) {
     return K % LP_BK == 0 && K >= LP_BK && N % 4 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 4 == 0;
 }
 
+static bool lp_reserve_lds() {                              // 144 KB of dynamic LDS: opt in once per kernel
+    static const bool ok =
+        hipFuncSetAttribute((const void*)linear3p_kernel<LP_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES) == hipSuccess &&
+        hipFuncSetAttribute((const void*)linear3p_kernel<LP_PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES) == hipSuccess &&
+        hipFuncSetAttribute((const void*)linear3p_kernel<LP_DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES) == hipSuccess;
+    return ok;
+}
+
 // Y (fp32, ldy floats) or Yh / Yl (fp16 planes, ldy halves) = act(X W^T * wscale_inv + bias (+ row bias)); exactly one of Y, Yh is set
 void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
                      const float* bias, float* Y, void* Yh, void* Yl, int64_t ldy, int64_t M, int N, int K, int act, float wscale_inv,
                      const float* row_bias, int64_t rows_per_group, const int* row_group) {
     if (M <= 0 || N <= 0) return;
-    static const bool lds_ok = []() {                     // 144 KB of dynamic LDS: opt in once per kernel
-        return hipFuncSetAttribute((const void*)linear3p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)linear3p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES) == hipSuccess;
-    }();
-    if (!lds_ok) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LP_LDS_BYTES); return; }
-    dim3 grid((unsigned)(cdiv(cdiv(M, LP_TM), 8) * 8 * cdiv(N, LP_TN)));          // 1-D: see the XCD-aware block order in the kernel
+    if (!lp_reserve_lds()) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LP_LDS_BYTES); return; }
+    dim3 grid((unsigned)(cdiv(cdiv(M, 256), 8) * 8 * cdiv(N, 128)));             // 1-D: see the XCD-aware block order in the kernel
     const long long rpg = rows_per_group > 0 ? rows_per_group : 1;
     if (Yh)
-        hipLaunchKernelGGL((linear3p_kernel<true>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
+        hipLaunchKernelGGL((linear3p_kernel<LP_PLANES>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
                            (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group, (float*)nullptr,
-                           (_Float16*)Yh, (_Float16*)Yl, (long long)ldy, (long long)M, N, K, act, wscale_inv);
+                           (_Float16*)Yh, (_Float16*)Yl, (long long)ldy, (long long)M, N, K, act, wscale_inv, (const float*)nullptr,
+                           (const float*)nullptr, 0);
     else
-        hipLaunchKernelGGL((linear3p_kernel<false>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
+        hipLaunchKernelGGL((linear3p_kernel<LP_F32>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
                            (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group, Y,
-                           (_Float16*)nullptr, (_Float16*)nullptr, (long long)ldy, (long long)M, N, K, act, wscale_inv);
+                           (_Float16*)nullptr, (_Float16*)nullptr, (long long)ldy, (long long)M, N, K, act, wscale_inv, (const float*)nullptr,
+                           (const float*)nullptr, 0);
+}
+
+// out[m] = act2( act(X W^T * wscale_inv + bias)[m][:] . v + c ) for a 256-feature layer (N == 256): two layers, one launch
+bool linear3p_dot_applicable(int N, int K, int64_t ldx, int64_t ldw) { return N == 256 && K % LP_BK == 0 && K >= LP_BK && ldx % 8 == 0 && ldw % 8 == 0; }
+void launch_linear3p_dot(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
+                         const float* bias, int64_t M, int K, int act, float wscale_inv, const float* v, const float* c, int act2, float* out) {
+    if (M <= 0) return;
+    if (!lp_reserve_lds()) { set_error("launch_linear3p_dot: cannot reserve %d bytes of LDS", LP_LDS_BYTES); return; }
+    dim3 grid((unsigned)(cdiv(cdiv(M, 128), 8) * 8));
+    hipLaunchKernelGGL((linear3p_kernel<LP_DOT>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
+                       (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, (const float*)nullptr, 1ll, (const int*)nullptr, out,
+                       (_Float16*)nullptr, (_Float16*)nullptr, 1ll, (long long)M, 256, K, act, wscale_inv, v, c, act2);
 }
 
 void launch_split_to_planes(hipStream_t s, const float* X, int64_t ldx, void* Ph, void* Pl, int64_t ldp, int64_t M, int E) {

@@ -173,6 +173,12 @@ static void run_head_planes(hipStream_t s, const float* x, const float* view_har
     launch_linear3p(s, fh, fl, 1344, Wh, Wl, 1344, lin1.b, nullptr, hh, hh + (size_t)T * 512, 512, T, 512, 1344, ACT_GELU, inv, gbias,
                     rows_per_group, row_group);
     head_planes_weights(s, 3, lin2.w, 512, 256, 512, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
+    static const bool fuse_tail = []() { const char* e = getenv("MCR_HEAD_FUSE_TAIL"); return !(e && e[0] == '0'); }();     // dev A/B knob
+    if (fuse_tail && linear3p_dot_applicable(256, 512, 512, 512)) {
+        // 512 -> 256 (GELU) -> 1 (GELU) in one launch: the block owns all 256 features of its rows and dots them with linear3.weight
+        launch_linear3p_dot(s, hh, hh + (size_t)T * 512, 512, Wh, Wl, 512, lin2.b, T, 512, ACT_GELU, inv, lin3.w, lin3.b, ACT_GELU, out);
+        return;
+    }
     launch_linear3p(s, hh, hh + (size_t)T * 512, 512, Wh, Wl, 512, lin2.b, w.h2, nullptr, nullptr, 256, T, 256, 512, ACT_GELU, inv, nullptr, 0,
                     nullptr);
     launch_linear(s, w.h2, 256, lin3.w, lin3.b, nullptr, 0, out, 1, T, 1, 256, ACT_GELU, nullptr, 0, 0, 1);

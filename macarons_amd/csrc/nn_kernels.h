@@ -78,6 +78,9 @@ bool linear3p_applicable(int N, int K, int64_t ldx, int64_t ldw, int64_t ldy);
 void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
                      const float* bias, float* Y, void* Yh, void* Yl, int64_t ldy, int64_t M, int N, int K, int act, float wscale_inv,
                      const float* row_bias, int64_t rows_per_group, const int* row_group);
+bool linear3p_dot_applicable(int N, int K, int64_t ldx, int64_t ldw);
+void launch_linear3p_dot(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
+                         const float* bias, int64_t M, int K, int act, float wscale_inv, const float* v, const float* c, int act2, float* out);
 void launch_split_to_planes(hipStream_t s, const float* X, int64_t ldx, void* Ph, void* Pl, int64_t ldp, int64_t M, int E);
 void launch_split_weights(hipStream_t s, const float* W, int64_t ldw, void* planes, int N, int K);   // linear3h.hip: [2][N][K] fp16 of W * 2^8
 // segmented kNN-16 with query offsets (knn.hip): see launch_knn16_segmented there
