@@ -120,3 +120,17 @@ def test_grid_pruned_equals_brute_force_kernels(dev, monkeypatch):
                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "mcr_knn_points")
     torch.cuda.synchronize()
     assert torch.equal(i0, i1) and torch.equal(d0, d1) and torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("M", [1023, 1024, 1025, 16384, 16385])
+def test_grid_routing_boundaries(dev, M):
+    """Either side of the sizes at which mcr_knn_points_grid switches between the brute-force kernels and the grid search
+    (1024 <= M <= 16384): the same exact answer, on a clustered cloud with far queries (so that groups get parked where the grid runs)."""
+    rng = np.random.default_rng(M)
+    c = rng.normal(size=(1, M, 3)); c /= np.linalg.norm(c, axis=-1, keepdims=True)
+    pc = (0.3 * c + 0.001 * rng.normal(size=(1, M, 3))).astype(np.float32)
+    X = rng.uniform(-.5, .5, (1, 1500, 3)).astype(np.float32)
+    X[0, :200] *= 0.05                                              # queries near the centre of the shell: heavy groups
+    p, d, i = _run(dev, X, pc, 16, sub=True)
+    po, do, io = knn.knn_offsets(X, pc, 16)
+    assert np.array_equal(i, io) and np.array_equal(d, do) and np.array_equal(p, po)

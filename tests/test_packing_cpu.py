@@ -52,3 +52,15 @@ def test_param_fingerprint_sees_every_kind_of_weight_change():
     assert k5 != k4
     invalidate(cache)
     assert _param_key(pct, cache) != k5
+
+
+def test_h2d_is_a_plain_copy_off_the_gpu():
+    """ops.h2d (the stall-free upload of the MACARONS glue: pinned staging + asynchronous copy on a GPU) degrades to a plain,
+    dtype-converting .to() on a CPU target."""
+    import numpy as np
+    import torch
+    from macarons_amd import ops
+    t = ops.h2d(np.arange(5), torch.int32, "cpu")
+    assert t.dtype == torch.int32 and t.tolist() == [0, 1, 2, 3, 4]
+    t = ops.h2d([1.5, 2.5], torch.float32, torch.device("cpu"))
+    assert t.dtype == torch.float32 and t.tolist() == [1.5, 2.5]
