@@ -396,9 +396,10 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_mfma_kernel(const float* __rest
 // the cloud's bounding box (kg_build_cloud_kernel: one workgroup per cloud, LDS counters) into an array of float4 (x, y, z, original
 // index), cut into SUB-TILES of 32 consecutive candidates with their bounding boxes; (ii) the queries are counting-sorted the same
 // way on a 32^3 grid over THEIR bounding box (kg_q*: once per SconeOcc forward, shared by the three scales), so that a wave's 32
-// queries are neighbours in space; (iii) a wave computes the box of its queries, seeds its lists from the four sub-tiles nearest
-// to it, and then visits only sub-tiles whose box-to-box lower bound lb does not exceed R^2 = the largest current 16th distance
-// among its queries (three rounds, lb <= R^2/8, <= 0.4 R^2, <= R^2, the lists -- and R -- tightening in between).  A sub-tile is
+// queries are neighbours in space; (iii) a wave computes the boxes of its queries (four groups of eight), seeds its lists from the
+// sub-tile nearest to them, and then visits only sub-tiles whose box-to-box lower bound lb does not exceed R^2 = the largest current
+// 16th distance among its queries (KG_ROUNDS rounds, lb <= 0.02 R^2 ... <= R^2: roughly near to far, the lists -- and R --
+// tightening in between).  A sub-tile is
 // processed like the brute-force MFMA kernel processes 32 candidates (two v_mfma_f32_32x32x2_f32 filter, exact recompute + insert
 // at the flush).  Candidates no longer arrive in index order: list entries are 64-bit keys (d2 bits << 32 | index), compared
 // lexicographically -- the documented convention (ascending (d2, index)) without relying on the scan order.
@@ -413,7 +414,7 @@ constexpr int KG_BUILD_BLOCK = 1024;
 
 struct KgCloud { float lo[3], inv[3]; float pmax2; int n_sub; };       // one per cloud (32 bytes)
 #ifdef KG_DEBUG
-__device__ unsigned kg_trace[8192 * 16];          // per wave (blockIdx.x < 8192): [0..3] sub-tiles, insert rounds, flushes, -; [8..] cycles per phase
+__device__ unsigned kg_trace[8192 * 16];          // dev instrumentation (-DKG_DEBUG, tools/time_knn.py): per wave [0..4] sub-tiles, insert rounds, flushes, max / mean insertions per lane; [8..] cycles per phase
 #define KG_COUNT(i, v) do { if (lane == 0 && blockIdx.x < 8192) kg_trace[blockIdx.x * 16 + (i)] = (unsigned)(v); } while (0)
 #define KG_LOCAL(...) __VA_ARGS__
 #define KG_T0() unsigned long long kg_t = __builtin_readcyclecounter()
