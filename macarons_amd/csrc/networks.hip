@@ -77,7 +77,9 @@ static void run_encoder(hipStream_t s, const EncW& w, float* x, float* h, float*
     launch_layernorm(s, x, E, w.n1g, w.n1b, h, E, T, E);                                   // Attention.py:287
     // every GEMM of the networks routes (fp32 vs split precision) on the rows of ONE sequence, not on T: see launch_linear
     launch_linear(s, h, E, w.qkv.w, w.qkv.b, nullptr, 0, qkv, W3, T, W3, E, ACT_NONE, nullptr, 0, 0, seq_route(L));       // :186-188
-    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, /*split_by_length=*/true);   // :191-198 (ff is free here: key-split scratch)
+    static const bool pvh_on = []() { const char* e = getenv("MCR_ATTN_PVH"); return !(e && e[0] == '0'); }();   // dev A/B knob
+    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, /*split_by_length=*/true,     // :191-198 (ff is free here: key-split scratch)
+                     /*pv_half=*/pvh_on && g_local_pct_variant == 6);
     launch_linear(s, h, E, w.out.w, w.out.b, x, E, x, E, T, E, E, ACT_NONE, nullptr, 0, 0, seq_route(L));                 // :201-202 + residual :290
     launch_layernorm(s, x, E, w.n2g, w.n2b, h, E, T, E);                                   // :293
     launch_linear(s, h, E, w.ff1.w, w.ff1.b, nullptr, 0, ff, 2 * E, T, 2 * E, E, ACT_GELU, nullptr, 0, 0, seq_route(L));  // :232

@@ -49,7 +49,7 @@ void launch_layernorm(hipStream_t s, const float* X, int64_t ldx, const float* g
 // that a cloud's result does not depend on how many clouds share the launch (the two forms differ by summation order, ~1e-6).
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
                       int DQK, int DV, const int* lens = nullptr, float* split_ws = nullptr, size_t split_ws_floats = 0,
-                      bool split_by_length = false);
+                      bool split_by_length = false, bool pv_half = false);
 size_t attention_split_floats(int64_t S, int L, int H, int DV);
 
 // Column max over the L rows of each of S sequences, broadcast into a column slice of every row:

@@ -6,6 +6,7 @@
 // All arithmetic is fp32; matrix products use v_mfma_f32_32x32x2_f32, which is bit-for-bit an fp32 fma chain
 // (no TF32/bf16 anywhere), so results differ from PyTorch only by summation order.
 #include "nn_kernels.h"
+#include "lp_split.h"
 #include <cstdlib>
 
 namespace mcr {
@@ -456,15 +457,28 @@ __global__ __launch_bounds__(64 * KS) void attention_flash_kernel(const float* _
 // SPLIT (one or two long sequences: L / 64 * H blocks do not fill the chip): grid.z = 2 * S, the two blocks of a (query tile,
 // head, sequence) take the two halves of the keys and write UNNORMALISED outputs (part 0 -> out, part 1 -> part1 [T, H*DV]) plus
 // their (running max, sum) per query -> ml [2][T][H][2]; attention_combine_kernel merges them.
-template <int DQ, int DV, bool SPLIT>
+// PVH (the fp16-split variant 6): O += P V on v_mfma_f32_16x16x16_f16 with both operands as fp16 hi/lo pairs (P in [0, 1] split in
+// registers -- its 4 values per lane ARE the A fragment; V split once per tile while it is staged, stored as [16-column block][key][16]
+// fp16 images and read back TRANSPOSED by ds_read_b64_tr_b16, which hands lane (c, g) the 4 keys 4g.. of column c = the B fragment):
+// three v_mfma_f32_16x16x32_f16 of ~17 pipe cycles per 32 keys x 16 columns instead of eight fp32 ones of 32 (the P V product is
+// 80 % of the kernel's matrix work; S = Q K^T stays exact fp32).  A tile holding a value outside the fp16 range (|v| >= 32768, inf, NaN) is detected
+// while it is staged (block-wide OR folded into the tile barrier) and takes the fp32 path: no range restriction, no flag.
+template <int DQ, int DV, bool SPLIT, bool PVH>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, long long ldq,
                                                              float* __restrict__ out, long long ldo, int L, int H,
                                                              const int* __restrict__ lens, float* __restrict__ part1,
                                                              float* __restrict__ ml) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
     constexpr int TK = 64, LDK = DQ + 1, LDV = DV + 4, NT = DV / 16, KQ = DQ / 4;
     __shared__ float s_k[TK * LDK];
     __shared__ __attribute__((aligned(16))) float s_v[TK * LDV];
+    // PVH: the same bytes hold the fp16 images of V instead: hi | lo, each [NT][64 keys][16 columns] (2 * NT * 2 KB <= the fp32 tile)
+    _Float16* s_vh = reinterpret_cast<_Float16*>(s_v);
+    _Float16* s_vl = s_vh + NT * TK * 16;
+    static_assert(2 * NT * TK * 16 * 2 <= TK * LDV * 4, "fp16 V images do not fit the fp32 tile");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
     const int hh = blockIdx.y;
     const int seq = SPLIT ? blockIdx.z >> 1 : blockIdx.z, part = SPLIT ? blockIdx.z & 1 : 0;
@@ -502,7 +516,20 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
                 stage[p] = *reinterpret_cast<const float4*>(qkv + (seq0 + t0 + r) * ldq + (c4 < DQ / 4 ? koff + 4 * c4 : voff + 4 * (c4 - DQ / 4)));
         }
     };
-    auto commit = [&]() {
+    auto out_of_half_range = [&]() -> int {            // does this thread's share of the V tile leave the fp16 range?
+        int big = 0;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int idx = threadIdx.x + p * 256, r = idx / F4K, c4 = idx - r * F4K;
+            if (idx < NF4 && c4 >= DQ / 4) {
+                const float mx = fmaxf(fmaxf(fabsf(stage[p].x), fabsf(stage[p].y)), fmaxf(fabsf(stage[p].z), fabsf(stage[p].w)));
+                big |= !(mx < 32768.f);                   // (NaN compares false: caught)
+            }
+            (void)r;
+        }
+        return big;
+    };
+    auto commit = [&](const bool half_v) {
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             const int idx = threadIdx.x + p * 256, r = idx / F4K, c4 = idx - r * F4K;
@@ -510,6 +537,13 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
                 if (c4 < DQ / 4) {
                     float* d = s_k + r * LDK + 4 * c4;          // odd row stride (bank-conflict-free fragment reads): scalar stores
                     d[0] = stage[p].x; d[1] = stage[p].y; d[2] = stage[p].z; d[3] = stage[p].w;
+                } else if (half_v) {
+                    const int col = 4 * (c4 - DQ / 4), off = ((col >> 4) * TK + r) * 16 + (col & 15);    // [16-column block][key][16]
+                    uint2 hi, lo;
+                    split2h(stage[p].x, stage[p].y, hi.x, lo.x);
+                    split2h(stage[p].z, stage[p].w, hi.y, lo.y);
+                    *reinterpret_cast<uint2*>(s_vh + off) = hi;
+                    *reinterpret_cast<uint2*>(s_vl + off) = lo;
                 } else {
                     *reinterpret_cast<float4*>(s_v + r * LDV + 4 * (c4 - DQ / 4)) = stage[p];
                 }
@@ -518,8 +552,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     };
     fetch(kb);
     for (int t0 = kb; t0 < Lk; t0 += TK) {
-        __syncthreads();                                  // the previous tile is consumed
-        commit();
+        // the previous tile is consumed (barrier); PVH: the same barrier tells every thread whether the tile fits the fp16 range
+        bool half_v = false;
+        if (PVH) half_v = !__syncthreads_or(out_of_half_range());
+        else __syncthreads();
+        commit(half_v);
         __syncthreads();
         if (t0 + TK < Lk) fetch(t0 + TK);
         // ---- scores of the 64 keys of the tile (all A fragments first: LLVM otherwise issues every ds_read right in
@@ -532,10 +569,12 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 #pragma unroll
             for (int sk = 0; sk < KQ; ++sk) ka[sub][sk] = kbase[sub * 16 * LDK + 4 * sk];
         float vb[2][4][NT];
+        if (!(PVH && half_v)) {
 #pragma unroll
-        for (int sk = 0; sk < 4; ++sk)
+            for (int sk = 0; sk < 4; ++sk)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) vb[0][sk][nt] = vbase[sk * LDV + nt * 16];
+                for (int nt = 0; nt < NT; ++nt) vb[0][sk][nt] = vbase[sk * LDV + nt * 16];
+        }
         f32x4 st[4];
         float tmax = -__builtin_inff();
 #pragma unroll
@@ -544,13 +583,17 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 #pragma unroll
             for (int sk = 0; sk < KQ; ++sk) st[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[sub][sk], qb[sk], st[sub], 0, 0, 0);
         }
+        if (t0 + TK > Lk) {                               // only the last tile of a sequence has keys past its end (block-uniform)
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (t0 + sub * 16 + 4 * g + r >= Lk) st[sub][r] = -__builtin_inff();
+        }
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (t0 + sub * 16 + 4 * g + r >= Lk) st[sub][r] = -__builtin_inff();     // keys past the sequence end
-                tmax = fmaxf(tmax, st[sub][r]);
-            }
+            for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, st[sub][r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m, tmax);
@@ -573,6 +616,36 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[nt][r] *= ar[r];
+        if (PVH && half_v) {
+            // P (this lane: queries li, keys 4g + r of every 16-key sub-tile) is the A fragment as it stands; V fragments by transpose read
+            const _Float16* vh0 = s_vh + (4 * g) * 16 + li * 4;
+            const _Float16* vl0 = s_vl + (4 * g) * 16 + li * 4;
+            // two 16-key sub-tiles per v_mfma_f32_16x16x32_f16 (the double-rate shape of gfx950; the 16x16x16 one runs at the fp32
+            // MFMA's cycle count): k index 8 g + r <-> key 4 g + r of sub-tile 2 q (r < 4) or 2 q + 1 (r >= 4), on both operands
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                uint4 ph, pl;
+                split2h(st[2 * q][0], st[2 * q][1], ph.x, pl.x);
+                split2h(st[2 * q][2], st[2 * q][3], ph.y, pl.y);
+                split2h(st[2 * q + 1][0], st[2 * q + 1][1], ph.z, pl.z);
+                split2h(st[2 * q + 1][2], st[2 * q + 1][3], ph.w, pl.w);
+                const f16x8 p_hi = __builtin_bit_cast(f16x8, ph), p_lo = __builtin_bit_cast(f16x8, pl);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const _Float16* bh = vh0 + (nt * TK + q * 32) * 16;
+                    const _Float16* bl = vl0 + (nt * TK + q * 32) * 16;
+                    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)bh), h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bh + 256));
+                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)bl), l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bl + 256));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const f16x8 v_hi = __builtin_bit_cast(f16x8, s16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]});
+                    const f16x8 v_lo = __builtin_bit_cast(f16x8, s16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]});
+                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_lo, v_hi, o[nt], 0, 0, 0);      // smallest terms first
+                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_hi, v_lo, o[nt], 0, 0, 0);
+                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_hi, v_hi, o[nt], 0, 0, 0);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             if (sub + 1 < 4) {
@@ -643,7 +716,7 @@ __global__ void attention_combine_kernel(float* __restrict__ out, long long ldo,
 size_t attention_split_floats(int64_t S, int L, int H, int DV) { return (size_t)S * L * DV + (size_t)4 * S * L * H; }
 
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
-                      int DQK, int DV, const int* lens, float* split_ws, size_t split_ws_floats, bool split_by_length) {
+                      int DQK, int DV, const int* lens, float* split_ws, size_t split_ws_floats, bool split_by_length, bool pv_half) {
     if (S <= 0 || L <= 0) return;
     const int dq = DQK / H, dv = DV / H;
     if (!lens && L == 16 && H == 4 && dq == 8 && dv == 32) {
@@ -660,21 +733,29 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
     const bool split = split_ws && split_ws_floats >= attention_split_floats(S, L, H, DV) && L >= 512 &&
                        2 * S <= 65535 && (split_by_length || (int64_t)grid.x * H * S <= 256);
     if (use_mfma && al16 && ((dq == 8 && dv == 32) || (dq == 16 && dv == 64))) {
+#define MCR_ATT(DQ_, DV_, SPLIT_, GRID_, P1_, ML_)                                                                                    \
+    do {                                                                                                                               \
+        if (pv_half)                                                                                                                   \
+            hipLaunchKernelGGL((attention_mfma_kernel<DQ_, DV_, SPLIT_, true>), GRID_, dim3(256), 0, s, qkv, (long long)ldq, out,       \
+                               (long long)ldo, L, H, lens, P1_, ML_);                                                                  \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((attention_mfma_kernel<DQ_, DV_, SPLIT_, false>), GRID_, dim3(256), 0, s, qkv, (long long)ldq, out,      \
+                               (long long)ldo, L, H, lens, P1_, ML_);                                                                  \
+    } while (0)
         if (split) {
             float* part1 = split_ws;
             float* ml = split_ws + (size_t)S * L * DV;
             const dim3 g2(grid.x, grid.y, (unsigned)(2 * S));
-            if (dq == 8)
-                hipLaunchKernelGGL((attention_mfma_kernel<8, 32, true>), g2, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H, lens, part1, ml);
-            else
-                hipLaunchKernelGGL((attention_mfma_kernel<16, 64, true>), g2, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H, lens, part1, ml);
+            if (dq == 8) MCR_ATT(8, 32, true, g2, part1, ml);
+            else MCR_ATT(16, 64, true, g2, part1, ml);
             hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv(S * L * DV, 256)), dim3(256), 0, s, out, (long long)ldo,
                                (const float*)part1, (const float*)ml, (long long)(S * L), H, dv);
         } else if (dq == 8) {
-            hipLaunchKernelGGL((attention_mfma_kernel<8, 32, false>), grid, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H, lens, (float*)nullptr, (float*)nullptr);
+            MCR_ATT(8, 32, false, grid, (float*)nullptr, (float*)nullptr);
         } else {
-            hipLaunchKernelGGL((attention_mfma_kernel<16, 64, false>), grid, dim3(256), 0, s, qkv, (long long)ldq, out, (long long)ldo, L, H, lens, (float*)nullptr, (float*)nullptr);
+            MCR_ATT(16, 64, false, grid, (float*)nullptr, (float*)nullptr);
         }
+#undef MCR_ATT
         return;
     }
     if (lens) {
