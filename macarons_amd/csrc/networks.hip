@@ -69,6 +69,12 @@ static inline int64_t seq_route(int64_t L) {
     return on && g_local_pct_variant >= 5 ? -L : L;
 }
 
+// long-sequence attention: P V on fp16 hi/lo pairs (nn_kernels.hip: PVH) on the fp16-split variant; MCR_ATTN_PVH=0: fp32 MFMA (A/B)
+static inline bool attn_pv_half() {
+    static const bool on = []() { const char* e = getenv("MCR_ATTN_PVH"); return !(e && e[0] == '0'); }();
+    return on && g_local_pct_variant == 6;
+}
+
 // x <- Encoder(x)  in place.  x [T, E]; scratch h [T, E], qkv [T, 2*dqk + E], ff [T, 2E]
 static void run_encoder(hipStream_t s, const EncW& w, float* x, float* h, float* qkv, float* ff, int64_t S, int L, int E,
                         int H, const int* lens = nullptr) {
@@ -77,9 +83,8 @@ static void run_encoder(hipStream_t s, const EncW& w, float* x, float* h, float*
     launch_layernorm(s, x, E, w.n1g, w.n1b, h, E, T, E);                                   // Attention.py:287
     // every GEMM of the networks routes (fp32 vs split precision) on the rows of ONE sequence, not on T: see launch_linear
     launch_linear(s, h, E, w.qkv.w, w.qkv.b, nullptr, 0, qkv, W3, T, W3, E, ACT_NONE, nullptr, 0, 0, seq_route(L));       // :186-188
-    static const bool pvh_on = []() { const char* e = getenv("MCR_ATTN_PVH"); return !(e && e[0] == '0'); }();   // dev A/B knob
     launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, /*split_by_length=*/true,     // :191-198 (ff is free here: key-split scratch)
-                     /*pv_half=*/pvh_on && g_local_pct_variant == 6);
+                     attn_pv_half());
     launch_linear(s, h, E, w.out.w, w.out.b, x, E, x, E, T, E, E, ACT_NONE, nullptr, 0, 0, seq_route(L));                 // :201-202 + residual :290
     launch_layernorm(s, x, E, w.n2g, w.n2b, h, E, T, E);                                   // :293
     launch_linear(s, h, E, w.ff1.w, w.ff1.b, nullptr, 0, ff, 2 * E, T, 2 * E, E, ACT_GELU, nullptr, 0, 0, seq_route(L));  // :232
@@ -220,7 +225,7 @@ int mcr_attention(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_
                 "mcr_attention: supported head layouts are 4 heads with (qk,v) = (32,128) or (64,256); got %d heads (%d,%d)",
                 n_heads, qk_dim, v_dim);
     MCR_REQUIRE(L == 16 || S <= 65535, "mcr_attention: too many long sequences");
-    launch_attention((hipStream_t)stream, qkv, ldq, out, ldo, S, (int)L, n_heads, qk_dim, v_dim);
+    launch_attention((hipStream_t)stream, qkv, ldq, out, ldo, S, (int)L, n_heads, qk_dim, v_dim, nullptr, nullptr, 0, false, attn_pv_half());
     MCR_LAUNCH_CHECK("mcr_attention");
     return 0;
 }
@@ -238,7 +243,7 @@ int mcr_attention_ws(const float* qkv, int64_t ldq, float* out, int64_t ldo, int
                 n_heads, qk_dim, v_dim);
     MCR_REQUIRE(L == 16 || S <= 32767, "mcr_attention_ws: too many long sequences");
     launch_attention((hipStream_t)stream, qkv, ldq, out, ldo, S, (int)L, n_heads, qk_dim, v_dim, nullptr, (float*)workspace,
-                     workspace ? workspace_bytes / sizeof(float) : 0);
+                     workspace ? workspace_bytes / sizeof(float) : 0, false, attn_pv_half());
     MCR_LAUNCH_CHECK("mcr_attention_ws");
     return 0;
 }

@@ -82,6 +82,29 @@ def test_long_sequence_attention_vs_numpy(dev, S, L, H, qk, v):
     assert np.abs(y - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
+def test_long_sequence_attention_outside_the_half_range(dev):
+    """On the fp16-split variant the P V product of the long-sequence attention runs on fp16 hi/lo pairs; a 64-key tile holding a
+    value the fp16 range cannot take (|v| >= 32768, inf) is detected while it is staged and takes the fp32 path: huge, mixed and
+    infinite values against the fp64 reference (an infinite v gives inf / NaN in its column in both)."""
+    from macarons_amd import ops
+    S, L, H, qk, v = 2, 400, 4, 64, 256
+    rng = np.random.default_rng(99)
+    qkv = rng.standard_normal((S, L, 2 * qk + v)).astype(np.float32)
+    qkv[0, 70:90, 2 * qk:] *= 1e6                                       # one tile of sequence 0 far outside, the others inside
+    qkv[1, :, 2 * qk:2 * qk + 64] *= 40000.                             # head 0 of sequence 1: every tile outside
+    qkv[1, 5, 2 * qk + 200] = 3e38                                      # and one value near the fp32 maximum
+    y = ops.attention_packed(T(qkv, dev), H, qk, v).cpu().numpy()
+    x = qkv.astype(np.float64)
+    hs = lambda t, d: t.reshape(S, L, H, d).transpose(0, 2, 1, 3)
+    q, k, vv = hs(x[..., :qk], qk // H), hs(x[..., qk:2 * qk], qk // H), hs(x[..., 2 * qk:], v // H)
+    sc = q @ k.transpose(0, 1, 3, 2) / np.sqrt(qk // H)
+    sc = np.exp(sc - sc.max(-1, keepdims=True))
+    ref = ((sc / sc.sum(-1, keepdims=True)) @ vv).transpose(0, 2, 1, 3).reshape(S, L, v)
+    assert np.isfinite(y).all()
+    col = np.abs(ref).max(axis=(0, 1), keepdims=True)                    # per output column: the columns differ by 44 orders of magnitude
+    assert (np.abs(y - ref) / np.maximum(col, 1.0)).max() < 2e-5
+
+
 def test_layernorm_and_pools(dev):
     from macarons_amd import ops
     rng = np.random.default_rng(0)
