@@ -166,8 +166,8 @@ static void run_head_planes(hipStream_t s, const float* x, const float* view_har
     const _Float16 *Wh, *Wl;
     float inv;
     // x embedding 3 -> 128 -> 256 -> 512, GELU each (SconeOcc.py:35-42)
-    launch_linear(s, x, 3, xe1.w, xe1.b, nullptr, 0, x1, 128, T, 128, 3, ACT_GELU, nullptr, 0, 0, 1);
-    launch_split_to_planes(s, x1, 128, x1h, x1l, 128, T, 128);
+    (void)x1;
+    launch_linear_smallk_planes(s, x, 3, xe1.w, xe1.b, x1h, x1l, 128, T, 128, 3, ACT_GELU);       // (planes directly: no fp32 rows, no split pass)
     head_planes_weights(s, 0, xe2.w, 128, 256, 128, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
     launch_linear3p(s, x1h, x1l, 128, Wh, Wl, 128, xe2.b, nullptr, hh, hh + (size_t)T * 256, 256, T, 256, 128, ACT_GELU, inv, nullptr, 0, nullptr);
     head_planes_weights(s, 1, xe3.w, 256, 512, 256, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);

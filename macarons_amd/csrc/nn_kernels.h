@@ -78,6 +78,8 @@ bool linear3p_applicable(int N, int K, int64_t ldx, int64_t ldw, int64_t ldy);
 void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
                      const float* bias, float* Y, void* Yh, void* Yl, int64_t ldy, int64_t M, int N, int K, int act, float wscale_inv,
                      const float* row_bias, int64_t rows_per_group, const int* row_group);
+void launch_linear_smallk_planes(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, void* Yh, void* Yl,
+                                 int64_t ldy, int64_t M, int N, int K, int act);
 bool linear3p_dot_applicable(int N, int K, int64_t ldx, int64_t ldw);
 void launch_linear3p_dot(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
                          const float* bias, int64_t M, int K, int act, float wscale_inv, const float* v, const float* c, int act2, float* out);

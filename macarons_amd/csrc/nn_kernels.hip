@@ -150,10 +150,14 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // K <= 4 (the xyz embeddings 3 -> 128 over all queries): a thread owns 4 consecutive outputs of one row.  The fmaf chain in
 // ascending k from 0, then + bias, is bit for bit what the zero-padded fp32 MFMA path returns (the fp32 MFMA is an exact fmaf
 // chain); that path spent 69 us on 100k x 128 outputs, this one is bound by its 51 MB of stores.
+// PLANES: the result leaves as fp16 hi/lo planes Yh / Yl [M][ldy] (the operand format of the planes GEMM that consumes it: the
+// SconeOcc head's x-embedding) instead of fp32 rows -- the same values split2h would make of them, without the 2 x 51 MB round trip.
+template <bool PLANES>
 __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ W,
                                                             long long ldw, const float* __restrict__ bias,
                                                             const float* __restrict__ R, long long ldr, float* __restrict__ Y,
-                                                            long long ldy, long long M, int N, int K, int act) {
+                                                            long long ldy, long long M, int N, int K, int act,
+                                                            _Float16* __restrict__ Yh, _Float16* __restrict__ Yl) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int n4 = N >> 2;
     if (idx >= M * n4) return;
@@ -171,7 +175,23 @@ __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restr
         if (R) acc += R[m * ldr + n + j];
         y[j] = acc;
     }
-    *reinterpret_cast<float4*>(Y + m * ldy + n) = make_float4(y[0], y[1], y[2], y[3]);
+    if (PLANES) {
+        uint2 hi, lo;
+        split2h(y[0], y[1], hi.x, lo.x);
+        split2h(y[2], y[3], hi.y, lo.y);
+        *reinterpret_cast<uint2*>(Yh + m * ldy + n) = hi;
+        *reinterpret_cast<uint2*>(Yl + m * ldy + n) = lo;
+    } else {
+        *reinterpret_cast<float4*>(Y + m * ldy + n) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+}
+
+// act(X W^T + bias) for K <= 4, written as fp16 hi/lo planes (N % 4 == 0, ldy % 4 == 0)
+void launch_linear_smallk_planes(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, void* Yh, void* Yl,
+                                 int64_t ldy, int64_t M, int N, int K, int act) {
+    if (M <= 0 || N <= 0) return;
+    hipLaunchKernelGGL(linear_smallk_kernel<true>, dim3((unsigned)cdiv(M * (N / 4), 256)), dim3(256), 0, s, X, (long long)ldx, W, (long long)K,
+                       bias, (const float*)nullptr, 0ll, (float*)nullptr, (long long)ldy, (long long)M, N, K, act, (_Float16*)Yh, (_Float16*)Yl);
 }
 
 void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R,
@@ -190,8 +210,8 @@ void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, c
         return;
     }
     if (K <= 4 && N % 4 == 0 && ldy % 4 == 0 && aligned16(Y) && !row_bias && M * (N / 4) >= 65536) {
-        hipLaunchKernelGGL(linear_smallk_kernel, dim3((unsigned)cdiv(M * (N / 4), 256)), dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw,
-                           bias, R, (long long)ldr, Y, (long long)ldy, (long long)M, N, K, act);
+        hipLaunchKernelGGL(linear_smallk_kernel<false>, dim3((unsigned)cdiv(M * (N / 4), 256)), dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw,
+                           bias, R, (long long)ldr, Y, (long long)ldy, (long long)M, N, K, act, (_Float16*)nullptr, (_Float16*)nullptr);
         return;
     }
     const int vec_x = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
