@@ -89,9 +89,9 @@ def _grid_cases():
     cases["offset_origin"] = (u(1, 777, 3) + 100.0, u(1, 2000, 3) + 100.0)
     cases["one_query"] = (u(1, 1, 3), u(1, 1024, 3))
     # every query near the centre of a sphere: all candidates are (nearly) equidistant, every group of 32 queries is "heavy" and is
-    # parked for the split pass -- 200 groups for 128 parking slots, so the groups that find no slot finish on their own as well
+    # parked for the split pass -- 500 groups for the 384 parking slots, so the groups that find no slot finish on their own as well
     sph = rng.normal(size=(1, 4096, 3)); sph /= np.linalg.norm(sph, axis=-1, keepdims=True)
-    cases["sphere_centre"] = (u(1, 6400, 3) * 0.02, (0.3 * sph).astype(np.float32))
+    cases["sphere_centre"] = (u(1, 16000, 3) * 0.02, (0.3 * sph).astype(np.float32))
     cases["sphere_centre_batch"] = (u(2, 640, 3) * 0.05, np.stack([(0.3 * sph[0]).astype(np.float32), (0.2 * sph[0, ::-1]).astype(np.float32)]))
     return cases
 
