@@ -153,20 +153,16 @@ static void head_planes_weights(hipStream_t s, int which, const float* W, int64_
     }
     Wl = Wh + (size_t)N * K;
 }
-template <class Join>
-static void run_head_planes(hipStream_t s, const float* x, const float* view_harmonics, int64_t T, const LinW& xe1, const LinW& xe2,
-                            const LinW& xe3, const LinW& lin1, const LinW& lin2, const LinW& lin3, const float* gbias,
-                            int64_t rows_per_group, const int* row_group, const void* const* head_planes, const float* head_inv_scales,
-                            const HeadScratch& w, float* out, Join join) {
+// the part of the planes head that needs nothing but the queries: x embedding 3 -> 128 -> 256 -> 512 (GELU each, SconeOcc.py:35-42)
+// into columns 768.. of the feature planes, the view harmonics into columns 1280..
+static void run_x_embedding_planes(hipStream_t s, const float* x, const float* view_harmonics, int64_t T, const LinW& xe1, const LinW& xe2,
+                                   const LinW& xe3, const void* const* head_planes, const float* head_inv_scales, const HeadScratch& w) {
     _Float16 *fh = w.featP, *fl = w.featP + (size_t)T * 1344;
     _Float16 *hh = w.h1P;
-    float* x1 = w.h2;                                                        // fp32 [T][128]
     _Float16* x1h = reinterpret_cast<_Float16*>(w.h2 + (size_t)T * 128);     // planes [2][T][128]
     _Float16* x1l = x1h + (size_t)T * 128;
     const _Float16 *Wh, *Wl;
     float inv;
-    // x embedding 3 -> 128 -> 256 -> 512, GELU each (SconeOcc.py:35-42)
-    (void)x1;
     launch_linear_smallk_planes(s, x, 3, xe1.w, xe1.b, x1h, x1l, 128, T, 128, 3, ACT_GELU);       // (planes directly: no fp32 rows, no split pass)
     head_planes_weights(s, 0, xe2.w, 128, 256, 128, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
     launch_linear3p(s, x1h, x1l, 128, Wh, Wl, 128, xe2.b, nullptr, hh, hh + (size_t)T * 256, 256, T, 256, 128, ACT_GELU, inv, nullptr, 0, nullptr);
@@ -174,6 +170,19 @@ static void run_head_planes(hipStream_t s, const float* x, const float* view_har
     launch_linear3p(s, hh, hh + (size_t)T * 256, 256, Wh, Wl, 256, xe3.b, nullptr, fh + 768, fl + 768, 1344, T, 512, 256, ACT_GELU, inv, nullptr, 0,
                     nullptr);
     launch_split_to_planes(s, view_harmonics, 64, fh + 1280, fl + 1280, 1344, T, 64);
+}
+
+// x_done: the x-embedding part has been queued elsewhere (the side stream: the join covers it)
+template <class Join>
+static void run_head_planes(hipStream_t s, const float* x, const float* view_harmonics, int64_t T, const LinW& xe1, const LinW& xe2,
+                            const LinW& xe3, const LinW& lin1, const LinW& lin2, const LinW& lin3, const float* gbias,
+                            int64_t rows_per_group, const int* row_group, const void* const* head_planes, const float* head_inv_scales,
+                            const HeadScratch& w, float* out, Join join, bool x_done = false) {
+    _Float16 *fh = w.featP, *fl = w.featP + (size_t)T * 1344;
+    _Float16 *hh = w.h1P;
+    const _Float16 *Wh, *Wl;
+    float inv;
+    if (!x_done) run_x_embedding_planes(s, x, view_harmonics, T, xe1, xe2, xe3, head_planes, head_inv_scales, w);
     join();                                               // the global feature (side stream) is needed from here on
     // head MLP 1856 -> 512 -> 256 -> 1, GELU after every layer incl. the last (SconeOcc.py:334-345); the global 512 columns are gbias
     head_planes_weights(s, 2, lin1.w + 512, 1856, 512, 1344, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
@@ -461,17 +470,6 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
             (void)hipStreamWaitEvent(s, side->join, 0);
         }
     } side_join{side, s, false, false};
-    {
-        run_pct(gs, wg, pc_global, gfeat, 512, B, (int)Lg, 256, garena);
-        MCR_REQUIRE(garena.ok(), "mcr_scone_occ_forward: workspace overflow (global)");
-        // its contribution to linear1: gbias[b, n] = sum_k gfeat[b, k] * W1[n, k]  (columns 0..511 of linear1.weight)
-        launch_linear(gs, gfeat, 512, lin1.w, nullptr, nullptr, 0, gbias, 512, B, 512, 512, ACT_NONE, nullptr, 0, 1856, 1);
-    }
-    if (side) {
-        MCR_REQUIRE(hipEventRecord(side->join, side->s) == hipSuccess, "mcr_scone_occ_forward: side stream (record)");
-        side_join.recorded = true;
-    }
-    // ---- local multi-scale neighbourhood features (SconeOcc.py:290-311) ----
     // fused path: one kNN + one LDS-resident transformer launch per (cloud, scale) over ALL queries (nothing but
     // the [Q,16,3] offsets is materialised); layer-by-layer path: chunked over queries to bound its workspace.
     const bool fused_all = local_blobs && local_blobs[0] && local_blobs[1] && local_blobs[2];
@@ -482,6 +480,24 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     const bool planes = planes_on && fused_all && g_local_pct_variant == 6;
     _Float16* featP = reinterpret_cast<_Float16*>(feat);
     const int64_t Tall = B * Q;
+    // the x embedding of the planes head (0.3 ms of GEMMs that need only the queries) rides on the side stream behind the global
+    // transformer: its workgroups fill the machine in the holes of the local path (kNN preparation, the parked kNN groups, kernel
+    // tails) instead of extending the serial tail of the step.  MCR_OCC_X_SIDE=0: on the caller's stream, after the local path.
+    static const bool x_side_on = []() { const char* e = getenv("MCR_OCC_X_SIDE"); return !(e && e[0] == '0'); }();
+    const bool x_on_side = planes && side && x_side_on;
+    const HeadScratch head_scratch{featP, reinterpret_cast<_Float16*>(h1), h2, wplanes};
+    {
+        run_pct(gs, wg, pc_global, gfeat, 512, B, (int)Lg, 256, garena);
+        MCR_REQUIRE(garena.ok(), "mcr_scone_occ_forward: workspace overflow (global)");
+        // its contribution to linear1: gbias[b, n] = sum_k gfeat[b, k] * W1[n, k]  (columns 0..511 of linear1.weight)
+        launch_linear(gs, gfeat, 512, lin1.w, nullptr, nullptr, 0, gbias, 512, B, 512, 512, ACT_NONE, nullptr, 0, 1856, 1);
+        if (x_on_side) run_x_embedding_planes(gs, x, view_harmonics, B * Q, xe1, xe2, xe3, head_planes, head_inv_scales, head_scratch);
+    }
+    if (side) {
+        MCR_REQUIRE(hipEventRecord(side->join, side->s) == hipSuccess, "mcr_scone_occ_forward: side stream (record)");
+        side_join.recorded = true;
+    }
+    // ---- local multi-scale neighbourhood features (SconeOcc.py:290-311) ----
     // grid-pruned kNN for the scales it applies to (whole-Q launches only): ONE query order for all three scales
     const int* knn_qperm = nullptr;
     KnnGridCloud knn_clouds[3]{};
@@ -553,12 +569,12 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     if (planes) {
         bool join_failed = false;
         run_head_planes(s, x, view_harmonics, T, xe1, xe2, xe3, lin1, lin2, lin3, gbias, Q, nullptr, head_planes, head_inv_scales,
-                        HeadScratch{featP, reinterpret_cast<_Float16*>(h1), h2, wplanes}, out, [&]() {
+                        head_scratch, out, [&]() {
                             if (side) {
                                 side_join.joined = true;
                                 join_failed = hipStreamWaitEvent(s, side->join, 0) != hipSuccess;
                             }
-                        });
+                        }, x_on_side);
         MCR_REQUIRE(!join_failed, "mcr_scone_occ_forward: side stream (join)");
         if (range_flag) launch_nonfinite_flag(s, out, T, range_flag);
         MCR_LAUNCH_CHECK("mcr_scone_occ_forward");
