@@ -13,7 +13,7 @@ from torch import nn
 from .. import autograd as A
 from .. import ops, _lib
 from .Attention import Embedding, Encoder, _f32c, _inference_only
-from .packing import BlobCache, HeadPlaneCache, TableCache, param_key, invalidate as _invalidate_key
+from .packing import BlobCache, HeadPlaneCache, TableCache, param_key, invalidate as _invalidate_key, freeze as _freeze_key
 
 
 class XEmbedding(nn.Module):
@@ -131,6 +131,11 @@ class SconeOcc(nn.Module):
     def clear_range_flag(self):
         if self._range_flag is not None:
             self._range_flag.zero_()
+
+    def freeze_weight_caches(self, on=True):
+        """Inference mode: fingerprint the parameters once, now, and trust them unchanged until freeze_weight_caches(False) or
+        invalidate_weight_caches() (an optimizer step or load_state_dict in between would go unnoticed: opt-in)."""
+        _freeze_key(self, self._key_cache, on)
 
     def invalidate_weight_caches(self):
         """Drop every derived weight image (pointer table, packed local-transformer blobs, stacked QKV, split head planes): call

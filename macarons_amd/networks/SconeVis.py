@@ -15,7 +15,7 @@ from torch import nn
 from .. import autograd as A
 from .. import ops
 from .Attention import Embedding, Encoder, _f32c
-from .packing import TableCache
+from .packing import TableCache, freeze as _freeze_key
 
 
 class SconeVis(nn.Module):
@@ -51,6 +51,10 @@ class SconeVis(nn.Module):
         self.nonlinear2 = nn.GELU()
         self.fc3 = nn.Linear(2 * n_harmonics, n_harmonics)
         self._table_cache = TableCache()
+
+    def freeze_weight_caches(self, on=True):
+        """Inference mode: see SconeOcc.freeze_weight_caches."""
+        _freeze_key(self, self._table_cache._c, on)
 
     def invalidate_weight_caches(self):
         """Drop the derived weight images (pointer table, stacked QKV); see packing._param_key for when this is needed."""

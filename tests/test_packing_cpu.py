@@ -64,3 +64,25 @@ def test_h2d_is_a_plain_copy_off_the_gpu():
     assert t.dtype == torch.int32 and t.tolist() == [0, 1, 2, 3, 4]
     t = ops.h2d([1.5, 2.5], torch.float32, torch.device("cpu"))
     assert t.dtype == torch.float32 and t.tolist() == [1.5, 2.5]
+
+
+def test_frozen_fingerprint_is_opt_in_and_reversible():
+    """freeze(): the key is taken once and returned unchanged whatever happens to the parameters; invalidate() / freeze(False) go
+    back to fingerprinting every call."""
+    import torch
+    from macarons_amd.networks.packing import _param_key, freeze, invalidate
+    m = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 2))
+    c = {}
+    k0 = _param_key(m, c)
+    freeze(m, c)
+    with torch.no_grad():
+        m[0].weight.add_(1.0)
+    assert _param_key(m, c) == k0                       # frozen: the edit goes unnoticed (documented)
+    freeze(m, c, False)
+    k1 = _param_key(m, c)
+    assert k1 != k0
+    freeze(m, c)
+    invalidate(c)
+    with torch.no_grad():
+        m[1].bias.add_(1.0)
+    assert _param_key(m, c) != k1
