@@ -68,10 +68,12 @@ def cpu_baseline(pts, harm, cams):
     p, h, c = pts.cpu().numpy(), harm.cpu().numpy(), cams.cpu().numpy()
     N, C_sample = p.shape[1], c.shape[1]
     cport.coverage_gain(p[:, :256], h[:, :256], c)        # warm-up / build
-    # every host core, and one thread per physical core (SMT siblings share the FP units: 256 threads measured SLOWER than 128 on
-    # the 2 x 64-core host); ~5 s of CPU work each, the better one is the baseline, both are reported
+    # every host core, one thread per physical core (SMT siblings share the FP units: 256 threads measured SLOWER than 128 on
+    # the 2 x 64-core host) and the CPUs the container's quota lets the process burn (16 on the pool's boxes: more threads than
+    # that only get the process throttled); ~5 s of CPU work each, the best one is the baseline, all are reported
+    from macarons_amd.utility.host import effective_cpus
     runs = []
-    for nt_req in sorted({os.cpu_count() or 1, max(1, (os.cpu_count() or 2) // 2)}, reverse=True):
+    for nt_req in sorted({os.cpu_count() or 1, max(1, (os.cpu_count() or 2) // 2), effective_cpus()}, reverse=True):
         cport.set_threads(nt_req)
         reps, t0 = 0, time.perf_counter()
         while True:
@@ -86,7 +88,8 @@ def cpu_baseline(pts, harm, cams):
     return {"value": best["evals_per_s"], "unit": "evals/s", "cores": int(nthreads), "thread_sweep": runs, "kind": "port",
             "sample": f"C port (oracle/csrc/scorer_port.c, OpenMP) of the reference scorer on the same cloud: "
                       f"N={N} points x {C_sample} cameras x {reps} passes, {dt:.2f} s wall; "
-                      f"`cores` = omp_get_num_threads() inside the parallel region; host has {os.cpu_count()} cores"}, g
+                      f"`cores` = omp_get_num_threads() inside the parallel region of the fastest of the thread counts tried; "
+                      f"host has {os.cpu_count()} cores, the container's quota is {effective_cpus()} CPUs"}, g
 
 
 def cpu_baseline_nbv(C):
@@ -117,7 +120,8 @@ def cpu_baseline_nbv(C):
     blas_threads = None
     try:
         from threadpoolctl import threadpool_limits, threadpool_info
-        threadpool_limits(limits=os.cpu_count() or 1)
+        from macarons_amd.utility.host import effective_cpus
+        threadpool_limits(limits=effective_cpus())
         blas_threads = {i.get("internal_api", i.get("user_api", "?")): int(i.get("num_threads", 0)) for i in threadpool_info()}
     except Exception:
         pass
@@ -132,7 +136,7 @@ def cpu_baseline_nbv(C):
     cores = max(blas_threads.values()) if blas_threads else int(torch.get_num_threads())
     return {"value": C / times[6000], "unit": "evals/s", "cores": int(cores), "thread_pools": blas_threads, "kind": "port",
             "sample": f"numpy restatement of the NBV step (oracle/nbv.py; `cores` = the largest thread pool numpy's BLAS / OpenMP "
-                      f"libraries report after asking for all {os.cpu_count()} host cores): M=10240 surface points, C={C} cameras, Q_s=6000 of the 100000 proxy points: "
+                      f"libraries report after asking for the {effective_cpus()} CPUs of the container's quota; the host has {os.cpu_count()} cores): M=10240 surface points, C={C} cameras, Q_s=6000 of the 100000 proxy points: "
                       f"{times[6000]:.2f} s (Q_s=1500: {times[1500]:.2f} s)",
             "sample_step_s": times[6000], "per_query_ms": per_q * 1e3, "fixed_s": fixed,
             "extrapolated_full_step_s": full, "extrapolated_full_evals_per_s": C / full,

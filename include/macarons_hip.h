@@ -155,6 +155,18 @@ int mcr_scone_occ_forward_ragged(const float* pc_global, const int* global_len, 
                                  const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
                                  size_t workspace_bytes, void* stream);
 
+/* The same as two calls on one stream with ONE workspace: phase 1 = what needs none of the hidden torch.randperm draws (the scale-0
+ * search and local transformer over the whole clouds; the x embedding on the fp16-planes path) -- it reads pc_scale[0], scale_off[0],
+ * x, view_harmonics, row_job, knn_blocks, local_blobs[0] only (the other arrays may hold anything, pc_global / global_len / out may be
+ * NULL); phase 2 = the rest.  The host makes the draws between the two calls while the GPU works on phase 1 (a MACARONS decision
+ * otherwise idles ~2.5 ms there).  phase 0 = both = mcr_scone_occ_forward_ragged. */
+int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global_len, int64_t Lg, const float* const* pc_scale,
+                                       const int64_t* const* scale_off, const float* x, const float* view_harmonics, const int* row_job,
+                                       const int* knn_blocks, int64_t n_blocks, float* out, int64_t J, int64_t T,
+                                       const float* const* weights, int n_weights, const float* const* local_blobs,
+                                       const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
+                                       size_t workspace_bytes, int phase, void* stream);
+
 /* Fused per-query local PCTransformer (the FLOP majority of SconeOcc.forward, SconeOcc.py:293-304 + :104-130):
  *   offsets [S,16,3] (kNN neighbours minus the query) -> features[s*ld_features + 0:256] = max(128) || avg(128).
  * `blob`: 16-byte-aligned device image of ONE local transformer's parameters, mcr_local_pct_blob_floats() floats,

@@ -615,13 +615,36 @@ size_t mcr_scone_occ_ragged_workspace_bytes(int64_t J, int64_t T, int64_t Lg) {
 }
 int mcr_knn_rows_per_block(void) { return knn_rows_per_block(); }
 
+int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global_len, int64_t Lg, const float* const* pc_scale,
+                                       const int64_t* const* scale_off, const float* x, const float* view_harmonics, const int* row_job,
+                                       const int* knn_blocks, int64_t n_blocks, float* out, int64_t J, int64_t T,
+                                       const float* const* weights, int n_weights, const float* const* local_blobs,
+                                       const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
+                                       size_t workspace_bytes, int phase, void* stream);
 int mcr_scone_occ_forward_ragged(const float* pc_global, const int* global_len, int64_t Lg, const float* const* pc_scale,
                                  const int64_t* const* scale_off, const float* x, const float* view_harmonics, const int* row_job,
                                  const int* knn_blocks, int64_t n_blocks, float* out, int64_t J, int64_t T,
                                  const float* const* weights, int n_weights, const float* const* local_blobs,
                                  const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-    MCR_REQUIRE(pc_global && global_len && pc_scale && scale_off && x && view_harmonics && row_job && knn_blocks && out && weights,
+    return mcr_scone_occ_forward_ragged_phase(pc_global, global_len, Lg, pc_scale, scale_off, x, view_harmonics, row_job, knn_blocks, n_blocks, out,
+                                              J, T, weights, n_weights, local_blobs, head_planes, head_inv_scales, range_flag, workspace,
+                                              workspace_bytes, 0, stream);
+}
+
+// The same in two calls on one stream and ONE workspace: phase 1 = everything that needs none of the hidden random draws (scale 0:
+// the whole clouds; the x embedding on the planes path), phase 2 = the rest (global transformer, scales 1 and 2, head).  The host
+// makes the draws (~60 us of torch.randperm per job) between the two calls while the GPU works on phase 1.  phase 0 = both.
+// Phase 1 reads pc_scale[0], scale_off[0], x, view_harmonics, row_job, knn_blocks, local_blobs[0]; phase 2 everything else too.
+int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global_len, int64_t Lg, const float* const* pc_scale,
+                                       const int64_t* const* scale_off, const float* x, const float* view_harmonics, const int* row_job,
+                                       const int* knn_blocks, int64_t n_blocks, float* out, int64_t J, int64_t T,
+                                       const float* const* weights, int n_weights, const float* const* local_blobs,
+                                       const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
+                                       size_t workspace_bytes, int phase, void* stream) {
+    MCR_REQUIRE(phase >= 0 && phase <= 2, "mcr_scone_occ_forward_ragged: phase must be 0, 1 or 2");
+    const bool early = phase != 2, late = phase != 1;
+    MCR_REQUIRE(pc_scale && scale_off && x && view_harmonics && row_job && knn_blocks && weights && (!late || (pc_global && global_len && out)),
                 "mcr_scone_occ_forward_ragged: null pointer");
     MCR_REQUIRE(n_weights == OCC_NW, "mcr_scone_occ_forward_ragged: expected %d weight pointers, got %d", OCC_NW, n_weights);
     MCR_REQUIRE(J > 0 && T > 0 && Lg > 0 && J <= 32767 && n_blocks > 0, "mcr_scone_occ_forward_ragged: bad problem size");
@@ -630,7 +653,7 @@ int mcr_scone_occ_forward_ragged(const float* pc_global, const int* global_len, 
     MCR_REQUIRE(!head_planes || head_inv_scales, "mcr_scone_occ_forward_ragged: head_planes need head_inv_scales");
     MCR_REQUIRE(workspace && workspace_bytes >= mcr_scone_occ_ragged_workspace_bytes(J, T, Lg), "mcr_scone_occ_forward_ragged: workspace too small");
     for (int i = 0; i < n_weights; ++i) MCR_REQUIRE(weights[i], "mcr_scone_occ_forward_ragged: weight %d is null", i);
-    for (int i = 0; i < 3; ++i) MCR_REQUIRE(pc_scale[i] && scale_off[i], "mcr_scone_occ_forward_ragged: scale %d is null", i);
+    for (int i = 0; i < (late ? 3 : 1); ++i) MCR_REQUIRE(pc_scale[i] && scale_off[i], "mcr_scone_occ_forward_ragged: scale %d is null", i);
     hipStream_t s = (hipStream_t)stream;
     const float* const* p = weights;
     const PctW wg = read_pct(p);
@@ -650,6 +673,25 @@ int mcr_scone_occ_forward_ragged(const float* pc_global, const int* global_len, 
     const size_t glob_bytes = pct_ws_bytes(J * Lg);
     Arena garena{(char*)workspace + head.off, glob_bytes, 0};
     Arena scratch{(char*)workspace + head.off + glob_bytes, workspace_bytes - head.off - glob_bytes, 0};
+    static const bool planes_on = []() { const char* e = getenv("MCR_HEAD_PLANES"); return !(e && e[0] == '0'); }();
+    const bool planes = planes_on && g_local_pct_variant == 6;
+    _Float16* featP = reinterpret_cast<_Float16*>(feat);
+    const HeadScratch head_scratch{featP, reinterpret_cast<_Float16*>(h1), h2, wplanes};
+    float* offs = scratch.f(T * 16 * 3);
+    MCR_REQUIRE(scratch.ok(), "mcr_scone_occ_forward_ragged: workspace overflow (kNN)");
+    auto local_scale = [&](int sc) {                      // one segmented kNN + one fused transformer launch over ALL rows
+        launch_knn16_segmented(s, x, pc_scale[sc], (const long long*)scale_off[sc], knn_blocks, n_blocks, T, offs);
+        if (planes) run_local_pct(s, offs, nullptr, FEAT, T, local_blobs[sc], featP + sc * 256, featP + T * FEAT + sc * 256);
+        else run_local_pct(s, offs, feat + sc * 256, FEAT, T, local_blobs[sc]);
+    };
+    if (early) {
+        if (planes && phase == 1) run_x_embedding_planes(s, x, view_harmonics, T, xe1, xe2, xe3, head_planes, head_inv_scales, head_scratch);
+        local_scale(0);
+        if (!late) {
+            MCR_LAUNCH_CHECK("mcr_scone_occ_forward_ragged (phase 1)");
+            return 0;
+        }
+    }
 
     OccSide* side = occ_side(s);
     hipStream_t gs = s;
@@ -670,26 +712,17 @@ int mcr_scone_occ_forward_ragged(const float* pc_global, const int* global_len, 
         MCR_REQUIRE(hipEventRecord(side->join, side->s) == hipSuccess, "mcr_scone_occ_forward_ragged: side stream (record)");
         side_join.recorded = true;
     }
-    // ---- local features: one segmented kNN + one fused transformer launch per scale over ALL rows ----
-    float* offs = scratch.f(T * 16 * 3);
-    MCR_REQUIRE(scratch.ok(), "mcr_scone_occ_forward_ragged: workspace overflow (kNN)");
-    static const bool planes_on = []() { const char* e = getenv("MCR_HEAD_PLANES"); return !(e && e[0] == '0'); }();
-    const bool planes = planes_on && g_local_pct_variant == 6;
-    _Float16* featP = reinterpret_cast<_Float16*>(feat);
-    for (int sc = 0; sc < 3; ++sc) {
-        launch_knn16_segmented(s, x, pc_scale[sc], (const long long*)scale_off[sc], knn_blocks, n_blocks, T, offs);
-        if (planes) run_local_pct(s, offs, nullptr, FEAT, T, local_blobs[sc], featP + sc * 256, featP + T * FEAT + sc * 256);
-        else run_local_pct(s, offs, feat + sc * 256, FEAT, T, local_blobs[sc]);
-    }
+    // ---- local features of scales 1 and 2 (scale 0: above) ----
+    for (int sc = 1; sc < 3; ++sc) local_scale(sc);
     if (planes) {
         bool join_failed = false;
         run_head_planes(s, x, view_harmonics, T, xe1, xe2, xe3, lin1, lin2, lin3, gbias, 0, row_job, head_planes, head_inv_scales,
-                        HeadScratch{featP, reinterpret_cast<_Float16*>(h1), h2, wplanes}, out, [&]() {
+                        head_scratch, out, [&]() {
                             if (side) {
                                 side_join.joined = true;
                                 join_failed = hipStreamWaitEvent(s, side->join, 0) != hipSuccess;
                             }
-                        });
+                        }, /*x_done=*/phase == 2);
         MCR_REQUIRE(!join_failed, "mcr_scone_occ_forward_ragged: side stream (join)");
         if (range_flag) launch_nonfinite_flag(s, out, T, range_flag);
         MCR_LAUNCH_CHECK("mcr_scone_occ_forward_ragged");

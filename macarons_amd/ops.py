@@ -7,6 +7,11 @@ import ctypes
 import torch
 
 from ._lib import lib, check, MacaronsHipError, c_i64, c_int, c_size, c_vp, c_f32
+from .utility.host import limit_host_threads
+
+# torch's intra-op pool follows the machine's core count, not the container's CPU quota: an oversubscribed parallel region gets
+# the whole process throttled, the launching thread included (utility/host.py has the measurement)
+limit_host_threads()
 
 
 def _stream():
@@ -289,35 +294,45 @@ def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_bl
 
 
 def scone_occ_forward_ragged(pc_global, global_len, pc_scales, scale_offsets, x, view_harmonics, row_job, knn_blocks, weights,
-                             local_blobs, head_planes=None, range_flag=None):
+                             local_blobs, head_planes=None, range_flag=None, phase=0, Lg=None, out=None):
     """J SconeOcc jobs of different sizes in one launch sequence (mcr_scone_occ_forward_ragged).  pc_global [J,Lg,3],
     global_len int32 [J], pc_scales: 3 ragged clouds [sum M_s,3], scale_offsets: 3 int64 [J+1], x [T,3], view_harmonics [T,64],
-    row_job int32 [T], knn_blocks int32 [n_blocks,4] -> out [T,1]."""
-    pc_global, x, view_harmonics = _req(pc_global, "pc_global"), _req(x, "x"), _req(view_harmonics, "view_harmonics")
-    global_len, row_job = _req(global_len, "global_len", torch.int32), _req(row_job, "row_job", torch.int32)
+    row_job int32 [T], knn_blocks int32 [n_blocks,4] -> out [T,1].
+    phase 1 / 2 (mcr_scone_occ_forward_ragged_phase): the part that needs no hidden draw / the rest, as two calls on the same stream
+    (phase 1: pc_global / global_len may be None with Lg given, pc_scales[1:], scale_offsets[1:] are ignored; returns None)."""
+    x, view_harmonics = _req(x, "x"), _req(view_harmonics, "view_harmonics")
+    row_job = _req(row_job, "row_job", torch.int32)
     knn_blocks = _req(knn_blocks, "knn_blocks", torch.int32)
-    pc_scales = [_req(p, "pc_scale") for p in pc_scales]
-    scale_offsets = [_req(o, "scale_offsets", torch.int64) for o in scale_offsets]
-    J, Lg = pc_global.shape[0], pc_global.shape[1]
+    late = phase != 1
+    pc_scales = [_req(p, "pc_scale") for p in (pc_scales if late else [pc_scales[0]] * 3)]
+    scale_offsets = [_req(o, "scale_offsets", torch.int64) for o in (scale_offsets if late else [scale_offsets[0]] * 3)]
+    J = scale_offsets[0].numel() - 1
+    if late:
+        pc_global, global_len = _req(pc_global, "pc_global"), _req(global_len, "global_len", torch.int32)
+        Lg = pc_global.shape[1]
+        if pc_global.shape[0] != J or global_len.numel() != J:
+            raise ValueError("scone_occ_forward_ragged: pc_global [J,Lg,3], global_len [J]")
     T = x.shape[0]
-    if x.shape != (T, 3) or view_harmonics.shape != (T, 64) or row_job.numel() != T or global_len.numel() != J:
-        raise ValueError("scone_occ_forward_ragged: x [T,3], view_harmonics [T,64], row_job [T], global_len [J]")
+    if x.shape != (T, 3) or view_harmonics.shape != (T, 64) or row_job.numel() != T:
+        raise ValueError("scone_occ_forward_ragged: x [T,3], view_harmonics [T,64], row_job [T]")
     if any(o.numel() != J + 1 for o in scale_offsets) or knn_blocks.dim() != 2 or knn_blocks.shape[1] != 4:
         raise ValueError("scone_occ_forward_ragged: scale_offsets must be [J+1], knn_blocks [n_blocks,4]")
     L_ = lib()
-    out = torch.empty((T, 1), dtype=torch.float32, device=x.device)
+    if late and out is None:
+        out = torch.empty((T, 1), dtype=torch.float32, device=x.device)
     ws = _workspace(x.device, L_.mcr_scone_occ_ragged_workspace_bytes(c_i64(J), c_i64(T), c_i64(Lg)))
     sc_ptrs = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in pc_scales])
     off_ptrs = (ctypes.c_void_p * 3)(*[o.data_ptr() for o in scale_offsets])
     blobs = (ctypes.c_void_p * 3)(*[_req(b, "local_blob").data_ptr() for b in local_blobs])
     with torch.cuda.device(x.device):
-        check(L_.mcr_scone_occ_forward_ragged(_p(pc_global), _p(global_len), c_i64(Lg), sc_ptrs, off_ptrs, _p(x), _p(view_harmonics),
-                                              _p(row_job), _p(knn_blocks), c_i64(knn_blocks.shape[0]), _p(out), c_i64(J), c_i64(T),
-                                              _ptr_table(weights), c_int(_n_weights(weights)), blobs,
-                                              head_planes[1] if head_planes is not None else None,
-                                              head_planes[2] if head_planes is not None else None,
-                                              _p(_req(range_flag, "range_flag", torch.int32)) if range_flag is not None else c_vp(0),
-                                              _p(ws), c_size(ws.numel()), _stream()), "mcr_scone_occ_forward_ragged")
+        check(L_.mcr_scone_occ_forward_ragged_phase(_p(pc_global) if late else c_vp(0), _p(global_len) if late else c_vp(0), c_i64(Lg), sc_ptrs,
+                                                    off_ptrs, _p(x), _p(view_harmonics), _p(row_job), _p(knn_blocks), c_i64(knn_blocks.shape[0]),
+                                                    _p(out) if late else c_vp(0), c_i64(J), c_i64(T),
+                                                    _ptr_table(weights), c_int(_n_weights(weights)), blobs,
+                                                    head_planes[1] if head_planes is not None else None,
+                                                    head_planes[2] if head_planes is not None else None,
+                                                    _p(_req(range_flag, "range_flag", torch.int32)) if range_flag is not None else c_vp(0),
+                                                    _p(ws), c_size(ws.numel()), c_int(int(phase)), _stream()), "mcr_scone_occ_forward_ragged")
     return out
 
 
@@ -470,16 +485,39 @@ def coverage_gain_multiple(pts, harmonics, cams, n_cam, use_sigmoid=True):
     return out, n_idx
 
 
+_pinned_pool = {}        # (device index) -> list of [pinned uint8 buffer, event of its last copy]
+
+
 def h2d(data, dtype, device):
     """Host data (list / numpy array / CPU tensor) -> device tensor WITHOUT stalling the host: a `.to(device)` from pageable memory
     is a stream-ordered blocking copy, i.e. the host waits for every kernel queued before it (the glue of a MACARONS decision did
-    that ~15 times per decision).  Staged through PyTorch's cached pinned allocator and copied asynchronously instead."""
+    that ~15 times per decision).  The data is staged in a small pool of re-used pinned buffers (power-of-two sizes; a buffer is
+    taken again once the event behind its last copy has fired) and copied asynchronously.  (torch's own pin_memory() allocates a
+    new pinned block for every new size: 80 ms for the 1 MB index array of a ragged occupancy pass.)"""
     t = data if torch.is_tensor(data) else torch.as_tensor(data)
     t = t.to(dtype) if t.dtype != dtype else t
     device = torch.device(device)
     if device.type != "cuda" or t.device.type != "cpu":
         return t.to(device)
-    return t.contiguous().pin_memory().to(device, non_blocking=True)
+    t = t.contiguous()
+    nbytes = t.numel() * t.element_size()
+    if nbytes == 0:
+        return torch.empty(t.shape, dtype=dtype, device=device)
+    pool = _pinned_pool.setdefault(device.index if device.index is not None else torch.cuda.current_device(), [])
+    slot = None
+    for ent in pool:
+        if ent[0].numel() >= nbytes and (slot is None or ent[0].numel() < slot[0].numel()) and ent[1].query():
+            slot = ent
+    if slot is None:
+        cap = 1 << max(12, (nbytes - 1).bit_length())
+        slot = [torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.cuda.Event()]
+        pool.append(slot)
+    stage = slot[0][:nbytes].view(dtype).view(t.shape)
+    stage.copy_(t)
+    with torch.cuda.device(device):
+        out = stage.to(device, non_blocking=True)
+        slot[1].record(torch.cuda.current_stream(device))
+    return out
 
 
 def gather_columns(x, idx):

@@ -1,5 +1,6 @@
 """Host-side weight packing of the fused local transformers (no GPU): blob sizes match what the kernels expect."""
 import io
+import os
 import contextlib
 
 import numpy as np
@@ -86,3 +87,20 @@ def test_frozen_fingerprint_is_opt_in_and_reversible():
     with torch.no_grad():
         m[1].bias.add_(1.0)
     assert _param_key(m, c) != k1
+
+
+def test_host_thread_cap_follows_the_quota_and_never_raises_the_count(monkeypatch):
+    from macarons_amd.utility import host
+    n = host.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.setenv("MCR_HOST_THREADS", "0")
+        assert host.limit_host_threads() == before                 # opt-out
+        monkeypatch.setenv("MCR_HOST_THREADS", str(before + 7))
+        assert host.limit_host_threads() == before                 # a cap, not a request for more
+        monkeypatch.delenv("MCR_HOST_THREADS")
+        assert host.limit_host_threads() <= max(n, 1) or before <= n
+        assert host.limit_host_threads(1) == 1
+    finally:
+        torch.set_num_threads(before)
