@@ -45,6 +45,20 @@ __device__ __forceinline__ float wave_sum_to_last(float v) {
     return v;
 }
 
+// The two cross-row steps as ONE instruction each: `v_add_f32_dpp v, v, v row_bcast:15 row_mask:0xa` adds the broadcast lane in the
+// enabled rows and leaves the other rows' v alone, which is what `v += dpp_mov0<0x142, 0xa>(v)` means -- but hipcc compiles
+// that to v_mov 0 + v_mov_dpp + v_add (it only folds full-mask DPP moves).  Same additions in the same order as
+// wave_sum_to_last().  The s_nop's are the two wait states a DPP read needs after a vector write of its source (the hazard
+// recogniser does not look inside inline asm).
+__device__ __forceinline__ float wave_sum_cross_rows(float v) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+
 // G independent reductions, step-major: the chains hide each other's DPP wait states.
 template <int G>
 __device__ __forceinline__ void wave_sum_to_last_multi(float (&v)[G]) {
@@ -57,9 +71,7 @@ __device__ __forceinline__ void wave_sum_to_last_multi(float (&v)[G]) {
 #pragma unroll
     for (int g = 0; g < G; ++g) v[g] += dpp_mov0<0x118>(v[g]);
 #pragma unroll
-    for (int g = 0; g < G; ++g) v[g] += dpp_mov0<0x142, 0xa>(v[g]);
-#pragma unroll
-    for (int g = 0; g < G; ++g) v[g] += dpp_mov0<0x143, 0xc>(v[g]);
+    for (int g = 0; g < G; ++g) v[g] = wave_sum_cross_rows(v[g]);
 }
 
 __device__ __forceinline__ float wave_max_all(float v) {

@@ -7,7 +7,7 @@
 // which materialise [B*C*N,64] SH tensors three times.  Here: one lane owns one point (its 64 SH
 // coefficients live in VGPRs, turned once into the monomial coefficients of 15 polynomials in cos(polar)), cameras
 // come from wave-uniform scalar loads, the dot with the 64 real SH of the ray direction is evaluated trig-free by
-// Horner steps (94 VALU ops per (point,camera) pair, ~130 with activation and reduction), sigmoid/relu applied, and the per-camera sum over points
+// Horner steps (94 VALU ops per (point,camera) pair, 106 with activation and reduction), sigmoid/relu applied, and the per-camera sum over points
 // is a wave64 DPP reduction -> per-wave-tile partials -> a deterministic second-pass reduce (bit-stable
 // run to run).  Bound: fp32 VALU (370 algorithmic flop / pair; N*268 B of HBM per cloud).
 //
@@ -73,7 +73,11 @@ __device__ __forceinline__ float sh_dot(float dx, float dy, float dz, const floa
 
 // One point's 64 SH coefficients -> VGPRs as the monomial coefficients of its 15 polynomials in cos(polar):
 //   a[m+k, +-m] = sum_{l = m+k, m+k+2, ... < 8} SH_MONO[m][l][k] * h[l, +-m]      (in place: a[m+k] only needs h[l >= m+k])
+// SCALE multiplies every coefficient (compile-time: folded into the SH_MONO immediates): the sigmoid kernels evaluate
+// -log2(e) * z directly, the argument of their v_exp_f32.
+template <bool SCALED = false>
 __device__ __forceinline__ void load_mono_coeffs(const float* __restrict__ h, float (&a)[64]) {
+    constexpr float S = SCALED ? -1.4426950408889634f : 1.f;
     const float4* h4 = reinterpret_cast<const float4*>(h);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -84,27 +88,29 @@ __device__ __forceinline__ void load_mono_coeffs(const float* __restrict__ h, fl
     for (int m = 0; m < 8; ++m)
 #pragma unroll
         for (int k = 0; k + m < 8; ++k) {
-            float u = a[shk(m + k, m)] * SH_MONO[m][m + k][k];
-            float v = a[shk(m + k, -m)] * SH_MONO[m][m + k][k];
+            float u = a[shk(m + k, m)] * (S * SH_MONO[m][m + k][k]);
+            float v = a[shk(m + k, -m)] * (S * SH_MONO[m][m + k][k]);
 #pragma unroll
             for (int l = m + k + 2; l < 8; l += 2) {
-                u = fmaf(a[shk(l, m)], SH_MONO[m][l][k], u);
-                v = fmaf(a[shk(l, -m)], SH_MONO[m][l][k], v);
+                u = fmaf(a[shk(l, m)], S * SH_MONO[m][l][k], u);
+                v = fmaf(a[shk(l, -m)], S * SH_MONO[m][l][k], v);
             }
             a[shk(m + k, m)] = u;
             if (m) a[shk(m + k, -m)] = v;
         }
 }
 
+// SIGMOID: zs = -log2(e) * z (the coefficients carry the factor, load_mono_coeffs<true>): 1 / (1 + exp(-z)) = 1 / (1 + 2^zs).
 template <bool SIGMOID>
-__device__ __forceinline__ float activate(float z) {
-    if (SIGMOID) {
-        // 1 / (1 + exp(-z));  exp via v_exp_f32 (2^x)
-        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z);
-        return __builtin_amdgcn_rcpf(1.f + e);
-    }
-    return fmaxf(z, 0.f);
+__device__ __forceinline__ float activate(float zs) {
+    if (SIGMOID) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(zs));
+    return fmaxf(zs, 0.f);
 }
+
+// Lanes past the end of the cloud (last wave-tile only) read this row instead of a point's coefficients: a constant term of
+// -1e30 and nothing else, so z = -2.8e29 and the activation is exactly 0 (sigmoid: 2^(+4e29) = inf, 1 / inf = 0; relu:
+// max(z, 0) = 0) -- no per-pair masking multiply.
+__device__ const float SC_BLANK_ROW[64] = {-1e30f};
 
 // ---- work decomposition (both kernels) ----------------------------------------------------------------------
 // A "wave-unit" is (wave-tile of 64 points, camera).  The U = B * ceil(N/64) * C units are split into W equal
@@ -149,8 +155,7 @@ __global__ __launch_bounds__(SC_BLOCK) void sh_gain_kernel(const float* __restri
         const float py = pts[pn * pts_stride + 1];
         const float pz = pts[pn * pts_stride + 2];
         float hs[64];
-        load_mono_coeffs(harm + pn * 64, hs);
-        const float keep = valid ? 1.f : 0.f;
+        load_mono_coeffs<SIGMOID>(valid ? harm + pn * 64 : SC_BLANK_ROW, hs);
         const float* cam_b = cams + (size_t)b * C * 3;
         float* part_col = partial + (size_t)b * C * n_wtiles + wt;   // partial[b][:][wt]  (camera-major: the reduce reads rows)
         // Cameras are walked SC_R at a time: the SC_R dot products run one after the other (one camera's registers), the SC_R
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(SC_BLOCK) void sh_gain_kernel(const float* __restri
             for (int c = 0; c < SC_R; ++c) {
                 // rays = X_cam - X_pts (SconeVis.py:230-231)
                 const float z = sh_dot(cc[c][0] - px, cc[c][1] - py, cc[c][2] - pz, hs);
-                sum[c] = activate<SIGMOID>(z) * keep;
+                sum[c] = activate<SIGMOID>(z);
                 asm volatile("" : "+v"(sum[c]));             // one camera at a time: interleaving the dots costs a resident wave
             }
             wave_sum_to_last_multi<SC_R>(sum);
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(SC_BLOCK) void sh_vis_kernel(const float* __restric
         const float py = pts[pn * pts_stride + 1];
         const float pz = pts[pn * pts_stride + 2];
         float hs[64];
-        load_mono_coeffs(harm + pn * 64, hs);
+        load_mono_coeffs<SIGMOID>(harm + pn * 64, hs);
         const float* cam_b = cams + (size_t)b * C * 3;
         for (int ci = c_begin; ci < c_end; ++ci) {
             const float z = sh_dot(cam_b[3 * ci + 0] - px, cam_b[3 * ci + 1] - py, cam_b[3 * ci + 2] - pz, hs);
