@@ -38,7 +38,7 @@ __device__ __forceinline__ constexpr int shk(int l, int m) { return l * l + l + 
 // simply has n_x = n_z = 0 and every m != 0 term vanishes; the reference's acos path is ill-conditioned there).
 // P_l^m / sin^m is a polynomial of degree l-m in x, so for one point the sum over l of each order m collapses into
 // ONE polynomial per (m, cos|sin):  U_m(x) = sum_k a[m+k,+m] x^k,  V_m(x) = sum_k a[m+k,-m] x^k, whose coefficients
-// a (64 per point, same storage as the SH coefficients) are produced once per point by load_mono_coeffs.  Then
+// a (64 per point, same storage as the SH coefficients) are produced once per point by to_mono_coeffs.  Then
 //   z = U_0(x) + sum_{m>=1} ( Re w^m U_m(x) + Im w^m V_m(x) ),   w = n_z + i n_x
 // = 49 Horner FMAs + 24 ops for the powers + 14 to combine + 7 to normalise: 94 VALU ops per (point, camera) pair --
 // the floor for 64 per-point coefficients (the rescaled-recurrence form this replaces needed 130).
@@ -76,14 +76,8 @@ __device__ __forceinline__ float sh_dot(float dx, float dy, float dz, const floa
 // SCALE multiplies every coefficient (compile-time: folded into the SH_MONO immediates): the sigmoid kernels evaluate
 // -log2(e) * z directly, the argument of their v_exp_f32.
 template <bool SCALED = false>
-__device__ __forceinline__ void load_mono_coeffs(const float* __restrict__ h, float (&a)[64]) {
+__device__ __forceinline__ void to_mono_coeffs(float (&a)[64]) {
     constexpr float S = SCALED ? -1.4426950408889634f : 1.f;
-    const float4* h4 = reinterpret_cast<const float4*>(h);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const float4 v = h4[j];
-        a[4 * j + 0] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
-    }
 #pragma unroll
     for (int m = 0; m < 8; ++m)
 #pragma unroll
@@ -100,17 +94,72 @@ __device__ __forceinline__ void load_mono_coeffs(const float* __restrict__ h, fl
         }
 }
 
-// SIGMOID: zs = -log2(e) * z (the coefficients carry the factor, load_mono_coeffs<true>): 1 / (1 + exp(-z)) = 1 / (1 + 2^zs).
+// SIGMOID: zs = -log2(e) * z (the coefficients carry the factor, to_mono_coeffs<true>): 1 / (1 + exp(-z)) = 1 / (1 + 2^zs).
 template <bool SIGMOID>
 __device__ __forceinline__ float activate(float zs) {
     if (SIGMOID) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(zs));
     return fmaxf(zs, 0.f);
 }
 
-// Lanes past the end of the cloud (last wave-tile only) read this row instead of a point's coefficients: a constant term of
-// -1e30 and nothing else, so z = -2.8e29 and the activation is exactly 0 (sigmoid: 2^(+4e29) = inf, 1 / inf = 0; relu:
+// Lanes past the end of the cloud (last wave-tile only) carry the cloud's last point with the constant coefficient replaced by
+// -1e30 (scaled form: +1e30), so z = -1e30 and the activation is exactly 0 (sigmoid: 2^(+1e30) = inf, 1 / inf = 0; relu:
 // max(z, 0) = 0) -- no per-pair masking multiply.
-__device__ const float SC_BLANK_ROW[64] = {-1e30f};
+template <bool SIGMOID>
+__device__ __forceinline__ void blank_lane(bool valid, float (&a)[64]) {
+    float big;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(big) : "n"(SIGMOID ? 0x7149f2ca : 0xf149f2ca));     // +-1e30, made here (not kept live through the camera loop)
+    a[0] = valid ? a[0] : big;
+}
+
+// The 64 x 64 coefficients of a wave-tile -> one row per lane.  A lane reading its own 256-byte row with sixteen 16-byte loads
+// makes every load instruction of the wave touch 64 different cache lines (1024 line requests for 128 lines; the L1 of the CU,
+// shared by 24 such waves, cannot hold them between instructions): the fixed part of a launch was 10 us of 53.  Here four
+// neighbouring lanes read one 64-byte piece of a row (16 lines per instruction, each line in two instructions), the 16 loads are
+// all in flight together, and the tile is turned by quarters through a 5 KB strip of LDS that only this wave touches (DS
+// operations of one wave execute in order: no barrier; rows padded to 80 bytes).  Rows past the end of the cloud repeat its last row.
+struct ScStage { float4 q[MCR_WAVE][5]; };
+__device__ __forceinline__ void load_tile_rows(const float* __restrict__ harm_b, int row0, int N, int lane, ScStage& st,
+                                               float (&a)[64]) {
+    asm volatile("" : "+v"(lane));      // addresses derived from the lane index are rebuilt per tile, not kept live through the camera loop
+    const int chunk = lane & 3, rsub = lane >> 2;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 v[4][4];                                             // [column quarter][row group]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // uniform base + 32-bit byte offset (the scalar-base addressing form: one address register per row group)
+        const float* src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(harm_b) +
+                                                          (unsigned)(min(row0 + 16 * i + rsub, N - 1) * 256 + 16 * chunk));
+#pragma unroll
+        for (int p = 0; p < 4; ++p) v[p][i] = *reinterpret_cast<const f32x4*>(src + 16 * p);
+    }
+    // In place: the four row groups of a quarter go out and the lane's own row comes back into the SAME registers (written as
+    // one asm block with tied operands; left to the register allocator the turn needed 101 VGPRs and cost two resident waves).
+    const unsigned wa = (unsigned)(size_t)&st.q[rsub][chunk], ra = (unsigned)(size_t)&st.q[lane][0];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        asm volatile("ds_write_b128 %4, %0\n\t"
+                     "ds_write_b128 %4, %1 offset:%c6\n\t"
+                     "ds_write_b128 %4, %2 offset:%c7\n\t"
+                     "ds_write_b128 %4, %3 offset:%c8\n\t"
+                     "ds_read_b128 %0, %5\n\t"
+                     "ds_read_b128 %1, %5 offset:16\n\t"
+                     "ds_read_b128 %2, %5 offset:32\n\t"
+                     "ds_read_b128 %3, %5 offset:48\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[p][0]), "+v"(v[p][1]), "+v"(v[p][2]), "+v"(v[p][3])
+                     : "v"(wa), "v"(ra), "n"(16 * 80), "n"(32 * 80), "n"(48 * 80)
+                     : "memory");
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            a[16 * p + 4 * c + 0] = v[p][c].x; a[16 * p + 4 * c + 1] = v[p][c].y;
+            a[16 * p + 4 * c + 2] = v[p][c].z; a[16 * p + 4 * c + 3] = v[p][c].w;
+        }
+    }
+    // plain 32-bit values from here on: with the coefficients still tied to their 128-bit tuples the instruction scheduler
+    // orders the camera loop differently (same instructions), 7 % slower per camera
+#pragma unroll
+    for (int k = 0; k < 64; ++k) asm volatile("" : "+v"(a[k]));
+}
 
 // ---- work decomposition (both kernels) ----------------------------------------------------------------------
 // A "wave-unit" is (wave-tile of 64 points, camera).  The U = B * ceil(N/64) * C units are split into W equal
@@ -136,26 +185,34 @@ __global__ __launch_bounds__(SC_BLOCK) void sh_gain_kernel(const float* __restri
                                                            const float* __restrict__ harm,
                                                            const float* __restrict__ cams, float* __restrict__ partial,
                                                            int N, int C, int n_wtiles, long long U, int W) {
+    __shared__ ScStage s_stage[SC_BLOCK / MCR_WAVE];
     const int lane = threadIdx.x & (MCR_WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(xcd_major_block(blockIdx.x, gridDim.x) * (SC_BLOCK / MCR_WAVE) + threadIdx.x / MCR_WAVE);
     if (w >= W) return;
-    long long u = (U * w) / W;
-    const long long u_end = (U * (w + 1)) / W;
-    while (u < u_end) {
-        const long long bt = u / C;                          // flattened (cloud, wave-tile)
-        const int c_begin = (int)(u - bt * C);
-        const int c_end = (int)min((long long)C, (long long)c_begin + (u_end - u));
-        const int b = (int)(bt / n_wtiles);
-        const int wt = (int)(bt - (long long)b * n_wtiles);
-        u += c_end - c_begin;
+    // The wave's range of units -> (cloud b, wave-tile wt, first camera, units left): divided ONCE, then walked (the quotients of a
+    // per-segment division, and the reciprocal seeds of its expansion, stayed in vector registers through the camera loop).
+    int b, wt, c_begin, left;
+    {
+        const long long u = (U * w) / W, bt = u / C;
+        b = __builtin_amdgcn_readfirstlane((int)(bt / n_wtiles));
+        wt = __builtin_amdgcn_readfirstlane((int)(bt - (long long)(bt / n_wtiles) * n_wtiles));
+        c_begin = __builtin_amdgcn_readfirstlane((int)(u - bt * C));
+        left = __builtin_amdgcn_readfirstlane((int)((U * (w + 1)) / W - u));
+    }
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / MCR_WAVE);
+    for (; left > 0; c_begin = 0, b += (wt + 1 == n_wtiles), wt = (wt + 1 == n_wtiles ? 0 : wt + 1)) {
+        const int c_end = min(C, c_begin + left);
+        left -= c_end - c_begin;
         const int n = wt * MCR_WAVE + lane;
         const bool valid = n < N;
         const size_t pn = (size_t)b * N + (valid ? n : N - 1);
-        const float px = pts[pn * pts_stride + 0];
+        float hs[64];
+        load_tile_rows(harm + (size_t)b * N * 64, wt * MCR_WAVE, N, lane, s_stage[wave_in_block], hs);
+        const float px = pts[pn * pts_stride + 0];            // after the tile: its 64 landing registers are the peak
         const float py = pts[pn * pts_stride + 1];
         const float pz = pts[pn * pts_stride + 2];
-        float hs[64];
-        load_mono_coeffs<SIGMOID>(valid ? harm + pn * 64 : SC_BLANK_ROW, hs);
+        to_mono_coeffs<SIGMOID>(hs);
+        blank_lane<SIGMOID>(valid, hs);
         const float* cam_b = cams + (size_t)b * C * 3;
         float* part_col = partial + (size_t)b * C * n_wtiles + wt;   // partial[b][:][wt]  (camera-major: the reduce reads rows)
         // Cameras are walked SC_R at a time: the SC_R dot products run one after the other (one camera's registers), the SC_R
@@ -215,26 +272,33 @@ __global__ __launch_bounds__(SC_BLOCK) void sh_vis_kernel(const float* __restric
                                                           const float* __restrict__ harm,
                                                           const float* __restrict__ cams, float* __restrict__ out,
                                                           int N, int C, int n_wtiles, long long U, int W) {
+    __shared__ ScStage s_stage[SC_BLOCK / MCR_WAVE];
     const int lane = threadIdx.x & (MCR_WAVE - 1);
     const int w = __builtin_amdgcn_readfirstlane(xcd_major_block(blockIdx.x, gridDim.x) * (SC_BLOCK / MCR_WAVE) + threadIdx.x / MCR_WAVE);
     if (w >= W) return;
-    long long u = (U * w) / W;
-    const long long u_end = (U * (w + 1)) / W;
-    while (u < u_end) {
-        const long long bt = u / C;                          // flattened (cloud, wave-tile)
-        const int c_begin = (int)(u - bt * C);
-        const int c_end = (int)min((long long)C, (long long)c_begin + (u_end - u));
-        const int b = (int)(bt / n_wtiles);
-        const int wt = (int)(bt - (long long)b * n_wtiles);
-        u += c_end - c_begin;
+    // The wave's range of units -> (cloud b, wave-tile wt, first camera, units left): divided ONCE, then walked (the quotients of a
+    // per-segment division, and the reciprocal seeds of its expansion, stayed in vector registers through the camera loop).
+    int b, wt, c_begin, left;
+    {
+        const long long u = (U * w) / W, bt = u / C;
+        b = __builtin_amdgcn_readfirstlane((int)(bt / n_wtiles));
+        wt = __builtin_amdgcn_readfirstlane((int)(bt - (long long)(bt / n_wtiles) * n_wtiles));
+        c_begin = __builtin_amdgcn_readfirstlane((int)(u - bt * C));
+        left = __builtin_amdgcn_readfirstlane((int)((U * (w + 1)) / W - u));
+    }
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / MCR_WAVE);
+    for (; left > 0; c_begin = 0, b += (wt + 1 == n_wtiles), wt = (wt + 1 == n_wtiles ? 0 : wt + 1)) {
+        const int c_end = min(C, c_begin + left);
+        left -= c_end - c_begin;
         const int n = wt * MCR_WAVE + lane;
         const bool valid = n < N;
         const size_t pn = (size_t)b * N + (valid ? n : N - 1);
+        float hs[64];
+        load_tile_rows(harm + (size_t)b * N * 64, wt * MCR_WAVE, N, lane, s_stage[wave_in_block], hs);
         const float px = pts[pn * pts_stride + 0];
         const float py = pts[pn * pts_stride + 1];
         const float pz = pts[pn * pts_stride + 2];
-        float hs[64];
-        load_mono_coeffs<SIGMOID>(harm + pn * 64, hs);
+        to_mono_coeffs<SIGMOID>(hs);
         const float* cam_b = cams + (size_t)b * C * 3;
         for (int ci = c_begin; ci < c_end; ++ci) {
             const float z = sh_dot(cam_b[3 * ci + 0] - px, cam_b[3 * ci + 1] - py, cam_b[3 * ci + 2] - pz, hs);
@@ -289,6 +353,7 @@ static int sh_gain_impl(const char* who, bool reduce, const float* pts, int pts_
     const int n_wtiles = (int)cdiv(N, MCR_WAVE);
     const long long U = (long long)B * n_wtiles * C;
     const int W = (int)std::min<long long>(U, resident);
+    MCR_REQUIRE(U / W < (1ll << 30), "%s: problem too large", who);          // a wave's unit count is an int
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)cdiv(W, SC_BLOCK / MCR_WAVE));
     float* partial = (float*)workspace;
@@ -332,6 +397,7 @@ int mcr_sh_visibilities(const float* pts, int pts_dim, const float* harmonics, c
     const int n_wtiles = (int)cdiv(N, MCR_WAVE);
     const long long U = (long long)B * n_wtiles * C;
     const int W = (int)std::min<long long>(U, resident);
+    MCR_REQUIRE(U / W < (1ll << 30), "mcr_sh_visibilities: problem too large");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)cdiv(W, SC_BLOCK / MCR_WAVE));
     if (use_sigmoid)
