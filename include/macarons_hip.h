@@ -137,6 +137,18 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
                           const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* mcr_scone_occ_forward in two calls on one stream and one workspace (phase 0 = the single call).
+ *   phase 1: what needs neither view_harmonics nor a hidden draw -- the query order of the grid search and scale 0 (the whole
+ *            cloud: k-NN + local transformer).  Reads x, pc_scale[0], M_scale[0..2]; pc_global, pc_scale[1..2], view_harmonics and
+ *            out may be NULL.  It is the first long kernel of an NBV step (testers/shapenet.py:126-144): queued before the host builds
+ *            the view state, the harmonics and the down-sampled clouds, it hides their launch latency.
+ *   phase 2: the rest (global transformer, scales 1 and 2, x embedding, head) -> out; same arguments as the single call. */
+int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float* const* pc_scale, const int64_t* M_scale,
+                                const float* x, const float* view_harmonics, float* out, int64_t B, int64_t Q,
+                                const float* const* weights, int n_weights, const float* const* local_blobs,
+                                const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
+                                size_t workspace_bytes, int phase, void* stream);
+
 /* Ragged SconeOcc: J independent SconeOcc.forward calls ("jobs" = one surface cloud + one chunk of queries, all of different
  * sizes: the per-cell passes of compute_scene_occupancy_probability_field, macarons/utility/macarons_utils.py:1395-1540, which
  * upstream runs one after the other from a Python loop over the grid cells) in ONE launch sequence.
@@ -251,6 +263,13 @@ int mcr_gather_columns(const float* in, const int* idx, float* out, int64_t rows
 int mcr_filter_proxy_points(const float* X, int64_t P, const float* pc, int64_t M, const float* proj, int n_view, float filter_tol,
                             float* bounds, unsigned char* mask, void* stream);
 int mcr_coverage_gain_multiple(const float* vis, float* gains, int64_t B, int64_t C, int64_t N, int n_cam, void* stream);
+
+/* The end of a single-rank NBV decision in one launch: gains [B,C] (in/out) -> max_gain [B], nbv_idx [B] (int64), torch.max over
+ * the cameras (testers/shapenet.py:172: first maximum, NaN wins); a cloud with n_unique[b] < 1 (nothing sampled: the reference
+ * fails there, scone_utils.py:1052-1061) gets NaN gains, a NaN maximum and index -1.  n_unique / range_flag may be NULL.
+ * record: 1 + 2 B doubles = (*range_flag or 0, nbv_idx[0..B), max_gain[0..B)) -- the one buffer a caller reads back. */
+int mcr_nbv_decide(float* gains, int64_t B, int64_t C, const int* n_unique, const int* range_flag, float* max_gain, int64_t* nbv_idx,
+                   double* record, void* stream);
 
 /* Arg-max exchange of the camera-sharded decision (the reference takes torch.max over all cameras on one GPU,
  * macarons/testers/shapenet.py:172; ties -> first = lowest camera index):

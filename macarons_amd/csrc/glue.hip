@@ -647,6 +647,41 @@ __global__ __launch_bounds__(64) void best_record_kernel(const float* __restrict
     }
 }
 
+// The end of a single-rank NBV decision in one launch (testers/shapenet.py:172 + the empty-sample rule of nbv.py): per cloud b, a
+// cloud nothing was sampled from (n_unique[b] < 1) gets NaN gains, a NaN maximum and index -1; otherwise torch.max over its cameras.
+// record = (range flag, idx[0..B), max[0..B)) as doubles: the ONE buffer the host reads back at the end of the decision.
+__global__ __launch_bounds__(64) void nbv_decide_kernel(float* __restrict__ gains, int C, const int* __restrict__ n_unique,
+                                                        const int* __restrict__ range_flag, float* __restrict__ max_gain,
+                                                        long long* __restrict__ nbv_idx, double* __restrict__ record, int B) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float* g = gains + (size_t)b * C;
+    const bool empty = n_unique && n_unique[b] < 1;
+    float bv, bi;
+    if (empty) {
+        for (int c = lane; c < C; c += 64) g[c] = __builtin_nanf("");
+        bv = __builtin_nanf(""); bi = -1.f;
+    } else {
+        bv = lane < C ? g[lane] : -__builtin_inff();
+        bi = lane < C ? (float)lane : 3.0e38f;
+        for (int c = lane + 64; c < C; c += 64) {
+            const float v = g[c];
+            if (best_before(v, (float)c, bv, bi)) { bv = v; bi = (float)c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64), oi = __shfl_xor(bi, o, 64);
+            if (best_before(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+    }
+    if (lane == 0) {
+        max_gain[b] = bv;
+        nbv_idx[b] = (long long)bi;
+        record[1 + b] = (double)bi;
+        record[1 + B + b] = (double)bv;
+        if (b == 0) record[0] = range_flag ? (double)*range_flag : 0.0;
+    }
+}
+
 // recs [world, B, 2] -> (vals[b], idx[b]) of the global arg-max; ties -> lowest camera index.  A rank with an empty camera shard
 // contributes (-inf, 3e38): it never wins against a rank that scored anything.
 __global__ __launch_bounds__(64) void best_merge_kernel(const float* __restrict__ recs, int world, int B, float* __restrict__ vals,
@@ -879,6 +914,16 @@ int mcr_best_record(const float* gains, int64_t B, int64_t C, int64_t idx_offset
     hipLaunchKernelGGL(best_record_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, gains, (int)C, (long long)idx_offset,
                        records);
     MCR_LAUNCH_CHECK("best_record_kernel");
+    return 0;
+}
+
+int mcr_nbv_decide(float* gains, int64_t B, int64_t C, const int* n_unique, const int* range_flag, float* max_gain, int64_t* nbv_idx,
+                   double* record, void* stream) {
+    MCR_REQUIRE(gains && max_gain && nbv_idx && record && B > 0 && C > 0, "mcr_nbv_decide: bad arguments");
+    MCR_REQUIRE(C <= (1ll << 24) && B <= 65535, "mcr_nbv_decide: camera indices must stay below 2^24");
+    hipLaunchKernelGGL(nbv_decide_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, gains, (int)C, n_unique, range_flag, max_gain,
+                       reinterpret_cast<long long*>(nbv_idx), record, (int)B);
+    MCR_LAUNCH_CHECK("nbv_decide_kernel");
     return 0;
 }
 

@@ -1066,14 +1066,15 @@ size_t knn_grid_cloud_bytes(int64_t B, int64_t M) {
     return kg_al(B * sizeof(KgCloud)) + kg_al(B * Mpad * 16) + kg_al(B * (Mpad / 32) * 32);
 }
 // qperm [B][Q] (device, inside ws): the queries of every cloud in the order the grid kernel walks them
-const int* knn_grid_order_queries(hipStream_t s, const float* X, int64_t B, int64_t Q, void* ws, void* park_ws) {
-    if (park_ws) (void)hipMemsetAsync(park_ws, 0, 256, s);         // the parked-group counters of the launches that will use this order
+const int* knn_grid_order_queries(hipStream_t s, const float* X, int64_t B, int64_t Q, void* ws, void* park_ws, bool launch) {
+    if (park_ws && launch) (void)hipMemsetAsync(park_ws, 0, 256, s);         // the parked-group counters of the launches that will use this order
     char* w = (char*)ws;
     int* qbox = (int*)w; w += kg_al(B * 8 * 4);
     int* hist = (int*)w; w += kg_al((size_t)B * KG_QCELLS * 4);
     int* code = (int*)w; w += kg_al((size_t)B * Q * 4);
     int* rank = (int*)w; w += kg_al((size_t)B * Q * 4);
     int* qperm = (int*)w;
+    if (!launch) return qperm;                                       // an earlier call on this workspace built it (phase 2 of a split forward)
     hipLaunchKernelGGL(kg_qinit_kernel, dim3(KG_QCELLS / 1024, (unsigned)B), dim3(1024), 0, s, hist, qbox);
     hipLaunchKernelGGL(kg_qbbox_kernel, dim3((unsigned)std::min<int64_t>(cdiv(Q, 1024), 64), (unsigned)B), dim3(256), 0, s, X, (int)Q, qbox);
     hipLaunchKernelGGL(kg_qcell_kernel, dim3((unsigned)cdiv(Q, 256), (unsigned)B), dim3(256), 0, s, X, (int)Q, qbox, hist, code, rank);

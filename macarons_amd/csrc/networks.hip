@@ -415,19 +415,42 @@ static OccSide* occ_side(hipStream_t caller) {
     return &x;
 }
 
+int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float* const* pc_scale, const int64_t* M_scale,
+                                const float* x, const float* view_harmonics, float* out, int64_t B, int64_t Q,
+                                const float* const* weights, int n_weights, const float* const* local_blobs,
+                                const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
+                                size_t workspace_bytes, int phase, void* stream);
 int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const* pc_scale, const int64_t* M_scale,
                           const float* x, const float* view_harmonics, float* out, int64_t B, int64_t Q,
                           const float* const* weights, int n_weights, const float* const* local_blobs,
                           const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
                           size_t workspace_bytes, void* stream) {
-    MCR_REQUIRE(pc_global && pc_scale && M_scale && x && view_harmonics && out && weights, "mcr_scone_occ_forward: null pointer");
+    return mcr_scone_occ_forward_phase(pc_global, Lg, pc_scale, M_scale, x, view_harmonics, out, B, Q, weights, n_weights, local_blobs,
+                                       head_planes, head_inv_scales, range_flag, workspace, workspace_bytes, 0, stream);
+}
+
+// The same in two calls on one stream and ONE workspace.  Phase 1 = what needs neither the view harmonics nor any hidden draw: the
+// query order of the grid search, scale 0 (the whole cloud: search + local transformer) -- it reads x, pc_scale[0] and M_scale[0..2]
+// only (the sizes of the down-sampled clouds are known before they are drawn) and is the first long kernel of an NBV step, so a
+// caller queues it BEFORE it builds the view state, the harmonics and the down-sampled clouds: the host work of those hides behind
+// it instead of leaving the GPU idle at the start of the step.  Phase 2 = the rest (global transformer, scales 1 and 2, x
+// embedding, head).  phase 0 = both, in the single-call order.
+int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float* const* pc_scale, const int64_t* M_scale,
+                                const float* x, const float* view_harmonics, float* out, int64_t B, int64_t Q,
+                                const float* const* weights, int n_weights, const float* const* local_blobs,
+                                const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
+                                size_t workspace_bytes, int phase, void* stream) {
+    MCR_REQUIRE(phase >= 0 && phase <= 2, "mcr_scone_occ_forward: phase must be 0, 1 or 2");
+    const bool early = phase != 2, late = phase != 1;
+    MCR_REQUIRE(pc_scale && M_scale && x && weights && (!late || (pc_global && view_harmonics && out)), "mcr_scone_occ_forward: null pointer");
     MCR_REQUIRE(!head_planes || head_inv_scales, "mcr_scone_occ_forward: head_planes need head_inv_scales");
     MCR_REQUIRE(n_weights == OCC_NW, "mcr_scone_occ_forward: expected %d weight pointers, got %d", OCC_NW, n_weights);
     MCR_REQUIRE(B > 0 && Q > 0 && Lg > 0 && B <= 65535, "mcr_scone_occ_forward: bad problem size");
     MCR_REQUIRE(workspace && workspace_bytes >= mcr_scone_occ_workspace_bytes(B, Q, Lg), "mcr_scone_occ_forward: workspace too small");
     for (int i = 0; i < n_weights; ++i) MCR_REQUIRE(weights[i], "mcr_scone_occ_forward: weight %d is null", i);
     for (int i = 0; i < 3; ++i)
-        MCR_REQUIRE(pc_scale[i] && M_scale[i] >= 16, "mcr_scone_occ_forward: scale %d has %ld points (< k = 16)", i, (long)M_scale[i]);
+        MCR_REQUIRE((pc_scale[i] || (!late && i > 0)) && M_scale[i] >= 16, "mcr_scone_occ_forward: scale %d has %ld points (< k = 16)", i,
+                    (long)M_scale[i]);
     hipStream_t s = (hipStream_t)stream;
     const float* const* p = weights;
     const PctW wg = read_pct(p);
@@ -455,7 +478,7 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     Arena scratch{(char*)workspace + head.off + glob_bytes, workspace_bytes - head.off - glob_bytes, 0};
 
     // ---- global feature (SconeOcc.py:269-277), on the side stream ----
-    OccSide* side = occ_side(s);
+    OccSide* side = late ? occ_side(s) : nullptr;
     hipStream_t gs = s;
     if (side && hipEventRecord(side->fork, s) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess) gs = side->s;
     else side = nullptr;
@@ -486,7 +509,7 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
     static const bool x_side_on = []() { const char* e = getenv("MCR_OCC_X_SIDE"); return !(e && e[0] == '0'); }();
     const bool x_on_side = planes && side && x_side_on;
     const HeadScratch head_scratch{featP, reinterpret_cast<_Float16*>(h1), h2, wplanes};
-    {
+    if (late) {
         run_pct(gs, wg, pc_global, gfeat, 512, B, (int)Lg, 256, garena);
         MCR_REQUIRE(garena.ok(), "mcr_scone_occ_forward: workspace overflow (global)");
         // its contribution to linear1: gbias[b, n] = sum_k gfeat[b, k] * W1[n, k]  (columns 0..511 of linear1.weight)
@@ -511,12 +534,19 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
                 knn_slot[sc] = n_grid++;
             }
         if (n_grid) {
-            knn_qperm = knn_grid_order_queries(s, x, B, Q, knn_q_ws, knn_park_ws);
-            knn_grid_build_clouds(s, n_grid, g_pc, g_M, B, g_ws, knn_clouds);
+            // the query order belongs to phase 1 (phase 2 finds it where phase 1 left it); every scale's cloud is built in the
+            // phase that searches it -- all of them in one launch on the single call
+            knn_qperm = knn_grid_order_queries(s, x, B, Q, knn_q_ws, knn_park_ws, /*launch=*/early);
+            if (phase == 0) knn_grid_build_clouds(s, n_grid, g_pc, g_M, B, g_ws, knn_clouds);
+            else {
+                const int first = early ? 0 : (knn_slot[0] >= 0 ? 1 : 0), count = early ? (knn_slot[0] >= 0 ? 1 : 0) : n_grid - first;
+                knn_grid_build_clouds(s, count, g_pc + first, g_M + first, B, g_ws + first, knn_clouds + first);
+            }
             MCR_LAUNCH_CHECK("knn grid preparation");
         }
     }
     for (int sc = 0; sc < 3; ++sc) {
+        if (sc == 0 ? !early : !late) continue;
         const bool grid_knn = knn_slot[sc] >= 0;
         const KnnGridCloud knn_cloud = grid_knn ? knn_clouds[knn_slot[sc]] : KnnGridCloud{};
         for (int64_t q0 = 0; q0 < Q; q0 += qc) {
@@ -544,8 +574,10 @@ int mcr_scone_occ_forward(const float* pc_global, int64_t Lg, const float* const
             }
         }
     }
-    // the large layers run on the split-precision matrix path of the selected variant (6: fp16 x 3 with the weights split once per
-    // call into `wplanes`; otherwise launch_linear's own routing: bf16 x 6 / exact fp32 MFMA)
+    if (!late) {
+        MCR_LAUNCH_CHECK("mcr_scone_occ_forward (phase 1)");
+        return 0;
+    }
     // The large layers run on the matrix path of the selected variant -- 6: fp16 x 3 with the weights split once per call into
     // `wplanes`; 5: bf16 x 6 (exact hi/mid/lo); 1: exact fp32 MFMA -- chosen by the variant and the layer alone, never by the
     // number of rows: a query's occupancy must not depend on how many other queries share the launch (query shards of the

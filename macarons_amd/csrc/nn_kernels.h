@@ -95,7 +95,7 @@ bool knn_grid_applicable(int64_t M, int k);
 size_t knn_grid_query_bytes(int64_t B, int64_t Q);
 size_t knn_grid_cloud_bytes(int64_t B, int64_t M);
 size_t knn_grid_park_bytes();
-const int* knn_grid_order_queries(hipStream_t s, const float* X, int64_t B, int64_t Q, void* ws, void* park_ws);
+const int* knn_grid_order_queries(hipStream_t s, const float* X, int64_t B, int64_t Q, void* ws, void* park_ws, bool launch = true);
 KnnGridCloud knn_grid_build_cloud(hipStream_t s, const float* pc, int64_t B, int64_t M, void* ws);
 void knn_grid_build_clouds(hipStream_t s, int n, const float* const* pc, const int64_t* M, int64_t B, void* const* ws, KnnGridCloud* out);
 void launch_knn16_grid(hipStream_t s, const float* X, const float* pc, int64_t M, const int* qperm, const KnnGridCloud& c, int64_t b_first,

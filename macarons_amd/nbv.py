@@ -25,6 +25,32 @@ class ViewStateGrid:
         self.base_harmonics, self.h_polar, self.h_azim = su.get_all_harmonics_under_degree(degree, n_elev, n_azim, device)
 
 
+_side_streams = {}
+
+
+def _harmonics_beside(scone_occ, pc, Xl, harmonics_of):
+    """(handle of scone_occ.forward_begin(pc, Xl), harmonics_of(Xl)).  The first long kernel of a decision (neighbour search + local
+    transformer over the whole cloud) needs neither the harmonics nor the down-sampled clouds: it is queued first, so that the host
+    work of everything after it hides behind it, and the view-state / harmonics kernels run on a side stream beside it instead of
+    in front of the rest.  Falls back to the plain order when the split forward does not apply."""
+    dev = Xl.device
+    main = torch.cuda.current_stream(dev)
+    fork = torch.cuda.Event()
+    fork.record(main)                                   # the inputs are ready here; what is queued next need not be waited for
+    begun = scone_occ.forward_begin(pc, Xl)
+    if begun is None or os.environ.get("MCR_NBV_SIDE") == "0":      # (A/B only: harmonics on the caller's stream after phase 1)
+        return begun, harmonics_of(Xl)
+    side = _side_streams.get((dev.index, main.cuda_stream))
+    if side is None:
+        side = _side_streams[(dev.index, main.cuda_stream)] = torch.cuda.Stream(device=dev)
+    side.wait_event(fork)
+    with torch.cuda.stream(side):
+        vh = harmonics_of(Xl)
+    main.wait_stream(side)
+    vh.record_stream(main)
+    return begun, vh
+
+
 def _guarded(impl, scone_occ, range_guard, group, draws):
     """Run one decision with SconeOcc's range check deferred to the END of the step (the step itself stays free of host
     synchronisation); if the flag comes back set (an activation left the fp16 range of the default matrix path, SconeOcc.range_guard)
@@ -48,8 +74,11 @@ def _guarded(impl, scone_occ, range_guard, group, draws):
                 flag = mdist.all_reduce_max(flag, group)
             # the one read-back, after the last kernel of the decision was queued; the decision itself rides along (a caller that
             # wants the camera index on the host reads out["host"]["nbv_idx"] instead of paying a second device->host round trip)
-            both = torch.cat((flag.to(out["nbv_idx"].device).view(-1).to(torch.float64), out["nbv_idx"].view(-1).to(torch.float64),
-                              out["max_gain"].view(-1).to(torch.float64))).cpu()
+            if world == 1 and "record" in out:       # written by the decision's last kernel (mcr_nbv_decide): nothing to assemble
+                both = out["record"].cpu()
+            else:
+                both = torch.cat((flag.to(out["nbv_idx"].device).view(-1).to(torch.float64), out["nbv_idx"].view(-1).to(torch.float64),
+                                  out["max_gain"].view(-1).to(torch.float64))).cpu()
             n_dec = out["nbv_idx"].numel()
             out["host"] = {"nbv_idx": both[1:1 + n_dec].to(torch.int64), "max_gain": both[1 + n_dec:].to(torch.float32)}
             if int(both[0]):
@@ -135,11 +164,12 @@ def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, mi
             if draw_u:
                 samples = got_u
         if q1 > q0:
-            view_state = su.compute_view_state(Xl, X_view, grid.n_elev, grid.n_azim)
-            vh_l = su.compute_view_harmonics(view_state, grid.base_harmonics, grid.h_polar, grid.h_azim, grid.n_elev, grid.n_azim)
+            harmonics_of = lambda pts: su.compute_view_harmonics(su.compute_view_state(pts, X_view, grid.n_elev, grid.n_azim),   # noqa: E731
+                                                                 grid.base_harmonics, grid.h_polar, grid.h_azim, grid.n_elev, grid.n_azim)
+            begun, vh_l = _harmonics_beside(scone_occ, pc, Xl, harmonics_of) if occ_perms is not None else (None, harmonics_of(Xl))
             # ---- occupancy (:139-144) ----
             if occ_perms is not None:
-                occ_l = scone_occ(pc, Xl, vh_l, perms=occ_perms).view(-1, 1)
+                occ_l = scone_occ(pc, Xl, vh_l, perms=occ_perms, begun=begun).view(-1, 1)
             else:
                 occ_l = su.compute_occupancy_probability(scone_occ, pc, Xl, vh_l, max_points_per_pass=max_points_per_pass).view(-1, 1)
         else:                                       # empty query shard (Q < world): no kernels, but the collectives below are joined
@@ -183,16 +213,20 @@ def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, mi
             gains = torch.zeros(1, 0, dtype=torch.float32, device=dev)
         # no proxy point above min_occ: nothing was sampled (the kernels then score one zero row): the reference fails on the empty
         # sample (scone_utils.py:1052-1061); here the decision says so on the device: gains NaN, nbv_idx -1
-        empty = n_unique.view(1, 1) < 1
-        gains = torch.where(empty, torch.full_like(gains, float("nan")), gains)
+        record = None
         if sharded:
+            empty = n_unique.view(1, 1) < 1
+            gains = torch.where(empty, torch.full_like(gains, float("nan")), gains)
             max_gain, nbv_idx = mdist.allgather_best(gains, c0, group)
-        else:
-            best = torch.max(gains, dim=1)
-            max_gain, nbv_idx = best.values, best.indices
-        nbv_idx = torch.where(empty.view(-1), torch.full_like(nbv_idx, -1), nbv_idx)
+            nbv_idx = torch.where(empty.view(-1), torch.full_like(nbv_idx, -1), nbv_idx)
+        else:                                       # the same rules + the host's read-back record in one launch (mcr_nbv_decide)
+            from . import ops
+            flag = scone_occ.range_flag() if scone_occ.range_guard != "off" else None
+            max_gain, nbv_idx, record = ops.nbv_decide(gains, n_unique.view(-1), flag)
     out = {"gains": gains[0], "cam_range": (c0, c1), "nbv_idx": nbv_idx, "max_gain": max_gain, "occ": occ,
            "n_unique": n_unique}
+    if record is not None:
+        out["record"] = record
     if return_samples:                              # the unique sampled proxy points (first n_unique of seq_len rows) and the inverse map [seq_len]
         out["proxy_points"], out["sample_idx"] = sampled
     return out
@@ -275,8 +309,8 @@ def _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=20
         # ---- view harmonics + occupancy of this rank's (clouds, queries) block ----
         if q1 > q0:
             Xl = X_b[:, q0:q1].contiguous()
-            vh_l = vs_of(Xl)
-            occ_l = scone_occ(pc_l, Xl, vh_l, perms=perms_l).view(Bl, q1 - q0)
+            begun, vh_l = _harmonics_beside(scone_occ, pc_l, Xl, vs_of)
+            occ_l = scone_occ(pc_l, Xl, vh_l, perms=perms_l, begun=begun).view(Bl, q1 - q0)
         else:
             vh_l, occ_l = None, torch.zeros(Bl, 0, dtype=torch.float32, device=dev)
         if q1 - q0 < Q:                               # query-sharded: only the occupancies travel (4 B per proxy point and cloud)
@@ -298,21 +332,24 @@ def _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=20
         cams = X_cam[b0:b1] if X_cam.dim() == 3 else X_cam[None].expand(Bl, -1, -1)
         cams = cams[:, c0:c1].contiguous()
         gains = scone_vis.compute_coverage_gain(pts_s, harm_s, cams) if c1 > c0 else torch.zeros(Bl, 0, dtype=torch.float32, device=dev)
-        gains = torch.where(nu.view(-1, 1) < 1, torch.full_like(gains, float("nan")), gains)      # nothing sampled: NaN gains, index -1
-        if by_cloud:
-            rec = mdist.allgather_rows(ops.best_record(gains, 0), B, group)
-            max_gain, nbv_idx = rec[:, 0].contiguous(), rec[:, 1].to(torch.int64)
-        elif world > 1:
-            max_gain, nbv_idx = mdist.allgather_best(gains, c0, group)
+        record = None
+        if world == 1:                                # NaN rule + arg-max + the host's read-back record in one launch (mcr_nbv_decide)
+            flag = scone_occ.range_flag() if scone_occ.range_guard != "off" else None
+            max_gain, nbv_idx, record = ops.nbv_decide(gains, nu.view(-1), flag)
         else:
-            rec = ops.best_record(gains, 0)
-            max_gain, nbv_idx = rec[:, 0].contiguous(), rec[:, 1].to(torch.int64)
-        if not by_cloud:                              # (cloud-sharded: a rank only knows its own clouds' counts; the NaN max_gain marks the others)
-            nbv_idx = torch.where(nu < 1, torch.full_like(nbv_idx, -1), nbv_idx)
-        else:
-            nbv_idx = torch.where(torch.isnan(max_gain), torch.full_like(nbv_idx, -1), nbv_idx)
+            gains = torch.where(nu.view(-1, 1) < 1, torch.full_like(gains, float("nan")), gains)  # nothing sampled: NaN gains, index -1
+            if by_cloud:
+                rec = mdist.allgather_rows(ops.best_record(gains, 0), B, group)
+                max_gain, nbv_idx = rec[:, 0].contiguous(), rec[:, 1].to(torch.int64)
+                # a rank only knows its own clouds' counts; the NaN max_gain marks the others
+                nbv_idx = torch.where(torch.isnan(max_gain), torch.full_like(nbv_idx, -1), nbv_idx)
+            else:
+                max_gain, nbv_idx = mdist.allgather_best(gains, c0, group)
+                nbv_idx = torch.where(nu < 1, torch.full_like(nbv_idx, -1), nbv_idx)
     out = {"gains": gains, "cloud_range": (b0, b1), "cam_range": (c0, c1), "max_gain": max_gain, "nbv_idx": nbv_idx,
            "occ": occ.view(Bl, Q, 1), "n_unique": nu}
+    if record is not None:
+        out["record"] = record
     if return_samples:
         out["proxy_points"], out["sample_idx"] = res, inv
     return out

@@ -7,6 +7,7 @@ Hidden RNG: SconeOcc.forward draws torch.randperm on the CPU
 explicitly through `perms=` so tests can pin them.
 """
 import numpy as np
+import os
 import torch
 from torch import nn
 
@@ -282,10 +283,42 @@ class SconeOcc(nn.Module):
                     L.mcr_set_local_pct_variant(variant)
         return res
 
-    def forward(self, pc, x, view_harmonics, mask=None, verbose=False, perms=None):
+    def scale_sizes(self, full_seq_len):
+        """Points of the three neighbourhood clouds of a forward on a cloud of full_seq_len points (SconeOcc.py:282-288, :311)."""
+        ds, sizes = self.ds_factor(full_seq_len), [full_seq_len]
+        for _ in range(self.n_scale - 1):
+            sizes.append(sizes[-1] // ds)
+        return sizes
+
+    def _images(self, variant):
+        key = param_key(self, self._key_cache)                      # one fingerprint of the parameters for every derived image
+        blobs = [c.get(t, variant, key) for c, t in zip(self._blob_caches, self.local_transformers)] if self.fused_local else None
+        head = self._head_cache.get(self, key) if variant == 6 else None
+        return self._table_cache.get(self, self.weight_table, key), blobs, head
+
+    def forward_begin(self, pc, x):
+        """Extension: queue the part of forward(pc, x, ...) that needs neither the view harmonics nor the hidden draws (the query
+        order of the neighbour search, scale 0: search + local transformer over the whole cloud) and return a handle for
+        forward(..., begun=handle), which then runs the rest.  A caller that still has host work to do before it can call forward --
+        view state, harmonics, down-sampled clouds (nbv_step) -- hides that work behind this first long kernel.  None (and nothing
+        queued) when the split does not apply (gradients wanted, non-default architecture, layer-by-layer path)."""
+        if not self._is_default_arch() or not self.fused_local or A.needs_grad(self, pc, x) or os.environ.get("MCR_OCC_BEGIN") == "0":
+            return None
+        variant = _lib.lib().mcr_get_local_pct_variant()
+        pc0, x_ = pc.contiguous(), x.contiguous()
+        sizes = self.scale_sizes(pc.shape[1])
+        if min(sizes) < self.k_for_knn:
+            return None
+        with torch.no_grad():
+            table, blobs, head = self._images(variant)
+            ops.scone_occ_forward(None, [pc0, None, None], x_, None, table, blobs, head, None, phase=1, M_scale=sizes, Lg=self.seq_len)
+        return {"pc": pc0, "x": x_, "variant": variant, "sizes": sizes, "src": (pc, x)}
+
+    def forward(self, pc, x, view_harmonics, mask=None, verbose=False, perms=None, begun=None):
         """pc [n_clouds, M, 3], x [n_clouds, Q, 3], view_harmonics [n_clouds, Q, 64] -> [n_clouds, Q, 1].
         `perms` (optional): the three index tensors draw_perms() would return, to pin the hidden RNG; each either 1-D (shared by
-        the clouds, as the reference draws them) or [n_clouds, n] (one draw per cloud)."""
+        the clouds, as the reference draws them) or [n_clouds, n] (one draw per cloud).  `begun`: the handle of forward_begin(pc, x)
+        (same tensors): only the remaining part runs."""
         if mask is not None:
             raise NotImplementedError("mask is None in every call site of the hot path")
         if not self._is_default_arch():
@@ -296,17 +329,20 @@ class SconeOcc(nn.Module):
             perms = self.draw_perms(full_seq_len)
         dev = pc.device
         pc_global = self._take(pc, perms[0])                                          # SconeOcc.py:269
-        scales = [pc.contiguous()]
+        scales = [begun["pc"] if begun is not None else pc.contiguous()]
         for p in perms[1:]:
             scales.append(self._take(scales[-1], p))                                  # :311
         L = _lib.lib()
         variant = L.mcr_get_local_pct_variant()
+        # the first part is already queued: valid only for the very tensors, numerics and cloud sizes it was queued with
+        phase = 0
+        if begun is not None and begun["src"][0] is pc and begun["src"][1] is x and begun["variant"] == variant \
+                and [s_.shape[1] for s_ in scales] == begun["sizes"] and pc_global.shape[1] == self.seq_len:
+            phase, x = 2, begun["x"]
 
-        def run(variant, pc_global, scales, x_, vh_, flag):
-            key = param_key(self, self._key_cache)                  # one fingerprint of the parameters for every derived image
-            blobs = [c.get(t, variant, key) for c, t in zip(self._blob_caches, self.local_transformers)] if self.fused_local else None
-            head = self._head_cache.get(self, key) if variant == 6 else None
-            return ops.scone_occ_forward(pc_global, scales, x_, vh_, self._table_cache.get(self, self.weight_table, key), blobs, head, flag)
+        def run(variant, pc_global, scales, x_, vh_, flag, phase=0):
+            table, blobs, head = self._images(variant)
+            return ops.scone_occ_forward(pc_global, scales, x_, vh_, table, blobs, head, flag, phase=phase)
 
         flag = None
         if variant == 6 and self.range_guard != "off":
@@ -335,7 +371,7 @@ class SconeOcc(nn.Module):
                 return A.scone_occ(self, g, sc, x_, vh_, idx)
             res = A.with_torch_backward(hip, composite, (pc, x, view_harmonics), self)
         else:
-            res = run(variant, pc_global, scales, x, view_harmonics, flag)
+            res = run(variant, pc_global, scales, x, view_harmonics, flag, phase)
             if flag is not None and self.range_guard == "sync" and int(flag):      # out of the fp16 range: the full-range path
                 L.mcr_set_local_pct_variant(5)
                 try:

@@ -186,12 +186,13 @@ def pool_max_avg(x):
 _ws_cache = {}
 
 
-def _workspace(device, nbytes):
+def _workspace(device, nbytes, tag=None):
     """One grow-only scratch arena per (device, stream): the C ABI never allocates, and two streams running workspace-using ops
     concurrently must not share scratch.  A grown arena replaces the old one; the old tensor is freed by torch's caching
-    allocator only after the work queued on its stream (record_stream)."""
+    allocator only after the work queued on its stream (record_stream).  `tag`: an arena of its own, for an op whose scratch has
+    to survive other ops on the stream (the two-phase SconeOcc forwards keep their features in it between the calls)."""
     stream = torch.cuda.current_stream(device)
-    key = (device.type, device.index, stream.cuda_stream)
+    key = (device.type, device.index, stream.cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.1) + 256, dtype=torch.uint8, device=device)
@@ -265,30 +266,44 @@ def local_pct_forward(offsets, blob):
     return out
 
 
-def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_blobs=None, head_planes=None, range_flag=None):
+def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_blobs=None, head_planes=None, range_flag=None, phase=0,
+                      M_scale=None, Lg=None, out=None):
     """head_planes: packing.HeadPlaneCache.get() triple (pre-split fp16 planes of the head matrices, variant 6) or None;
-    range_flag: int32 device tensor [1] the call ORs 1 into when an occupancy comes out non-finite (or None)."""
-    pc_global, x, view_harmonics = _req(pc_global, "pc_global"), _req(x, "x"), _req(view_harmonics, "view_harmonics")
-    pc_scales = [_req(p, "pc_scale") for p in pc_scales]
-    B, Lg, _ = pc_global.shape
-    Q = x.shape[1]
-    if len(pc_scales) != 3 or x.shape != (B, Q, 3) or view_harmonics.shape != (B, Q, 64):
-        raise ValueError("SconeOcc HIP path needs 3 scales, x [B,Q,3] and view_harmonics [B,Q,64]")
+    range_flag: int32 device tensor [1] the call ORs 1 into when an occupancy comes out non-finite (or None).
+    phase 1 / 2 (mcr_scone_occ_forward_phase): scale 0 and the query order / the rest, as two calls on the same stream.  Phase 1
+    takes pc_scales = [whole cloud, None, None] with the three sizes in M_scale and Lg, no pc_global / view_harmonics, and returns
+    None; phase 2 takes everything (and `out`, if the caller already has the buffer)."""
+    late = phase != 1
+    x = _req(x, "x")
+    B, Q = x.shape[0], x.shape[1]
+    if late:
+        pc_global, view_harmonics = _req(pc_global, "pc_global"), _req(view_harmonics, "view_harmonics")
+        pc_scales = [_req(p, "pc_scale") for p in pc_scales]
+        Lg = pc_global.shape[1]
+        M_scale = [p.shape[1] for p in pc_scales]
+        if pc_global.shape[0] != B or len(pc_scales) != 3 or x.shape != (B, Q, 3) or view_harmonics.shape != (B, Q, 64):
+            raise ValueError("SconeOcc HIP path needs 3 scales, x [B,Q,3] and view_harmonics [B,Q,64]")
+    else:
+        pc_scales = [_req(pc_scales[0], "pc_scale"), None, None]
+        if x.shape != (B, Q, 3) or M_scale is None or len(M_scale) != 3 or Lg is None or pc_scales[0].shape[1] != M_scale[0]:
+            raise ValueError("SconeOcc phase 1 needs x [B,Q,3], the whole cloud, the three scale sizes and Lg")
     L_ = lib()
-    out = torch.empty((B, Q, 1), dtype=torch.float32, device=x.device)
+    if late and out is None:
+        out = torch.empty((B, Q, 1), dtype=torch.float32, device=x.device)
     nb = L_.mcr_scone_occ_workspace_bytes(c_i64(B), c_i64(Q), c_i64(Lg))
-    ws = _workspace(x.device, nb)
+    ws = _workspace(x.device, nb, "scone_occ")
     tab = _ptr_table(weights)
-    sc_ptrs = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in pc_scales])
-    sc_m = (ctypes.c_int64 * 3)(*[p.shape[1] for p in pc_scales])
+    sc_ptrs = (ctypes.c_void_p * 3)(*[p.data_ptr() if p is not None else None for p in pc_scales])
+    sc_m = (ctypes.c_int64 * 3)(*[int(m) for m in M_scale])
     blobs = (ctypes.c_void_p * 3)(*[_req(b, "local_blob").data_ptr() for b in local_blobs]) if local_blobs else None
     with torch.cuda.device(x.device):
-        check(L_.mcr_scone_occ_forward(_p(pc_global), c_i64(Lg), sc_ptrs, sc_m, _p(x), _p(view_harmonics), _p(out), c_i64(B),
-                                       c_i64(Q), tab, c_int(_n_weights(weights)), blobs,
-                                       head_planes[1] if head_planes is not None else None,
-                                       head_planes[2] if head_planes is not None else None,
-                                       _p(_req(range_flag, "range_flag", torch.int32)) if range_flag is not None else c_vp(0),
-                                       _p(ws), c_size(ws.numel()), _stream()),
+        check(L_.mcr_scone_occ_forward_phase(_p(pc_global) if late else c_vp(0), c_i64(Lg), sc_ptrs, sc_m, _p(x),
+                                             _p(view_harmonics) if late else c_vp(0), _p(out) if late else c_vp(0), c_i64(B),
+                                             c_i64(Q), tab, c_int(_n_weights(weights)), blobs,
+                                             head_planes[1] if head_planes is not None else None,
+                                             head_planes[2] if head_planes is not None else None,
+                                             _p(_req(range_flag, "range_flag", torch.int32)) if range_flag is not None else c_vp(0),
+                                             _p(ws), c_size(ws.numel()), c_int(int(phase)), _stream()),
               "mcr_scone_occ_forward")
     return out
 
@@ -320,7 +335,7 @@ def scone_occ_forward_ragged(pc_global, global_len, pc_scales, scale_offsets, x,
     L_ = lib()
     if late and out is None:
         out = torch.empty((T, 1), dtype=torch.float32, device=x.device)
-    ws = _workspace(x.device, L_.mcr_scone_occ_ragged_workspace_bytes(c_i64(J), c_i64(T), c_i64(Lg)))
+    ws = _workspace(x.device, L_.mcr_scone_occ_ragged_workspace_bytes(c_i64(J), c_i64(T), c_i64(Lg)), "scone_occ_ragged")
     sc_ptrs = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in pc_scales])
     off_ptrs = (ctypes.c_void_p * 3)(*[o.data_ptr() for o in scale_offsets])
     blobs = (ctypes.c_void_p * 3)(*[_req(b, "local_blob").data_ptr() for b in local_blobs])
@@ -565,6 +580,23 @@ def best_record(gains, idx_offset=0, out=None):
     with torch.cuda.device(gains.device):
         check(lib().mcr_best_record(_p(gains), c_i64(B), c_i64(C), c_i64(int(idx_offset)), _p(out), _stream()), "mcr_best_record")
     return out
+
+
+def nbv_decide(gains, n_unique=None, range_flag=None):
+    """gains [B,C] (modified in place: NaN rows where n_unique < 1) -> (max_gain [B], nbv_idx [B] int64, record float64 [1 + 2B] =
+    (range flag, indices, maxima)); mcr_nbv_decide."""
+    gains = _req(gains, "gains")
+    B, C = gains.shape
+    dev = gains.device
+    max_gain = torch.empty(B, dtype=torch.float32, device=dev)
+    nbv_idx = torch.empty(B, dtype=torch.int64, device=dev)
+    record = torch.empty(1 + 2 * B, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().mcr_nbv_decide(_p(gains), c_i64(B), c_i64(C),
+                                   _p(_req(n_unique, "n_unique", torch.int32)) if n_unique is not None else c_vp(0),
+                                   _p(_req(range_flag, "range_flag", torch.int32)) if range_flag is not None else c_vp(0),
+                                   _p(max_gain), _p(nbv_idx), _p(record), _stream()), "mcr_nbv_decide")
+    return max_gain, nbv_idx, record
 
 
 def best_merge(records, out_vals=None, out_idx=None):

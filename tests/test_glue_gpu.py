@@ -301,3 +301,34 @@ def test_move_view_state_to_view_space(dev):
     idx = torch.randperm(98)
     x = torch.randn(5, 1000, 98, device=dev)
     assert torch.equal(ops.gather_columns(x, idx), x[..., idx.to(dev)])
+
+
+@pytest.mark.gpu
+def test_nbv_decide_follows_torch_max_and_the_empty_sample_rule():
+    """mcr_nbv_decide = where(n_unique < 1, NaN, gains) -> torch.max over the cameras (testers/shapenet.py:172: first maximum, a
+    NaN wins) -> index -1 for the empty clouds, plus the read-back record (range flag, indices, maxima)."""
+    from macarons_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, C = 7, 200
+    gains = torch.rand(B, C, generator=g)
+    gains[1, 17] = gains[1, 150] = 2.0                       # a tie: the first one
+    gains[2, 40] = float("nan"); gains[2, 90] = float("nan")  # NaN beats every number, the first NaN
+    gains[3] = float("-inf")                                 # still a valid index (0)
+    gains[5, 199] = 3.0                                      # the last column
+    nu = torch.tensor([5, 1, 9, 2, 0, 2048, 0], dtype=torch.int32)
+    ref = torch.where(nu.view(-1, 1) < 1, torch.full_like(gains, float("nan")), gains)
+    best = torch.max(ref, dim=1)
+    ref_idx = torch.where(nu < 1, torch.full_like(best.indices, -1), best.indices)
+    flag = torch.tensor([1], dtype=torch.int32, device=dev)
+    gd = gains.to(dev)
+    mx, idx, rec = ops.nbv_decide(gd, nu.to(dev), flag)
+    assert torch.equal(idx.cpu(), ref_idx)
+    assert torch.equal(torch.nan_to_num(mx.cpu(), nan=-7.0), torch.nan_to_num(best.values, nan=-7.0))
+    assert torch.equal(torch.nan_to_num(gd.cpu(), nan=-7.0), torch.nan_to_num(ref, nan=-7.0))          # the NaN rows, in place
+    rec = rec.cpu()
+    assert rec.dtype == torch.float64 and rec.numel() == 1 + 2 * B and rec[0] == 1.0
+    assert torch.equal(rec[1:1 + B].to(torch.int64), ref_idx)
+    assert torch.equal(torch.nan_to_num(rec[1 + B:].to(torch.float32), nan=-7.0), torch.nan_to_num(best.values, nan=-7.0))
+    mx2, idx2, rec2 = ops.nbv_decide(gains[:1].contiguous().to(dev))                                       # no counts, no flag
+    assert int(idx2) == int(torch.argmax(gains[0])) and rec2[0] == 0.0
