@@ -576,7 +576,7 @@ def main():
         step_ms = dev_ms / args.steps              # device time of one whole step (gain + reduce + decision record)
         alg_flop = N * C * FLOP_PER_PAIR
         achieved = alg_flop / (kern_ms * 1e-3) / 1e12
-        pmc = pmc_profile("r02_scorer_pmc.json") or pmc_profile("r01_scorer_pmc.json") or {}
+        pmc = pmc_profile("r03_scorer_pmc.json") or pmc_profile("r02_scorer_pmc.json") or pmc_profile("r01_scorer_pmc.json") or {}
         valu = (pmc.get("per_dispatch_mean") or {}).get("SQ_INSTS_VALU")
         roof = {"bound": "valu-fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS, "kernel": "sh_gain_kernel<true>", "device_ms_per_launch": kern_ms,
