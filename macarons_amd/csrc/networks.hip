@@ -536,11 +536,20 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
         if (n_grid) {
             // the query order belongs to phase 1 (phase 2 finds it where phase 1 left it); every scale's cloud is built in the
             // phase that searches it -- all of them in one launch on the single call
-            knn_qperm = knn_grid_order_queries(s, x, B, Q, knn_q_ws, knn_park_ws, /*launch=*/early);
-            if (phase == 0) knn_grid_build_clouds(s, n_grid, g_pc, g_M, B, g_ws, knn_clouds);
-            else {
+            if (phase == 0) {
+                knn_qperm = knn_grid_order_queries(s, x, B, Q, knn_q_ws, knn_park_ws);
+                knn_grid_build_clouds(s, n_grid, g_pc, g_M, B, g_ws, knn_clouds);
+            } else {
                 const int first = early ? 0 : (knn_slot[0] >= 0 ? 1 : 0), count = early ? (knn_slot[0] >= 0 ? 1 : 0) : n_grid - first;
-                knn_grid_build_clouds(s, count, g_pc + first, g_M + first, B, g_ws + first, knn_clouds + first);
+                // phase 1 opens the step on an idle GPU: the cloud build (one workgroup per cloud, 40 us) runs on the side stream beside
+                // the five small launches of the query order instead of after them
+                OccSide* bside = early && count > 0 ? occ_side(s) : nullptr;
+                if (bside && !(hipEventRecord(bside->fork, s) == hipSuccess && hipStreamWaitEvent(bside->s, bside->fork, 0) == hipSuccess)) bside = nullptr;
+                knn_grid_build_clouds(bside ? bside->s : s, count, g_pc + first, g_M + first, B, g_ws + first, knn_clouds + first);
+                const bool recorded = !bside || hipEventRecord(bside->join, bside->s) == hipSuccess;
+                knn_qperm = knn_grid_order_queries(s, x, B, Q, knn_q_ws, knn_park_ws, /*launch=*/early);
+                const bool joined = !bside || hipStreamWaitEvent(s, bside->join, 0) == hipSuccess;        // (waits for a stale record at worst)
+                MCR_REQUIRE(recorded && joined, "mcr_scone_occ_forward: side stream (cloud build)");
             }
             MCR_LAUNCH_CHECK("knn grid preparation");
         }

@@ -32,7 +32,8 @@ def test_golden(dev):
 
 
 @pytest.mark.parametrize("B,Q,M,k", [(1, 1, 16, 16), (2, 300, 257, 16), (1, 1000, 5000, 16), (3, 129, 64, 8),
-                                     (1, 50, 4097, 4), (2, 10, 2048, 1)])
+                                     (1, 50, 4097, 4), (2, 10, 2048, 1),
+                                     (2, 300, 126, 16), (1, 1000, 256, 16), (3, 129, 17, 16), (1, 70000, 160, 16)])   # small clouds (SconeOcc's coarsest scale)
 def test_ragged_vs_oracle(dev, B, Q, M, k):
     rng = np.random.default_rng(Q * 7 + M)
     X = rng.uniform(-.5, .5, (B, Q, 3)).astype(np.float32)
