@@ -513,3 +513,32 @@ def test_torch_ops_namespace_matches_module_path(dev):
     assert rel_err(yo.cpu().numpy(), ref.cpu().numpy()) < 2e-6        # (the module passes host-split head planes, the operator lets the kernel split)
     with pytest.raises(RuntimeError):
         torch.ops.macarons.sh_coverage_gain(pts, harm[:, :10], cams, True)           # TORCH_CHECK on a shape mismatch
+
+
+@pytest.mark.parametrize("B,M,Q", [(1, 10240, 30000), (2, 1500, 9000), (1, 300, 5000)])
+def test_scone_occ_two_call_forward_equals_the_single_call(dev, B, M, Q):
+    """forward_begin(pc, x) + forward(..., begun=handle) (mcr_scone_occ_forward_phase 1 / 2: scale 0 queued before the caller has the
+    view harmonics) returns the very bits of the single call -- with other work on the stream between the two calls, on the
+    grid-pruned and the brute-force search, and a handle is refused when it was made for other tensors."""
+    from macarons_amd.networks import SconeOcc
+    from macarons_amd import ops
+    m, _ = _mod(SconeOcc, 2, dev)
+    rng = np.random.default_rng(M + Q)
+    pc = T(rng.uniform(-.4, .4, (B, M, 3)).astype(np.float32), dev)
+    x = T(rng.uniform(-.5, .5, (B, Q, 3)).astype(np.float32), dev)
+    vh = T((rng.standard_normal((B, Q, 64)) * .3).astype(np.float32), dev)
+    torch.manual_seed(5)
+    perms = m.draw_perms(M)
+    with torch.no_grad():
+        one = m(pc, x, vh, perms=perms).clone()
+        h = m.forward_begin(pc, x)
+        assert h is not None
+        ops.knn_points(x[:, :4096].contiguous(), pc, 16)          # a workspace-using op in between must not disturb the first part
+        scratch = torch.randn(1 << 20, device=dev).sum()          # nor an allocation + kernel of torch's
+        two = m(pc, x, vh, perms=perms, begun=h)
+        assert torch.equal(one, two)
+        other = x.clone()
+        h2 = m.forward_begin(pc, other)
+        three = m(pc, x, vh, perms=perms, begun=h2)               # made for another tensor: ignored, the whole forward runs
+        assert torch.equal(one, three)
+    assert float(scratch) == float(scratch)
