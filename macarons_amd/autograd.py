@@ -106,9 +106,9 @@ def encoder(enc, x, lengths=None):
 
 
 def scone_vis(model, pts, view_harmonics, lengths=None):
+    """SconeVis.forward (SconeVis.py:121-162), default architecture."""
     if lengths is not None:                         # the kernels treat an empty cloud as its first row (max(1, length)); so does this
         lengths = lengths.clamp(min=1)
-    """SconeVis.forward (SconeVis.py:121-162), default architecture."""
     x = embedding(model.embedding, pts, lengths)
     for enc in model.encoders:
         x = encoder(enc, x, lengths)

@@ -51,8 +51,17 @@ def per_file_flags(src):
     return extra
 
 
+def _clean_unbundled(lib_path, stamp):
+    """hipcc leaves per-object unbundled images (`<lib>.N.hipv4-...`, `<lib>.N.host-...`) next to its output; they are never
+    loaded, but they would travel to the GPU box with every snapshot."""
+    for tmp in glob.glob(lib_path + ".*"):
+        if tmp != stamp:
+            os.remove(tmp)
+
+
 def build(force=False, verbose=False):
     dig = _digest()
+    _clean_unbundled(LIB_PATH, STAMP)               # also when nothing is rebuilt (left by an interrupted or manual link)
     if not force and os.path.exists(LIB_PATH) and os.path.exists(STAMP):
         with open(STAMP) as f:
             if f.read().strip() == dig:
@@ -78,9 +87,7 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
-    for tmp in glob.glob(LIB_PATH + ".*"):          # hipcc leaves its per-object unbundled images next to the output
-        if tmp != STAMP:
-            os.remove(tmp)
+    _clean_unbundled(LIB_PATH, STAMP)
     with open(STAMP, "w") as f:
         f.write(dig)
     return LIB_PATH
@@ -101,6 +108,7 @@ def build_torch_ops(force=False, verbose=False):
             h.update(f.read())
     h.update(torch.__version__.encode())
     stamp = TORCH_LIB_PATH + ".stamp"
+    _clean_unbundled(TORCH_LIB_PATH, stamp)
     if not force and os.path.exists(TORCH_LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == h.hexdigest():
         return TORCH_LIB_PATH
     cmd = [hipcc_path(), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
@@ -114,9 +122,7 @@ def build_torch_ops(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {TORCH_SRC}:\n{r.stdout.decode()}")
-    for tmp in glob.glob(TORCH_LIB_PATH + ".*"):
-        if tmp != stamp:
-            os.remove(tmp)
+    _clean_unbundled(TORCH_LIB_PATH, stamp)
     with open(stamp, "w") as f:
         f.write(h.hexdigest())
     return TORCH_LIB_PATH

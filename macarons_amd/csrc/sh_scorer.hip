@@ -344,7 +344,8 @@ static int sh_gain_impl(const char* who, bool reduce, const float* pts, int pts_
     MCR_REQUIRE(pts && harmonics && cams && (gains || !reduce), "%s: null pointer", who);
     MCR_REQUIRE(pts_dim >= 3, "%s: pts_dim must be >= 3 (got %d)", who, pts_dim);
     MCR_REQUIRE(B > 0 && N > 0 && C > 0, "%s: empty problem B=%ld N=%ld C=%ld", who, (long)B, (long)N, (long)C);
-    MCR_REQUIRE(C <= 65535 * 64 && N < (1ll << 31) && B <= 65535, "%s: problem too large", who);
+    // N <= 2^23: load_tile_rows addresses a coefficient row as a 32-bit byte offset (row * 256) from the cloud's base
+    MCR_REQUIRE(C <= 65535 * 64 && N <= (1ll << 23) && B <= 65535, "%s: problem too large (N <= 2^23 points per cloud)", who);
     MCR_REQUIRE(waves_per_simd >= 0 && waves_per_simd <= 16, "%s: waves_per_simd out of range", who);
     MCR_REQUIRE(workspace && workspace_bytes >= mcr_sh_coverage_gain_workspace_bytes(B, N, C), "%s: workspace too small", who);
     static int cache_sig = 0, cache_relu = 0;
@@ -390,7 +391,7 @@ int mcr_sh_visibilities(const float* pts, int pts_dim, const float* harmonics, c
     MCR_REQUIRE(pts && harmonics && cams && vis, "mcr_sh_visibilities: null pointer");
     MCR_REQUIRE(pts_dim >= 3, "mcr_sh_visibilities: pts_dim must be >= 3 (got %d)", pts_dim);
     MCR_REQUIRE(B > 0 && N > 0 && C > 0, "mcr_sh_visibilities: empty problem");
-    MCR_REQUIRE(C < (1 << 24) && N < (1ll << 31), "mcr_sh_visibilities: problem too large");
+    MCR_REQUIRE(C < (1 << 24) && N <= (1ll << 23), "mcr_sh_visibilities: problem too large (N <= 2^23 points per cloud)");
     static int cache_sig = 0, cache_relu = 0;
     const int resident = use_sigmoid ? resident_waves_cached(sh_vis_kernel<true>, 0, &cache_sig)
                                      : resident_waves_cached(sh_vis_kernel<false>, 0, &cache_relu);

@@ -51,7 +51,7 @@ def _harmonics_beside(scone_occ, pc, Xl, harmonics_of):
     return begun, vh
 
 
-def _guarded(impl, scone_occ, range_guard, group, draws):
+def _guarded(impl, scone_occ, range_guard, group, draws, device):
     """Run one decision with SconeOcc's range check deferred to the END of the step (the step itself stays free of host
     synchronisation); if the flag comes back set (an activation left the fp16 range of the default matrix path, SconeOcc.range_guard)
     the decision is repeated on variant 5 with the SAME hidden draws.  `draws()` pins the draws before the first attempt when
@@ -63,12 +63,14 @@ def _guarded(impl, scone_occ, range_guard, group, draws):
     guard = range_guard and prev != "off" and L.mcr_get_local_pct_variant() == 6
     scone_occ.range_guard = "defer" if (guard or prev != "off") else "off"
     try:
-        scone_occ.clear_range_flag()
+        # the flag exists on every rank before the step (not only on ranks that run a guarded forward: a rank with an empty query
+        # shard runs none), so that whether the all-reduce below is entered depends on rank-invariant state only
+        scone_occ.clear_range_flag(device if guard else None)
         kw = draws() if (guard and not capturing) else {}
         out = impl(**kw)
         flag = scone_occ.range_flag() if L.mcr_get_local_pct_variant() == 6 else None
         out["range_flag"] = flag
-        if guard and not capturing and flag is not None:
+        if guard and not capturing:
             world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
             if world > 1:
                 flag = mdist.all_reduce_max(flag, group)
@@ -121,7 +123,7 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
     inited = torch.distributed.is_available() and torch.distributed.is_initialized()
     if inited and torch.distributed.get_world_size(group) > 1:
         draws = lambda: {}                          # noqa: E731  (sharded: rank 0's draws are broadcast inside the step; a repeat redraws)
-    return _guarded(impl, scone_occ, range_guard, group, draws)
+    return _guarded(impl, scone_occ, range_guard, group, draws, X.device)
 
 
 def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1,
@@ -259,7 +261,7 @@ def nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=204
     def impl():
         return _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len, min_occ, true_monte_carlo_sampling,
                                fixed["occ_perms"], fixed["samples"], group, return_samples)
-    return _guarded(impl, scone_occ, range_guard, group, draws)
+    return _guarded(impl, scone_occ, range_guard, group, draws, X.device)
 
 
 def _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1, true_monte_carlo_sampling=True,

@@ -129,8 +129,12 @@ class SconeOcc(nn.Module):
         guarded forward)."""
         return self._range_flag
 
-    def clear_range_flag(self):
-        if self._range_flag is not None:
+    def clear_range_flag(self, device=None):
+        """Zero the flag; with `device`, create it there first if this module has not run a guarded forward on it yet (a rank whose
+        query shard is empty never runs one, yet has to bring a flag to the step's all-reduce)."""
+        if device is not None and (self._range_flag is None or self._range_flag.device != torch.device(device)):
+            self._range_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        elif self._range_flag is not None:
             self._range_flag.zero_()
 
     def freeze_weight_caches(self, on=True):
@@ -232,6 +236,7 @@ class SconeOcc(nn.Module):
 
         with torch.no_grad():
             phase1(variant)
+        epoch1 = ops.scone_occ_epoch(dev, "scone_occ_ragged")
         if perms is None:
             perms = [self.draw_perms(int(m)) for m in cloud_sizes]
         self.last_ragged_perms = perms                                 # (a caller that repeats the pass on another variant re-uses the draws)
@@ -274,7 +279,8 @@ class SconeOcc(nn.Module):
                 self._range_flag.zero_()
             flag = self._range_flag
         with torch.no_grad():
-            res = run(variant, flag, False)
+            # (phase 1's results live in the stream's arena: if anything else wrote it since -- another thread on this stream -- redo it)
+            res = run(variant, flag, ops.scone_occ_epoch(dev, "scone_occ_ragged") != epoch1)
             if flag is not None and self.range_guard == "sync" and int(flag):
                 L.mcr_set_local_pct_variant(5)
                 try:
@@ -312,7 +318,7 @@ class SconeOcc(nn.Module):
         with torch.no_grad():
             table, blobs, head = self._images(variant)
             ops.scone_occ_forward(None, [pc0, None, None], x_, None, table, blobs, head, None, phase=1, M_scale=sizes, Lg=self.seq_len)
-        return {"pc": pc0, "x": x_, "variant": variant, "sizes": sizes, "src": (pc, x)}
+        return {"pc": pc0, "x": x_, "variant": variant, "sizes": sizes, "src": (pc, x), "epoch": ops.scone_occ_epoch(pc0.device, "scone_occ")}
 
     def forward(self, pc, x, view_harmonics, mask=None, verbose=False, perms=None, begun=None):
         """pc [n_clouds, M, 3], x [n_clouds, Q, 3], view_harmonics [n_clouds, Q, 64] -> [n_clouds, Q, 1].
@@ -328,16 +334,22 @@ class SconeOcc(nn.Module):
         if perms is None:
             perms = self.draw_perms(full_seq_len)
         dev = pc.device
+        L = _lib.lib()
+        variant = L.mcr_get_local_pct_variant()
+        # A handle of forward_begin is valid only for the very tensors, numerics and cloud sizes it was queued with -- and only while
+        # nothing else has written the arena that holds its phase-1 results (ops.scone_occ_epoch).  Checked BEFORE anything of the
+        # handle is used: a stale or foreign handle is ignored and the whole forward runs on `pc` / `x`.
+        sizes = self.scale_sizes(full_seq_len)
+        if begun is not None and not (begun["src"][0] is pc and begun["src"][1] is x and begun["variant"] == variant
+                                      and begun["sizes"] == sizes and [p_.shape[-1] for p_ in perms] == [self.seq_len] + sizes[1:]
+                                      and begun["epoch"] == ops.scone_occ_epoch(dev, "scone_occ")):
+            begun = None
         pc_global = self._take(pc, perms[0])                                          # SconeOcc.py:269
         scales = [begun["pc"] if begun is not None else pc.contiguous()]
         for p in perms[1:]:
             scales.append(self._take(scales[-1], p))                                  # :311
-        L = _lib.lib()
-        variant = L.mcr_get_local_pct_variant()
-        # the first part is already queued: valid only for the very tensors, numerics and cloud sizes it was queued with
         phase = 0
-        if begun is not None and begun["src"][0] is pc and begun["src"][1] is x and begun["variant"] == variant \
-                and [s_.shape[1] for s_ in scales] == begun["sizes"] and pc_global.shape[1] == self.seq_len:
+        if begun is not None:
             phase, x = 2, begun["x"]
 
         def run(variant, pc_global, scales, x_, vh_, flag, phase=0):

@@ -201,6 +201,23 @@ def _workspace(device, nbytes, tag=None):
     return buf
 
 
+_ws_epoch = {}
+
+
+def _bump_epoch(device, tag):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream, tag)
+    _ws_epoch[key] = _ws_epoch.get(key, 0) + 1
+
+
+def scone_occ_epoch(device, tag="scone_occ"):
+    """How many SconeOcc launch sequences have written the tagged arena of the current stream of `device`.  The two-phase forwards
+    keep phase 1's results (feature planes, query order, park counters) in that arena: a handle remembers the count after its phase 1
+    and is honoured only while the count still stands (any other forward on the stream in between would have clobbered them)."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream, tag)
+    return _ws_epoch.get(key, 0)
+
+
 def _ptr_table(tensors):
     """tensors: a list of tensors, or a (tensors, ready-made ctypes pointer array) pair from networks.packing.TableCache."""
     if isinstance(tensors, tuple):
@@ -292,6 +309,7 @@ def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_bl
         out = torch.empty((B, Q, 1), dtype=torch.float32, device=x.device)
     nb = L_.mcr_scone_occ_workspace_bytes(c_i64(B), c_i64(Q), c_i64(Lg))
     ws = _workspace(x.device, nb, "scone_occ")
+    _bump_epoch(x.device, "scone_occ")
     tab = _ptr_table(weights)
     sc_ptrs = (ctypes.c_void_p * 3)(*[p.data_ptr() if p is not None else None for p in pc_scales])
     sc_m = (ctypes.c_int64 * 3)(*[int(m) for m in M_scale])
@@ -336,6 +354,7 @@ def scone_occ_forward_ragged(pc_global, global_len, pc_scales, scale_offsets, x,
     if late and out is None:
         out = torch.empty((T, 1), dtype=torch.float32, device=x.device)
     ws = _workspace(x.device, L_.mcr_scone_occ_ragged_workspace_bytes(c_i64(J), c_i64(T), c_i64(Lg)), "scone_occ_ragged")
+    _bump_epoch(x.device, "scone_occ_ragged")
     sc_ptrs = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in pc_scales])
     off_ptrs = (ctypes.c_void_p * 3)(*[o.data_ptr() for o in scale_offsets])
     blobs = (ctypes.c_void_p * 3)(*[_req(b, "local_blob").data_ptr() for b in local_blobs])

@@ -76,6 +76,14 @@ def main():
         if not bool(cond):
             fails.append(what)
 
+    # B0: the empty-shard case on a FRESH module (its range flag has never been created on rank 1, whose query shard is empty): every
+    # rank must still enter the range-flag all-reduce (a rank that skipped it hung / mis-paired the collectives)
+    occ_f = SconeOcc()
+    occ_f.load_state_dict(occ.state_dict())
+    occ_f = occ_f.to(dev).eval()
+    r = nbv_step(occ_f, *tiny[1:], occ_perms=P(g1), samples=T(g1["samples"]))
+    expect(torch.equal(r["occ"], s_tiny["occ"]) and torch.equal(r["max_gain"], s_tiny["max_gain"]) and int(r["nbv_idx"]) == 0, "B0 fresh module")
+
     # A: query- and camera-sharded single-cloud step (config-2 shape) == the 1-rank step, bit for bit; == the reference golden at 1e-4
     r = nbv_step(*a2, occ_perms=P(g2), samples=T(g2["samples"]))
     c0, c1 = r["cam_range"]

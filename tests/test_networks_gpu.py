@@ -541,4 +541,18 @@ def test_scone_occ_two_call_forward_equals_the_single_call(dev, B, M, Q):
         h2 = m.forward_begin(pc, other)
         three = m(pc, x, vh, perms=perms, begun=h2)               # made for another tensor: ignored, the whole forward runs
         assert torch.equal(one, three)
+        # a handle made for ANOTHER CLOUD: nothing of it may be used -- not its scale-0 cloud either
+        pc_other = T(rng.uniform(-.4, .4, (B, M, 3)).astype(np.float32), dev)
+        h3 = m.forward_begin(pc_other, x)
+        four = m(pc, x, vh, perms=perms, begun=h3)
+        assert torch.equal(one, four)
+        # a valid handle whose arena was overwritten by another forward on the stream in between: stale, ignored
+        h4 = m.forward_begin(pc, x)
+        m(pc_other, other[:, :Q // 2].contiguous(), vh[:, :Q // 2].contiguous(), perms=perms)
+        five = m(pc, x, vh, perms=perms, begun=h4)
+        assert torch.equal(one, five)
+        h5 = m.forward_begin(pc, x)
+        m.forward_begin(pc_other, other)                          # ... or by another phase 1
+        six = m(pc, x, vh, perms=perms, begun=h5)
+        assert torch.equal(one, six)
     assert float(scratch) == float(scratch)
