@@ -191,11 +191,7 @@ def measure_nbv_step(dev, rank, world, args):
         r = nbv_step(occ, vis, pc, X, X_view, cams, grid, occ_perms=perms, samples=u, group=group)
         int(r["host"]["nbv_idx"][0]) if "host" in r else int(r["nbv_idx"])     # the decision reaches the host (with the range flag: one read-back)
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tw = torch.tensor([dt], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
-            dt = float(tw.item())
+        dt = max_over_ranks(time.perf_counter() - t0, dev, torch.distributed if world > 1 else None)
         if it >= n_warm:
             times.append(dt)
     p50 = float(np.median(times))
@@ -276,11 +272,7 @@ def measure_nbv_batch(dev, rank, world, args):
         r = nbv_step_batch(occ, vis, pc, X, X_view, cams, grid, occ_perms=perms, samples=u, group=group)
         r["nbv_idx"].tolist()                              # the 8 decisions reach the host
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tw = torch.tensor([dt], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
-            dt = float(tw.item())
+        dt = max_over_ranks(time.perf_counter() - t0, dev, torch.distributed if world > 1 else None)
         if it >= 3:
             times.append(dt)
     p50 = float(np.median(times))
@@ -291,11 +283,14 @@ def measure_nbv_batch(dev, rank, world, args):
             "nbv_idx": r["nbv_idx"].tolist()}
 
 
-def measure_macarons_step(dev):
+def measure_macarons_step(dev, rank=0, world=1):
     """BASELINE config 5 minus the depth network: p50 latency of one MACARONS next-best-view decision
     (macarons_utils.macarons_nbv_decision = testers/scene.py:391-454) on a synthetic scene of liberty's proportions: 3 x 8 x 3
     grid, 100 000 proxy points, surface = an ellipsoid shell (capacity 1000 points per cell), 256 x 456 analytic depth maps,
-    30 neighbour cameras, seq_len 2048.  The poses cycle through three positions (the state keeps evolving as in a trajectory)."""
+    30 neighbour cameras, seq_len 2048.  The poses cycle through three positions (the state keeps evolving as in a trajectory).
+    With N ranks every rank holds a replica of the scene and the decision is sharded (query rows of the occupancy field and neighbour
+    cameras block-partitioned); the time of an iteration is the max over the ranks.  After the clock of every iteration
+    has stopped, invariants of the decision are checked at this size (nothing of this size has a golden): see `checks`."""
     from types import SimpleNamespace as NS
     from macarons_amd.networks import Macarons
     from macarons_amd.utility import macarons_utils as mu
@@ -348,22 +343,56 @@ def measure_macarons_step(dev):
                 torch.from_numpy(ne.astype(np.float32)).to(dev))
     poses = [pose([34., 10., -30.], [0., 5., 0.]), pose([-36., -8., -26.], [0., -10., 0.]), pose([30., 25., 32.], [0., 20., 0.])]
     times, info = [], None
+    group = torch.distributed.group.WORLD if world > 1 else None
+    dist = torch.distributed if world > 1 else None
+    checks = {"iterations": 0, "n_inside_grows_by_fov_count": True, "fov_subset_of_in_field": True, "stored_proxy_indices_unique": True,
+              "stored_points_inside_their_cell": True, "occupancies_finite_in_range": True, "field_rows_equal_selected_plus_out_of_field": True,
+              "next_idx_is_first_strict_max": True, "gains_finite_nonnegative": True}
     for it in range(2 + 9):
         cam, depth, dmask, recs, ne = poses[it % 3]
+        n_in_before = float(proxy.proxy_n_inside_fov.sum())
         torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
         t0 = time.perf_counter()
         with torch.no_grad():
-            r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, depth, dmask, recs, ne, dev)
+            r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, depth, dmask, recs, ne, dev, group=group)
         nxt = int(r["next_idx"])
         torch.cuda.synchronize()
+        dt = max_over_ranks(time.perf_counter() - t0, dev, dist)
         if it >= 2:
-            times.append(time.perf_counter() - t0)
-        info = {"field_points": int(r["X_world"].shape[0]), "proxy_in_fov": int(r["fov_mask"].sum()), "next_idx": nxt}
+            times.append(dt)
+        # ---- invariants at full size (outside the timed region)
+        fm = r["fov_mask"]
+        n_fov = int(fm.sum())
+        checks["iterations"] += 1
+        checks["n_inside_grows_by_fov_count"] &= float(proxy.proxy_n_inside_fov.sum()) - n_in_before == float(n_fov)
+        checks["fov_subset_of_in_field"] &= bool((proxy.out_of_field[fm] == 0).all())
+        stored = torch.cat([c.cell_features[:, 0] for c in proxy.cells.values() if c.cell_pts.shape[0] > 0]).long()
+        checks["stored_proxy_indices_unique"] &= int(torch.unique(stored).numel()) == int(stored.numel())
+        for c in proxy.cells.values():
+            if c.cell_pts.shape[0] > 0:
+                checks["stored_points_inside_their_cell"] &= bool(((c.cell_pts > c.x_min) & (c.cell_pts < c.x_max)).all()) and \
+                    bool(torch.equal(proxy.proxy_points[c.cell_features[:, 0].long()], c.cell_pts))
+        occ_p = r["occ_probs"]
+        checks["occupancies_finite_in_range"] &= bool(torch.isfinite(occ_p).all()) and float(occ_p.min()) > -0.2
+        n_sel = int(((proxy.proxy_supervision_occ > 0)[:, 0] & (proxy.out_of_field < 1)[:, 0]).sum())
+        n_oof = int((proxy.out_of_field > 0).sum())
+        checks["field_rows_equal_selected_plus_out_of_field"] &= r["X_world"].shape[0] == n_sel + n_oof == r["view_harmonics"].shape[0] == occ_p.shape[0]
+        g_all = r["gains"]
+        if world > 1:                                       # the ranks' camera shards, gathered for the check only
+            from macarons_amd import dist as mdist
+            g_all = mdist.allgather_rows(g_all.view(-1, 1), K, group).view(-1)
+        g_h = g_all.cpu().numpy()
+        checks["gains_finite_nonnegative"] &= bool(np.isfinite(g_h).all() and (g_h >= 0).all())
+        checks["next_idx_is_first_strict_max"] &= nxt == int(np.argmax(g_h)) and abs(float(r["max_gain"]) - float(g_h.max())) == 0.0
+        info = {"field_points": int(r["X_world"].shape[0]), "proxy_in_fov": n_fov, "next_idx": nxt}
     p50 = float(np.median(times))
-    return {"p50_ms": p50 * 1e3, "evals_per_s": K / p50, "iters": len(times), "last": info,
+    checks["all_hold"] = all(v for k_, v in checks.items() if k_ != "iterations")
+    return {"p50_ms": p50 * 1e3, "evals_per_s": K / p50, "iters": len(times), "last": info, "checks": checks, "scaling": "strong",
             "config": {"workload": "MACARONS decision (BASELINE config 5 minus the depth network): 100000 proxy points, 3x8x3 grid, "
                                    "30 neighbour cameras, 256x456 depth map, seq_len 2048", "cams": K, "proxy_points": P,
-                       "note": "the per-cell occupancy pass keeps upstream's host-side cell loop"}}
+                       "parallelism": f"field-row + neighbour-camera shard x{world}" if world > 1 else "1 GPU"}}
 
 
 def measure_local_pct(dev):
@@ -423,6 +452,36 @@ def measure_local_pct(dev):
                                         "frac": gemm_flops / (out[1] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}}
 
 
+def max_over_ranks(dt, dev, dist):
+    """MAX of a host float over the ranks (RCCL: a device tensor; the gloo test mode: a host tensor)."""
+    if dist is None:
+        return dt
+    tw = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    return float(tw.item())
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run on this node and hand
+    rank 0's JSON line through as the LAST line of stdout (everything else the ranks print goes to stderr)."""
+    import socket
+    import subprocess
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MCR_BENCH_CHILD="1")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = r.stdout.splitlines()
+    last_json = max((i for i, ln in enumerate(lines) if ln.startswith('{"metric"')), default=None)
+    for i, ln in enumerate(lines):
+        if i != last_json:
+            print(ln, file=sys.stderr)
+    sys.stderr.flush()
+    if last_json is not None:
+        print(lines[last_json], flush=True)
+    sys.exit(r.returncode if last_json is not None or r.returncode else 3)
+
+
 def timed_scorer_loop(step, finish, steps, warmup, dev, dist):
     """W untimed + exactly `steps` timed calls of step(), bracketed by barrier + synchronize on both sides; returns
     (wall seconds = max over ranks, device ms between HIP events on the launch stream)."""
@@ -454,11 +513,7 @@ def timed_scorer_loop(step, finish, steps, warmup, dev, dist):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        tw = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
+    wall = max_over_ranks(time.perf_counter() - t0, dev, dist)
     return wall, ev0.elapsed_time(ev1), out
 
 
@@ -480,11 +535,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)                                  # plain `python bench.py --gpus N`: become the launcher of N ranks (never returns)
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running with WORLD_SIZE", file=sys.stderr)
+    # MCR_TEST_BACKEND=gloo: every rank on cuda:0 of a one-GPU box with host-staged collectives (RCCL refuses duplicate devices) --
+    # the mode the test suite uses to run the N = 2 path end to end on one GPU; the product path is RCCL
+    backend = os.environ.get("MCR_TEST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -492,7 +551,7 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from macarons_amd import ops
     from macarons_amd import dist as mdist
@@ -501,7 +560,7 @@ def main():
     ranks_seen = 1
     if dist is not None:                                   # every rank's id through an RCCL all-gather
         ids = torch.empty(world, dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int32, device=dev))
+        mdist.all_gather_into(ids, torch.tensor([rank], dtype=torch.int32, device=dev))
         ranks_seen = int(torch.unique(ids).numel())
 
     def scorer_run(pts, harm, cams, cam_offset, steps, warmup):
@@ -562,10 +621,12 @@ def main():
     nbv_batch = measure_nbv_batch(dev, rank, world, args) if not args.no_nbv else None
     lp = measure_local_pct(dev) if (rank == 0 and not args.no_nbv) else None
     mac = None
-    if rank == 0 and not args.no_nbv:
+    if not args.no_nbv:                                     # every rank: the decision is sharded over the ranks
         try:
-            mac = measure_macarons_step(dev)
+            mac = measure_macarons_step(dev, rank, world)
         except Exception as e:                              # an extra leg: reported, never fatal for the contract line
+            if world > 1:
+                raise                                       # (a rank that left the collectives would hang the others)
             mac = {"error": repr(e)[:300]}
     if dist is not None:
         dist.barrier()

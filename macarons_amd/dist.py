@@ -188,7 +188,7 @@ class PipelinedBest:
         s["ready"].record(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(s["ready"])
-            dist.all_gather_into_tensor(s["recv"].view(-1), s["send"].view(-1), group=self.group)
+            all_gather_into(s["recv"].view(-1), s["send"].view(-1), self.group)
             self._ops.best_merge(s["recv"], out_vals=s["vals"], out_idx=s["idx"])
             s["done"].record(self.comm)
         s["used"], s["fill"] = True, 0

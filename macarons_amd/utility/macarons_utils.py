@@ -128,7 +128,7 @@ class SceneCamera:
 
 
 def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, depth, depth_mask, neighbor_records, X_neighbors,
-                          device, samples=None, return_signed_distances=False, range_guard=True):
+                          device, samples=None, return_signed_distances=False, range_guard=True, group=None):
     """One next-best-view decision of the MACARONS loop after the depth map of the current pose is known -- the body of
     testers/scene.py:391-454 (everything between the depth network and the move to the chosen pose):
       1. proxy points in the current frustum (Camera.get_points_in_fov :391), registered in the proxy grid (:394-395);
@@ -137,10 +137,19 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
       4. coverage gain of every valid neighbour pose (:434-450), all cameras in one launch sequence; first strict maximum (:452-454).
     camera: SceneCamera of the current pose (it is also the prediction camera, fov_camera_0 of :305); depth [H,W] (+ optional
     leading/trailing singleton dims), depth_mask like depth; neighbor_records [K,40], X_neighbors [K,3].
+    `group` (torch.distributed; every rank holds replicas of both scenes and calls with the same arguments): SURVEY §8e -- the query
+    rows of the occupancy field and the K neighbour cameras are block-partitioned over the ranks, the occupancies (4 B per proxy
+    point) and one 8-byte (gain, index) record per rank are all-gathered, the hidden draws (Cell.fill subsets, SconeOcc's
+    down-samples, the sampling uniforms) are rank 0's; the cheap state updates run replicated.  Bit for bit the 1-rank decision;
+    `gains` then holds this rank's cameras only (`cam_range`).
     Returns dict(next_idx (device int64: index into the neighbour list), gains [K], fov_mask [P] bool, X_world, view_harmonics,
     occ_probs).  The scene objects are updated in place like upstream.  Host synchronisations: the cell counts of the occupancy-field
     pass (cell bookkeeping on the host, as upstream), fill_cells' one, and -- range_guard=True -- the range flag of the fp16-split
     path, read once at the end (range_guard=False: the caller checks macarons.occupancy.range_flag() itself)."""
+    from .. import dist as mdist
+    import torch.distributed as tdist
+    world = tdist.get_world_size(group) if (tdist.is_available() and tdist.is_initialized()) else 1
+    rank = tdist.get_rank(group) if world > 1 else 0
     H, W = params.image_height, params.image_width
     depth2 = depth.reshape(H, W).contiguous().float()
     dmask2 = depth_mask.reshape(H, W) if depth_mask is not None else None
@@ -148,7 +157,8 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     # 1 ---- proxy points in the current field of view, registered in their grid cells with their index as feature
     fov_mask = ops.points_in_fov(proxy_scene.proxy_points, rec.view(1, 40))[0]
     fov_idx = proxy_scene.get_proxy_indices_from_mask(fov_mask)
-    proxy_scene.fill_cells(proxy_scene.proxy_points[fov_idx.view(-1)], features=fov_idx.view(-1, 1).float())   # (index, not mask: one read-back less)
+    proxy_scene.fill_cells(proxy_scene.proxy_points[fov_idx.view(-1)], features=fov_idx.view(-1, 1).float(),   # (index, not mask: one read-back less)
+                           **({"group": group} if world > 1 else {}))
     # 2 ---- carve with the depth map: signed distance, view states, supervision occupancy, out-of-field, one launch
     sgn = proxy_scene.update_from_depth(fov_mask, rec, ops.h2d(camera.X_cam, torch.float32, device), depth2, dmask2, fill=1.1 * camera.zfar,
                                         tol=params.carving_tolerance, return_signed_distances=return_signed_distances)
@@ -176,25 +186,50 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     occ_net = getattr(macarons, "occupancy", macarons)
     nrec, xn = ops.h2d(neighbor_records, torch.float32, device), ops.h2d(X_neighbors, torch.float32, device)
 
+    k0, k1 = mdist.shard_range(K, rank, world)
+    S = params.seq_len
+
     def field_and_gains(ragged_perms, smp, record):
         X_world, view_harmonics, occ_probs = compute_scene_occupancy_probability_field(params, macarons, None, surface_scene, proxy_scene,
-                                                                                       device, prediction_camera=Mv_field, ragged_perms=ragged_perms)
+                                                                                       device, prediction_camera=Mv_field, ragged_perms=ragged_perms,
+                                                                                       group=group if world > 1 else None, record=record)
+        if world > 1:                                   # the uniforms of ALL cameras are rank 0's (one torch.rand(S, 1) per camera, in order)
+            if smp is None:
+                smp = torch.stack([torch.rand(S, 1, device=device).view(-1) for _ in range(K)])
+                _, smp = mdist.broadcast_draws([], smp, 0, group)
+            elif not torch.is_tensor(smp):
+                smp = torch.stack([torch.as_tensor(x_, device=device).reshape(-1) for x_ in smp]).float()
+            smp = smp.to(device).reshape(K, S).float()
+            if record is not None:
+                record["samples_all"] = smp
+            if k1 > k0:
+                gains = predict_coverage_gain_for_cameras(vis_model, X_world, view_harmonics, occ_probs, nrec[k0:k1].contiguous(), xn[k0:k1].contiguous(),
+                                                          Mv.reshape(1, 4, 4).expand(k1 - k0, -1, -1), diag, seq_len=S,
+                                                          min_occ=params.min_occ_for_proxy_points, distance_th=float(th), samples=smp[k0:k1].contiguous(),
+                                                          smooth=smooth)
+            else:                                       # empty camera shard (K < world)
+                gains = torch.zeros(0, dtype=torch.float32, device=device)
+            return X_world, view_harmonics, occ_probs, gains
         gains = predict_coverage_gain_for_cameras(vis_model, X_world, view_harmonics, occ_probs, nrec, xn,
-                                                  Mv.reshape(1, 4, 4).expand(K, -1, -1), diag, seq_len=params.seq_len,
+                                                  Mv.reshape(1, 4, 4).expand(K, -1, -1), diag, seq_len=S,
                                                   min_occ=params.min_occ_for_proxy_points, distance_th=float(th), samples=smp,
                                                   smooth=smooth, record=record)
+        if record is not None and "samples" in record:
+            record["samples_all"] = record["samples"]
         return X_world, view_harmonics, occ_probs, gains
 
     deferred = range_guard and getattr(occ_net, "range_guard", None) == "sync" and hasattr(occ_net, "forward_ragged")
     record = {}
     if deferred:
         occ_net.range_guard = "defer"
-        occ_net.clear_range_flag()
+        occ_net.clear_range_flag(device)                # (exists on every rank before the pass: the all-reduce below is rank-invariant)
     try:
         X_world, view_harmonics, occ_probs, gains = field_and_gains(None, samples, record)
         fallback = None
         if deferred:
             flag = occ_net.range_flag()
+            if world > 1:
+                flag = mdist.all_reduce_max(flag, group)                # every rank repeats, or none
             if flag is not None and int(flag):      # the one read-back; out of the fp16 range: repeat on the full-range variant
                 from .. import _lib
                 import ctypes
@@ -202,8 +237,7 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
                 v0 = L.mcr_get_local_pct_variant()
                 L.mcr_set_local_pct_variant(ctypes.c_int(5))
                 try:
-                    X_world, view_harmonics, occ_probs, gains = field_and_gains(getattr(occ_net, "last_ragged_perms", None),
-                                                                                record.get("samples"), None)
+                    X_world, view_harmonics, occ_probs, gains = field_and_gains(record.get("ragged_perms"), record.get("samples_all"), None)
                 finally:
                     L.mcr_set_local_pct_variant(ctypes.c_int(v0))
                 occ_net.clear_range_flag()
@@ -212,9 +246,13 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
         if deferred:
             occ_net.range_guard = "sync"
     # `if coverage_gain > max_coverage_gain` from -1: the first strict maximum (a NaN gain never wins upstream; here it would)
-    rec_best = ops.best_record(gains.view(1, K), 0)
-    out = {"next_idx": rec_best[0, 1].to(torch.int64), "max_gain": rec_best[0, 0], "gains": gains, "fov_mask": fov_mask,
-           "X_world": X_world, "view_harmonics": view_harmonics, "occ_probs": occ_probs}
+    if world > 1:                                       # ties -> the lowest index over all ranks = the first strict maximum
+        max_gain, next_idx = mdist.allgather_best(gains.view(1, -1), k0, group)
+        out = {"next_idx": next_idx[0], "max_gain": max_gain[0], "cam_range": (k0, k1)}
+    else:
+        rec_best = ops.best_record(gains.view(1, K), 0)
+        out = {"next_idx": rec_best[0, 1].to(torch.int64), "max_gain": rec_best[0, 0]}
+    out.update({"gains": gains, "fov_mask": fov_mask, "X_world": X_world, "view_harmonics": view_harmonics, "occ_probs": occ_probs})
     if fallback:
         out["fallback_variant"] = fallback
     if return_signed_distances:
@@ -341,7 +379,8 @@ def _grid_tables(scene, device):
 
 def compute_scene_occupancy_probability_field(params, macarons, camera, surface_scene, proxy_scene, device,
                                               use_supervision_occ_mask=True, prediction_camera=None,
-                                              use_supervision_occ_instead_of_predicted=False, chunk=20000, ragged_perms=None):
+                                              use_supervision_occ_instead_of_predicted=False, chunk=20000, ragged_perms=None,
+                                              group=None, record=None):
     """Occupancy probability of every proxy point the cameras have seen (macarons_utils.py:1395-1540), as ONE batched pass.
 
     Upstream walks the grid cells that hold seen proxy points from Python: per cell it gathers the surface points of the 27-cell
@@ -355,8 +394,17 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
     Returns (X_world [N,3], view_harmonics [N,64], occ_probs [N,1]) in upstream's order (cells in lexicographic order, points by
     index, then the never-seen points with their stored probability) and updates proxy_scene.proxy_proba in place.
     `surface_scene` / `proxy_scene`: macarons_amd.utility.scene.Scene or objects with the reference Scene's attributes;
-    `prediction_camera`: a PyTorch3D-like camera, or the [4,4] world->view matrix."""
+    `prediction_camera`: a PyTorch3D-like camera, or the [4,4] world->view matrix.
+    `group` (torch.distributed, ranks holding replicas of both scenes): the T query rows of all jobs are block-partitioned over the
+    ranks (every (cell, chunk) job is independent, and so is every query of a job given the job's cloud and draws), each
+    rank runs the jobs its rows belong to, the occupancies (4 B per proxy point) are all-gathered; the hidden draws of ALL jobs are
+    rank 0's, in job order, in one broadcast -- the result is bit for bit the 1-rank field.  `record` (dict): receives the draws
+    used (`ragged_perms`) so that a caller can repeat the pass."""
     from . import scone_utils as su
+    from .. import dist as mdist
+    import torch.distributed as tdist
+    world = tdist.get_world_size(group) if (tdist.is_available() and tdist.is_initialized()) else 1
+    rank = tdist.get_rank(group) if world > 1 else 0
     ps, ss = proxy_scene, surface_scene
     gl, gw, gh = ps.grid_l, ps.grid_w, ps.grid_h
     n_cells = gl * gw * gh
@@ -458,8 +506,25 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
             occ = ps.proxy_supervision_occ[rows]
         else:
             occ_net = getattr(macarons, "occupancy", macarons)
-            if hasattr(occ_net, "forward_ragged"):
+            if hasattr(occ_net, "forward_ragged") and world > 1:
+                sizes_m, sizes_q = [m for _, _, m in jobs], [q for _, q, _ in jobs]
+                if ragged_perms is None:                # rank 0 draws for every job, in job order (what the 1-rank pass draws)
+                    ragged_perms = _broadcast_job_perms(occ_net, sizes_m, device, group, rank)
+                t0, t1 = mdist.shard_range(T, rank, world)
+                q_start = np.concatenate(([0], np.cumsum(sizes_q)))
+                m_start = np.concatenate(([0], np.cumsum(sizes_m)))
+                mine = [j for j in range(J) if q_start[j] < t1 and q_start[j + 1] > t0]
+                if mine:
+                    q_l = [int(min(q_start[j + 1], t1) - max(q_start[j], t0)) for j in mine]
+                    p0, p1 = int(m_start[mine[0]]), int(m_start[mine[-1] + 1])
+                    occ_l = occ_net.forward_ragged(pc_all[p0:p1].contiguous(), [sizes_m[j] for j in mine], X_q[t0:t1].contiguous(),
+                                                   vh[t0:t1].contiguous(), q_l, perms=[ragged_perms[j] for j in mine]).view(-1, 1)
+                else:                                   # empty row shard (T < world): no kernels, the all-gather is joined
+                    occ_l = torch.zeros(0, 1, dtype=torch.float32, device=device)
+                occ = mdist.allgather_rows(occ_l, T, group)
+            elif hasattr(occ_net, "forward_ragged"):
                 occ = occ_net.forward_ragged(pc_all, [m for _, _, m in jobs], X_q, vh, [q for _, q, _ in jobs], perms=ragged_perms).view(-1, 1)
+                ragged_perms = occ_net.last_ragged_perms
             else:                                       # any other module with the reference's call signature: job by job
                 outs, r0, p0 = [], 0, 0
                 for _, q, m in jobs:
@@ -467,6 +532,8 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
                                          view_harmonics=vh[r0:r0 + q][None]).view(-1, 1))
                     r0, p0 = r0 + q, p0 + m
                 occ = torch.cat(outs)
+            if record is not None:
+                record["ragged_perms"] = ragged_perms
         ps.proxy_proba[rows] = occ                                                                # :1525
         X_parts, H_parts, O_parts = [X_sel], [vh], [occ]
     oof_idx = torch.nonzero((ps.out_of_field > 0.)[..., 0]).view(-1)                          # (one read-back for both gathers)
@@ -475,6 +542,33 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
     view_harmonics = torch.cat(H_parts + [torch.zeros(len(oof_X), nh, device=device)])
     occ_probs = torch.cat(O_parts + [ps.proxy_proba[oof_idx]])
     return X_world, view_harmonics, occ_probs
+
+
+def _broadcast_job_perms(occ_net, cloud_sizes, device, group, rank):
+    """The hidden draws of SconeOcc for J jobs (three index tensors per job, SconeOcc.draw_perms), made by rank 0 in job order on
+    its CPU generator -- exactly what a 1-rank pass draws -- and handed to every rank in ONE broadcast.  Every rank knows the
+    sizes (they follow from the cloud sizes), so the other ranks only allocate."""
+    from .. import dist as mdist
+    lens = []
+    for m_ in cloud_sizes:
+        sz = occ_net.scale_sizes(int(m_))
+        lens.append([min(int(m_), occ_net.seq_len)] + sz[1:])
+    total = sum(sum(l_) for l_ in lens)
+    if rank == 0:
+        drawn = [occ_net.draw_perms(int(m_)) for m_ in cloud_sizes]
+        flat = torch.cat([p_.reshape(-1) for job in drawn for p_ in job]).to(torch.int64)
+        buf = ops.h2d(flat, torch.int64, device)
+    else:
+        buf = torch.empty(total, dtype=torch.int64, device=device)
+    mdist.broadcast(buf, 0, group)
+    host = buf.cpu()
+    out, o = [], 0
+    for l_ in lens:
+        job = []
+        for n_ in l_:
+            job.append(host[o:o + n_]); o += n_
+        out.append(job)
+    return out
 
 
 def compute_occupancy_probability(macarons, pc, X, view_harmonics, mask=None, max_points_per_pass=20000):

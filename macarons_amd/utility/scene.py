@@ -139,13 +139,15 @@ class Scene:
             t = self._table = (order, lo, hi)
         return t
 
-    def fill_cells(self, pts, features=None, n_point_min=0):
+    def fill_cells(self, pts, features=None, n_point_min=0, group=None):
         """Scene.fill_cells (macarons_utils.py:2727-2737) over Cell.fill (:2551-2577) for ALL touched cells at once: upstream loops
         the cells from Python, each testing every point against its box and its store.  Here one stable sort groups the points by
         cell (floor rule, then the strict box test of that cell), ONE segmented fp64 nearest-distance launch runs every cell's
         admission test against its own store, a second stable sort compacts the admitted points, and the host -- after reading
         two integers per cell -- draws each touched cell's torch.randperm on the CPU generator in cell order (the reference's
-        draws) and turns them into one gather.  A point exactly on a cell face belongs to no cell, as upstream."""
+        draws) and turns them into one gather.  A point exactly on a cell face belongs to no cell, as upstream.
+        `group` (a torch.distributed group whose ranks hold replicas of this scene and call together): the permutations are rank 0's,
+        broadcast once -- every rank drawing its own would let the replicas diverge."""
         from .. import ops
         dev = self.device
         N = pts.shape[0]
@@ -182,17 +184,29 @@ class Scene:
             F_all = torch.cat([c.cell_features for c in cells if c.cell_pts.shape[0] > 0] + [torch.zeros(0, self.feature_dim, device=dev)])
             src_f = torch.cat((F_all, features[order][order2[:n_adm]].to(F_all.dtype).view(-1, self.feature_dim)))
         adm_off = np.concatenate(([0], np.cumsum(host[1])))
+        import torch.distributed as tdist
+        world = tdist.get_world_size(group) if (tdist.is_available() and tdist.is_initialized()) else 1
+        draws_here = world == 1 or tdist.get_rank(group) == 0
         gidx, touched = [], []
         for c in range(n_cells):
             if host[0, c] <= n_point_min:
                 continue                                  # Cell.fill returns before the random subset (:2562): no draw
-            comb = np.concatenate((np.arange(b_off_h[c], b_off_h[c + 1]), b_off_h[-1] + np.arange(adm_off[c], adm_off[c + 1])))
-            perm = torch.randperm(len(comb))[:cells[c].capacity].numpy()                          # :2573, CPU generator, cell order
-            gidx.append(comb[perm])
-            touched.append((c, len(perm)))
+            n_comb = int(b_off_h[c + 1] - b_off_h[c] + adm_off[c + 1] - adm_off[c])
+            n_keep = min(n_comb, cells[c].capacity)
+            if draws_here:
+                comb = np.concatenate((np.arange(b_off_h[c], b_off_h[c + 1]), b_off_h[-1] + np.arange(adm_off[c], adm_off[c + 1])))
+                perm = torch.randperm(n_comb)[:cells[c].capacity].numpy()                         # :2573, CPU generator, cell order
+                gidx.append(comb[perm])
+            touched.append((c, n_keep))
         if not touched:
             return
-        g = ops.h2d(np.concatenate(gidx), torch.int64, dev)
+        if draws_here:
+            g = ops.h2d(np.concatenate(gidx), torch.int64, dev)
+        else:
+            g = torch.empty(sum(n for _, n in touched), dtype=torch.int64, device=dev)
+        if world > 1:
+            from .. import dist as mdist
+            mdist.broadcast(g, 0, group)
         new_pts = src[g]
         new_fts = src_f[g] if with_fts else None
         o = 0

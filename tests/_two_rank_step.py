@@ -39,6 +39,38 @@ def batch_scene(g, B, dev):
     return pc, X, X_view, T(cams), perms, u
 
 
+def macarons_decisions(dev, group=None):
+    """The two consecutive MACARONS decisions of the reference golden (tests/golden/macarons_decision.npz) on fresh scenes; with
+    `group` the decision is sharded over its ranks.  -> per decision (result dict, snapshot of the proxy-scene state)."""
+    from types import SimpleNamespace as NS
+    import test_macarons_regime_gpu as tm
+    from macarons_amd.utility import macarons_utils as mu
+    g = golden("macarons_decision")
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    m = tm._models(dev)
+    surface, proxy = tm._decision_scenes(g, dev)
+    H, W = int(g["hw"][0]), int(g["hw"][1])
+    params = NS(n_harmonics=64, harmonic_degree=8, view_state_n_elev=7, view_state_n_azim=14, k_for_knn=16,
+                prediction_neighborhood_size=3, n_view_state_cameras=98, sensor_range=40., min_occ_for_proxy_points=0.1, seq_len=2048,
+                distance_factor_th=17., image_height=H, image_width=W, carving_tolerance=0.05)
+    dmask = np.unpackbits(g["dmask"])[:2 * H * W].reshape(2, H, W).astype(bool)
+    out = []
+    for c in range(2):
+        cam = mu.SceneCamera(mu.camera_record(g["Mview"][c], g["Mfull"][c], g["ndc"], g["eyes"][c], params.sensor_range).to(dev),
+                             T(g["eyes"][c:c + 1]), float(g["zfar"]))
+        nrec = torch.stack([mu.camera_record(g[f"nMview_{c}"][k], g[f"nMfull_{c}"][k], g["ndc"], g["n_eyes"][c, k], params.sensor_range)
+                            for k in range(5)]).to(dev)
+        torch.manual_seed(5100 + c)
+        with torch.no_grad():
+            r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, T(g["depth"][c]), T(dmask[c]), nrec, T(g["n_eyes"][c]), dev,
+                                         samples=T(g[f"u_{c}"]), group=group)
+        state = {k: getattr(proxy, k).clone() for k in ("view_states", "proxy_supervision_occ", "out_of_field", "proxy_n_inside_fov",
+                                                         "proxy_n_behind_depth", "proxy_proba")}
+        state["cells"] = torch.cat([proxy.cells[k].cell_features[:, 0] for k in sorted(proxy.cells)])
+        out.append((r, state))
+    return out, g
+
+
 def main():
     rank, lr = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
     backend = os.environ.get("MCR_TEST_BACKEND", "nccl")
@@ -67,6 +99,7 @@ def main():
     s_tiny = nbv_step(*tiny, occ_perms=P(g1), samples=T(g1["samples"]))
     s_b3 = nbv_step_batch(*ab, occ_perms=permb, samples=ub)
     s_b1 = nbv_step_batch(occ, vis, pcb[:1], Xb[:1], Xvb[:1], camb, grid, occ_perms=[p[:1] for p in permb], samples=ub[:1])
+    mac1, gmac = macarons_decisions(dev)
     torch.cuda.synchronize()
 
     dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
@@ -124,6 +157,19 @@ def main():
     v4, i4 = mdist.allgather_best(mine4, c0)
     ref4 = torch.max(full, dim=1)
     expect(torch.equal(mine4, full[:, c0:c1]) and torch.equal(v4, ref4.values) and torch.equal(i4, ref4.indices), "F config-4 scorer shards")
+    # G: the MACARONS decision (config 5's regime) sharded over the two ranks -- field rows and neighbour cameras block-partitioned,
+    # Cell.fill / SconeOcc draws from rank 0 -- on the reference's two-decision golden: bit-equal to the 1-rank decisions (which
+    # tests/test_macarons_regime_gpu.py holds to the reference at 1e-4), state included
+    torch.manual_seed(977 + rank)                                        # the ranks' own CPU generators disagree on purpose ...
+    mac2, _ = macarons_decisions(dev, group=dist.group.WORLD)            # ... (macarons_decisions re-seeds: so shift rank 1's draws)
+    for c in range(2):
+        (r1, s1), (r2, s2) = mac1[c], mac2[c]
+        k0, k1 = r2["cam_range"]
+        expect((k0, k1) == ((0, 3) if rank == 0 else (3, 5)), f"G{c} cam_range")
+        expect(torch.equal(r2["occ_probs"], r1["occ_probs"]) and torch.equal(r2["X_world"], r1["X_world"]), f"G{c} field")
+        expect(torch.equal(r2["gains"], r1["gains"][k0:k1]), f"G{c} gains")
+        expect(int(r2["next_idx"]) == int(r1["next_idx"]) == int(gmac[f"next_idx_{c}"]) and float(r2["max_gain"]) == float(r1["max_gain"]), f"G{c} decision")
+        expect(all(torch.equal(s1[k], s2[k]) for k in s1), f"G{c} state")
     # E: hidden draws (nothing pinned): rank 0's reach rank 1 -> identical decisions on both ranks, single-cloud and batch
     torch.manual_seed(100 + rank)                                        # the ranks' own generators disagree on purpose
     r1 = nbv_step(*a2)

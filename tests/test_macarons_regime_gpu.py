@@ -318,3 +318,96 @@ def test_coverage_metrics_match_reference(dev):
         c.cell_features[::2] = 1.
     gain = surface.camera_coverage_gain(T(g["cov_part2"], dev), surface_epsilon=0.2)
     assert float(gain) == float(g["cov_gain"])
+
+
+def test_macarons_trajectory_matches_reference(dev):
+    """TEN consecutive decisions with the state accumulating (BASELINE config 5: "10 trajectory steps ... achieved surface coverage vs
+    reference"): the golden is the REFERENCE's tester body (testers/scene.py:284-454) driven pose after pose on its own Scene / Cell /
+    Camera objects -- 3 x 2 x 3 grid, 24 000 proxy points, the surface scene empty at the start and fed by every depth map, 5-8
+    neighbour poses per step, the camera MOVING to the chosen one (make_golden.py: gen_trajectory).  Replayed here through
+    Scene.fill_cells / scene_coverage / compute_partial_point_cloud / macarons_nbv_decision with the hidden draws keyed by position
+    (tests/golden/keyed_rng.py; a draw the reference did not make, or made with another size, raises).  Per step: achieved surface
+    coverage EXACT, frustum mask / supervision occupancy / out-of-field flags / counters / view-state row sums exact, the number of
+    field rows, occupancies 1e-4, view harmonics 1e-5, every neighbour's gain 1e-4, the SAME ten choices; at the end the whole
+    view-state table exact and the stored probabilities at 1e-4."""
+    import keyed_rng as KR
+    from macarons_amd.utility import macarons_utils as mu
+    from macarons_amd.utility.scene import Scene
+    g = golden("macarons_trajectory")
+    m = _models(dev)
+    G = float(g["G"])
+    n_steps, base = int(g["n_steps"]), int(g["base_seed"])
+    H, W = int(g["hw"][0]), int(g["hw"][1])
+    P = len(g["proxy"])
+    x_min, x_max, grid = T(g["x_min"], dev), T(g["x_max"], dev), [int(v) for v in g["grid"]]
+    F = lambda a: T(a.astype(np.float32) / G, dev)                              # grid coordinates stored as int16 multiples of 2^-6
+    stages = ["part_gt", "covered_fill", "part", "surface_fill", "decision"]
+    expect = KR.unpack_sizes(g["rng_sizes"], g["rng_off"], n_steps, stages)
+    expect[(-1, "gt_fill")] = [int(v) for v in g["gt_fill_sizes"]]
+    mk = lambda cap, res, sc=1.: Scene(x_min, x_max, *grid, cell_capacity=cap, cell_resolution=res, n_proxy_points=P, device=dev,
+                                       feature_dim=1, score_threshold=sc)
+    params = NS(n_harmonics=64, harmonic_degree=8, view_state_n_elev=7, view_state_n_azim=14, k_for_knn=16,
+                prediction_neighborhood_size=3, n_view_state_cameras=98, sensor_range=float(g["sensor_range"]), min_occ_for_proxy_points=0.1,
+                seq_len=2048, distance_factor_th=17., image_height=H, image_width=W, carving_tolerance=0.05)
+    fixes = {}
+    for (s_, k_, j_), v_ in zip(g["u_fix_rows"].tolist(), g["u_fix_vals"].tolist()):
+        fixes.setdefault((s_, k_), {})[j_] = v_
+    kr = KR.KeyedRandperm(base, expect=expect)
+    zeros = lambda n: torch.zeros(n, 1, device=dev)
+    with kr.installed(), torch.no_grad():
+        kr.at(-1, "gt_fill")
+        gt_scene, covered, surface, proxy = mk(3000, 0.15), mk(1500, 0.2), mk(500, 0.2), mk(100000, 1e-4, 0.95)
+        gt_scene.fill_cells(F(g["gt"]), features=zeros(len(g["gt"])))
+        proxy.initialize_proxy_points()
+        proxy.proxy_points = F(g["proxy"])
+        assert abs(3 * proxy.distance_between_proxy_points - float(g["dts"])) < 1e-12
+        for step in range(n_steps):
+            depth = T(g[f"depth_{step}"], dev)
+            dmask = T(np.unpackbits(g[f"dmask_{step}"])[:H * W].reshape(H, W).astype(bool), dev)
+            dcam = mu.depth_camera_record(g[f"Mfull_{step}"], float(g["P"][2, 2]), float(g["P"][3, 2]))
+            snapped = lambda p: {tuple(r_) for r_ in np.round(p.cpu().numpy() * G).astype(np.int64).tolist()}
+            # ---- ground-truth partial cloud -> covered scene -> achieved coverage (testers/scene.py:318-336)
+            for stage, fill, scene, key in (("part_gt", "covered_fill", covered, "part_gt"), ("part", "surface_fill", surface, "part")):
+                kr.at(step, stage)
+                part = mu.compute_partial_point_cloud(depth.view(1, H, W, 1), dmask.view(1, H, W, 1), dcam, float(g["gf"]),
+                                                      fov_range=params.sensor_range)
+                want = {tuple(r_) for r_ in g[f"{key}_{step}"].astype(np.int64).tolist()}
+                got = snapped(part)                      # the harness's sensor quantisation: the 2^-6 grid (cell faces excepted)
+                assert len(part) == int(g[f"part_raw_n_{step}"][0 if key == "part_gt" else 1])
+                assert len(got & want) >= 0.985 * len(want), (step, key, len(got & want), len(want))
+                kr.at(step, fill)
+                scene.fill_cells(F(g[f"{key}_{step}"]), features=zeros(len(g[f"{key}_{step}"])))   # (the reference's own snapped cloud: the state stays exact)
+                if key == "part_gt":
+                    cov, n_gt = gt_scene.scene_coverage(covered, surface_epsilon=float(g["eps_cov"]))
+                    assert n_gt == int(g["cov_n"]) and float(cov) == float(g["coverage"][step]), (step, float(cov), float(g["coverage"][step]))
+            assert np.array_equal(np.array([len(c.cell_pts) for _, c in sorted(surface.cells.items())]), g[f"surface_n_{step}"]), step
+            # ---- the decision (:391-454)
+            kr.at(step, "decision")
+            eye = g[f"eye_{step}"]
+            cam = mu.SceneCamera(mu.camera_record(g[f"Mview_{step}"], g[f"Mfull_{step}"], g["ndc"], eye, params.sensor_range).to(dev),
+                                 T(eye[None], dev), float(g["zfar"]))
+            n_eyes, nb = g[f"n_eyes_{step}"], g[f"nb_{step}"]
+            K = len(n_eyes)
+            nrec = torch.stack([mu.camera_record(g[f"nMview_{step}"][k], g[f"nMfull_{step}"][k], g["ndc"], n_eyes[k], params.sensor_range)
+                                for k in range(K)]).to(dev)
+            u = torch.stack([KR.keyed_uniforms(base, step, int(a) * 8 + int(e)).view(-1) for a, e in nb.tolist()])
+            for k, (a, e) in enumerate(nb.tolist()):
+                for j_, v_ in fixes.get((step, int(a) * 8 + int(e)), {}).items():
+                    u[k, j_] = v_
+            r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, depth, dmask, nrec, T(n_eyes, dev), dev, samples=u.to(dev))
+            bits = lambda t_: np.packbits(t_.cpu().numpy().reshape(-1).astype(np.uint8))
+            assert np.array_equal(bits(r["fov_mask"]), g[f"fov_mask_{step}"]), step
+            assert np.array_equal(bits(proxy.proxy_supervision_occ), g[f"sup_occ_{step}"]), step
+            assert np.array_equal(bits(proxy.out_of_field), g[f"oof_{step}"]), step
+            assert np.array_equal(proxy.view_states.sum(-1).cpu().numpy().astype(np.uint8), g[f"vs_rowsum_{step}"]), step
+            assert np.array_equal(proxy.proxy_n_inside_fov.cpu().numpy()[:, 0].astype(np.uint8), g[f"n_inside_{step}"]), step
+            assert np.array_equal(proxy.proxy_n_behind_depth.cpu().numpy()[:, 0].astype(np.uint8), g[f"n_behind_{step}"]), step
+            assert r["X_world"].shape[0] == int(g[f"field_n_{step}"]), step
+            occ_ref = g[f"occ_{step}"]
+            assert np.abs(r["occ_probs"].cpu().numpy()[::7, 0] - occ_ref).max() < 1e-4 * np.abs(occ_ref).max(), step
+            assert rel_err(r["view_harmonics"].cpu().numpy()[::37], g[f"vh_{step}"]) < 1e-5, step
+            assert rel_err(r["gains"].cpu().numpy(), g[f"gains_{step}"]) < 1e-4, (step, r["gains"].cpu().numpy(), g[f"gains_{step}"])
+            assert int(r["next_idx"]) == int(g["next_idx"][step]), step
+    assert np.array_equal(np.packbits(proxy.view_states.cpu().numpy().astype(np.uint8), axis=-1), g["view_states_final"])
+    assert np.abs(proxy.proxy_proba.cpu().numpy()[:, 0] - g["proxy_proba_final"]).max() < 1e-4 * np.abs(g["proxy_proba_final"]).max()
+    assert [k_ for k_ in expect if len(expect[k_]) != len(kr.sizes().get(k_, []))] == []       # every draw the reference made was made

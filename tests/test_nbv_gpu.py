@@ -83,7 +83,8 @@ def test_config1_real_valued_vs_oracle(dev):
 def test_headline_step_runs_and_is_consistent(dev):
     """BASELINE headline size: Q = 100k proxy points, M = 10240 surface points, C = 200 cameras."""
     from macarons_amd.nbv import nbv_step, ViewStateGrid
-    occ, vis, _, _ = _models(dev)
+    from _oracle_sample import check_step_against_oracle
+    occ, vis, sdo, sdv = _models(dev)
     gen = torch.Generator().manual_seed(0)
     pc = (torch.rand(1, 10240, 3, generator=gen) - 0.5).to(dev)
     X = (torch.rand(1, 100_000, 3, generator=gen) - 0.5).to(dev)
@@ -93,11 +94,16 @@ def test_headline_step_runs_and_is_consistent(dev):
     torch.manual_seed(1)
     perms = occ.draw_perms(10240)
     u = torch.rand(2048, generator=gen).to(dev)
-    a = nbv_step(occ, vis, pc, X, cams[:3].contiguous(), cams, grid, occ_perms=perms, samples=u)
+    a = nbv_step(occ, vis, pc, X, cams[:3].contiguous(), cams, grid, occ_perms=perms, samples=u, return_samples=True)
     b = nbv_step(occ, vis, pc, X, cams[:3].contiguous(), cams, grid, occ_perms=perms, samples=u)
     assert torch.equal(a["gains"], b["gains"]) and int(a["nbv_idx"]) == int(b["nbv_idx"])      # deterministic
     assert a["gains"].shape == (200,) and torch.isfinite(a["gains"]).all() and torch.isfinite(a["occ"]).all()
     assert int(a["nbv_idx"]) == int(torch.argmax(a["gains"]))
+    # values at THIS size against the oracle (a bounded sample: 66 of the 100k queries through oracle.nets.scone_occ_forward with the
+    # same draws, the sampler on all occupancies, oracle SconeVis on the sampled set, 7 cameras through the C port of the scorer)
+    info = check_step_against_oracle(a, sdo, sdv, pc.cpu().numpy(), X.cpu().numpy(), cams[:3].cpu().numpy(), cams.cpu().numpy(),
+                                     [p.numpy() for p in perms], u.cpu().numpy())
+    assert info["queries"] >= 64 and info["cams"] >= 5
 
 
 def test_pipelined_best_exchange_nccl_single_rank(dev):
@@ -235,7 +241,8 @@ def test_batch_step_equals_single_cloud_steps(dev, B, M, Q, C):
     cameras) == B single-cloud nbv_step calls with the same per-cloud hidden draws (testers/shapenet.py:33-37 loops the objects):
     occupancies, sampled sets, gains, decisions bit for bit."""
     from macarons_amd.nbv import nbv_step, nbv_step_batch, draw_batch, ViewStateGrid
-    occ, vis, _, _ = _models(dev)
+    from _oracle_sample import check_step_against_oracle
+    occ, vis, sdo, sdv = _models(dev)
     grid = ViewStateGrid(dev)
     pc, X, X_view, cams = _batch_scene(dev, B, M, Q, C, seed=11 + B)
     torch.manual_seed(5)
@@ -245,6 +252,9 @@ def test_batch_step_equals_single_cloud_steps(dev, B, M, Q, C):
     for b in range(B):
         s = nbv_step(occ, vis, pc[b:b + 1], X[b:b + 1], X_view[b], cams, grid, occ_perms=[p[b] for p in perms], samples=u[b],
                      return_samples=True)
+        if b == B - 1:                                  # one cloud of the batch at THIS size against the oracle (bounded sample)
+            check_step_against_oracle(s, sdo, sdv, pc[b:b + 1].cpu().numpy(), X[b:b + 1].cpu().numpy(), X_view[b].cpu().numpy(),
+                                      cams.cpu().numpy(), [p[b].cpu().numpy() for p in perms], u[b].cpu().numpy(), seed=b)
         assert torch.equal(r["occ"][b], s["occ"]), b
         assert int(r["n_unique"][b]) == int(s["n_unique"]) and torch.equal(r["proxy_points"][b], s["proxy_points"]), b
         assert torch.equal(r["sample_idx"][b], s["sample_idx"]), b

@@ -426,3 +426,65 @@ def test_direction_lattices_bit_exact():
         assert torch.equal(h_polar, -he + math.pi / 2) and torch.equal(h_azim, ha)
     X, dist, elev, azim = su.get_cameras_on_sphere(n_elev=4, n_azim=5, camera_dist=2.0, pole_cameras=True)
     assert X.shape == (22, 3) and float(elev[0]) == np.float32(-89.9) and float(elev[-1]) == np.float32(89.9) and float(azim[0]) == 0.0
+
+
+def test_trajectory_coverage_oracle_matches_reference():
+    """Ten poses of the reference's trajectory (tests/golden/macarons_trajectory.npz, make_golden.py: gen_trajectory): the partial
+    point cloud of every depth map through oracle.scene (pytorch3d's unprojection restated) lands on the reference's snapped
+    cloud, and the covered scene filled pose after pose with oracle.macarons_regime.cell_fill (hidden draws keyed by position,
+    tests/golden/keyed_rng.py) gives the reference's ACHIEVED SURFACE COVERAGE at every pose, exactly (Scene.scene_coverage,
+    macarons_utils.py:3031-3056: fp64 nearest distance against epsilon, cell by cell)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import keyed_rng as KR
+    from oracle import macarons_regime as R, scene as S
+    g = golden("macarons_trajectory")
+    G, n_steps, base = float(g["G"]), int(g["n_steps"]), int(g["base_seed"])
+    H, W = int(g["hw"][0]), int(g["hw"][1])
+    x_min, x_max, grid = g["x_min"].astype(np.float32), g["x_max"].astype(np.float32), [int(v) for v in g["grid"]]
+    step3 = ((x_max - x_min) / np.array(grid, np.float32)).astype(np.float32)
+    cells = [(i, j, k) for i in range(grid[0]) for j in range(grid[1]) for k in range(grid[2])]
+    box = {c: (x_min + np.array(c, np.float32) * step3, x_min + (np.array(c, np.float32) + 1) * step3) for c in cells}
+    stages = ["part_gt", "covered_fill", "part", "surface_fill", "decision"]
+    expect = KR.unpack_sizes(g["rng_sizes"], g["rng_off"], n_steps, stages)
+    expect[(-1, "gt_fill")] = [int(v) for v in g["gt_fill_sizes"]]
+    kr = KR.KeyedRandperm(base, expect=expect)
+
+    def fill(store, pts, resolution, capacity):
+        """Scene.fill_cells (:2727-2737): the cells the in-box points fall in, in lexicographic order, each through Cell.fill."""
+        inside = pts[((pts >= x_min) & (pts <= x_max)).all(-1)]
+        d = inside - x_min
+        idx = np.minimum(((d - np.mod(d, step3)) / step3).astype(np.int64), np.array(grid) - 1).clip(min=0)
+        for c in sorted({tuple(r_) for r_ in idx.tolist()}):
+            lo, hi = box[c]
+            n_in = int((((inside - hi).max(-1) < 0) & ((inside - lo).min(-1) > 0)).sum())
+            if n_in == 0:
+                continue                                 # Cell.fill returns before its draw
+            before = store[c]
+            adm = n_in if len(before) == 0 else int((S.min_dist(inside[((inside - hi).max(-1) < 0) & ((inside - lo).min(-1) > 0)], before) > resolution).sum())
+            perm = kr(len(before) + adm).numpy()
+            store[c] = R.cell_fill(before, inside, lo, hi, resolution, capacity, perm)
+
+    gt = {c: np.zeros((0, 3), np.float32) for c in cells}
+    covered = {c: np.zeros((0, 3), np.float32) for c in cells}
+    kr.at(-1, "gt_fill")
+    fill(gt, g["gt"].astype(np.float32) / G, 0.15, 3000)
+    n_gt = sum(len(v) for v in gt.values())
+    assert n_gt == int(g["cov_n"])
+    for step in range(n_steps):
+        depth = g[f"depth_{step}"]
+        dmask = np.unpackbits(g[f"dmask_{step}"])[:H * W].astype(bool)
+        Minv = np.linalg.inv(g[f"Mfull_{step}"].astype(np.float64)).astype(np.float32)
+        kr.at(step, "part_gt")
+        n_keep = int((dmask & (depth.reshape(-1) < float(g["sensor_range"]))).sum())
+        part = S.compute_partial_point_cloud(depth[None, :, :, None], dmask, Minv, float(g["P"][2, 2]), float(g["P"][3, 2]), float(g["gf"]),
+                                             float(g["sensor_range"]), kr(n_keep).numpy())
+        want = {tuple(r_) for r_ in g[f"part_gt_{step}"].astype(np.int64).tolist()}
+        got = {tuple(r_) for r_ in np.round(part * G).astype(np.int64).tolist()}
+        assert len(part) == int(g[f"part_raw_n_{step}"][0]) and len(got & want) >= 0.985 * len(want), step
+        kr.at(step, "covered_fill")
+        fill(covered, g[f"part_gt_{step}"].astype(np.float32) / G, 0.2, 1500)
+        n_cov = sum(int((S.min_dist(gt[c], covered[c]) < float(g["eps_cov"])).sum()) for c in cells if len(gt[c]) and len(covered[c]))
+        assert n_cov / n_gt == float(g["coverage"][step]), (step, n_cov / n_gt, float(g["coverage"][step]))
+    assert float(g["coverage"][-1]) > float(g["coverage"][0]) + 0.25                    # the trajectory does uncover the surface
