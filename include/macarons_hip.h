@@ -89,6 +89,14 @@ int mcr_attention(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_
 size_t mcr_attention_workspace_bytes(int64_t S, int64_t L, int n_heads, int v_dim);
 int mcr_attention_ws(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim,
                      int v_dim, void* workspace, size_t workspace_bytes, void* stream);
+/* attention(q, k, v, mask) of Attention.py:8-36 WITH a mask (:24-27): where the mask byte of (sequence s, head h, query q, key k) --
+ * mask[s * mask_seq_stride + h * mask_head_stride + q * mask_query_stride + k] -- is 0 the score is replaced by -1e3 BEFORE the
+ * division by sqrt(d) (upstream's masked_fill rule: a fully masked query attends uniformly over the keys; it is not -inf).  Strides
+ * of 0 broadcast: a [S, L] key mask has query and head stride 0, upstream's [S, 1, L, L] has head stride 0.  workspace: as
+ * mcr_attention_ws (may be NULL).  fp32 P V (the fp16-split P V of the unmasked path is not taken). */
+int mcr_attention_masked(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim,
+                         int v_dim, const unsigned char* mask, int64_t mask_seq_stride, int64_t mask_head_stride,
+                         int64_t mask_query_stride, void* workspace, size_t workspace_bytes, void* stream);
 int mcr_colmax_broadcast(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int64_t L, int E, void* stream);
 int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int64_t L, int E, void* stream);
 

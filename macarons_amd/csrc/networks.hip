@@ -239,6 +239,22 @@ int mcr_attention(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_
     return 0;
 }
 
+int mcr_attention_masked(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim, int v_dim,
+                         const unsigned char* mask, int64_t mask_seq_stride, int64_t mask_head_stride, int64_t mask_query_stride,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    MCR_REQUIRE(qkv && out && mask, "mcr_attention_masked: null pointer");
+    MCR_REQUIRE(S > 0 && L > 0, "mcr_attention_masked: empty problem");
+    MCR_REQUIRE(n_heads == 4 && ((qk_dim == 32 && v_dim == 128) || (qk_dim == 64 && v_dim == 256)),
+                "mcr_attention_masked: supported head layouts are 4 heads with (qk,v) = (32,128) or (64,256); got %d heads (%d,%d)",
+                n_heads, qk_dim, v_dim);
+    MCR_REQUIRE(mask_seq_stride >= 0 && mask_head_stride >= 0 && mask_query_stride >= 0, "mcr_attention_masked: negative mask stride");
+    MCR_REQUIRE(L == 16 || S <= 32767, "mcr_attention_masked: too many long sequences");
+    launch_attention((hipStream_t)stream, qkv, ldq, out, ldo, S, (int)L, n_heads, qk_dim, v_dim, nullptr, (float*)workspace,
+                     workspace ? workspace_bytes / sizeof(float) : 0, false, false, mask, mask_seq_stride, mask_head_stride, mask_query_stride);
+    MCR_LAUNCH_CHECK("mcr_attention_masked");
+    return 0;
+}
+
 size_t mcr_attention_workspace_bytes(int64_t S, int64_t L, int n_heads, int v_dim) {
     return attention_split_floats(S, (int)L, n_heads, v_dim) * sizeof(float);
 }

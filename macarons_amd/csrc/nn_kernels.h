@@ -44,12 +44,16 @@ void launch_layernorm(hipStream_t s, const float* X, int64_t ldx, const float* g
 //   qkv[m, 0:DQK | DQK:2DQK | 2DQK:2DQK+DV], head h owns channels [h*d,(h+1)*d); scores / sqrt(dqk_per_head);
 //   out[m, h*dv:(h+1)*dv].   Sequences are S consecutive blocks of L rows.
 //   lens (optional, device int per sequence): keys = the first min(L, lens[s]) rows (padded variable-length batches).
+// mask (optional, bytes; Attention.py:24-27): pair (sequence s, head h, query q, key k) is masked where
+//   mask[s * mask_seq_stride + h * mask_head_stride + q * mask_query_stride + k] == 0: its score becomes -1e3 BEFORE the 1/sqrt(d)
+//   scale (so a fully masked query attends uniformly, as upstream); strides of 0 broadcast (a [S, L] key mask: query stride 0).
 // split_ws (optional, attention_split_floats(S, L, H, DV) floats): lets one or two long sequences split their keys over two blocks
 // (L >= 512 and at most 256 blocks otherwise); split_by_length: split whenever L >= 512, whatever S -- the networks use this so
 // that a cloud's result does not depend on how many clouds share the launch (the two forms differ by summation order, ~1e-6).
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
                       int DQK, int DV, const int* lens = nullptr, float* split_ws = nullptr, size_t split_ws_floats = 0,
-                      bool split_by_length = false, bool pv_half = false);
+                      bool split_by_length = false, bool pv_half = false, const unsigned char* mask = nullptr,
+                      int64_t mask_seq_stride = 0, int64_t mask_head_stride = 0, int64_t mask_query_stride = 0);
 size_t attention_split_floats(int64_t S, int L, int H, int DV);
 
 // Column max over the L rows of each of S sequences, broadcast into a column slice of every row:

@@ -304,9 +304,12 @@ void launch_layernorm(hipStream_t s, const float* X, int64_t ldx, const float* g
 // Attention, short sequences (L <= 16 tokens: the k=16 neighbourhoods of SconeOcc).  One thread per
 // (sequence, head, query row); a block stages SPB sequences' packed QKV rows in LDS.
 // =====================================================================================================
+// mask (optional; Attention.py:24-27): byte (sequence s, head h, query q, key k) at mask[s * ms + h * mh + q * mq + k]; where it is 0 the
+// score is REPLACED by -1e3 before the 1/sqrt(d) scale (not -inf: a fully masked row attends uniformly, as upstream).
+struct AttnMask { const unsigned char* p; long long ms, mh, mq; };
 template <int L, int H, int DQ, int DV, int SPB>
 __global__ __launch_bounds__(SPB* H* L) void attention_small_kernel(const float* __restrict__ qkv, long long ldq,
-                                                                   float* __restrict__ out, long long ldo, long long S) {
+                                                                   float* __restrict__ out, long long ldo, long long S, AttnMask mk) {
     constexpr int W = 2 * H * DQ + H * DV;          // packed row width
     constexpr int WP = W + 1;                       // +1: rows land on different banks
     __shared__ float s_qkv[SPB * L * WP];
@@ -333,6 +336,7 @@ __global__ __launch_bounds__(SPB* H* L) void attention_small_kernel(const float*
         float a = 0.f;
 #pragma unroll
         for (int d = 0; d < DQ; ++d) a = fmaf(q[d], base[j * WP + H * DQ + hh * DQ + d], a);
+        if (mk.p && mk.p[(s0 + sl) * mk.ms + hh * mk.mh + qi * mk.mq + j] == 0) a = -1e3f;
         sc[j] = a * scale;
         mx = fmaxf(mx, sc[j]);
     }
@@ -483,11 +487,11 @@ __global__ __launch_bounds__(64 * KS) void attention_flash_kernel(const float* _
 // three v_mfma_f32_16x16x32_f16 of ~17 pipe cycles per 32 keys x 16 columns instead of eight fp32 ones of 32 (the P V product is
 // 80 % of the kernel's matrix work; S = Q K^T stays exact fp32).  A tile holding a value outside the fp16 range (|v| >= 32768, inf, NaN) is detected
 // while it is staged (block-wide OR folded into the tile barrier) and takes the fp32 path: no range restriction, no flag.
-template <int DQ, int DV, bool SPLIT, bool PVH>
+template <int DQ, int DV, bool SPLIT, bool PVH, bool MASK = false>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, long long ldq,
                                                              float* __restrict__ out, long long ldo, int L, int H,
                                                              const int* __restrict__ lens, float* __restrict__ part1,
-                                                             float* __restrict__ ml) {
+                                                             float* __restrict__ ml, AttnMask mk = AttnMask{nullptr, 0, 0, 0}) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
     typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -602,6 +606,16 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             st[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int sk = 0; sk < KQ; ++sk) st[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[sub][sk], qb[sk], st[sub], 0, 0, 0);
+        }
+        if (MASK) {                                       // Attention.py:24-27: masked pairs score -1e3 (then / sqrt(d)), not -inf
+            const unsigned char* mrow = mk.p + (long long)seq * mk.ms + hh * mk.mh + (long long)min(q0 + li, L - 1) * mk.mq + t0;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = sub * 16 + 4 * g + r;
+                    if (t0 + key < L && mrow[key] == 0) st[sub][r] = -1e3f * scale;
+                }
         }
         if (t0 + TK > Lk) {                               // only the last tile of a sequence has keys past its end (block-uniform)
 #pragma unroll
@@ -736,13 +750,15 @@ __global__ void attention_combine_kernel(float* __restrict__ out, long long ldo,
 size_t attention_split_floats(int64_t S, int L, int H, int DV) { return (size_t)S * L * DV + (size_t)4 * S * L * H; }
 
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
-                      int DQK, int DV, const int* lens, float* split_ws, size_t split_ws_floats, bool split_by_length, bool pv_half) {
+                      int DQK, int DV, const int* lens, float* split_ws, size_t split_ws_floats, bool split_by_length, bool pv_half,
+                      const unsigned char* mask, int64_t mask_seq_stride, int64_t mask_head_stride, int64_t mask_query_stride) {
     if (S <= 0 || L <= 0) return;
     const int dq = DQK / H, dv = DV / H;
+    const AttnMask mk{mask, (long long)mask_seq_stride, (long long)mask_head_stride, (long long)mask_query_stride};
     if (!lens && L == 16 && H == 4 && dq == 8 && dv == 32) {
         constexpr int SPB = 4;
         hipLaunchKernelGGL((attention_small_kernel<16, 4, 8, 32, SPB>), dim3((unsigned)cdiv(S, SPB)), dim3(SPB * 4 * 16), 0,
-                           s, qkv, (long long)ldq, out, (long long)ldo, (long long)S);
+                           s, qkv, (long long)ldq, out, (long long)ldo, (long long)S, mk);
         return;
     }
     constexpr int KS = 4;
@@ -755,7 +771,10 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
     if (use_mfma && al16 && ((dq == 8 && dv == 32) || (dq == 16 && dv == 64))) {
 #define MCR_ATT(DQ_, DV_, SPLIT_, GRID_, P1_, ML_)                                                                                    \
     do {                                                                                                                               \
-        if (pv_half)                                                                                                                   \
+        if (mask)                                                                                                                      \
+            hipLaunchKernelGGL((attention_mfma_kernel<DQ_, DV_, SPLIT_, false, true>), GRID_, dim3(256), 0, s, qkv, (long long)ldq,     \
+                               out, (long long)ldo, L, H, lens, P1_, ML_, mk);                                                         \
+        else if (pv_half)                                                                                                              \
             hipLaunchKernelGGL((attention_mfma_kernel<DQ_, DV_, SPLIT_, true>), GRID_, dim3(256), 0, s, qkv, (long long)ldq, out,       \
                                (long long)ldo, L, H, lens, P1_, ML_);                                                                  \
         else                                                                                                                           \
@@ -778,8 +797,8 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
 #undef MCR_ATT
         return;
     }
-    if (lens) {
-        set_error("launch_attention: per-sequence lengths need the MFMA kernel (16-byte aligned qkv, head dims (8,32) or (16,64))");
+    if (lens || mask) {
+        set_error("launch_attention: per-sequence lengths / masks need the MFMA kernel (16-byte aligned qkv, head dims (8,32) or (16,64))");
         return;
     }
     if (dq == 8 && dv == 32)

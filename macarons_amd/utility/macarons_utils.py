@@ -4,6 +4,7 @@
 PyTorch3D camera objects stay outside: cameras are passed as the 40-float records of mcr_points_in_fov
 (M_view, M_proj, ndc bounds, centre, range) and a prediction-view matrix.
 """
+import numpy as np
 import torch
 
 from .. import ops

@@ -309,7 +309,9 @@ class Scene:
         A, a_off = self._csr([self.cells[k].cell_pts for k in both])
         B, b_off = self._csr([recovered_scene.cells[k].cell_pts for k in both])
         covered = mu.covered_mask(A, B, epsilon, a_off, b_off)
-        return covered.sum().double() / n_gt, n_gt
+        # a TENSOR divisor: dividing a device tensor by a Python scalar multiplies by its reciprocal (1 ulp off the quotient upstream's
+        # CPU division returns)
+        return covered.sum().double() / torch.full((), float(n_gt), dtype=torch.float64, device=self.device), n_gt
 
     def camera_coverage_gain(self, part_pc, surface_epsilon=None, surface_epsilon_factor=None):
         """(:2987-3029) number of not-yet-covered surface points (cell feature 0) of the cells the partial cloud touches that

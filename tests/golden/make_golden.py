@@ -1393,35 +1393,40 @@ def gen_trajectory():
                     fn = _StandInCameras(t(Rn[k:k + 1]), t(Tn[k:k + 1]), t(P1[None]), squeeze=True)
                     bad_idx_k = np.nonzero(frustum_margin(Xw_np, fn, n_eyes[k]) < 2e-5)[0]
                     bad_idx += [lut[tuple(r_)] for r_ in Xw_np[bad_idx_k].tolist()]      # X_world rows back to proxy indices
-                    for attempt in range(6):
-                        u = KR.keyed_uniforms(base_seed, step, cam_key[k])
-                        for j_, v_ in u_fix.get((step, cam_key[k]), {}).items():
-                            u[j_, 0] = v_
-                        torch.rand = lambda *a, **kw: u.clone()
-                        try:
-                            with torch.no_grad():
-                                pw, _, _, cg = mu.predict_coverage_gain_for_single_camera(
-                                    params=params, macarons=m, proxy_scene=ps, surface_scene=surface_scene, X_world=X_world,
-                                    proxy_view_harmonics=vh, occ_probs=occ, camera=cam, X_cam_world=t(n_eyes[k:k + 1]), fov_camera=fn)
-                        finally:
-                            torch.rand = real_rand
-                        # the exact-CDF sampler (the convention of the HIP kernel) must pick the same points: a uniform within fp32
-                        # rounding of a CDF step is replaced (and recorded) and the camera re-run
-                        _, km = cam.get_points_in_fov(X_world, return_mask=True, fov_camera=fn, fov_range=params.sensor_range)
-                        km = km.numpy()
-                        if not km.any():
-                            break
+                    # Which point a uniform selects hangs on the CDF of the occupancies; the kernels' occupancies differ from the reference's
+                    # in the last bits, so a uniform within ~1e-8 of a CDF step would select a neighbouring point there (1 sample of 2048 moves
+                    # a gain by up to 5e-4).  Every uniform closer than 1e-6 to a step of the EXACT CDF is moved to the middle of its
+                    # interval (same point selected, far from both steps) and recorded; the fp32 sampler of the reference, the fp64 one
+                    # of the oracle and the kernels' then agree sample for sample (checked below for the first two).
+                    _, km = cam.get_points_in_fov(X_world, return_mask=True, fov_camera=fn, fov_range=params.sensor_range)
+                    km = km.numpy()
+                    u = KR.keyed_uniforms(base_seed, step, cam_key[k])
+                    fix = u_fix.setdefault((step, cam_key[k]), {})
+                    for j_, v_ in fix.items():
+                        u[j_, 0] = v_
+                    kept = km & (occ_np[:, 0] > params.min_occ_for_proxy_points)
+                    if kept.any():
+                        cn = np.cumsum(occ_np[kept, 0].astype(np.float64))
+                        cn /= cn[-1]
+                        u64 = u.numpy().reshape(-1).astype(np.float64)
+                        ii = np.minimum(np.searchsorted(cn, u64, side="left"), len(cn) - 1)
+                        lower, upper = np.where(ii > 0, cn[np.maximum(ii - 1, 0)], 0.0), cn[ii]
+                        viol = np.nonzero(np.minimum(upper - u64, u64 - lower) < 1e-6)[0]
+                        for j_ in viol.tolist():
+                            fix[j_] = float(np.float32((lower[j_] + upper[j_]) / 2))
+                            u[j_, 0] = fix[j_]
+                    torch.rand = lambda *a, **kw: u.clone()
+                    try:
+                        with torch.no_grad():
+                            pw, _, _, cg = mu.predict_coverage_gain_for_single_camera(
+                                params=params, macarons=m, proxy_scene=ps, surface_scene=surface_scene, X_world=X_world,
+                                proxy_view_harmonics=vh, occ_probs=occ, camera=cam, X_cam_world=t(n_eyes[k:k + 1]), fov_camera=fn)
+                    finally:
+                        torch.rand = real_rand
+                    if km.any():
                         res, _, inv, _ = V.sample_proxy_points(Xw_np[km], occ_np[km], np.zeros((int(km.sum()), 1), np.float32), u.numpy().reshape(-1),
                                                                params.min_occ_for_proxy_points, exact=True)
-                        diff = np.nonzero((res[inv] != pw[0].numpy()).any(axis=1))[0]
-                        if len(diff) == 0:
-                            break
-                        fix = u_fix.setdefault((step, cam_key[k]), {})
-                        for j_ in diff.tolist():
-                            fix[j_] = float(np.float32(u[j_, 0].item() * 0.999 + 3e-4))
-                        print(f"    step {step} camera {k}: {len(diff)} uniform(s) on a CDF step replaced")
-                    else:
-                        raise RuntimeError("sampler fix-up did not converge")
+                        assert np.array_equal(res[inv], pw[0].numpy()), "the reference's sampler and the exact CDF disagree despite the margin"
                     gains.append(float(cg.view(-1)[0]))
                     if cg.shape[0] > 0 and cg > max_gain:
                         max_gain, next_idx = cg, k
