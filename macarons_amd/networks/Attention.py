@@ -36,14 +36,16 @@ def _f32c(p):
 
 
 def attention(q, k, v, mask=None, dropout=None):
-    """Attention.py:8-36.  q,k [B,H,N,d], v [B,H,N,dv] -> [B,H,N,dv]  (mask=None, dropout=None only)."""
-    if mask is not None or dropout is not None:
-        raise NotImplementedError("macarons_amd.attention: mask / dropout are not used on the hot path (SURVEY §8 a9)")
+    """Attention.py:8-36.  q,k [B,H,N,d], v [B,H,N,dv] -> [B,H,N,dv].  mask: anything that broadcasts against the [B,H,N,N] scores
+    as upstream's masked_fill does ([B,1,N,N], [N,N], [B,H,N,N]); masked pairs score -1e3 BEFORE the 1/sqrt(d) scale (:24-27).
+    dropout: inference path, None only."""
+    if dropout is not None:
+        raise NotImplementedError("macarons_amd.attention: dropout is not used on the hot path (SURVEY §8 a9)")
     B, H, N, d = q.shape
     dv = v.shape[-1]
     packed = torch.cat((q.transpose(1, 2).reshape(B, N, H * d), k.transpose(1, 2).reshape(B, N, H * d),
                         v.transpose(1, 2).reshape(B, N, H * dv)), dim=-1).contiguous()
-    out = ops.attention_packed(packed, H, H * d, H * dv)
+    out = ops.attention_packed(packed, H, H * d, H * dv, mask=mask)
     return out.reshape(B, N, H, dv).transpose(1, 2)
 
 
@@ -129,12 +131,12 @@ class MultiHeadSelfAttention(nn.Module):
                 v.reshape(v.shape[0], -1, self.n_heads, self.v_dim_per_head))
 
     def forward(self, x, mask=None):
+        """mask (optional): [B,1,N,N] / [N,N] / [B,H,N,N] as upstream broadcasts it, or [B,N,N] (the shape upstream's docstring
+        names), or a [B,N] key mask; see ops.attention_packed."""
         _inference_only(self, x)
-        if mask is not None:
-            raise NotImplementedError("mask is None in every call site of the hot path (SURVEY §8 a6)")
         w, b = self.packed_qkv()
         qkv = ops.linear(x, w, b)
-        scores = ops.attention_packed(qkv, self.n_heads, self.qk_dim, self.v_dim)
+        scores = ops.attention_packed(qkv, self.n_heads, self.qk_dim, self.v_dim, mask=mask)
         if self.n_heads > 1:
             scores = ops.linear(scores, _f32c(self.out.weight), _f32c(self.out.bias))
         return scores
@@ -185,11 +187,9 @@ class Encoder(nn.Module):
     def forward(self, x, mask=None):
         _inference_only(self, x)
         res = ops.layernorm(x, _f32c(self.norm1.weight), _f32c(self.norm1.bias))
-        if mask is not None:
-            raise NotImplementedError("mask is None in every call site of the hot path")
         w, b = self.mhsa.packed_qkv()
         qkv = ops.linear(res, w, b)
-        att = ops.attention_packed(qkv, self.n_heads, self.qk_dim, self.embedding_dim)
+        att = ops.attention_packed(qkv, self.n_heads, self.qk_dim, self.embedding_dim, mask=mask)    # mask: see MultiHeadSelfAttention
         res = ops.linear(att, _f32c(self.mhsa.out.weight), _f32c(self.mhsa.out.bias), residual=x) \
             if self.n_heads > 1 else x + att
         if self.FF:

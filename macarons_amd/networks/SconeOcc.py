@@ -71,10 +71,14 @@ class PCTransformer(nn.Module):
     def forward(self, pc, mask=None):
         """pc [n_clouds, seq_len, 3] -> [n_clouds, feature_dim]."""
         _inference_only(self, pc)
-        if mask is not None:
-            raise NotImplementedError("mask is None in every call site of the hot path")
         if not self._is_default_arch():
             raise NotImplementedError("the fused MI355X PCTransformer implements the reference's default architecture")
+        if mask is not None:                            # SconeOcc.py:106-118: the mask goes to every encoder; block by block (see SconeVis.forward)
+            x = self.embedding(pc)
+            for enc in self.encoders:
+                x = enc(x, mask=mask)
+            x = ops.linear(ops.layernorm(x, _f32c(self.norm.weight), _f32c(self.norm.bias)), _f32c(self.linear0.weight), _f32c(self.linear0.bias))
+            return ops.pool_max_avg(x)
         return ops.pc_transformer_forward(pc, self.weight_table(), self.feature_dim)
 
 
@@ -326,7 +330,9 @@ class SconeOcc(nn.Module):
         the clouds, as the reference draws them) or [n_clouds, n] (one draw per cloud).  `begun`: the handle of forward_begin(pc, x)
         (same tensors): only the remaining part runs."""
         if mask is not None:
-            raise NotImplementedError("mask is None in every call site of the hot path")
+            # upstream hands ONE mask to the 2048-token global transformer and to the 16-token local ones (SconeOcc.py:271, :301): no
+            # shape fits both, so no caller can pass one; PCTransformer.forward(mask=...) itself is supported
+            raise NotImplementedError("SconeOcc.forward(mask=...): upstream applies the same mask to sequences of 2048 and of 16 tokens")
         if not self._is_default_arch():
             raise NotImplementedError("the fused MI355X SconeOcc forward implements the reference's default architecture")
         n_clouds, full_seq_len = pc.shape[0], pc.shape[1]

@@ -84,13 +84,23 @@ class SconeVis(nn.Module):
         """pts [n_clouds, seq_len, 4], view_harmonics [n_clouds, seq_len, 64] -> [n_clouds, seq_len, 64].
         lengths (extension, optional int32 device tensor [n_clouds]): cloud b is its first lengths[b] rows; the rest of the
         batch is padding (the reference slices on the host instead, which costs a device->host sync per decision)."""
-        if mask is not None:
-            raise NotImplementedError("mask is None in every call site of the hot path (SURVEY §8 a6)")
         if not self._is_default_arch():
             raise NotImplementedError("the fused MI355X SconeVis forward implements the reference's default architecture")
         if view_harmonics is None:
             raise ValueError("view_harmonics is required (view_state_mode='end')")
         n_clouds, seq_len = pts.shape[0], pts.shape[1]
+        if mask is not None:
+            # An attention mask (SconeVis.py:121-141 hands it to every encoder): no call site of the hot path builds one, so the
+            # fused launch sequence does not carry it; the same kernels run block by block (inference only).
+            if lengths is not None or A.needs_grad(self, pts, view_harmonics):
+                raise NotImplementedError("SconeVis.forward(mask=...) is the inference path without `lengths`")
+            x = self.embedding(pts)
+            for enc in self.encoders:
+                x = enc(x, mask=mask)
+            res = ops.layernorm(x, _f32c(self.norm.weight), _f32c(self.norm.bias))
+            res = ops.linear(res, _f32c(self.fc1.weight), _f32c(self.fc1.bias), gelu=True)
+            res = ops.linear(torch.cat((res, view_harmonics), dim=-1), _f32c(self.fc2.weight), _f32c(self.fc2.bias), gelu=True)
+            return ops.linear(res, _f32c(self.fc3.weight), _f32c(self.fc3.bias)).view(n_clouds, seq_len, self.n_harmonics)
         hip = lambda p, vh: ops.scone_vis_forward(p, vh, self._table_cache.get(self, self.weight_table), lengths)
         if A.needs_grad(self, pts, view_harmonics):     # trainers (pretrain_scone_vis.py:224): HIP forward, composite-torch backward
             res = A.with_torch_backward(hip, lambda p, vh: A.scone_vis(self, p, vh, lengths), (pts, view_harmonics), self)

@@ -141,16 +141,58 @@ def layernorm(x, weight, bias):
     return y.reshape(*lead, E)
 
 
-def attention_packed(qkv, n_heads, qk_dim, v_dim, split=True):
+def _mask_bytes(mask, S, H, L, device):
+    """A reference-style attention mask -> (uint8 device tensor [s, h, q, L], seq / head / query strides in bytes) for
+    mcr_attention_masked.  Accepted: whatever broadcasts against the [S, H, L, L] scores the way upstream's
+    `scores.masked_fill(mask == 0, -1e3)` does (Attention.py:24-27) -- [L, L], [S, 1, L, L], [1, 1, L, L], [S, H, L, L] -- plus
+    [S, L, L] (the shape upstream's docstrings name: read as [S, 1, L, L]) and key masks [S, L] (a 2-D mask of shape [L, L] is
+    upstream's; use key_mask() to force the key reading when S == L) / [S, 1, 1, L].  Non-zero = attend."""
+    m = mask if torch.is_tensor(mask) else torch.as_tensor(mask)
+    m = (m != 0).to(device=device, dtype=torch.uint8)
+    if m.dim() == 2 and tuple(m.shape) == (L, L):
+        m4 = m.view(1, 1, L, L)
+    elif m.dim() == 2 and tuple(m.shape) == (S, L):
+        m4 = m.view(S, 1, 1, L)
+    elif m.dim() == 3 and tuple(m.shape) == (S, L, L):
+        m4 = m.view(S, 1, L, L)
+    elif m.dim() == 4 and m.shape[3] == L and m.shape[2] in (1, L) and m.shape[0] in (1, S) and m.shape[1] in (1, H):
+        m4 = m
+    else:
+        raise ValueError(f"attention mask of shape {tuple(m.shape)} does not fit {S} sequences x {H} heads x {L} tokens")
+    m4 = m4.contiguous()
+    s_seq = m4.stride(0) if m4.shape[0] > 1 else 0
+    s_head = m4.stride(1) if m4.shape[1] > 1 else 0
+    s_q = m4.stride(2) if m4.shape[2] > 1 else 0
+    return m4, s_seq, s_head, s_q
+
+
+def key_mask(mask, S, L, device):
+    """[S, L] key mask as the [S, 1, 1, L] form _mask_bytes takes (also when S == L)."""
+    m = mask if torch.is_tensor(mask) else torch.as_tensor(mask)
+    if tuple(m.shape) != (S, L):
+        raise ValueError(f"key mask must be [S, L] = {(S, L)}, got {tuple(m.shape)}")
+    return (m != 0).to(device=device, dtype=torch.uint8).view(S, 1, 1, L)
+
+
+def attention_packed(qkv, n_heads, qk_dim, v_dim, split=True, mask=None):
     """qkv [S, L, 2*qk_dim + v_dim] -> [S, L, v_dim]; attention() + head split/merge of Attention.py:8-36,174-198.
-    split=True hands the kernel a scratch buffer so that one or two long sequences can split their keys over two blocks."""
+    split=True hands the kernel a scratch buffer so that one or two long sequences can split their keys over two blocks.
+    mask (optional): see _mask_bytes; masked pairs score -1e3 before the 1/sqrt(d) scale, as upstream (:24-27)."""
     qkv = _req(qkv, "qkv")
     S, L, W = qkv.shape
     if W != 2 * qk_dim + v_dim:
         raise ValueError("packed qkv width mismatch")
     out = torch.empty((S, L, v_dim), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        if split and L >= 512 and -(-L // 64) * n_heads * S <= 256:      # the kernel's own key-split predicate (launch_attention)
+        use_ws = split and L >= 512 and -(-L // 64) * n_heads * S <= 256      # the kernel's own key-split predicate (launch_attention)
+        if mask is not None:
+            m4, s_seq, s_head, s_q = _mask_bytes(mask, S, n_heads, L, qkv.device)
+            ws = _workspace(qkv.device, int(lib().mcr_attention_workspace_bytes(c_i64(S), c_i64(L), c_int(n_heads), c_int(v_dim)))) if use_ws else None
+            check(lib().mcr_attention_masked(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads), c_int(qk_dim),
+                                             c_int(v_dim), _p(m4), c_i64(s_seq), c_i64(s_head), c_i64(s_q),
+                                             _p(ws) if ws is not None else c_vp(0), ctypes.c_size_t(ws.numel() if ws is not None else 0),
+                                             _stream()), "mcr_attention_masked")
+        elif use_ws:
             ws = _workspace(qkv.device, int(lib().mcr_attention_workspace_bytes(c_i64(S), c_i64(L), c_int(n_heads), c_int(v_dim))))
             check(lib().mcr_attention_ws(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads),
                                          c_int(qk_dim), c_int(v_dim), _p(ws), ctypes.c_size_t(ws.numel()), _stream()), "mcr_attention_ws")

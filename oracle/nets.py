@@ -28,9 +28,12 @@ def layernorm(sd, name, x, eps=1e-5):
             + sd[name + ".bias"].astype(x.dtype)).astype(x.dtype)
 
 
-def attention(q, k, v):
-    """Attention.py:8-36 (mask None): q,k [...,N,d], v [...,N,dv]."""
+def attention(q, k, v, mask=None):
+    """Attention.py:8-36: q,k [...,N,d], v [...,N,dv]; mask (optional, broadcastable to the scores): where it is 0 the score is
+    REPLACED by -1e3 before the division by sqrt(d) (:24-27)."""
     s = q @ np.swapaxes(k, -1, -2)
+    if mask is not None:
+        s = np.where(np.asarray(mask) == 0, q.dtype.type(-1e3), s)
     s = s / np.sqrt(q.dtype.type(q.shape[-1]))
     s = s - s.max(-1, keepdims=True)
     e = np.exp(s)
@@ -47,26 +50,26 @@ def embedding(sd, pre, x, global_feature):
     return np.concatenate(parts, axis=-1).astype(x.dtype)
 
 
-def mhsa(sd, pre, x, n_heads):
+def mhsa(sd, pre, x, n_heads, mask=None):
     B, N, E = x.shape
     q, k, v = _lin(sd, pre + ".w_q", x), _lin(sd, pre + ".w_k", x), _lin(sd, pre + ".w_v", x)
     sp = lambda t: t.reshape(B, N, n_heads, -1).transpose(0, 2, 1, 3)           # :174-176,195
-    o = attention(sp(q), sp(k), sp(v)).transpose(0, 2, 1, 3).reshape(B, N, E)
+    o = attention(sp(q), sp(k), sp(v), mask).transpose(0, 2, 1, 3).reshape(B, N, E)
     return _lin(sd, pre + ".out", o)
 
 
-def encoder(sd, pre, x, n_heads=4):
-    res = x + mhsa(sd, pre + ".mhsa", layernorm(sd, pre + ".norm1", x), n_heads)                      # :287-290
+def encoder(sd, pre, x, n_heads=4, mask=None):
+    res = x + mhsa(sd, pre + ".mhsa", layernorm(sd, pre + ".norm1", x), n_heads, mask)                # :287-290
     ffin = layernorm(sd, pre + ".norm2", res)
     return (res + _lin(sd, pre + ".ff.linear2", gelu(_lin(sd, pre + ".ff.linear1", ffin)))).astype(x.dtype)   # :293-298
 
 
-def scone_vis_forward(sd, pts, view_harmonics, dtype=np.float32, n_code=3):
+def scone_vis_forward(sd, pts, view_harmonics, dtype=np.float32, n_code=3, mask=None):
     pts = np.asarray(pts, dtype)
     vh = np.asarray(view_harmonics, dtype)
     x = embedding(sd, "embedding", pts, True)
     for i in range(n_code):
-        x = encoder(sd, f"encoders.{i}", x)
+        x = encoder(sd, f"encoders.{i}", x, mask=mask)
     res = layernorm(sd, "norm", x)
     res = gelu(_lin(sd, "fc1", res))
     res = np.concatenate((res, vh), axis=-1)
@@ -74,11 +77,11 @@ def scone_vis_forward(sd, pts, view_harmonics, dtype=np.float32, n_code=3):
     return _lin(sd, "fc3", res).astype(dtype)
 
 
-def pc_transformer(sd, pre, pc, dtype=np.float32, n_code=2):
+def pc_transformer(sd, pre, pc, dtype=np.float32, n_code=2, mask=None):
     pc = np.asarray(pc, dtype)
     x = embedding(sd, pre + "embedding", pc, False)
     for i in range(n_code):
-        x = encoder(sd, f"{pre}encoders.{i}", x)
+        x = encoder(sd, f"{pre}encoders.{i}", x, mask=mask)
     f = _lin(sd, pre + "linear0", layernorm(sd, pre + "norm", x))
     return np.concatenate((f.max(axis=1), f.mean(axis=1)), axis=-1).astype(dtype)       # max || avg pooling
 

@@ -161,6 +161,50 @@ def gen_blocks():
     save("blocks", **out)
 
 
+def gen_masked():
+    """attention / Encoder / SconeVis.forward / PCTransformer.forward WITH a mask (Attention.py:24-27: masked_fill(mask == 0, -1e3)
+    BEFORE the division by sqrt(d)): random [B,1,N,N] masks incl. a fully masked query row (which attends uniformly over the keys --
+    the -1e3 rule, not -inf) and a fully masked key column, a [N,N] mask shared by the batch, for both dimension sets of the hot
+    path; 130 tokens (MFMA kernel, ragged last tile), 16 tokens (neighbourhood kernel) and 520 tokens (key split; every 4th query
+    row stored).  Inputs are fp16-representable (stored as fp16: half the bytes, exact in fp32)."""
+    A = ref["Attention"]
+    rng = np.random.default_rng(37)
+    h = lambda a: np.asarray(a, np.float16)
+    out = {}
+    for tag, (E, qk, N, Bb) in {"vis": (256, 64, 130, 1), "occ": (128, 32, 16, 9), "long": (128, 32, 520, 1)}.items():
+        q, k = h(rng.standard_normal((Bb, 4, N, qk // 4))), h(rng.standard_normal((Bb, 4, N, qk // 4)))
+        v = h(rng.standard_normal((Bb, 4, N, E // 4)))
+        mask = (rng.random((Bb, 1, N, N)) < 0.6)
+        mask[0, 0, 3, :] = False                     # a query with every key masked
+        mask[-1, 0, :, 5] = False                    # a key nobody may attend to
+        mask[0, 0, 7, :] = True
+        f = lambda a: t(a.astype(np.float32))
+        with torch.no_grad():
+            out[f"{tag}_q"], out[f"{tag}_k"], out[f"{tag}_v"], out[f"{tag}_mask"] = q, k, v, np.packbits(mask)
+            att = A.attention(f(q), f(k), f(v), mask=torch.from_numpy(mask)).numpy()
+            out[f"{tag}_att"] = att if tag != "long" else att[:, :, ::4]
+            if tag != "long":
+                x = h(rng.standard_normal((Bb, N, E)))
+                enc = _load(A.Encoder(seq_len=N, qk_dim=qk, embedding_dim=E, n_heads=4), 100 + E)
+                out[f"{tag}_x"] = x
+                out[f"{tag}_enc"] = enc(f(x), mask=torch.from_numpy(mask)).numpy()
+                if tag == "occ":
+                    out[f"{tag}_att_shared"] = A.attention(f(q), f(k), f(v), mask=torch.from_numpy(mask[0, 0])).numpy()   # [N,N]: broadcast over batch and heads
+    vis = _load(ref["SconeVis"].SconeVis(), 1)
+    N = 150
+    pts = h(np.concatenate([rng.uniform(-0.5, 0.5, (2, N, 3)), rng.uniform(0.1, 1, (2, N, 1))], -1))
+    vh = h(rng.standard_normal((2, N, 64)) * 0.3)
+    mask = (rng.random((2, 1, N, N)) < 0.7)
+    mask[1, 0, 10, :] = False
+    pct = _load(ref["SconeOcc"].PCTransformer(seq_len=N, pts_embedding_dim=128, feature_dim=512), 12)
+    pc = h(rng.uniform(-0.4, 0.4, (2, N, 3)))
+    f = lambda a: t(a.astype(np.float32))
+    with torch.no_grad():
+        out.update(sv_pts=pts, sv_vh=vh, sv_mask=np.packbits(mask), sv_y=vis(f(pts), mask=torch.from_numpy(mask), view_harmonics=f(vh)).numpy(),
+                   pct_pc=pc, pct_y=pct(f(pc), mask=torch.from_numpy(mask)).numpy())
+    save("blocks_masked", **out)
+
+
 def gen_vis():
     """G5: SconeVis.forward with deterministic weights (tests/golden/weights.py, seed 1)."""
     m = _load(ref["SconeVis"].SconeVis(), 1)
@@ -1488,7 +1532,7 @@ def gen_trajectory():
     save("macarons_trajectory", **out)
 
 
-GROUPS = {"trajectory": gen_trajectory, "decision": gen_decision, "occ_field": gen_occ_field, "formats": gen_formats, "e2e_grid": gen_e2e_grid, "fov": gen_fov, "distance": gen_distance, "wrapper": gen_macarons_wrapper, "single_camera": gen_single_camera, "cell": gen_cell, "unproject": gen_unproject, "viewspace": gen_viewspace, "filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
+GROUPS = {"masked": gen_masked, "trajectory": gen_trajectory, "decision": gen_decision, "occ_field": gen_occ_field, "formats": gen_formats, "e2e_grid": gen_e2e_grid, "fov": gen_fov, "distance": gen_distance, "wrapper": gen_macarons_wrapper, "single_camera": gen_single_camera, "cell": gen_cell, "unproject": gen_unproject, "viewspace": gen_viewspace, "filter": gen_filter, "macarons": gen_macarons, "e2e": gen_e2e, "view": gen_view, "scorer": gen_scorer, "sh": gen_sh, "knn": gen_knn, "blocks": gen_blocks, "vis": gen_vis, "occ": gen_occ}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

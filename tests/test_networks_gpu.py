@@ -556,3 +556,48 @@ def test_scone_occ_two_call_forward_equals_the_single_call(dev, B, M, Q):
         six = m(pc, x, vh, perms=perms, begun=h5)
         assert torch.equal(one, six)
     assert float(scratch) == float(scratch)
+
+
+def test_masked_attention_matches_reference(dev):
+    """attention / Encoder / SconeVis.forward / PCTransformer.forward with a MASK vs the reference's own outputs (make_golden.py:
+    gen_masked; Attention.py:24-27: the score of a masked pair is replaced by -1e3 BEFORE the division by sqrt(d) -- not -inf: a
+    query with every key masked attends uniformly).  [B,1,N,N] masks on the 16-token kernel, the MFMA kernel (130 tokens: a ragged
+    last tile) and its key-split form (520 tokens), a [N,N] mask shared by batch and heads, the [B,N,N] reading and a [B,N] key mask."""
+    from macarons_amd.networks import SconeVis, Attention as A
+    from macarons_amd.networks.SconeOcc import PCTransformer
+    from macarons_amd import ops
+    g = golden("blocks_masked")
+    f = lambda a: T(np.asarray(a, np.float32), dev)
+    um = lambda key, shape: np.unpackbits(g[key])[:int(np.prod(shape))].reshape(shape).astype(bool)
+    with torch.no_grad():
+        for tag, (E, qk, N, Bb) in {"vis": (256, 64, 130, 1), "occ": (128, 32, 16, 9), "long": (128, 32, 520, 1)}.items():
+            mask = um(f"{tag}_mask", (Bb, 1, N, N))
+            y = A.attention(f(g[f"{tag}_q"]), f(g[f"{tag}_k"]), f(g[f"{tag}_v"]), mask=torch.from_numpy(mask)).cpu().numpy()
+            assert rel_err(y if tag != "long" else y[:, :, ::4], g[f"{tag}_att"]) < TOL, tag
+            vmean = np.asarray(g[f"{tag}_v"], np.float32)[0].mean(axis=1)
+            assert rel_err(y[0, :, 3], vmean) < TOL, tag                          # the fully masked query: uniform weights (-1e3, not -inf)
+            y3 = A.attention(f(g[f"{tag}_q"]), f(g[f"{tag}_k"]), f(g[f"{tag}_v"]), mask=torch.from_numpy(mask[:, 0]).to(dev)).cpu().numpy()
+            assert np.array_equal(y3, y), tag                                       # [B,N,N] on the device == [B,1,N,N] from the host
+            if tag != "long":
+                enc, _ = _mod(lambda: A.Encoder(seq_len=N, qk_dim=qk, embedding_dim=E, n_heads=4), 100 + E, dev)
+                assert rel_err(enc(f(g[f"{tag}_x"]), mask=torch.from_numpy(mask)).cpu().numpy(), g[f"{tag}_enc"]) < TOL, tag
+        shared = um("occ_mask", (9, 1, 16, 16))[0, 0]
+        y = A.attention(f(g["occ_q"]), f(g["occ_k"]), f(g["occ_v"]), mask=torch.from_numpy(shared)).cpu().numpy()
+        assert rel_err(y, g["occ_att_shared"]) < TOL
+        # a [B,N] key mask == the [B,1,N,N] mask with every query row equal to it
+        km = um("vis_mask", (1, 1, 130, 130))[:, 0, 9]                   # one row of the random mask as the key mask
+        q, k, v = f(g["vis_q"]), f(g["vis_k"]), f(g["vis_v"])
+        full = np.broadcast_to(km[:, None, None, :], (1, 1, 130, 130)).copy()
+        a_ = A.attention(q, k, v, mask=torch.from_numpy(full))
+        b_ = A.attention(q, k, v, mask=ops.key_mask(torch.from_numpy(km), 1, 130, dev))
+        assert torch.equal(a_, b_)
+        vis, _ = _mod(SconeVis, 1, dev)
+        m = um("sv_mask", (2, 1, 150, 150))
+        y = vis(f(g["sv_pts"]), mask=torch.from_numpy(m), view_harmonics=f(g["sv_vh"])).cpu().numpy()
+        assert rel_err(y, g["sv_y"]) < TOL
+        all_on = vis(f(g["sv_pts"]), mask=torch.ones(2, 1, 150, 150, dtype=torch.bool), view_harmonics=f(g["sv_vh"]))
+        assert rel_err(all_on.cpu().numpy(), vis(f(g["sv_pts"]), view_harmonics=f(g["sv_vh"])).cpu().numpy()) < 2e-6    # mask of ones == no mask
+        pct, _ = _mod(lambda: PCTransformer(seq_len=150, pts_embedding_dim=128, feature_dim=512), 12, dev)
+        assert rel_err(pct(f(g["pct_pc"]), mask=torch.from_numpy(m)).cpu().numpy(), g["pct_y"]) < TOL
+        with pytest.raises(ValueError):
+            A.attention(q, k, v, mask=torch.ones(3, 130))

@@ -488,3 +488,39 @@ def test_trajectory_coverage_oracle_matches_reference():
         n_cov = sum(int((S.min_dist(gt[c], covered[c]) < float(g["eps_cov"])).sum()) for c in cells if len(gt[c]) and len(covered[c]))
         assert n_cov / n_gt == float(g["coverage"][step]), (step, n_cov / n_gt, float(g["coverage"][step]))
     assert float(g["coverage"][-1]) > float(g["coverage"][0]) + 0.25                    # the trajectory does uncover the surface
+
+
+def _unpack_mask(g, key, shape):
+    return np.unpackbits(g[key])[:int(np.prod(shape))].reshape(shape).astype(bool)
+
+
+def test_masked_attention_oracle_matches_reference():
+    """oracle.nets with a mask == the reference's attention / Encoder / SconeVis.forward / PCTransformer.forward(mask=...)
+    (Attention.py:24-27: masked_fill(mask == 0, -1e3) BEFORE the 1/sqrt(d) scale), incl. a fully masked query row."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import weights
+    from oracle import nets
+    from macarons_amd.networks import SconeVis, Attention as A
+    from macarons_amd.networks.SconeOcc import PCTransformer
+    g = golden("blocks_masked")
+    f = lambda a: np.asarray(a, np.float32)
+    for tag, (E, qk, N, Bb) in {"vis": (256, 64, 130, 1), "occ": (128, 32, 16, 9), "long": (128, 32, 520, 1)}.items():
+        mask = _unpack_mask(g, f"{tag}_mask", (Bb, 1, N, N))
+        y = nets.attention(f(g[f"{tag}_q"]), f(g[f"{tag}_k"]), f(g[f"{tag}_v"]), mask)
+        ref = g[f"{tag}_att"]
+        assert rel_err(y if tag != "long" else y[:, :, ::4], ref) < 1e-5, tag
+        # the fully masked query attends UNIFORMLY (every score -1e3): its output is the mean of the values
+        assert rel_err(y[0, :, 3], f(g[f"{tag}_v"])[0].mean(axis=1)) < 1e-5, tag
+        if tag != "long":
+            enc = A.Encoder(seq_len=N, qk_dim=qk, embedding_dim=E, n_heads=4)
+            sd = weights.make_state_dict(weights.shapes_of(enc), 100 + E)
+            assert rel_err(nets.encoder({"e." + k_: v_ for k_, v_ in sd.items()}, "e", f(g[f"{tag}_x"]), 4, mask), g[f"{tag}_enc"]) < 1e-5, tag
+    assert rel_err(nets.attention(f(g["occ_q"]), f(g["occ_k"]), f(g["occ_v"]), _unpack_mask(g, "occ_mask", (9, 1, 16, 16))[0, 0]), g["occ_att_shared"]) < 1e-5
+    _, sdv = _weights(SconeVis, 1)
+    m = _unpack_mask(g, "sv_mask", (2, 1, 150, 150))
+    assert rel_err(nets.scone_vis_forward(sdv, f(g["sv_pts"]), f(g["sv_vh"]), mask=m), g["sv_y"]) < 1e-5
+    pct = PCTransformer(seq_len=150, pts_embedding_dim=128, feature_dim=512)
+    sdp = weights.make_state_dict(weights.shapes_of(pct), 12)
+    assert rel_err(nets.pc_transformer(sdp, "", f(g["pct_pc"]), mask=m), g["pct_y"]) < 1e-5
