@@ -601,3 +601,20 @@ def test_masked_attention_matches_reference(dev):
         assert rel_err(pct(f(g["pct_pc"]), mask=torch.from_numpy(m)).cpu().numpy(), g["pct_y"]) < TOL
         with pytest.raises(ValueError):
             A.attention(q, k, v, mask=torch.ones(3, 130))
+
+
+def test_one_cloud_returns_the_bits_it_has_inside_a_batch_of_30(dev):
+    """Launch-shape independence of the 2048-token encoders at the sizes of a MACARONS decision: SconeVis on ONE cloud (narrow column
+    tiles, key-split attention) must return, bit for bit, the rows it returns for that cloud inside a batch of 30 (the neighbour
+    cameras: wide tiles) -- at 2048 tokens and at a ragged 1500."""
+    from macarons_amd.networks import SconeVis
+    vis, _ = _mod(SconeVis, 1, dev)
+    rng = np.random.default_rng(77)
+    for N in (2048, 1500):
+        pts = T(np.concatenate([rng.uniform(-.5, .5, (30, N, 3)), rng.uniform(.1, 1, (30, N, 1))], -1).astype(np.float32), dev)
+        vh = T((rng.standard_normal((30, N, 64)) * .3).astype(np.float32), dev)
+        with torch.no_grad():
+            big = vis(pts, view_harmonics=vh)
+            for b in (0, 17, 29):
+                one = vis(pts[b:b + 1].contiguous(), view_harmonics=vh[b:b + 1].contiguous())
+                assert torch.equal(one[0], big[b]), (N, b)
