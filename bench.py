@@ -362,6 +362,9 @@ def measure_macarons_step(dev, rank=0, world=1):
         dt = max_over_ranks(time.perf_counter() - t0, dev, dist)
         if it >= 2:
             times.append(dt)
+        info = {"field_points": int(r["X_world"].shape[0]), "next_idx": nxt}
+        if os.environ.get("MCR_BENCH_NO_CHECKS"):          # (kernel traces of the decision alone: tools/trace_macarons_step.sh)
+            continue
         # ---- invariants at full size (outside the timed region)
         fm = r["fov_mask"]
         n_fov = int(fm.sum())
@@ -389,7 +392,27 @@ def measure_macarons_step(dev, rank=0, world=1):
         info = {"field_points": int(r["X_world"].shape[0]), "proxy_in_fov": n_fov, "next_idx": nxt}
     p50 = float(np.median(times))
     checks["all_hold"] = all(v for k_, v in checks.items() if k_ != "iterations")
+    # the same decision with the hidden permutations drawn on the device (opt-in perm_source="device": no host randperm loop)
+    times_d = []
+    for it in range(2 + 9):
+        cam, depth, dmask, recs, ne = poses[it % 3]
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, depth, dmask, recs, ne, dev, group=group, perm_source="device")
+        int(r["next_idx"])
+        torch.cuda.synchronize()
+        dt = max_over_ranks(time.perf_counter() - t0, dev, dist)
+        if it >= 2:
+            times_d.append(dt)
+    p50_d = float(np.median(times_d))
     return {"p50_ms": p50 * 1e3, "evals_per_s": K / p50, "iters": len(times), "last": info, "checks": checks, "scaling": "strong",
+            "device_perms": {"p50_ms": p50_d * 1e3, "evals_per_s": K / p50_d,
+                             "note": "perm_source='device' (opt-in): Cell.fill subsets and SconeOcc down-samples drawn on the GPU by segmented "
+                                     "sorts instead of ~190 torch.randperm calls on the CPU generator; p50_ms above is the default "
+                                     "(the reference's CPU-generator order, the one the goldens pin)"},
             "config": {"workload": "MACARONS decision (BASELINE config 5 minus the depth network): 100000 proxy points, 3x8x3 grid, "
                                    "30 neighbour cameras, 256x456 depth map, seq_len 2048", "cams": K, "proxy_points": P,
                        "parallelism": f"field-row + neighbour-camera shard x{world}" if world > 1 else "1 GPU"}}

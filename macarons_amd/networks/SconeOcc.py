@@ -199,12 +199,54 @@ class SconeOcc(nn.Module):
             return pc[:, p].contiguous()
         return torch.gather(pc, 1, p[..., None].expand(-1, -1, pc.shape[-1])).contiguous()
 
-    def forward_ragged(self, pc, cloud_sizes, x, view_harmonics, query_sizes, perms=None):
+    def ragged_index_arrays_device(self, cloud_sizes, device):
+        """The down-sample index arrays of forward_ragged drawn ON THE DEVICE (perm_source="device"): per job three uniformly random
+        permutation prefixes, as SconeOcc.py:269 / :311 take them, from torch's device generator -- one float64 key per element, ONE
+        segmented sort per scale, no host loop (the ~3 J torch.randperm draws of the default path are 2 ms of CPU generator work per
+        MACARONS decision).  Not the reference's CPU-generator stream: statistically the same draws, different numbers (opt-in).
+        -> dict(g_idx int64 [J*Lg], g_len int32 [J], idx1, idx2 int64, off1, off2 int64 [J+1]) as forward_ragged(index_arrays=...) takes."""
+        J, Lg = len(cloud_sizes), self.seq_len
+        sizes = [self.scale_sizes(int(m)) for m in cloud_sizes]
+        m0, m1, m2 = [s_[0] for s_ in sizes], [s_[1] for s_ in sizes], [s_[2] for s_ in sizes]
+        cum = lambda v: np.concatenate(([0], np.cumsum(v))).astype(np.int64)
+        o0, o1, o2 = cum(m0), cum(m1), cum(m2)
+        n0 = [min(m, Lg) for m in m0]
+        host = ops.h2d(np.concatenate([o0, o1, o2, np.asarray(m0, np.int64), np.asarray(m1, np.int64), np.asarray(m2, np.int64),
+                                       np.asarray(n0, np.int64)]), torch.int64, device)
+        d_o0, d_o1, d_o2 = host[:J + 1], host[J + 1:2 * J + 2], host[2 * J + 2:3 * J + 3]
+        d_m0, d_m1, d_m2, d_n0 = (host[3 * J + 3 + k * J:3 * J + 3 + (k + 1) * J] for k in range(4))
+
+        def seg_perm(lens, offs, total):
+            """-> (seg [total], rank-sorted local index [total]): position off_j + r holds the r-th element of a random permutation of
+            [0, len_j).  Composite key = segment + uniform in [0, 1) in float64 (no collisions worth a bias), one sort."""
+            seg = torch.repeat_interleave(torch.arange(J, device=device), lens, output_size=total)
+            order = torch.argsort(seg.double() + torch.rand(total, dtype=torch.float64, device=device))
+            return seg, order - offs[seg]
+        T0, T1, T2 = int(o0[-1]), int(o1[-1]), int(o2[-1])
+        seg0, loc0 = seg_perm(d_m0, d_o0, T0)                                   # global down-sample: randperm(M)[:Lg]
+        r0 = torch.arange(T0, device=device) - d_o0[seg0]
+        keep = r0 < Lg
+        g_idx = d_o0[:J].view(J, 1).expand(J, Lg).clone()                       # padding rows: any valid point (masked by global_len)
+        g_idx[seg0[keep], r0[keep]] = (d_o0[seg0] + loc0)[keep]
+        seg1, loc1 = seg_perm(d_m0, d_o0, T0)                                   # scale 0 -> 1: randperm(M)[:M // ds]
+        r1 = torch.arange(T0, device=device) - d_o0[seg1]
+        k1 = r1 < d_m1[seg1]
+        idx1 = (d_o0[seg1] + loc1)[k1]
+        seg2, loc2 = seg_perm(d_m1, d_o1, T1)                                   # scale 1 -> 2: randperm(M // ds)[:(M // ds) // ds]
+        r2 = torch.arange(T1, device=device) - d_o1[seg2]
+        k2 = r2 < d_m2[seg2]
+        idx2 = (d_o1[seg2] + loc2)[k2]
+        assert idx1.numel() == T1 and idx2.numel() == T2
+        return {"g_idx": g_idx.reshape(-1), "g_len": d_n0.to(torch.int32), "idx1": idx1, "idx2": idx2, "off1": d_o1, "off2": d_o2}
+
+    def forward_ragged(self, pc, cloud_sizes, x, view_harmonics, query_sizes, perms=None, index_arrays=None, perm_source="host"):
         """J forward() calls of different sizes as ONE launch sequence (extension; the reference calls forward once per grid cell and
         chunk from a Python loop, macarons_utils.py:1395-1540).  Job j: surface cloud = the next cloud_sizes[j] rows of pc [sum M, 3],
         queries = the next query_sizes[j] rows of x [T,3] / view_harmonics [T,64] (host lists).  perms: per job the three index
         tensors draw_perms(cloud_sizes[j]) returns; None = drawn here in job order on the CPU generator, exactly the draws J
-        sequential forward() calls would make.  -> [T,1].  Inference only (no autograd graph)."""
+        sequential forward() calls would make -- or, perm_source="device" (opt-in), on the device by ragged_index_arrays_device();
+        index_arrays: what that function returns (a caller that repeats a pass, or hands rank 0's draws to every rank).
+        -> [T,1].  Inference only (no autograd graph)."""
         if not self._is_default_arch() or not self.fused_local:
             raise NotImplementedError("forward_ragged implements the default architecture on the fused local-transformer path")
         dev = x.device
@@ -241,39 +283,49 @@ class SconeOcc(nn.Module):
         with torch.no_grad():
             phase1(variant)
         epoch1 = ops.scone_occ_epoch(dev, "scone_occ_ragged")
-        if perms is None:
-            perms = [self.draw_perms(int(m)) for m in cloud_sizes]
-        self.last_ragged_perms = perms                                 # (a caller that repeats the pass on another variant re-uses the draws)
-        # ---- index arrays of the down-sampled clouds, built on the host from the draws, ONE upload
-        g_idx = np.zeros((J, Lg), np.int64)
-        g_len = np.zeros(J, np.int32)
-        idx1, idx2, off1, off2 = [], [], [0], [0]
-        for j, (p0, p1, p2) in enumerate(perms):
-            p0, p1, p2 = (np.asarray(p0, dtype=np.int64), np.asarray(p1, dtype=np.int64), np.asarray(p2, dtype=np.int64))
-            n0 = min(len(p0), Lg)
-            g_idx[j, :n0] = off0[j] + p0[:n0]
-            g_idx[j, n0:] = off0[j]                                  # padding rows: any valid point (masked by global_len)
-            g_len[j] = n0
-            idx1.append(off0[j] + p1)
-            idx2.append(off1[-1] + p2)                               # scale 2 indexes scale 1's rows (SconeOcc.py:311)
-            off1.append(off1[-1] + len(p1))
-            off2.append(off2[-1] + len(p2))
-        ints = np.concatenate([g_idx.reshape(-1), np.concatenate(idx1), np.concatenate(idx2), np.asarray(off1, np.int64),
-                               np.asarray(off2, np.int64), g_len.astype(np.int64)])
-        d = ops.h2d(ints, torch.int64, dev)
-        cut, o = [], 0
-        for n in (J * Lg, off1[-1], off2[-1], J + 1, J + 1, J):
-            cut.append(d[o:o + n]); o += n
-        pc_global = pc[cut[0]].view(J, Lg, 3)
-        pc1 = pc[cut[1]]
-        pc2 = pc1[cut[2]]
-        g_len_d = cut[5].to(torch.int32)
+        if index_arrays is None and perms is None and perm_source == "device":
+            index_arrays = self.ragged_index_arrays_device(cloud_sizes, dev)
+        if index_arrays is not None:
+            ia = index_arrays
+            self.last_ragged_perms = ia                                    # (a caller that repeats the pass on another variant re-uses the draws)
+            pc_global = pc[ia["g_idx"]].view(J, Lg, 3)
+            pc1 = pc[ia["idx1"]]
+            pc2 = pc1[ia["idx2"]]
+            g_len_d, d_off1, d_off2 = ia["g_len"], ia["off1"], ia["off2"]
+        else:
+            if perms is None:
+                perms = [self.draw_perms(int(m)) for m in cloud_sizes]
+            self.last_ragged_perms = perms
+            # ---- index arrays of the down-sampled clouds, built on the host from the draws, ONE upload
+            g_idx = np.zeros((J, Lg), np.int64)
+            g_len = np.zeros(J, np.int32)
+            idx1, idx2, off1, off2 = [], [], [0], [0]
+            for j, (p0, p1, p2) in enumerate(perms):
+                p0, p1, p2 = (np.asarray(p0, dtype=np.int64), np.asarray(p1, dtype=np.int64), np.asarray(p2, dtype=np.int64))
+                n0 = min(len(p0), Lg)
+                g_idx[j, :n0] = off0[j] + p0[:n0]
+                g_idx[j, n0:] = off0[j]                                  # padding rows: any valid point (masked by global_len)
+                g_len[j] = n0
+                idx1.append(off0[j] + p1)
+                idx2.append(off1[-1] + p2)                               # scale 2 indexes scale 1's rows (SconeOcc.py:311)
+                off1.append(off1[-1] + len(p1))
+                off2.append(off2[-1] + len(p2))
+            ints = np.concatenate([g_idx.reshape(-1), np.concatenate(idx1), np.concatenate(idx2), np.asarray(off1, np.int64),
+                                   np.asarray(off2, np.int64), g_len.astype(np.int64)])
+            d = ops.h2d(ints, torch.int64, dev)
+            cut, o = [], 0
+            for n in (J * Lg, off1[-1], off2[-1], J + 1, J + 1, J):
+                cut.append(d[o:o + n]); o += n
+            pc_global = pc[cut[0]].view(J, Lg, 3)
+            pc1 = pc[cut[1]]
+            pc2 = pc1[cut[2]]
+            g_len_d, d_off1, d_off2 = cut[5].to(torch.int32), cut[3], cut[4]
 
         def run(v, flag, redo_phase1):
             if redo_phase1:
                 phase1(v)
             blobs, head, table = state[v] if v in state else caches(v)
-            return ops.scone_occ_forward_ragged(pc_global, g_len_d, [pc, pc1, pc2], [d_off0, cut[3], cut[4]], x, view_harmonics,
+            return ops.scone_occ_forward_ragged(pc_global, g_len_d, [pc, pc1, pc2], [d_off0, d_off1, d_off2], x, view_harmonics,
                                                 d_row_job, d_blocks, table, blobs, head, flag, phase=2)
         flag = None
         if variant == 6 and self.range_guard != "off":

@@ -74,9 +74,11 @@ def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harm
     mask = ops.points_in_fov(X_world, cameras)                                            # :1603
     occ_k = ops.fov_mask_occ(mask, occ_probs.reshape(-1).contiguous())                    # :1606-1613 folded into the sampler
     # ---- sampling inside every frustum (:1624): K distributions over the ONE shared point set in one launch sequence, nothing
-    # read back (padded rows, counts on the device).  Uniforms: one torch.rand(S, 1) per camera in order, as K calls would draw.
+    # read back (padded rows, counts on the device).  Uniforms: ONE draw of [K, S] from the device generator (upstream draws
+    # torch.rand(S, 1) inside every per-camera call; 30 launches of a 2 us kernel are 0.35 ms of a host-bound decision -- callers that
+    # need particular uniforms pass `samples`).
     if samples is None:
-        u = torch.stack([torch.rand(S, 1, device=dev).view(-1) for _ in range(K)])
+        u = torch.rand(K, S, device=dev)
     elif torch.is_tensor(samples):
         u = samples.to(dev).reshape(K, S).float()
     else:
@@ -129,7 +131,7 @@ class SceneCamera:
 
 
 def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, depth, depth_mask, neighbor_records, X_neighbors,
-                          device, samples=None, return_signed_distances=False, range_guard=True, group=None):
+                          device, samples=None, return_signed_distances=False, range_guard=True, group=None, perm_source="host"):
     """One next-best-view decision of the MACARONS loop after the depth map of the current pose is known -- the body of
     testers/scene.py:391-454 (everything between the depth network and the move to the chosen pose):
       1. proxy points in the current frustum (Camera.get_points_in_fov :391), registered in the proxy grid (:394-395);
@@ -143,6 +145,9 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     point) and one 8-byte (gain, index) record per rank are all-gathered, the hidden draws (Cell.fill subsets, SconeOcc's
     down-samples, the sampling uniforms) are rank 0's; the cheap state updates run replicated.  Bit for bit the 1-rank decision;
     `gains` then holds this rank's cameras only (`cam_range`).
+    perm_source: "host" (default) draws the hidden permutations (Cell.fill's subsets, SconeOcc's down-samples) with torch.randperm on
+    the CPU generator in upstream's order -- what the reference goldens pin; "device" (opt-in, production) draws them on the GPU in
+    two segmented sorts (statistically the same, a different stream): ~190 host draws = 2.7 ms of CPU time per decision less.
     Returns dict(next_idx (device int64: index into the neighbour list), gains [K], fov_mask [P] bool, X_world, view_harmonics,
     occ_probs).  The scene objects are updated in place like upstream.  Host synchronisations: the cell counts of the occupancy-field
     pass (cell bookkeeping on the host, as upstream), fill_cells' one, and -- range_guard=True -- the range flag of the fp16-split
@@ -159,7 +164,7 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     fov_mask = ops.points_in_fov(proxy_scene.proxy_points, rec.view(1, 40))[0]
     fov_idx = proxy_scene.get_proxy_indices_from_mask(fov_mask)
     proxy_scene.fill_cells(proxy_scene.proxy_points[fov_idx.view(-1)], features=fov_idx.view(-1, 1).float(),   # (index, not mask: one read-back less)
-                           **({"group": group} if world > 1 else {}))
+                           **({"group": group} if world > 1 else {}), **({"perm_source": perm_source} if perm_source != "host" else {}))
     # 2 ---- carve with the depth map: signed distance, view states, supervision occupancy, out-of-field, one launch
     sgn = proxy_scene.update_from_depth(fov_mask, rec, ops.h2d(camera.X_cam, torch.float32, device), depth2, dmask2, fill=1.1 * camera.zfar,
                                         tol=params.carving_tolerance, return_signed_distances=return_signed_distances)
@@ -193,10 +198,11 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     def field_and_gains(ragged_perms, smp, record):
         X_world, view_harmonics, occ_probs = compute_scene_occupancy_probability_field(params, macarons, None, surface_scene, proxy_scene,
                                                                                        device, prediction_camera=Mv_field, ragged_perms=ragged_perms,
-                                                                                       group=group if world > 1 else None, record=record)
-        if world > 1:                                   # the uniforms of ALL cameras are rank 0's (one torch.rand(S, 1) per camera, in order)
+                                                                                       group=group if world > 1 else None, record=record,
+                                                                                       perm_source=perm_source)
+        if world > 1:                                   # the uniforms of ALL cameras are rank 0's
             if smp is None:
-                smp = torch.stack([torch.rand(S, 1, device=device).view(-1) for _ in range(K)])
+                smp = torch.rand(K, S, device=device)
                 _, smp = mdist.broadcast_draws([], smp, 0, group)
             elif not torch.is_tensor(smp):
                 smp = torch.stack([torch.as_tensor(x_, device=device).reshape(-1) for x_ in smp]).float()
@@ -381,7 +387,7 @@ def _grid_tables(scene, device):
 def compute_scene_occupancy_probability_field(params, macarons, camera, surface_scene, proxy_scene, device,
                                               use_supervision_occ_mask=True, prediction_camera=None,
                                               use_supervision_occ_instead_of_predicted=False, chunk=20000, ragged_perms=None,
-                                              group=None, record=None):
+                                              group=None, record=None, perm_source="host"):
     """Occupancy probability of every proxy point the cameras have seen (macarons_utils.py:1395-1540), as ONE batched pass.
 
     Upstream walks the grid cells that hold seen proxy points from Python: per cell it gathers the surface points of the 27-cell
@@ -400,7 +406,8 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
     ranks (every (cell, chunk) job is independent, and so is every query of a job given the job's cloud and draws), each
     rank runs the jobs its rows belong to, the occupancies (4 B per proxy point) are all-gathered; the hidden draws of ALL jobs are
     rank 0's, in job order, in one broadcast -- the result is bit for bit the 1-rank field.  `record` (dict): receives the draws
-    used (`ragged_perms`) so that a caller can repeat the pass."""
+    used (`ragged_perms`) so that a caller can repeat the pass.  perm_source="device" (opt-in): SconeOcc's hidden down-samples are
+    drawn on the device (SconeOcc.ragged_index_arrays_device) instead of ~3 torch.randperm calls per job on the host."""
     from . import scone_utils as su
     from .. import dist as mdist
     import torch.distributed as tdist
@@ -507,10 +514,16 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
             occ = ps.proxy_supervision_occ[rows]
         else:
             occ_net = getattr(macarons, "occupancy", macarons)
+            def ragged(pc_, sizes_m_, X_, vh_, sizes_q_, draws):
+                if isinstance(draws, dict):                 # index arrays drawn on the device (or handed back by a caller)
+                    return occ_net.forward_ragged(pc_, sizes_m_, X_, vh_, sizes_q_, index_arrays=draws).view(-1, 1)
+                return occ_net.forward_ragged(pc_, sizes_m_, X_, vh_, sizes_q_, perms=draws, perm_source=perm_source).view(-1, 1)
+
             if hasattr(occ_net, "forward_ragged") and world > 1:
                 sizes_m, sizes_q = [m for _, _, m in jobs], [q for _, q, _ in jobs]
                 if ragged_perms is None:                # rank 0 draws for every job, in job order (what the 1-rank pass draws)
-                    ragged_perms = _broadcast_job_perms(occ_net, sizes_m, device, group, rank)
+                    ragged_perms = (_broadcast_job_index_arrays(occ_net, sizes_m, device, group, rank) if perm_source == "device"
+                                    else _broadcast_job_perms(occ_net, sizes_m, device, group, rank))
                 t0, t1 = mdist.shard_range(T, rank, world)
                 q_start = np.concatenate(([0], np.cumsum(sizes_q)))
                 m_start = np.concatenate(([0], np.cumsum(sizes_m)))
@@ -518,13 +531,15 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
                 if mine:
                     q_l = [int(min(q_start[j + 1], t1) - max(q_start[j], t0)) for j in mine]
                     p0, p1 = int(m_start[mine[0]]), int(m_start[mine[-1] + 1])
-                    occ_l = occ_net.forward_ragged(pc_all[p0:p1].contiguous(), [sizes_m[j] for j in mine], X_q[t0:t1].contiguous(),
-                                                   vh[t0:t1].contiguous(), q_l, perms=[ragged_perms[j] for j in mine]).view(-1, 1)
+                    draws_l = (_slice_index_arrays(occ_net, ragged_perms, sizes_m, mine[0], mine[-1] + 1) if isinstance(ragged_perms, dict)
+                               else [ragged_perms[j] for j in mine])
+                    occ_l = ragged(pc_all[p0:p1].contiguous(), [sizes_m[j] for j in mine], X_q[t0:t1].contiguous(),
+                                   vh[t0:t1].contiguous(), q_l, draws_l)
                 else:                                   # empty row shard (T < world): no kernels, the all-gather is joined
                     occ_l = torch.zeros(0, 1, dtype=torch.float32, device=device)
                 occ = mdist.allgather_rows(occ_l, T, group)
             elif hasattr(occ_net, "forward_ragged"):
-                occ = occ_net.forward_ragged(pc_all, [m for _, _, m in jobs], X_q, vh, [q for _, q, _ in jobs], perms=ragged_perms).view(-1, 1)
+                occ = ragged(pc_all, [m for _, _, m in jobs], X_q, vh, [q for _, q, _ in jobs], ragged_perms)
                 ragged_perms = occ_net.last_ragged_perms
             else:                                       # any other module with the reference's call signature: job by job
                 outs, r0, p0 = [], 0, 0
@@ -570,6 +585,37 @@ def _broadcast_job_perms(occ_net, cloud_sizes, device, group, rank):
             job.append(host[o:o + n_]); o += n_
         out.append(job)
     return out
+
+
+def _broadcast_job_index_arrays(occ_net, cloud_sizes, device, group, rank):
+    """perm_source="device" on several ranks: rank 0 draws the index arrays of ALL jobs on its device; one broadcast of
+    [g_idx | idx1 | idx2] (the offsets and lengths follow from the cloud sizes on every rank)."""
+    from .. import dist as mdist
+    J, Lg = len(cloud_sizes), occ_net.seq_len
+    sz = [occ_net.scale_sizes(int(m_)) for m_ in cloud_sizes]
+    n1, n2 = sum(s_[1] for s_ in sz), sum(s_[2] for s_ in sz)
+    if rank == 0:
+        ia = occ_net.ragged_index_arrays_device(cloud_sizes, device)
+        buf = torch.cat((ia["g_idx"], ia["idx1"], ia["idx2"]))
+    else:
+        buf = torch.empty(J * Lg + n1 + n2, dtype=torch.int64, device=device)
+    mdist.broadcast(buf, 0, group)
+    cum = lambda v: np.concatenate(([0], np.cumsum(v))).astype(np.int64)
+    offs = ops.h2d(np.concatenate([cum([s_[1] for s_ in sz]), cum([s_[2] for s_ in sz]), np.asarray([min(s_[0], Lg) for s_ in sz], np.int64)]),
+                   torch.int64, device)
+    return {"g_idx": buf[:J * Lg], "idx1": buf[J * Lg:J * Lg + n1], "idx2": buf[J * Lg + n1:], "off1": offs[:J + 1],
+            "off2": offs[J + 1:2 * J + 2], "g_len": offs[2 * J + 2:].to(torch.int32)}
+
+
+def _slice_index_arrays(occ_net, ia, cloud_sizes, j0, j1):
+    """The index arrays of jobs j0 .. j1-1 out of those of all jobs, re-based to the sub-list's own row offsets."""
+    Lg = occ_net.seq_len
+    sz = [occ_net.scale_sizes(int(m_)) for m_ in cloud_sizes]
+    c0 = int(sum(s_[0] for s_ in sz[:j0]))
+    a1, b1 = int(sum(s_[1] for s_ in sz[:j0])), int(sum(s_[1] for s_ in sz[:j1]))
+    a2, b2 = int(sum(s_[2] for s_ in sz[:j0])), int(sum(s_[2] for s_ in sz[:j1]))
+    return {"g_idx": ia["g_idx"][j0 * Lg:j1 * Lg] - c0, "g_len": ia["g_len"][j0:j1], "idx1": ia["idx1"][a1:b1] - c0,
+            "idx2": ia["idx2"][a2:b2] - a1, "off1": ia["off1"][j0:j1 + 1] - a1, "off2": ia["off2"][j0:j1 + 1] - a2}
 
 
 def compute_occupancy_probability(macarons, pc, X, view_harmonics, mask=None, max_points_per_pass=20000):

@@ -2,6 +2,7 @@
 # Dev: GPU busy / idle inside one MACARONS decision (kernel trace of bench.measure_macarons_step): decisions are delimited by the
 # fused depth update (proxy_update_kernel)
 cd /tmp && export TMPDIR=/tmp
+export MCR_BENCH_NO_CHECKS=1
 rm -rf /tmp/mtrace; timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/mtrace -o t -- python -c "
 import sys; sys.path.insert(0, '/root/repo')
 import torch, bench
@@ -30,5 +31,10 @@ print(f"median decision: {n} kernels, span {span/1e6:.3f} ms, busy {busy/1e6:.3f
 for g, a, b in gaps: print(f"  gap {g/1e3:8.1f} us  after {a}  before {b}")
 agg = collections.defaultdict(lambda: [0, 0])
 for s_, e_, n_ in seg: agg[n_[:60]][0] += e_ - s_; agg[n_[:60]][1] += 1
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]: print(f"  {v[0]/1e3:9.1f} us x{v[1]:4d}  {k}")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]: print(f"  {v[0]/1e3:9.1f} us x{v[1]:4d}  {k}")
+print("---- timeline of the median decision (start us, duration us, gap before us, kernel)")
+t0 = seg[0][0]; prev_end = t0
+for s_, e_, n_ in seg:
+    print(f"{(s_-t0)/1e3:9.1f} {(e_-s_)/1e3:8.1f} {max(0,(s_-prev_end))/1e3:8.1f}  {n_[:70]}")
+    prev_end = max(prev_end, e_)
 PY
