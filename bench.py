@@ -283,7 +283,7 @@ def measure_nbv_batch(dev, rank, world, args):
             "nbv_idx": r["nbv_idx"].tolist()}
 
 
-def measure_macarons_step(dev, rank=0, world=1):
+def measure_macarons_step(dev, rank=0, world=1, perm_sources=("host", "device")):
     """BASELINE config 5 minus the depth network: p50 latency of one MACARONS next-best-view decision
     (macarons_utils.macarons_nbv_decision = testers/scene.py:391-454) on a synthetic scene of liberty's proportions: 3 x 8 x 3
     grid, 100 000 proxy points, surface = an ellipsoid shell (capacity 1000 points per cell), 256 x 456 analytic depth maps,
@@ -348,7 +348,7 @@ def measure_macarons_step(dev, rank=0, world=1):
     checks = {"iterations": 0, "n_inside_grows_by_fov_count": True, "fov_subset_of_in_field": True, "stored_proxy_indices_unique": True,
               "stored_points_inside_their_cell": True, "occupancies_finite_in_range": True, "field_rows_equal_selected_plus_out_of_field": True,
               "next_idx_is_first_strict_max": True, "gains_finite_nonnegative": True}
-    for it in range(2 + 9):
+    for it in range((2 + 9) if "host" in perm_sources else 0):
         cam, depth, dmask, recs, ne = poses[it % 3]
         n_in_before = float(proxy.proxy_n_inside_fov.sum())
         torch.cuda.synchronize()
@@ -390,11 +390,11 @@ def measure_macarons_step(dev, rank=0, world=1):
         checks["gains_finite_nonnegative"] &= bool(np.isfinite(g_h).all() and (g_h >= 0).all())
         checks["next_idx_is_first_strict_max"] &= nxt == int(np.argmax(g_h)) and abs(float(r["max_gain"]) - float(g_h.max())) == 0.0
         info = {"field_points": int(r["X_world"].shape[0]), "proxy_in_fov": n_fov, "next_idx": nxt}
-    p50 = float(np.median(times))
+    p50 = float(np.median(times)) if times else float("nan")
     checks["all_hold"] = all(v for k_, v in checks.items() if k_ != "iterations")
     # the same decision with the hidden permutations drawn on the device (opt-in perm_source="device": no host randperm loop)
     times_d = []
-    for it in range(2 + 9):
+    for it in range((2 + 9) if "device" in perm_sources else 0):
         cam, depth, dmask, recs, ne = poses[it % 3]
         torch.cuda.synchronize()
         if dist is not None:
@@ -407,7 +407,7 @@ def measure_macarons_step(dev, rank=0, world=1):
         dt = max_over_ranks(time.perf_counter() - t0, dev, dist)
         if it >= 2:
             times_d.append(dt)
-    p50_d = float(np.median(times_d))
+    p50_d = float(np.median(times_d)) if times_d else float("nan")
     return {"p50_ms": p50 * 1e3, "evals_per_s": K / p50, "iters": len(times), "last": info, "checks": checks, "scaling": "strong",
             "device_perms": {"p50_ms": p50_d * 1e3, "evals_per_s": K / p50_d,
                              "note": "perm_source='device' (opt-in): Cell.fill subsets and SconeOcc down-samples drawn on the GPU by segmented "

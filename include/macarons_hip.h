@@ -333,6 +333,21 @@ int mcr_min_dist_segmented(const float* A, const int64_t* a_offsets, const float
                            int64_t max_a_per_segment, double* dmin, void* stream);
 int mcr_unproject_depth(const float* depth, int H, int W, const float* cameras, int64_t n_cam, float* world, void* stream);
 
+/* ---- scene-grid bookkeeping fused (Scene.fill_cells macarons_utils.py:2727-2737 over Cell.fill :2551-2577; the cell lookup of
+ * compute_scene_occupancy_probability_field :1434) --------------------------------------------------------------------------------
+ * mcr_cell_keys: key[i] = linear id ((i_l * grid_w + i_w) * grid_h + i_h) of the cell point i falls in by upstream's floor rule
+ *   (utils.floor_divide :113-117 on pts - x_min, capped at grid - 1); box_test != 0: n_cells instead when the point is outside the
+ *   scene box [x_min, x_max] (closed, get_pts_in_bounding_box :2676-2691), not STRICTLY inside its cell's box (lo_tab / hi_tab
+ *   [n_cells, 3]: Cell.fill's two masks) or not offered (valid[i] == 0; valid may be NULL).  grid_consts = x_min[3] x_max[3] step[3].
+ * mcr_key_histogram: counts[k] = #{i: key[i] == k}, k = 0 .. nk, and their exclusive prefix sums offsets[0 .. nk + 1]  (nk <= 1023).
+ * mcr_admit_keys: Cell.fill's admission on candidates sorted by cell: key2[i] = key_s[i] if the cell has more than n_point_min
+ *   candidates (cand[key]) and the candidate's fp64 distance d[i] to the cell's stored points exceeds `resolution`, else nk. */
+int mcr_cell_keys(const float* pts, int64_t N, const unsigned char* valid, const float* grid_consts, int grid_l, int grid_w, int grid_h,
+                  const float* lo_tab, const float* hi_tab, int box_test, int* key, void* stream);
+int mcr_key_histogram(const int* key, int64_t N, int nk, int64_t* counts, int64_t* offsets, void* stream);
+int mcr_admit_keys(const double* d, const int* key_s, const int64_t* cand, int64_t N, double resolution, int64_t n_point_min, int nk,
+                   int* key2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -697,6 +697,84 @@ __global__ __launch_bounds__(64) void best_merge_kernel(const float* __restrict_
     idx[b] = (long long)bi;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Scene-grid bookkeeping of Scene.fill_cells / compute_scene_occupancy_probability_field (macarons_utils.py:2693-2737, :1434): the
+// per-point cell lookup, Cell.fill's box tests and the per-cell counts -- fifteen small elementwise launches of the host code as one.
+// Bit-compatible with the torch expressions it replaces:
+//   d = pts - x_min;  idx = min((d - remainder(d, step)) / step, grid - 1) truncated to an integer, clamped at 0   (utils.floor_divide)
+//   key = linear cell id if the point lies in the scene box (closed), strictly inside ITS cell's box (Cell.fill :2552-2557) and is
+//   offered (valid), else n_cells.   box_test = 0: the cell id alone (:1434 uses the lookup without the tests).
+__device__ __forceinline__ float torch_remainder(float a, float b) {       // torch.remainder on floats: fmod, then the divisor's sign
+    float m = fmodf(a, b);
+    if (m != 0.f && ((b < 0.f) != (m < 0.f))) m = __fadd_rn(m, b);
+    return m;
+}
+__global__ void cell_keys_kernel(const float* __restrict__ pts, long long N, const unsigned char* __restrict__ valid,
+                                 const float* __restrict__ gc, int gl, int gw, int gh, const float* __restrict__ lo_tab,
+                                 const float* __restrict__ hi_tab, int box_test, int* __restrict__ key) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int g[3] = {gl, gw, gh};
+    float p[3];
+    int idx[3];
+    bool in_scene = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        p[a] = pts[i * 3 + a];
+        const float d = __fsub_rn(p[a], gc[a]), st = gc[6 + a];
+        float q = __fdiv_rn(__fsub_rn(d, torch_remainder(d, st)), st);
+        q = fminf(q, (float)(g[a] - 1));                  // (NaN-propagating in torch; a NaN coordinate fails every test below anyway)
+        long long t = (long long)q;                       // .long(): truncation
+        idx[a] = (int)(t < 0 ? 0 : t);
+        in_scene = in_scene && p[a] >= gc[a] && p[a] <= gc[3 + a];
+    }
+    const int n_cells = gl * gw * gh;
+    int cid = (idx[0] * gw + idx[1]) * gh + idx[2];
+    if (cid >= n_cells) cid = n_cells - 1;                // (unreachable: idx[a] <= g[a] - 1)
+    if (box_test) {
+        bool ok = in_scene && (!valid || valid[i]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            ok = ok && (__fsub_rn(p[a], hi_tab[cid * 3 + a]) < 0.f) && (__fsub_rn(p[a], lo_tab[cid * 3 + a]) > 0.f);
+        key[i] = ok ? cid : n_cells;
+    } else {
+        key[i] = cid;
+    }
+}
+
+// counts[k] = #{i : key[i] == k} for k <= nk, offsets = their exclusive prefix sums (nk + 2 entries): ONE block (N is a few 10^5,
+// nk <= 1023), no zero-initialised scratch, no second launch for the scan.
+__global__ __launch_bounds__(1024) void key_histogram_kernel(const int* __restrict__ key, long long N, int nk,
+                                                            long long* __restrict__ counts, long long* __restrict__ offsets) {
+    __shared__ unsigned s_cnt[1024];
+    for (int k = threadIdx.x; k <= nk; k += 1024) s_cnt[k] = 0u;
+    __syncthreads();
+    for (long long i = threadIdx.x; i < N; i += 1024) {
+        const int k = key[i];
+        if (k >= 0 && k <= nk) atomicAdd(&s_cnt[k], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        for (int k = 0; k <= nk; ++k) {
+            counts[k] = s_cnt[k];
+            offsets[k] = run;
+            run += s_cnt[k];
+        }
+        offsets[nk + 1] = run;
+    }
+}
+
+// Cell.fill's admission (:2565-2568) on the sorted candidates: key2 = the cell of a candidate that is offered to a cell with more
+// than n_point_min candidates and whose fp64 distance to every stored point exceeds the resolution, else nk
+__global__ void admit_keys_kernel(const double* __restrict__ d, const int* __restrict__ key_s, const long long* __restrict__ cand,
+                                  long long N, double resolution, long long n_point_min, int nk, int* __restrict__ key2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int k = key_s[i];
+    key2[i] = (k < nk && cand[k] > n_point_min && d[i] > resolution) ? k : nk;
+}
+
 extern "C" {
 
 static int view_state_impl(const char* who, const float* pts, int pts_dim, const float* X_view, float* view_state, int64_t n_clouds,
@@ -935,4 +1013,32 @@ int mcr_best_merge(const float* records, int world, int64_t B, float* vals, int6
     return 0;
 }
 
+
+int mcr_cell_keys(const float* pts, int64_t N, const unsigned char* valid, const float* grid_consts, int grid_l, int grid_w, int grid_h,
+                  const float* lo_tab, const float* hi_tab, int box_test, int* key, void* stream) {
+    MCR_REQUIRE(pts && grid_consts && key && N > 0, "mcr_cell_keys: bad arguments");
+    MCR_REQUIRE(grid_l > 0 && grid_w > 0 && grid_h > 0 && (long long)grid_l * grid_w * grid_h < (1 << 30), "mcr_cell_keys: bad grid");
+    MCR_REQUIRE(!box_test || (lo_tab && hi_tab), "mcr_cell_keys: the box tests need the cells' bounds");
+    hipLaunchKernelGGL(cell_keys_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, pts, (long long)N, valid, grid_consts,
+                       grid_l, grid_w, grid_h, lo_tab, hi_tab, box_test, key);
+    MCR_LAUNCH_CHECK("cell_keys_kernel");
+    return 0;
+}
+
+int mcr_key_histogram(const int* key, int64_t N, int nk, int64_t* counts, int64_t* offsets, void* stream) {
+    MCR_REQUIRE(key && counts && offsets && N >= 0 && nk >= 0 && nk <= 1023, "mcr_key_histogram: bad arguments (nk <= 1023)");
+    hipLaunchKernelGGL(key_histogram_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, key, (long long)N, nk, (long long*)counts,
+                       (long long*)offsets);
+    MCR_LAUNCH_CHECK("key_histogram_kernel");
+    return 0;
+}
+
+int mcr_admit_keys(const double* d, const int* key_s, const int64_t* cand, int64_t N, double resolution, int64_t n_point_min, int nk,
+                   int* key2, void* stream) {
+    MCR_REQUIRE(d && key_s && cand && key2 && N > 0 && nk >= 0, "mcr_admit_keys: bad arguments");
+    hipLaunchKernelGGL(admit_keys_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, d, key_s, (const long long*)cand,
+                       (long long)N, resolution, (long long)n_point_min, nk, key2);
+    MCR_LAUNCH_CHECK("admit_keys_kernel");
+    return 0;
+}
 }  // extern "C"

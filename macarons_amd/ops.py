@@ -778,3 +778,44 @@ def proxy_scene_update_(proxy_points, fov_mask, camera, depth, depth_mask, fill,
                                            _p(n_behind), _p(supervision_occ), _p(out_of_field), _p(sgn) if sgn is not None else c_vp(0),
                                            _stream()), "mcr_proxy_scene_update")
     return sgn
+
+
+# ---- scene-grid bookkeeping, fused (Scene.fill_cells / the cell lookup of the occupancy field) -----------------------------------------
+def cell_keys(pts, grid_consts, grid, lo_tab=None, hi_tab=None, valid=None):
+    """pts [N,3] -> int32 [N]: linear id of the cell each point falls in (upstream's floor rule); with the cells' bounds lo_tab / hi_tab
+    [n_cells,3] also Cell.fill's tests: n_cells for a point outside the scene box, not strictly inside its cell, or with valid[i] == 0.
+    grid_consts: fp32 device tensor [9] = x_min, x_max, step; grid = (grid_l, grid_w, grid_h)."""
+    pts, gc = _req(pts, "pts"), _req(grid_consts, "grid_consts")
+    N = pts.shape[0]
+    key = torch.empty(N, dtype=torch.int32, device=pts.device)
+    if N == 0:
+        return key
+    box = lo_tab is not None
+    v = valid.to(torch.uint8).contiguous() if valid is not None else None
+    with torch.cuda.device(pts.device):
+        check(lib().mcr_cell_keys(_p(pts), c_i64(N), _p(v) if v is not None else c_vp(0), _p(gc), c_int(grid[0]), c_int(grid[1]), c_int(grid[2]),
+                                  _p(_req(lo_tab, "lo_tab")) if box else c_vp(0), _p(_req(hi_tab, "hi_tab")) if box else c_vp(0),
+                                  c_int(int(box)), _p(key), _stream()), "mcr_cell_keys")
+    return key
+
+
+def key_histogram(key, nk):
+    """key int32 [N] -> (counts int64 [nk+1], exclusive offsets int64 [nk+2])."""
+    key = _req(key, "key", torch.int32)
+    counts = torch.empty(nk + 1, dtype=torch.int64, device=key.device)
+    offsets = torch.empty(nk + 2, dtype=torch.int64, device=key.device)
+    with torch.cuda.device(key.device):
+        check(lib().mcr_key_histogram(_p(key), c_i64(key.numel()), c_int(nk), _p(counts), _p(offsets), _stream()), "mcr_key_histogram")
+    return counts, offsets
+
+
+def admit_keys(d, key_s, cand, resolution, n_point_min, nk):
+    """Cell.fill's admission on the sorted candidates (mcr_admit_keys) -> key2 int32 [N]."""
+    d, key_s, cand = _req(d, "d", torch.float64), _req(key_s, "key_s", torch.int32), _req(cand, "cand", torch.int64)
+    key2 = torch.empty_like(key_s)
+    if key_s.numel() == 0:
+        return key2
+    with torch.cuda.device(d.device):
+        check(lib().mcr_admit_keys(_p(d), _p(key_s), _p(cand), c_i64(key_s.numel()), ctypes.c_double(float(resolution)), c_i64(int(n_point_min)),
+                                   c_int(nk), _p(key2), _stream()), "mcr_admit_keys")
+    return key2

@@ -162,9 +162,12 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     rec = ops.h2d(camera.record, torch.float32, device)
     # 1 ---- proxy points in the current field of view, registered in their grid cells with their index as feature
     fov_mask = ops.points_in_fov(proxy_scene.proxy_points, rec.view(1, 40))[0]
-    fov_idx = proxy_scene.get_proxy_indices_from_mask(fov_mask)
-    proxy_scene.fill_cells(proxy_scene.proxy_points[fov_idx.view(-1)], features=fov_idx.view(-1, 1).float(),   # (index, not mask: one read-back less)
-                           **({"group": group} if world > 1 else {}), **({"perm_source": perm_source} if perm_source != "host" else {}))
+    # every proxy point is offered with its index as feature, the ones outside the frustum flagged invalid: compacting them first
+    # (`points[mask]`) is a read-back of the count
+    P_all = proxy_scene.proxy_points.shape[0]
+    proxy_scene.fill_cells(proxy_scene.proxy_points, features=torch.arange(P_all, device=device, dtype=torch.float32).view(-1, 1),
+                           valid=fov_mask, **({"group": group} if world > 1 else {}),
+                           **({"perm_source": perm_source} if perm_source != "host" else {}))
     # 2 ---- carve with the depth map: signed distance, view states, supervision occupancy, out-of-field, one launch
     sgn = proxy_scene.update_from_depth(fov_mask, rec, ops.h2d(camera.X_cam, torch.float32, device), depth2, dmask2, fill=1.1 * camera.zfar,
                                         tol=params.carving_tolerance, return_signed_distances=return_signed_distances)
@@ -376,7 +379,7 @@ def _grid_tables(scene, device):
     centers = torch.stack([c.center.reshape(3) for c in order]).to(device)
     diag = torch.linalg.norm(torch.stack([c.x_max.reshape(3) for c in order]) - torch.stack([c.x_min.reshape(3) for c in order]), dim=1).to(device)
     tab = {"device": str(device), "keys": keys, "lin_of": lin_of, "neighbours": [neigh(c) for c in range(n_cells)], "centers": centers,
-           "diag": diag}
+           "diag": diag, "centers_host": centers.cpu(), "diag_host": diag.cpu()}
     try:
         scene._mcr_grid_tables = tab
     except Exception:
@@ -430,7 +433,8 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
     Mv_host = Mv_any.detach().to(torch.float32) if Mv_any.device.type == "cpu" else None     # (a host matrix stays usable on the host)
     Mv = ops.h2d(Mv_host, torch.float32, device).contiguous() if Mv_host is not None else Mv_any.to(device=device, dtype=torch.float32).contiguous()
     # ---- per proxy point: the cell its coordinates fall in (which cells are visited, :1434) and the cell whose store holds it
-    cell_by_pos = _lin(ps.get_cells_for_each_pt(ps.proxy_points), gw, gh)
+    cell_by_pos = (ps.linear_cell_ids(ps.proxy_points) if hasattr(ps, "linear_cell_ids")
+                   else _lin(ps.get_cells_for_each_pt(ps.proxy_points), gw, gh))
     tab = _grid_tables(ps, device)                       # static per scene: cells in linear-id order, their centres / diagonals, 27-neighbourhoods
     keys, lin_of = tab["keys"], tab["lin_of"]
     stored_cell = torch.full((P,), -1, dtype=torch.int64, device=device)
@@ -447,7 +451,14 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
     visit = torch.zeros(n_cells + 1, dtype=torch.int64, device=device).scatter_(0, torch.where(visit_pts, cell_by_pos, big), 1)
     counts = torch.zeros(n_cells + 1, dtype=torch.int64, device=device).scatter_add_(0, torch.where(sel, stored_cell, big),
                                                                                    torch.ones_like(stored_cell))
-    host = torch.stack((visit[:n_cells], counts[:n_cells])).cpu().numpy()                        # the one read-back of the pass
+    # the one read-back of the pass; the number of never-seen points rides along (the tail of the field is their compaction: with the
+    # count known here, it is built without a second read-back -- torch.nonzero after the occupancy pass stalled the host until the
+    # pass had run, and the launches of everything behind it then started on an idle GPU)
+    oof_mask = (ps.out_of_field > 0.)[..., 0]
+    n_oof_t = torch.zeros(n_cells + 1, dtype=torch.int64, device=device)
+    n_oof_t[0] = oof_mask.sum()
+    host3 = torch.stack((visit, counts, n_oof_t)).cpu().numpy()
+    host, n_oof = host3[:2, :n_cells], int(host3[2, 0])
     # ---- host: which cells run, their surface neighbourhoods (sizes are tensor shapes: no read-back), the (cell, chunk) jobs
     s_keys = keys if set(ss.cells.keys()) == set(keys) else sorted(ss.cells.keys(), key=lambda k: lin_of.get(k, 0))
     s_len = {lin_of[k]: int(ss.cells[k].cell_pts.shape[0]) for k in s_keys}
@@ -495,10 +506,19 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
         cloud_of = torch.repeat_interleave(jid, job_m, output_size=tot).to(torch.int32)
         row_job = torch.repeat_interleave(jid, job_q, output_size=T).to(torch.int32)
         # ---- prediction boxes: cell centres in view space, 1 / (neighbourhood size x cell diagonal)   (:1468-1478)
-        centers_w, diag = tab["centers"][job_cell], tab["diag"][job_cell]               # per job, gathered from the per-scene tables
-        centers = (torch.cat((centers_w, torch.ones(J, 1, device=device)), 1) @ Mv)[:, :3].contiguous()
-        inv_diag = (1.0 / (params.prediction_neighborhood_size * diag)).float().contiguous()
-        MvJ = Mv.reshape(1, 16).expand(J, -1).contiguous()
+        if Mv_host is not None:
+            # J <= a few dozen jobs: their prediction boxes on the HOST (same fp32 arithmetic: torch CPU), one upload -- six small launches less
+            jc = [c for c, _, _ in jobs]
+            cw, dg = tab["centers_host"][jc], tab["diag_host"][jc]
+            cen_h = (torch.cat((cw, torch.ones(J, 1)), 1) @ Mv_host.reshape(4, 4))[:, :3]
+            inv_h = (1.0 / (params.prediction_neighborhood_size * dg)).float()
+            up = ops.h2d(torch.cat((cen_h.reshape(-1), inv_h, Mv_host.reshape(1, 16).expand(J, -1).reshape(-1))), torch.float32, device)
+            centers, inv_diag, MvJ = up[:3 * J].view(J, 3), up[3 * J:4 * J], up[4 * J:].view(J, 16)
+        else:
+            centers_w, diag = tab["centers"][job_cell], tab["diag"][job_cell]               # per job, gathered from the per-scene tables
+            centers = (torch.cat((centers_w, torch.ones(J, 1, device=device)), 1) @ Mv)[:, :3].contiguous()
+            inv_diag = (1.0 / (params.prediction_neighborhood_size * diag)).float().contiguous()
+            MvJ = Mv.reshape(1, 16).expand(J, -1).contiguous()
         ops.transform_points_batched_(pc_all, MvJ, centers, inv_diag, cloud_of=cloud_of)
         X_q = ops.transform_points_batched_(X_sel.clone().contiguous(), MvJ, centers, inv_diag, cloud_of=row_job)
         # ---- view states -> prediction frame -> harmonics, all rows at once   (:1486-1497)
@@ -552,7 +572,10 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
                 record["ragged_perms"] = ragged_perms
         ps.proxy_proba[rows] = occ                                                                # :1525
         X_parts, H_parts, O_parts = [X_sel], [vh], [occ]
-    oof_idx = torch.nonzero((ps.out_of_field > 0.)[..., 0]).view(-1)                          # (one read-back for both gathers)
+    # indices of the never-seen points in ascending order, n_oof known: exclusive ranks scattered into place (no read-back)
+    pos = torch.cumsum(oof_mask, 0) - 1
+    oof_idx = torch.zeros(n_oof + 1, dtype=torch.int64, device=device).scatter_(
+        0, torch.where(oof_mask, pos, torch.full_like(pos, n_oof)), torch.arange(P, device=device))[:n_oof]
     oof_X = ps.proxy_points[oof_idx]
     X_world = torch.cat(X_parts + [oof_X])
     view_harmonics = torch.cat(H_parts + [torch.zeros(len(oof_X), nh, device=device)])

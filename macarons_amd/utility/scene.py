@@ -101,6 +101,8 @@ class Scene:
                  "step": torch.stack((self.l, self.w, self.h)).to(device).view(1, 3),
                  "x_min": self.x_min.to(device), "x_max": self.x_max.to(device),
                  "hi": torch.tensor([self.grid_l - 1, self.grid_w - 1, self.grid_h - 1], device=device, dtype=torch.float32),
+                 "gc": torch.cat((self.x_min.reshape(3).float(), self.x_max.reshape(3).float(),
+                                  torch.stack((self.l, self.w, self.h)).reshape(3).float())).to(device).contiguous(),
                  "lin": torch.tensor([self.grid_w * self.grid_h, self.grid_h, 1], device=device)}
             self._dev_consts = c
         return c
@@ -111,6 +113,13 @@ class Scene:
         d = pts - c["x_min"]
         idx = (d - d % step) / step                                   # utils.floor_divide (non-negative modulo)
         return torch.minimum(idx, c["hi"].to(idx.dtype)).long().clamp_(min=0)
+
+    def linear_cell_ids(self, pts):
+        """int32 [N]: (i_l * grid_w + i_w) * grid_h + i_h of get_cells_for_each_pt(pts), one fused launch on a HIP device."""
+        if pts.is_cuda:
+            from .. import ops
+            return ops.cell_keys(pts, self._consts(pts.device)["gc"], (self.grid_l, self.grid_w, self.grid_h))
+        return (self.get_cells_for_each_pt(pts) * self._consts(pts.device)["lin"]).sum(-1).to(torch.int32)
 
     def get_englobing_cells(self, pts, list=False):
         res = torch.unique(self.get_cells_for_each_pt(pts), dim=0)
@@ -139,7 +148,7 @@ class Scene:
             t = self._table = (order, lo, hi)
         return t
 
-    def fill_cells(self, pts, features=None, n_point_min=0, group=None, perm_source="host"):
+    def fill_cells(self, pts, features=None, n_point_min=0, group=None, perm_source="host", valid=None):
         """Scene.fill_cells (macarons_utils.py:2727-2737) over Cell.fill (:2551-2577) for ALL touched cells at once: upstream loops
         the cells from Python, each testing every point against its box and its store.  Here one stable sort groups the points by
         cell (floor rule, then the strict box test of that cell), ONE segmented fp64 nearest-distance launch runs every cell's
@@ -148,6 +157,8 @@ class Scene:
         draws) and turns them into one gather.  A point exactly on a cell face belongs to no cell, as upstream.
         `group` (a torch.distributed group whose ranks hold replicas of this scene and call together): the permutations are rank 0's,
         broadcast once -- every rank drawing its own would let the replicas diverge.
+        `valid` (bool [N], optional): only these rows of pts are offered -- the same as fill_cells(pts[valid], features[valid]) without
+        the read-back that boolean indexing costs.
         perm_source="device" (opt-in): every touched cell's random subset / order comes from the device generator in ONE segmented
         sort instead of one torch.randperm per cell on the host (72 draws = 0.7 ms of a MACARONS decision): statistically the same,
         not the reference's CPU-generator stream."""
@@ -159,26 +170,19 @@ class Scene:
         cells, lo, hi = self._cell_table()
         n_cells = len(cells)
         with_fts = self.feature_dim > 0 and features is not None
-        cid = (self.get_cells_for_each_pt(pts) * self._consts(pts.device)["lin"]).sum(-1)
-        ok = ((pts >= self.x_min.to(dev)) & (pts <= self.x_max.to(dev))).all(-1)                  # get_pts_in_bounding_box
-        ok = ok & (torch.max(pts - hi[cid], dim=-1)[0] < 0.) & (torch.min(pts - lo[cid], dim=-1)[0] > 0.)      # Cell.fill's box masks
-        big = torch.full_like(cid, n_cells)
-        key = torch.where(ok, cid, big)
+        # cell lookup + scene box + Cell.fill's strict box tests + the validity mask -> one key per point (n_cells = not offered), one launch
+        key = ops.cell_keys(pts, self._consts(dev)["gc"], (self.grid_l, self.grid_w, self.grid_h), lo, hi, valid)
         order = torch.sort(key, stable=True).indices
         key_s = key[order]
-        ones = torch.ones_like(key)
-        cand = torch.zeros(n_cells + 1, dtype=torch.int64, device=dev).scatter_add_(0, key, ones)
-        a_off = torch.zeros(n_cells + 1, dtype=torch.int64, device=dev)
-        a_off[1:] = torch.cumsum(cand[:n_cells], 0)
+        cand, a_off = ops.key_histogram(key, n_cells)                                             # counts per cell (+ rejected), their offsets
         b_len = [int(c.cell_pts.shape[0]) for c in cells]
         b_off_h = np.concatenate(([0], np.cumsum(b_len))).astype(np.int64)
         B_all = torch.cat([c.cell_pts for c in cells if c.cell_pts.shape[0] > 0] + [torch.zeros(0, 3, device=dev)])
         A_s = pts[order].contiguous()
-        d = ops.min_dist_segmented(A_s, a_off, B_all.contiguous(), ops.h2d(b_off_h, torch.int64, dev), max_a=N)
-        admit = (d > cells[0].resolution) & (key_s < n_cells) & (cand[key_s] > n_point_min)       # fp64 compare (:2566-2567)
-        key2 = torch.where(admit, key_s, big)
+        d = ops.min_dist_segmented(A_s, a_off[:n_cells + 1], B_all.contiguous(), ops.h2d(b_off_h, torch.int64, dev), max_a=N)
+        key2 = ops.admit_keys(d, key_s, cand, cells[0].resolution, n_point_min, n_cells)          # fp64 compare (:2566-2567)
         order2 = torch.sort(key2, stable=True).indices
-        adm = torch.zeros(n_cells + 1, dtype=torch.int64, device=dev).scatter_add_(0, key2, ones)
+        adm, _ = ops.key_histogram(key2, n_cells)
         host = torch.stack((cand[:n_cells], adm[:n_cells])).cpu().numpy()                         # the one read-back
         n_adm = int(host[1].sum())
         add_pts = A_s[order2[:n_adm]]
