@@ -143,6 +143,37 @@ def cpu_baseline_nbv(C):
             "note": "extrapolation = fixed + 100000 x per-query cost from the two sample sizes; not a measurement of the full step"}
 
 
+def measure_scorer_traffic(N, C, timeout_s=150):
+    """HBM read bytes of ONE sh_gain_kernel launch at the headline size, measured in THIS run when rocprofv3 is on the box: a separate
+    process runs the scorer under `rocprofv3 --pmc FETCH_SIZE` (counters only, no tracing, as MI355X_MICROARCH.md prescribes), the
+    per-dispatch mean of the kernel is read from the counter csv and corrected x2 (gfx950: FETCH_SIZE counts 64-byte units of 128-byte
+    requests, KiB as reported).  -> (bytes or None, how it was obtained)."""
+    import glob, shutil, subprocess, tempfile, csv
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not on this box"
+    out = tempfile.mkdtemp(prefix="mcr_pmc_")
+    code = ("import sys; sys.path.insert(0, %r); import torch, bench; from macarons_amd import ops; d = torch.device('cuda:0'); "
+            "p, h, c = bench.make_inputs(%d, %d, 1234, d); [ops.sh_coverage_gain(p, h, c) for _ in range(40)]; torch.cuda.synchronize()" % (ROOT, N, C))
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        subprocess.run([exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, "-c", code],
+                       cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, timeout=timeout_s)
+        vals = []
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "sh_gain_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == "FETCH_SIZE":
+                    vals.append(float(r["Counter_Value"]))
+        if len(vals) < 8:
+            return None, f"rocprofv3 --pmc FETCH_SIZE returned {len(vals)} dispatches of the kernel"
+        vals = vals[len(vals) // 4:]                          # (the first launches warm the caches / page tables)
+        return float(np.mean(vals)) * 1024.0 * 2.0, f"measured in this run: rocprofv3 --pmc FETCH_SIZE (own process, counters only), mean of {len(vals)} launches, x2 per MI355X_MICROARCH.md"
+    except Exception as e:
+        return None, f"in-run PMC pass failed: {repr(e)[:120]}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def pmc_profile(name):
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -550,6 +581,7 @@ def main():
     ap.add_argument("--strong-cams", type=int, default=512, help="total cameras of the strong-scaling scorer run (config 4)")
     ap.add_argument("--waves-per-simd", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc FETCH_SIZE pass (roofline.traffic then comes from profiles/)")
     ap.add_argument("--no-nbv", action="store_true", help="skip the NBV-step latency measurement")
     ap.add_argument("--no-strong", action="store_true", help="skip the config-4 strong-scaling scorer leg (profiling the headline size alone)")
     ap.add_argument("--nbv-iters", type=int, default=50)
@@ -660,21 +692,30 @@ def main():
         step_ms = dev_ms / args.steps              # device time of one whole step (gain + reduce + decision record)
         alg_flop = N * C * FLOP_PER_PAIR
         achieved = alg_flop / (kern_ms * 1e-3) / 1e12
-        pmc = pmc_profile("r03_scorer_pmc.json") or pmc_profile("r02_scorer_pmc.json") or pmc_profile("r01_scorer_pmc.json") or {}
+        pmc_name = next((n_ for n_ in ("r04_scorer_pmc.json", "r03_scorer_pmc.json", "r02_scorer_pmc.json", "r01_scorer_pmc.json") if pmc_profile(n_)), None)
+        pmc = pmc_profile(pmc_name) if pmc_name else {}
         valu = (pmc.get("per_dispatch_mean") or {}).get("SQ_INSTS_VALU")
+        traffic, traffic_source = (None, "skipped (--no-pmc)") if args.no_pmc else measure_scorer_traffic(N, C)
+        if traffic is None:                                # no rocprofv3 / pass failed: the committed profile's figure, labelled as such
+            traffic_source = f"static: profiles/{pmc_name} ({traffic_source})"
+            traffic = pmc.get("hbm_read_bytes_per_launch_corrected")
         roof = {"bound": "valu-fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS, "kernel": "sh_gain_kernel<true>", "device_ms_per_launch": kern_ms,
+                "frac_meaning": "ALGORITHMIC flop of the reference's formulation (370 per pair, SURVEY 8d) / kernel time / fp32 vector peak; the "
+                                "kernel itself issues fewer instructions than that formulation: see executed_valu_frac",
                 "timing": "HIP events around 300 back-to-back launches of the kernel alone (mcr_sh_coverage_gain_partials)",
                 "algorithmic_flop_per_launch": alg_flop, "algorithmic_bytes": N * BYTES_PER_POINT,
-                "traffic": pmc.get("hbm_read_bytes_per_launch_corrected"),
-                "traffic_source": "profiles/*_scorer_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 per MI355X_MICROARCH.md, own pass)",
+                "traffic": traffic, "traffic_source": traffic_source,
                 "hbm_algorithmic_GBs": N * BYTES_PER_POINT / (kern_ms * 1e-3) / 1e9,
                 "step_device_ms": step_ms, "step_achieved": alg_flop / (step_ms * 1e-3) / 1e12,
                 "step_frac": alg_flop / (step_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
         if valu:
             # wave-level vector instructions issued per launch (PMC) x 2 cycles each (a SIMD retires 32 fp32 lanes per cycle:
             # 157.3 TFLOP/s = 1024 SIMDs x 2.4 GHz x 64 flop) / (SIMDs x kernel cycles at 2.4 GHz)
-            roof["valu_issue_utilisation"] = valu * 2.0 / (1024 * kern_ms * 1e-3 * 2.4e9)
+            roof["executed_valu_frac"] = valu * 2.0 / (1024 * kern_ms * 1e-3 * 2.4e9)
+            roof["executed_valu_frac_meaning"] = (f"vector instructions the kernel EXECUTES (SQ_INSTS_VALU per launch from profiles/{pmc_name}: a "
+                                                  "static property of the code at this size) x 2 issue cycles / (1024 SIMDs x kernel cycles at "
+                                                  "2.4 GHz): how busy the vector pipe is, as opposed to `frac`")
             roof["valu_insts_per_launch"] = valu
         res = {
             "metric": "candidate-camera coverage-gain evals/sec (100k pts, 200 cams)",

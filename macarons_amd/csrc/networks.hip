@@ -53,6 +53,12 @@ static size_t al(size_t n_floats) { return (n_floats * sizeof(float) + 255) & ~(
 
 // 1: local_pct.hip exact-fp32 MFMA; 5: local_pct5.hip split-precision bf16 hi/mid/lo (6 MFMAs per product, whole fp32
 // range); 6 (default): local_pct6.hip two-term fp16 split (3 MFMAs per product).  Each has its own blob format.
+#ifdef MCR_DEV_LOCAL_PCT8      // dev builds only (tools/build_variant.py with tools/experiments/local_pct8.hip): the shelved register-resident kernel as variant 8
+void launch_local_pct8(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);
+#define MCR_VARIANT8_OK(v) ((v) == 8)
+#else
+#define MCR_VARIANT8_OK(v) false
+#endif
 static int g_local_pct_variant = []() {                 // env MCR_LOCAL_PCT_VARIANT picks the start-up value (testing: whole suites on a variant)
     const char* e = getenv("MCR_LOCAL_PCT_VARIANT");
     const int v = e ? atoi(e) : 6;
@@ -293,7 +299,7 @@ int mcr_local_pct3_blob_floats(void) { return local_pct3_blob_floats(); }
 int mcr_local_pct6_blob_floats(void) { return local_pct6_blob_floats(); }
 
 int mcr_set_local_pct_variant(int v) {
-    MCR_REQUIRE(v == 1 || v == 5 || v == 6, "mcr_set_local_pct_variant: variant must be 1, 5 or 6 (got %d)", v);
+    MCR_REQUIRE(v == 1 || v == 5 || v == 6 || MCR_VARIANT8_OK(v), "mcr_set_local_pct_variant: variant must be 1, 5 or 6 (got %d)", v);
     g_local_pct_variant = v;
     return 0;
 }
@@ -302,6 +308,9 @@ static void run_local_pct(hipStream_t s, const float* offs, float* feat, int64_t
                           void* feat_h = nullptr, void* feat_l = nullptr) {
     if (g_local_pct_variant == 1) launch_local_pct(s, offs, feat, ld, S, blob);
     else if (g_local_pct_variant == 5) launch_local_pct5(s, offs, feat, ld, S, blob);
+#ifdef MCR_DEV_LOCAL_PCT8
+    else if (g_local_pct_variant == 8) launch_local_pct8(s, offs, feat, ld, S, blob);
+#endif
     else launch_local_pct6(s, offs, feat, ld, S, blob, feat_h, feat_l);       // planes out (variant 6 only) when feat_h is set
 }
 
