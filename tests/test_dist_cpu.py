@@ -64,6 +64,19 @@ def _worker(rank, world, port, q):
             ok3 = ok3 and all(torch.equal(a, b) for a, b in zip(got_p, want)) and torch.equal(got_u, u0) and got_u.shape == (n_u, 1)
         only_p, none_u = mdist.broadcast_draws(perms, None)
         ok3 = ok3 and none_u is None and all(torch.equal(a, b) for a, b in zip(only_p, want))
+        # the sharded MACARONS decision: SconeOcc's hidden draws of ALL (cell, chunk) jobs are rank 0's, in job order -- every rank ends
+        # up with the permutations a 1-rank pass seeded like rank 0 would have drawn
+        import contextlib, io
+        from macarons_amd.networks import SconeOcc
+        from macarons_amd.utility import macarons_utils as mu
+        with contextlib.redirect_stdout(io.StringIO()):
+            occ = SconeOcc()
+        sizes = [700, 2300, 130, 5000]
+        torch.manual_seed(500 + rank)                                        # the ranks' own CPU generators disagree
+        got = mu._broadcast_job_perms(occ, sizes, torch.device("cpu"), None, rank)
+        torch.manual_seed(500)
+        want_j = [occ.draw_perms(m) for m in sizes]
+        ok3 = ok3 and all(torch.equal(a, b) for ja, jb in zip(got, want_j) for a, b in zip(ja, jb))
         q.put((rank, bool(ok1), bool(ok2 and ok3), (c0, c1), (q0, q1)))
     finally:
         dist.destroy_process_group()
@@ -91,3 +104,34 @@ def test_allgather_argmax_and_rows_world2():
     for p in procs:
         p.join(30)
     assert all(r[1] and r[2] for r in res), res
+
+
+def test_slice_index_arrays_matches_a_direct_build():
+    """The index arrays a rank of the sharded MACARONS decision cuts out of rank 0's draws for ITS jobs (re-based to its own sub-list
+    of clouds) are what building them for that sub-list alone gives."""
+    import contextlib, io
+    from macarons_amd.networks import SconeOcc
+    from macarons_amd.utility import macarons_utils as mu
+    with contextlib.redirect_stdout(io.StringIO()):
+        occ = SconeOcc()
+    sizes = [700, 2300, 130, 5000, 1024]
+    Lg = occ.seq_len
+    torch.manual_seed(3)
+    perms = [occ.draw_perms(m) for m in sizes]
+
+    def build(ps, ms):                                                       # the host construction of SconeOcc.forward_ragged
+        off0 = np.concatenate(([0], np.cumsum(ms)))
+        g_idx, g_len, i1, i2, o1, o2 = np.zeros((len(ms), Lg), np.int64), [], [], [], [0], [0]
+        for j, (p0, p1, p2) in enumerate(ps):
+            n0 = min(len(p0), Lg)
+            g_idx[j, :n0] = off0[j] + p0[:n0].numpy(); g_idx[j, n0:] = off0[j]; g_len.append(n0)
+            i1.append(off0[j] + p1.numpy()); i2.append(o1[-1] + p2.numpy())
+            o1.append(o1[-1] + len(p1)); o2.append(o2[-1] + len(p2))
+        T = lambda a, dt=torch.int64: torch.as_tensor(np.asarray(a), dtype=dt)
+        return {"g_idx": T(g_idx.reshape(-1)), "g_len": T(g_len, torch.int32), "idx1": T(np.concatenate(i1)), "idx2": T(np.concatenate(i2)),
+                "off1": T(o1), "off2": T(o2)}
+    full = build(perms, sizes)
+    for j0, j1 in ((0, 5), (1, 3), (2, 5), (4, 5)):
+        cut = mu._slice_index_arrays(occ, full, sizes, j0, j1)
+        want = build(perms[j0:j1], sizes[j0:j1])
+        assert all(torch.equal(cut[k], want[k]) for k in want), (j0, j1)
