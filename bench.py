@@ -618,11 +618,21 @@ def main():
         mdist.all_gather_into(ids, torch.tensor([rank], dtype=torch.int32, device=dev))
         ranks_seen = int(torch.unique(ids).numel())
 
+    # the scorer as the product exposes it: torch.ops.macarons.sh_coverage_gain of the C++ TORCH_LIBRARY extension (what
+    # SconeVis.compute_coverage_gain calls); the ctypes wrapper of the same C entry point when a non-default occupancy is asked for
+    scorer_entry = "torch.ops.macarons.sh_coverage_gain (libmacarons_torch.so -> mcr_sh_coverage_gain)"
+    if args.waves_per_simd == 0:
+        import macarons_amd.torch_ops  # noqa: F401
+        score = lambda p_, h_, c_: torch.ops.macarons.sh_coverage_gain(p_, h_, c_, True)
+    else:
+        scorer_entry = "macarons_amd.ops.sh_coverage_gain (ctypes -> mcr_sh_coverage_gain)"
+        score = lambda p_, h_, c_: ops.sh_coverage_gain(p_, h_, c_, True, args.waves_per_simd)
+
     def scorer_run(pts, harm, cams, cam_offset, steps, warmup):
         pipe = mdist.PipelinedBest(1, dev, batch=16, depth=3) if dist is not None else None
 
         def step():
-            gains = ops.sh_coverage_gain(pts, harm, cams, True, args.waves_per_simd)
+            gains = score(pts, harm, cams)
             if pipe is not None:                           # records of 16 decisions per all-gather, on a side stream
                 return pipe.submit(gains, cam_offset)
             return ops.best_record(gains)                  # [B,2] = (max gain, arg-max camera): the decision (torch.max semantics)
@@ -724,7 +734,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"scorer: B=1 cloud x N={N} points x C={C} cameras per GPU "
                                    f"(BASELINE headline 100k pts / 200 cams), inputs resident in HBM",
-                       "points": N, "cams_per_gpu": C, "parallelism": f"camera-shard x{world}"},
+                       "points": N, "cams_per_gpu": C, "parallelism": f"camera-shard x{world}", "entry": scorer_entry},
             "ranks_seen": ranks_seen,
             "roofline": roof,
             "scorer_strong": strong,

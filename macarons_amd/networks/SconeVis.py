@@ -108,11 +108,18 @@ class SconeVis(nn.Module):
             res = hip(pts, view_harmonics)
         return res.view(n_clouds, seq_len, self.n_harmonics)
 
+    @staticmethod
+    def _scorer_ops():
+        """The scorer's operators: `torch.ops.macarons.*` of the C++ TORCH_LIBRARY extension (libmacarons_torch.so over the C ABI; loaded
+        on first use, raises if it was not built -- there is no Python or CPU fallback)."""
+        from .. import torch_ops  # noqa: F401  (loads the library, registers the operators)
+        return torch.ops.macarons
+
     def compute_visibilities(self, pts, harmonics, X_cam):
         """-> [n_clouds, n_camera_candidates, seq_len]   (SconeVis.py:164-208)."""
         self._check_scorer(harmonics)
         sig = self.use_sigmoid
-        hip = lambda p, h, c: ops.sh_visibilities(p, h, c, sig)
+        hip = lambda p, h, c: self._scorer_ops().sh_visibilities(p, h, c, sig)
         if A.needs_grad(None, pts, harmonics, X_cam):
             return A.with_torch_backward(hip, lambda p, h, c: A.visibilities(p, h, c, sig), (pts, harmonics, X_cam))
         return hip(pts, harmonics, X_cam)
@@ -121,7 +128,7 @@ class SconeVis(nn.Module):
         """-> [n_clouds, n_camera_candidates]   (SconeVis.py:210-252)."""
         self._check_scorer(harmonics)
         sig = self.use_sigmoid
-        hip = lambda p, h, c: ops.sh_coverage_gain(p, h, c, sig)
+        hip = lambda p, h, c: self._scorer_ops().sh_coverage_gain(p, h, c, sig)
         if A.needs_grad(None, pts, harmonics, X_cam):
             return A.with_torch_backward(hip, lambda p, h, c: A.coverage_gain(p, h, c, sig), (pts, harmonics, X_cam))
         return hip(pts, harmonics, X_cam)
