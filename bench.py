@@ -143,7 +143,7 @@ def cpu_baseline_nbv(C):
             "note": "extrapolation = fixed + 100000 x per-query cost from the two sample sizes; not a measurement of the full step"}
 
 
-def measure_scorer_traffic(N, C, timeout_s=150):
+def measure_scorer_traffic(N, C, timeout_s=90):
     """HBM read bytes of ONE sh_gain_kernel launch at the headline size, measured in THIS run when rocprofv3 is on the box: a separate
     process runs the scorer under `rocprofv3 --pmc FETCH_SIZE` (counters only, no tracing, as MI355X_MICROARCH.md prescribes), the
     per-dispatch mean of the kernel is read from the counter csv and corrected x2 (gfx950: FETCH_SIZE counts 64-byte units of 128-byte
@@ -157,8 +157,19 @@ def measure_scorer_traffic(N, C, timeout_s=150):
             "p, h, c = bench.make_inputs(%d, %d, 1234, d); [ops.sh_coverage_gain(p, h, c) for _ in range(40)]; torch.cuda.synchronize()" % (ROOT, N, C))
     try:
         env = dict(os.environ, TMPDIR="/tmp")
-        subprocess.run([exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, "-c", code],
-                       cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, timeout=timeout_s)
+        for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k_, None)
+        # its own session: on a time-out the WHOLE tree (rocprofv3 -> python) is killed, nothing is left holding the GPU
+        pr = subprocess.Popen([exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, "-c", code],
+                              cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL,
+                              start_new_session=True)
+        try:
+            pr.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(pr.pid, signal.SIGKILL)
+            pr.wait()
+            return None, f"in-run PMC pass exceeded {timeout_s} s"
         vals = []
         for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
@@ -542,14 +553,12 @@ def timed_scorer_loop(step, finish, steps, warmup, dev, dist):
     for _ in range(warmup):
         step()
     # The W warm-up steps of a short run (the driver's --steps 20 --warmup 5 = 0.3 ms of GPU work) end before the shader clock has
-    # left its idle state: keep issuing UNTIMED steps until the GPU has been busy for ~50 ms, so that the K timed steps measure the
-    # kernel and not the clock ramp (a 2000-step run is unaffected: its warm-up is long enough anyway)
-    t_w = time.perf_counter()
+    # left its idle state: 1000 more UNTIMED steps (>= 50 ms of GPU work) follow, so that the K timed steps measure the kernel and not
+    # the clock ramp.  A FIXED count: every rank must submit the same number of decisions to the exchange (a time-based loop ran a
+    # different number of steps on each rank, their record batches fell out of step and the ranks met in different collectives).
+    for _ in range(1000):
+        step()
     torch.cuda.synchronize()
-    while time.perf_counter() - t_w < 0.05:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
     finish(None)
     torch.cuda.synchronize()
     if dist is not None:
@@ -585,8 +594,13 @@ def main():
     ap.add_argument("--no-nbv", action="store_true", help="skip the NBV-step latency measurement")
     ap.add_argument("--no-strong", action="store_true", help="skip the config-4 strong-scaling scorer leg (profiling the headline size alone)")
     ap.add_argument("--nbv-iters", type=int, default=50)
+    ap.add_argument("--watchdog", type=int, default=0, help="seconds after which every rank dumps its Python stacks to stderr and exits (0 = off): "
+                                                            "a rank stuck in a collective reports where, instead of hanging the job")
     args = ap.parse_args()
 
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -705,7 +719,8 @@ def main():
         pmc_name = next((n_ for n_ in ("r04_scorer_pmc.json", "r03_scorer_pmc.json", "r02_scorer_pmc.json", "r01_scorer_pmc.json") if pmc_profile(n_)), None)
         pmc = pmc_profile(pmc_name) if pmc_name else {}
         valu = (pmc.get("per_dispatch_mean") or {}).get("SQ_INSTS_VALU")
-        traffic, traffic_source = (None, "skipped (--no-pmc)") if args.no_pmc else measure_scorer_traffic(N, C)
+        traffic, traffic_source = ((None, "skipped (--no-pmc / N > 1)") if (args.no_pmc or world > 1 or os.environ.get("MCR_BENCH_NO_PMC"))
+                                   else measure_scorer_traffic(N, C))
         if traffic is None:                                # no rocprofv3 / pass failed: the committed profile's figure, labelled as such
             traffic_source = f"static: profiles/{pmc_name} ({traffic_source})"
             traffic = pmc.get("hbm_read_bytes_per_launch_corrected")

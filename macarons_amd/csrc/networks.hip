@@ -175,7 +175,7 @@ static void run_x_embedding_planes(hipStream_t s, const float* x, const float* v
     head_planes_weights(s, 1, xe3.w, 256, 512, 256, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
     launch_linear3p(s, hh, hh + (size_t)T * 256, 256, Wh, Wl, 256, xe3.b, nullptr, fh + 768, fl + 768, 1344, T, 512, 256, ACT_GELU, inv, nullptr, 0,
                     nullptr);
-    launch_split_to_planes(s, view_harmonics, 64, fh + 1280, fl + 1280, 1344, T, 64);
+    if (view_harmonics) launch_split_to_planes(s, view_harmonics, 64, fh + 1280, fl + 1280, 1344, T, 64);      // (NULL: the caller splits them later)
 }
 
 // x_done: the x-embedding part has been queued elsewhere (the side stream: the join covers it)
@@ -421,15 +421,17 @@ int mcr_knn_points(const float* X, const float* pc, int64_t* idx, float* dists, 
 struct OccSide { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 // One side stream + fork / join event pair per (device, CALLER stream): two host streams (or threads) running SconeOcc
 // concurrently never share an event pair; creation is serialised.
-static OccSide* occ_side(hipStream_t caller) {
+// slot 0: the global transformer / the cloud build; slot 1: the x embedding queued with the early part (its own stream: on slot 0 the
+// cloud build of the first search would queue up behind its GEMMs)
+static OccSide* occ_side(hipStream_t caller, int slot = 0) {
     static const bool on = []() { const char* e = getenv("MCR_OCC_OVERLAP"); return !(e && e[0] == '0'); }();
     if (!on) return nullptr;
     static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, OccSide> table;
+    static std::map<std::pair<std::pair<int, int>, hipStream_t>, OccSide> table;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
-    OccSide& x = table[std::make_pair(dev, caller)];
+    OccSide& x = table[std::make_pair(std::make_pair(dev, slot), caller)];
     if (!x.s) {
         if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
@@ -532,14 +534,36 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
     // transformer: its workgroups fill the machine in the holes of the local path (kNN preparation, the parked kNN groups, kernel
     // tails) instead of extending the serial tail of the step.  MCR_OCC_X_SIDE=0: on the caller's stream, after the local path.
     static const bool x_side_on = []() { const char* e = getenv("MCR_OCC_X_SIDE"); return !(e && e[0] == '0'); }();
-    const bool x_on_side = planes && side && x_side_on;
     const HeadScratch head_scratch{featP, reinterpret_cast<_Float16*>(h1), h2, wplanes};
+    // ... and it needs nothing but the queries, so it is queued with the EARLY part (phase 1 / the start of the single call), where the
+    // GPU is nearly idle for ~0.4 ms (query order, cloud build, the scale-0 search): behind the global transformer it only found the
+    // holes between the local-transformer launches and finished 0.15 ms AFTER the last of them -- the head waited for it
+    // (profiles/r04_nbv_step_breakdown.txt).  The view harmonics (known in phase 2 only) are split there.  MCR_OCC_X_EARLY=0: as before.
+    static const bool x_early_on = []() { const char* e = getenv("MCR_OCC_X_EARLY"); return !(e && e[0] == '0'); }();
+    OccSide* xside = planes && x_side_on && x_early_on && occ_side(s) ? occ_side(s, 1) : nullptr;
+    const bool x_early = xside != nullptr;               // (the same answer in phase 1 and in phase 2 of one forward)
+    const bool x_on_side = planes && side && x_side_on;
+    // the caller's stream waits for the early x embedding BEHIND the early part's own kernels (end of phase 1 / before the head); every
+    // way out of the function in between queues that wait too (a dangling fork would poison a capture)
+    struct XJoin {
+        OccSide* side; hipStream_t s; bool armed;
+        bool wait() { if (!armed) return true; armed = false; return hipStreamWaitEvent(s, side->join, 0) == hipSuccess; }
+        ~XJoin() { (void)wait(); }
+    } x_join{xside, s, false};
+    if (x_early && early) {
+        MCR_REQUIRE(hipEventRecord(xside->fork, s) == hipSuccess && hipStreamWaitEvent(xside->s, xside->fork, 0) == hipSuccess,
+                    "mcr_scone_occ_forward: side stream (x embedding fork)");
+        run_x_embedding_planes(xside->s, x, nullptr, B * Q, xe1, xe2, xe3, head_planes, head_inv_scales, head_scratch);
+        MCR_REQUIRE(hipEventRecord(xside->join, xside->s) == hipSuccess, "mcr_scone_occ_forward: side stream (x embedding record)");
+        x_join.armed = true;
+    }
     if (late) {
         run_pct(gs, wg, pc_global, gfeat, 512, B, (int)Lg, 256, garena);
         MCR_REQUIRE(garena.ok(), "mcr_scone_occ_forward: workspace overflow (global)");
         // its contribution to linear1: gbias[b, n] = sum_k gfeat[b, k] * W1[n, k]  (columns 0..511 of linear1.weight)
         launch_linear(gs, gfeat, 512, lin1.w, nullptr, nullptr, 0, gbias, 512, B, 512, 512, ACT_NONE, nullptr, 0, 1856, 1);
-        if (x_on_side) run_x_embedding_planes(gs, x, view_harmonics, B * Q, xe1, xe2, xe3, head_planes, head_inv_scales, head_scratch);
+        if (x_on_side && x_early) launch_split_to_planes(gs, view_harmonics, 64, featP + 1280, featP + Tall * FEAT + 1280, 1344, B * Q, 64);
+        else if (x_on_side) run_x_embedding_planes(gs, x, view_harmonics, B * Q, xe1, xe2, xe3, head_planes, head_inv_scales, head_scratch);
     }
     if (side) {
         MCR_REQUIRE(hipEventRecord(side->join, side->s) == hipSuccess, "mcr_scone_occ_forward: side stream (record)");
@@ -608,6 +632,7 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
             }
         }
     }
+    MCR_REQUIRE(x_join.wait(), "mcr_scone_occ_forward: side stream (x embedding join)");
     if (!late) {
         MCR_LAUNCH_CHECK("mcr_scone_occ_forward (phase 1)");
         return 0;

@@ -17,7 +17,7 @@ def test_bench_self_launches_two_ranks_on_one_gpu(dev):
     env = dict(os.environ, MCR_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--nbv-iters", "3",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+                        "--no-cpu-baseline", "--watchdog", "150"], capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     last = r.stdout.strip().splitlines()[-1]
     res = json.loads(last)                                     # rank 0's line is the LAST line of stdout
