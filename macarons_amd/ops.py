@@ -802,6 +802,11 @@ def cell_keys(pts, grid_consts, grid, lo_tab=None, hi_tab=None, valid=None):
 def key_histogram(key, nk):
     """key int32 [N] -> (counts int64 [nk+1], exclusive offsets int64 [nk+2])."""
     key = _req(key, "key", torch.int32)
+    if nk > 1023:                                   # grids beyond the one-block kernel's LDS table (> 1023 cells): device ops, same result
+        counts = torch.zeros(nk + 1, dtype=torch.int64, device=key.device).scatter_add_(0, key.long().clamp_(0, nk), torch.ones_like(key, dtype=torch.int64))
+        offsets = torch.zeros(nk + 2, dtype=torch.int64, device=key.device)
+        offsets[1:] = torch.cumsum(counts, 0)
+        return counts, offsets
     counts = torch.empty(nk + 1, dtype=torch.int64, device=key.device)
     offsets = torch.empty(nk + 2, dtype=torch.int64, device=key.device)
     with torch.cuda.device(key.device):

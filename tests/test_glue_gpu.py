@@ -332,3 +332,46 @@ def test_nbv_decide_follows_torch_max_and_the_empty_sample_rule():
     assert torch.equal(torch.nan_to_num(rec[1 + B:].to(torch.float32), nan=-7.0), torch.nan_to_num(best.values, nan=-7.0))
     mx2, idx2, rec2 = ops.nbv_decide(gains[:1].contiguous().to(dev))                                       # no counts, no flag
     assert int(idx2) == int(torch.argmax(gains[0])) and rec2[0] == 0.0
+
+
+def test_scene_grid_kernels_match_the_torch_expressions(dev):
+    """mcr_cell_keys / mcr_key_histogram / mcr_admit_keys (the fused bookkeeping of Scene.fill_cells and of the occupancy field's cell
+    lookup) against the torch expressions they replace (get_cells_for_each_pt's floor rule, the closed scene box, Cell.fill's strict
+    box masks, per-cell counts, the fp64 admission compare): bit-exact on points inside, outside, on cell faces and on the scene's
+    boundary, for two grids (one with more than 1023 cells: the histogram's device-op form)."""
+    from macarons_amd import ops
+    from macarons_amd.utility.scene import Scene
+    rng = np.random.default_rng(12)
+    for grid, lo_c, hi_c in (((3, 2, 3), [-12., -6., -12.], [12., 6., 12.]), ((11, 10, 12), [-1.3, -2.0, 0.5], [3.1, 2.2, 4.0])):
+        x_min, x_max = torch.tensor(lo_c, device=dev), torch.tensor(hi_c, device=dev)
+        sc = Scene(x_min, x_max, *grid, cell_capacity=1000, cell_resolution=0.05, n_proxy_points=10, device=dev, feature_dim=1)
+        n_cells = grid[0] * grid[1] * grid[2]
+        ext = np.array(hi_c) - np.array(lo_c)
+        pts = rng.uniform(-0.1, 1.1, (20000, 3)) * ext + np.array(lo_c)                            # some outside the box
+        step = ext / np.array(grid)
+        faces = np.array(lo_c) + rng.integers(0, np.array(grid) + 1, (3000, 3)) * step             # exactly on cell faces / the boundary
+        mix = rng.uniform(0, 1, (3000, 3)) * ext + np.array(lo_c)
+        on = rng.random((3000, 3)) < 0.4
+        pts = torch.from_numpy(np.concatenate([pts, np.where(on, faces, mix)]).astype(np.float32)).to(dev)
+        valid = torch.from_numpy(rng.random(len(pts)) < 0.8).to(dev)
+        cells, lo, hi = sc._cell_table()
+        # the torch expressions of Scene.fill_cells (round 3 form)
+        cid = (sc.get_cells_for_each_pt(pts) * sc._consts(dev)["lin"]).sum(-1)
+        ok = ((pts >= x_min) & (pts <= x_max)).all(-1)
+        ok = ok & (torch.max(pts - hi[cid], dim=-1)[0] < 0.) & (torch.min(pts - lo[cid], dim=-1)[0] > 0.) & valid
+        key_ref = torch.where(ok, cid, torch.full_like(cid, n_cells))
+        key = ops.cell_keys(pts, sc._consts(dev)["gc"], grid, lo, hi, valid)
+        assert torch.equal(key.long(), key_ref)
+        assert torch.equal(sc.linear_cell_ids(pts).long(), cid)
+        assert 0 < int((key < n_cells).sum()) < len(pts)
+        counts, offsets = ops.key_histogram(key, n_cells)
+        ref = torch.bincount(key_ref, minlength=n_cells + 1)
+        assert torch.equal(counts, ref) and torch.equal(offsets[1:], torch.cumsum(ref, 0)) and int(offsets[0]) == 0
+        order = torch.sort(key, stable=True).indices
+        key_s = key[order].contiguous()
+        d = torch.from_numpy(rng.uniform(0, 0.1, len(pts))).to(dev)
+        d[::7] = 0.05                                                                               # exactly the resolution: not admitted (strict)
+        for n_min in (0, 3):
+            k2 = ops.admit_keys(d, key_s, counts, 0.05, n_min, n_cells)
+            adm = (d > 0.05) & (key_s < n_cells) & (counts[key_s.long()] > n_min)
+            assert torch.equal(k2.long(), torch.where(adm, key_s.long(), torch.full_like(key_s.long(), n_cells)))
