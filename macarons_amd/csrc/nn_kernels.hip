@@ -487,21 +487,40 @@ __global__ __launch_bounds__(64 * KS) void attention_flash_kernel(const float* _
 // three v_mfma_f32_16x16x32_f16 of ~17 pipe cycles per 32 keys x 16 columns instead of eight fp32 ones of 32 (the P V product is
 // 80 % of the kernel's matrix work; S = Q K^T stays exact fp32).  A tile holding a value outside the fp16 range (|v| >= 32768, inf, NaN) is detected
 // while it is staged (block-wide OR folded into the tile barrier) and takes the fp32 path: no range restriction, no flag.
-template <int DQ, int DV, bool SPLIT, bool PVH, bool MASK = false>
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, long long ldq,
+// QG (1 or 2): 16-query groups per wave.  A batch of sequences (8 clouds of a scene batch, the 30 neighbour cameras of a MACARONS
+// decision) fills the chip with 128-query blocks too: every K / V tile staged (fetch, fp16 split, LDS commit: half of the kernel's
+// vector instructions at QG = 1) and every K / V fragment read then serves 32 queries of a wave instead of 16.  Each query's
+// arithmetic -- scores, 64-key softmax steps, the order of the P V products -- is the same instruction sequence whatever QG is:
+// the result does not depend on it (tests: batch == single sequence, bit for bit).
+// (Measured and not kept: K / V tiles double-buffered in LDS for one barrier per tile instead of two -- no change; the split of P and V
+// by v_fma_mix -- no change: the kernel waits, it is not issue-bound.  Occupancy is what moves it: att_occ below.)
+#ifndef MCR_ATT_OCC_16_1
+#define MCR_ATT_OCC_16_1 2
+#endif
+#ifndef MCR_ATT_OCC_16_2
+#define MCR_ATT_OCC_16_2 2
+#endif
+#ifndef MCR_ATT_OCC_8_1
+#define MCR_ATT_OCC_8_1 3
+#endif
+#ifndef MCR_ATT_OCC_8_2
+#define MCR_ATT_OCC_8_2 3
+#endif
+constexpr int att_occ(int dq, int qg) { return dq == 16 ? (qg == 1 ? MCR_ATT_OCC_16_1 : MCR_ATT_OCC_16_2) : (qg == 1 ? MCR_ATT_OCC_8_1 : MCR_ATT_OCC_8_2); }
+template <int DQ, int DV, bool SPLIT, bool PVH, bool MASK = false, int QG = 1>
+__global__ __launch_bounds__(256, att_occ(DQ, QG)) void attention_mfma_kernel(const float* __restrict__ qkv, long long ldq,
                                                              float* __restrict__ out, long long ldo, int L, int H,
                                                              const int* __restrict__ lens, float* __restrict__ part1,
                                                              float* __restrict__ ml, AttnMask mk = AttnMask{nullptr, 0, 0, 0}) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
     typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-    constexpr int TK = 64, LDK = DQ + 1, LDV = DV + 4, NT = DV / 16, KQ = DQ / 4;
+    constexpr int TK = 64, LDK = DQ + 1, LDV = DV + 4, NT = DV / 16, KQ = DQ / 4, QB = 64 * QG;
     __shared__ float s_k[TK * LDK];
     __shared__ __attribute__((aligned(16))) float s_v[TK * LDV];
-    // PVH: the same bytes hold the fp16 images of V instead: hi | lo, each [NT][64 keys][16 columns] (2 * NT * 2 KB <= the fp32 tile)
-    _Float16* s_vh = reinterpret_cast<_Float16*>(s_v);
-    _Float16* s_vl = s_vh + NT * TK * 16;
+    // PVH: the bytes of a V buffer hold the fp16 images of V instead: hi | lo, each [NT][64 keys][16 columns] (2 * NT * 2 KB <= the fp32 tile)
     static_assert(2 * NT * TK * 16 * 2 <= TK * LDV * 4, "fp16 V images do not fit the fp32 tile");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
     const int hh = blockIdx.y;
@@ -510,25 +529,30 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     const int Lk_all = lens ? max(1, min(L, __builtin_amdgcn_readfirstlane(lens[seq]))) : L;             // number of keys
     const int kmid = min(Lk_all, ((Lk_all / 2 + TK - 1) / TK) * TK);                                    // tile-aligned cut
     const int kb = SPLIT && part ? kmid : 0, Lk = SPLIT && !part ? kmid : Lk_all;                        // this block's keys [kb, Lk)
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int q0 = blockIdx.x * QB + wave * 16 * QG;    // + 16 qg: the wave's query groups
     const int koff = H * DQ + hh * DQ, voff = 2 * H * DQ + hh * DV;
     const float scale = 1.0f / sqrtf((float)DQ);
 
-    float qb[KQ];                                       // B operand of S^T: Q[q0 + li][4s + g] * scale
-    {
-        const int qi = min(q0 + li, L - 1);
+    float qb[QG][KQ];                                   // B operand of S^T: Q[q0 + 16 qg + li][4s + g] * scale
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        const int qi = min(q0 + 16 * qg + li, L - 1);
         const float* qp = qkv + (seq0 + qi) * ldq + hh * DQ;
 #pragma unroll
-        for (int sk = 0; sk < KQ; ++sk) qb[sk] = qp[4 * sk + g] * scale;
+        for (int sk = 0; sk < KQ; ++sk) qb[qg][sk] = qp[4 * sk + g] * scale;
     }
-    float m = -__builtin_inff(), l = 0.f;              // running max (shared by the 4 lanes of a query), this lane's part of the sum
-    f32x4 o[NT];
+    float m[QG], l[QG];                                 // running max (shared by the 4 lanes of a query), this lane's part of the sum
+    f32x4 o[QG][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qg = 0; qg < QG; ++qg) {
+        m[qg] = -__builtin_inff(); l[qg] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o[qg][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    // staging: every thread moves PT float4 of the [64 keys x (DQ + DV)] tile; the next tile's loads are all issued before
-    // this tile's MFMA phase and land in LDS after it (the per-element copy loop of the VALU kernel serialises ~20 load
-    // latencies per tile and is what bounds it)
+    // staging: every thread moves PT float4 of the [64 keys x (DQ + DV)] tile; a tile's loads are all issued one MFMA phase
+    // before they are committed to LDS (the per-element copy loop of the VALU kernel serialises ~20 load latencies per tile and
+    // is what bounds it)
     constexpr int F4K = (DQ + DV) / 4, NF4 = TK * F4K, PT = (NF4 + 255) / 256;
     float4 stage[PT];
     auto fetch = [&](int t0) {
@@ -553,6 +577,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         }
         return big;
     };
+    _Float16* s_vh = reinterpret_cast<_Float16*>(s_v);
+    _Float16* s_vl = s_vh + NT * TK * 16;
     auto commit = [&](const bool half_v) {
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
@@ -599,57 +625,64 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) vb[0][sk][nt] = vbase[sk * LDV + nt * 16];
         }
-        f32x4 st[4];
-        float tmax = -__builtin_inff();
+        f32x4 st[QG][4];
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            st[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qg = 0; qg < QG; ++qg)
 #pragma unroll
-            for (int sk = 0; sk < KQ; ++sk) st[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[sub][sk], qb[sk], st[sub], 0, 0, 0);
-        }
-        if (MASK) {                                       // Attention.py:24-27: masked pairs score -1e3 (then / sqrt(d)), not -inf
-            const unsigned char* mrow = mk.p + (long long)seq * mk.ms + hh * mk.mh + (long long)min(q0 + li, L - 1) * mk.mq + t0;
+            for (int sub = 0; sub < 4; ++sub) {
+                st[qg][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sk = 0; sk < KQ; ++sk)
+                    st[qg][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[sub][sk], qb[qg][sk], st[qg][sub], 0, 0, 0);
+            }
+        float ar[QG][4];
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+            if (MASK) {                                   // Attention.py:24-27: masked pairs score -1e3 (then / sqrt(d)), not -inf
+                const unsigned char* mrow = mk.p + (long long)seq * mk.ms + hh * mk.mh + (long long)min(q0 + 16 * qg + li, L - 1) * mk.mq + t0;
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = sub * 16 + 4 * g + r;
+                        if (t0 + key < L && mrow[key] == 0) st[qg][sub][r] = -1e3f * scale;
+                    }
+            }
+            if (t0 + TK > Lk) {                           // only the last tile of a sequence has keys past its end (block-uniform)
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t0 + sub * 16 + 4 * g + r >= Lk) st[qg][sub][r] = -__builtin_inff();
+            }
+            float tmax = -__builtin_inff();
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, st[qg][sub][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m[qg], tmax);
+            const float alpha = __expf(m[qg] - m_new);   // m = -inf on the first tile -> 0 (o = l = 0 anyway)
+            m[qg] = m_new;
+            float psum = 0.f;
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = sub * 16 + 4 * g + r;
-                    if (t0 + key < L && mrow[key] == 0) st[sub][r] = -1e3f * scale;
+                    st[qg][sub][r] = __expf(st[qg][sub][r] - m_new);
+                    psum += st[qg][sub][r];
                 }
+            l[qg] = fmaf(l[qg], alpha, psum);
+            // ---- rescale O (rows = queries 4g + r live in lane group g) ----
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ar[qg][r] = __shfl(alpha, 4 * g + r, 64);   // alpha of query 4g + r (any lane group holds it)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qg][nt][r] *= ar[qg][r];
         }
-        if (t0 + TK > Lk) {                               // only the last tile of a sequence has keys past its end (block-uniform)
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (t0 + sub * 16 + 4 * g + r >= Lk) st[sub][r] = -__builtin_inff();
-        }
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, st[sub][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m, tmax);
-        const float alpha = __expf(m - m_new);           // m = -inf on the first tile -> 0 (o = l = 0 anyway)
-        m = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                st[sub][r] = __expf(st[sub][r] - m_new);
-                psum += st[sub][r];
-            }
-        l = fmaf(l, alpha, psum);
-        // ---- rescale O (rows = queries 4g + r live in lane group g) and accumulate P V ----
-        float ar[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r, 64);   // alpha of query 4g + r (any lane group holds it)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[nt][r] *= ar[r];
+        // ---- accumulate P V ----
         if (PVH && half_v) {
             // P (this lane: queries li, keys 4g + r of every 16-key sub-tile) is the A fragment as it stands; V fragments by transpose read
             const _Float16* vh0 = s_vh + (4 * g) * 16 + li * 4;
@@ -658,78 +691,92 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             // MFMA's cycle count): k index 8 g + r <-> key 4 g + r of sub-tile 2 q (r < 4) or 2 q + 1 (r >= 4), on both operands
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                uint4 ph, pl;
-                split2h(st[2 * q][0], st[2 * q][1], ph.x, pl.x);
-                split2h(st[2 * q][2], st[2 * q][3], ph.y, pl.y);
-                split2h(st[2 * q + 1][0], st[2 * q + 1][1], ph.z, pl.z);
-                split2h(st[2 * q + 1][2], st[2 * q + 1][3], ph.w, pl.w);
-                const f16x8 p_hi = __builtin_bit_cast(f16x8, ph), p_lo = __builtin_bit_cast(f16x8, pl);
+                f16x8 p_hi[QG], p_lo[QG];
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg) {
+                    uint4 ph, pl;
+                    split2h(st[qg][2 * q][0], st[qg][2 * q][1], ph.x, pl.x);
+                    split2h(st[qg][2 * q][2], st[qg][2 * q][3], ph.y, pl.y);
+                    split2h(st[qg][2 * q + 1][0], st[qg][2 * q + 1][1], ph.z, pl.z);
+                    split2h(st[qg][2 * q + 1][2], st[qg][2 * q + 1][3], ph.w, pl.w);
+                    p_hi[qg] = __builtin_bit_cast(f16x8, ph); p_lo[qg] = __builtin_bit_cast(f16x8, pl);
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const _Float16* bh = vh0 + (nt * TK + q * 32) * 16;
                     const _Float16* bl = vl0 + (nt * TK + q * 32) * 16;
                     const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)bh), h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bh + 256));
                     const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)bl), l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bl + 256));
-                    typedef short s16x8 __attribute__((ext_vector_type(8)));
                     const f16x8 v_hi = __builtin_bit_cast(f16x8, s16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]});
                     const f16x8 v_lo = __builtin_bit_cast(f16x8, s16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]});
-                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_lo, v_hi, o[nt], 0, 0, 0);      // smallest terms first
-                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_hi, v_lo, o[nt], 0, 0, 0);
-                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_hi, v_hi, o[nt], 0, 0, 0);
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg) {
+                        o[qg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_lo[qg], v_hi, o[qg][nt], 0, 0, 0);      // smallest terms first
+                        o[qg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_hi[qg], v_lo, o[qg][nt], 0, 0, 0);
+                        o[qg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_hi[qg], v_hi, o[qg][nt], 0, 0, 0);
+                    }
                 }
             }
-            continue;
-        }
+        } else {
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            if (sub + 1 < 4) {
+            for (int sub = 0; sub < 4; ++sub) {
+                if (sub + 1 < 4) {
 #pragma unroll
-                for (int sk = 0; sk < 4; ++sk)
+                    for (int sk = 0; sk < 4; ++sk)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) vb[(sub + 1) & 1][sk][nt] = vbase[((sub + 1) * 16 + sk) * LDV + nt * 16];
-            }
+                        for (int nt = 0; nt < NT; ++nt) vb[(sub + 1) & 1][sk][nt] = vbase[((sub + 1) * 16 + sk) * LDV + nt * 16];
+                }
 #pragma unroll
-            for (int sk = 0; sk < 4; ++sk)
+                for (int qg = 0; qg < QG; ++qg)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[sub][sk], vb[sub & 1][sk][nt], o[nt], 0, 0, 0);
-            if (sub + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4 * NT, 0);     // next sub-tile's V fragments ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);                      // ... then this one's MFMAs
-        }
-    }
-    // ---- normalise and write: lane (c = li, g) owns O[q0 + 4g + r][nt*16 + li] ----
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    if (SPLIT) {
-        if (g == 0 && q0 + li < L) {
-            float* p = ml + (((long long)part * gridDim.z / 2 * L + seq0 + q0 + li) * H + hh) * 2;
-            p[0] = m; p[1] = l;
-        }
-        float* dst = part ? part1 : out;
-        const long long ld = part ? (long long)H * DV : ldo;
+                    for (int sk = 0; sk < 4; ++sk)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qi = q0 + 4 * g + r;
-            if (qi < L) {
-                float* orow = dst + (seq0 + qi) * ld + hh * DV;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) orow[nt * 16 + li] = o[nt][r];
+                        for (int nt = 0; nt < NT; ++nt)
+                            o[qg][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[qg][sub][sk], vb[sub & 1][sk][nt], o[qg][nt], 0, 0, 0);
+                if (sub + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4 * NT, 0);     // next sub-tile's V fragments ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * QG, 0);                 // ... then this one's MFMAs
             }
         }
-        return;
     }
-    const float inv = 1.0f / l;
+    // ---- normalise and write: lane (c = li, g) owns O[q0 + 16 qg + 4g + r][nt*16 + li] ----
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float ir = __shfl(inv, 4 * g + r, 64);
-        const int qi = q0 + 4 * g + r;
-        if (qi < L) {
-            float* orow = out + (seq0 + qi) * ldo + hh * DV;
+    for (int qg = 0; qg < QG; ++qg) {
+        float lq = l[qg];
+        lq += __shfl_xor(lq, 16, 64);
+        lq += __shfl_xor(lq, 32, 64);
+        const int qbase = q0 + 16 * qg;
+        if (SPLIT) {
+            if (g == 0 && qbase + li < L) {
+                float* p = ml + (((long long)part * gridDim.z / 2 * L + seq0 + qbase + li) * H + hh) * 2;
+                p[0] = m[qg]; p[1] = lq;
+            }
+            float* dst = part ? part1 : out;
+            const long long ld = part ? (long long)H * DV : ldo;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) orow[nt * 16 + li] = o[nt][r] * ir;
+            for (int r = 0; r < 4; ++r) {
+                const int qi = qbase + 4 * g + r;
+                if (qi < L) {
+                    float* orow = dst + (seq0 + qi) * ld + hh * DV;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) orow[nt * 16 + li] = o[qg][nt][r];
+                }
+            }
+        } else {
+            const float inv = 1.0f / lq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ir = __shfl(inv, 4 * g + r, 64);
+                const int qi = qbase + 4 * g + r;
+                if (qi < L) {
+                    float* orow = out + (seq0 + qi) * ldo + hh * DV;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) orow[nt * 16 + li] = o[qg][nt][r] * ir;
+                }
+            }
         }
     }
 }
+
 
 // out[t, h, :] = (w0 o0 + w1 o1) / (w0 l0 + w1 l1),  w_p = exp(m_p - max(m0, m1)); a part without keys has m = -inf, l = 0
 __global__ void attention_combine_kernel(float* __restrict__ out, long long ldo, const float* __restrict__ part1,
@@ -781,19 +828,43 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
             hipLaunchKernelGGL((attention_mfma_kernel<DQ_, DV_, SPLIT_, false>), GRID_, dim3(256), 0, s, qkv, (long long)ldq, out,      \
                                (long long)ldo, L, H, lens, P1_, ML_);                                                                  \
     } while (0)
+#define MCR_ATT2(DQ_, DV_, SPLIT_, GRID_, P1_, ML_)                                                                                   \
+    do {                                                                                                                               \
+        if (pv_half)                                                                                                                   \
+            hipLaunchKernelGGL((attention_mfma_kernel<DQ_, DV_, SPLIT_, true, false, 2>), GRID_, dim3(256), 0, s, qkv, (long long)ldq,  \
+                               out, (long long)ldo, L, H, lens, P1_, ML_);                                                             \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((attention_mfma_kernel<DQ_, DV_, SPLIT_, false, false, 2>), GRID_, dim3(256), 0, s, qkv, (long long)ldq, \
+                               out, (long long)ldo, L, H, lens, P1_, ML_);                                                             \
+    } while (0)
+        // a batch of sequences fills the chip with 128-query blocks (two 16-query groups per wave: half the staging and fragment
+        // reads per query; same bits): >= 2 blocks per CU; MCR_ATTN_QG=1: always 64-query blocks (A/B)
+        static const bool qg2_on = []() { const char* e = getenv("MCR_ATTN_QG"); return !(e && e[0] == '1'); }();
+        const dim3 grid2((unsigned)cdiv(L, 128), (unsigned)H, (unsigned)(split ? 2 * S : S));
+        const bool qg2 = qg2_on && !mask && (int64_t)grid2.x * grid2.y * grid2.z >= 512;
         if (split) {
             float* part1 = split_ws;
             float* ml = split_ws + (size_t)S * L * DV;
             const dim3 g2(grid.x, grid.y, (unsigned)(2 * S));
-            if (dq == 8) MCR_ATT(8, 32, true, g2, part1, ml);
-            else MCR_ATT(16, 64, true, g2, part1, ml);
+            if (qg2) {
+                if (dq == 8) MCR_ATT2(8, 32, true, grid2, part1, ml);
+                else MCR_ATT2(16, 64, true, grid2, part1, ml);
+            } else if (dq == 8) {
+                MCR_ATT(8, 32, true, g2, part1, ml);
+            } else {
+                MCR_ATT(16, 64, true, g2, part1, ml);
+            }
             hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv(S * L * DV, 256)), dim3(256), 0, s, out, (long long)ldo,
                                (const float*)part1, (const float*)ml, (long long)(S * L), H, dv);
+        } else if (qg2) {
+            if (dq == 8) MCR_ATT2(8, 32, false, grid2, (float*)nullptr, (float*)nullptr);
+            else MCR_ATT2(16, 64, false, grid2, (float*)nullptr, (float*)nullptr);
         } else if (dq == 8) {
             MCR_ATT(8, 32, false, grid, (float*)nullptr, (float*)nullptr);
         } else {
             MCR_ATT(16, 64, false, grid, (float*)nullptr, (float*)nullptr);
         }
+#undef MCR_ATT2
 #undef MCR_ATT
         return;
     }

@@ -105,6 +105,54 @@ def test_long_sequence_attention_outside_the_half_range(dev):
     assert (np.abs(y - ref) / np.maximum(col, 1.0)).max() < 2e-5
 
 
+@pytest.mark.parametrize("S,L,H,qk,v", [(12, 1777, 4, 64, 256), (18, 1500, 4, 32, 128)])
+def test_batched_attention_returns_the_single_sequence_bits(dev, S, L, H, qk, v):
+    """A batch that fills the chip runs the long-sequence attention in 128-query blocks (two 16-query groups per wave share every
+    staged K / V tile); one sequence alone runs in 64-query blocks with its keys split over two blocks when the sequence is long.
+    Same arithmetic per query in the 128- and 64-query forms: equal bit for bit when neither splits its keys, within rounding of the
+    key-split combine otherwise -- incl. a ragged length (not a multiple of 128 / 64 / 16) and a V tile outside the fp16 range
+    (fp32 fallback inside the 128-query form); and the batch against fp64."""
+    from macarons_amd import ops
+    rng = np.random.default_rng(S + L)
+    qkv = rng.standard_normal((S, L, 2 * qk + v)).astype(np.float32)
+    qkv[3, 130:150, 2 * qk:] *= 1e6                                    # one tile of sequence 3 leaves the fp16 range
+    x = T(qkv, dev)
+    big = ops.attention_packed(x, H, qk, v)
+    for b in (0, 3, S - 1):
+        one = ops.attention_packed(x[b:b + 1].contiguous(), H, qk, v, split=False)       # 64-query blocks, all keys in one block
+        assert torch.equal(one[0], big[b]), b
+        two = ops.attention_packed(x[b:b + 1].contiguous(), H, qk, v, split=True)        # keys over two blocks + combine
+        assert float((two[0] - big[b]).abs().max()) <= 2e-6 * float(big[b].abs().max()), b
+    xs = qkv[:2].astype(np.float64)
+    hs = lambda t, d: t.reshape(2, L, H, d).transpose(0, 2, 1, 3)
+    q, k, vv = hs(xs[..., :qk], qk // H), hs(xs[..., qk:2 * qk], qk // H), hs(xs[..., 2 * qk:], v // H)
+    sc = q @ k.transpose(0, 1, 3, 2) / np.sqrt(qk // H)
+    sc = np.exp(sc - sc.max(-1, keepdims=True))
+    ref = ((sc / sc.sum(-1, keepdims=True)) @ vv).transpose(0, 2, 1, 3).reshape(2, L, v)
+    assert np.abs(big[:2].cpu().numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_scone_vis_padded_lengths_in_a_chip_filling_batch(dev):
+    """lengths= (device-side key counts) inside the 128-query-block attention: a batch of 12 padded clouds of up to 2048 points ==
+    the same clouds in batches of 2 (64-query blocks), bit for bit."""
+    from macarons_amd.networks import SconeVis
+    m, _ = _mod(SconeVis, 1, dev)
+    rng = np.random.default_rng(13)
+    N, lens = 2048, [2048, 1999, 1025, 1024, 700, 129, 128, 127, 65, 17, 16, 1]
+    pts = np.concatenate([rng.uniform(-0.5, 0.5, (12, N, 3)), rng.uniform(0.1, 1.0, (12, N, 1))], -1).astype(np.float32)
+    vh = (rng.standard_normal((12, N, 64)) * 0.3).astype(np.float32)
+    for b, n in enumerate(lens):
+        pts[b, n:] = 1e3
+        vh[b, n:] = -7.0
+    ln = torch.tensor(lens, dtype=torch.int32, device=dev)
+    with torch.no_grad():
+        y = m(T(pts, dev), view_harmonics=T(vh, dev), lengths=ln)
+        for b in range(0, 12, 2):
+            yb = m(T(pts[b:b + 2], dev), view_harmonics=T(vh[b:b + 2], dev), lengths=ln[b:b + 2].contiguous())
+            for i in range(2):
+                assert torch.equal(yb[i, :lens[b + i]], y[b + i, :lens[b + i]]), b + i
+
+
 def test_layernorm_and_pools(dev):
     from macarons_amd import ops
     rng = np.random.default_rng(0)
