@@ -143,8 +143,12 @@ void launch_linear3(hipStream_t s, const float* X, int64_t ldx, const float* W, 
                     int64_t ldw, const int* row_group) {
     const int64_t mb = cdiv(M, L3G_BM);
     const long long rpg = rows_per_group > 0 ? rows_per_group : 1;
-    // widest column tile that still gives the chip ~2 blocks per CU (performance only: see the note on L3G_NT above)
-    int nt = 4;
+    // widest column tile that still gives the chip ~2 blocks per CU (performance only: see the note on L3G_NT above); the short-K
+    // GEMMs of the encoders (K = 256 / 512: eight or sixteen chunks between an exposed first load and the epilogue) run better on
+    // 64-column blocks, four per CU, than on 128-column ones, three per CU (SconeVis on 30 x 2048 tokens: 3.80 vs 4.11 ms); the
+    // head's K = 1344 the other way round.  MCR_L3_SHORTK=0: 128-column blocks whatever K is (A/B)
+    static const bool shortk = []() { const char* e = getenv("MCR_L3_SHORTK"); return !(e && e[0] == '0'); }();
+    int nt = shortk && K <= 512 ? 2 : 4;
     while (nt > 1 && mb * cdiv(N, nt * 32) < 512) nt >>= 1;
 #define MCR_L3(NT)                                                                                                              \
     hipLaunchKernelGGL((linear3_kernel<NT>), dim3((unsigned)mb, (unsigned)cdiv(N, NT * 32)), dim3(256), 0, s, X, (long long)ldx, W, \

@@ -838,8 +838,8 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
                                out, (long long)ldo, L, H, lens, P1_, ML_);                                                             \
     } while (0)
         // a batch of sequences fills the chip with 128-query blocks (two 16-query groups per wave: half the staging and fragment
-        // reads per query; same bits): >= 2 blocks per CU; MCR_ATTN_QG=1: always 64-query blocks (A/B)
-        static const bool qg2_on = []() { const char* e = getenv("MCR_ATTN_QG"); return !(e && e[0] == '1'); }();
+        // reads per query; same bits): >= 2 blocks per CU; MCR_ATTN_QG2=0: always 64-query blocks (A/B)
+        static const bool qg2_on = []() { const char* e = getenv("MCR_ATTN_QG2"); return !(e && e[0] == '0'); }();
         const dim3 grid2((unsigned)cdiv(L, 128), (unsigned)H, (unsigned)(split ? 2 * S : S));
         const bool qg2 = qg2_on && !mask && (int64_t)grid2.x * grid2.y * grid2.z >= 512;
         if (split) {
