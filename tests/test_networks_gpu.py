@@ -112,17 +112,24 @@ def test_batched_attention_returns_the_single_sequence_bits(dev, S, L, H, qk, v)
     Same arithmetic per query in the 128- and 64-query forms: equal bit for bit when neither splits its keys, within rounding of the
     key-split combine otherwise -- incl. a ragged length (not a multiple of 128 / 64 / 16) and a V tile outside the fp16 range
     (fp32 fallback inside the 128-query form); and the batch against fp64."""
-    from macarons_amd import ops
+    import ctypes
+    from macarons_amd import ops, _lib
     rng = np.random.default_rng(S + L)
     qkv = rng.standard_normal((S, L, 2 * qk + v)).astype(np.float32)
     qkv[3, 130:150, 2 * qk:] *= 1e6                                    # one tile of sequence 3 leaves the fp16 range
     x = T(qkv, dev)
-    big = ops.attention_packed(x, H, qk, v)
-    for b in (0, 3, S - 1):
-        one = ops.attention_packed(x[b:b + 1].contiguous(), H, qk, v, split=False)       # 64-query blocks, all keys in one block
-        assert torch.equal(one[0], big[b]), b
-        two = ops.attention_packed(x[b:b + 1].contiguous(), H, qk, v, split=True)        # keys over two blocks + combine
-        assert float((two[0] - big[b]).abs().max()) <= 2e-6 * float(big[b].abs().max()), b
+    prev = _lib.lib().mcr_get_local_pct_variant()
+    try:
+        for variant in (5, prev):                                      # 5: P V on the fp32 matrix pipe in both forms; default: fp16 pairs
+            _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(variant))
+            big = ops.attention_packed(x, H, qk, v)
+            for b in (0, 3, S - 1):
+                one = ops.attention_packed(x[b:b + 1].contiguous(), H, qk, v, split=False)   # 64-query blocks, all keys in one block
+                assert torch.equal(one[0], big[b]), (variant, b)
+                two = ops.attention_packed(x[b:b + 1].contiguous(), H, qk, v, split=True)    # keys over two blocks + combine
+                assert float((two[0] - big[b]).abs().max()) <= 2e-6 * float(big[b].abs().max()), (variant, b)
+    finally:
+        _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(prev))
     xs = qkv[:2].astype(np.float64)
     hs = lambda t, d: t.reshape(2, L, H, d).transpose(0, 2, 1, 3)
     q, k, vv = hs(xs[..., :qk], qk // H), hs(xs[..., qk:2 * qk], qk // H), hs(xs[..., 2 * qk:], v // H)
