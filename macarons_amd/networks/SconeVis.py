@@ -115,9 +115,23 @@ class SconeVis(nn.Module):
         from .. import torch_ops  # noqa: F401  (loads the library, registers the operators)
         return torch.ops.macarons
 
+    @staticmethod
+    def _degenerate(pts, X_cam, reduced, n_tuple=1):
+        """What upstream's tensor algebra returns when a dimension is 0 (the kernels refuse empty problems): no clouds / no cameras
+        -> an empty tensor; no points -> empty visibilities, and gains = sum over nothing / 0 = NaN (SconeVis.py:250).  None otherwise."""
+        B, N, C = pts.shape[0], pts.shape[1], X_cam.shape[1]
+        if B and N and C:
+            return None
+        if not reduced:
+            return torch.empty((B, C, N), dtype=torch.float32, device=pts.device)
+        return torch.full((B, C ** n_tuple), float("nan"), dtype=torch.float32, device=pts.device)    # (empty when B or C is 0)
+
     def compute_visibilities(self, pts, harmonics, X_cam):
         """-> [n_clouds, n_camera_candidates, seq_len]   (SconeVis.py:164-208)."""
         self._check_scorer(harmonics)
+        d = self._degenerate(pts, X_cam, reduced=False)
+        if d is not None:
+            return d
         sig = self.use_sigmoid
         hip = lambda p, h, c: self._scorer_ops().sh_visibilities(p, h, c, sig)
         if A.needs_grad(None, pts, harmonics, X_cam):
@@ -127,6 +141,9 @@ class SconeVis(nn.Module):
     def compute_coverage_gain(self, pts, harmonics, X_cam):
         """-> [n_clouds, n_camera_candidates]   (SconeVis.py:210-252)."""
         self._check_scorer(harmonics)
+        d = self._degenerate(pts, X_cam, reduced=True)
+        if d is not None:
+            return d
         sig = self.use_sigmoid
         hip = lambda p, h, c: self._scorer_ops().sh_coverage_gain(p, h, c, sig)
         if A.needs_grad(None, pts, harmonics, X_cam):
@@ -138,6 +155,10 @@ class SconeVis(nn.Module):
         self._check_scorer(harmonics)
         if n_cam not in (2, 3):
             raise NameError("n_cam is too large.")                       # SconeVis.py:298
+        d = self._degenerate(pts, X_cam, reduced=True, n_tuple=n_cam)
+        if d is not None:
+            single = torch.arange(0, X_cam.shape[1])
+            return d, torch.cartesian_prod(*([single] * n_cam)).reshape(-1, n_cam)
         return ops.coverage_gain_multiple(pts, harmonics, X_cam, n_cam, self.use_sigmoid)
 
     def _check_scorer(self, harmonics):

@@ -142,3 +142,19 @@ def test_random_shapes_and_tile_edges(dev):
             truth = scorer.compute_coverage_gain(pts[..., :3], harm, cams, use_sigmoid=sig, dtype=np.float64)
             scale = max(1e-6, float(np.abs(truth).max()))
             assert np.abs(g - truth).max() / scale < 2e-6 and np.abs(v.mean(-1) - truth).max() / scale < 2e-6, (B, N, C, P, sig)
+
+
+def test_empty_dimensions_follow_upstream(dev):
+    """No points / no cameras / no clouds: upstream's tensor algebra returns NaN gains for an empty cloud (sum over nothing / 0,
+    SconeVis.py:250) and empty tensors otherwise (checked against the imported reference when this test was written: shapes
+    (1,3) NaN, (2,0), (0,3); visibilities (B,C,N); the n-tuple form (B, C^n) + its index table)."""
+    from macarons_amd.networks import SconeVis
+    m = SconeVis().to(dev).eval()
+    for (B, N, C) in [(1, 0, 3), (2, 5, 0), (0, 5, 3)]:
+        pts, h, cams = torch.rand(B, N, 4, device=dev), torch.rand(B, N, 64, device=dev), torch.rand(B, C, 3, device=dev)
+        with torch.no_grad():
+            g = m.compute_coverage_gain(pts, h, cams)
+            v = m.compute_visibilities(pts, h, cams)
+            g2, idx2 = m.compute_coverage_gain_multiple(pts, h, cams, 2)
+        assert tuple(g.shape) == (B, C) and tuple(v.shape) == (B, C, N) and tuple(g2.shape) == (B, C * C) and tuple(idx2.shape) == (C * C, 2)
+        assert g.device.type == "cuda" and (g.numel() == 0 or bool(torch.isnan(g).all())) and (g2.numel() == 0 or bool(torch.isnan(g2).all()))
