@@ -75,6 +75,13 @@ static inline int64_t seq_route(int64_t L) {
     return on && g_local_pct_variant >= 5 ? -L : L;
 }
 
+// the wide layers behind the encoders (SconeVis fc1 / fc2, the global transformer's lin0): on the encoders' matrix path;
+// MCR_HEAD_SPLIT=0: the exact-fp32 kernels, as before round 4 (A/B)
+static inline int64_t head_route(int64_t L) {
+    static const bool on = []() { const char* e = getenv("MCR_HEAD_SPLIT"); return !(e && e[0] == '0'); }();
+    return on ? seq_route(L) : L;
+}
+
 // long-sequence attention: P V on fp16 hi/lo pairs (nn_kernels.hip: PVH) on the fp16-split variant; MCR_ATTN_PVH=0: fp32 MFMA (A/B)
 static inline bool attn_pv_half() {
     static const bool on = []() { const char* e = getenv("MCR_ATTN_PVH"); return !(e && e[0] == '0'); }();
@@ -127,7 +134,7 @@ static void run_pct(hipStream_t s, const PctW& w, const float* pc, float* feat, 
     launch_copy2d(s, pc, 3, x + PCT_INNER, PCT_E, T, 3);
     for (int e = 0; e < 2; ++e) run_encoder(s, w.enc[e], x, h, qkv, ff, S, L, PCT_E, 4, lens);
     launch_layernorm(s, x, PCT_E, w.ng, w.nb, h, PCT_E, T, PCT_E);                          // SconeOcc.py:119
-    launch_linear(s, h, PCT_E, w.lin0.w, w.lin0.b, nullptr, 0, ff, half, T, half, PCT_E, ACT_NONE, nullptr, 0, 0, L);   // :122
+    launch_linear(s, h, PCT_E, w.lin0.w, w.lin0.b, nullptr, 0, ff, half, T, half, PCT_E, ACT_NONE, nullptr, 0, 0, head_route(L));   // :122
     launch_pool_max_avg(s, ff, half, feat, ld_feat, S, L, half, lens);                       // :124-126
 }
 
@@ -385,9 +392,9 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
     for (int e = 0; e < 3; ++e) run_encoder(s, enc[e], x, h, qkv, ff, B, (int)N, VIS_E, 4, lengths);   // SconeVis.py:139-140
     launch_layernorm(s, x, VIS_E, ng, nb, h, VIS_E, T, VIS_E);                                   // :143
     // fc1 256->192 GELU, || view_harmonics (64), fc2 256->128 GELU, fc3 128->64                  (:146-152)
-    launch_linear(s, h, VIS_E, fc1.w, fc1.b, nullptr, 0, ff, VIS_E, T, 192, VIS_E, ACT_GELU, nullptr, 0, 0, N);
+    launch_linear(s, h, VIS_E, fc1.w, fc1.b, nullptr, 0, ff, VIS_E, T, 192, VIS_E, ACT_GELU, nullptr, 0, 0, head_route(N));
     launch_copy2d(s, view_harmonics, 64, ff + 192, VIS_E, T, 64);
-    launch_linear(s, ff, VIS_E, fc2.w, fc2.b, nullptr, 0, h, 128, T, 128, VIS_E, ACT_GELU, nullptr, 0, 0, N);
+    launch_linear(s, ff, VIS_E, fc2.w, fc2.b, nullptr, 0, h, 128, T, 128, VIS_E, ACT_GELU, nullptr, 0, 0, head_route(N));
     launch_linear(s, h, 128, fc3.w, fc3.b, nullptr, 0, out, 64, T, 64, 128, ACT_NONE, nullptr, 0, 0, N);
     MCR_LAUNCH_CHECK("mcr_scone_vis_forward");
     return 0;
