@@ -596,6 +596,8 @@ def main():
     ap.add_argument("--nbv-iters", type=int, default=50)
     ap.add_argument("--watchdog", type=int, default=0, help="seconds after which every rank dumps its Python stacks to stderr and exits (0 = off): "
                                                             "a rank stuck in a collective reports where, instead of hanging the job")
+    ap.add_argument("--legs-deadline", type=int, default=240, help="seconds the extra legs (NBV step, scene batch, MACARONS decision, CPU baselines) "
+                                                                   "may take together before every rank leaves and rank 0 prints the contract line without them")
     args = ap.parse_args()
 
     if args.watchdog > 0:
@@ -695,20 +697,35 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    # ---- (B) the NBV step, sharded over the ranks ----------------------------------------------------------------------------
-    nbv = measure_nbv_step(dev, rank, world, args) if not args.no_nbv else None
-    nbv_batch = measure_nbv_batch(dev, rank, world, args) if not args.no_nbv else None
-    lp = measure_local_pct(dev) if (rank == 0 and not args.no_nbv) else None
-    mac = None
-    if not args.no_nbv:                                     # every rank: the decision is sharded over the ranks
+    # ---- (B) the extra legs (NBV step, scene batch, MACARONS decision), sharded over the ranks -------------------------------
+    # The contract line (the scorer loop above) is complete at this point.  The extra legs run under a deadline on EVERY rank: a leg
+    # that raises is reported in its field; if the legs hang (a rank that left a collective) every rank leaves at the deadline and
+    # rank 0 still prints the contract line with what was measured -- a secondary leg must not cost the job its record.
+    import threading
+    legs = {}
+    legs_done = threading.Event()
+    state = {"emit": None}
+
+    def on_deadline():
+        if legs_done.is_set():
+            return
+        sys.stderr.write(f"bench.py: rank {rank}: the extra legs did not finish within {args.legs_deadline} s -- leaving with the contract line\n")
         try:
-            mac = measure_macarons_step(dev, rank, world)
-        except Exception as e:                              # an extra leg: reported, never fatal for the contract line
-            if world > 1:
-                raise                                       # (a rank that left the collectives would hang the others)
-            mac = {"error": repr(e)[:300]}
-    if dist is not None:
-        dist.barrier()
+            import faulthandler
+            faulthandler.dump_traceback(file=sys.stderr)
+        except Exception:
+            pass
+        sys.stderr.flush()
+        if rank == 0 and state["emit"] is not None:
+            state["emit"](f"extra legs stopped at the {args.legs_deadline} s deadline; finished: {sorted(legs)}")
+        os._exit(0)
+
+    def run_leg(name, fn):
+        try:
+            legs[name] = fn()
+        except Exception as e:                              # reported in the leg's field, never fatal for the contract line
+            legs[name] = {"error": repr(e)[:300]}
+            sys.stderr.write(f"bench.py: rank {rank}: leg {name} failed: {e!r}\n")
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
@@ -754,30 +771,52 @@ def main():
             "roofline": roof,
             "scorer_strong": strong,
         }
-        if nbv is not None:
-            res["nbv_step"] = nbv
-        if nbv_batch is not None:
-            res["nbv_batch"] = nbv_batch
-        if mac is not None:
-            res["macarons_step"] = mac
-        if lp is not None:
-            res["roofline_nbv_dominant"] = lp
-        if not args.no_cpu_baseline and world == 1:
+    else:
+        res = None
+
+    def emit(note=None):
+        out = dict(res)
+        for k_, v_ in (("nbv_step", legs.get("nbv")), ("nbv_batch", legs.get("nbv_batch")), ("macarons_step", legs.get("mac")),
+                       ("roofline_nbv_dominant", legs.get("lp"))):
+            if v_ is not None:
+                out[k_] = v_
+        for k_ in ("cpu_baseline", "cpu_baseline_nbv"):
+            if k_ in legs:
+                out[k_] = legs[k_]
+        if note:
+            out["legs_incomplete"] = note
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    if rank == 0:
+        state["emit"] = emit
+    timer = threading.Timer(args.legs_deadline, on_deadline)
+    timer.daemon = True
+    timer.start()
+    if not args.no_nbv:
+        run_leg("nbv", lambda: measure_nbv_step(dev, rank, world, args))
+        run_leg("nbv_batch", lambda: measure_nbv_batch(dev, rank, world, args))
+        if rank == 0:
+            run_leg("lp", lambda: measure_local_pct(dev))
+        run_leg("mac", lambda: measure_macarons_step(dev, rank, world))   # every rank: the decision is sharded over the ranks
+    if dist is not None:
+        dist.barrier()
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        def cpu_leg():
             n_s = min(C, max(24, os.cpu_count() or 1))
             cb, g_cpu = cpu_baseline(pts, harm, cams[:, :n_s].contiguous())
-            res["cpu_baseline"] = cb
             g_gpu = ops.sh_coverage_gain(pts, harm, cams[:, :n_s].contiguous()).cpu().numpy()
-            res["cpu_baseline"]["max_rel_diff_vs_gpu"] = float(np.abs(g_gpu - g_cpu).max() / np.abs(g_cpu).max())
-            if not args.no_nbv:
-                res["cpu_baseline_nbv"] = cpu_baseline_nbv(C)
-        line = json.dumps(res)
-    else:
-        line = None
+            cb["max_rel_diff_vs_gpu"] = float(np.abs(g_gpu - g_cpu).max() / np.abs(g_cpu).max())
+            return cb
+        run_leg("cpu_baseline", cpu_leg)
+        if not args.no_nbv:
+            run_leg("cpu_baseline_nbv", lambda: cpu_baseline_nbv(C))
+    legs_done.set()
+    timer.cancel()
     if dist is not None:
         dist.destroy_process_group()       # RCCL prints its version banner to stdout on the way out: keep the JSON the LAST line
     sys.stdout.flush()
-    if line is not None:
-        print(line, flush=True)
+    if rank == 0:
+        emit()
     if dist is not None:
         # librccl prints its version banner to stdout when the process winds down (after destroy_process_group, on every rank):
         # leave without running the exit handlers so that rank 0's JSON stays the LAST line of the job's output

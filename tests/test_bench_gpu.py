@@ -27,3 +27,16 @@ def test_bench_self_launches_two_ranks_on_one_gpu(dev):
     assert res["nbv_batch"]["config"]["parallelism"] == "cloud shard x2"
     mac = res["macarons_step"]
     assert mac["p50_ms"] > 0 and mac["config"]["parallelism"].endswith("x2") and mac["checks"]["all_hold"], mac
+
+
+def test_contract_line_survives_the_extra_legs(dev):
+    """The extra legs (NBV step, scene batch, MACARONS decision) run under a deadline: when they do not finish -- here a 1 s deadline;
+    on a real node a rank stuck in a collective -- every rank leaves and rank 0 still prints the contract line (the scorer loop's
+    result, complete before the legs start), marked `legs_incomplete`, with exit code 0."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-pmc", "--no-cpu-baseline",
+                        "--legs-deadline", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["value"] > 0 and res["steps"] == 20 and res["roofline"]["frac"] > 0 and "legs_incomplete" in res, res
