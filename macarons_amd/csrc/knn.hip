@@ -221,13 +221,18 @@ template <int K, bool OFFSETS>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_mfma_kernel(const float* __restrict__ X, const float* __restrict__ pc,
                                                              long long* __restrict__ out_idx, float* __restrict__ out_dist,
                                                              float* __restrict__ out_pts, int Q, int M, const int4* __restrict__ blocks,
-                                                             const long long* __restrict__ pc_off) {
+                                                             const long long* __restrict__ pc_off, int n_split = 1,
+                                                             unsigned long long* __restrict__ part_out = nullptr) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     __shared__ __attribute__((aligned(16))) float s_p[4][KM_TILE];           // x | y | z | |p|^2
     __shared__ int s_q[KM_QCAP * KNN_BLOCK];                                  // queue; reused as the merge buffer
     __shared__ unsigned s_pmax;
     static_assert(2 * K * 128 * 2 <= KM_QCAP * KNN_BLOCK, "merge buffer does not fit");
-    const int b = blockIdx.y;
+    // segmented form with n_split > 1 (few query blocks against large clouds: the ragged occupancy pass has ~200 blocks for 256 CUs):
+    // grid.y = n_split, workgroup (i, sp) scans the sp-th slice of its job's candidates and leaves its 16 best (d2 bits << 32 | index)
+    // keys per query in part_out [n_split][Q][K]; knn_split_merge_kernel takes the K smallest keys of the n_split lists -- the same
+    // (d2, index) order, so the same neighbours in the same order as the unsplit scan
+    const int b = blocks ? 0 : blockIdx.y, sp = blocks ? blockIdx.y : 0;
     const int lane = threadIdx.x & (MCR_WAVE - 1), wave = threadIdx.x / MCR_WAVE;
     const int j = lane & 31, h = lane >> 5;
     int q_first = blockIdx.x * 128, q_end = Q;
@@ -237,6 +242,12 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_mfma_kernel(const float* __rest
         q_first = bk.y; q_end = bk.y + bk.z;
         pcb = pc + (size_t)pc_off[bk.x] * 3;
         M = (int)(pc_off[bk.x + 1] - pc_off[bk.x]);
+    }
+    int c_first = 0;
+    if (n_split > 1) {                             // this workgroup's candidates [c_first, M)
+        const int chunk = (((M + n_split - 1) / n_split) + 31) & ~31;
+        c_first = min(M, sp * chunk);
+        M = min(M, c_first + chunk);
     }
     const int q = q_first + wave * 32 + j;
     const bool valid = q < q_end;
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_mfma_kernel(const float* __rest
         thr = (tau - q2) + eps;
         cnt = 0;
     };
-    for (t0 = 0; t0 < M; t0 += KM_TILE) {
+    for (t0 = c_first; t0 < M; t0 += KM_TILE) {
         const int nt = min(KM_TILE, M - t0);
         const int nt_pad = (nt + 31) & ~31;
         __syncthreads();                           // the previous tile (fragments and flushes) is done with
@@ -356,11 +367,14 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_mfma_kernel(const float* __rest
             head[1] += best_w == 1 ? 1 : 0;
             mi[r] = best_i;
             if (valid) {
+                if (part_out)
+                    part_out[((size_t)sp * Q + q) * K + r] = ((unsigned long long)__builtin_bit_cast(unsigned, best_d) << 32) | (unsigned)best_i;
                 if (out_idx) out_idx[o + r] = (long long)best_i;
                 if (out_dist) out_dist[o + r] = sqrt_cr(best_d);
             }
         }
     }
+    if (part_out) return;                          // (block-uniform) the coordinates are written by the merge
     // ---- the neighbour coordinates leave through LDS: a block's 128 queries x K x 3 floats are ONE contiguous range of out_pts,
     // written as whole 16-byte chunks by all 256 threads (a lane storing its own 48 floats 12 bytes at a time at a 192-byte
     // stride was ~65 us of every launch: more than the whole search at M = 126)
@@ -1018,6 +1032,50 @@ __global__ __launch_bounds__(MODE ? 64 * KG_SPLIT : 64, MODE ? 2 : 4) void knn_g
     }
 }
 
+// Second pass of the split segmented search: workgroup i = blocks[i] (128 threads = its <= 128 query rows); a thread merges the n_split
+// ascending key lists of its query (K smallest, lexicographic = (d2, index)) and the block writes the neighbours' offsets from the
+// query through LDS as one contiguous range (like knn_mfma_kernel's epilogue).
+template <int K>
+__global__ __launch_bounds__(128) void knn_split_merge_kernel(const float* __restrict__ X, const float* __restrict__ pc,
+                                                              const long long* __restrict__ pc_off, const int4* __restrict__ blocks,
+                                                              const unsigned long long* __restrict__ part, int n_split, int Q,
+                                                              float* __restrict__ out_pts) {
+    __shared__ __attribute__((aligned(16))) float st[128 * K * 3];
+    const int4 bk = blocks[blockIdx.x];
+    const int q_first = bk.y, n_valid = max(0, min(128, bk.z));
+    const float* pcb = pc + (size_t)pc_off[bk.x] * 3;
+    const int t = threadIdx.x;
+    if (t < n_valid) {
+        const int q = q_first + t;
+        const float qx = X[(size_t)q * 3], qy = X[(size_t)q * 3 + 1], qz = X[(size_t)q * 3 + 2];
+        int head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < K; ++r) {
+            unsigned long long best = ~0ull;
+            int best_w = 0;
+            for (int w = 0; w < n_split; ++w) {
+                const unsigned long long k = head[w] < K ? part[((size_t)w * Q + q) * K + head[w]] : ~0ull;
+                if (k < best) { best = k; best_w = w; }
+            }
+            for (int w = 0; w < n_split; ++w) head[w] += (w == best_w) ? 1 : 0;
+            const unsigned bi = (unsigned)best;
+            const int id = bi == 0x7fffffffu ? 0 : (int)bi;               // (an unfilled slot: cannot happen with >= K candidates)
+            const float* p = pcb + (size_t)id * 3;
+            st[(t * K + r) * 3 + 0] = p[0] - qx;
+            st[(t * K + r) * 3 + 1] = p[1] - qy;
+            st[(t * K + r) * 3 + 2] = p[2] - qz;
+        }
+    }
+    __syncthreads();
+    const int n_f = n_valid * K * 3;
+    float* dst = out_pts + (size_t)q_first * K * 3;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        for (int c = t; c * 4 + 3 < n_f; c += 128) reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(st)[c];
+        for (int e = (n_f & ~3) + t; e < n_f; e += 128) dst[e] = st[e];
+    } else {
+        for (int e = t; e < n_f; e += 128) dst[e] = st[e];
+    }
+}
+
 template <int K>
 static void launch_knn(bool offsets, dim3 grid, hipStream_t s, const float* X, const float* pc, long long* idx, float* dist,
                        float* pts, int Q, int M, const int4* blocks = nullptr, const long long* pc_off = nullptr) {
@@ -1042,9 +1100,26 @@ using namespace mcr;
 // Segmented k = 16 search with the query offsets (SconeOcc's use): n_blocks workgroups, workgroup i = blocks[i] = (job, first query
 // row, number of rows <= 128, 0); job j's candidates are pc[pc_off[j] .. pc_off[j+1]).  Every job needs >= 16 candidates.
 namespace mcr {
+// split_ws (optional, knn16_segmented_split_floats(T) floats): lets a launch with few query blocks split every job's candidates over
+// up to KNN_SEG_SPLIT workgroups per block (+ one merge launch); same neighbours in the same order.  MCR_KNN_SEG_SPLIT=0: never (A/B)
+constexpr int KNN_SEG_SPLIT = 4;
+size_t knn16_segmented_split_floats(int64_t T) { return (size_t)KNN_SEG_SPLIT * T * 16 * 2; }
 void launch_knn16_segmented(hipStream_t s, const float* X, const float* pc, const long long* pc_off, const int* blocks,
-                            int64_t n_blocks, int64_t T, float* offsets_out) {
+                            int64_t n_blocks, int64_t T, float* offsets_out, float* split_ws, bool large_clouds) {
     if (n_blocks <= 0) return;
+    static const bool split_on = []() { const char* e = getenv("MCR_KNN_SEG_SPLIT"); return !(e && e[0] == '0'); }();
+    static const bool use_mfma = []() { const char* e = getenv("MCR_KNN_MFMA"); return !(e && e[0] == '0'); }();
+    // four waves per block: ~3 waves per SIMD need 768 blocks
+    int n_split = 1;
+    if (split_on && use_mfma && split_ws && large_clouds) n_split = (int)std::min<int64_t>(KNN_SEG_SPLIT, std::max<int64_t>(1, 768 / n_blocks));
+    if (n_split > 1) {
+        unsigned long long* part = reinterpret_cast<unsigned long long*>(split_ws);
+        hipLaunchKernelGGL((knn_mfma_kernel<16, true>), dim3((unsigned)n_blocks, (unsigned)n_split), dim3(KNN_BLOCK), 0, s, X, pc,
+                           (long long*)nullptr, (float*)nullptr, offsets_out, (int)T, 0, reinterpret_cast<const int4*>(blocks), pc_off, n_split, part);
+        hipLaunchKernelGGL((knn_split_merge_kernel<16>), dim3((unsigned)n_blocks), dim3(128), 0, s, X, pc, pc_off,
+                           reinterpret_cast<const int4*>(blocks), (const unsigned long long*)part, n_split, (int)T, offsets_out);
+        return;
+    }
     launch_knn<16>(true, dim3((unsigned)n_blocks, 1), s, X, pc, nullptr, nullptr, offsets_out, (int)T, 0,
                    reinterpret_cast<const int4*>(blocks), pc_off);
 }

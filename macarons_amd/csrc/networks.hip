@@ -706,7 +706,7 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
 // pc_scale[s][scale_off[s][j] .. scale_off[s][j+1]), queries = the rows r of x with row_job[r] == j (rows sorted by job).
 // knn_blocks: n_blocks x int4 (job, first row, rows <= mcr_knn_rows_per_block(), 0) covering every row once.
 size_t mcr_scone_occ_ragged_workspace_bytes(int64_t J, int64_t T, int64_t Lg) {
-    size_t local = al(T * 16 * 3) + 1024;
+    size_t local = al(T * 16 * 3) + al(knn16_segmented_split_floats(T)) + 1024;
     size_t glob = pct_ws_bytes(J * Lg);
     size_t head = al(T * 1344) + al(T * 512) + al(T * 256) + al(J * 512) * 2 + linear3h_planes_bytes(512, 1344);
     return local + glob + head + 8192;
@@ -776,9 +776,11 @@ int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global
     _Float16* featP = reinterpret_cast<_Float16*>(feat);
     const HeadScratch head_scratch{featP, reinterpret_cast<_Float16*>(h1), h2, wplanes};
     float* offs = scratch.f(T * 16 * 3);
+    float* knn_split_ws = scratch.f(knn16_segmented_split_floats(T));
     MCR_REQUIRE(scratch.ok(), "mcr_scone_occ_forward_ragged: workspace overflow (kNN)");
     auto local_scale = [&](int sc) {                      // one segmented kNN + one fused transformer launch over ALL rows
-        launch_knn16_segmented(s, x, pc_scale[sc], (const long long*)scale_off[sc], knn_blocks, n_blocks, T, offs);
+        // (the whole clouds of scale 0 are the large ones: a launch with few query blocks splits their candidates over workgroups)
+        launch_knn16_segmented(s, x, pc_scale[sc], (const long long*)scale_off[sc], knn_blocks, n_blocks, T, offs, knn_split_ws, sc == 0);
         if (planes) run_local_pct(s, offs, nullptr, FEAT, T, local_blobs[sc], featP + sc * 256, featP + T * FEAT + sc * 256);
         else run_local_pct(s, offs, feat + sc * 256, FEAT, T, local_blobs[sc]);
     };

@@ -91,7 +91,8 @@ void launch_split_to_planes(hipStream_t s, const float* X, int64_t ldx, void* Ph
 void launch_split_weights(hipStream_t s, const float* W, int64_t ldw, void* planes, int N, int K);   // linear3h.hip: [2][N][K] fp16 of W * 2^8
 // segmented kNN-16 with query offsets (knn.hip): see launch_knn16_segmented there
 void launch_knn16_segmented(hipStream_t s, const float* X, const float* pc, const long long* pc_off, const int* blocks,
-                            int64_t n_blocks, int64_t T, float* offsets_out);
+                            int64_t n_blocks, int64_t T, float* offsets_out, float* split_ws = nullptr, bool large_clouds = false);
+size_t knn16_segmented_split_floats(int64_t T);
 int knn_rows_per_block();
 // grid-pruned exact kNN-16 (knn.hip: K1-grid): query order once per query set, one sorted copy per candidate cloud
 struct KnnGridCloud { const void* cand; const void* boxes; const void* hdr; int64_t cand_stride, box_stride; };
