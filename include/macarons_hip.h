@@ -68,6 +68,16 @@ size_t mcr_knn_grid_workspace_bytes(int64_t B, int64_t Q, int64_t M);
 int mcr_knn_points_grid(const float* X, const float* pc, int64_t* idx, float* dists, float* pts, int64_t B, int64_t Q, int64_t M,
                         int k, int subtract_query, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The k = 16 search of J independent jobs in one launch (the ragged occupancy pass, macarons_utils.py:1395-1540: every (cell, chunk)
+ * job runs utils.py:1497-1509 + SconeOcc.py:297-298 on its own cloud): X [T,3] query rows sorted by job; pc = the jobs' clouds
+ * back to back, job j = rows pc_off[j] .. pc_off[j+1] (device int64 [J+1], every job >= 16 points); blocks (device int32
+ * [n_blocks,4]) = (job, first query row, rows <= mcr_knn_rows_per_block(), 0), one workgroup each; offsets_out [T,16,3] = neighbour
+ * minus query, neighbours in mcr_knn_points' order.  workspace (optional, mcr_knn_offsets_segmented_workspace_bytes(T) bytes): lets a
+ * launch with few blocks split every job's candidates over several workgroups (same result). */
+size_t mcr_knn_offsets_segmented_workspace_bytes(int64_t T);
+int mcr_knn_offsets_segmented(const float* X, const float* pc, const int64_t* pc_off, const int* blocks, int64_t n_blocks, int64_t T,
+                              float* offsets_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K4/K5 building blocks (macarons/networks/Attention.py) -------------------------------------------
  * mcr_linear: nn.Linear (+ optional exact-erf GELU, + optional residual add):
  *   Y[m*ldy+n] = act(sum_k X[m*ldx+k] * W[n*K+k] + bias[n]) + residual[m*ldr+n]     (Attention.py:98-103,186-188,232-235)

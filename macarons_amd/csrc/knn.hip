@@ -1257,6 +1257,17 @@ extern "C" int mcr_knn_points_grid(const float* X, const float* pc, int64_t* idx
     return 0;
 }
 
+extern "C" size_t mcr_knn_offsets_segmented_workspace_bytes(int64_t T) { return knn16_segmented_split_floats(T) * sizeof(float); }
+extern "C" int mcr_knn_offsets_segmented(const float* X, const float* pc, const int64_t* pc_off, const int* blocks, int64_t n_blocks,
+                                         int64_t T, float* offsets_out, void* workspace, size_t workspace_bytes, void* stream) {
+    MCR_REQUIRE(X && pc && pc_off && blocks && offsets_out, "mcr_knn_offsets_segmented: null pointer");
+    MCR_REQUIRE(n_blocks >= 0 && T >= 0 && T < (1ll << 31) && n_blocks <= 65535ll * 32768, "mcr_knn_offsets_segmented: bad sizes");
+    float* ws = workspace && workspace_bytes >= mcr_knn_offsets_segmented_workspace_bytes(T) ? (float*)workspace : nullptr;
+    launch_knn16_segmented((hipStream_t)stream, X, pc, (const long long*)pc_off, blocks, n_blocks, T, offsets_out, ws, ws != nullptr);
+    MCR_LAUNCH_CHECK("mcr_knn_offsets_segmented");
+    return 0;
+}
+
 #ifdef KG_DEBUG
 extern "C" int mcr_knn_grid_debug(unsigned* out) {      // out[8192 * 16]
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(kg_trace), sizeof(unsigned) * 8192 * 16) == hipSuccess ? 0 : 1;

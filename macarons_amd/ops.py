@@ -5,6 +5,7 @@ scratch on the input's device and launches on the current HIP stream.  No CPU fa
 """
 import ctypes
 import torch
+import numpy as np
 
 from ._lib import lib, check, MacaronsHipError, c_i64, c_int, c_size, c_vp, c_f32
 from .utility.host import limit_host_threads
@@ -102,6 +103,31 @@ def knn_points(X, pc, k, subtract_query=False):
                                         c_int(int(bool(subtract_query))), _p(ws), ctypes.c_size_t(ws.numel()), _stream()),
               "mcr_knn_points_grid")
     return pts, dists, idx
+
+
+def knn_offsets_segmented(X, pc, cloud_sizes, query_sizes, split=True):
+    """offsets [T,16,3] (neighbour minus query) of J independent k = 16 searches in one launch: job j = query rows
+    sum(query_sizes[:j]) .. against cloud rows sum(cloud_sizes[:j]) ..; neighbours in knn_points' order (the ragged occupancy pass).
+    split=False withholds the scratch that lets a small launch split the candidates over several workgroups (same result)."""
+    X, pc = _req(X, "X"), _req(pc, "pc")
+    T, J = X.shape[0], len(cloud_sizes)
+    if sum(query_sizes) != T or sum(cloud_sizes) != pc.shape[0] or len(query_sizes) != J or min(cloud_sizes) < 16:
+        raise ValueError("knn_offsets_segmented: sizes do not match (every cloud needs >= 16 points)")
+    L = lib()
+    rows = int(L.mcr_knn_rows_per_block())
+    blocks, r0 = [], 0
+    for j, q in enumerate(query_sizes):
+        blocks += [(j, r0 + b0, min(rows, q - b0), 0) for b0 in range(0, q, rows)]
+        r0 += q
+    d_off = h2d(np.concatenate(([0], np.cumsum(cloud_sizes))).astype(np.int64), torch.int64, X.device)
+    d_blocks = h2d(np.asarray(blocks, np.int32).reshape(-1, 4), torch.int32, X.device)
+    out = torch.empty((T, 16, 3), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        ws = _workspace(X.device, max(int(L.mcr_knn_offsets_segmented_workspace_bytes(c_i64(T))), 4)) if split else None
+        check(L.mcr_knn_offsets_segmented(_p(X), _p(pc), _p(d_off), _p(d_blocks), c_i64(len(blocks)), c_i64(T), _p(out),
+                                          _p(ws) if ws is not None else c_vp(0), c_size(ws.numel() * ws.element_size() if ws is not None else 0),
+                                          _stream()), "mcr_knn_offsets_segmented")
+    return out
 
 
 # ---- K4/K5 building blocks ---------------------------------------------------------------------------

@@ -135,3 +135,28 @@ def test_grid_routing_boundaries(dev, M):
     p, d, i = _run(dev, X, pc, 16, sub=True)
     po, do, io = knn.knn_offsets(X, pc, 16)
     assert np.array_equal(i, io) and np.array_equal(d, do) and np.array_equal(p, po)
+
+
+def test_segmented_search_equals_the_per_job_search(dev):
+    """mcr_knn_offsets_segmented (J jobs of different sizes in one launch: the ragged occupancy pass) == mcr_knn_points job by job, bit
+    for bit -- with and without the scratch that lets a launch with few query blocks split every job's candidates over several
+    workgroups and merge their (d2, index) lists (the merge must keep the tie order: clouds on a 2^-3 grid with duplicated points,
+    i.e. hundreds of equal distances per query), incl. a job of one query, a cloud of exactly 16 points and one whose candidate
+    slices come out ragged."""
+    from macarons_amd import ops
+    rng = np.random.default_rng(31)
+    sizes_m, sizes_q = [16, 5000, 1025, 12001, 33, 4097], [1, 300, 129, 40, 128, 7]
+    clouds = [(rng.integers(-4, 5, (m, 3)) / 8.0).astype(np.float32) for m in sizes_m]
+    clouds[3] = rng.uniform(-.5, .5, (sizes_m[3], 3)).astype(np.float32)             # one real-valued job
+    xs = [(rng.integers(-8, 9, (q, 3)) / 16.0).astype(np.float32) for q in sizes_q]
+    X, pc = torch.from_numpy(np.concatenate(xs)).to(dev), torch.from_numpy(np.concatenate(clouds)).to(dev)
+    split = ops.knn_offsets_segmented(X, pc, sizes_m, sizes_q, split=True)
+    plain = ops.knn_offsets_segmented(X, pc, sizes_m, sizes_q, split=False)
+    assert torch.equal(split, plain)
+    r0 = 0
+    for c, x in zip(clouds, xs):
+        pts, _, _ = ops.knn_points(torch.from_numpy(x[None]).to(dev), torch.from_numpy(c[None]).to(dev), 16, subtract_query=True)
+        assert torch.equal(pts[0], split[r0:r0 + len(x)]), len(c)
+        po, _, _ = knn.knn_offsets(x[None], c[None], 16)                       # and the oracle convention itself
+        assert np.array_equal(po[0], split[r0:r0 + len(x)].cpu().numpy()), len(c)
+        r0 += len(x)
