@@ -410,7 +410,7 @@ constexpr int OCC_NW = PCT_NW * 4 + 6 + 6, OCC_CHUNK = 16384;
 size_t mcr_scone_occ_workspace_bytes(int64_t B, int64_t Q, int64_t Lg) {
     const int64_t qc = std::min<int64_t>(Q, OCC_CHUNK);
     size_t local = pct_ws_bytes(qc * 16) + al(qc * 16 * 3) + al(qc * 16) + al(qc * 16 * 2) + 1024;
-    local = std::max(local, al(Q * 16 * 3) + al(Q * 16) + al(Q * 16 * 2) + 1024);      // fused path: kNN outputs for all Q
+    local = std::max(local, al(B * Q * 16 * 3) + al(Q * 16) + al(Q * 16 * 2) + 1024);  // fused path: kNN outputs for all B x Q rows
     size_t glob = pct_ws_bytes(B * Lg);
     size_t head = al(B * Q * 1344) + al(B * Q * 512) + al(B * Q * 256) + al(B * 512) * 2;
     head += linear3h_planes_bytes(512, 1344);        // split weight planes of the largest head layer (reused layer after layer)
@@ -614,6 +614,24 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
         if (sc == 0 ? !early : !late) continue;
         const bool grid_knn = knn_slot[sc] >= 0;
         const KnnGridCloud knn_cloud = grid_knn ? knn_clouds[knn_slot[sc]] : KnnGridCloud{};
+        // a batch of clouds on the fused path (config 3's scene batch): ONE search and ONE transformer launch per scale over all B x Q
+        // rows instead of one per cloud -- eight brute-force searches of 256 workgroups each (one wave per SIMD: every wave waits out
+        // its own latencies) become one of 2048.  The rows are the same rows: same bits.  MCR_OCC_BATCH_LOCAL=0: per cloud (A/B)
+        static const bool batch_local_on = []() { const char* e = getenv("MCR_OCC_BATCH_LOCAL"); return !(e && e[0] == '0'); }();
+        if (batch_local_on && B > 1 && qc == Q && (planes || (local_blobs && local_blobs[sc]))) {
+            Arena a = scratch;
+            float* offs = a.f(Tall * 16 * 3);
+            if (a.ok()) {
+                if (grid_knn) {
+                    launch_knn16_grid(s, x, pc_scale[sc], M_scale[sc], knn_qperm, knn_cloud, 0, B, Q, nullptr, nullptr, offs, true, knn_park_ws, sc);
+                    MCR_LAUNCH_CHECK("knn_grid_kernel");
+                } else if (int e = mcr_knn_points(x, pc_scale[sc], nullptr, nullptr, offs, B, Q, M_scale[sc], 16, 1, stream))
+                    return e;
+                if (planes) run_local_pct(s, offs, nullptr, FEAT, Tall, local_blobs[sc], featP + sc * 256, featP + Tall * FEAT + sc * 256);
+                else run_local_pct(s, offs, feat + sc * 256, FEAT, Tall, local_blobs[sc]);
+                continue;
+            }                                              // (workspace sized by an older caller: the per-cloud form below)
+        }
         for (int64_t q0 = 0; q0 < Q; q0 += qc) {
             const int64_t nq = std::min<int64_t>(qc, Q - q0);
             for (int64_t b = 0; b < B; ++b) {
