@@ -743,8 +743,10 @@ __global__ void cell_keys_kernel(const float* __restrict__ pts, long long N, con
 }
 
 // counts[k] = #{i : key[i] == k} for k <= nk, offsets = their exclusive prefix sums (nk + 2 entries): ONE block (N is a few 10^5,
-// nk <= 1023), no zero-initialised scratch, no second launch for the scan.  Sixteen keys per thread and round with all four 16-byte
-// loads in flight (one key per round was a chain of ~100 load latencies: 40-90 us at N = 100k), the scan by wave prefix sums.
+// nk <= 1023), no zero-initialised scratch, no second launch for the scan.  The keys are cell ids of points that arrive in image /
+// cloud order, i.e. long runs of one value: LDS atomics on one address serialise (64 per wave instruction: 87 us at N = 230k with
+// one atomic per key).  A thread therefore takes 32 CONSECUTIVE keys per round (eight 16-byte loads in flight), folds runs of equal
+// keys in registers, and a wave whose lanes all end on the same key adds its counts up first and issues ONE atomic.
 __global__ __launch_bounds__(1024) void key_histogram_kernel(const int* __restrict__ key, long long N, int nk,
                                                             long long* __restrict__ counts, long long* __restrict__ offsets) {
     __shared__ unsigned s_cnt[1024];
@@ -752,21 +754,46 @@ __global__ __launch_bounds__(1024) void key_histogram_kernel(const int* __restri
     const int tid = threadIdx.x;
     s_cnt[tid] = 0u;
     __syncthreads();
-    auto add = [&](int k) { if (k >= 0 && k <= nk) atomicAdd(&s_cnt[k], 1u); };
     const bool al16 = (reinterpret_cast<uintptr_t>(key) & 15) == 0;
     const long long N4 = al16 ? N / 4 : 0;                              // whole int4 groups
     const int4* key4 = reinterpret_cast<const int4*>(key);
-    for (long long g0 = 0; g0 < N4; g0 += 4 * 1024) {
-        int4 v[4];
+    constexpr int G = 8;                                                // int4 groups per thread and round
+    for (long long g0 = 0; g0 < N4; g0 += (long long)G * 1024) {       // (block-uniform trip count: the wave votes below are convergent)
+        int4 v[G];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long g = g0 + u * 1024 + tid;
+        for (int u = 0; u < G; ++u) {
+            const long long g = g0 + (long long)tid * G + u;
             v[u] = g < N4 ? key4[g] : make_int4(-1, -1, -1, -1);
         }
+        int cur = -1;                                                   // the open run (cur < 0: none)
+        unsigned n = 0;
+        auto take = [&](int k) {
+            if (k < 0 || k > nk) return;                                // not a key: ignored
+            if (k == cur) { ++n; return; }
+            if (n) atomicAdd(&s_cnt[cur], n);                           // a run ended inside the thread's 32 keys: rare
+            cur = k; n = 1;
+        };
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { add(v[u].x); add(v[u].y); add(v[u].z); add(v[u].w); }
+        for (int u = 0; u < G; ++u) { take(v[u].x); take(v[u].y); take(v[u].z); take(v[u].w); }
+        // the last (usually the only) run of every lane: one atomic per wave when the lanes that have one agree on the key
+        const unsigned long long has = __ballot(n > 0);
+        if (has) {
+            const int first = __builtin_ctzll(has);
+            const int kf = __shfl(cur, first, 64);
+            if (__all(n == 0 || cur == kf)) {
+                unsigned tot = n;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+                if ((tid & 63) == first) atomicAdd(&s_cnt[kf], tot);
+            } else if (n) {
+                atomicAdd(&s_cnt[cur], n);
+            }
+        }
     }
-    for (long long i = N4 * 4 + tid; i < N; i += 1024) add(key[i]);
+    for (long long i = N4 * 4 + tid; i < N; i += 1024) {                // the tail (and unaligned inputs): one key at a time
+        const int k = key[i];
+        if (k >= 0 && k <= nk) atomicAdd(&s_cnt[k], 1u);
+    }
     __syncthreads();
     // exclusive scan over k = 0 .. 1023 (entries above nk are zero): lane prefix inside a wave, then the 16 wave totals
     const unsigned c = s_cnt[tid];

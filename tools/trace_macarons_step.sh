@@ -11,7 +11,12 @@ tail -1 /tmp/mtrace.log
 python - <<'PY'
 import csv, glob, collections
 f = glob.glob("/tmp/mtrace/**/t_kernel_trace.csv", recursive=True)[0]
-rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
+raw = list(csv.DictReader(open(f)))
+rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in raw))
+def _wg(r):
+    t = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+    return int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(1, t), t
+grid = {int(r["Start_Timestamp"]): _wg(r) for r in raw}
 starts = [i for i, r in enumerate(rows) if "proxy_update_kernel" in r[2]]
 res = []
 for a, b in zip(starts[3:-1], starts[4:]):
@@ -32,6 +37,10 @@ for g, a, b in gaps: print(f"  gap {g/1e3:8.1f} us  after {a}  before {b}")
 agg = collections.defaultdict(lambda: [0, 0])
 for s_, e_, n_ in seg: agg[n_[:60]][0] += e_ - s_; agg[n_[:60]][1] += 1
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]: print(f"  {v[0]/1e3:9.1f} us x{v[1]:4d}  {k}")
+print("---- launches of the median decision that take > 15 us with fewer than 1024 workgroups (workgroups x threads, us, kernel)")
+for s_, e_, n_ in seg:
+    g_ = grid.get(s_, (0, 0))
+    if e_ - s_ > 15000 and g_[0] < 1024: print(f"  {g_[0]:6d} x {g_[1]:4d}  {(e_-s_)/1e3:8.1f}  {n_[:90]}")
 print("---- timeline of the median decision (start us, duration us, gap before us, kernel)")
 t0 = seg[0][0]; prev_end = t0
 for s_, e_, n_ in seg:
