@@ -1,6 +1,11 @@
 """Dev: per-kernel time inside the median NBV step of a rocprofv3 kernel trace (csv); steps = spans between view_state_kernel launches."""
 import csv, sys, collections
-rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1]))))
+raw = list(csv.DictReader(open(sys.argv[1])))
+rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in raw))
+def _wg(r):
+    t = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+    return int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(1, t), t
+grid = {int(r["Start_Timestamp"]): _wg(r) for r in raw}
 starts = [i for i, r in enumerate(rows) if "view_state_kernel" in r[2]]
 steps = []
 for a, b in zip(starts[8:-1], starts[9:]):
@@ -15,3 +20,8 @@ for s, e, n in seg:
 print(f"median step span {span/1e6:.3f} ms, {len(seg)} kernels, sum of kernel times {sum(v[0] for v in agg.values())/1e6:.3f} ms")
 for k, (t, c) in sorted(agg.items(), key=lambda x: -x[1][0])[:28]:
     print(f"  {t/1e3:9.1f} us  x{c:3d}  {k}")
+if len(sys.argv) > 2:                  # any second argument: the launches that take > 10 us with fewer than 1024 workgroups
+    print("---- > 10 us with < 1024 workgroups (workgroups x threads, us, kernel)")
+    for s_, e_, n_ in seg:
+        g_ = grid.get(s_, (0, 0))
+        if e_ - s_ > 10000 and g_[0] < 1024: print(f"  {g_[0]:6d} x {g_[1]:4d}  {(e_-s_)/1e3:8.1f}  {n_[:100]}")
