@@ -596,8 +596,9 @@ def main():
     ap.add_argument("--nbv-iters", type=int, default=50)
     ap.add_argument("--watchdog", type=int, default=0, help="seconds after which every rank dumps its Python stacks to stderr and exits (0 = off): "
                                                             "a rank stuck in a collective reports where, instead of hanging the job")
-    ap.add_argument("--legs-deadline", type=int, default=240, help="seconds the extra legs (NBV step, scene batch, MACARONS decision, CPU baselines) "
-                                                                   "may take together before every rank leaves and rank 0 prints the contract line without them")
+    ap.add_argument("--legs-deadline", type=int, default=None, help="seconds the extra legs (NBV step, scene batch, MACARONS decision, CPU baselines) "
+                                                                    "may take together before every rank leaves and rank 0 prints the contract line without them "
+                                                                    "(default: 240 on one GPU -- they take ~25 s -- and 120 on several)")
     args = ap.parse_args()
 
     if args.watchdog > 0:
@@ -606,6 +607,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.legs_deadline is None:
+        args.legs_deadline = 240 if max(world, args.gpus) == 1 else 120
     if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)                                  # plain `python bench.py --gpus N`: become the launcher of N ranks (never returns)
     if world != args.gpus and rank == 0:
