@@ -4,3 +4,4 @@ Host side mirrors the reference's `macarons.networks` class surface; the work is
 HIP kernels in libmacarons_hip.so behind the C ABI of include/macarons_hip.h.
 """
 __version__ = "0.1.0"
+from .patch import patch_reference, unpatch_reference   # noqa: E402,F401  (the reference-side binding; INTEGRATION.md §2)

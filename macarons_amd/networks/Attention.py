@@ -10,8 +10,10 @@ import warnings
 import numpy as np
 import torch
 from torch import nn
+import torch.nn.functional as F          # noqa: F401  (handed on by upstream's `from .Attention import *`)
 
 from .. import ops
+from ..utility.utils import knn_gather   # noqa: F401  (Attention.py:5 imports it from pytorch3d.ops; same gather)
 
 _warned = [False]
 

@@ -9,11 +9,14 @@ explicitly through `perms=` so tests can pin them.
 import numpy as np
 import os
 import torch
+import torch.nn.functional as F          # noqa: F401
 from torch import nn
 
 from .. import autograd as A
 from .. import ops, _lib
-from .Attention import Embedding, Encoder, _f32c, _inference_only
+from .Attention import (Embedding, Encoder, FeedForward, MultiHeadSelfAttention, attention, knn_gather,   # noqa: F401
+                        _f32c, _inference_only)     # the public ones are what upstream's `from .Attention import *` hands on
+from ..utility.utils import get_knn_points   # noqa: F401  (SconeOcc.py:4)
 from .packing import BlobCache, HeadPlaneCache, TableCache, param_key, invalidate as _invalidate_key, freeze as _freeze_key
 
 

@@ -7,14 +7,20 @@ Same constructor, attributes (n_harmonics, max_harmonic_rank, use_sigmoid ...), 
   SconeVis.compute_visibilities            :164-208
   SconeVis.compute_coverage_gain           :210-252
   SconeVis.compute_coverage_gain_multiple  :254-303
-The loss modules (:306-378) are training-only and out of this tier.
+The three loss modules the trainers import from this module (`scone_utils.py:14`: KLDivCE :306, L1_loss :322,
+Uncentered_L1_loss :353) are defined at the bottom: plain torch (training-only, no kernel), restated from their definitions so
+that `from ..networks.SconeVis import SconeVis, KLDivCE, L1_loss, Uncentered_L1_loss` resolves after `patch_reference()`.
 """
+import numpy as np                       # noqa: F401  (upstream's `from .SconeVis import *` hands these names on: Macarons.py:5-6)
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .. import autograd as A
 from .. import ops
-from .Attention import Embedding, Encoder, _f32c
+from .Attention import Embedding, Encoder, FeedForward, MultiHeadSelfAttention, attention, knn_gather, _f32c   # noqa: F401
+from ..utility.CustomGeometry import get_spherical_coords                                                # noqa: F401
+from ..utility.spherical_harmonics import clear_spherical_harmonics_cache, get_spherical_harmonics       # noqa: F401
 from .packing import TableCache, freeze as _freeze_key
 
 
@@ -165,3 +171,44 @@ class SconeVis(nn.Module):
         if self.n_harmonics != 64 or self.max_harmonic_rank != 8 or harmonics.shape[-1] != 64:
             # the reference hard-codes 64 at SconeVis.py:241
             raise NotImplementedError("the SH scorer is specialised for 64 harmonics (rank 8), as the reference hard-codes")
+
+
+# ---- training losses (SconeVis.py:306-378).  Training-only; torch composite ops, autograd does the backward. ----
+class KLDivCE(nn.Module):
+    """KL(softmax(y) || softmax(x)) over dim 1, summed and divided by the batch size ('batchmean').  SconeVis.py:306-319."""
+
+    def forward(self, x, y):
+        return F.kl_div(F.log_softmax(x, dim=1), F.softmax(y, dim=1), reduction="batchmean")
+
+
+def _camera_axis_l1(nx, ny):
+    # mean over the cameras (dim 1) of |nx - ny|, then over everything left
+    return (nx - ny).abs().mean(dim=1).mean()
+
+
+class L1_loss(nn.Module):
+    """L1 distance between the two coverage distributions after each is standardised over the cameras (dim 1): minus its mean, over
+    its (unbiased) standard deviation + epsilon.  x, y [batch, n_camera, 1].  SconeVis.py:322-350."""
+
+    def __init__(self):
+        super().__init__()
+        self.epsilon = 1e-7
+
+    def _standardise(self, t):
+        return (t - t.mean(dim=1, keepdim=True)) / (t.std(dim=1, keepdim=True) + self.epsilon)
+
+    def forward(self, x, y):
+        return _camera_axis_l1(self._standardise(x), self._standardise(y))
+
+
+class Uncentered_L1_loss(nn.Module):
+    """L1 distance between the two coverage distributions after each is divided by its mean over the cameras (+ epsilon).
+    SconeVis.py:353-378."""
+
+    def __init__(self):
+        super().__init__()
+        self.epsilon = 1e-7
+
+    def forward(self, x, y):
+        scale = lambda t: t / (t.mean(dim=1, keepdim=True) + self.epsilon)
+        return _camera_axis_l1(scale(x), scale(y))
