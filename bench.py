@@ -349,7 +349,10 @@ def measure_macarons_step(dev, rank=0, world=1, perm_sources=("host", "device"))
     d = rng.standard_normal((60000, 3))
     surf = torch.from_numpy((d / np.linalg.norm(d, axis=1, keepdims=True) * axes).astype(np.float32)).to(dev)
     torch.manual_seed(3)
-    surface.fill_cells(surf, features=torch.zeros(len(surf), 1, device=dev))
+    # the replicas of the surface scene are filled by ONE set of draws: rank 0's, through the group passed explicitly (group=None is a
+    # local fill whatever process groups exist -- Scene.fill_cells)
+    surface.fill_cells(surf, features=torch.zeros(len(surf), 1, device=dev),
+                       **({"group": torch.distributed.group.WORLD} if world > 1 else {}))
     proxy.initialize_proxy_points()
     params = NS(n_harmonics=64, harmonic_degree=8, view_state_n_elev=7, view_state_n_azim=14, k_for_knn=16,
                 prediction_neighborhood_size=3, n_view_state_cameras=98, sensor_range=70., min_occ_for_proxy_points=0.1, seq_len=2048,

@@ -358,6 +358,75 @@ int mcr_key_histogram(const int* key, int64_t N, int nk, int64_t* counts, int64_
 int mcr_admit_keys(const double* d, const int* key_s, const int64_t* cand, int64_t N, double resolution, int64_t n_point_min, int nk,
                    int* key2, void* stream);
 
+/* ---- one MACARONS decision without the host glue (testers/scene.py:391-454; macarons/utility/macarons_utils.py:2727-2737 Scene.fill_cells
+ * over :2551-2577 Cell.fill, :1395-1540 compute_scene_occupancy_probability_field, :1631-1704 predict_coverage_gain_for_single_camera):
+ * each phase of the loop body is a handful of launches behind ONE call, the host reads two small count tables back.
+ *
+ * mcr_group_by_key: stable grouping of N rows by key[i] in 0 .. nk (anything else counts as nk; nk <= 1023): order[pos] = source row --
+ *   rows of one key contiguous, ascending row index inside a key, i.e. torch.sort(key, stable=True).indices -- with counts[0 .. nk] and
+ *   their exclusive offsets[0 .. nk + 1].  (The reference compacts with boolean masks cell by cell; the sort replaced it in round 3.)
+ *
+ * mcr_scene_fill_begin: the device part of Scene.fill_cells for ALL cells: key[i] = cell of point i (mcr_cell_keys, box_test = 1),
+ *   order = candidates grouped by cell, dmin[i] = fp64 distance of the i-th candidate IN CELL ORDER to the store of its cell
+ *   (store_pts: every cell's stored points, cells in linear order; store_off [n_cells + 1] their offsets), key2 / order2 = the admitted
+ *   candidates (Cell.fill :2562-2568) grouped by cell.  counts = cand [n_cells+1] | a_off [n_cells+2] | adm [n_cells+1] | adm_off [n_cells+2].
+ * mcr_scene_fill_gather: new store row r = row g[r] of the virtual table [old store (n_store rows) | admitted candidates in cell order]
+ *   (the host builds g from the cells' torch.randperm draws, :2573); features ride along (F floats per row; NULL = none).
+ *
+ * mcr_field_select: which proxy points take part in the occupancy pass and where (:1428-1442): stored_cell[p] = cell whose store holds
+ *   proxy point p (features column 0 = proxy index; `pend_*` = the arrays of a mcr_scene_fill_begin whose gather has not run yet, NULL =
+ *   none), proxy_proba <- 0 where seen (:1431), visit[c] = 1 for cells holding a seen point (:1434), rows_order = selected points
+ *   grouped by storing cell (ascending index), oof_order = never-seen points first (ascending index).
+ *   counts = visit [n+1] | sel_counts [n+1] | sel_off [n+2] | oof_counts [2] | oof_off [3], n = n_cells.
+ * mcr_field_build: the (cell, chunk) jobs of the pass from host tables -- jobs [J][4] int64 = first position in rows_order, first query row,
+ *   first cloud row, unused; segs [n_seg][4] int64 = first row in S_all (the surface store), first cloud row, job, unused; job_xf [J][20] =
+ *   world->view matrix (16, row-vector), box centre in view space (3), 1 / (neighbourhood size x cell diagonal) (:1468-1478) --:
+ *   rows [T], row_job [T], X_world [T,3] = the selected proxy points, X_q [T,3] / pc_all [tot,3] = queries / surface clouds in their
+ *   jobs' prediction spaces (:1479-1484), vh [T,64] = view harmonics of the rows (mcr_view_harmonics_rows).
+ * mcr_view_harmonics_rows: vh[t, k] = sum_v view_states[rows[t], bin_perm[v]] * vh_matrix_t[v, k]: move_view_state_to_view_space
+ *   (scone_utils.py:863-931) + compute_view_harmonics (:934-960) of selected rows (rows / bin_perm may be NULL = identity).
+ * mcr_field_finish: proxy_proba[rows[t]] = occ[t] (:1525), then the field's tail: the n_oof never-seen points with their stored
+ *   probability (:1531-1537).
+ *
+ * mcr_camera_boxes: per neighbour camera k, centre of the bounding box of its first n_unique[k] sampled points (sampled [K,S,4]) in
+ *   the prediction camera's view space (:1631-1641) and the camera centre in the normalised prediction space (:1655-1659).
+ * mcr_macarons_gain_indexed: gains[k] = mean_s vis_unique[k, inverse[k,s]] * factor(|world_unique[k, inverse[k,s]] - cam_world[k]|)
+ *   * volume[k], 0 when n_unique[k] == 0 (:1668-1704; the Monte-Carlo duplicates read through the inverse map).
+ * mcr_philox_uniform_rows: out [K,S] = what K consecutive torch.rand(S, 1, device=...) calls return for a device generator at
+ *   (seed, offset): the per-camera sampling uniforms of scone_utils.py:1052 in one launch (mapping 1 = rocRAND's (0,1] map, 0 = cuRAND's). */
+size_t mcr_group_by_key_workspace_bytes(int64_t N, int nk);
+int mcr_group_by_key(const int* key, int64_t N, int nk, int* order, int64_t* counts, int64_t* offsets, void* workspace,
+                     size_t workspace_bytes, void* stream);
+size_t mcr_scene_fill_workspace_bytes(int64_t N, int n_cells);
+int mcr_scene_fill_begin(const float* pts, int64_t N, const unsigned char* valid, const float* grid_consts, int grid_l, int grid_w,
+                         int grid_h, const float* lo_tab, const float* hi_tab, const float* store_pts, const int64_t* store_off,
+                         double resolution, int64_t n_point_min, int* key, int* order, double* dmin, int* key2, int* order2,
+                         int64_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+int mcr_scene_fill_gather(const int64_t* g, int64_t n_new, const float* store_pts, const float* store_fts, int64_t n_store, int F,
+                          const float* pts, const float* features, const int* order, const int* order2, float* new_pts, float* new_fts,
+                          void* stream);
+size_t mcr_field_select_workspace_bytes(int64_t P, int n_cells);
+int mcr_field_select(const float* proxy_points, int64_t P, const float* supervision_occ, const float* out_of_field, float* proxy_proba,
+                     const float* store_fts, int F, int64_t n_store, const int64_t* store_off, const float* pend_features,
+                     const int* pend_order, const int* pend_order2, const int* pend_key2, const int64_t* pend_adm_off, int64_t pend_N,
+                     const float* grid_consts, int grid_l, int grid_w, int grid_h, int use_supervision_occ_mask, int* stored_cell,
+                     int* key_sel, int* key_oof, int* rows_order, int* oof_order, int64_t* counts, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int mcr_field_build(const int64_t* jobs, int J, const int64_t* segs, int n_seg, const float* job_xf, const int* rows_order,
+                    const float* proxy_points, const float* S_all, const float* view_states, int n_bins, const int* bin_perm,
+                    const float* vh_matrix_t, int64_t T, int64_t tot, int* rows, int* row_job, float* X_world, float* X_q, float* vh,
+                    float* pc_all, void* stream);
+int mcr_view_harmonics_rows(const float* view_states, int n_bins, const int* rows, const int* bin_perm, const float* vh_matrix_t,
+                            int64_t T, float* vh, void* stream);
+int mcr_field_finish(const int* rows, const float* occ, int64_t T, float* proxy_proba, const int* oof_order, int64_t n_oof,
+                     const float* proxy_points, float* X_tail, float* occ_tail, void* stream);
+int mcr_camera_boxes(const float* sampled, const int* n_unique, int64_t K, int S, const float* M_view, const float* cam_world,
+                     float inv_diag, float* center, float* cam_view, void* stream);
+int mcr_macarons_gain_indexed(const float* vis_unique, const float* world_unique, const int64_t* inverse, const int* n_unique,
+                              const float* cam_world, const float* volume, float distance_th, int factor_mode, int64_t K, int S,
+                              float* gains, void* stream);
+int mcr_philox_uniform_rows(uint64_t seed, uint64_t offset, int64_t K, int S, int mapping, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

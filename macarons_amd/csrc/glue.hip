@@ -553,36 +553,6 @@ __global__ __launch_bounds__(256) void macarons_gain_kernel(float* __restrict__ 
     if (threadIdx.x == 0) gains[b] = (float)(((s[0] + s[1]) + (s[2] + s[3])) / (double)N) * volume[b];
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// K11: segmented nearest-distance in fp64 ("is any point of B within eps of each point of A", per grid cell):
-//   dmin[i] = min_j |A[i] - B[j]|  over the B points of A[i]'s segment  (torch.min(torch.cdist(a.double(), b.double())),
-//   macarons_utils.py:2566 Cell.fill, :3022 camera_coverage_gain, :3049 scene_coverage).  +inf for an empty B segment.
-// grid = (ceil(max_a/256), n_seg): one block column per segment, B streamed through LDS.
-__global__ __launch_bounds__(256) void min_dist_seg_kernel(const float* __restrict__ A, const long long* __restrict__ a_off,
-                                                           const float* __restrict__ B, const long long* __restrict__ b_off,
-                                                           double* __restrict__ dmin) {
-    __shared__ double sb[512 * 3];
-    const int seg = blockIdx.y;
-    const long long a0 = a_off[seg], a1 = a_off[seg + 1], b0 = b_off[seg], b1 = b_off[seg + 1];
-    const long long i = a0 + (long long)blockIdx.x * 256 + threadIdx.x;
-    if ((long long)blockIdx.x * 256 >= a1 - a0) return;
-    const bool valid = i < a1;
-    double ax = 0, ay = 0, az = 0;
-    if (valid) { ax = A[3 * i]; ay = A[3 * i + 1]; az = A[3 * i + 2]; }
-    double best = __builtin_inf();
-    for (long long t0 = b0; t0 < b1; t0 += 512) {
-        const int nt = (int)min((long long)512, b1 - t0);
-        __syncthreads();
-        for (int k = threadIdx.x; k < nt * 3; k += 256) sb[k] = (double)B[3 * t0 + k];
-        __syncthreads();
-        for (int j = 0; j < nt; ++j) {
-            const double dx = ax - sb[3 * j], dy = ay - sb[3 * j + 1], dz = az - sb[3 * j + 2];
-            best = fmin(best, (dx * dx + dy * dy) + dz * dz);
-        }
-    }
-    if (valid) dmin[i] = sqrt(best);
-}
-
 // K12: depth map -> world points (Camera.project_depth_in_3D macarons_utils.py:2339-2360 / utils.project_depth_back_to_3D
 // utils.py:1458-1487 with pytorch3d FoVPerspectiveCameras.unproject_points(scaled_depth_input=False)):
 //   ndc_x = W/m - 2 j/(m-1), ndc_y = H/m - 2 i/(m-1), m = min(W,H);  sdepth = (k22 * d + k32) / d;
@@ -695,131 +665,6 @@ __global__ __launch_bounds__(64) void best_merge_kernel(const float* __restrict_
     }
     vals[b] = bv;
     idx[b] = (long long)bi;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Scene-grid bookkeeping of Scene.fill_cells / compute_scene_occupancy_probability_field (macarons_utils.py:2693-2737, :1434): the
-// per-point cell lookup, Cell.fill's box tests and the per-cell counts -- fifteen small elementwise launches of the host code as one.
-// Bit-compatible with the torch expressions it replaces:
-//   d = pts - x_min;  idx = min((d - remainder(d, step)) / step, grid - 1) truncated to an integer, clamped at 0   (utils.floor_divide)
-//   key = linear cell id if the point lies in the scene box (closed), strictly inside ITS cell's box (Cell.fill :2552-2557) and is
-//   offered (valid), else n_cells.   box_test = 0: the cell id alone (:1434 uses the lookup without the tests).
-__device__ __forceinline__ float torch_remainder(float a, float b) {       // torch.remainder on floats: fmod, then the divisor's sign
-    float m = fmodf(a, b);
-    if (m != 0.f && ((b < 0.f) != (m < 0.f))) m = __fadd_rn(m, b);
-    return m;
-}
-__global__ void cell_keys_kernel(const float* __restrict__ pts, long long N, const unsigned char* __restrict__ valid,
-                                 const float* __restrict__ gc, int gl, int gw, int gh, const float* __restrict__ lo_tab,
-                                 const float* __restrict__ hi_tab, int box_test, int* __restrict__ key) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const int g[3] = {gl, gw, gh};
-    float p[3];
-    int idx[3];
-    bool in_scene = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        p[a] = pts[i * 3 + a];
-        const float d = __fsub_rn(p[a], gc[a]), st = gc[6 + a];
-        float q = __fdiv_rn(__fsub_rn(d, torch_remainder(d, st)), st);
-        q = fminf(q, (float)(g[a] - 1));                  // (NaN-propagating in torch; a NaN coordinate fails every test below anyway)
-        long long t = (long long)q;                       // .long(): truncation
-        idx[a] = (int)(t < 0 ? 0 : t);
-        in_scene = in_scene && p[a] >= gc[a] && p[a] <= gc[3 + a];
-    }
-    const int n_cells = gl * gw * gh;
-    int cid = (idx[0] * gw + idx[1]) * gh + idx[2];
-    if (cid >= n_cells) cid = n_cells - 1;                // (unreachable: idx[a] <= g[a] - 1)
-    if (box_test) {
-        bool ok = in_scene && (!valid || valid[i]);
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-            ok = ok && (__fsub_rn(p[a], hi_tab[cid * 3 + a]) < 0.f) && (__fsub_rn(p[a], lo_tab[cid * 3 + a]) > 0.f);
-        key[i] = ok ? cid : n_cells;
-    } else {
-        key[i] = cid;
-    }
-}
-
-// counts[k] = #{i : key[i] == k} for k <= nk, offsets = their exclusive prefix sums (nk + 2 entries): ONE block (N is a few 10^5,
-// nk <= 1023), no zero-initialised scratch, no second launch for the scan.  The keys are cell ids of points that arrive in image /
-// cloud order, i.e. long runs of one value: LDS atomics on one address serialise (64 per wave instruction: 87 us at N = 230k with
-// one atomic per key).  A thread therefore takes 32 CONSECUTIVE keys per round (eight 16-byte loads in flight), folds runs of equal
-// keys in registers, and a wave whose lanes all end on the same key adds its counts up first and issues ONE atomic.
-__global__ __launch_bounds__(1024) void key_histogram_kernel(const int* __restrict__ key, long long N, int nk,
-                                                            long long* __restrict__ counts, long long* __restrict__ offsets) {
-    __shared__ unsigned s_cnt[1024];
-    __shared__ unsigned s_wave[16];
-    const int tid = threadIdx.x;
-    s_cnt[tid] = 0u;
-    __syncthreads();
-    const bool al16 = (reinterpret_cast<uintptr_t>(key) & 15) == 0;
-    const long long N4 = al16 ? N / 4 : 0;                              // whole int4 groups
-    const int4* key4 = reinterpret_cast<const int4*>(key);
-    constexpr int G = 8;                                                // int4 groups per thread and round
-    for (long long g0 = 0; g0 < N4; g0 += (long long)G * 1024) {       // (block-uniform trip count: the wave votes below are convergent)
-        int4 v[G];
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            const long long g = g0 + (long long)tid * G + u;
-            v[u] = g < N4 ? key4[g] : make_int4(-1, -1, -1, -1);
-        }
-        int cur = -1;                                                   // the open run (cur < 0: none)
-        unsigned n = 0;
-        auto take = [&](int k) {
-            if (k < 0 || k > nk) return;                                // not a key: ignored
-            if (k == cur) { ++n; return; }
-            if (n) atomicAdd(&s_cnt[cur], n);                           // a run ended inside the thread's 32 keys: rare
-            cur = k; n = 1;
-        };
-#pragma unroll
-        for (int u = 0; u < G; ++u) { take(v[u].x); take(v[u].y); take(v[u].z); take(v[u].w); }
-        // the last (usually the only) run of every lane: one atomic per wave when the lanes that have one agree on the key
-        const unsigned long long has = __ballot(n > 0);
-        if (has) {
-            const int first = __builtin_ctzll(has);
-            const int kf = __shfl(cur, first, 64);
-            if (__all(n == 0 || cur == kf)) {
-                unsigned tot = n;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-                if ((tid & 63) == first) atomicAdd(&s_cnt[kf], tot);
-            } else if (n) {
-                atomicAdd(&s_cnt[cur], n);
-            }
-        }
-    }
-    for (long long i = N4 * 4 + tid; i < N; i += 1024) {                // the tail (and unaligned inputs): one key at a time
-        const int k = key[i];
-        if (k >= 0 && k <= nk) atomicAdd(&s_cnt[k], 1u);
-    }
-    __syncthreads();
-    // exclusive scan over k = 0 .. 1023 (entries above nk are zero): lane prefix inside a wave, then the 16 wave totals
-    const unsigned c = s_cnt[tid];
-    unsigned incl = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned up = __shfl_up(incl, o, 64);
-        if ((tid & 63) >= o) incl += up;
-    }
-    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
-    __syncthreads();
-    unsigned base = 0;
-    for (int w = 0; w < (tid >> 6); ++w) base += s_wave[w];
-    const unsigned excl = base + incl - c;
-    if (tid <= nk) { counts[tid] = c; offsets[tid] = excl; }
-    if (tid == nk) offsets[nk + 1] = excl + c;
-}
-
-// Cell.fill's admission (:2565-2568) on the sorted candidates: key2 = the cell of a candidate that is offered to a cell with more
-// than n_point_min candidates and whose fp64 distance to every stored point exceeds the resolution, else nk
-__global__ void admit_keys_kernel(const double* __restrict__ d, const int* __restrict__ key_s, const long long* __restrict__ cand,
-                                  long long N, double resolution, long long n_point_min, int nk, int* __restrict__ key2) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const int k = key_s[i];
-    key2[i] = (k < nk && cand[k] > n_point_min && d[i] > resolution) ? k : nk;
 }
 
 extern "C" {
@@ -1003,16 +848,6 @@ int mcr_macarons_gain(float* vis, const float* pts_world, int pts_dim, const flo
     return 0;
 }
 
-int mcr_min_dist_segmented(const float* A, const int64_t* a_offsets, const float* B, const int64_t* b_offsets, int64_t n_segments,
-                           int64_t max_a_per_segment, double* dmin, void* stream) {
-    MCR_REQUIRE(A && a_offsets && B && b_offsets && dmin, "mcr_min_dist_segmented: null pointer");
-    MCR_REQUIRE(n_segments > 0 && n_segments <= 65535 && max_a_per_segment > 0, "mcr_min_dist_segmented: bad sizes");
-    hipLaunchKernelGGL(min_dist_seg_kernel, dim3((unsigned)cdiv(max_a_per_segment, 256), (unsigned)n_segments), dim3(256), 0,
-                       (hipStream_t)stream, A, (const long long*)a_offsets, B, (const long long*)b_offsets, dmin);
-    MCR_LAUNCH_CHECK("min_dist_seg_kernel");
-    return 0;
-}
-
 int mcr_unproject_depth(const float* depth, int H, int W, const float* cameras, int64_t n_cam, float* world, void* stream) {
     MCR_REQUIRE(depth && cameras && world && H > 1 && W > 1 && n_cam > 0, "mcr_unproject_depth: bad arguments");
     hipLaunchKernelGGL(unproject_depth_kernel, dim3((unsigned)cdiv(n_cam * H * W, 256)), dim3(256), 0, (hipStream_t)stream, depth, H,
@@ -1060,32 +895,4 @@ int mcr_best_merge(const float* records, int world, int64_t B, float* vals, int6
     return 0;
 }
 
-
-int mcr_cell_keys(const float* pts, int64_t N, const unsigned char* valid, const float* grid_consts, int grid_l, int grid_w, int grid_h,
-                  const float* lo_tab, const float* hi_tab, int box_test, int* key, void* stream) {
-    MCR_REQUIRE(pts && grid_consts && key && N > 0, "mcr_cell_keys: bad arguments");
-    MCR_REQUIRE(grid_l > 0 && grid_w > 0 && grid_h > 0 && (long long)grid_l * grid_w * grid_h < (1 << 30), "mcr_cell_keys: bad grid");
-    MCR_REQUIRE(!box_test || (lo_tab && hi_tab), "mcr_cell_keys: the box tests need the cells' bounds");
-    hipLaunchKernelGGL(cell_keys_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, pts, (long long)N, valid, grid_consts,
-                       grid_l, grid_w, grid_h, lo_tab, hi_tab, box_test, key);
-    MCR_LAUNCH_CHECK("cell_keys_kernel");
-    return 0;
-}
-
-int mcr_key_histogram(const int* key, int64_t N, int nk, int64_t* counts, int64_t* offsets, void* stream) {
-    MCR_REQUIRE(key && counts && offsets && N >= 0 && nk >= 0 && nk <= 1023, "mcr_key_histogram: bad arguments (nk <= 1023)");
-    hipLaunchKernelGGL(key_histogram_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, key, (long long)N, nk, (long long*)counts,
-                       (long long*)offsets);
-    MCR_LAUNCH_CHECK("key_histogram_kernel");
-    return 0;
-}
-
-int mcr_admit_keys(const double* d, const int* key_s, const int64_t* cand, int64_t N, double resolution, int64_t n_point_min, int nk,
-                   int* key2, void* stream) {
-    MCR_REQUIRE(d && key_s && cand && key2 && N > 0 && nk >= 0, "mcr_admit_keys: bad arguments");
-    hipLaunchKernelGGL(admit_keys_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, d, key_s, (const long long*)cand,
-                       (long long)N, resolution, (long long)n_point_min, nk, key2);
-    MCR_LAUNCH_CHECK("admit_keys_kernel");
-    return 0;
-}
 }  // extern "C"

@@ -10,6 +10,16 @@ import torch
 import torch.distributed as dist
 
 
+def group_world_rank(group):
+    """(world, rank) of a sharded / replicated call.  `group=None` means LOCAL -- (1, 0) -- even when a default process group
+    exists: a data-parallel job whose ranks each own a different scene (how upstream's DDP trainers call these routines) must not
+    find an implicit collective inside a method that used to be local.  Pass `torch.distributed.group.WORLD` (or a sub-group)
+    to shard over it."""
+    if group is None or not (dist.is_available() and dist.is_initialized()):
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
 def shard_range(n_items, rank, world):
     """Contiguous block partition of n_items over world ranks (first ranks get the remainder)."""
     q, r = divmod(n_items, world)

@@ -71,7 +71,7 @@ def _guarded(impl, scone_occ, range_guard, group, draws, device):
         flag = scone_occ.range_flag() if L.mcr_get_local_pct_variant() == 6 else None
         out["range_flag"] = flag
         if guard and not capturing:
-            world = torch.distributed.get_world_size(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+            world = mdist.group_world_rank(group)[0]
             if world > 1:
                 flag = mdist.all_reduce_max(flag, group)
             # the one read-back, after the last kernel of the decision was queued; the decision itself rides along (a caller that
@@ -120,8 +120,7 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
     def impl():
         return _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len, min_occ, max_points_per_pass,
                          true_monte_carlo_sampling, fixed["occ_perms"], fixed["samples"], group, view_proj, filter_tol, return_samples)
-    inited = torch.distributed.is_available() and torch.distributed.is_initialized()
-    if inited and torch.distributed.get_world_size(group) > 1:
+    if mdist.group_world_rank(group)[0] > 1:
         draws = lambda: {}                          # noqa: E731  (sharded: rank 0's draws are broadcast inside the step; a repeat redraws)
     return _guarded(impl, scone_occ, range_guard, group, draws, X.device)
 
@@ -135,12 +134,10 @@ def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, mi
     (n_unique: int32 [1]); nothing is read back inside the step, so it runs without a single host synchronisation.
     `occ_perms` / `samples` pin the hidden RNG draws (SconeOcc randperms; sampling uniforms).  `view_proj` [n_view,4,4]
     (full-projection matrices of the past views) switches on the tester's proxy-point filter (testers/shapenet.py:117-122)."""
-    inited = torch.distributed.is_available() and torch.distributed.is_initialized()
-    world = torch.distributed.get_world_size(group) if inited else 1
-    rank = torch.distributed.get_rank(group) if world > 1 else 0
+    world, rank = mdist.group_world_rank(group)            # group=None: local (pass torch.distributed.group.WORLD to shard)
     # the exchange path (broadcast of the hidden draws, all-gathers, record merge) normally needs world > 1; the env knob runs it
     # through RCCL on a single rank too, so that a one-GPU box can test it end to end
-    sharded = world > 1 or (inited and bool(os.environ.get("MCR_FORCE_DIST_PATH")))
+    sharded = world > 1 or (group is not None and torch.distributed.is_initialized() and bool(os.environ.get("MCR_FORCE_DIST_PATH")))
     dev = X.device
     if view_proj is not None:                                                       # testers/shapenet.py:122
         X = su.filter_proxy_points(view_proj, X[0], pc.reshape(-1, 3), filter_tol=filter_tol)[0][None]
@@ -248,8 +245,7 @@ def nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=204
                    occ_perms=None, samples=None, group=None, return_samples=False, range_guard=True):
     """B independent decisions in one launch sequence; see _nbv_step_batch.  range_guard as in nbv_step."""
     fixed = dict(occ_perms=occ_perms, samples=samples)
-    inited = torch.distributed.is_available() and torch.distributed.is_initialized()
-    world = torch.distributed.get_world_size(group) if inited else 1
+    world = mdist.group_world_rank(group)[0]
 
     def draws():
         if world == 1 and (fixed["occ_perms"] is None or fixed["samples"] is None):
@@ -279,9 +275,7 @@ def _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=20
     Returns dict(gains [B_local, C_local], cloud_range, cam_range, max_gain [B], nbv_idx [B] int64, occ [B_local, Q, 1],
     n_unique int32 [B_local]); device tensors, no host synchronisation inside."""
     from . import ops
-    inited = torch.distributed.is_available() and torch.distributed.is_initialized()
-    world = torch.distributed.get_world_size(group) if inited else 1
-    rank = torch.distributed.get_rank(group) if world > 1 else 0
+    world, rank = mdist.group_world_rank(group)            # group=None: local (pass torch.distributed.group.WORLD to shard)
     dev = X.device
     B, Q, M, C = X.shape[0], X.shape[1], pc.shape[1], X_cam.shape[-2]
     if pc.shape[0] != B:

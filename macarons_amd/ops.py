@@ -171,11 +171,22 @@ def _mask_bytes(mask, S, H, L, device):
     """A reference-style attention mask -> (uint8 device tensor [s, h, q, L], seq / head / query strides in bytes) for
     mcr_attention_masked.  Accepted: whatever broadcasts against the [S, H, L, L] scores the way upstream's
     `scores.masked_fill(mask == 0, -1e3)` does (Attention.py:24-27) -- [L, L], [S, 1, L, L], [1, 1, L, L], [S, H, L, L] -- plus
-    [S, L, L] (the shape upstream's docstrings name: read as [S, 1, L, L]) and key masks [S, L] (a 2-D mask of shape [L, L] is
+    [S, L, L] (the shape upstream's docstrings name: read as [S, 1, L, L]; REFUSED when S == H != 1, where upstream's broadcast
+    means one mask per head instead) and key masks [S, L] (a 2-D mask of shape [L, L] is
     upstream's; use key_mask() to force the key reading when S == L) / [S, 1, 1, L].  Non-zero = attend."""
     m = mask if torch.is_tensor(mask) else torch.as_tensor(mask)
     m = (m != 0).to(device=device, dtype=torch.uint8)
+    if m.dim() == 3 and tuple(m.shape) == (S, L, L) and S == H and S != 1:
+        # upstream's masked_fill broadcasts [B,N,N] against [B,H,N,N] as [1,B,N,N]: with B == H that is one mask PER HEAD shared by
+        # the sequences, while upstream's docstrings (and the [S,1,L,L] reading below) mean one mask per sequence -- refuse to guess
+        raise ValueError(f"a 3-D attention mask of shape {tuple(m.shape)} with as many sequences as heads ({H}) is ambiguous: upstream "
+                         "broadcasts it per HEAD, its docstrings mean per SEQUENCE; pass mask[:, None] ([S,1,L,L]) or mask[None] "
+                         "([1,H,L,L]) explicitly")
     if m.dim() == 2 and tuple(m.shape) == (L, L):
+        if S == L and S != 1:
+            import warnings
+            warnings.warn(f"2-D attention mask [{L}, {L}] with {S} sequences of {L} tokens: read as upstream's [L, L] pair mask; for a "
+                          "[S, L] key mask use ops.key_mask()", stacklevel=3)
         m4 = m.view(1, 1, L, L)
     elif m.dim() == 2 and tuple(m.shape) == (S, L):
         m4 = m.view(S, 1, 1, L)
@@ -850,3 +861,190 @@ def admit_keys(d, key_s, cand, resolution, n_point_min, nk):
         check(lib().mcr_admit_keys(_p(d), _p(key_s), _p(cand), c_i64(key_s.numel()), ctypes.c_double(float(resolution)), c_i64(int(n_point_min)),
                                    c_int(nk), _p(key2), _stream()), "mcr_admit_keys")
     return key2
+
+
+# ---- one MACARONS decision without the host glue (scene.hip): each phase = a handful of launches behind one C call ----------------
+def group_by_key(key, nk):
+    """key int32 [N] in 0 .. nk (anything else counts as nk) -> (order int32 [N] = torch.sort(key, stable=True).indices,
+    counts int64 [nk+1], exclusive offsets int64 [nk+2]); a three-launch counting sort (nk <= 1023)."""
+    key = _req(key, "key", torch.int32)
+    N, dev = key.numel(), key.device
+    order = torch.empty(N, dtype=torch.int32, device=dev)
+    co = torch.empty(2 * nk + 3, dtype=torch.int64, device=dev)
+    L_ = lib()
+    ws = _workspace(dev, max(int(L_.mcr_group_by_key_workspace_bytes(c_i64(N), c_int(nk))), 4))
+    with torch.cuda.device(dev):
+        check(L_.mcr_group_by_key(_p(key), c_i64(N), c_int(nk), _p(order), _p(co), c_vp(co.data_ptr() + 8 * (nk + 1)), _p(ws),
+                                  c_size(ws.numel()), _stream()), "mcr_group_by_key")
+    return order, co[:nk + 1], co[nk + 1:]
+
+
+class PendingFill:
+    """What mcr_scene_fill_begin left on the device: the candidates grouped by cell and the admitted ones among them; `counts`
+    (int64 [4 nk + 6] = cand | a_off | adm | adm_off) is what the host reads back before it draws the cells' permutations."""
+    __slots__ = ("pts", "features", "N", "nk", "key", "order", "dmin", "key2", "order2", "counts")
+
+
+def scene_fill_begin(pts, valid, grid_consts, grid, lo_tab, hi_tab, store_pts, store_off, resolution, n_point_min, features=None):
+    """The device part of Scene.fill_cells (mcr_scene_fill_begin): nothing returns to the host.  pts [N,3]; valid bool/uint8 [N] or
+    None; store_pts [n_store,3] = every cell's stored points (cells in linear order), store_off int64 device [n_cells+1]."""
+    pts, gc = _req(pts, "pts"), _req(grid_consts, "grid_consts")
+    N, dev = pts.shape[0], pts.device
+    nk = grid[0] * grid[1] * grid[2]
+    h = PendingFill()
+    h.pts, h.N, h.nk = pts, N, nk
+    h.features = None if features is None else features.to(torch.float32).contiguous()
+    ib = torch.empty(4 * N, dtype=torch.int32, device=dev)
+    h.key, h.order, h.key2, h.order2 = ib[:N], ib[N:2 * N], ib[2 * N:3 * N], ib[3 * N:]
+    h.dmin = torch.empty(N, dtype=torch.float64, device=dev)
+    h.counts = torch.empty(4 * nk + 6, dtype=torch.int64, device=dev)
+    v = valid.to(torch.uint8).contiguous() if valid is not None else None
+    L_ = lib()
+    ws = _workspace(dev, max(int(L_.mcr_scene_fill_workspace_bytes(c_i64(N), c_int(nk))), 4))
+    with torch.cuda.device(dev):
+        check(L_.mcr_scene_fill_begin(_p(pts), c_i64(N), _p(v) if v is not None else c_vp(0), _p(gc), c_int(grid[0]), c_int(grid[1]),
+                                      c_int(grid[2]), _p(_req(lo_tab, "lo_tab")), _p(_req(hi_tab, "hi_tab")),
+                                      _p(store_pts) if store_pts is not None and store_pts.numel() else c_vp(0),
+                                      _p(_req(store_off, "store_off", torch.int64)), ctypes.c_double(float(resolution)), c_i64(int(n_point_min)),
+                                      _p(h.key), _p(h.order), _p(h.dmin), _p(h.key2), _p(h.order2), _p(h.counts), _p(ws), c_size(ws.numel()),
+                                      _stream()), "mcr_scene_fill_begin")
+    return h
+
+
+def scene_fill_gather(g, h, store_pts, store_fts, n_store, F):
+    """New store rows = rows g of [old store | admitted candidates of the pending fill h in cell order] -> (pts [n,3], features [n,F] | None)."""
+    g = _req(g, "g", torch.int64)
+    n, dev = g.numel(), g.device
+    new_pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    new_fts = torch.empty((n, F), dtype=torch.float32, device=dev) if F > 0 else None
+    with torch.cuda.device(dev):
+        check(lib().mcr_scene_fill_gather(_p(g), c_i64(n), _p(store_pts) if n_store else c_vp(0),
+                                          _p(store_fts) if (n_store and store_fts is not None) else c_vp(0), c_i64(n_store), c_int(F), _p(h.pts),
+                                          _p(h.features) if h.features is not None else c_vp(0), _p(h.order), _p(h.order2), _p(new_pts),
+                                          _p(new_fts) if new_fts is not None else c_vp(0), _stream()), "mcr_scene_fill_gather")
+    return new_pts, new_fts
+
+
+class FieldSelection:
+    """What mcr_field_select left on the device; `counts` (int64 [3 nk + 9] = visit | sel_counts | sel_off | oof_counts | oof_off)."""
+    __slots__ = ("P", "nk", "stored_cell", "rows_order", "oof_order", "counts")
+
+
+def field_select(proxy_points, supervision_occ, out_of_field, proxy_proba, store_fts, n_store, store_off, grid_consts, grid, use_mask,
+                 pending=None):
+    """Selection + grouping of the occupancy-field pass (mcr_field_select); proxy_proba is updated in place (:1431)."""
+    pp = _req(proxy_points, "proxy_points")
+    P, dev = pp.shape[0], pp.device
+    nk = grid[0] * grid[1] * grid[2]
+    for name, t in (("proxy_supervision_occ", supervision_occ), ("out_of_field", out_of_field), ("proxy_proba", proxy_proba)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == P):
+            raise ValueError(f"{name} must be a contiguous fp32 device tensor with one entry per proxy point")
+    F = store_fts.shape[1] if (store_fts is not None and store_fts.dim() == 2) else 1
+    if pending is not None and (pending.features is None or pending.features.shape[1] != F):
+        raise ValueError("field_select: the pending fill carries no features (the proxy indices)")
+    s = FieldSelection()
+    s.P, s.nk = P, nk
+    ib = torch.empty(5 * P, dtype=torch.int32, device=dev)
+    s.stored_cell, key_sel, key_oof, s.rows_order, s.oof_order = (ib[k * P:(k + 1) * P] for k in range(5))
+    s.counts = torch.empty(3 * nk + 9, dtype=torch.int64, device=dev)
+    L_ = lib()
+    ws = _workspace(dev, max(int(L_.mcr_field_select_workspace_bytes(c_i64(P), c_int(nk))), 4))
+    pe = pending
+    with torch.cuda.device(dev):
+        check(L_.mcr_field_select(_p(pp), c_i64(P), _p(supervision_occ), _p(out_of_field), _p(proxy_proba),
+                                  _p(store_fts) if n_store else c_vp(0), c_int(F), c_i64(n_store), _p(_req(store_off, "store_off", torch.int64)),
+                                  _p(pe.features) if pe is not None else c_vp(0), _p(pe.order) if pe is not None else c_vp(0),
+                                  _p(pe.order2) if pe is not None else c_vp(0), _p(pe.key2) if pe is not None else c_vp(0),
+                                  c_vp(pe.counts.data_ptr() + 8 * (3 * nk + 4)) if pe is not None else c_vp(0), c_i64(pe.N if pe is not None else 0),
+                                  _p(_req(grid_consts, "grid_consts")), c_int(grid[0]), c_int(grid[1]), c_int(grid[2]), c_int(int(bool(use_mask))),
+                                  _p(s.stored_cell), _p(key_sel), _p(key_oof), _p(s.rows_order), _p(s.oof_order), _p(s.counts), _p(ws),
+                                  c_size(ws.numel()), _stream()), "mcr_field_select")
+    return s
+
+
+def field_build(tables, J, n_seg, sel, proxy_points, S_all, view_states, bin_perm, vh_matrix_t, T, tot, X_world, vh):
+    """The jobs of the occupancy-field pass (mcr_field_build).  tables: ONE uploaded fp64-free buffer = int64 [J*4 + n_seg*4] followed
+    (as raw bytes) by fp32 [J*20]; X_world [>=T,3] and vh [>=T,64] are written in their first T rows.
+    -> (rows int32 [T], row_job int32 [T], X_q [T,3], pc_all [tot,3])."""
+    dev = proxy_points.device
+    ib = torch.empty(2 * T, dtype=torch.int32, device=dev)
+    rows, row_job = ib[:T], ib[T:]
+    fb = torch.empty(3 * (T + tot), dtype=torch.float32, device=dev)
+    X_q, pc_all = fb[:3 * T].view(T, 3), fb[3 * T:].view(tot, 3)
+    base = tables.data_ptr()
+    n_bins = view_states.shape[1]
+    with torch.cuda.device(dev):
+        check(lib().mcr_field_build(c_vp(base), c_int(J), c_vp(base + 32 * J), c_int(n_seg), c_vp(base + 32 * (J + n_seg)), _p(sel.rows_order),
+                                    _p(proxy_points), _p(S_all), _p(view_states), c_int(n_bins), _p(bin_perm), _p(vh_matrix_t), c_i64(T),
+                                    c_i64(tot), _p(rows), _p(row_job), _p(X_world), _p(X_q), _p(vh), _p(pc_all), _stream()), "mcr_field_build")
+    return rows, row_job, X_q, pc_all
+
+
+def view_harmonics_rows(view_states, rows, bin_perm, vh_matrix_t, out=None):
+    """vh [T,64] of rows `rows` (int32 device, None = all) of a view-state table: bins permuted by bin_perm (int32 device, None = identity),
+    then the [n_bins, 64] product (mcr_view_harmonics_rows)."""
+    vs = _req(view_states, "view_states")
+    T = rows.numel() if rows is not None else vs.shape[0]
+    if out is None:
+        out = torch.empty((T, 64), dtype=torch.float32, device=vs.device)
+    if T == 0:
+        return out
+    with torch.cuda.device(vs.device):
+        check(lib().mcr_view_harmonics_rows(_p(vs), c_int(vs.shape[1]), _p(rows) if rows is not None else c_vp(0),
+                                            _p(bin_perm) if bin_perm is not None else c_vp(0), _p(_req(vh_matrix_t, "vh_matrix_t")), c_i64(T),
+                                            _p(out), _stream()), "mcr_view_harmonics_rows")
+    return out
+
+
+def field_finish(rows, occ, T, proxy_proba, sel, n_oof, proxy_points, X_tail, occ_tail):
+    with torch.cuda.device(proxy_points.device):
+        check(lib().mcr_field_finish(_p(rows) if T else c_vp(0), _p(occ) if T else c_vp(0), c_i64(T), _p(proxy_proba), _p(sel.oof_order),
+                                     c_i64(n_oof), _p(proxy_points), _p(X_tail) if n_oof else c_vp(0), _p(occ_tail) if n_oof else c_vp(0),
+                                     _stream()), "mcr_field_finish")
+
+
+def camera_boxes(sampled, n_unique, M_view, cam_world, inv_diag):
+    """sampled [K,S,4], n_unique int32 [K], M_view [K,4,4], cam_world [K,3] -> (centre [K,3] of each camera's prediction box in view space,
+    camera centres [K,3] in the normalised prediction space)   (mcr_camera_boxes)."""
+    sampled = _req(sampled, "sampled")
+    K, S = sampled.shape[0], sampled.shape[1]
+    out = torch.empty((2, K, 3), dtype=torch.float32, device=sampled.device)
+    with torch.cuda.device(sampled.device):
+        check(lib().mcr_camera_boxes(_p(sampled), _p(_req(n_unique, "n_unique", torch.int32)), c_i64(K), c_int(S), _p(_req(M_view, "M_view")),
+                                     _p(_req(cam_world, "cam_world")), c_f32(float(inv_diag)), _p(out[0]), _p(out[1]), _stream()),
+              "mcr_camera_boxes")
+    return out[0], out[1]
+
+
+def macarons_gain_indexed(vis_unique, world_unique, inverse, n_unique, cam_world, volume, distance_th, smooth=False):
+    """gains [K] from the per-UNIQUE-point visibility gains vis_unique [K,S] and the inverse map of the Monte-Carlo samples
+    (mcr_macarons_gain_indexed)."""
+    vis_unique, world_unique = _req(vis_unique, "vis_unique"), _req(world_unique, "world_unique")
+    K, S = vis_unique.shape
+    gains = torch.empty(K, dtype=torch.float32, device=vis_unique.device)
+    with torch.cuda.device(vis_unique.device):
+        check(lib().mcr_macarons_gain_indexed(_p(vis_unique), _p(world_unique), _p(_req(inverse, "inverse", torch.int64)),
+                                              _p(_req(n_unique, "n_unique", torch.int32)), _p(_req(cam_world, "cam_world")),
+                                              _p(_req(volume, "volume")), c_f32(float(distance_th)), c_int(int(bool(smooth))), c_i64(K), c_int(S),
+                                              _p(gains), _stream()), "mcr_macarons_gain_indexed")
+    return gains
+
+
+_PHILOX_MAPPING = 1          # rocRAND's (0, 1] map (what torch.rand uses on ROCm); tests/test_glue_gpu.py pins it against torch.rand
+
+
+def uniform_rows(K, S, device, generator=None):
+    """[K, S] uniforms = what K consecutive torch.rand(S, 1, device=device) calls return (upstream's per-camera sampling draws,
+    scone_utils.py:1052), from ONE launch; the device generator advances exactly as those K calls would advance it."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    gen = generator if generator is not None else torch.cuda.default_generators[idx]
+    if S > 65536:                                    # beyond one element per thread torch's kernel changes its indexing: the literal draws
+        return torch.cat([torch.rand(S, 1, device=device, generator=generator) for _ in range(K)], 1).t().contiguous()
+    seed, off = gen.initial_seed(), gen.get_offset()
+    out = torch.empty((K, S), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        check(lib().mcr_philox_uniform_rows(ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(off), c_i64(K), c_int(S),
+                                            c_int(_PHILOX_MAPPING), _p(out), _stream()), "mcr_philox_uniform_rows")
+    gen.set_offset(off + 4 * K)
+    return out

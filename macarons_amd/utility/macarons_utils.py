@@ -153,9 +153,7 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     pass (cell bookkeeping on the host, as upstream), fill_cells' one, and -- range_guard=True -- the range flag of the fp16-split
     path, read once at the end (range_guard=False: the caller checks macarons.occupancy.range_flag() itself)."""
     from .. import dist as mdist
-    import torch.distributed as tdist
-    world = tdist.get_world_size(group) if (tdist.is_available() and tdist.is_initialized()) else 1
-    rank = tdist.get_rank(group) if world > 1 else 0
+    world, rank = mdist.group_world_rank(group)            # group=None: local, whatever process groups exist
     H, W = params.image_height, params.image_width
     depth2 = depth.reshape(H, W).contiguous().float()
     dmask2 = depth_mask.reshape(H, W) if depth_mask is not None else None
@@ -413,9 +411,7 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
     drawn on the device (SconeOcc.ragged_index_arrays_device) instead of ~3 torch.randperm calls per job on the host."""
     from . import scone_utils as su
     from .. import dist as mdist
-    import torch.distributed as tdist
-    world = tdist.get_world_size(group) if (tdist.is_available() and tdist.is_initialized()) else 1
-    rank = tdist.get_rank(group) if world > 1 else 0
+    world, rank = mdist.group_world_rank(group)            # group=None: local, whatever process groups exist
     ps, ss = proxy_scene, surface_scene
     gl, gw, gh = ps.grid_l, ps.grid_w, ps.grid_h
     n_cells = gl * gw * gh

@@ -191,9 +191,9 @@ class Scene:
             F_all = torch.cat([c.cell_features for c in cells if c.cell_pts.shape[0] > 0] + [torch.zeros(0, self.feature_dim, device=dev)])
             src_f = torch.cat((F_all, features[order][order2[:n_adm]].to(F_all.dtype).view(-1, self.feature_dim)))
         adm_off = np.concatenate(([0], np.cumsum(host[1])))
-        import torch.distributed as tdist
-        world = tdist.get_world_size(group) if (tdist.is_available() and tdist.is_initialized()) else 1
-        draws_here = world == 1 or tdist.get_rank(group) == 0
+        from .. import dist as mdist
+        world, rank_ = mdist.group_world_rank(group)        # group=None: local, whatever process groups exist
+        draws_here = rank_ == 0
         gidx, touched = [], []
         device_perm = perm_source == "device"
         seg_len, seg_b0, seg_a0 = [], [], []
@@ -232,7 +232,6 @@ class Scene:
         else:
             g = torch.empty(sum(n for _, n in touched), dtype=torch.int64, device=dev)
         if world > 1:
-            from .. import dist as mdist
             mdist.broadcast(g, 0, group)
         new_pts = src[g]
         new_fts = src_f[g] if with_fts else None

@@ -114,11 +114,11 @@ def main():
     occ_f = SconeOcc()
     occ_f.load_state_dict(occ.state_dict())
     occ_f = occ_f.to(dev).eval()
-    r = nbv_step(occ_f, *tiny[1:], occ_perms=P(g1), samples=T(g1["samples"]))
+    r = nbv_step(occ_f, *tiny[1:], occ_perms=P(g1), samples=T(g1["samples"]), group=dist.group.WORLD)
     expect(torch.equal(r["occ"], s_tiny["occ"]) and torch.equal(r["max_gain"], s_tiny["max_gain"]) and int(r["nbv_idx"]) == 0, "B0 fresh module")
 
     # A: query- and camera-sharded single-cloud step (config-2 shape) == the 1-rank step, bit for bit; == the reference golden at 1e-4
-    r = nbv_step(*a2, occ_perms=P(g2), samples=T(g2["samples"]))
+    r = nbv_step(*a2, occ_perms=P(g2), samples=T(g2["samples"]), group=dist.group.WORLD)
     c0, c1 = r["cam_range"]
     expect((c0, c1) == ((0, 50) if rank == 0 else (50, 100)), "A cam_range")
     expect(torch.equal(r["occ"], s_full["occ"]), "A occ")
@@ -126,17 +126,18 @@ def main():
     expect(torch.equal(r["max_gain"], s_full["max_gain"]) and int(r["nbv_idx"]) == int(s_full["nbv_idx"]) == int(g2["nbv_idx"]), "A decision")
     expect(float(np.abs(r["gains"].cpu().numpy() - g2["gains"][c0:c1]).max()) < 1e-4 * float(np.abs(g2["gains"]).max()), "A golden")
     # B: fewer queries and cameras than ranks: rank 1 holds empty shards but joins every collective
-    r = nbv_step(*tiny, occ_perms=P(g1), samples=T(g1["samples"]))
+    r = nbv_step(*tiny, occ_perms=P(g1), samples=T(g1["samples"]), group=dist.group.WORLD)
     expect(r["cam_range"] == ((0, 1) if rank == 0 else (1, 1)), "B cam_range")
     expect(torch.equal(r["occ"], s_tiny["occ"]) and torch.equal(r["max_gain"], s_tiny["max_gain"]) and int(r["nbv_idx"]) == 0, "B decision")
     # C: scene batch, B = 3 >= world: clouds sharded (2 + 1), one record all-gather
-    r = nbv_step_batch(*ab, occ_perms=permb, samples=ub)
+    r = nbv_step_batch(*ab, occ_perms=permb, samples=ub, group=dist.group.WORLD)
     b0, b1 = r["cloud_range"]
     expect((b0, b1) == ((0, 2) if rank == 0 else (2, 3)) and r["cam_range"] == (0, camb.shape[0]), "C ranges")
     expect(torch.equal(r["occ"], s_b3["occ"][b0:b1]) and torch.equal(r["gains"], s_b3["gains"][b0:b1]), "C own clouds")
     expect(torch.equal(r["max_gain"], s_b3["max_gain"]) and torch.equal(r["nbv_idx"], s_b3["nbv_idx"]), "C decisions")
     # D: scene batch smaller than the world (B = 1 < 2): replicated cloud, queries and cameras sharded
-    r = nbv_step_batch(occ, vis, pcb[:1], Xb[:1], Xvb[:1], camb, grid, occ_perms=[p[:1] for p in permb], samples=ub[:1])
+    r = nbv_step_batch(occ, vis, pcb[:1], Xb[:1], Xvb[:1], camb, grid, occ_perms=[p[:1] for p in permb], samples=ub[:1],
+                       group=dist.group.WORLD)
     c0, c1 = r["cam_range"]
     expect(r["cloud_range"] == (0, 1) and (c0, c1) == ((0, 10) if rank == 0 else (10, 20)), "D ranges")
     expect(torch.equal(r["occ"], s_b1["occ"]) and torch.equal(r["gains"], s_b1["gains"][:, c0:c1]), "D shards")
@@ -170,10 +171,21 @@ def main():
         expect(torch.equal(r2["gains"], r1["gains"][k0:k1]), f"G{c} gains")
         expect(int(r2["next_idx"]) == int(r1["next_idx"]) == int(gmac[f"next_idx_{c}"]) and float(r2["max_gain"]) == float(r1["max_gain"]), f"G{c} decision")
         expect(all(torch.equal(s1[k], s2[k]) for k in s1), f"G{c} state")
+    # H: group=None under an initialised process group is LOCAL (a data-parallel job whose ranks own different scenes must
+    # not meet an implicit collective): the two ranks run DIFFERENT steps at the same time, each gets its own 1-rank answer
+    if rank == 0:
+        r = nbv_step(*a2, occ_perms=P(g2), samples=T(g2["samples"]))
+        expect(r["cam_range"] == (0, 100) and torch.equal(r["gains"], s_full["gains"]) and int(r["nbv_idx"]) == int(s_full["nbv_idx"]), "H rank 0")
+    else:
+        r = nbv_step(*tiny, occ_perms=P(g1), samples=T(g1["samples"]))
+        expect(torch.equal(r["occ"], s_tiny["occ"]) and torch.equal(r["max_gain"], s_tiny["max_gain"]), "H rank 1")
+        macl, _ = macarons_decisions(dev)                                # a whole local MACARONS decision on rank 1 only
+        expect(all(int(macl[c][0]["next_idx"]) == int(mac1[c][0]["next_idx"]) and torch.equal(macl[c][0]["gains"], mac1[c][0]["gains"])
+                   for c in range(2)), "H local MACARONS decision")
     # E: hidden draws (nothing pinned): rank 0's reach rank 1 -> identical decisions on both ranks, single-cloud and batch
     torch.manual_seed(100 + rank)                                        # the ranks' own generators disagree on purpose
-    r1 = nbv_step(*a2)
-    r2 = nbv_step_batch(*ab)
+    r1 = nbv_step(*a2, group=dist.group.WORLD)
+    r2 = nbv_step_batch(*ab, group=dist.group.WORLD)
     mine = torch.cat((r1["max_gain"].view(-1), r1["nbv_idx"].view(-1).float(), r2["max_gain"], r2["nbv_idx"].float(),
                       r1["occ"].sum().view(1)))
     mine = mine if backend == "nccl" else mine.cpu()

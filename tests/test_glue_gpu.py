@@ -375,3 +375,87 @@ def test_scene_grid_kernels_match_the_torch_expressions(dev):
             k2 = ops.admit_keys(d, key_s, counts, 0.05, n_min, n_cells)
             adm = (d > 0.05) & (key_s < n_cells) & (counts[key_s.long()] > n_min)
             assert torch.equal(k2.long(), torch.where(adm, key_s.long(), torch.full_like(key_s.long(), n_cells)))
+
+
+# ---- the fused scene-side kernels of one MACARONS decision (scene.hip) ------------------------------------------------------------------
+@pytest.mark.parametrize("N,nk,runs", [(1, 3, False), (63, 1, False), (2048, 72, False), (2049, 72, True), (100_000, 72, False),
+                                       (230_000, 72, True), (50_000, 1023, False), (4097, 300, True)])
+def test_group_by_key_is_the_stable_sort(dev, N, nk, runs):
+    """mcr_group_by_key == torch.sort(key, stable=True).indices, torch.bincount and its exclusive prefix sums: random keys, long runs of
+    one key (cell ids of points in cloud order), keys outside 0 .. nk (counted as nk), sizes around the 2048-row tile."""
+    from macarons_amd import ops
+    g = torch.Generator().manual_seed(N + nk)
+    key = torch.randint(0, nk + 1, (N,), generator=g, dtype=torch.int32)
+    if runs:
+        key = torch.repeat_interleave(torch.randint(0, nk + 1, (N // 37 + 1,), generator=g, dtype=torch.int32), 37)[:N].contiguous()
+        key[::101] = -5                                      # not a key: the last group
+        key[7::203] = nk + 9
+    order, counts, offsets = ops.group_by_key(key.to(dev), nk)
+    eff = torch.where((key < 0) | (key > nk), torch.full_like(key, nk), key).long()
+    ref = torch.sort(eff, stable=True).indices
+    cnt = torch.bincount(eff, minlength=nk + 1)
+    assert torch.equal(order.cpu().long(), ref)
+    assert torch.equal(counts.cpu(), cnt)
+    assert torch.equal(offsets.cpu(), torch.cat((torch.zeros(1, dtype=torch.int64), torch.cumsum(cnt, 0))))
+
+
+def test_uniform_rows_are_the_per_camera_torch_rand_draws(dev):
+    """ops.uniform_rows(K, S) == K consecutive torch.rand(S, 1, device=...) calls, bit for bit, and leaves the device generator where those
+    calls would leave it (upstream draws the sampling uniforms camera by camera, scone_utils.py:1052): pins torch's Philox indexing, the
+    offset step per call and rocRAND's uniform map -- if a torch upgrade changes any of them this fails, it does not drift."""
+    from macarons_amd import ops
+    for seed, K, S, warm in ((1234, 30, 2048, 0), (7, 1, 2048, 3), (99, 5, 16, 1), (3, 4, 5000, 2)):
+        torch.manual_seed(seed)
+        for _ in range(warm):
+            torch.rand(17, device=dev)                                     # the generator is not at offset 0
+        want = torch.cat([torch.rand(S, 1, device=dev) for _ in range(K)], 1).t().contiguous()
+        after_want = torch.rand(8, device=dev)
+        torch.manual_seed(seed)
+        for _ in range(warm):
+            torch.rand(17, device=dev)
+        got = ops.uniform_rows(K, S, dev)
+        after_got = torch.rand(8, device=dev)
+        assert torch.equal(got, want), (seed, K, S, float((got - want).abs().max()))
+        assert torch.equal(after_got, after_want)
+
+
+def test_view_harmonics_rows_and_camera_boxes_and_indexed_gain(dev):
+    from macarons_amd import ops
+    from macarons_amd.utility import scone_utils as su
+    g = torch.Generator().manual_seed(11)
+    # view harmonics of selected rows with a bin permutation == gather_columns + the [98] x [98, 64] product
+    vs = (torch.rand(5000, 98, generator=g) < 0.06).float().to(dev)
+    rows = torch.randperm(5000, generator=g)[:1777].to(torch.int32).to(dev)
+    perm = torch.randperm(98, generator=g)
+    base, h_polar, h_azim = su.get_all_harmonics_under_degree(8, 7, 14, dev)
+    m = su._view_harmonics_matrix(base, h_polar, 7, 14)                     # [64, 98]
+    got = ops.view_harmonics_rows(vs, rows, perm.to(torch.int32).to(dev), m.t().contiguous())
+    want = (vs[rows.long()][:, perm.to(dev)].double() @ m.t().double()).float()
+    assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 2e-6
+    assert torch.equal(ops.view_harmonics_rows(vs, None, None, m.t().contiguous())[rows.long()],
+                       ops.view_harmonics_rows(vs, rows, None, m.t().contiguous()))
+    # prediction boxes (macarons_utils.py:1631-1660)
+    K, S = 7, 300
+    res = torch.randn(K, S, 4, generator=g).to(dev)
+    nu = torch.tensor([300, 1, 0, 17, 299, 64, 65], dtype=torch.int32, device=dev)
+    Mv = torch.randn(K, 4, 4, generator=g).to(dev)
+    cam = torch.randn(K, 3, generator=g).to(dev)
+    center, cam_v = ops.camera_boxes(res, nu, Mv, cam, 0.25)
+    for k in range(K):
+        n = int(nu[k])
+        cw = (res[k, :n, :3].amax(0) + res[k, :n, :3].amin(0)) / 2. if n else torch.zeros(3, device=dev)
+        c = (torch.cat((cw, torch.ones(1, device=dev))).double() @ Mv[k].double())[:3]
+        assert torch.allclose(center[k].double(), c, rtol=1e-5, atol=1e-6), k
+        cv = ((torch.cat((cam[k], torch.ones(1, device=dev))).double() @ Mv[k].double())[:3] - c) * 0.25
+        assert torch.allclose(cam_v[k].double(), cv, rtol=1e-5, atol=1e-5), k
+    # gains through the inverse map == gather the Monte-Carlo duplicates, then mcr_macarons_gain  (bit for bit: same sum, same order)
+    vis_u = torch.rand(K, S, generator=g).to(dev)
+    inv = torch.stack([torch.randint(0, max(int(n), 1), (S,), generator=g) for n in nu.tolist()]).to(dev)
+    vol = (torch.rand(K, generator=g) * 100).to(dev)
+    for th, smooth in ((1.3, False), (0.9, True)):
+        got = ops.macarons_gain_indexed(vis_u, res, inv, nu, cam, vol, th, smooth)
+        vis_mc = torch.gather(vis_u, 1, inv).contiguous()
+        world = torch.gather(res, 1, inv[..., None].expand(-1, -1, 4)).contiguous()
+        want = ops.macarons_gain_(vis_mc, world, cam, vol, th, smooth)
+        want = torch.where(nu > 0, want, torch.zeros_like(want))
+        assert torch.equal(got, want)

@@ -191,10 +191,13 @@ def test_sharded_step_path_through_rccl_single_rank(dev, monkeypatch):
     monkeypatch.setenv("MCR_FORCE_DIST_PATH", "1")
     try:
         torch.manual_seed(int(g["seed"]))
-        b = nbv_step(*args, samples=T(g["samples"], dev))
+        b = nbv_step(*args, samples=T(g["samples"], dev), group=dist.group.WORLD)
         assert torch.equal(a["occ"], b["occ"]) and torch.equal(a["gains"], b["gains"])
         assert int(a["nbv_idx"]) == int(b["nbv_idx"]) == int(g["nbv_idx"]) and float(a["max_gain"]) == float(b["max_gain"])
-        c = nbv_step(*args)                                  # uniforms drawn + broadcast inside
+        c = nbv_step(*args, group=dist.group.WORLD)          # uniforms drawn + broadcast inside
+        d = nbv_step(*args, samples=T(g["samples"], dev))    # group=None: local even with a process group up (no exchange path)
+        assert "cam_range" not in d or d["cam_range"] == (0, 20)
+        assert torch.equal(a["gains"], d["gains"])
         assert torch.isfinite(c["gains"]).all() and 0 <= int(c["nbv_idx"]) < 20
     finally:
         dist.destroy_process_group()
