@@ -402,7 +402,7 @@ def measure_macarons_step(dev, rank=0, world=1, perm_sources=("host", "device"))
         t0 = time.perf_counter()
         with torch.no_grad():
             r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, depth, dmask, recs, ne, dev, group=group)
-        nxt = int(r["next_idx"])
+        nxt = r["host"]["next_idx"] if "host" in r else int(r["next_idx"])     # (the decision rides on the range-flag read-back)
         torch.cuda.synchronize()
         dt = max_over_ranks(time.perf_counter() - t0, dev, dist)
         if it >= 2:
@@ -447,7 +447,7 @@ def measure_macarons_step(dev, rank=0, world=1, perm_sources=("host", "device"))
         t0 = time.perf_counter()
         with torch.no_grad():
             r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, depth, dmask, recs, ne, dev, group=group, perm_source="device")
-        int(r["next_idx"])
+        r["host"]["next_idx"] if "host" in r else int(r["next_idx"])
         torch.cuda.synchronize()
         dt = max_over_ranks(time.perf_counter() - t0, dev, dist)
         if it >= 2:

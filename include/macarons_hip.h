@@ -405,6 +405,12 @@ int mcr_scene_fill_begin(const float* pts, int64_t N, const unsigned char* valid
 int mcr_scene_fill_gather(const int64_t* g, int64_t n_new, const float* store_pts, const float* store_fts, int64_t n_store, int F,
                           const float* pts, const float* features, const int* order, const int* order2, float* new_pts, float* new_fts,
                           void* stream);
+/* The same with the row map evaluated on the device: pm = the touched cells' torch.randperm prefixes back to back (int32), tables =
+ * new_off | b_off | adm_off | pm_off | touched, int64, n_cells + 1 entries each (offsets of the new store, of the old store, of the
+ * admitted candidates, of pm; touched[c] != 0: cell c drew a permutation, else it keeps its rows in order). */
+int mcr_scene_fill_gather_perm(const int* pm, const int64_t* tables, int n_cells, int64_t n_new, const float* store_pts,
+                               const float* store_fts, int64_t n_store, int F, const float* pts, const float* features, const int* order,
+                               const int* order2, float* new_pts, float* new_fts, void* stream);
 size_t mcr_field_select_workspace_bytes(int64_t P, int n_cells);
 int mcr_field_select(const float* proxy_points, int64_t P, const float* supervision_occ, const float* out_of_field, float* proxy_proba,
                      const float* store_fts, int F, int64_t n_store, const int64_t* store_off, const float* pend_features,

@@ -333,6 +333,42 @@ __global__ void fill_gather_kernel(const long long* __restrict__ g, long long n_
         for (int f = 0; f < F; ++f) new_fts[(long long)F * r + f] = sf ? sf[f] : 0.f;
 }
 
+// the same with the row map evaluated here: tab = new_off | b_off | adm_off | pm_off | touched (int64, n_cells + 1 entries each);
+// new row r of cell c is row pm[pm_off[c] + local] of the cell's [stored | admitted] rows when the cell was touched (its
+// torch.randperm prefix), else its local-th stored row
+__global__ void fill_gather_pm_kernel(const int* __restrict__ pm, const long long* __restrict__ tab, int n_cells, long long n_new,
+                                      const float* __restrict__ store_pts, const float* __restrict__ store_fts, long long n_store, int F,
+                                      const float* __restrict__ pts, const float* __restrict__ features, const int* __restrict__ order,
+                                      const int* __restrict__ order2, float* __restrict__ new_pts, float* __restrict__ new_fts) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_new) return;
+    const int n1 = n_cells + 1;
+    const long long *new_off = tab, *b_off = tab + n1, *adm_off = tab + 2 * n1, *pm_off = tab + 3 * n1, *touched = tab + 4 * n1;
+    int lo = 0, hi = n_cells;                              // last cell with new_off[c] <= r (empty cells share an offset: take the last)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (new_off[mid] <= r) lo = mid; else hi = mid;
+    }
+    const int c = lo;
+    const long long local = r - new_off[c];
+    const long long val = touched[c] ? (long long)pm[pm_off[c] + local] : local;
+    const long long b_len = b_off[c + 1] - b_off[c];
+    const float* sp;
+    const float* sf;
+    if (val < b_len) {
+        const long long s_ = b_off[c] + val;
+        sp = store_pts + 3 * s_;
+        sf = store_fts ? store_fts + (long long)F * s_ : nullptr;
+    } else {
+        const long long src = order[order2[adm_off[c] + (val - b_len)]];
+        sp = pts + 3 * src;
+        sf = features ? features + (long long)F * src : nullptr;
+    }
+    new_pts[3 * r] = sp[0]; new_pts[3 * r + 1] = sp[1]; new_pts[3 * r + 2] = sp[2];
+    if (new_fts)
+        for (int f = 0; f < F; ++f) new_fts[(long long)F * r + f] = sf ? sf[f] : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Occupancy-field pass (compute_scene_occupancy_probability_field, macarons_utils.py:1395-1540): selection, grouping, job building.
 __device__ __forceinline__ int cell_of_point(const float* __restrict__ p3, const float* __restrict__ gc, int gl, int gw, int gh) {
@@ -669,6 +705,18 @@ int mcr_scene_fill_gather(const int64_t* g, int64_t n_new, const float* store_pt
     hipLaunchKernelGGL(fill_gather_kernel, dim3((unsigned)cdiv(n_new, 256)), dim3(256), 0, (hipStream_t)stream, (const long long*)g,
                        (long long)n_new, store_pts, store_fts, (long long)n_store, F, pts, features, order, order2, new_pts, new_fts);
     MCR_LAUNCH_CHECK("fill_gather_kernel");
+    return 0;
+}
+
+int mcr_scene_fill_gather_perm(const int* pm, const int64_t* tables, int n_cells, int64_t n_new, const float* store_pts,
+                               const float* store_fts, int64_t n_store, int F, const float* pts, const float* features, const int* order,
+                               const int* order2, float* new_pts, float* new_fts, void* stream) {
+    MCR_REQUIRE(tables && new_pts && n_new > 0 && n_store >= 0 && F >= 0 && n_cells > 0, "mcr_scene_fill_gather_perm: bad arguments");
+    MCR_REQUIRE(n_store == 0 || store_pts, "mcr_scene_fill_gather_perm: the old store is missing");
+    MCR_REQUIRE(!new_fts || F > 0, "mcr_scene_fill_gather_perm: features need F > 0");
+    hipLaunchKernelGGL(fill_gather_pm_kernel, dim3((unsigned)cdiv(n_new, 256)), dim3(256), 0, (hipStream_t)stream, pm, (const long long*)tables,
+                       n_cells, (long long)n_new, store_pts, store_fts, (long long)n_store, F, pts, features, order, order2, new_pts, new_fts);
+    MCR_LAUNCH_CHECK("fill_gather_pm_kernel");
     return 0;
 }
 

@@ -9,6 +9,8 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
+#include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "macarons_hip.h"
@@ -172,9 +174,75 @@ at::Tensor scone_occ_forward(const at::Tensor& pcg_, c10::List<at::Tensor> pc_sc
     return out;
 }
 
+// ---- hidden draws of the reference, batched (host side; no device work) -----------------------------------------------------------
+// The reference draws torch.randperm on the CPU default generator deep inside its loops: once per touched grid cell in Cell.fill
+// (macarons_utils.py:2573) and three times per SconeOcc.forward (SconeOcc.py:269, :311).  A MACARONS decision makes ~200 of them;
+// from Python every one is a dispatcher round trip plus index bookkeeping in numpy.  These two operators make the SAME at::randperm
+// calls in the SAME order on the SAME generator -- the stream of draws is the reference's, bit for bit -- and return the index arrays
+// the launches need, ready to upload.
+
+// randperm(n[i])[:keep[i]] for every i, concatenated.
+at::Tensor randperm_prefixes(c10::IntArrayRef n, c10::IntArrayRef keep) {
+    TORCH_CHECK(n.size() == keep.size(), "randperm_prefixes: one prefix length per draw");
+    int64_t total = 0;
+    for (size_t i = 0; i < n.size(); ++i) total += std::min<int64_t>(n[i], keep[i]);
+    at::Tensor out = at::empty({total}, at::kLong);
+    int64_t* o = out.data_ptr<int64_t>();
+    for (size_t i = 0; i < n.size(); ++i) {
+        const at::Tensor p = at::randperm(n[i], at::TensorOptions().dtype(at::kLong));
+        const int64_t k = std::min<int64_t>(n[i], keep[i]);
+        std::memcpy(o, p.data_ptr<int64_t>(), (size_t)k * sizeof(int64_t));
+        o += k;
+    }
+    return out;
+}
+
+// The three draws of J SconeOcc.forward calls in job order -- randperm(m0)[:Lg], randperm(m0)[:m1], randperm(m1)[:m2] per job
+// (m0 = the job's cloud, m1 = m0 // ds, m2 = m1 // ds) -- as the index arrays of SconeOcc.forward_ragged over the concatenated clouds:
+//   [ g_idx (J*Lg: row of `pc` per global-transformer token, padded with the cloud's first row) | idx1 (rows of pc of scale 1) |
+//     idx2 (rows of scale 1's cloud of scale 2) | off1 (J+1) | off2 (J+1) | g_len (J) ]     one int64 tensor.
+at::Tensor scone_occ_draws(c10::IntArrayRef m0, c10::IntArrayRef m1, c10::IntArrayRef m2, int64_t Lg) {
+    const int64_t J = (int64_t)m0.size();
+    TORCH_CHECK((int64_t)m1.size() == J && (int64_t)m2.size() == J && Lg > 0, "scone_occ_draws: one (m0, m1, m2) per job");
+    int64_t n1 = 0, n2 = 0;
+    for (int64_t j = 0; j < J; ++j) {
+        TORCH_CHECK(m0[j] > 0 && m1[j] <= m0[j] && m2[j] <= m1[j] && m1[j] >= 0 && m2[j] >= 0, "scone_occ_draws: bad sizes");
+        n1 += m1[j]; n2 += m2[j];
+    }
+    at::Tensor out = at::empty({J * Lg + n1 + n2 + 2 * (J + 1) + J}, at::kLong);
+    int64_t* g = out.data_ptr<int64_t>();
+    int64_t* i1 = g + J * Lg;
+    int64_t* i2 = i1 + n1;
+    int64_t* off1 = i2 + n2;
+    int64_t* off2 = off1 + J + 1;
+    int64_t* glen = off2 + J + 1;
+    int64_t c0 = 0, a1 = 0, a2 = 0;
+    off1[0] = off2[0] = 0;
+    const at::TensorOptions opt = at::TensorOptions().dtype(at::kLong);
+    for (int64_t j = 0; j < J; ++j) {
+        const at::Tensor p0 = at::randperm(m0[j], opt);                  // SconeOcc.py:269
+        const int64_t n0 = std::min<int64_t>(m0[j], Lg);
+        const int64_t* q = p0.data_ptr<int64_t>();
+        for (int64_t t = 0; t < n0; ++t) g[j * Lg + t] = c0 + q[t];
+        for (int64_t t = n0; t < Lg; ++t) g[j * Lg + t] = c0;
+        glen[j] = n0;
+        const at::Tensor p1 = at::randperm(m0[j], opt);                  // :311, scale 0 -> 1
+        q = p1.data_ptr<int64_t>();
+        for (int64_t t = 0; t < m1[j]; ++t) i1[a1 + t] = c0 + q[t];
+        const at::Tensor p2 = at::randperm(m1[j], opt);                  // :311, scale 1 -> 2 (rows of scale 1's cloud)
+        q = p2.data_ptr<int64_t>();
+        for (int64_t t = 0; t < m2[j]; ++t) i2[a2 + t] = a1 + q[t];
+        c0 += m0[j]; a1 += m1[j]; a2 += m2[j];
+        off1[j + 1] = a1; off2[j + 1] = a2;
+    }
+    return out;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(macarons, m) {
+    m.def("randperm_prefixes(int[] n, int[] keep) -> Tensor", &randperm_prefixes);
+    m.def("scone_occ_draws(int[] m0, int[] m1, int[] m2, int Lg) -> Tensor", &scone_occ_draws);
     m.def("sh_coverage_gain(Tensor pts, Tensor harmonics, Tensor cams, bool use_sigmoid) -> Tensor");
     m.def("sh_visibilities(Tensor pts, Tensor harmonics, Tensor cams, bool use_sigmoid) -> Tensor");
     m.def("knn_gather_offset(Tensor x, Tensor pc, int k) -> (Tensor, Tensor, Tensor)");

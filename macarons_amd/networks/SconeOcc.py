@@ -242,14 +242,22 @@ class SconeOcc(nn.Module):
         assert idx1.numel() == T1 and idx2.numel() == T2
         return {"g_idx": g_idx.reshape(-1), "g_len": d_n0.to(torch.int32), "idx1": idx1, "idx2": idx2, "off1": d_o1, "off2": d_o2}
 
-    def forward_ragged(self, pc, cloud_sizes, x, view_harmonics, query_sizes, perms=None, index_arrays=None, perm_source="host"):
+    def forward_ragged(self, pc, cloud_sizes, x, view_harmonics, query_sizes, perms=None, index_arrays=None, perm_source="host", out=None):
         """J forward() calls of different sizes as ONE launch sequence (extension; the reference calls forward once per grid cell and
         chunk from a Python loop, macarons_utils.py:1395-1540).  Job j: surface cloud = the next cloud_sizes[j] rows of pc [sum M, 3],
         queries = the next query_sizes[j] rows of x [T,3] / view_harmonics [T,64] (host lists).  perms: per job the three index
         tensors draw_perms(cloud_sizes[j]) returns; None = drawn here in job order on the CPU generator, exactly the draws J
         sequential forward() calls would make -- or, perm_source="device" (opt-in), on the device by ragged_index_arrays_device();
         index_arrays: what that function returns (a caller that repeats a pass, or hands rank 0's draws to every rank).
-        -> [T,1].  Inference only (no autograd graph)."""
+        -> [T,1] (`out`: written there).  Inference only (no autograd graph).  = forward_ragged_begin + forward_ragged_finish."""
+        h = self.forward_ragged_begin(pc, cloud_sizes, x, view_harmonics, query_sizes)
+        return self.forward_ragged_finish(h, perms=perms, index_arrays=index_arrays, perm_source=perm_source, out=out)
+
+    def forward_ragged_begin(self, pc, cloud_sizes, x, view_harmonics, query_sizes, row_job=None, arena="scone_occ_ragged"):
+        """First half of forward_ragged: what needs no hidden draw is uploaded and LAUNCHED (phase 1: the x embedding, the scale-0 search
+        and local transformer on the whole clouds), so that the GPU works while the host makes the ~3 J torch.randperm draws
+        (forward_ragged_finish).  row_job (int32 device [T], optional): the job of every query row when the caller already holds it.
+        arena: tag of the scratch arena that keeps phase 1's results until the finish (several begun passes need one each)."""
         if not self._is_default_arch() or not self.fused_local:
             raise NotImplementedError("forward_ragged implements the default architecture on the fused local-transformer path")
         dev = x.device
@@ -258,18 +266,21 @@ class SconeOcc(nn.Module):
         Lg = self.seq_len
         pc = pc.contiguous()
         variant = L.mcr_get_local_pct_variant()
-        # ---- what needs no draw, uploaded and LAUNCHED first (phase 1: scale 0 = the whole clouds, x embedding): the GPU works on it
-        # while the host makes the ~3 J torch.randperm draws below (2.5 ms of a MACARONS decision used to pass with the GPU idle here)
         off0 = np.concatenate(([0], np.cumsum(cloud_sizes))).astype(np.int64)
         rows = int(L.mcr_knn_rows_per_block())
-        blocks, row_job, r0 = [], np.empty(int(sum(query_sizes)), np.int32), 0
-        for j, q in enumerate(query_sizes):
-            row_job[r0:r0 + q] = j
-            for b0 in range(0, q, rows):
-                blocks.append((j, r0 + b0, min(rows, q - b0), 0))
-            r0 += q
-        early = ops.h2d(np.concatenate([off0, row_job.astype(np.int64), np.asarray(blocks, np.int64).reshape(-1)]), torch.int64, dev)
-        d_off0, d_row_job, d_blocks = early[:J + 1], early[J + 1:J + 1 + len(row_job)].to(torch.int32), early[J + 1 + len(row_job):].to(torch.int32).view(-1, 4)
+        qs = np.asarray(query_sizes, np.int64)
+        q0 = np.concatenate(([0], np.cumsum(qs)))
+        nb = -(-qs // rows)                                              # query blocks per job
+        bj = np.repeat(np.arange(J, dtype=np.int64), nb)                 # job of every block
+        b_in = np.arange(int(nb.sum()), dtype=np.int64) - np.repeat(np.cumsum(nb) - nb, nb)     # block index inside its job
+        blocks = np.stack((bj, q0[bj] + b_in * rows, np.minimum(rows, qs[bj] - b_in * rows), np.zeros_like(bj)), 1)
+        parts = [off0, blocks.reshape(-1)]
+        if row_job is None:
+            parts.append(np.repeat(np.arange(J, dtype=np.int64), qs))
+        early = ops.h2d(np.concatenate(parts), torch.int64, dev)
+        d_off0 = early[:J + 1]
+        d_blocks = early[J + 1:J + 1 + blocks.size].to(torch.int32).view(-1, 4)
+        d_row_job = early[J + 1 + blocks.size:].to(torch.int32) if row_job is None else row_job
         state = {}
 
         def caches(v):
@@ -279,13 +290,23 @@ class SconeOcc(nn.Module):
             return state[v]
 
         def phase1(v):
-            blobs, head, table = caches(v)
+            blobs, head, table = state[v] if v in state else caches(v)
             ops.scone_occ_forward_ragged(None, None, [pc], [d_off0], x, view_harmonics, d_row_job, d_blocks, table, blobs, head, None,
-                                         phase=1, Lg=Lg)
+                                         phase=1, Lg=Lg, arena=arena)
 
         with torch.no_grad():
             phase1(variant)
-        epoch1 = ops.scone_occ_epoch(dev, "scone_occ_ragged")
+        return {"pc": pc, "x": x, "vh": view_harmonics, "J": J, "Lg": Lg, "variant": variant, "off0": off0, "d_off0": d_off0,
+                "d_row_job": d_row_job, "d_blocks": d_blocks, "state": state, "caches": caches, "phase1": phase1,
+                "cloud_sizes": cloud_sizes, "arena": arena, "epoch1": ops.scone_occ_epoch(dev, arena)}
+
+    def forward_ragged_finish(self, h, perms=None, index_arrays=None, perm_source="host", out=None):
+        """Second half of forward_ragged: the hidden draws (unless given), the down-sampled clouds, phase 2."""
+        L = _lib.lib()
+        pc, x, view_harmonics, J, Lg, variant, off0 = h["pc"], h["x"], h["vh"], h["J"], h["Lg"], h["variant"], h["off0"]
+        cloud_sizes, d_off0, d_row_job, d_blocks, state, caches, phase1 = (h["cloud_sizes"], h["d_off0"], h["d_row_job"], h["d_blocks"],
+                                                                          h["state"], h["caches"], h["phase1"])
+        dev = x.device
         if index_arrays is None and perms is None and perm_source == "device":
             index_arrays = self.ragged_index_arrays_device(cloud_sizes, dev)
         if index_arrays is not None:
@@ -296,40 +317,51 @@ class SconeOcc(nn.Module):
             pc2 = pc1[ia["idx2"]]
             g_len_d, d_off1, d_off2 = ia["g_len"], ia["off1"], ia["off2"]
         else:
-            if perms is None:
+            from ..utility.host import batched_draws_ok
+            if perms is None and not batched_draws_ok():                 # torch.randperm was replaced from Python: honour it
                 perms = [self.draw_perms(int(m)) for m in cloud_sizes]
-            self.last_ragged_perms = perms
-            # ---- index arrays of the down-sampled clouds, built on the host from the draws, ONE upload
-            g_idx = np.zeros((J, Lg), np.int64)
-            g_len = np.zeros(J, np.int32)
-            idx1, idx2, off1, off2 = [], [], [0], [0]
-            for j, (p0, p1, p2) in enumerate(perms):
-                p0, p1, p2 = (np.asarray(p0, dtype=np.int64), np.asarray(p1, dtype=np.int64), np.asarray(p2, dtype=np.int64))
-                n0 = min(len(p0), Lg)
-                g_idx[j, :n0] = off0[j] + p0[:n0]
-                g_idx[j, n0:] = off0[j]                                  # padding rows: any valid point (masked by global_len)
-                g_len[j] = n0
-                idx1.append(off0[j] + p1)
-                idx2.append(off1[-1] + p2)                               # scale 2 indexes scale 1's rows (SconeOcc.py:311)
-                off1.append(off1[-1] + len(p1))
-                off2.append(off2[-1] + len(p2))
-            ints = np.concatenate([g_idx.reshape(-1), np.concatenate(idx1), np.concatenate(idx2), np.asarray(off1, np.int64),
-                                   np.asarray(off2, np.int64), g_len.astype(np.int64)])
-            d = ops.h2d(ints, torch.int64, dev)
+            if perms is None:
+                # the 3 J draws in job order on the CPU generator -- exactly the draws J sequential forward() calls make -- by ONE call
+                # into the C++ extension (the same at::randperm calls; no dispatcher round trip and no numpy per draw), which returns
+                # the index arrays below ready to upload
+                from .. import torch_ops  # noqa: F401
+                sz = [self.scale_sizes(int(m)) for m in cloud_sizes]
+                flat = torch.ops.macarons.scone_occ_draws([s_[0] for s_ in sz], [s_[1] for s_ in sz], [s_[2] for s_ in sz], Lg)
+                n1, n2 = sum(s_[1] for s_ in sz), sum(s_[2] for s_ in sz)
+            else:
+                # ---- index arrays of the down-sampled clouds, built on the host from the given draws
+                p0s = [np.asarray(p[0], dtype=np.int64)[:Lg] for p in perms]
+                p1s = [np.asarray(p[1], dtype=np.int64) for p in perms]
+                p2s = [np.asarray(p[2], dtype=np.int64) for p in perms]
+                n0 = np.asarray([len(p) for p in p0s], np.int64)
+                n1a = np.asarray([len(p) for p in p1s], np.int64)
+                n2a = np.asarray([len(p) for p in p2s], np.int64)
+                off1 = np.concatenate(([0], np.cumsum(n1a)))
+                off2 = np.concatenate(([0], np.cumsum(n2a)))
+                g_idx = np.repeat(off0[:J], Lg).reshape(J, Lg)                # padding rows: any valid point (masked by global_len)
+                col = np.arange(int(n0.sum()), dtype=np.int64) - np.repeat(np.cumsum(n0) - n0, n0)
+                g_idx[np.repeat(np.arange(J), n0), col] = np.concatenate(p0s) + np.repeat(off0[:J], n0)
+                idx1 = np.concatenate(p1s) + np.repeat(off0[:J], n1a)
+                idx2 = np.concatenate(p2s) + np.repeat(off1[:J], n2a)          # scale 2 indexes scale 1's rows (SconeOcc.py:311)
+                flat = np.concatenate([g_idx.reshape(-1), idx1, idx2, off1, off2, n0])
+                n1, n2 = int(off1[-1]), int(off2[-1])
+            d = ops.h2d(flat, torch.int64, dev)                            # ONE upload
             cut, o = [], 0
-            for n in (J * Lg, off1[-1], off2[-1], J + 1, J + 1, J):
+            for n in (J * Lg, n1, n2, J + 1, J + 1, J):
                 cut.append(d[o:o + n]); o += n
-            pc_global = pc[cut[0]].view(J, Lg, 3)
-            pc1 = pc[cut[1]]
-            pc2 = pc1[cut[2]]
-            g_len_d, d_off1, d_off2 = cut[5].to(torch.int32), cut[3], cut[4]
+            ia = {"g_idx": cut[0], "idx1": cut[1], "idx2": cut[2], "off1": cut[3], "off2": cut[4], "g_len": cut[5].to(torch.int32)}
+            self.last_ragged_perms = ia                                    # (a caller that repeats the pass re-uses the draws: index_arrays=)
+            pc_global = pc[ia["g_idx"]].view(J, Lg, 3)
+            pc1 = pc[ia["idx1"]]
+            pc2 = pc1[ia["idx2"]]
+            g_len_d, d_off1, d_off2 = ia["g_len"], ia["off1"], ia["off2"]
 
-        def run(v, flag, redo_phase1):
+        def run(v, flag, redo_phase1, out_):
             if redo_phase1:
                 phase1(v)
             blobs, head, table = state[v] if v in state else caches(v)
             return ops.scone_occ_forward_ragged(pc_global, g_len_d, [pc, pc1, pc2], [d_off0, d_off1, d_off2], x, view_harmonics,
-                                                d_row_job, d_blocks, table, blobs, head, flag, phase=2)
+                                                d_row_job, d_blocks, table, blobs, head, flag, phase=2, out=out_, arena=h["arena"])
         flag = None
         if variant == 6 and self.range_guard != "off":
             if self._range_flag is None or self._range_flag.device != dev:
@@ -339,11 +371,11 @@ class SconeOcc(nn.Module):
             flag = self._range_flag
         with torch.no_grad():
             # (phase 1's results live in the stream's arena: if anything else wrote it since -- another thread on this stream -- redo it)
-            res = run(variant, flag, ops.scone_occ_epoch(dev, "scone_occ_ragged") != epoch1)
+            res = run(variant, flag, ops.scone_occ_epoch(dev, h["arena"]) != h["epoch1"], out)
             if flag is not None and self.range_guard == "sync" and int(flag):
                 L.mcr_set_local_pct_variant(5)
                 try:
-                    res = run(5, None, True)
+                    res = run(5, None, True, out)
                 finally:
                     L.mcr_set_local_pct_variant(variant)
         return res

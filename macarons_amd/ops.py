@@ -406,7 +406,7 @@ def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_bl
 
 
 def scone_occ_forward_ragged(pc_global, global_len, pc_scales, scale_offsets, x, view_harmonics, row_job, knn_blocks, weights,
-                             local_blobs, head_planes=None, range_flag=None, phase=0, Lg=None, out=None):
+                             local_blobs, head_planes=None, range_flag=None, phase=0, Lg=None, out=None, arena="scone_occ_ragged"):
     """J SconeOcc jobs of different sizes in one launch sequence (mcr_scone_occ_forward_ragged).  pc_global [J,Lg,3],
     global_len int32 [J], pc_scales: 3 ragged clouds [sum M_s,3], scale_offsets: 3 int64 [J+1], x [T,3], view_harmonics [T,64],
     row_job int32 [T], knn_blocks int32 [n_blocks,4] -> out [T,1].
@@ -432,8 +432,8 @@ def scone_occ_forward_ragged(pc_global, global_len, pc_scales, scale_offsets, x,
     L_ = lib()
     if late and out is None:
         out = torch.empty((T, 1), dtype=torch.float32, device=x.device)
-    ws = _workspace(x.device, L_.mcr_scone_occ_ragged_workspace_bytes(c_i64(J), c_i64(T), c_i64(Lg)), "scone_occ_ragged")
-    _bump_epoch(x.device, "scone_occ_ragged")
+    ws = _workspace(x.device, L_.mcr_scone_occ_ragged_workspace_bytes(c_i64(J), c_i64(T), c_i64(Lg)), arena)
+    _bump_epoch(x.device, arena)
     sc_ptrs = (ctypes.c_void_p * 3)(*[p.data_ptr() for p in pc_scales])
     off_ptrs = (ctypes.c_void_p * 3)(*[o.data_ptr() for o in scale_offsets])
     blobs = (ctypes.c_void_p * 3)(*[_req(b, "local_blob").data_ptr() for b in local_blobs])
@@ -922,6 +922,23 @@ def scene_fill_gather(g, h, store_pts, store_fts, n_store, F):
                                           _p(store_fts) if (n_store and store_fts is not None) else c_vp(0), c_i64(n_store), c_int(F), _p(h.pts),
                                           _p(h.features) if h.features is not None else c_vp(0), _p(h.order), _p(h.order2), _p(new_pts),
                                           _p(new_fts) if new_fts is not None else c_vp(0), _stream()), "mcr_scene_fill_gather")
+    return new_pts, new_fts
+
+
+def scene_fill_gather_perm(pm_tab, n_pm, n_cells, n_new, h, store_pts, store_fts, n_store, F):
+    """As scene_fill_gather with the row map evaluated on the device: pm_tab = ONE uploaded int64 buffer holding the five (n_cells + 1)
+    tables of mcr_scene_fill_gather_perm followed (as raw bytes) by the n_pm int32 permutation entries."""
+    dev = pm_tab.device
+    new_pts = torch.empty((n_new, 3), dtype=torch.float32, device=dev)
+    new_fts = torch.empty((n_new, F), dtype=torch.float32, device=dev) if F > 0 else None
+    base = pm_tab.data_ptr()
+    with torch.cuda.device(dev):
+        check(lib().mcr_scene_fill_gather_perm(c_vp(base + 40 * (n_cells + 1)), c_vp(base), c_int(n_cells), c_i64(n_new),
+                                               _p(store_pts) if n_store else c_vp(0),
+                                               _p(store_fts) if (n_store and store_fts is not None) else c_vp(0), c_i64(n_store), c_int(F),
+                                               _p(h.pts), _p(h.features) if h.features is not None else c_vp(0), _p(h.order), _p(h.order2),
+                                               _p(new_pts), _p(new_fts) if new_fts is not None else c_vp(0), _stream()),
+              "mcr_scene_fill_gather_perm")
     return new_pts, new_fts
 
 

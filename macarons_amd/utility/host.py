@@ -8,6 +8,7 @@ decision whose host glue touches ~1 MB index arrays went from 16 ms to 96 ms.  `
 what the process may actually use; macarons_amd.ops applies it on import (MCR_HOST_THREADS=0 leaves torch alone,
 MCR_HOST_THREADS=N asks for N).
 """
+import torch
 import math
 import os
 
@@ -57,3 +58,14 @@ def limit_host_threads(n=None):
     if torch.get_num_threads() > n:
         torch.set_num_threads(n)
     return torch.get_num_threads()
+
+
+# ---- the reference's hidden torch.randperm draws, batched ---------------------------------------------------------------------------
+_TORCH_RANDPERM = torch.randperm
+
+
+def batched_draws_ok():
+    """True while torch.randperm is torch's own: the C++ operators that make a decision's ~200 hidden draws in two calls
+    (torch.ops.macarons.randperm_prefixes / scone_occ_draws: the same at::randperm calls on the same generator) bypass the Python
+    name -- a harness that replaced it (the golden generator's keyed draws, tests/golden/keyed_rng.py) gets the Python loop instead."""
+    return torch.randperm is _TORCH_RANDPERM

@@ -57,7 +57,8 @@ def get_distance_factor_smooth(params, pts, X_cam, fov_camera, cell_resolution):
 
 def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harmonics, occ_probs, cameras, X_cam_world,
                                       prediction_view_matrices, prediction_box_diag, seq_len=2048, min_occ=0.1,
-                                      distance_th=17., samples=None, smooth=False, return_parts=False, record=None):
+                                      distance_th=17., samples=None, smooth=False, return_parts=False, record=None,
+                                      uniform_draws="per_camera"):
     """The per-neighbour-camera scoring loop of testers/scene.py:434-454 around
     predict_coverage_gain_for_single_camera (macarons_utils.py:1580-1738), for K cameras AT ONCE and without a host
     synchronisation (the reference runs one SconeVis forward and reads a count back per camera):
@@ -67,18 +68,19 @@ def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harm
     prediction_view_matrices [K,4,4] (world -> prediction-camera view, row-vector).  distance_th / smooth select the distance
     factor (params.distance_factor_th: a number -> threshold factor; None -> sensor_distance_threshold(...), smooth=False;
     'smooth' -> sensor_distance_threshold(...), smooth=True).  Returns gains [K] (and, with return_parts, the per-camera lists of
-    factored per-point gains [N] and sampled world points [N,4])."""
+    factored per-point gains [N] and sampled world points [N,4]).
+    Uniforms (`samples` None): uniform_draws="per_camera" (default) = what upstream's K calls draw one after the other,
+    torch.rand(S, 1, device=...) inside every per-camera call (scone_utils.py:1052), bit for bit and with the same effect on the device
+    generator -- from ONE launch (ops.uniform_rows: torch's Philox indexing restated); "batched" = one torch.rand(K, S) (another stream)."""
     K = cameras.shape[0]
     dev = X_world.device
     S = seq_len
     mask = ops.points_in_fov(X_world, cameras)                                            # :1603
     occ_k = ops.fov_mask_occ(mask, occ_probs.reshape(-1).contiguous())                    # :1606-1613 folded into the sampler
     # ---- sampling inside every frustum (:1624): K distributions over the ONE shared point set in one launch sequence, nothing
-    # read back (padded rows, counts on the device).  Uniforms: ONE draw of [K, S] from the device generator (upstream draws
-    # torch.rand(S, 1) inside every per-camera call; 30 launches of a 2 us kernel are 0.35 ms of a host-bound decision -- callers that
-    # need particular uniforms pass `samples`).
+    # read back (padded rows, counts on the device)
     if samples is None:
-        u = torch.rand(K, S, device=dev)
+        u = ops.uniform_rows(K, S, dev) if uniform_draws == "per_camera" else torch.rand(K, S, device=dev)
     elif torch.is_tensor(samples):
         u = samples.to(dev).reshape(K, S).float()
     else:
@@ -87,33 +89,27 @@ def predict_coverage_gain_for_cameras(visibility_model, X_world, proxy_view_harm
         record["samples"] = u                                                               # (a re-run must see the same uniforms)
     res, res_h, inv, _, nu, vol = ops.sample_proxy_batched(X_world, occ_k, proxy_view_harmonics, u.contiguous(), min_occ)
     vol = vol.float()                                                                      # [K,S,4] [K,S,64] [K,S]; [K] int32, [K]
-    # ---- prediction box: centre of the sampled points' bounding box, in the prediction camera's view space (:1631-1641)
-    valid = (torch.arange(S, device=dev)[None, :] < nu[:, None])[..., None]               # [K,S,1]
-    xyz = res[..., :3]
-    hi = torch.where(valid, xyz, torch.full_like(xyz, float("-inf"))).amax(dim=1)
-    lo = torch.where(valid, xyz, torch.full_like(xyz, float("inf"))).amin(dim=1)
-    center_w = torch.where((nu > 0)[:, None], (hi + lo) / 2., torch.zeros_like(hi))       # empty frustum: any finite centre
+    # ---- prediction boxes (:1631-1641) and the cameras in the normalised prediction space (:1655-1659): one launch
     Mv = prediction_view_matrices.to(device=dev, dtype=torch.float32).contiguous()
-    center = torch.bmm(torch.cat((center_w, torch.ones(K, 1, device=dev)), 1)[:, None, :], Mv)[:, 0, :3].contiguous()
+    xc = X_cam_world.reshape(K, 3).contiguous()
+    inv_d = 1.0 / prediction_box_diag
+    center, cam_view = ops.camera_boxes(res, nu, Mv, xc, inv_d)
     pts = res.clone()
-    cam4 = torch.cat((X_cam_world.reshape(K, 3), torch.ones(K, 1, device=dev)), 1).contiguous()
-    inv_diag = torch.full((K,), 1.0 / prediction_box_diag, dtype=torch.float32, device=dev)
-    ops.transform_points_batched_(pts, Mv, center, inv_diag)                               # :1647-1650, all cameras in one launch
-    ops.transform_points_batched_(cam4.view(K, 1, 4), Mv, center, inv_diag)                # :1655-1659
-    # ---- ONE SconeVis forward over the K padded clouds (:1664), ONE scorer launch (C = 1 per cloud, :1683), ONE gain launch
+    ops.transform_points_batched_(pts, Mv, center, torch.full((K,), inv_d, dtype=torch.float32, device=dev))   # :1647-1650, all cameras in one launch
+    # ---- ONE SconeVis forward over the K padded clouds (:1664), ONE scorer launch on the UNIQUE points (C = 1 per cloud, :1683), ONE
+    # gain launch that reads the Monte-Carlo duplicates (:1668-1671) through the inverse map
     harm = visibility_model(pts, view_harmonics=res_h, lengths=nu)
-    gi = inv[..., None]
-    pts_mc = torch.gather(pts, 1, gi.expand(-1, -1, 4)).contiguous()                      # MC duplicates (:1668-1671)
-    harm_mc = torch.gather(harm, 1, gi.expand(-1, -1, 64)).contiguous()
-    world = torch.gather(res, 1, gi.expand(-1, -1, 4)).contiguous()
-    vis = ops.sh_visibilities(pts_mc, harm_mc, cam4[:, None, :3].contiguous(), True).view(K, S)
-    gains = ops.macarons_gain_(vis, world, X_cam_world.reshape(K, 3).contiguous(), vol, distance_th, smooth)     # :1699-1704
-    gains = torch.where(nu > 0, gains, torch.zeros_like(gains))                           # empty frustum: gain 0 (:1707-1736)
+    vis_u = ops.sh_visibilities(pts, harm, cam_view.view(K, 1, 3), True).view(K, S)
     if return_parts:
+        gi = inv[..., None]
+        world = torch.gather(res, 1, gi.expand(-1, -1, 4)).contiguous()
+        vis = torch.gather(vis_u, 1, inv).contiguous()
+        gains = ops.macarons_gain_(vis, world, xc, vol, distance_th, smooth)               # :1699-1704 (vis scaled in place)
+        gains = torch.where(nu > 0, gains, torch.zeros_like(gains))                       # empty frustum: gain 0 (:1707-1736)
         n_host = nu.tolist()
         return (gains, [vis[k] if n_host[k] > 0 else None for k in range(K)],
                 [world[k] if n_host[k] > 0 else None for k in range(K)])
-    return gains
+    return ops.macarons_gain_indexed(vis_u, res, inv, nu, xc, vol, distance_th, smooth)   # :1699-1704; empty frustum: gain 0 (:1707-1736)
 
 
 class SceneCamera:
@@ -131,7 +127,8 @@ class SceneCamera:
 
 
 def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, depth, depth_mask, neighbor_records, X_neighbors,
-                          device, samples=None, return_signed_distances=False, range_guard=True, group=None, perm_source="host"):
+                          device, samples=None, return_signed_distances=False, range_guard=True, group=None, perm_source="host",
+                          uniform_draws="per_camera"):
     """One next-best-view decision of the MACARONS loop after the depth map of the current pose is known -- the body of
     testers/scene.py:391-454 (everything between the depth network and the move to the chosen pose):
       1. proxy points in the current frustum (Camera.get_points_in_fov :391), registered in the proxy grid (:394-395);
@@ -140,40 +137,51 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
       4. coverage gain of every valid neighbour pose (:434-450), all cameras in one launch sequence; first strict maximum (:452-454).
     camera: SceneCamera of the current pose (it is also the prediction camera, fov_camera_0 of :305); depth [H,W] (+ optional
     leading/trailing singleton dims), depth_mask like depth; neighbor_records [K,40], X_neighbors [K,3].
-    `group` (torch.distributed; every rank holds replicas of both scenes and calls with the same arguments): SURVEY §8e -- the query
-    rows of the occupancy field and the K neighbour cameras are block-partitioned over the ranks, the occupancies (4 B per proxy
-    point) and one 8-byte (gain, index) record per rank are all-gathered, the hidden draws (Cell.fill subsets, SconeOcc's
-    down-samples, the sampling uniforms) are rank 0's; the cheap state updates run replicated.  Bit for bit the 1-rank decision;
-    `gains` then holds this rank's cameras only (`cam_range`).
+    `group` (torch.distributed; every rank holds replicas of both scenes and calls with the same arguments; None = a local decision
+    whatever process groups exist): SURVEY §8e -- the query rows of the occupancy field and the K neighbour cameras are
+    block-partitioned over the ranks, the occupancies (4 B per proxy point) and one 8-byte (gain, index) record per rank are
+    all-gathered, the hidden draws (Cell.fill subsets, SconeOcc's down-samples, the sampling uniforms) are rank 0's; the cheap state
+    updates run replicated.  Bit for bit the 1-rank decision; `gains` then holds this rank's cameras only (`cam_range`).
     perm_source: "host" (default) draws the hidden permutations (Cell.fill's subsets, SconeOcc's down-samples) with torch.randperm on
     the CPU generator in upstream's order -- what the reference goldens pin; "device" (opt-in, production) draws them on the GPU in
-    two segmented sorts (statistically the same, a different stream): ~190 host draws = 2.7 ms of CPU time per decision less.
+    two segmented sorts (statistically the same, a different stream).  uniform_draws: see predict_coverage_gain_for_cameras.
     Returns dict(next_idx (device int64: index into the neighbour list), gains [K], fov_mask [P] bool, X_world, view_harmonics,
-    occ_probs).  The scene objects are updated in place like upstream.  Host synchronisations: the cell counts of the occupancy-field
-    pass (cell bookkeeping on the host, as upstream), fill_cells' one, and -- range_guard=True -- the range flag of the fp16-split
-    path, read once at the end (range_guard=False: the caller checks macarons.occupancy.range_flag() itself)."""
+    occ_probs).  The scene objects are updated in place like upstream.
+    Host synchronisations: ONE in the middle (the per-cell counts of fill_cells and of the field's selection come back together: the
+    shapes of everything behind them depend on them) and -- range_guard=True -- one at the end (the range flag of the fp16-split path
+    with the decision's record; range_guard=False: the caller checks macarons.occupancy.range_flag() itself).  The reference's order of
+    CPU-generator draws is kept (Cell.fill's, then SconeOcc's job by job) while the first launches of the occupancy pass, which need
+    none of them, are already queued."""
     from .. import dist as mdist
     world, rank = mdist.group_world_rank(group)            # group=None: local, whatever process groups exist
     H, W = params.image_height, params.image_width
     depth2 = depth.reshape(H, W).contiguous().float()
     dmask2 = depth_mask.reshape(H, W) if depth_mask is not None else None
     rec = ops.h2d(camera.record, torch.float32, device)
-    # 1 ---- proxy points in the current field of view, registered in their grid cells with their index as feature
-    fov_mask = ops.points_in_fov(proxy_scene.proxy_points, rec.view(1, 40))[0]
-    # every proxy point is offered with its index as feature, the ones outside the frustum flagged invalid: compacting them first
-    # (`points[mask]`) is a read-back of the count
-    P_all = proxy_scene.proxy_points.shape[0]
-    proxy_scene.fill_cells(proxy_scene.proxy_points, features=torch.arange(P_all, device=device, dtype=torch.float32).view(-1, 1),
-                           valid=fov_mask, **({"group": group} if world > 1 else {}),
-                           **({"perm_source": perm_source} if perm_source != "host" else {}))
+    ps = proxy_scene
+    # 1 ---- proxy points in the current field of view, offered to their grid cells with their index as feature (every point is offered,
+    # the ones outside the frustum flagged invalid: compacting them first -- `points[mask]` -- is a read-back of the count)
+    fov_mask = ops.points_in_fov(ps.proxy_points, rec.view(1, 40))[0]
+    P_all = ps.proxy_points.shape[0]
+    idx_f = getattr(ps, "_mcr_index_feature", None)
+    if idx_f is None or idx_f.shape[0] != P_all or idx_f.device != ps.proxy_points.device:
+        idx_f = torch.arange(P_all, device=device, dtype=torch.float32).view(-1, 1)
+        try:
+            ps._mcr_index_feature = idx_f
+        except Exception:
+            pass
+    fused = hasattr(ps, "fill_cells_begin")
+    if fused:
+        fill = ps.fill_cells_begin(ps.proxy_points, features=idx_f, valid=fov_mask)
+    else:                                                   # a reference Scene: its own fill (one Python loop over the cells)
+        ps.fill_cells(ps.proxy_points[fov_mask], features=idx_f[fov_mask])
     # 2 ---- carve with the depth map: signed distance, view states, supervision occupancy, out-of-field, one launch
-    sgn = proxy_scene.update_from_depth(fov_mask, rec, ops.h2d(camera.X_cam, torch.float32, device), depth2, dmask2, fill=1.1 * camera.zfar,
-                                        tol=params.carving_tolerance, return_signed_distances=return_signed_distances)
+    sgn = ps.update_from_depth(fov_mask, rec, ops.h2d(camera.X_cam, torch.float32, device), depth2, dmask2, fill=1.1 * camera.zfar,
+                               tol=params.carving_tolerance, return_signed_distances=return_signed_distances)
     surface_scene.set_all_features_to_value(value=1.)
     # 3 ---- occupancy probability field, in the current camera's view space; 4 ---- neighbours.
     # The range check of the fp16-split path (SconeOcc.range_guard) is DEFERRED to one read-back at the very end: checked inside
-    # the occupancy pass it stalls the host until the pass has run, and the ~200 small launches of the glue behind it then start
-    # on an idle GPU (kernel trace of one decision: 9 of 22 ms idle).  On a set flag steps 3-4 are repeated on the full-range
+    # the occupancy pass it stalls the host until the pass has run.  On a set flag steps 3-4 are repeated on the full-range
     # variant with the SAME hidden draws (cell permutations, sampling uniforms).
     Mv_field = camera.M_view                          # where the caller keeps it: a host matrix is used on the host, uploaded without a stall
     Mv = ops.h2d(Mv_field, torch.float32, device)
@@ -183,27 +191,49 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     if th is None or smooth:
         th = sensor_distance_threshold(params, camera, surface_scene.cell_resolution)
     vis_model = macarons.visibility                 # `macarons` = the SCONE part (Macarons.scone upstream): .occupancy / .visibility
-    diag = getattr(proxy_scene, "_mcr_box_diag", None)      # a constant of the scene: read back once, not once per decision
+    diag = getattr(ps, "_mcr_box_diag", None)       # a constant of the scene: read back once, not once per decision
     if diag is None:
-        diag = torch.linalg.norm(proxy_scene.x_max - proxy_scene.x_min).item()
+        diag = torch.linalg.norm(ps.x_max - ps.x_min).item()
         try:
-            proxy_scene._mcr_box_diag = diag
+            ps._mcr_box_diag = diag
         except Exception:
             pass
     occ_net = getattr(macarons, "occupancy", macarons)
     nrec, xn = ops.h2d(neighbor_records, torch.float32, device), ops.h2d(X_neighbors, torch.float32, device)
-
     k0, k1 = mdist.shard_range(K, rank, world)
     S = params.seq_len
+    # ---- the selection of the field pass is queued BEHIND the fill's device part and BEFORE its host part: with no cell over its
+    # capacity the set a cell ends up with does not depend on the draws (only its order does), so both count tables come back in ONE
+    # read-back, and the fill's draws + gather (fill_cells_end) run while the GPU already works on the occupancy pass
+    field_state = {"selection": None, "between": None, "after": None}
+    if fused:
+        sel = _field_select(ps, device, True, pending=fill)
+        prep = _field_prepare(params, ps, Mv_field, device)        # (count-independent host work, while the GPU runs the launches above)
+        nkf = 4 * fill.nk + 6
+        host = torch.cat((fill.counts, sel.counts)).cpu().numpy()                                  # THE read-back of the decision's first half
+        cand, adm = ps.fill_counts(host[:nkf])
+        gfill = group if world > 1 else None
+        if ps.fill_overflows(cand, adm):            # a full cell: WHICH points stay is random -> the selection has to wait for the draws
+            ps.fill_cells_end(fill, cand, adm, 0, gfill, perm_source)
+        else:
+            plan = {}
+            field_state["selection"] = (sel, host[nkf:], prep)
+            # the fill's draws come before the occupancy pass's on the CPU generator (upstream's order); its gather can wait until the
+            # pass is queued -- nothing of THIS decision reads the proxy cells any more
+            field_state["between"] = lambda: plan.update(p=ps.fill_cells_draw(fill, cand, adm, 0, gfill, perm_source))   # noqa: E731
+            field_state["after"] = lambda: ps.fill_cells_apply(plan.get("p"))                                         # noqa: E731
 
     def field_and_gains(ragged_perms, smp, record):
-        X_world, view_harmonics, occ_probs = compute_scene_occupancy_probability_field(params, macarons, None, surface_scene, proxy_scene,
+        selection, between, after = field_state["selection"], field_state["between"], field_state["after"]
+        field_state["selection"] = field_state["between"] = field_state["after"] = None   # (a repeat selects again: the stores are final by then)
+        X_world, view_harmonics, occ_probs = compute_scene_occupancy_probability_field(params, macarons, None, surface_scene, ps,
                                                                                        device, prediction_camera=Mv_field, ragged_perms=ragged_perms,
                                                                                        group=group if world > 1 else None, record=record,
-                                                                                       perm_source=perm_source)
+                                                                                       perm_source=perm_source, _selection=selection,
+                                                                                       _between=between, _after=after)
         if world > 1:                                   # the uniforms of ALL cameras are rank 0's
             if smp is None:
-                smp = torch.rand(K, S, device=device)
+                smp = ops.uniform_rows(K, S, device) if uniform_draws == "per_camera" else torch.rand(K, S, device=device)
                 _, smp = mdist.broadcast_draws([], smp, 0, group)
             elif not torch.is_tensor(smp):
                 smp = torch.stack([torch.as_tensor(x_, device=device).reshape(-1) for x_ in smp]).float()
@@ -221,7 +251,7 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
         gains = predict_coverage_gain_for_cameras(vis_model, X_world, view_harmonics, occ_probs, nrec, xn,
                                                   Mv.reshape(1, 4, 4).expand(K, -1, -1), diag, seq_len=S,
                                                   min_occ=params.min_occ_for_proxy_points, distance_th=float(th), samples=smp,
-                                                  smooth=smooth, record=record)
+                                                  smooth=smooth, record=record, uniform_draws=uniform_draws)
         if record is not None and "samples" in record:
             record["samples_all"] = record["samples"]
         return X_world, view_harmonics, occ_probs, gains
@@ -233,12 +263,18 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
         occ_net.clear_range_flag(device)                # (exists on every rank before the pass: the all-reduce below is rank-invariant)
     try:
         X_world, view_harmonics, occ_probs, gains = field_and_gains(None, samples, record)
+        # `if coverage_gain > max_coverage_gain` from -1: the first strict maximum (a NaN gain never wins upstream; here it would)
+        rec_best = None if world > 1 else ops.best_record(gains.view(1, K), 0)
         fallback = None
         if deferred:
             flag = occ_net.range_flag()
             if world > 1:
                 flag = mdist.all_reduce_max(flag, group)                # every rank repeats, or none
-            if flag is not None and int(flag):      # the one read-back; out of the fp16 range: repeat on the full-range variant
+            hit = False
+            if flag is not None:                    # the one read-back of the second half: range flag + the decision's record together
+                both = torch.cat((flag.view(1).float(), rec_best.view(-1))).cpu() if rec_best is not None else flag.cpu()
+                hit = bool(both.view(-1)[0] != 0)
+            if hit:                                 # out of the fp16 range: repeat on the full-range variant
                 from .. import _lib
                 import ctypes
                 L = _lib.lib()
@@ -250,16 +286,17 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
                     L.mcr_set_local_pct_variant(ctypes.c_int(v0))
                 occ_net.clear_range_flag()
                 fallback = 5
+                rec_best = None if world > 1 else ops.best_record(gains.view(1, K), 0)
     finally:
         if deferred:
             occ_net.range_guard = "sync"
-    # `if coverage_gain > max_coverage_gain` from -1: the first strict maximum (a NaN gain never wins upstream; here it would)
     if world > 1:                                       # ties -> the lowest index over all ranks = the first strict maximum
         max_gain, next_idx = mdist.allgather_best(gains.view(1, -1), k0, group)
         out = {"next_idx": next_idx[0], "max_gain": max_gain[0], "cam_range": (k0, k1)}
     else:
-        rec_best = ops.best_record(gains.view(1, K), 0)
         out = {"next_idx": rec_best[0, 1].to(torch.int64), "max_gain": rec_best[0, 0]}
+        if deferred and fallback is None and flag is not None:      # the decision came back with the range flag: no second read-back needed
+            out["host"] = {"max_gain": float(both[1]), "next_idx": int(both[2])}
     out.update({"gains": gains, "fov_mask": fov_mask, "X_world": X_world, "view_harmonics": view_harmonics, "occ_probs": occ_probs})
     if fallback:
         out["fallback_variant"] = fallback
@@ -376,7 +413,11 @@ def _grid_tables(scene, device):
     order = [by_lin[c] for c in range(n_cells)]
     centers = torch.stack([c.center.reshape(3) for c in order]).to(device)
     diag = torch.linalg.norm(torch.stack([c.x_max.reshape(3) for c in order]) - torch.stack([c.x_min.reshape(3) for c in order]), dim=1).to(device)
-    tab = {"device": str(device), "keys": keys, "lin_of": lin_of, "neighbours": [neigh(c) for c in range(n_cells)], "centers": centers,
+    nbl = [neigh(c) for c in range(n_cells)]
+    nbm = np.full((n_cells, 27), -1, np.int64)            # the 27-neighbourhoods as a padded matrix (ascending ids, -1 = none)
+    for c, l_ in enumerate(nbl):
+        nbm[c, :len(l_)] = l_
+    tab = {"device": str(device), "keys": keys, "lin_of": lin_of, "neighbours": nbl, "neighbour_matrix": nbm, "centers": centers,
            "diag": diag, "centers_host": centers.cpu(), "diag_host": diag.cpu()}
     try:
         scene._mcr_grid_tables = tab
@@ -385,197 +426,276 @@ def _grid_tables(scene, device):
     return tab
 
 
+class _ForeignStore:
+    """Flat store (see scene._Store) of a Scene-like object that keeps one tensor per cell -- the reference's Scene."""
+
+    def __init__(self, scene, keys, device):
+        from .. import ops as _ops
+        cells = [scene.cells[k] for k in keys]
+        lens = [int(c.cell_pts.shape[0]) for c in cells]
+        self.off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+        self.off_dev = _ops.h2d(self.off, torch.int64, device)
+        self.pts = torch.cat([c.cell_pts for c, n in zip(cells, lens) if n] + [torch.zeros(0, 3, device=device)]).float().contiguous()
+        fd = getattr(scene, "feature_dim", 0)
+        self.fts = (torch.cat([c.cell_features.reshape(n, -1) for c, n in zip(cells, lens) if n] + [torch.zeros(0, max(fd, 1), device=device)])
+                    .float().contiguous() if fd > 0 else None)
+
+
+def _store_of(scene, device):
+    if hasattr(scene, "flat_store"):
+        return scene.flat_store()
+    return _ForeignStore(scene, _grid_tables(scene, device)["keys"], device)
+
+
+def _grid_consts(scene, device):
+    """x_min | x_max | step as 9 fp32 on the device (mcr_cell_keys' grid_consts) and the grid shape."""
+    if hasattr(scene, "_consts"):
+        return scene._consts(device)["gc"], (scene.grid_l, scene.grid_w, scene.grid_h)
+    tab = _grid_tables(scene, device)
+    if "gc" not in tab:
+        step = torch.stack([torch.as_tensor(v, dtype=torch.float32).reshape(()) for v in (scene.l, scene.w, scene.h)])
+        tab["gc"] = torch.cat((scene.x_min.reshape(3).float().cpu(), scene.x_max.reshape(3).float().cpu(), step.cpu())).to(device).contiguous()
+    return tab["gc"], (scene.grid_l, scene.grid_w, scene.grid_h)
+
+
+def _field_select(proxy_scene, device, use_supervision_occ_mask=True, pending=None):
+    """Device part of the field pass's selection (ops.field_select); `pending`: a fill of the proxy scene whose host part has not
+    run yet (macarons_nbv_decision reads both count tables back together)."""
+    ps = proxy_scene
+    st = _store_of(ps, device)
+    if st.fts is None:
+        raise ValueError("the proxy scene's cells must carry the proxy indices as feature (feature_dim >= 1)")
+    gc, grid = _grid_consts(ps, device)
+    return ops.field_select(ps.proxy_points, ps.proxy_supervision_occ, ps.out_of_field, ps.proxy_proba, st.fts, int(st.off[-1]), st.off_dev,
+                            gc, grid, use_supervision_occ_mask, pending)
+
+
+def _job_groups(cloud_sizes):
+    """Consecutive groups of (cell, chunk) jobs with about the same amount of hidden draws (a job draws ~2.3 indices per surface point
+    of its cloud): one group below ~350k indices, at most three (every extra group repeats ~40 launches).  env MCR_FIELD_GROUPS=n forces n."""
+    import os
+    J = len(cloud_sizes)
+    work = np.cumsum(np.asarray(cloud_sizes, np.float64))
+    forced = os.environ.get("MCR_FIELD_GROUPS")
+    G = int(forced) if forced else int(min(3, max(1, round(2.3 * work[-1] / 350e3))))
+    G = max(1, min(G, J))
+    cuts = [0] + [int(np.searchsorted(work, work[-1] * g / G)) + 1 for g in range(1, G)] + [J]
+    cuts = sorted(set(min(max(c, 0), J) for c in cuts))
+    return [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+
+_vh_matrix_t_cache = {}
+
+
+def _vh_matrix_t(params, device):
+    """[n_bins, 64] on the device: the constant matrix of compute_view_harmonics (scone_utils.py:953-958), transposed for the fused
+    row kernel; built once per (degree, lattice, device)."""
+    from . import scone_utils as su
+    key = (params.harmonic_degree, params.view_state_n_elev, params.view_state_n_azim, str(device))
+    m = _vh_matrix_t_cache.get(key)
+    if m is None:
+        base, h_polar, _ = su.get_all_harmonics_under_degree(params.harmonic_degree, params.view_state_n_elev, params.view_state_n_azim, device)
+        m = su._view_harmonics_matrix(base, h_polar, params.view_state_n_elev, params.view_state_n_azim).t().contiguous()
+        _vh_matrix_t_cache[key] = m
+    return m
+
+
+def _field_prepare(params, proxy_scene, prediction_camera, device):
+    """Host work of the field pass that does not depend on the selection's counts (so that macarons_nbv_decision can do it while the
+    GPU still works towards the read-back): the world->view matrix on the host, every cell's prediction-box transform
+    (:1468-1478), the bin permutation of move_view_state_to_view_space (:863-931)."""
+    from . import scone_utils as su
+    tab = _grid_tables(proxy_scene, device)
+    Mv_any = _world_to_view_matrix(prediction_camera)
+    Mv_host = Mv_any.detach().to("cpu", torch.float32).reshape(4, 4)    # (a device matrix is read back here)
+    cw, dg = tab["centers_host"], tab["diag_host"]
+    n = cw.shape[0]
+    cen_h = (torch.cat((cw, torch.ones(n, 1)), 1) @ Mv_host)[:, :3]
+    inv_h = (1.0 / (params.prediction_neighborhood_size * dg)).float()
+    xf_all = torch.cat((Mv_host.reshape(1, 16).expand(n, -1), cen_h, inv_h.view(n, 1)), 1).contiguous().numpy()
+    perm = su.view_space_bin_permutation((Mv_host[:3, :3].contiguous() if torch.is_tensor(prediction_camera) else prediction_camera),
+                                         params.view_state_n_elev, params.view_state_n_azim, device).numpy().astype(np.int32)
+    return {"tab": tab, "xf_all": xf_all, "perm": perm, "vh_mt": _vh_matrix_t(params, device)}
+
+
 def compute_scene_occupancy_probability_field(params, macarons, camera, surface_scene, proxy_scene, device,
                                               use_supervision_occ_mask=True, prediction_camera=None,
                                               use_supervision_occ_instead_of_predicted=False, chunk=20000, ragged_perms=None,
-                                              group=None, record=None, perm_source="host"):
+                                              group=None, record=None, perm_source="host", _selection=None, _between=None, _after=None):
     """Occupancy probability of every proxy point the cameras have seen (macarons_utils.py:1395-1540), as ONE batched pass.
 
     Upstream walks the grid cells that hold seen proxy points from Python: per cell it gathers the surface points of the 27-cell
     neighbourhood and the cell's registered proxy points, moves both to the prediction camera's view space (centred on the cell,
     scaled by prediction_neighborhood_size x the cell diagonal), rotates the view states into that frame, and calls the occupancy
-    network in chunks of 20 000 queries.  Here the cells are SEGMENTS of flat device arrays: one stable sort groups the selected
-    proxy points by cell, one gather builds every cell's surface cloud, one launch each transforms clouds / queries with a per-row
-    cell id, one gather + one product give the view harmonics, and all (cell, chunk) jobs go through SconeOcc.forward_ragged
-    together.  The host learns two integers per cell (visited?, how many selected points) in a single read-back; the hidden draws
-    of the network are made job by job on the CPU generator, i.e. exactly the draws of the cell loop.
+    network in chunks of 20 000 queries.  Here the cells are SEGMENTS of flat device arrays: one call selects and groups the proxy
+    points by cell (ops.field_select: a counting sort), the host learns two integers per cell in a single read-back and lists the
+    (cell, chunk) jobs, one call builds every job's surface cloud, queries and view harmonics in its prediction space
+    (ops.field_build), and all jobs go through SconeOcc.forward_ragged together; the hidden draws of the network are made job by
+    job on the CPU generator, i.e. exactly the draws of the cell loop.
     Returns (X_world [N,3], view_harmonics [N,64], occ_probs [N,1]) in upstream's order (cells in lexicographic order, points by
     index, then the never-seen points with their stored probability) and updates proxy_scene.proxy_proba in place.
     `surface_scene` / `proxy_scene`: macarons_amd.utility.scene.Scene or objects with the reference Scene's attributes;
     `prediction_camera`: a PyTorch3D-like camera, or the [4,4] world->view matrix.
-    `group` (torch.distributed, ranks holding replicas of both scenes): the T query rows of all jobs are block-partitioned over the
-    ranks (every (cell, chunk) job is independent, and so is every query of a job given the job's cloud and draws), each
-    rank runs the jobs its rows belong to, the occupancies (4 B per proxy point) are all-gathered; the hidden draws of ALL jobs are
-    rank 0's, in job order, in one broadcast -- the result is bit for bit the 1-rank field.  `record` (dict): receives the draws
-    used (`ragged_perms`) so that a caller can repeat the pass.  perm_source="device" (opt-in): SconeOcc's hidden down-samples are
-    drawn on the device (SconeOcc.ragged_index_arrays_device) instead of ~3 torch.randperm calls per job on the host."""
-    from . import scone_utils as su
+    `group` (torch.distributed, ranks holding replicas of both scenes; None = local): the T query rows of all jobs are
+    block-partitioned over the ranks (every (cell, chunk) job is independent, and so is every query of a job given the
+    job's cloud and draws), each rank runs the jobs its rows belong to, the occupancies (4 B per proxy point) are all-gathered; the
+    hidden draws of ALL jobs are rank 0's, in job order, in one broadcast -- the result is bit for bit the 1-rank field.  `record`
+    (dict): receives the draws used (`ragged_perms`) so that a caller can repeat the pass.  perm_source="device" (opt-in): SconeOcc's
+    hidden down-samples are drawn on the device (SconeOcc.ragged_index_arrays_device) instead of ~3 torch.randperm calls per job on
+    the host.  `_selection` / `_between` / `_after` (macarons_nbv_decision): a selection whose counts are already on the host (with the
+    count-independent host work, _field_prepare); host work to run once the first launches of the occupancy pass are queued and BEFORE
+    the network's draws (the fill's draws: upstream's order on the CPU generator); host work to run once the whole pass is queued
+    (the fill's gather: the GPU is busy meanwhile)."""
     from .. import dist as mdist
     world, rank = mdist.group_world_rank(group)            # group=None: local, whatever process groups exist
     ps, ss = proxy_scene, surface_scene
     gl, gw, gh = ps.grid_l, ps.grid_w, ps.grid_h
     n_cells = gl * gw * gh
-    P = ps.proxy_points.shape[0]
     nh = params.n_harmonics
-    occ_mask = (ps.proxy_supervision_occ > 0.)[..., 0]
-    seen = occ_mask & (ps.out_of_field < 1.)[..., 0]
-    visit_pts = seen if use_supervision_occ_mask else (ps.out_of_field < 1.)[..., 0]
-    ps.proxy_proba.masked_fill_(seen.view(-1, 1), 0.)                                            # :1431
     if prediction_camera is None:
         if camera is None:
             raise NameError("Both camera and prediction_camera are equal to None.")
         prediction_camera = camera.fov_camera_0
-    Mv_any = _world_to_view_matrix(prediction_camera)
-    Mv_host = Mv_any.detach().to(torch.float32) if Mv_any.device.type == "cpu" else None     # (a host matrix stays usable on the host)
-    Mv = ops.h2d(Mv_host, torch.float32, device).contiguous() if Mv_host is not None else Mv_any.to(device=device, dtype=torch.float32).contiguous()
-    # ---- per proxy point: the cell its coordinates fall in (which cells are visited, :1434) and the cell whose store holds it
-    cell_by_pos = (ps.linear_cell_ids(ps.proxy_points) if hasattr(ps, "linear_cell_ids")
-                   else _lin(ps.get_cells_for_each_pt(ps.proxy_points), gw, gh))
-    tab = _grid_tables(ps, device)                       # static per scene: cells in linear-id order, their centres / diagonals, 27-neighbourhoods
+    # ---- selection: which proxy points take part, grouped by the cell that stores them (:1428-1442); ONE read-back of the counts
+    if _selection is None:
+        sel = _field_select(ps, device, use_supervision_occ_mask)
+        prep = _field_prepare(params, ps, prediction_camera, device)
+        hostc = sel.counts.cpu().numpy()
+    else:
+        sel, hostc, prep = _selection
+    visit, counts = hostc[:n_cells], hostc[n_cells + 1:2 * n_cells + 1]
+    sel_off = hostc[2 * n_cells + 2:3 * n_cells + 4]
+    n_oof = int(hostc[3 * n_cells + 4])
+    tab = prep["tab"]                                    # static per scene: cells in linear-id order, their centres / diagonals, 27-neighbourhoods
     keys, lin_of = tab["keys"], tab["lin_of"]
-    stored_cell = torch.full((P,), -1, dtype=torch.int64, device=device)
-    filled = [k for k in keys if ps.cells[k].cell_pts.shape[0] > 0]
-    if filled:                                           # every stored index -> its cell, three launches for the whole grid
-        idx_all = torch.cat([ps.cells[k].cell_features[:, 0] for k in filled]).long()
-        lens = torch.tensor([ps.cells[k].cell_pts.shape[0] for k in filled], dtype=torch.int64)
-        lins = torch.tensor([lin_of[k] for k in filled], dtype=torch.int64)
-        stored_cell[idx_all] = ops.h2d(torch.repeat_interleave(lins, lens), torch.int64, device)
-    sel = stored_cell >= 0
-    if use_supervision_occ_mask:
-        sel = sel & occ_mask
-    big = torch.full_like(stored_cell, n_cells)
-    visit = torch.zeros(n_cells + 1, dtype=torch.int64, device=device).scatter_(0, torch.where(visit_pts, cell_by_pos, big), 1)
-    counts = torch.zeros(n_cells + 1, dtype=torch.int64, device=device).scatter_add_(0, torch.where(sel, stored_cell, big),
-                                                                                   torch.ones_like(stored_cell))
-    # the one read-back of the pass; the number of never-seen points rides along (the tail of the field is their compaction: with the
-    # count known here, it is built without a second read-back -- torch.nonzero after the occupancy pass stalled the host until the
-    # pass had run, and the launches of everything behind it then started on an idle GPU)
-    oof_mask = (ps.out_of_field > 0.)[..., 0]
-    n_oof_t = torch.zeros(n_cells + 1, dtype=torch.int64, device=device)
-    n_oof_t[0] = oof_mask.sum()
-    host3 = torch.stack((visit, counts, n_oof_t)).cpu().numpy()
-    host, n_oof = host3[:2, :n_cells], int(host3[2, 0])
-    # ---- host: which cells run, their surface neighbourhoods (sizes are tensor shapes: no read-back), the (cell, chunk) jobs
+    # ---- host: which cells run, their surface neighbourhoods (sizes are host numbers: no read-back), the (cell, chunk) jobs
+    s_st = _store_of(ss, device)
     s_keys = keys if set(ss.cells.keys()) == set(keys) else sorted(ss.cells.keys(), key=lambda k: lin_of.get(k, 0))
-    s_len = {lin_of[k]: int(ss.cells[k].cell_pts.shape[0]) for k in s_keys}
-    s_start, o = {}, 0
-    for k in s_keys:
-        s_start[lin_of[k]] = o
-        o += s_len[lin_of[k]]
-
-    neighbours = tab["neighbours"].__getitem__
-    jobs, seg_src, seg_len = [], [], []                 # job = (cell, number of queries); surface segments in job order
-    valid_cell = torch.zeros(n_cells + 1, dtype=torch.bool)
-    for c in range(n_cells):
-        if not host[0, c]:
-            continue
-        nb = [n for n in neighbours(c) if s_len[n] > 0]
-        m_c = sum(s_len[n] for n in nb)
-        q_c = int(host[1, c])
-        if not (m_c > 2 * 2 * params.k_for_knn and q_c > 0):
-            continue
-        valid_cell[c] = True
-        for lo in range(0, q_c, chunk):
-            jobs.append((c, min(chunk, q_c - lo), m_c))
-            seg_src += [s_start[n] for n in nb]
-            seg_len += [s_len[n] for n in nb]
-    X_parts, H_parts, O_parts = [], [], []
-    if jobs:
-        J = len(jobs)
-        T = sum(q for _, q, _ in jobs)
-        tot = sum(seg_len)
-        # ---- selected proxy points grouped by cell (stable: ascending index inside a cell)
-        key = torch.where(sel & ops.h2d(valid_cell, torch.bool, device)[stored_cell.clamp(min=0)], stored_cell, big)
-        rows = torch.sort(key, stable=True).indices[:T]
-        X_sel = ps.proxy_points[rows]
-        # ---- every job's surface cloud in one gather
-        ints = ops.h2d(torch.tensor([seg_src, seg_len, [c for c, _, _ in jobs] + [0] * (len(seg_src) - J),
-                                     [q for _, q, _ in jobs] + [0] * (len(seg_src) - J), [m for _, _, m in jobs] + [0] * (len(seg_src) - J)],
-                                    dtype=torch.int64), torch.int64, device)
-        src, ln = ints[0], ints[1]
-        dst = torch.cumsum(ln, 0) - ln
-        gather = torch.arange(tot, device=device) + torch.repeat_interleave(src - dst, ln, output_size=tot)
-        S_all = torch.cat([ss.cells[k].cell_pts for k in s_keys if ss.cells[k].cell_pts.shape[0] > 0], dim=0)
-        pc_all = S_all[gather].contiguous()
-        job_cell, job_q, job_m = ints[2, :J], ints[3, :J], ints[4, :J]
-        jid = torch.arange(J, device=device)
-        cloud_of = torch.repeat_interleave(jid, job_m, output_size=tot).to(torch.int32)
-        row_job = torch.repeat_interleave(jid, job_q, output_size=T).to(torch.int32)
-        # ---- prediction boxes: cell centres in view space, 1 / (neighbourhood size x cell diagonal)   (:1468-1478)
-        if Mv_host is not None:
-            # J <= a few dozen jobs: their prediction boxes on the HOST (same fp32 arithmetic: torch CPU), one upload -- six small launches less
-            jc = [c for c, _, _ in jobs]
-            cw, dg = tab["centers_host"][jc], tab["diag_host"][jc]
-            cen_h = (torch.cat((cw, torch.ones(J, 1)), 1) @ Mv_host.reshape(4, 4))[:, :3]
-            inv_h = (1.0 / (params.prediction_neighborhood_size * dg)).float()
-            up = ops.h2d(torch.cat((cen_h.reshape(-1), inv_h, Mv_host.reshape(1, 16).expand(J, -1).reshape(-1))), torch.float32, device)
-            centers, inv_diag, MvJ = up[:3 * J].view(J, 3), up[3 * J:4 * J], up[4 * J:].view(J, 16)
-        else:
-            centers_w, diag = tab["centers"][job_cell], tab["diag"][job_cell]               # per job, gathered from the per-scene tables
-            centers = (torch.cat((centers_w, torch.ones(J, 1, device=device)), 1) @ Mv)[:, :3].contiguous()
-            inv_diag = (1.0 / (params.prediction_neighborhood_size * diag)).float().contiguous()
-            MvJ = Mv.reshape(1, 16).expand(J, -1).contiguous()
-        ops.transform_points_batched_(pc_all, MvJ, centers, inv_diag, cloud_of=cloud_of)
-        X_q = ops.transform_points_batched_(X_sel.clone().contiguous(), MvJ, centers, inv_diag, cloud_of=row_job)
-        # ---- view states -> prediction frame -> harmonics, all rows at once   (:1486-1497)
-        vs = ps.view_states[rows].view(1, T, params.n_view_state_cameras)
-        vs = su.move_view_state_to_view_space(vs, ((Mv_host if Mv_host is not None else Mv)[:3, :3].contiguous()
-                                                   if torch.is_tensor(prediction_camera) else prediction_camera),
-                                              n_elev=params.view_state_n_elev, n_azim=params.view_state_n_azim)
-        base_harmonics, h_polar, h_azim = su.get_all_harmonics_under_degree(params.harmonic_degree, params.view_state_n_elev,
-                                                                             params.view_state_n_azim, device)
-        vh = su.compute_view_harmonics(vs, base_harmonics, h_polar, h_azim, params.view_state_n_elev, params.view_state_n_azim)[0]
+    if len(s_keys) == n_cells:
+        s_len, s_start = np.diff(s_st.off), s_st.off[:-1]
+    else:                                               # a surface scene on another grid: by key
+        s_len = np.zeros(n_cells, np.int64); s_start = np.zeros(n_cells, np.int64)
+        for i_, k in enumerate(s_keys):
+            s_len[lin_of[k]] = s_st.off[i_ + 1] - s_st.off[i_]; s_start[lin_of[k]] = s_st.off[i_]
+    nbm = tab["neighbour_matrix"]                        # [n_cells, 27], -1 padded
+    nb_len = np.where(nbm >= 0, s_len[np.maximum(nbm, 0)], 0)              # surface points of every neighbour cell
+    m_cell = nb_len.sum(1)
+    run = (np.asarray(visit) != 0) & (m_cell > 2 * 2 * params.k_for_knn) & (np.asarray(counts) > 0)       # :1455-1456
+    cells_run = np.nonzero(run)[0]
+    n_chunks = -(-np.asarray(counts)[cells_run] // chunk)
+    job_cell = np.repeat(cells_run, n_chunks)                              # one job per (cell, chunk of <= 20 000 queries)
+    J = int(job_cell.size)
+    P = ps.proxy_points.shape[0]
+    T = tot = 0
+    if J:
+        lo = (np.arange(J) - np.repeat(np.cumsum(n_chunks) - n_chunks, n_chunks)) * chunk
+        job_q = np.minimum(chunk, np.asarray(counts)[job_cell] - lo).astype(np.int64)
+        job_m = m_cell[job_cell].astype(np.int64)
+        q_start = np.concatenate(([0], np.cumsum(job_q)))
+        m_start = np.concatenate(([0], np.cumsum(job_m)))
+        T, tot = int(q_start[-1]), int(m_start[-1])
+        jt = np.stack((sel_off[job_cell] + lo, q_start[:-1], m_start[:-1], np.zeros(J, np.int64)), 1).astype(np.int64)
+        # surface segments of every job: its cell's non-empty neighbours, in ascending cell order
+        seg_len = nb_len[job_cell]                                         # [J, 27]
+        keep = seg_len > 0
+        seg_job = np.nonzero(keep)[0]
+        seg_l = seg_len[keep]
+        seg_dst = np.cumsum(seg_l) - seg_l
+        st_ = np.stack((s_start[nbm[job_cell][keep]], seg_dst, seg_job, np.zeros(seg_l.size, np.int64)), 1).astype(np.int64)
+    N_out = T + n_oof
+    X_world = torch.empty((N_out, 3), dtype=torch.float32, device=device)
+    view_harmonics = torch.empty((N_out, nh), dtype=torch.float32, device=device)
+    occ_probs = torch.empty((N_out, 1), dtype=torch.float32, device=device)
+    rows = None
+    if J:
+        # ---- ONE upload: job table, segment table, per-job transform (world->view matrix, box centre in view space, 1 / (neighbourhood
+        # size x cell diagonal), :1468-1478), the bin permutation of move_view_state_to_view_space (:863-931)
+        xf = np.ascontiguousarray(prep["xf_all"][job_cell])
+        raw = np.concatenate((jt.reshape(-1).view(np.uint8), st_.reshape(-1).view(np.uint8), xf.reshape(-1).view(np.uint8),
+                              prep["perm"].view(np.uint8)))
+        tables = ops.h2d(raw, torch.uint8, device)
+        n_seg = int(st_.shape[0])
+        perm_d = tables[32 * (J + n_seg) + 80 * J:].view(torch.int32)
+        rows, row_job, X_q, pc_all = ops.field_build(tables, J, n_seg, sel, ps.proxy_points, s_st.pts, ps.view_states, perm_d,
+                                                     prep["vh_mt"], T, tot, X_world, view_harmonics)
+        vh = view_harmonics[:T]
+        occ_out = occ_probs[:T]
+        sizes_m, sizes_q = job_m.tolist(), job_q.tolist()
         # ---- occupancy of all jobs
         if use_supervision_occ_instead_of_predicted:
-            occ = ps.proxy_supervision_occ[rows]
+            if _between is not None:
+                _between()
+            occ_out.copy_(ps.proxy_supervision_occ[rows.long()])
         else:
             occ_net = getattr(macarons, "occupancy", macarons)
-            def ragged(pc_, sizes_m_, X_, vh_, sizes_q_, draws):
-                if isinstance(draws, dict):                 # index arrays drawn on the device (or handed back by a caller)
-                    return occ_net.forward_ragged(pc_, sizes_m_, X_, vh_, sizes_q_, index_arrays=draws).view(-1, 1)
-                return occ_net.forward_ragged(pc_, sizes_m_, X_, vh_, sizes_q_, perms=draws, perm_source=perm_source).view(-1, 1)
-
             if hasattr(occ_net, "forward_ragged") and world > 1:
-                sizes_m, sizes_q = [m for _, _, m in jobs], [q for _, q, _ in jobs]
+                if _between is not None:
+                    _between()
                 if ragged_perms is None:                # rank 0 draws for every job, in job order (what the 1-rank pass draws)
                     ragged_perms = (_broadcast_job_index_arrays(occ_net, sizes_m, device, group, rank) if perm_source == "device"
                                     else _broadcast_job_perms(occ_net, sizes_m, device, group, rank))
                 t0, t1 = mdist.shard_range(T, rank, world)
-                q_start = np.concatenate(([0], np.cumsum(sizes_q)))
-                m_start = np.concatenate(([0], np.cumsum(sizes_m)))
                 mine = [j for j in range(J) if q_start[j] < t1 and q_start[j + 1] > t0]
                 if mine:
                     q_l = [int(min(q_start[j + 1], t1) - max(q_start[j], t0)) for j in mine]
                     p0, p1 = int(m_start[mine[0]]), int(m_start[mine[-1] + 1])
                     draws_l = (_slice_index_arrays(occ_net, ragged_perms, sizes_m, mine[0], mine[-1] + 1) if isinstance(ragged_perms, dict)
                                else [ragged_perms[j] for j in mine])
-                    occ_l = ragged(pc_all[p0:p1].contiguous(), [sizes_m[j] for j in mine], X_q[t0:t1].contiguous(),
-                                   vh[t0:t1].contiguous(), q_l, draws_l)
+                    kw = {"index_arrays": draws_l} if isinstance(draws_l, dict) else {"perms": draws_l, "perm_source": perm_source}
+                    occ_l = occ_net.forward_ragged(pc_all[p0:p1].contiguous(), [sizes_m[j] for j in mine], X_q[t0:t1].contiguous(),
+                                                   vh[t0:t1].contiguous(), q_l, **kw).view(-1, 1)
                 else:                                   # empty row shard (T < world): no kernels, the all-gather is joined
                     occ_l = torch.zeros(0, 1, dtype=torch.float32, device=device)
-                occ = mdist.allgather_rows(occ_l, T, group)
+                occ_out.copy_(mdist.allgather_rows(occ_l, T, group))
             elif hasattr(occ_net, "forward_ragged"):
-                occ = ragged(pc_all, [m for _, _, m in jobs], X_q, vh, [q for _, q, _ in jobs], ragged_perms)
-                ragged_perms = occ_net.last_ragged_perms
+                # The jobs run in G consecutive GROUPS when their hidden draws are made here on the CPU generator (~1 ms per 400k
+                # permuted indices, inherent to the reference's stream): the first launches of EVERY group (which need no draw) are queued
+                # at once, then, while the GPU works on group g, the host draws for group g + 1 -- only the first group's draws pass with
+                # the GPU short of work.  Every job computes what it computes alone (launch shapes are chosen per cloud), so the grouping
+                # does not change a bit of the result; the draws stay in job order.
+                given = ragged_perms["groups"] if (isinstance(ragged_perms, dict) and "groups" in ragged_perms) else None
+                if given is not None:
+                    groups = [(j0, j1) for j0, j1, _ in given]
+                elif ragged_perms is None and perm_source == "host":
+                    groups = _job_groups(sizes_m)
+                else:
+                    groups = [(0, J)]
+                hdls = []
+                for gi, (j0, j1) in enumerate(groups):
+                    t0, t1, p0, p1 = int(q_start[j0]), int(q_start[j1]), int(m_start[j0]), int(m_start[j1])
+                    whole = (j0, j1) == (0, J)
+                    hdls.append(occ_net.forward_ragged_begin(pc_all if whole else pc_all[p0:p1], sizes_m[j0:j1], X_q if whole else X_q[t0:t1],
+                                                             vh if whole else vh[t0:t1], sizes_q[j0:j1], row_job=row_job if whole else None,
+                                                             arena="scone_occ_ragged" if gi == 0 else f"scone_occ_ragged_g{gi}"))
+                if _between is not None:
+                    _between()                          # phase 1 is queued; the fill's CPU draws come first, as upstream (Cell.fill, then the pass)
+                used = []
+                for gi, (j0, j1) in enumerate(groups):
+                    t0, t1 = int(q_start[j0]), int(q_start[j1])
+                    src = given[gi][2] if given is not None else ragged_perms
+                    kw = {"index_arrays": src} if isinstance(src, dict) else {"perms": src, "perm_source": perm_source}
+                    occ_net.forward_ragged_finish(hdls[gi], out=occ_out if (j0, j1) == (0, J) else occ_out[t0:t1], **kw)
+                    used.append((j0, j1, occ_net.last_ragged_perms))
+                ragged_perms = used[0][2] if len(used) == 1 else {"groups": used}
             else:                                       # any other module with the reference's call signature: job by job
-                outs, r0, p0 = [], 0, 0
-                for _, q, m in jobs:
-                    outs.append(macarons(mode='occupancy', partial_point_cloud=pc_all[p0:p0 + m][None], proxy_points=X_q[r0:r0 + q][None],
-                                         view_harmonics=vh[r0:r0 + q][None]).view(-1, 1))
+                if _between is not None:
+                    _between()
+                r0, p0 = 0, 0
+                for q, m in zip(sizes_q, sizes_m):
+                    occ_out[r0:r0 + q] = macarons(mode='occupancy', partial_point_cloud=pc_all[p0:p0 + m][None], proxy_points=X_q[r0:r0 + q][None],
+                                                  view_harmonics=vh[r0:r0 + q][None]).view(-1, 1)
                     r0, p0 = r0 + q, p0 + m
-                occ = torch.cat(outs)
             if record is not None:
                 record["ragged_perms"] = ragged_perms
-        ps.proxy_proba[rows] = occ                                                                # :1525
-        X_parts, H_parts, O_parts = [X_sel], [vh], [occ]
-    # indices of the never-seen points in ascending order, n_oof known: exclusive ranks scattered into place (no read-back)
-    pos = torch.cumsum(oof_mask, 0) - 1
-    oof_idx = torch.zeros(n_oof + 1, dtype=torch.int64, device=device).scatter_(
-        0, torch.where(oof_mask, pos, torch.full_like(pos, n_oof)), torch.arange(P, device=device))[:n_oof]
-    oof_X = ps.proxy_points[oof_idx]
-    X_world = torch.cat(X_parts + [oof_X])
-    view_harmonics = torch.cat(H_parts + [torch.zeros(len(oof_X), nh, device=device)])
-    occ_probs = torch.cat(O_parts + [ps.proxy_proba[oof_idx]])
+    elif _between is not None:
+        _between()
+    # ---- :1525 (the stored probabilities of the visited points), then the field's tail: the never-seen points in ascending order with
+    # their stored probability and zero harmonics (:1531-1537)
+    if n_oof:
+        view_harmonics[T:].zero_()
+    ops.field_finish(rows, occ_probs, T, ps.proxy_proba, sel, n_oof, ps.proxy_points, X_world[T:], occ_probs[T:])
+    if _after is not None:
+        _after()
     return X_world, view_harmonics, occ_probs
 
 

@@ -37,6 +37,45 @@ class Cell:
         self.use_feature, self.feature_dim = feature_dim > 0, feature_dim
         self.empty()
 
+    # ---- storage: a cell of a Scene is a SEGMENT of the scene's flat store (all cells' rows, cells in linear order) whenever that
+    # store is current; assigning to a cell's tensors hands every cell its own tensors back (Scene._release_store)
+    _scene, _lin, _pts, _fts = None, -1, None, None
+
+    def _served(self):
+        return self._scene is not None and self._scene._store is not None
+
+    @property
+    def cell_pts(self):
+        if self._served():
+            st = self._scene._store
+            return st.pts[int(st.off[self._lin]):int(st.off[self._lin + 1])]
+        return self._pts
+
+    @cell_pts.setter
+    def cell_pts(self, v):
+        if self._served():
+            self._scene._release_store()
+        self._pts = v
+
+    @property
+    def cell_features(self):
+        if self._served():
+            st = self._scene._store
+            return st.fts[int(st.off[self._lin]):int(st.off[self._lin + 1])]
+        return self._fts
+
+    @cell_features.setter
+    def cell_features(self, v):
+        if self._served():
+            self._scene._release_store()
+        self._fts = v
+
+    def n_points(self):
+        if self._served():
+            st = self._scene._store
+            return int(st.off[self._lin + 1] - st.off[self._lin])
+        return int(self._pts.shape[0])
+
     def empty(self):
         self.cell_pts = torch.zeros(0, 3, device=self.device)
         if self.use_feature:
@@ -64,6 +103,15 @@ class Cell:
             self.cell_features = torch.vstack((self.cell_features, fts))[idx]
 
 
+class _Store:
+    """Flat store of a Scene: every cell's points (and features), cells in linear-id order.  off: host int64 [n_cells + 1]; off_dev: the
+    same on the device."""
+    __slots__ = ("pts", "fts", "off", "off_dev")
+
+    def __init__(self, pts, fts, off, off_dev):
+        self.pts, self.fts, self.off, self.off_dev = pts, fts, off, off_dev
+
+
 class Scene:
     def __init__(self, x_min, x_max, grid_l, grid_w, grid_h, cell_capacity, cell_resolution, n_proxy_points, device,
                  view_state_n_elev=7, view_state_n_azim=2 * 7, feature_dim=0, score_threshold=1.):
@@ -73,6 +121,7 @@ class Scene:
         self.l, self.w, self.h = ext[0] / grid_l, ext[1] / grid_w, ext[2] / grid_h
         self.device, self.feature_dim = device, feature_dim
         self.cells = {}
+        self._store = None
         for i in range(grid_l):
             for j in range(grid_w):
                 for k in range(grid_h):
@@ -80,6 +129,7 @@ class Scene:
                                            self.x_min[2] + (0.5 + k) * self.h]).to(device)
                     cell = Cell(center, self.l, self.w, self.h, cell_capacity, cell_resolution, device, feature_dim)
                     cell_capacity, cell_resolution = cell.capacity, cell.resolution      # derived once, shared by all cells
+                    cell._scene, cell._lin = self, (i * grid_w + j) * grid_h + k
                     self.cells[_key((i, j, k))] = cell
         self.cell_capacity, self.cell_resolution = cell_capacity, cell_resolution
         self.n_proxy_points = n_proxy_points
@@ -148,99 +198,167 @@ class Scene:
             t = self._table = (order, lo, hi)
         return t
 
+    # ---- the flat store ----
+    def flat_store(self):
+        """The cells' points / features as ONE pair of tensors (cells in linear order) + offsets; built from the cells' own tensors when
+        something assigned to them since the last fill."""
+        if self._store is None:
+            from .. import ops
+            cells, _, _ = self._cell_table()
+            lens = [int(c._pts.shape[0]) for c in cells]
+            off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+            dev = self.device
+            pts = torch.cat([c._pts for c, n in zip(cells, lens) if n] + [torch.zeros(0, 3, device=dev)]).contiguous()
+            fts = None
+            if self.feature_dim > 0:
+                fts = torch.cat([c._fts.to(torch.float32).view(-1, self.feature_dim) for c, n in zip(cells, lens) if n]
+                                + [torch.zeros(0, self.feature_dim, device=dev)]).contiguous()
+            self._store = _Store(pts, fts, off, ops.h2d(off, torch.int64, dev))
+            for c in cells:
+                c._pts = c._fts = None
+        return self._store
+
+    def _release_store(self):
+        """Every cell takes its segment as a tensor of its own (somebody is about to assign to a cell)."""
+        st, self._store = self._store, None
+        if st is None:
+            return
+        for c in self._cell_table()[0]:
+            o0, o1 = int(st.off[c._lin]), int(st.off[c._lin + 1])
+            c._pts = st.pts[o0:o1]
+            if st.fts is not None:
+                c._fts = st.fts[o0:o1]
+
+    def fill_cells_begin(self, pts, features=None, n_point_min=0, valid=None):
+        """Device part of fill_cells (ops.scene_fill_begin): nothing returns to the host.  -> handle for fill_cells_end; its `.counts`
+        (device int64) holds, per cell, the number of candidates and of admitted candidates."""
+        from .. import ops
+        cells, lo, hi = self._cell_table()
+        st = self.flat_store()
+        with_fts = self.feature_dim > 0 and features is not None
+        h = ops.scene_fill_begin(pts, valid, self._consts(self.device)["gc"], (self.grid_l, self.grid_w, self.grid_h), lo, hi, st.pts, st.off_dev,
+                                 cells[0].resolution, n_point_min, features.reshape(pts.shape[0], self.feature_dim) if with_fts else None)
+        return h
+
+    def fill_counts(self, host_counts):
+        """(candidates per cell, admitted per cell) out of a host copy of a fill handle's counts."""
+        nk = self.grid_l * self.grid_w * self.grid_h
+        return host_counts[:nk], host_counts[2 * nk + 3:3 * nk + 3]
+
+    def fill_overflows(self, cand, adm, n_point_min=0):
+        """True when a touched cell would exceed its capacity: the subset Cell.fill keeps is then random (the draws decide WHICH points
+        stay), otherwise only their order is."""
+        st = self.flat_store()
+        cap = self._cell_table()[0][0].capacity
+        b_len = np.diff(st.off)
+        return bool(np.any((cand > n_point_min) & (b_len + adm > cap)))
+
+    def fill_cells_draw(self, h, cand, adm, n_point_min=0, group=None, perm_source="host"):
+        """Host part of fill_cells, first half: the touched cells' torch.randperm draws on the CPU generator in cell order (Cell.fill
+        :2573 -- the reference's draws).  -> plan for fill_cells_apply (None: no cell was touched).  Nothing is launched."""
+        from .. import dist as mdist
+        cells, _, _ = self._cell_table()
+        st = self.flat_store()
+        cap = cells[0].capacity
+        b_off = st.off
+        b_len = np.diff(b_off)
+        adm = np.asarray(adm, np.int64)
+        touched = np.asarray(cand) > n_point_min                # Cell.fill returns before the random subset (:2562): no draw
+        if not touched.any():
+            return None
+        n_comb = b_len + adm
+        n_keep = np.where(touched, np.minimum(n_comb, cap), b_len)
+        world, rank_ = mdist.group_world_rank(group)           # group=None: local, whatever process groups exist
+        plan = {"h": h, "touched": touched, "n_keep": n_keep, "adm": adm, "b_len": b_len, "group": group, "world": world,
+                "perm_source": perm_source, "pm": None}
+        if perm_source != "device" and rank_ == 0:
+            # torch.randperm(n_comb)[:capacity] per touched cell, cell order, CPU generator (:2573) -- the reference's draws, made by one
+            # call into the C++ extension (the same at::randperm calls without ~70 dispatcher round trips)
+            from .host import batched_draws_ok
+            t_idx = np.nonzero(touched)[0]
+            if batched_draws_ok():
+                from .. import torch_ops  # noqa: F401
+                plan["pm"] = torch.ops.macarons.randperm_prefixes([int(n_comb[c]) for c in t_idx], [int(cap)] * len(t_idx)).numpy()
+            else:                                                       # torch.randperm was replaced from Python: honour it
+                plan["pm"] = np.concatenate([torch.randperm(int(n_comb[c]))[:cap].numpy() for c in t_idx])
+        return plan
+
+    def fill_cells_apply(self, plan):
+        """Host part of fill_cells, second half: the draws become ONE gather that writes the scene's new flat store."""
+        from .. import ops
+        from .. import dist as mdist
+        if plan is None:
+            return
+        h, touched, n_keep, adm, b_len = plan["h"], plan["touched"], plan["n_keep"], plan["adm"], plan["b_len"]
+        group, world = plan["group"], plan["world"]
+        cells, _, _ = self._cell_table()
+        n_cells, dev = len(cells), self.device
+        st = self.flat_store()
+        b_off = st.off
+        n_store = int(b_off[-1])
+        adm_off = np.concatenate(([0], np.cumsum(adm))).astype(np.int64)
+        new_off = np.concatenate(([0], np.cumsum(n_keep))).astype(np.int64)
+        n_new = int(new_off[-1])
+        F = self.feature_dim
+        if plan["perm_source"] == "device":
+            # every cell's rows of the virtual table [store | admitted]: a random order per touched cell by ONE sort of (cell + uniform)
+            # float64 keys (the uniform capped below 1: cell + u never rounds up to the next cell), the stored order for the others
+            tab = ops.h2d(np.concatenate([b_len, adm, n_keep, b_off[:-1], n_store + adm_off[:-1], touched.astype(np.int64)]), torch.int64, dev)
+            d_nb, d_na, d_nk, d_b0, d_a0, d_t = (tab[k_ * n_cells:(k_ + 1) * n_cells] for k_ in range(6))
+            d_n = d_nb + d_na * d_t
+            total = int((b_len + adm * touched).sum())
+            off = torch.cumsum(d_n, 0) - d_n
+            seg = torch.repeat_interleave(torch.arange(n_cells, device=dev), d_n, output_size=total)
+            local = torch.arange(total, device=dev) - off[seg]
+            comb = torch.where(local < d_nb[seg], d_b0[seg] + local, d_a0[seg] + local - d_nb[seg])
+            u = torch.rand(total, dtype=torch.float64, device=dev).clamp_(max=1.0 - 2.0 ** -30)
+            u = torch.where(d_t[seg] > 0, u, local.double() / d_n[seg].double().clamp(min=1.0) * (1.0 - 2.0 ** -30))
+            order = torch.argsort(seg.double() + u)
+            g = comb[order][local < d_nk[seg]]                   # (sorted position p of segment s has rank p - off[s] = local[p])
+            if world > 1:
+                mdist.broadcast(g, 0, group)
+            new_pts, new_fts = ops.scene_fill_gather(g, h, st.pts, st.fts, n_store, F)
+        else:
+            # ONE upload: the cells' tables and the permutation prefixes; the gather maps every new row to its source on the device
+            n_pm_cell = np.where(touched, n_keep, 0)
+            pm_off = np.concatenate(([0], np.cumsum(n_pm_cell))).astype(np.int64)
+            n_pm = int(pm_off[-1])
+            pm = plan["pm"] if plan["pm"] is not None else np.zeros(n_pm, np.int64)
+            tabs = np.concatenate([new_off, b_off, adm_off, pm_off, np.concatenate((touched.astype(np.int64), [0]))])
+            pm32 = np.ascontiguousarray(pm, dtype=np.int32)
+            if n_pm % 2:
+                pm32 = np.concatenate((pm32, np.zeros(1, np.int32)))
+            buf = ops.h2d(np.concatenate((tabs, pm32.view(np.int64))), torch.int64, dev)
+            if world > 1:                                       # rank 0's draws for every replica
+                mdist.broadcast(buf, 0, group)
+            new_pts, new_fts = ops.scene_fill_gather_perm(buf, n_pm, n_cells, n_new, h, st.pts, st.fts, n_store, F)
+        from .. import ops as _o
+        self._store = _Store(new_pts, new_fts, new_off, _o.h2d(new_off, torch.int64, dev))
+
+    def fill_cells_end(self, h, cand, adm, n_point_min=0, group=None, perm_source="host"):
+        """Host part of fill_cells (fill_cells_draw + fill_cells_apply)."""
+        self.fill_cells_apply(self.fill_cells_draw(h, cand, adm, n_point_min, group, perm_source))
+
     def fill_cells(self, pts, features=None, n_point_min=0, group=None, perm_source="host", valid=None):
         """Scene.fill_cells (macarons_utils.py:2727-2737) over Cell.fill (:2551-2577) for ALL touched cells at once: upstream loops
-        the cells from Python, each testing every point against its box and its store.  Here one stable sort groups the points by
-        cell (floor rule, then the strict box test of that cell), ONE segmented fp64 nearest-distance launch runs every cell's
-        admission test against its own store, a second stable sort compacts the admitted points, and the host -- after reading
-        two integers per cell -- draws each touched cell's torch.randperm on the CPU generator in cell order (the reference's
-        draws) and turns them into one gather.  A point exactly on a cell face belongs to no cell, as upstream.
-        `group` (a torch.distributed group whose ranks hold replicas of this scene and call together): the permutations are rank 0's,
-        broadcast once -- every rank drawing its own would let the replicas diverge.
+        the cells from Python, each testing every point against its box and its store.  Here (fill_cells_begin) a counting sort groups
+        the points by cell (floor rule, then the strict box test of that cell), ONE segmented fp64 nearest-distance launch runs every
+        cell's admission test against its own store, a second grouping compacts the admitted points, and (fill_cells_end) the host --
+        after reading two integers per cell -- draws each touched cell's torch.randperm on the CPU generator in cell order (the
+        reference's draws) and turns them into one gather.  A point exactly on a cell face belongs to no cell, as upstream.
+        `group` (a torch.distributed group whose ranks hold replicas of this scene and call together; None = a local call whatever
+        process groups exist): the permutations are rank 0's, broadcast once -- every rank drawing its own would let the replicas
+        diverge.
         `valid` (bool [N], optional): only these rows of pts are offered -- the same as fill_cells(pts[valid], features[valid]) without
         the read-back that boolean indexing costs.
         perm_source="device" (opt-in): every touched cell's random subset / order comes from the device generator in ONE segmented
         sort instead of one torch.randperm per cell on the host (72 draws = 0.7 ms of a MACARONS decision): statistically the same,
         not the reference's CPU-generator stream."""
-        from .. import ops
-        dev = self.device
-        N = pts.shape[0]
-        if N == 0:
+        if pts.shape[0] == 0:
             return
-        cells, lo, hi = self._cell_table()
-        n_cells = len(cells)
-        with_fts = self.feature_dim > 0 and features is not None
-        # cell lookup + scene box + Cell.fill's strict box tests + the validity mask -> one key per point (n_cells = not offered), one launch
-        key = ops.cell_keys(pts, self._consts(dev)["gc"], (self.grid_l, self.grid_w, self.grid_h), lo, hi, valid)
-        order = torch.sort(key, stable=True).indices
-        key_s = key[order]
-        cand, a_off = ops.key_histogram(key, n_cells)                                             # counts per cell (+ rejected), their offsets
-        b_len = [int(c.cell_pts.shape[0]) for c in cells]
-        b_off_h = np.concatenate(([0], np.cumsum(b_len))).astype(np.int64)
-        B_all = torch.cat([c.cell_pts for c in cells if c.cell_pts.shape[0] > 0] + [torch.zeros(0, 3, device=dev)])
-        A_s = pts[order].contiguous()
-        d = ops.min_dist_segmented(A_s, a_off[:n_cells + 1], B_all.contiguous(), ops.h2d(b_off_h, torch.int64, dev), max_a=N)
-        key2 = ops.admit_keys(d, key_s, cand, cells[0].resolution, n_point_min, n_cells)          # fp64 compare (:2566-2567)
-        order2 = torch.sort(key2, stable=True).indices
-        adm, _ = ops.key_histogram(key2, n_cells)
-        host = torch.stack((cand[:n_cells], adm[:n_cells])).cpu().numpy()                         # the one read-back
-        n_adm = int(host[1].sum())
-        add_pts = A_s[order2[:n_adm]]
-        src = torch.cat((B_all, add_pts))
-        if with_fts:
-            F_all = torch.cat([c.cell_features for c in cells if c.cell_pts.shape[0] > 0] + [torch.zeros(0, self.feature_dim, device=dev)])
-            src_f = torch.cat((F_all, features[order][order2[:n_adm]].to(F_all.dtype).view(-1, self.feature_dim)))
-        adm_off = np.concatenate(([0], np.cumsum(host[1])))
-        from .. import dist as mdist
-        world, rank_ = mdist.group_world_rank(group)        # group=None: local, whatever process groups exist
-        draws_here = rank_ == 0
-        gidx, touched = [], []
-        device_perm = perm_source == "device"
-        seg_len, seg_b0, seg_a0 = [], [], []
-        for c in range(n_cells):
-            if host[0, c] <= n_point_min:
-                continue                                  # Cell.fill returns before the random subset (:2562): no draw
-            n_comb = int(b_off_h[c + 1] - b_off_h[c] + adm_off[c + 1] - adm_off[c])
-            n_keep = min(n_comb, cells[c].capacity)
-            if device_perm:
-                seg_len.append((int(b_off_h[c + 1] - b_off_h[c]), int(adm_off[c + 1] - adm_off[c]), n_keep))
-                seg_b0.append(int(b_off_h[c])); seg_a0.append(int(b_off_h[-1] + adm_off[c]))
-            elif draws_here:
-                comb = np.concatenate((np.arange(b_off_h[c], b_off_h[c + 1]), b_off_h[-1] + np.arange(adm_off[c], adm_off[c + 1])))
-                perm = torch.randperm(n_comb)[:cells[c].capacity].numpy()                         # :2573, CPU generator, cell order
-                gidx.append(comb[perm])
-            touched.append((c, n_keep))
-        if not touched:
-            return
-        if device_perm:
-            # comb of every touched cell = its stored rows then its admitted rows (indices into `src`); a random order of each segment by
-            # ONE sort of (segment + uniform) float64 keys; the first n_keep of every segment are kept
-            nb, na, nk = (np.asarray([t_[k_] for t_ in seg_len], np.int64) for k_ in range(3))
-            tab = ops.h2d(np.concatenate([nb, na, nk, np.asarray(seg_b0, np.int64), np.asarray(seg_a0, np.int64)]), torch.int64, dev)
-            S_ = len(seg_len)
-            d_nb, d_na, d_nk, d_b0, d_a0 = (tab[k_ * S_:(k_ + 1) * S_] for k_ in range(5))
-            d_n = d_nb + d_na
-            total = int((nb + na).sum())
-            off = torch.cumsum(d_n, 0) - d_n
-            seg = torch.repeat_interleave(torch.arange(S_, device=dev), d_n, output_size=total)
-            local = torch.arange(total, device=dev) - off[seg]
-            comb = torch.where(local < d_nb[seg], d_b0[seg] + local, d_a0[seg] + local - d_nb[seg])
-            order = torch.argsort(seg.double() + torch.rand(total, dtype=torch.float64, device=dev))
-            g = comb[order][local < d_nk[seg]]            # (sorted position p of segment s has rank p - off[s] = local[p])
-        elif draws_here:
-            g = ops.h2d(np.concatenate(gidx), torch.int64, dev)
-        else:
-            g = torch.empty(sum(n for _, n in touched), dtype=torch.int64, device=dev)
-        if world > 1:
-            mdist.broadcast(g, 0, group)
-        new_pts = src[g]
-        new_fts = src_f[g] if with_fts else None
-        o = 0
-        for c, n in touched:
-            cells[c].cell_pts = new_pts[o:o + n]
-            if with_fts:
-                cells[c].cell_features = new_fts[o:o + n]
-            o += n
+        h = self.fill_cells_begin(pts, features, n_point_min, valid)
+        cand, adm = self.fill_counts(h.counts.cpu().numpy())                                       # the one read-back
+        self.fill_cells_end(h, cand, adm, n_point_min, group, perm_source)
 
     def get_pt_cloud_from_cells(self, cell_indices, return_features=True):
         with_fts = return_features and self.feature_dim > 0
@@ -312,18 +430,13 @@ class Scene:
                                        self.out_of_field, return_sgn=return_signed_distances)
 
     def set_all_features_to_value(self, value):
-        """:2931-2941.  One fill for the whole scene (every cell's feature tensor becomes a view of it): upstream's loop is two
-        launches per non-empty cell -- 46 launches of 2 us each, host-bound, for the 23 surface cells of the bench scene."""
+        """:2931-2941.  One fill for the whole scene (the flat store's feature table is replaced): upstream's loop is two launches per
+        non-empty cell -- 46 launches of 2 us each, host-bound, for the 23 surface cells of the bench scene."""
         if self.feature_dim <= 0:
             return
-        cells = [c for c in self.cells.values() if len(c.cell_features) > 0]
-        if not cells:
-            return
-        sizes = [int(c.cell_features.shape[0]) for c in cells]
-        like = cells[0].cell_features
-        flat = torch.full((sum(sizes), self.feature_dim), float(value), dtype=like.dtype, device=like.device)
-        for c, part in zip(cells, torch.split(flat, sizes)):
-            c.cell_features = part
+        st = self.flat_store()
+        if st.fts.shape[0]:
+            st.fts = torch.full_like(st.fts, float(value))
 
     # ---- coverage metrics (macarons_utils.py:2987-3056): one segmented fp64 nearest-distance launch over all cells ----
     def _csr(self, clouds):

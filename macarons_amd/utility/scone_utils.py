@@ -127,13 +127,10 @@ def view_space_bin_indices(X_cam_inv, n_elev, n_azim):
     return idx_elev.long() * n_azim + idx_azim.long()
 
 
-def move_view_state_to_view_space(view_state, fov_camera, n_elev, n_azim):
-    """"Rotate" the view-state vectors into a camera's view space (scone_utils.py:863-931): view_state [n_cloud, seq_len,
-    n_elev*n_azim] -> same shape, column v taken from the bin the v-th grid direction lands in after the inverse
-    world-to-view transform.  `fov_camera`: the reference's camera object (its get_world_to_view_transform().inverse()
-    .transform_points and get_camera_center are called exactly as the reference does; PyTorch3D stays outside the kernels)
-    or the 3x3 world-to-view rotation R of the row-vector convention X_view = X_world R + T (a CPU tensor costs nothing; a device
-    tensor is read back)."""
+def view_space_bin_permutation(fov_camera, n_elev, n_azim, device="cpu"):
+    """The bin permutation of move_view_state_to_view_space (scone_utils.py:863-931) as int64 indices on the host: column v of the
+    rotated view state comes from bin indices[v].  `fov_camera`: see move_view_state_to_view_space; `device`: where a camera object's
+    transform runs."""
     n_view = n_elev * n_azim
     elev = torch.Tensor([-90. + (i + 1) / (n_elev + 1) * 180. for i in range(n_elev) for j in range(n_azim)])
     azim = torch.Tensor([360. * j / n_azim for i in range(n_elev) for j in range(n_azim)])
@@ -141,9 +138,18 @@ def move_view_state_to_view_space(view_state, fov_camera, n_elev, n_azim):
     if torch.is_tensor(fov_camera):
         X_inv = X_ref @ fov_camera.detach().to("cpu", torch.float32).view(3, 3).T
     else:
-        dev = view_state.device
-        X_inv = fov_camera.get_world_to_view_transform().inverse().transform_points(X_ref.to(dev)) - fov_camera.get_camera_center()
-    indices = view_space_bin_indices(X_inv.reshape(-1, 3), n_elev, n_azim)
+        X_inv = fov_camera.get_world_to_view_transform().inverse().transform_points(X_ref.to(device)) - fov_camera.get_camera_center()
+    return view_space_bin_indices(X_inv.reshape(-1, 3), n_elev, n_azim)
+
+
+def move_view_state_to_view_space(view_state, fov_camera, n_elev, n_azim):
+    """"Rotate" the view-state vectors into a camera's view space (scone_utils.py:863-931): view_state [n_cloud, seq_len,
+    n_elev*n_azim] -> same shape, column v taken from the bin the v-th grid direction lands in after the inverse
+    world-to-view transform.  `fov_camera`: the reference's camera object (its get_world_to_view_transform().inverse()
+    .transform_points and get_camera_center are called exactly as the reference does; PyTorch3D stays outside the kernels)
+    or the 3x3 world-to-view rotation R of the row-vector convention X_view = X_world R + T (a CPU tensor costs nothing; a device
+    tensor is read back)."""
+    indices = view_space_bin_permutation(fov_camera, n_elev, n_azim, view_state.device)
     return ops.gather_columns(view_state.contiguous(), indices)
 
 

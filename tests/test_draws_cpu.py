@@ -1,0 +1,45 @@
+"""The batched hidden draws (csrc_torch/macarons_torch.cpp: randperm_prefixes, scone_occ_draws) make the reference's torch.randperm
+calls -- same values, same generator state afterwards -- and lay the indices out as SconeOcc.forward_ragged / Scene.fill_cells need."""
+import contextlib
+import importlib
+import io
+
+import numpy as np
+import torch
+
+
+def test_randperm_prefixes_is_the_loop_of_torch_randperm():
+    import macarons_amd.torch_ops  # noqa: F401
+    for seed, spec in ((9, ((10, 4), (5000, 100000), (7, 7), (1, 1), (20000, 1000))), (1, ((3, 0), (2, 5)))):
+        torch.manual_seed(seed)
+        want = torch.cat([torch.randperm(n)[:k] for n, k in spec])
+        after = torch.randperm(11)
+        torch.manual_seed(seed)
+        got = torch.ops.macarons.randperm_prefixes([n for n, _ in spec], [k for _, k in spec])
+        assert torch.equal(got, want) and torch.equal(torch.randperm(11), after)
+
+
+def test_scone_occ_draws_are_draw_perms_job_by_job():
+    import macarons_amd.torch_ops  # noqa: F401
+    M = importlib.import_module("macarons_amd.networks.SconeOcc")
+    with contextlib.redirect_stdout(io.StringIO()):
+        occ = M.SconeOcc()
+    sizes = [700, 2300, 130, 5000, 1024, 27000, 65, 2048, 2049]
+    sz = [occ.scale_sizes(m) for m in sizes]
+    J, Lg = len(sizes), occ.seq_len
+    torch.manual_seed(3)
+    perms = [occ.draw_perms(m) for m in sizes]                     # SconeOcc.py:269, :311 -- three torch.randperm per forward
+    after = torch.randperm(5)
+    off0 = np.concatenate(([0], np.cumsum(sizes)))
+    g_idx, g_len, idx1, idx2, off1, off2 = np.zeros((J, Lg), np.int64), np.zeros(J, np.int64), [], [], [0], [0]
+    for j, (p0, p1, p2) in enumerate(perms):
+        p0, p1, p2 = np.asarray(p0), np.asarray(p1), np.asarray(p2)
+        assert len(p1) == sz[j][1] and len(p2) == sz[j][2]
+        n0 = min(len(p0), Lg)
+        g_idx[j, :n0] = off0[j] + p0[:n0]; g_idx[j, n0:] = off0[j]; g_len[j] = n0
+        idx1.append(off0[j] + p1); idx2.append(off1[-1] + p2)
+        off1.append(off1[-1] + len(p1)); off2.append(off2[-1] + len(p2))
+    want = np.concatenate([g_idx.reshape(-1), np.concatenate(idx1), np.concatenate(idx2), off1, off2, g_len])
+    torch.manual_seed(3)
+    got = torch.ops.macarons.scone_occ_draws([s[0] for s in sz], [s[1] for s in sz], [s[2] for s in sz], Lg)
+    assert np.array_equal(got.numpy(), want) and torch.equal(torch.randperm(5), after)

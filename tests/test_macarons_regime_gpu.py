@@ -141,7 +141,7 @@ def test_macarons_wrapper_matches_reference(dev):
         m.compute_visibility_gains(pts=T(g["pts"], dev), harmonics=T(g["harm"], dev), X_cam=T(g["cams"], dev))
 
 
-def test_scene_occupancy_field_matches_reference(dev):
+def test_scene_occupancy_field_matches_reference(dev, monkeypatch):
     """compute_scene_occupancy_probability_field on macarons_amd.utility.scene.Scene objects vs the golden the reference function
     produced on its own Scene / Cell objects (tests/golden/make_golden.py: gen_occ_field): identical points in identical order,
     view harmonics 1e-5, occupancies and the updated proxy_proba at 1e-4 (the hidden randperm draws replay from the seed)."""
@@ -174,6 +174,21 @@ def test_scene_occupancy_field_matches_reference(dev):
     scale = np.abs(g["occ_probs"]).max()
     assert np.abs(O.cpu().numpy() - g["occ_probs"]).max() < 1e-4 * scale
     assert np.abs(proxy.proxy_proba.cpu().numpy() - g["proxy_proba"]).max() < 1e-4 * scale
+    # the jobs in three groups (the host draws of group g + 1 overlap the GPU work of group g) or in one: the same bits, the same draws
+    for n_groups in ("3", "1"):
+        monkeypatch.setenv("MCR_FIELD_GROUPS", n_groups)
+        torch.manual_seed(int(g["seed"]))
+        rec = {}
+        with torch.no_grad():
+            X2, H2, O2 = mu.compute_scene_occupancy_probability_field(params, m, None, surface, proxy, dev, prediction_camera=T(g["Mpred"][0], dev),
+                                                                      record=rec)
+        assert torch.equal(X2, X) and torch.equal(H2, H) and torch.equal(O2, O), n_groups
+        assert ("groups" in rec["ragged_perms"]) == (n_groups == "3")
+        with torch.no_grad():                                   # a repeat with the recorded draws (what the range-guard fallback does)
+            _, _, O3 = mu.compute_scene_occupancy_probability_field(params, m, None, surface, proxy, dev, prediction_camera=T(g["Mpred"][0], dev),
+                                                                    ragged_perms=rec["ragged_perms"])
+        assert torch.equal(O3, O)
+    monkeypatch.delenv("MCR_FIELD_GROUPS")
     # the grid bookkeeping itself: cell lookup and Cell.fill through Scene.fill_cells reproduce the reference's cells
     s2 = Scene(x_min, x_max, *grid, cell_capacity=500, cell_resolution=0.2, n_proxy_points=n, device=dev)
     torch.manual_seed(4000)

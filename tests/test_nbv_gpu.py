@@ -195,6 +195,7 @@ def test_sharded_step_path_through_rccl_single_rank(dev, monkeypatch):
         assert torch.equal(a["occ"], b["occ"]) and torch.equal(a["gains"], b["gains"])
         assert int(a["nbv_idx"]) == int(b["nbv_idx"]) == int(g["nbv_idx"]) and float(a["max_gain"]) == float(b["max_gain"])
         c = nbv_step(*args, group=dist.group.WORLD)          # uniforms drawn + broadcast inside
+        torch.manual_seed(int(g["seed"]))
         d = nbv_step(*args, samples=T(g["samples"], dev))    # group=None: local even with a process group up (no exchange path)
         assert "cam_range" not in d or d["cam_range"] == (0, 20)
         assert torch.equal(a["gains"], d["gains"])

@@ -17,7 +17,9 @@ def wrap(mod, name):
 for m, n in ((mu, "compute_scene_occupancy_probability_field"), (mu, "predict_coverage_gain_for_cameras"), (sc.Scene, "fill_cells"),
              (sc.Scene, "update_from_depth"), (sc.Scene, "set_all_features_to_value"), (_Occ, "forward_ragged"), (_Occ, "draw_perms"),
              (_ops, "scone_occ_forward_ragged"), (_ops, "scone_vis_forward"), (_ops, "sample_proxy_batched"), (_ops, "points_in_fov"),
-             (mu, "macarons_nbv_decision")):
+             (mu, "macarons_nbv_decision"), (sc.Scene, "fill_cells_begin"), (sc.Scene, "fill_cells_end"), (mu, "_field_select"),
+             (_Occ, "forward_ragged_begin"), (_Occ, "forward_ragged_finish"), (_ops, "field_build"), (_ops, "field_finish"),
+             (_ops, "uniform_rows"), (_ops, "h2d"), (_ops, "camera_boxes"), (_ops, "best_record")):
     wrap(m, n)
 r = bench.measure_macarons_step(torch.device("cuda:0"))
 print("p50 ms", r["p50_ms"])
