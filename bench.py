@@ -575,10 +575,16 @@ def timed_scorer_loop(step, finish, steps, warmup, dev, dist):
         out = step()
     out = finish(out)
     ev1.record()
+    if os.environ.get("MCR_BENCH_SPIN_SYNC", "1") != "0":
+        # hipDeviceSynchronize may put the host thread to sleep and be woken by an interrupt tens of microseconds after the last kernel
+        # retired -- 5 us per step of a 20-step run; polling the event notices the end within a microsecond, the synchronize behind it
+        # (still there: the contract's bracket) then returns at once
+        while not ev1.query():
+            pass
     torch.cuda.synchronize()
-    if dist is not None:
+    if dist is not None:                                    # (one rank: the synchronize above already is the closing bracket)
         dist.barrier()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     wall = max_over_ranks(time.perf_counter() - t0, dev, dist)
     return wall, ev0.elapsed_time(ev1), out
 
@@ -643,21 +649,25 @@ def main():
     # the scorer as the product exposes it: torch.ops.macarons.sh_coverage_gain of the C++ TORCH_LIBRARY extension (what
     # SconeVis.compute_coverage_gain calls); the ctypes wrapper of the same C entry point when a non-default occupancy is asked for
     scorer_entry = "torch.ops.macarons.sh_coverage_gain (libmacarons_torch.so -> mcr_sh_coverage_gain)"
+    # one step = the gains of every camera + the decision (torch.max over them): torch.ops.macarons.sh_coverage_gain_best -- ONE
+    # dispatcher call for the three launches (gain kernel, deterministic reduce, arg-max record)
+    scorer_entry = ("torch.ops.macarons.sh_coverage_gain_best (libmacarons_torch.so -> mcr_sh_coverage_gain_best = mcr_sh_coverage_gain, "
+                    "what SconeVis.compute_coverage_gain calls, + the arg-max record)")
     if args.waves_per_simd == 0:
         import macarons_amd.torch_ops  # noqa: F401
-        score = lambda p_, h_, c_: torch.ops.macarons.sh_coverage_gain(p_, h_, c_, True)
+        score_best = lambda p_, h_, c_: torch.ops.macarons.sh_coverage_gain_best(p_, h_, c_, True)
     else:
-        scorer_entry = "macarons_amd.ops.sh_coverage_gain (ctypes -> mcr_sh_coverage_gain)"
-        score = lambda p_, h_, c_: ops.sh_coverage_gain(p_, h_, c_, True, args.waves_per_simd)
+        scorer_entry = "macarons_amd.ops.sh_coverage_gain_best (ctypes -> mcr_sh_coverage_gain_best)"
+        score_best = lambda p_, h_, c_: ops.sh_coverage_gain_best(p_, h_, c_, True, args.waves_per_simd)
 
     def scorer_run(pts, harm, cams, cam_offset, steps, warmup):
         pipe = mdist.PipelinedBest(1, dev, batch=16, depth=3) if dist is not None else None
 
         def step():
-            gains = score(pts, harm, cams)
+            gains, record = score_best(pts, harm, cams)    # record [B,2] = (max gain, arg-max camera): the decision (torch.max semantics)
             if pipe is not None:                           # records of 16 decisions per all-gather, on a side stream
                 return pipe.submit(gains, cam_offset)
-            return ops.best_record(gains)                  # [B,2] = (max gain, arg-max camera): the decision (torch.max semantics)
+            return record
 
         def finish(handle):
             if pipe is None:
@@ -739,7 +749,7 @@ def main():
         step_ms = dev_ms / args.steps              # device time of one whole step (gain + reduce + decision record)
         alg_flop = N * C * FLOP_PER_PAIR
         achieved = alg_flop / (kern_ms * 1e-3) / 1e12
-        pmc_name = next((n_ for n_ in ("r04_scorer_pmc.json", "r03_scorer_pmc.json", "r02_scorer_pmc.json", "r01_scorer_pmc.json") if pmc_profile(n_)), None)
+        pmc_name = next((n_ for n_ in ("r05_scorer_pmc.json", "r04_scorer_pmc.json", "r03_scorer_pmc.json", "r02_scorer_pmc.json", "r01_scorer_pmc.json") if pmc_profile(n_)), None)
         pmc = pmc_profile(pmc_name) if pmc_name else {}
         valu = (pmc.get("per_dispatch_mean") or {}).get("SQ_INSTS_VALU")
         traffic, traffic_source = ((None, "skipped (--no-pmc / N > 1)") if (args.no_pmc or world > 1 or os.environ.get("MCR_BENCH_NO_PMC"))

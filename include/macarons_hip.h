@@ -43,6 +43,12 @@ int mcr_sh_coverage_gain_partials(const float* pts, int pts_dim, const float* ha
                                   int64_t C, int use_sigmoid, int waves_per_simd, void* workspace, size_t workspace_bytes,
                                   void* stream);
 
+/* mcr_sh_coverage_gain + the decision behind it (testers/shapenet.py:172: torch.max over the cameras) in one call: record [B,2] =
+ * (max_c gains[b,c], first arg-max camera as fp32; a NaN gain wins like torch.max; C < 2^24). */
+int mcr_sh_coverage_gain_best(const float* pts, int pts_dim, const float* harmonics, const float* cams, float* gains, float* record,
+                              int64_t B, int64_t N, int64_t C, int use_sigmoid, int waves_per_simd, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* Replaces SconeVis.compute_visibilities (SconeVis.py:164-208) == Macarons.compute_visibility_gains
  * (macarons/networks/Macarons.py:138-178): the same without the mean.  vis [B,C,N]. */
 int mcr_sh_visibilities(const float* pts, int pts_dim, const float* harmonics, const float* cams, float* vis,

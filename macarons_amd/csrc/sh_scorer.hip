@@ -266,6 +266,37 @@ __global__ __launch_bounds__(256) void sh_reduce_kernel(const float* __restrict_
     if (threadIdx.x == 0) gains[(size_t)b * C + c] = (float)((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])) * inv_n;
 }
 
+// The decision behind the gains (testers/shapenet.py:172: torch.max over the cameras): record[b] = (max_c gains[b][c], first arg-max as
+// fp32) with torch.max's ordering -- NaN beats every number (the first NaN wins), ties go to the lower index.  One block per cloud.
+__global__ __launch_bounds__(256) void sh_best_kernel(const float* __restrict__ gains, int C, float* __restrict__ record) {
+    __shared__ float s_v[4], s_i[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    float bv = -__builtin_inff(), bi = 3.0e38f;
+    bool first = true;
+    auto before = [](float v, float i, float ov, float oi) {          // (v, i) precedes (ov, oi)
+        const bool vn = v != v, on = ov != ov;
+        return vn != on ? vn : (!vn && v != ov ? v > ov : i < oi);
+    };
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float g = gains[(size_t)b * C + c];
+        if (first || before(g, (float)c, bv, bi)) { bv = g; bi = (float)c; }
+        first = false;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64), oi = __shfl_xor(bi, o, 64);
+        if (before(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { s_v[threadIdx.x >> 6] = bv; s_i[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (before(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
+        record[2 * b] = bv;
+        record[2 * b + 1] = bi;
+    }
+}
+
 // ---- per-point kernel (visibilities [B,C,N]) ---------------------------------------------------------------
 template <bool SIGMOID>
 __global__ __launch_bounds__(SC_BLOCK) void sh_vis_kernel(const float* __restrict__ pts, int pts_stride,
@@ -377,6 +408,19 @@ int mcr_sh_coverage_gain(const float* pts, int pts_dim, const float* harmonics, 
                          size_t workspace_bytes, void* stream) {
     return sh_gain_impl("mcr_sh_coverage_gain", true, pts, pts_dim, harmonics, cams, gains, B, N, C, use_sigmoid, waves_per_simd,
                         workspace, workspace_bytes, stream);
+}
+
+int mcr_sh_coverage_gain_best(const float* pts, int pts_dim, const float* harmonics, const float* cams, float* gains, float* record,
+                              int64_t B, int64_t N, int64_t C, int use_sigmoid, int waves_per_simd, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    MCR_REQUIRE(record, "mcr_sh_coverage_gain_best: null pointer");
+    MCR_REQUIRE(C < (1ll << 24), "mcr_sh_coverage_gain_best: camera indices must stay below 2^24");
+    if (int e = sh_gain_impl("mcr_sh_coverage_gain_best", true, pts, pts_dim, harmonics, cams, gains, B, N, C, use_sigmoid, waves_per_simd,
+                             workspace, workspace_bytes, stream))
+        return e;
+    hipLaunchKernelGGL(sh_best_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, gains, (int)C, record);
+    MCR_LAUNCH_CHECK("sh_best_kernel");
+    return 0;
 }
 
 int mcr_sh_coverage_gain_partials(const float* pts, int pts_dim, const float* harmonics, const float* cams, int64_t B, int64_t N,

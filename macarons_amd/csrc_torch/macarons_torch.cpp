@@ -11,6 +11,9 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "macarons_hip.h"
@@ -37,8 +40,10 @@ std::vector<const float*> pointers(const c10::List<at::Tensor>& ts, std::vector<
     return p;
 }
 
-// SconeVis.compute_coverage_gain (SconeVis.py:210-252): pts [B,N,3|4], harmonics [B,N,64], cams [B,C,3] -> [B,C]
-at::Tensor sh_coverage_gain(const at::Tensor& pts_, const at::Tensor& harm_, const at::Tensor& cams_, bool use_sigmoid) {
+// SconeVis.compute_coverage_gain (SconeVis.py:210-252): pts [B,N,3|4], harmonics [B,N,64], cams [B,C,3] -> [B,C]; with want_record also
+// the decision of testers/shapenet.py:172 (torch.max over the cameras) as record [B,2] = (max gain, first arg-max camera as fp32)
+std::tuple<at::Tensor, at::Tensor> sh_gain_impl(const at::Tensor& pts_, const at::Tensor& harm_, const at::Tensor& cams_, bool use_sigmoid,
+                                               bool want_record) {
     const at::Tensor pts = f32(pts_, "pts"), harm = f32(harm_, "harmonics"), cams = f32(cams_, "cams");
     TORCH_CHECK(pts.dim() == 3 && harm.dim() == 3 && cams.dim() == 3, "sh_coverage_gain: pts [B,N,P], harmonics [B,N,64], cams [B,C,3]");
     const int64_t B = pts.size(0), N = pts.size(1), P = pts.size(2), C = cams.size(1);
@@ -46,10 +51,24 @@ at::Tensor sh_coverage_gain(const at::Tensor& pts_, const at::Tensor& harm_, con
                 "sh_coverage_gain: shape mismatch");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(pts.device());
     at::Tensor gains = at::empty({B, C}, pts.options());
+    at::Tensor record = want_record ? at::empty({B, 2}, pts.options()) : at::Tensor();
     at::Tensor ws = scratch(pts, mcr_sh_coverage_gain_workspace_bytes(B, N, C));
-    ok(mcr_sh_coverage_gain(pts.data_ptr<float>(), (int)P, harm.data_ptr<float>(), cams.data_ptr<float>(), gains.data_ptr<float>(), B, N, C,
-                            use_sigmoid ? 1 : 0, 0, ws.data_ptr(), (size_t)ws.numel(), stream_of(pts)), "mcr_sh_coverage_gain");
-    return gains;
+    if (want_record)
+        ok(mcr_sh_coverage_gain_best(pts.data_ptr<float>(), (int)P, harm.data_ptr<float>(), cams.data_ptr<float>(), gains.data_ptr<float>(),
+                                     record.data_ptr<float>(), B, N, C, use_sigmoid ? 1 : 0, 0, ws.data_ptr(), (size_t)ws.numel(),
+                                     stream_of(pts)), "mcr_sh_coverage_gain_best");
+    else
+        ok(mcr_sh_coverage_gain(pts.data_ptr<float>(), (int)P, harm.data_ptr<float>(), cams.data_ptr<float>(), gains.data_ptr<float>(), B, N, C,
+                                use_sigmoid ? 1 : 0, 0, ws.data_ptr(), (size_t)ws.numel(), stream_of(pts)), "mcr_sh_coverage_gain");
+    return std::make_tuple(gains, record);
+}
+
+at::Tensor sh_coverage_gain(const at::Tensor& pts, const at::Tensor& harm, const at::Tensor& cams, bool use_sigmoid) {
+    return std::get<0>(sh_gain_impl(pts, harm, cams, use_sigmoid, false));
+}
+
+std::tuple<at::Tensor, at::Tensor> sh_coverage_gain_best(const at::Tensor& pts, const at::Tensor& harm, const at::Tensor& cams, bool use_sigmoid) {
+    return sh_gain_impl(pts, harm, cams, use_sigmoid, true);
 }
 
 // SconeVis.compute_visibilities (SconeVis.py:164-208) -> [B,C,N]
@@ -244,6 +263,7 @@ TORCH_LIBRARY(macarons, m) {
     m.def("randperm_prefixes(int[] n, int[] keep) -> Tensor", &randperm_prefixes);
     m.def("scone_occ_draws(int[] m0, int[] m1, int[] m2, int Lg) -> Tensor", &scone_occ_draws);
     m.def("sh_coverage_gain(Tensor pts, Tensor harmonics, Tensor cams, bool use_sigmoid) -> Tensor");
+    m.def("sh_coverage_gain_best(Tensor pts, Tensor harmonics, Tensor cams, bool use_sigmoid) -> (Tensor, Tensor)");
     m.def("sh_visibilities(Tensor pts, Tensor harmonics, Tensor cams, bool use_sigmoid) -> Tensor");
     m.def("knn_gather_offset(Tensor x, Tensor pc, int k) -> (Tensor, Tensor, Tensor)");
     m.def("points_in_fov(Tensor pts, Tensor cameras) -> Tensor");
@@ -256,6 +276,7 @@ TORCH_LIBRARY(macarons, m) {
 
 TORCH_LIBRARY_IMPL(macarons, CUDA, m) {
     m.impl("sh_coverage_gain", &sh_coverage_gain);
+    m.impl("sh_coverage_gain_best", &sh_coverage_gain_best);
     m.impl("sh_visibilities", &sh_visibilities);
     m.impl("knn_gather_offset", &knn_gather_offset);
     m.impl("points_in_fov", &points_in_fov);

@@ -35,8 +35,7 @@ def _p(t):
 
 
 # ---- K9 scorer -------------------------------------------------------------------------------------
-def sh_coverage_gain(pts, harmonics, cams, use_sigmoid=True, waves_per_simd=0):
-    """gains [B,C]; replaces SconeVis.compute_coverage_gain (SconeVis.py:210-252)."""
+def _scorer_args(pts, harmonics, cams):
     pts, harmonics, cams = _req(pts, "pts"), _req(harmonics, "harmonics"), _req(cams, "X_cam")
     B, N, P = pts.shape
     C = cams.shape[1]
@@ -44,22 +43,41 @@ def sh_coverage_gain(pts, harmonics, cams, use_sigmoid=True, waves_per_simd=0):
         raise ValueError(f"harmonics must be [B,N,64] = {(B, N, 64)}, got {tuple(harmonics.shape)}")
     if cams.shape != (B, C, 3):
         raise ValueError(f"X_cam must be [B,C,3], got {tuple(cams.shape)}")
-    L = lib()
+    return pts, harmonics, cams, B, N, P, C
+
+
+def sh_coverage_gain(pts, harmonics, cams, use_sigmoid=True, waves_per_simd=0):
+    """gains [B,C]; replaces SconeVis.compute_coverage_gain (SconeVis.py:210-252)."""
+    pts, harmonics, cams, B, N, P, C = _scorer_args(pts, harmonics, cams)
     gains = torch.empty((B, C), dtype=torch.float32, device=pts.device)
-    ws_bytes = L.mcr_sh_coverage_gain_workspace_bytes(c_i64(B), c_i64(N), c_i64(C))
-    ws = _workspace(pts.device, max(ws_bytes, 4))
+    L = lib()
+    ws = _workspace(pts.device, L.mcr_sh_coverage_gain_workspace_bytes(c_i64(B), c_i64(N), c_i64(C)))
     with torch.cuda.device(pts.device):
-        check(L.mcr_sh_coverage_gain(_p(pts), c_int(P), _p(harmonics), _p(cams), _p(gains), c_i64(B), c_i64(N),
-                                     c_i64(C), c_int(int(bool(use_sigmoid))), c_int(waves_per_simd), _p(ws),
-                                     c_size(ws.numel()), _stream()), "mcr_sh_coverage_gain")
+        check(L.mcr_sh_coverage_gain(_p(pts), c_int(P), _p(harmonics), _p(cams), _p(gains), c_i64(B), c_i64(N), c_i64(C),
+                                     c_int(int(bool(use_sigmoid))), c_int(waves_per_simd), _p(ws), c_size(ws.numel()), _stream()),
+              "mcr_sh_coverage_gain")
     return gains
 
 
+def sh_coverage_gain_best(pts, harmonics, cams, use_sigmoid=True, waves_per_simd=0):
+    """(gains [B,C], record [B,2] = (max gain, first arg-max camera as fp32)): SconeVis.compute_coverage_gain (SconeVis.py:210-252) and
+    the decision of testers/shapenet.py:172 (torch.max over the cameras; a NaN gain wins) in one call (mcr_sh_coverage_gain_best)."""
+    pts, harmonics, cams, B, N, P, C = _scorer_args(pts, harmonics, cams)
+    gains = torch.empty((B, C), dtype=torch.float32, device=pts.device)
+    record = torch.empty((B, 2), dtype=torch.float32, device=pts.device)
+    L = lib()
+    ws = _workspace(pts.device, L.mcr_sh_coverage_gain_workspace_bytes(c_i64(B), c_i64(N), c_i64(C)))
+    with torch.cuda.device(pts.device):
+        check(L.mcr_sh_coverage_gain_best(_p(pts), c_int(P), _p(harmonics), _p(cams), _p(gains), _p(record), c_i64(B), c_i64(N), c_i64(C),
+                                          c_int(int(bool(use_sigmoid))), c_int(waves_per_simd), _p(ws), c_size(ws.numel()), _stream()),
+              "mcr_sh_coverage_gain_best")
+    return gains, record
+
+
 def sh_coverage_gain_partials(pts, harmonics, cams, use_sigmoid=True, waves_per_simd=0):
-    """First stage of sh_coverage_gain only (sh_gain_kernel; the partial sums stay in the scratch arena): timing hook."""
-    pts, harmonics, cams = _req(pts, "pts"), _req(harmonics, "harmonics"), _req(cams, "X_cam")
-    B, N, P = pts.shape
-    C = cams.shape[1]
+    """First stage of the scorer only (sh_gain_kernel; per-(wave tile, camera) partial sums stay in the scratch arena): lets
+    bench.py time the dominant kernel alone with HIP events.  Returns nothing."""
+    pts, harmonics, cams, B, N, P, C = _scorer_args(pts, harmonics, cams)
     L = lib()
     ws = _workspace(pts.device, max(L.mcr_sh_coverage_gain_workspace_bytes(c_i64(B), c_i64(N), c_i64(C)), 4))
     with torch.cuda.device(pts.device):

@@ -18,7 +18,7 @@ import torch
 from . import _lib
 
 LIB_PATH = os.path.join(_lib.PKG_DIR, "libmacarons_torch.so")
-_NAMES = ("sh_coverage_gain", "sh_visibilities", "knn_gather_offset", "points_in_fov", "view_state", "view_harmonics", "sample_proxy",
+_NAMES = ("sh_coverage_gain", "sh_coverage_gain_best", "sh_visibilities", "knn_gather_offset", "points_in_fov", "view_state", "view_harmonics", "sample_proxy",
           "scone_vis_forward", "scone_occ_forward")
 
 if not os.path.exists(LIB_PATH):

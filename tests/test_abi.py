@@ -53,7 +53,7 @@ def test_torch_ops_registered_without_cpu_fallback():
     import pytest
     import torch
     import macarons_amd.torch_ops as t
-    assert t.registered() == sorted(["sh_coverage_gain", "sh_visibilities", "knn_gather_offset", "points_in_fov", "view_state",
+    assert t.registered() == sorted(["sh_coverage_gain", "sh_coverage_gain_best", "sh_visibilities", "knn_gather_offset", "points_in_fov", "view_state",
                                      "view_harmonics", "sample_proxy", "scone_vis_forward", "scone_occ_forward"])
     for name in t.registered():
         assert hasattr(torch.ops.macarons, name)

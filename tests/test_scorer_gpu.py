@@ -158,3 +158,27 @@ def test_empty_dimensions_follow_upstream(dev):
             g2, idx2 = m.compute_coverage_gain_multiple(pts, h, cams, 2)
         assert tuple(g.shape) == (B, C) and tuple(v.shape) == (B, C, N) and tuple(g2.shape) == (B, C * C) and tuple(idx2.shape) == (C * C, 2)
         assert g.device.type == "cuda" and (g.numel() == 0 or bool(torch.isnan(g).all())) and (g2.numel() == 0 or bool(torch.isnan(g2).all()))
+
+
+def test_gain_best_is_the_gains_plus_torch_max(dev):
+    """mcr_sh_coverage_gain_best (one call: gains + the arg-max record of testers/shapenet.py:172) == mcr_sh_coverage_gain + torch.max,
+    through the ctypes wrapper and through torch.ops.macarons; a NaN gain wins the arg-max like torch.max."""
+    from macarons_amd import ops
+    import macarons_amd.torch_ops  # noqa: F401
+    rng = np.random.default_rng(5)
+    for B, N, C, sig in ((1, 2048, 20, True), (2, 500, 7, True), (1, 100_000, 200, True), (3, 65, 300, False), (1, 1, 1, True)):
+        pts = torch.from_numpy(rng.uniform(-.5, .5, (B, N, 4)).astype(np.float32)).to(dev)
+        harm = torch.from_numpy((rng.standard_normal((B, N, 64)) * 0.5).astype(np.float32)).to(dev)
+        cams = rng.standard_normal((B, C, 3)).astype(np.float32)
+        cams = torch.from_numpy((1.5 * cams / np.linalg.norm(cams, axis=-1, keepdims=True)).astype(np.float32)).to(dev)
+        want = ops.sh_coverage_gain(pts, harm, cams, sig)
+        g1, r1 = ops.sh_coverage_gain_best(pts, harm, cams, sig)
+        g2, r2 = torch.ops.macarons.sh_coverage_gain_best(pts, harm, cams, sig)
+        assert torch.equal(g1, want) and torch.equal(g2, want) and torch.equal(r1, r2), (B, N, C)
+        ref = torch.max(want, dim=1)
+        assert torch.equal(r1[:, 0], ref.values) and torch.equal(r1[:, 1], ref.indices.float()), (B, N, C)
+    bad = harm.clone()
+    bad[0, 0, 5] = float("nan")
+    gb, rb = ops.sh_coverage_gain_best(pts, bad, cams, True)
+    ref = torch.max(gb, dim=1)
+    assert bool(torch.isnan(rb[0, 0])) and float(rb[0, 1]) == float(ref.indices[0])
