@@ -219,8 +219,13 @@ int mcr_local_pct6_blob_floats(void);
  *      for the whole fp32 range (local_pct5.hip; mcr_local_pct3_blob_floats() floats);
  *   6 (default): two-term fp16 split (hi + lo, 22 significant bits), three MFMAs per product, same structure
  *      (local_pct6.hip; mcr_local_pct6_blob_floats() floats); needs |activation| < 65504. */
+ * The variant is a property of a CALL: mcr_call_variant(v) is the per-call argument -- the NEXT network entry point (mcr_linear,
+ * mcr_attention*, mcr_local_pct_forward, mcr_pc_transformer_forward, mcr_scone_vis_forward, mcr_scone_occ_forward*) called on THIS
+ * thread runs on variant v (one-shot, thread-local; 0 = the default again).  mcr_set_local_pct_variant only sets the process DEFAULT
+ * (start-up value: env MCR_LOCAL_PCT_VARIANT, else 6) that calls without a one-shot take; no call ever changes it. */
 int mcr_set_local_pct_variant(int variant);
 int mcr_get_local_pct_variant(void);
+int mcr_call_variant(int variant);
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,
                           void* stream);
 

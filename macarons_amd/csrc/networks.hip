@@ -59,11 +59,31 @@ void launch_local_pct8(hipStream_t s, const float* offs, float* feat, int64_t ld
 #else
 #define MCR_VARIANT8_OK(v) false
 #endif
-static int g_local_pct_variant = []() {                 // env MCR_LOCAL_PCT_VARIANT picks the start-up value (testing: whole suites on a variant)
+// The numerics variant is a property of a CALL, not of the process: every network entry point opens a VariantScope, which fixes the
+// variant of that call on the calling thread -- the one-shot value mcr_call_variant(v) left for it (the per-call argument of the ABI:
+// "the next network entry point on this thread runs on v"), else the process default (mcr_set_local_pct_variant / env
+// MCR_LOCAL_PCT_VARIANT).  Two host threads, or two models on different variants, cannot see each other's choice, and a failed
+// call cannot leave a flipped switch behind (round 4 flipped a process-global around the range-guard fallback).
+static int g_default_variant = []() {                   // env MCR_LOCAL_PCT_VARIANT picks the start-up value (testing: whole suites on a variant)
     const char* e = getenv("MCR_LOCAL_PCT_VARIANT");
     const int v = e ? atoi(e) : 6;
     return (v == 1 || v == 5 || v == 6) ? v : 6;
 }();
+static thread_local int t_next_variant = 0;             // one-shot: consumed by the next VariantScope of this thread
+static thread_local int t_variant = 0;                  // the variant of the entry point running on this thread
+static thread_local int t_scope_depth = 0;              // (an entry point may call another: the outermost scope decides)
+struct VariantScope {
+    VariantScope() {
+        if (t_scope_depth++ == 0) {
+            t_variant = t_next_variant ? t_next_variant : g_default_variant;
+            t_next_variant = 0;
+        }
+    }
+    ~VariantScope() {
+        if (--t_scope_depth == 0) t_variant = 0;
+    }
+};
+#define g_local_pct_variant (t_variant ? t_variant : g_default_variant)
 // rows-per-sequence argument of launch_linear for the encoders of the 2048-token networks (SconeVis, SconeOcc's global
 // transformer): on the split-precision variants (5, 6) their GEMMs take the split-precision kernel for EVERY launch size (negative
 // argument = "choose on the layer's shape"; its column-tile width follows the launch, which does not change a single bit) -- one
@@ -222,6 +242,7 @@ extern "C" {
 // ---- individual blocks (used by the host mirrors of Attention.py's modules and by the block-level tests) ----
 int mcr_linear(const float* X, int64_t ldx, const float* W, const float* bias, const float* residual, int64_t ldr, float* Y,
                int64_t ldy, int64_t M, int N, int K, int gelu, void* stream) {
+    VariantScope variant_scope_;
     MCR_REQUIRE(X && W && Y, "mcr_linear: null pointer");
     MCR_REQUIRE(M > 0 && N > 0 && K > 0, "mcr_linear: empty problem");
     MCR_REQUIRE(ldx >= K && ldy >= N && (!residual || ldr >= N), "mcr_linear: leading dimension too small");
@@ -241,6 +262,7 @@ int mcr_layernorm(const float* X, int64_t ldx, const float* gamma, const float* 
 
 int mcr_attention(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim,
                   int v_dim, void* stream) {
+    VariantScope variant_scope_;
     MCR_REQUIRE(qkv && out, "mcr_attention: null pointer");
     MCR_REQUIRE(S > 0 && L > 0, "mcr_attention: empty problem");
     MCR_REQUIRE(n_heads == 4 && ((qk_dim == 32 && v_dim == 128) || (qk_dim == 64 && v_dim == 256)),
@@ -255,6 +277,7 @@ int mcr_attention(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_
 int mcr_attention_masked(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim, int v_dim,
                          const unsigned char* mask, int64_t mask_seq_stride, int64_t mask_head_stride, int64_t mask_query_stride,
                          void* workspace, size_t workspace_bytes, void* stream) {
+    VariantScope variant_scope_;
     MCR_REQUIRE(qkv && out && mask, "mcr_attention_masked: null pointer");
     MCR_REQUIRE(S > 0 && L > 0, "mcr_attention_masked: empty problem");
     MCR_REQUIRE(n_heads == 4 && ((qk_dim == 32 && v_dim == 128) || (qk_dim == 64 && v_dim == 256)),
@@ -274,6 +297,7 @@ size_t mcr_attention_workspace_bytes(int64_t S, int64_t L, int n_heads, int v_di
 
 int mcr_attention_ws(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim,
                      int v_dim, void* workspace, size_t workspace_bytes, void* stream) {
+    VariantScope variant_scope_;
     MCR_REQUIRE(qkv && out, "mcr_attention_ws: null pointer");
     MCR_REQUIRE(S > 0 && L > 0, "mcr_attention_ws: empty problem");
     MCR_REQUIRE(n_heads == 4 && ((qk_dim == 32 && v_dim == 128) || (qk_dim == 64 && v_dim == 256)),
@@ -307,10 +331,15 @@ int mcr_local_pct6_blob_floats(void) { return local_pct6_blob_floats(); }
 
 int mcr_set_local_pct_variant(int v) {
     MCR_REQUIRE(v == 1 || v == 5 || v == 6 || MCR_VARIANT8_OK(v), "mcr_set_local_pct_variant: variant must be 1, 5 or 6 (got %d)", v);
-    g_local_pct_variant = v;
+    g_default_variant = v;
     return 0;
 }
-int mcr_get_local_pct_variant(void) { return g_local_pct_variant; }
+int mcr_get_local_pct_variant(void) { return g_default_variant; }
+int mcr_call_variant(int v) {
+    MCR_REQUIRE(v == 0 || v == 1 || v == 5 || v == 6 || MCR_VARIANT8_OK(v), "mcr_call_variant: variant must be 0 (default), 1, 5 or 6 (got %d)", v);
+    t_next_variant = v;
+    return 0;
+}
 static void run_local_pct(hipStream_t s, const float* offs, float* feat, int64_t ld, int64_t S, const float* blob,
                           void* feat_h = nullptr, void* feat_l = nullptr) {
     if (g_local_pct_variant == 1) launch_local_pct(s, offs, feat, ld, S, blob);
@@ -323,6 +352,7 @@ static void run_local_pct(hipStream_t s, const float* offs, float* feat, int64_t
 
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,
                           void* stream) {
+    VariantScope variant_scope_;
     MCR_REQUIRE(offsets && features && blob, "mcr_local_pct_forward: null pointer");
     MCR_REQUIRE(S > 0 && ld_features >= 256, "mcr_local_pct_forward: bad sizes");
     MCR_REQUIRE((reinterpret_cast<uintptr_t>(blob) & 15) == 0, "mcr_local_pct_forward: blob must be 16-byte aligned");
@@ -337,6 +367,7 @@ size_t mcr_pc_transformer_workspace_bytes(int64_t S, int64_t L) { return pct_ws_
 int mcr_pc_transformer_forward(const float* pc, float* features, int64_t S, int64_t L, int feature_dim,
                                const float* const* weights, int n_weights, void* workspace, size_t workspace_bytes,
                                void* stream) {
+    VariantScope variant_scope_;
     MCR_REQUIRE(pc && features && weights, "mcr_pc_transformer_forward: null pointer");
     MCR_REQUIRE(n_weights == PCT_NW, "mcr_pc_transformer_forward: expected %d weight pointers, got %d", PCT_NW, n_weights);
     MCR_REQUIRE(S > 0 && L > 0, "mcr_pc_transformer_forward: empty problem");
@@ -365,6 +396,7 @@ size_t mcr_scone_vis_workspace_bytes(int64_t B, int64_t N) {
 int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* out, int64_t B, int64_t N,
                           const float* const* weights, int n_weights, const int* lengths, void* workspace,
                           size_t workspace_bytes, void* stream) {
+    VariantScope variant_scope_;
     MCR_REQUIRE(pts && view_harmonics && out && weights, "mcr_scone_vis_forward: null pointer");
     MCR_REQUIRE(n_weights == VIS_NW, "mcr_scone_vis_forward: expected %d weight pointers, got %d", VIS_NW, n_weights);
     MCR_REQUIRE(B > 0 && N > 0 && B <= 65535, "mcr_scone_vis_forward: bad problem size B=%ld N=%ld", (long)B, (long)N);
@@ -474,6 +506,7 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
                                 const float* const* weights, int n_weights, const float* const* local_blobs,
                                 const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
                                 size_t workspace_bytes, int phase, void* stream) {
+    VariantScope variant_scope_;
     MCR_REQUIRE(phase >= 0 && phase <= 2, "mcr_scone_occ_forward: phase must be 0, 1 or 2");
     const bool early = phase != 2, late = phase != 1;
     MCR_REQUIRE(pc_scale && M_scale && x && weights && (!late || (pc_global && view_harmonics && out)), "mcr_scone_occ_forward: null pointer");
@@ -758,6 +791,7 @@ int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global
                                        const float* const* weights, int n_weights, const float* const* local_blobs,
                                        const void* const* head_planes, const float* head_inv_scales, int* range_flag, void* workspace,
                                        size_t workspace_bytes, int phase, void* stream) {
+    VariantScope variant_scope_;
     MCR_REQUIRE(phase >= 0 && phase <= 2, "mcr_scone_occ_forward_ragged: phase must be 0, 1 or 2");
     const bool early = phase != 2, late = phase != 1;
     MCR_REQUIRE(pc_scale && scale_off && x && view_harmonics && row_job && knn_blocks && weights && (!late || (pc_global && global_len && out)),

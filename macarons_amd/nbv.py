@@ -56,11 +56,10 @@ def _guarded(impl, scone_occ, range_guard, group, draws, device):
     synchronisation); if the flag comes back set (an activation left the fp16 range of the default matrix path, SconeOcc.range_guard)
     the decision is repeated on variant 5 with the SAME hidden draws.  `draws()` pins the draws before the first attempt when
     the caller did not.  With several ranks the flag is all-reduced first: every rank repeats, or none."""
-    from . import _lib
-    L = _lib.lib()
+    from . import ops
     capturing = torch.cuda.is_current_stream_capturing()
     prev = scone_occ.range_guard
-    guard = range_guard and prev != "off" and L.mcr_get_local_pct_variant() == 6
+    guard = range_guard and prev != "off" and ops.current_variant() == 6
     scone_occ.range_guard = "defer" if (guard or prev != "off") else "off"
     try:
         # the flag exists on every rank before the step (not only on ranks that run a guarded forward: a rank with an empty query
@@ -68,7 +67,7 @@ def _guarded(impl, scone_occ, range_guard, group, draws, device):
         scone_occ.clear_range_flag(device if guard else None)
         kw = draws() if (guard and not capturing) else {}
         out = impl(**kw)
-        flag = scone_occ.range_flag() if L.mcr_get_local_pct_variant() == 6 else None
+        flag = scone_occ.range_flag() if ops.current_variant() == 6 else None
         out["range_flag"] = flag
         if guard and not capturing:
             world = mdist.group_world_rank(group)[0]
@@ -84,11 +83,8 @@ def _guarded(impl, scone_occ, range_guard, group, draws, device):
             n_dec = out["nbv_idx"].numel()
             out["host"] = {"nbv_idx": both[1:1 + n_dec].to(torch.int64), "max_gain": both[1 + n_dec:].to(torch.float32)}
             if int(both[0]):
-                L.mcr_set_local_pct_variant(5)
-                try:
+                with ops.variant(5):                 # (scoped to this thread's calls: the process default is not touched)
                     out = impl(**kw)
-                finally:
-                    L.mcr_set_local_pct_variant(6)
                 out["range_flag"], out["fallback_variant"] = None, 5
                 out.pop("host", None)
     finally:

@@ -125,16 +125,56 @@ class SconeOcc(nn.Module):
         # Range guard of the default numerics (variant 6: matrix products on fp16 hi/lo planes, valid for |activation| < 65504;
         # the reference is plain fp32, Attention.py:98-128): the kernels flag a non-finite occupancy -- what an out-of-range
         # activation turns into -- and the forward is repeated on variant 5 (bf16 hi/mid/lo, the whole fp32 range).
-        #   "sync"  (default) read the flag after every forward (one 4-byte read-back) and repeat at once;
-        #   "defer" leave it in range_flag() for the caller (nbv_step checks it once, at the end of the decision);
+        #   "async" (default) never stalls: after every forward the flag is copied to pinned host memory behind the kernels; the NEXT
+        #           forward (or check_range()) looks at copies that have landed.  A set flag means an earlier forward returned
+        #           non-finite occupancies (visible as such to the caller): it is reported once (RuntimeWarning) and every later
+        #           forward of this module runs on variant 5 -- a drop-in caller that keeps upstream's chunk loop pays no
+        #           device->host round trip per chunk;
+        #   "sync"  read the flag after every forward (one 4-byte read-back = a pipeline drain) and repeat that forward at once;
+        #   "defer" leave it in range_flag() for the caller (nbv_step / macarons_nbv_decision check it once, at the end of the decision);
         #   "off"   no check.
-        self.range_guard = "sync"
+        self.range_guard = "async"
         self._range_flag = None
+        self._range_pending = []            # (pinned host int32 [1], event) of forwards whose flag has not been looked at yet
+        self._full_range = False            # True once an overflow was seen: variant 5 from then on
 
     def range_flag(self):
         """int32 device tensor [1]: 1 if a forward since clear_range_flag() produced a non-finite occupancy (None before the first
         guarded forward)."""
         return self._range_flag
+
+    def _post_range_check(self, flag):
+        """"async" guard: queue a copy of the flag to pinned host memory behind the forward's kernels (no stall)."""
+        host = torch.empty(1, dtype=torch.int32).pin_memory() if not self._range_pool else self._range_pool.pop()
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(flag.device))
+        self._range_pending.append((host, ev))
+
+    _range_pool = ()
+
+    def check_range(self, wait=False):
+        """Look at the range flags of earlier forwards ("async" guard).  wait=False: only copies that have already landed (never stalls);
+        wait=True: wait for all of them.  -> True if an overflow of the fp16-split path was seen (now or earlier); from then on this
+        module runs on the full-range variant 5.  The forward that overflowed returned non-finite occupancies."""
+        keep = []
+        for host, ev in self._range_pending:
+            if wait:
+                ev.synchronize()
+            if wait or ev.query():
+                if int(host[0]) and not self._full_range:
+                    import warnings
+                    warnings.warn("SconeOcc: an activation left the fp16 range of the default matrix path (variant 6) -- that forward "
+                                  "returned non-finite occupancies; this module runs on the full-range variant 5 from now on "
+                                  "(range_guard='sync' repeats the forward itself at the price of a read-back per call)", RuntimeWarning, stacklevel=3)
+                    self._full_range = True
+                if not isinstance(self._range_pool, list):
+                    self._range_pool = []
+                self._range_pool.append(host)
+            else:
+                keep.append((host, ev))
+        self._range_pending = keep
+        return self._full_range
 
     def clear_range_flag(self, device=None):
         """Zero the flag; with `device`, create it there first if this module has not run a guarded forward on it yet (a rank whose
@@ -265,7 +305,7 @@ class SconeOcc(nn.Module):
         L = _lib.lib()
         Lg = self.seq_len
         pc = pc.contiguous()
-        variant = L.mcr_get_local_pct_variant()
+        variant = ops.current_variant()
         off0 = np.concatenate(([0], np.cumsum(cloud_sizes))).astype(np.int64)
         rows = int(L.mcr_knn_rows_per_block())
         qs = np.asarray(query_sizes, np.int64)
@@ -366,18 +406,17 @@ class SconeOcc(nn.Module):
         if variant == 6 and self.range_guard != "off":
             if self._range_flag is None or self._range_flag.device != dev:
                 self._range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
-            elif self.range_guard == "sync":
+            elif self.range_guard in ("sync", "async"):
                 self._range_flag.zero_()
             flag = self._range_flag
         with torch.no_grad():
             # (phase 1's results live in the stream's arena: if anything else wrote it since -- another thread on this stream -- redo it)
             res = run(variant, flag, ops.scone_occ_epoch(dev, h["arena"]) != h["epoch1"], out)
             if flag is not None and self.range_guard == "sync" and int(flag):
-                L.mcr_set_local_pct_variant(5)
-                try:
+                with ops.variant(5):
                     res = run(5, None, True, out)
-                finally:
-                    L.mcr_set_local_pct_variant(variant)
+            elif flag is not None and self.range_guard == "async":
+                self._post_range_check(flag)
         return res
 
     def scale_sizes(self, full_seq_len):
@@ -401,7 +440,7 @@ class SconeOcc(nn.Module):
         queued) when the split does not apply (gradients wanted, non-default architecture, layer-by-layer path)."""
         if not self._is_default_arch() or not self.fused_local or A.needs_grad(self, pc, x) or os.environ.get("MCR_OCC_BEGIN") == "0":
             return None
-        variant = _lib.lib().mcr_get_local_pct_variant()
+        variant = ops.current_variant()
         pc0, x_ = pc.contiguous(), x.contiguous()
         sizes = self.scale_sizes(pc.shape[1])
         if min(sizes) < self.k_for_knn:
@@ -428,7 +467,12 @@ class SconeOcc(nn.Module):
             perms = self.draw_perms(full_seq_len)
         dev = pc.device
         L = _lib.lib()
-        variant = L.mcr_get_local_pct_variant()
+        if self.range_guard == "async" and (self._range_pending or self._full_range):
+            self.check_range()
+        if self._full_range and ops.current_variant() == 6:        # an earlier forward overflowed the fp16 split: full range from now on
+            with ops.variant(5):
+                return self.forward(pc, x, view_harmonics, mask, verbose, perms, None)
+        variant = ops.current_variant()
         # A handle of forward_begin is valid only for the very tensors, numerics and cloud sizes it was queued with -- and only while
         # nothing else has written the arena that holds its phase-1 results (ops.scone_occ_epoch).  Checked BEFORE anything of the
         # handle is used: a stale or foreign handle is ignored and the whole forward runs on `pc` / `x`.
@@ -455,6 +499,8 @@ class SconeOcc(nn.Module):
                 self._range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
             elif self.range_guard == "sync":
                 self._range_flag.zero_()
+            elif self.range_guard == "async":
+                self._range_flag.zero_()
             flag = self._range_flag
         if A.needs_grad(self, pc, x, view_harmonics):   # trainers: HIP forward, composite-torch backward (autograd.py)
             pidx = [p.to(dev) for p in perms]
@@ -478,9 +524,8 @@ class SconeOcc(nn.Module):
         else:
             res = run(variant, pc_global, scales, x, view_harmonics, flag, phase)
             if flag is not None and self.range_guard == "sync" and int(flag):      # out of the fp16 range: the full-range path
-                L.mcr_set_local_pct_variant(5)
-                try:
+                with ops.variant(5):
                     res = run(5, pc_global, scales, x, view_harmonics, None)
-                finally:
-                    L.mcr_set_local_pct_variant(variant)
+            elif flag is not None and self.range_guard == "async":
+                self._post_range_check(flag)
         return res.view(n_clouds, n_sample, self.output_dim)

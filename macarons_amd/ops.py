@@ -34,6 +34,39 @@ def _p(t):
     return c_vp(t.data_ptr())
 
 
+# ---- numerics variant of the network entry points: a property of the CALL (mcr_call_variant), scoped per thread on the host ------------
+import contextlib
+import threading
+
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def variant(v):
+    """`with ops.variant(5): ...` -- every network entry point called inside, ON THIS THREAD, runs on variant v (the one-shot per-call
+    argument of the C ABI, mcr_call_variant, set before each of them).  The process default (mcr_set_local_pct_variant) is never
+    touched: another thread, or another model, does not see the choice, and an exception cannot leave a flipped switch behind."""
+    prev = getattr(_tls, "variant", 0)
+    _tls.variant = int(v)
+    try:
+        yield
+    finally:
+        _tls.variant = prev
+
+
+def current_variant():
+    """The variant a network call made here and now would run on."""
+    return getattr(_tls, "variant", 0) or int(lib().mcr_get_local_pct_variant())
+
+
+def _net(L_):
+    """Hand the scoped variant (if any) to the next network entry point of this thread; returns the library."""
+    v = getattr(_tls, "variant", 0)
+    if v:
+        L_.mcr_call_variant(c_int(v))
+    return L_
+
+
 # ---- K9 scorer -------------------------------------------------------------------------------------
 def _scorer_args(pts, harmonics, cams):
     pts, harmonics, cams = _req(pts, "pts"), _req(harmonics, "harmonics"), _req(cams, "X_cam")
@@ -168,7 +201,7 @@ def linear(x, weight, bias=None, gelu=False, residual=None):
     b = _req(bias, "bias") if bias is not None else None
     r = _req(residual, "residual").reshape(M, N) if residual is not None else None
     with torch.cuda.device(x.device):
-        check(lib().mcr_linear(_p(x2), c_i64(K), _p(weight), _p(b) if b is not None else c_vp(0),
+        check(_net(lib()).mcr_linear(_p(x2), c_i64(K), _p(weight), _p(b) if b is not None else c_vp(0),
                                _p(r) if r is not None else c_vp(0), c_i64(N), _p(y), c_i64(N), c_i64(M), c_int(N), c_int(K),
                                c_int(int(gelu)), _stream()), "mcr_linear")
     return y.reshape(*lead, N)
@@ -243,16 +276,16 @@ def attention_packed(qkv, n_heads, qk_dim, v_dim, split=True, mask=None):
         if mask is not None:
             m4, s_seq, s_head, s_q = _mask_bytes(mask, S, n_heads, L, qkv.device)
             ws = _workspace(qkv.device, int(lib().mcr_attention_workspace_bytes(c_i64(S), c_i64(L), c_int(n_heads), c_int(v_dim)))) if use_ws else None
-            check(lib().mcr_attention_masked(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads), c_int(qk_dim),
+            check(_net(lib()).mcr_attention_masked(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads), c_int(qk_dim),
                                              c_int(v_dim), _p(m4), c_i64(s_seq), c_i64(s_head), c_i64(s_q),
                                              _p(ws) if ws is not None else c_vp(0), ctypes.c_size_t(ws.numel() if ws is not None else 0),
                                              _stream()), "mcr_attention_masked")
         elif use_ws:
             ws = _workspace(qkv.device, int(lib().mcr_attention_workspace_bytes(c_i64(S), c_i64(L), c_int(n_heads), c_int(v_dim))))
-            check(lib().mcr_attention_ws(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads),
+            check(_net(lib()).mcr_attention_ws(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads),
                                          c_int(qk_dim), c_int(v_dim), _p(ws), ctypes.c_size_t(ws.numel()), _stream()), "mcr_attention_ws")
         else:
-            check(lib().mcr_attention(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads),
+            check(_net(lib()).mcr_attention(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads),
                                       c_int(qk_dim), c_int(v_dim), _stream()), "mcr_attention")
     return out
 
@@ -338,7 +371,7 @@ def pc_transformer_forward(pc, weights, feature_dim):
     ws = _workspace(pc.device, nb)
     tab = _ptr_table(weights)
     with torch.cuda.device(pc.device):
-        check(L_.mcr_pc_transformer_forward(_p(pc), _p(out), c_i64(S), c_i64(L), c_int(feature_dim), tab,
+        check(_net(L_).mcr_pc_transformer_forward(_p(pc), _p(out), c_i64(S), c_i64(L), c_int(feature_dim), tab,
                                             c_int(_n_weights(weights)), _p(ws), c_size(ws.numel()), _stream()),
               "mcr_pc_transformer_forward")
     return out
@@ -361,7 +394,7 @@ def scone_vis_forward(pts, view_harmonics, weights, lengths=None):
         if lengths.numel() != B:
             raise ValueError(f"lengths must hold one int32 per cloud ({B}), got {lengths.numel()}")
     with torch.cuda.device(pts.device):
-        check(L_.mcr_scone_vis_forward(_p(pts), _p(view_harmonics), _p(out), c_i64(B), c_i64(N), tab, c_int(_n_weights(weights)),
+        check(_net(L_).mcr_scone_vis_forward(_p(pts), _p(view_harmonics), _p(out), c_i64(B), c_i64(N), tab, c_int(_n_weights(weights)),
                                        _p(lengths) if lengths is not None else c_vp(0), _p(ws), c_size(ws.numel()), _stream()),
               "mcr_scone_vis_forward")
     return out
@@ -375,7 +408,7 @@ def local_pct_forward(offsets, blob):
         raise ValueError("offsets must be [S,16,3]")
     out = torch.empty((S, 256), dtype=torch.float32, device=offsets.device)
     with torch.cuda.device(offsets.device):
-        check(lib().mcr_local_pct_forward(_p(offsets), _p(out), c_i64(256), c_i64(S), _p(blob), _stream()),
+        check(_net(lib()).mcr_local_pct_forward(_p(offsets), _p(out), c_i64(256), c_i64(S), _p(blob), _stream()),
               "mcr_local_pct_forward")
     return out
 
@@ -412,7 +445,7 @@ def scone_occ_forward(pc_global, pc_scales, x, view_harmonics, weights, local_bl
     sc_m = (ctypes.c_int64 * 3)(*[int(m) for m in M_scale])
     blobs = (ctypes.c_void_p * 3)(*[_req(b, "local_blob").data_ptr() for b in local_blobs]) if local_blobs else None
     with torch.cuda.device(x.device):
-        check(L_.mcr_scone_occ_forward_phase(_p(pc_global) if late else c_vp(0), c_i64(Lg), sc_ptrs, sc_m, _p(x),
+        check(_net(L_).mcr_scone_occ_forward_phase(_p(pc_global) if late else c_vp(0), c_i64(Lg), sc_ptrs, sc_m, _p(x),
                                              _p(view_harmonics) if late else c_vp(0), _p(out) if late else c_vp(0), c_i64(B),
                                              c_i64(Q), tab, c_int(_n_weights(weights)), blobs,
                                              head_planes[1] if head_planes is not None else None,
@@ -456,7 +489,7 @@ def scone_occ_forward_ragged(pc_global, global_len, pc_scales, scale_offsets, x,
     off_ptrs = (ctypes.c_void_p * 3)(*[o.data_ptr() for o in scale_offsets])
     blobs = (ctypes.c_void_p * 3)(*[_req(b, "local_blob").data_ptr() for b in local_blobs])
     with torch.cuda.device(x.device):
-        check(L_.mcr_scone_occ_forward_ragged_phase(_p(pc_global) if late else c_vp(0), _p(global_len) if late else c_vp(0), c_i64(Lg), sc_ptrs,
+        check(_net(L_).mcr_scone_occ_forward_ragged_phase(_p(pc_global) if late else c_vp(0), _p(global_len) if late else c_vp(0), c_i64(Lg), sc_ptrs,
                                                     off_ptrs, _p(x), _p(view_harmonics), _p(row_job), _p(knn_blocks), c_i64(knn_blocks.shape[0]),
                                                     _p(out) if late else c_vp(0), c_i64(J), c_i64(T),
                                                     _ptr_table(weights), c_int(_n_weights(weights)), blobs,

@@ -256,7 +256,8 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
             record["samples_all"] = record["samples"]
         return X_world, view_harmonics, occ_probs, gains
 
-    deferred = range_guard and getattr(occ_net, "range_guard", None) == "sync" and hasattr(occ_net, "forward_ragged")
+    guard_before = getattr(occ_net, "range_guard", None)
+    deferred = range_guard and guard_before in ("sync", "async") and hasattr(occ_net, "forward_ragged")
     record = {}
     if deferred:
         occ_net.range_guard = "defer"
@@ -275,21 +276,14 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
                 both = torch.cat((flag.view(1).float(), rec_best.view(-1))).cpu() if rec_best is not None else flag.cpu()
                 hit = bool(both.view(-1)[0] != 0)
             if hit:                                 # out of the fp16 range: repeat on the full-range variant
-                from .. import _lib
-                import ctypes
-                L = _lib.lib()
-                v0 = L.mcr_get_local_pct_variant()
-                L.mcr_set_local_pct_variant(ctypes.c_int(5))
-                try:
+                with ops.variant(5):                 # (scoped to this thread's calls: the process default is not touched)
                     X_world, view_harmonics, occ_probs, gains = field_and_gains(record.get("ragged_perms"), record.get("samples_all"), None)
-                finally:
-                    L.mcr_set_local_pct_variant(ctypes.c_int(v0))
                 occ_net.clear_range_flag()
                 fallback = 5
                 rec_best = None if world > 1 else ops.best_record(gains.view(1, K), 0)
     finally:
         if deferred:
-            occ_net.range_guard = "sync"
+            occ_net.range_guard = guard_before
     if world > 1:                                       # ties -> the lowest index over all ranks = the first strict maximum
         max_gain, next_idx = mdist.allgather_best(gains.view(1, -1), k0, group)
         out = {"next_idx": next_idx[0], "max_gain": max_gain[0], "cam_range": (k0, k1)}

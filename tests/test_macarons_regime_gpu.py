@@ -304,7 +304,7 @@ def test_macarons_decision_range_guard_is_deferred_and_falls_back(dev):
             with torch.no_grad():
                 r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, T(g["depth"][0], dev), T(dmask[0], dev), nrec,
                                              T(g["n_eyes"][0], dev), dev, samples=T(g["u_0"], dev))
-            assert m.occupancy.range_guard == "sync"                    # restored
+            assert m.occupancy.range_guard == "async"                   # restored (the default)
         finally:
             L.mcr_set_local_pct_variant(ctypes.c_int(v0))
         return r
