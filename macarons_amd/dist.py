@@ -20,6 +20,16 @@ def group_world_rank(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+def exchange_on(group):
+    """True when the exchange path of a sharded routine (broadcast of rank 0's draws, all-gathers, record merge) is to run: a group of
+    more than one rank -- or, with env MCR_FORCE_DIST_PATH set, any explicitly passed group, so that a one-GPU box runs every
+    collective of every sharded leg through RCCL on a one-rank group (tests/test_nbv_gpu.py)."""
+    import os
+    if group is None or not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or bool(os.environ.get("MCR_FORCE_DIST_PATH"))
+
+
 def shard_range(n_items, rank, world):
     """Contiguous block partition of n_items over world ranks (first ranks get the remainder)."""
     q, r = divmod(n_items, world)

@@ -70,12 +70,12 @@ def _guarded(impl, scone_occ, range_guard, group, draws, device):
         flag = scone_occ.range_flag() if ops.current_variant() == 6 else None
         out["range_flag"] = flag
         if guard and not capturing:
-            world = mdist.group_world_rank(group)[0]
-            if world > 1:
+            xch = mdist.exchange_on(group)
+            if xch:
                 flag = mdist.all_reduce_max(flag, group)
             # the one read-back, after the last kernel of the decision was queued; the decision itself rides along (a caller that
             # wants the camera index on the host reads out["host"]["nbv_idx"] instead of paying a second device->host round trip)
-            if world == 1 and "record" in out:       # written by the decision's last kernel (mcr_nbv_decide): nothing to assemble
+            if not xch and "record" in out:          # written by the decision's last kernel (mcr_nbv_decide): nothing to assemble
                 both = out["record"].cpu()
             else:
                 both = torch.cat((flag.to(out["nbv_idx"].device).view(-1).to(torch.float64), out["nbv_idx"].view(-1).to(torch.float64),
@@ -123,7 +123,7 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
 
 def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1,
               max_points_per_pass=300000, true_monte_carlo_sampling=True, occ_perms=None, samples=None, group=None,
-              view_proj=None, filter_tol=0.01, return_samples=False):
+              view_proj=None, filter_tol=0.01, return_samples=False, _emulate=None):
     """pc [1,M,3] surface points, X [1,Q,3] proxy points, X_view [n_view,3] past camera positions, X_cam [C,3]
     candidate cameras (all in the normalised prediction-view space, as the reference feeds its networks).
     Returns dict(gains [C_local or C], nbv_idx (global camera index), max_gain, occ [Q,1], n_unique) -- all device tensors
@@ -133,7 +133,19 @@ def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, mi
     world, rank = mdist.group_world_rank(group)            # group=None: local (pass torch.distributed.group.WORLD to shard)
     # the exchange path (broadcast of the hidden draws, all-gathers, record merge) normally needs world > 1; the env knob runs it
     # through RCCL on a single rank too, so that a one-GPU box can test it end to end
-    sharded = world > 1 or (group is not None and torch.distributed.is_initialized() and bool(os.environ.get("MCR_FORCE_DIST_PATH")))
+    sharded = mdist.exchange_on(group)
+    gather_rows, gather_best = mdist.allgather_rows, mdist.allgather_best
+    if _emulate is not None:
+        # TIMING ONLY (bench.py's N = 1 line): what rank `r` of a `w`-rank job computes, on this one GPU -- its query shard, the
+        # redundant part (sampling, SconeVis, its camera shard) -- with the two exchanges replaced by local stand-ins of the same
+        # size (the other ranks' occupancies are copies of this rank's): the critical path of one rank, i.e. what a w-GPU step
+        # costs apart from the collectives' latency.  The decision it returns is not the real one.
+        rank, world = _emulate
+        sharded = True
+        gather_rows = lambda t, n, g_=None: t.repeat(-(-n // max(t.shape[0], 1)), 1)[:n].contiguous()      # noqa: E731
+        def gather_best(g_, c0_, grp=None):                                                             # noqa: E306
+            b_ = torch.max(g_, dim=1)
+            return b_.values, b_.indices + c0_
     dev = X.device
     if view_proj is not None:                                                       # testers/shapenet.py:122
         X = su.filter_proxy_points(view_proj, X[0], pc.reshape(-1, 3), filter_tol=filter_tol)[0][None]
@@ -144,7 +156,7 @@ def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, mi
         # ---- view state -> harmonics for this rank's slice of the queries (testers/shapenet.py:126-130) ----
         q0, q1 = mdist.shard_range(Q, rank, world)
         Xl = X[:, q0:q1].contiguous()
-        if sharded and (occ_perms is None or samples is None):
+        if sharded and _emulate is None and (occ_perms is None or samples is None):
             # one chunk per rank; the hidden draws (SconeOcc.forward's three randperms from the CPU generator, the sampling
             # uniforms from the device generator) are rank 0's and reach the others in ONE broadcast (the uniforms travel
             # bit-cast inside the int64 buffer): every rank drawing its own would silently diverge
@@ -173,7 +185,7 @@ def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, mi
         if sharded:
             # only the occupancies travel (4 B per proxy point); the view harmonics of the <= seq_len sampled points are
             # recomputed locally below (a row is a function of its own point): all-gathering them would move 256 B per point
-            occ = mdist.allgather_rows(occ_l, Q, group)
+            occ = gather_rows(occ_l, Q, group)
             vh = None
         else:
             occ, vh = occ_l, vh_l[0]
@@ -212,7 +224,7 @@ def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, mi
         if sharded:
             empty = n_unique.view(1, 1) < 1
             gains = torch.where(empty, torch.full_like(gains, float("nan")), gains)
-            max_gain, nbv_idx = mdist.allgather_best(gains, c0, group)
+            max_gain, nbv_idx = gather_best(gains, c0, group)
             nbv_idx = torch.where(empty.view(-1), torch.full_like(nbv_idx, -1), nbv_idx)
         else:                                       # the same rules + the host's read-back record in one launch (mcr_nbv_decide)
             from . import ops
@@ -241,10 +253,10 @@ def nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=204
                    occ_perms=None, samples=None, group=None, return_samples=False, range_guard=True):
     """B independent decisions in one launch sequence; see _nbv_step_batch.  range_guard as in nbv_step."""
     fixed = dict(occ_perms=occ_perms, samples=samples)
-    world = mdist.group_world_rank(group)[0]
+    xch = mdist.exchange_on(group)
 
     def draws():
-        if world == 1 and (fixed["occ_perms"] is None or fixed["samples"] is None):
+        if not xch and (fixed["occ_perms"] is None or fixed["samples"] is None):
             dp, du = draw_batch(scone_occ, X.shape[0], pc.shape[1], seq_len, X.device)
             fixed["occ_perms"] = dp if fixed["occ_perms"] is None else fixed["occ_perms"]
             fixed["samples"] = du if fixed["samples"] is None else fixed["samples"]
@@ -276,12 +288,13 @@ def _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=20
     B, Q, M, C = X.shape[0], X.shape[1], pc.shape[1], X_cam.shape[-2]
     if pc.shape[0] != B:
         raise ValueError("nbv_step_batch: pc and X must hold the same number of clouds")
-    by_cloud = world > 1 and B >= world
+    xch = mdist.exchange_on(group)                         # (a one-rank group with MCR_FORCE_DIST_PATH runs every collective too)
+    by_cloud = xch and B >= world
     with torch.no_grad():
         # ---- hidden draws: rank 0's, for ALL clouds, in one broadcast ----
         if occ_perms is None or samples is None:
             dp, du = draw_batch(scone_occ, B, M, seq_len, dev)
-            if world > 1:
+            if xch:
                 got_p, got_u = mdist.broadcast_draws(dp if occ_perms is None else [], du if samples is None else None, 0, group)
                 dp, du = (got_p if occ_perms is None else dp), (got_u if samples is None else du)
             occ_perms = dp if occ_perms is None else occ_perms
@@ -289,8 +302,8 @@ def _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=20
         samples = samples.reshape(B, seq_len).to(dev)
         occ_perms = [p.to(dev) for p in occ_perms]
         b0, b1 = mdist.shard_range(B, rank, world) if by_cloud else (0, B)
-        q0, q1 = (0, Q) if (by_cloud or world == 1) else mdist.shard_range(Q, rank, world)
-        c0, c1 = (0, C) if (by_cloud or world == 1) else mdist.shard_range(C, rank, world)
+        q0, q1 = (0, Q) if (by_cloud or not xch) else mdist.shard_range(Q, rank, world)
+        c0, c1 = (0, C) if (by_cloud or not xch) else mdist.shard_range(C, rank, world)
         Bl = b1 - b0
         pc_l, X_b = pc[b0:b1].contiguous(), X[b0:b1].contiguous()
         Xv_l = X_view[b0:b1].contiguous() if X_view.dim() == 3 else X_view
@@ -325,7 +338,7 @@ def _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=20
         cams = cams[:, c0:c1].contiguous()
         gains = scone_vis.compute_coverage_gain(pts_s, harm_s, cams) if c1 > c0 else torch.zeros(Bl, 0, dtype=torch.float32, device=dev)
         record = None
-        if world == 1:                                # NaN rule + arg-max + the host's read-back record in one launch (mcr_nbv_decide)
+        if not xch:                                   # NaN rule + arg-max + the host's read-back record in one launch (mcr_nbv_decide)
             flag = scone_occ.range_flag() if scone_occ.range_guard != "off" else None
             max_gain, nbv_idx, record = ops.nbv_decide(gains, nu.view(-1), flag)
         else:

@@ -154,6 +154,7 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     none of them, are already queued."""
     from .. import dist as mdist
     world, rank = mdist.group_world_rank(group)            # group=None: local, whatever process groups exist
+    xch = mdist.exchange_on(group)                         # the exchange path (rank 0's draws, all-gathers, record merge) runs
     H, W = params.image_height, params.image_width
     depth2 = depth.reshape(H, W).contiguous().float()
     dmask2 = depth_mask.reshape(H, W) if depth_mask is not None else None
@@ -212,7 +213,7 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
         nkf = 4 * fill.nk + 6
         host = torch.cat((fill.counts, sel.counts)).cpu().numpy()                                  # THE read-back of the decision's first half
         cand, adm = ps.fill_counts(host[:nkf])
-        gfill = group if world > 1 else None
+        gfill = group if xch else None
         if ps.fill_overflows(cand, adm):            # a full cell: WHICH points stay is random -> the selection has to wait for the draws
             ps.fill_cells_end(fill, cand, adm, 0, gfill, perm_source)
         else:
@@ -228,10 +229,10 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
         field_state["selection"] = field_state["between"] = field_state["after"] = None   # (a repeat selects again: the stores are final by then)
         X_world, view_harmonics, occ_probs = compute_scene_occupancy_probability_field(params, macarons, None, surface_scene, ps,
                                                                                        device, prediction_camera=Mv_field, ragged_perms=ragged_perms,
-                                                                                       group=group if world > 1 else None, record=record,
+                                                                                       group=group if xch else None, record=record,
                                                                                        perm_source=perm_source, _selection=selection,
                                                                                        _between=between, _after=after)
-        if world > 1:                                   # the uniforms of ALL cameras are rank 0's
+        if xch:                                         # the uniforms of ALL cameras are rank 0's
             if smp is None:
                 smp = ops.uniform_rows(K, S, device) if uniform_draws == "per_camera" else torch.rand(K, S, device=device)
                 _, smp = mdist.broadcast_draws([], smp, 0, group)
@@ -265,11 +266,11 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     try:
         X_world, view_harmonics, occ_probs, gains = field_and_gains(None, samples, record)
         # `if coverage_gain > max_coverage_gain` from -1: the first strict maximum (a NaN gain never wins upstream; here it would)
-        rec_best = None if world > 1 else ops.best_record(gains.view(1, K), 0)
+        rec_best = None if xch else ops.best_record(gains.view(1, K), 0)
         fallback = None
         if deferred:
             flag = occ_net.range_flag()
-            if world > 1:
+            if xch:
                 flag = mdist.all_reduce_max(flag, group)                # every rank repeats, or none
             hit = False
             if flag is not None:                    # the one read-back of the second half: range flag + the decision's record together
@@ -280,11 +281,11 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
                     X_world, view_harmonics, occ_probs, gains = field_and_gains(record.get("ragged_perms"), record.get("samples_all"), None)
                 occ_net.clear_range_flag()
                 fallback = 5
-                rec_best = None if world > 1 else ops.best_record(gains.view(1, K), 0)
+                rec_best = None if xch else ops.best_record(gains.view(1, K), 0)
     finally:
         if deferred:
             occ_net.range_guard = guard_before
-    if world > 1:                                       # ties -> the lowest index over all ranks = the first strict maximum
+    if xch:                                             # ties -> the lowest index over all ranks = the first strict maximum
         max_gain, next_idx = mdist.allgather_best(gains.view(1, -1), k0, group)
         out = {"next_idx": next_idx[0], "max_gain": max_gain[0], "cam_range": (k0, k1)}
     else:
@@ -622,7 +623,7 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
             occ_out.copy_(ps.proxy_supervision_occ[rows.long()])
         else:
             occ_net = getattr(macarons, "occupancy", macarons)
-            if hasattr(occ_net, "forward_ragged") and world > 1:
+            if hasattr(occ_net, "forward_ragged") and mdist.exchange_on(group):
                 if _between is not None:
                     _between()
                 if ragged_perms is None:                # rank 0 draws for every job, in job order (what the 1-rank pass draws)

@@ -315,7 +315,7 @@ class Scene:
             u = torch.where(d_t[seg] > 0, u, local.double() / d_n[seg].double().clamp(min=1.0) * (1.0 - 2.0 ** -30))
             order = torch.argsort(seg.double() + u)
             g = comb[order][local < d_nk[seg]]                   # (sorted position p of segment s has rank p - off[s] = local[p])
-            if world > 1:
+            if mdist.exchange_on(group):
                 mdist.broadcast(g, 0, group)
             new_pts, new_fts = ops.scene_fill_gather(g, h, st.pts, st.fts, n_store, F)
         else:
@@ -329,7 +329,7 @@ class Scene:
             if n_pm % 2:
                 pm32 = np.concatenate((pm32, np.zeros(1, np.int32)))
             buf = ops.h2d(np.concatenate((tabs, pm32.view(np.int64))), torch.int64, dev)
-            if world > 1:                                       # rank 0's draws for every replica
+            if mdist.exchange_on(group):                        # rank 0's draws for every replica
                 mdist.broadcast(buf, 0, group)
             new_pts, new_fts = ops.scene_fill_gather_perm(buf, n_pm, n_cells, n_new, h, st.pts, st.fts, n_store, F)
         from .. import ops as _o

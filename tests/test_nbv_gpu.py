@@ -204,6 +204,43 @@ def test_sharded_step_path_through_rccl_single_rank(dev, monkeypatch):
         dist.destroy_process_group()
 
 
+def test_every_sharded_leg_through_rccl_single_rank(dev, monkeypatch):
+    """The exchange paths of the OTHER sharded legs -- the scene batch (nbv_step_batch: rank-0 draws broadcast, record all-gather) and
+    the MACARONS decision (Cell.fill's draws broadcast, SconeOcc's job draws broadcast, occupancy-row all-gather, uniforms broadcast,
+    (gain, index) record merge) -- through RCCL on a one-rank group (MCR_FORCE_DIST_PATH): bit for bit the plain, local calls.  With
+    tests/_two_rank_step.py (two processes on one GPU, gloo) this is every collective of every leg bench.py times with N > 1."""
+    import socket
+    import torch.distributed as dist
+    import _two_rank_step as two
+    from macarons_amd.nbv import nbv_step_batch, ViewStateGrid
+    g = golden("e2e_grid_config1")
+    occ, vis, _, _ = _models(dev)
+    grid = ViewStateGrid(dev)
+    B = 3
+    pc, X, Xv, cams, perms, u = two.batch_scene(g, B, dev)
+    a = nbv_step_batch(occ, vis, pc, X, Xv, cams, grid, occ_perms=perms, samples=u)
+    mac_local, gmac = two.macarons_decisions(dev)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    monkeypatch.setenv("MCR_FORCE_DIST_PATH", "1")
+    try:
+        b = nbv_step_batch(occ, vis, pc, X, Xv, cams, grid, occ_perms=perms, samples=u, group=dist.group.WORLD)
+        assert b["cloud_range"] == (0, B) and torch.equal(a["occ"], b["occ"]) and torch.equal(a["gains"], b["gains"])
+        assert torch.equal(a["nbv_idx"], b["nbv_idx"]) and torch.equal(a["max_gain"], b["max_gain"])
+        torch.manual_seed(33)
+        c = nbv_step_batch(occ, vis, pc, X, Xv, cams, grid, group=dist.group.WORLD)          # hidden draws: made + broadcast inside
+        assert torch.isfinite(c["gains"]).all()
+        mac_rccl, _ = two.macarons_decisions(dev, group=dist.group.WORLD)
+        for c_ in range(2):
+            (r1, s1), (r2, s2) = mac_local[c_], mac_rccl[c_]
+            assert r2["cam_range"] == (0, 5)
+            assert torch.equal(r2["occ_probs"], r1["occ_probs"]) and torch.equal(r2["X_world"], r1["X_world"]) and torch.equal(r2["gains"], r1["gains"])
+            assert int(r2["next_idx"]) == int(r1["next_idx"]) == int(gmac[f"next_idx_{c_}"]) and float(r2["max_gain"]) == float(r1["max_gain"])
+            assert all(torch.equal(s1[k], s2[k]) for k in s1), c_
+    finally:
+        dist.destroy_process_group()
+
+
 def _run_two_ranks(backend, port):
     import subprocess, sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
