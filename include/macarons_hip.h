@@ -219,13 +219,19 @@ int mcr_local_pct6_blob_floats(void);
  *      for the whole fp32 range (local_pct5.hip; mcr_local_pct3_blob_floats() floats);
  *   6 (default): two-term fp16 split (hi + lo, 22 significant bits), three MFMAs per product, same structure
  *      (local_pct6.hip; mcr_local_pct6_blob_floats() floats); needs |activation| < 65504. */
- * The variant is a property of a CALL: mcr_call_variant(v) is the per-call argument -- the NEXT network entry point (mcr_linear,
+/* The variant is a property of a CALL: mcr_call_variant(v) is the per-call argument -- the NEXT network entry point (mcr_linear,
  * mcr_attention*, mcr_local_pct_forward, mcr_pc_transformer_forward, mcr_scone_vis_forward, mcr_scone_occ_forward*) called on THIS
  * thread runs on variant v (one-shot, thread-local; 0 = the default again).  mcr_set_local_pct_variant only sets the process DEFAULT
  * (start-up value: env MCR_LOCAL_PCT_VARIANT, else 6) that calls without a one-shot take; no call ever changes it. */
 int mcr_set_local_pct_variant(int variant);
 int mcr_get_local_pct_variant(void);
 int mcr_call_variant(int variant);
+/* Range guard of variant 6 for outputs that leave through an entry point without a flag argument (mcr_scone_vis_forward's harmonics):
+ * *flag |= 1 if any of x[0 .. n) is inf / NaN -- what an activation beyond the fp16 range of the split matrix path turns into.  On
+ * variant 6 the encoders of sequences of >= 512 tokens (SconeVis, SconeOcc's global transformer; Attention.py:278-300) run their
+ * GEMMs on fp16 hi/lo planes (LayerNorm / GELU epilogues write the planes, operands reach LDS by DMA; env MCR_ENC_PLANES=0: the
+ * full-range bf16 x 6 kernels of variant 5). */
+int mcr_nonfinite_flag(const float* x, int64_t n, int* flag, void* stream);
 int mcr_local_pct_forward(const float* offsets, float* features, int64_t ld_features, int64_t S, const float* blob,
                           void* stream);
 

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(512, 1) void linear3p_kernel(const _Float16* __rest
                                                           long long rows_per_group, const int* __restrict__ row_group,
                                                           float* __restrict__ Y, _Float16* __restrict__ Yh, _Float16* __restrict__ Yl,
                                                           long long ldy, long long M, int N, int K, int act, float wscale_inv,
-                                                          const float* __restrict__ dot_v, const float* __restrict__ dot_c, int act2) {
+                                                          const float* __restrict__ dot_v, const float* __restrict__ dot_c, int act2,
+                                                          const float* __restrict__ R, long long ldr) {
     constexpr int LP_TN = MODE == LP_DOT ? 256 : 128, LP_TM = MODE == LP_DOT ? 128 : 256;     // features / activation rows per block
     constexpr int LP_XC = LP_TM * 4, LP_WC = LP_TN * 4;                                       // 16-byte chunks per X / W tile and plane
     constexpr int GX = LP_TM / 128, GW = LP_TN / 128;                                         // DMA chunk groups (64 chunks) per wave and plane
@@ -228,6 +229,10 @@ __global__ __launch_bounds__(512, 1) void linear3p_kernel(const _Float16* __rest
                 *reinterpret_cast<uint2*>(Yh + m * ldy + n) = hi;
                 *reinterpret_cast<uint2*>(Yl + m * ldy + n) = lo;
             } else {
+                if (R) {                                   // residual (Attention.py:290, :298); R may be Y: read before the store
+                    const float4 r4 = *reinterpret_cast<const float4*>(R + m * ldr + n);
+                    y[0] += r4.x; y[1] += r4.y; y[2] += r4.z; y[3] += r4.w;
+                }
                 *reinterpret_cast<float4*>(Y + m * ldy + n) = make_float4(y[0], y[1], y[2], y[3]);
             }
         }
@@ -264,7 +269,7 @@ static bool lp_reserve_lds() {                              // 144 KB of dynamic
 // Y (fp32, ldy floats) or Yh / Yl (fp16 planes, ldy halves) = act(X W^T * wscale_inv + bias (+ row bias)); exactly one of Y, Yh is set
 void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
                      const float* bias, float* Y, void* Yh, void* Yl, int64_t ldy, int64_t M, int N, int K, int act, float wscale_inv,
-                     const float* row_bias, int64_t rows_per_group, const int* row_group) {
+                     const float* row_bias, int64_t rows_per_group, const int* row_group, const float* R, int64_t ldr) {
     if (M <= 0 || N <= 0) return;
     if (!lp_reserve_lds()) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LP_LDS_BYTES); return; }
     dim3 grid((unsigned)(cdiv(cdiv(M, 256), 8) * 8 * cdiv(N, 128)));             // 1-D: see the XCD-aware block order in the kernel
@@ -273,12 +278,12 @@ void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx,
         hipLaunchKernelGGL((linear3p_kernel<LP_PLANES>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
                            (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group, (float*)nullptr,
                            (_Float16*)Yh, (_Float16*)Yl, (long long)ldy, (long long)M, N, K, act, wscale_inv, (const float*)nullptr,
-                           (const float*)nullptr, 0);
+                           (const float*)nullptr, 0, (const float*)nullptr, 0ll);
     else
         hipLaunchKernelGGL((linear3p_kernel<LP_F32>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
                            (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group, Y,
                            (_Float16*)nullptr, (_Float16*)nullptr, (long long)ldy, (long long)M, N, K, act, wscale_inv, (const float*)nullptr,
-                           (const float*)nullptr, 0);
+                           (const float*)nullptr, 0, R, (long long)ldr);
 }
 
 // out[m] = act2( act(X W^T * wscale_inv + bias)[m][:] . v + c ) for a 256-feature layer (N == 256): two layers, one launch
@@ -290,7 +295,7 @@ void launch_linear3p_dot(hipStream_t s, const void* Xh, const void* Xl, int64_t 
     dim3 grid((unsigned)(cdiv(cdiv(M, 128), 8) * 8));
     hipLaunchKernelGGL((linear3p_kernel<LP_DOT>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
                        (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, (const float*)nullptr, 1ll, (const int*)nullptr, out,
-                       (_Float16*)nullptr, (_Float16*)nullptr, 1ll, (long long)M, 256, K, act, wscale_inv, v, c, act2);
+                       (_Float16*)nullptr, (_Float16*)nullptr, 1ll, (long long)M, 256, K, act, wscale_inv, v, c, act2, (const float*)nullptr, 0ll);
 }
 
 void launch_split_to_planes(hipStream_t s, const float* X, int64_t ldx, void* Ph, void* Pl, int64_t ldp, int64_t M, int E) {

@@ -108,11 +108,57 @@ static inline bool attn_pv_half() {
     return on && g_local_pct_variant == 6;
 }
 
+// Encoder GEMMs of the long-sequence networks on fp16 hi/lo PLANES (variant 6, sequences of >= 512 tokens; MCR_ENC_PLANES=0: the
+// bf16 x 6 kernels as on variant 5, A/B): the GEMM inputs are split once where they are produced -- LayerNorm writes planes, the FF's
+// first GEMM writes planes, the attention output is split in one pass -- and every operand reaches LDS by DMA (linear3p.hip): no
+// split and no staging registers inside the GEMMs, three MFMAs per product instead of six.  Chosen on the sequence length alone, so a
+// cloud's result does not depend on how many clouds share the launch.  Needs |activation| < 65504 like the rest of variant 6: the
+// occupancy / harmonics that come out non-finite otherwise are what the range guards look at.
+static inline bool enc_planes(int L, int E) {
+    static const bool on = []() { const char* e = getenv("MCR_ENC_PLANES"); return !(e && e[0] == '0'); }();
+    return on && g_local_pct_variant == 6 && L >= 512 && E % 32 == 0;
+}
+
+// The planes live in the encoder's own scratch (an fp32 row = two fp16 rows): h <- planes of LayerNorm(x) / fp32 attention output,
+// ff <- planes of the attention output, then of the FF's hidden layer; the weights' planes (split per call, 2^8 scale: linear3h.hip)
+// go to whichever of ff / qkv is idle.  L >= 512 makes every region large enough for them.
+static void run_encoder_planes(hipStream_t s, const EncW& w, float* x, float* h, float* qkv, float* ff, int64_t S, int L, int E, int H,
+                               const int* lens) {
+    const int64_t T = S * L;
+    const int dqk = E / 4, W3 = 2 * dqk + E;
+    const float inv = 1.0f / 256.0f;
+    _Float16 *hh = reinterpret_cast<_Float16*>(h), *hl = hh + (size_t)T * E;                 // planes [2][T][E] over h
+    _Float16 *fh = reinterpret_cast<_Float16*>(ff);                                          // planes over ff: [2][T][E] or [2][T][2E]
+    auto wsplit = [&](const float* W, int N, int K, void* dst) {
+        launch_split_weights(s, W, K, dst, N, K);
+        return (const _Float16*)dst;
+    };
+    launch_layernorm_planes(s, x, E, w.n1g, w.n1b, hh, hl, E, T, E);                         // Attention.py:287
+    const _Float16* Wq = wsplit(w.qkv.w, W3, E, ff);
+    launch_linear3p(s, hh, hl, E, Wq, Wq + (size_t)W3 * E, E, w.qkv.b, qkv, nullptr, nullptr, W3, T, W3, E, ACT_NONE, inv, nullptr, 0, nullptr);   // :186-188
+    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, /*split_by_length=*/true, attn_pv_half());   // :191-198
+    launch_split_to_planes(s, h, E, fh, fh + (size_t)T * E, E, T, E);
+    const _Float16* Wo = wsplit(w.out.w, E, E, qkv);
+    launch_linear3p(s, fh, fh + (size_t)T * E, E, Wo, Wo + (size_t)E * E, E, w.out.b, x, nullptr, nullptr, E, T, E, E, ACT_NONE, inv, nullptr, 0,
+                    nullptr, x, E);                                                            // :201-202 + residual :290
+    launch_layernorm_planes(s, x, E, w.n2g, w.n2b, hh, hl, E, T, E);                         // :293
+    const _Float16* W1 = wsplit(w.ff1.w, 2 * E, E, qkv);
+    launch_linear3p(s, hh, hl, E, W1, W1 + (size_t)2 * E * E, E, w.ff1.b, nullptr, fh, fh + (size_t)T * 2 * E, 2 * E, T, 2 * E, E, ACT_GELU, inv,
+                    nullptr, 0, nullptr);                                                      // :232 (planes out)
+    const _Float16* W2 = wsplit(w.ff2.w, E, 2 * E, qkv);
+    launch_linear3p(s, fh, fh + (size_t)T * 2 * E, 2 * E, W2, W2 + (size_t)E * 2 * E, 2 * E, w.ff2.b, x, nullptr, nullptr, E, T, E, 2 * E, ACT_NONE,
+                    inv, nullptr, 0, nullptr, x, E);                                           // :235 + residual :298
+}
+
 // x <- Encoder(x)  in place.  x [T, E]; scratch h [T, E], qkv [T, 2*dqk + E], ff [T, 2E]
 static void run_encoder(hipStream_t s, const EncW& w, float* x, float* h, float* qkv, float* ff, int64_t S, int L, int E,
                         int H, const int* lens = nullptr) {
     const int64_t T = S * L;
     const int dqk = E / 4, W3 = 2 * dqk + E;
+    if (enc_planes(L, E)) {
+        run_encoder_planes(s, w, x, h, qkv, ff, S, L, E, H, lens);
+        return;
+    }
     launch_layernorm(s, x, E, w.n1g, w.n1b, h, E, T, E);                                   // Attention.py:287
     // every GEMM of the networks routes (fp32 vs split precision) on the rows of ONE sequence, not on T: see launch_linear
     launch_linear(s, h, E, w.qkv.w, w.qkv.b, nullptr, 0, qkv, W3, T, W3, E, ACT_NONE, nullptr, 0, 0, seq_route(L));       // :186-188
@@ -321,6 +367,15 @@ int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t
     MCR_REQUIRE(X && Y && S > 0 && L > 0 && E > 0, "mcr_pool_max_avg: bad arguments");
     launch_pool_max_avg((hipStream_t)stream, X, ldx, Y, ldy, S, (int)L, E);
     MCR_LAUNCH_CHECK("mcr_pool_max_avg");
+    return 0;
+}
+
+// *flag |= 1 if any of x[0 .. n) is inf / NaN: the range guard of the fp16-split matrix path for outputs that leave through an entry
+// point without a flag of its own (SconeVis' harmonics)
+int mcr_nonfinite_flag(const float* x, int64_t n, int* flag, void* stream) {
+    MCR_REQUIRE(x && flag && n > 0, "mcr_nonfinite_flag: bad arguments");
+    launch_nonfinite_flag((hipStream_t)stream, x, n, flag);
+    MCR_LAUNCH_CHECK("nonfinite_flag_kernel");
     return 0;
 }
 

@@ -81,7 +81,10 @@ void launch_local_pct6(hipStream_t s, const float* offs, float* feat, int64_t ld
 bool linear3p_applicable(int N, int K, int64_t ldx, int64_t ldw, int64_t ldy);
 void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
                      const float* bias, float* Y, void* Yh, void* Yl, int64_t ldy, int64_t M, int N, int K, int act, float wscale_inv,
-                     const float* row_bias, int64_t rows_per_group, const int* row_group);
+                     const float* row_bias, int64_t rows_per_group, const int* row_group, const float* R = nullptr, int64_t ldr = 0);
+// LayerNorm whose output leaves as fp16 hi/lo planes (row stride ldp halves): the input of a planes GEMM, split where it is produced
+void launch_layernorm_planes(hipStream_t s, const float* X, int64_t ldx, const float* g, const float* b, void* Yh, void* Yl, int64_t ldp,
+                             int64_t M, int E);
 void launch_linear_smallk_planes(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, void* Yh, void* Yl,
                                  int64_t ldy, int64_t M, int N, int K, int act);
 bool linear3p_dot_applicable(int N, int K, int64_t ldx, int64_t ldw);

@@ -287,6 +287,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// The same normalisation, the result written as fp16 hi/lo planes (hi = fp16(y), lo = fp16(y - hi): lp_split.h's split of the
+// planes GEMMs): exactly the planes a split of the fp32 rows would give, without the fp32 round trip through HBM.
+template <int EPL>
+__global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ g,
+                                                               const float* __restrict__ b, _Float16* __restrict__ Yh,
+                                                               _Float16* __restrict__ Yl, long long ldp, long long M, int E) {
+    const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    float v[EPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + e * 64;
+        v[e] = c < E ? X[m * ldx + c] : 0.f;
+        sum += v[e];
+    }
+    const float mean = wave_sum_all(sum) / (float)E;
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + e * 64;
+        const float d = c < E ? v[e] - mean : 0.f;
+        sq = fmaf(d, d, sq);
+    }
+    const float var = wave_sum_all(sq) / (float)E;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int c = lane + e * 64;
+        if (c < E) {
+            const float y = (v[e] - mean) * rstd * g[c] + b[c];
+            const _Float16 hi = (_Float16)y;
+            Yh[m * ldp + c] = hi;
+            Yl[m * ldp + c] = (_Float16)(y - (float)hi);
+        }
+    }
+}
+
+void launch_layernorm_planes(hipStream_t s, const float* X, int64_t ldx, const float* g, const float* b, void* Yh, void* Yl, int64_t ldp,
+                             int64_t M, int E) {
+    if (M <= 0) return;
+    dim3 grid((unsigned)cdiv(M, 4));
+    const int epl = (E + 63) / 64;
+#define MCR_LNP(EPL) \
+    hipLaunchKernelGGL((layernorm_planes_kernel<EPL>), grid, dim3(256), 0, s, X, (long long)ldx, g, b, (_Float16*)Yh, (_Float16*)Yl, \
+                       (long long)ldp, (long long)M, E)
+    if (epl <= 2) MCR_LNP(2);
+    else if (epl <= 4) MCR_LNP(4);
+    else MCR_LNP(8);
+#undef MCR_LNP
+}
+
 void launch_layernorm(hipStream_t s, const float* X, int64_t ldx, const float* g, const float* b, float* Y, int64_t ldy,
                       int64_t M, int E) {
     if (M <= 0) return;

@@ -51,7 +51,7 @@ def _harmonics_beside(scone_occ, pc, Xl, harmonics_of):
     return begun, vh
 
 
-def _guarded(impl, scone_occ, range_guard, group, draws, device):
+def _guarded(impl, scone_occ, range_guard, group, draws, device, scone_vis=None):
     """Run one decision with SconeOcc's range check deferred to the END of the step (the step itself stays free of host
     synchronisation); if the flag comes back set (an activation left the fp16 range of the default matrix path, SconeOcc.range_guard)
     the decision is repeated on variant 5 with the SAME hidden draws.  `draws()` pins the draws before the first attempt when
@@ -61,10 +61,17 @@ def _guarded(impl, scone_occ, range_guard, group, draws, device):
     prev = scone_occ.range_guard
     guard = range_guard and prev != "off" and ops.current_variant() == 6
     scone_occ.range_guard = "defer" if (guard or prev != "off") else "off"
+    # SconeVis (its encoders run on the same fp16 planes) reports into the SAME flag: one read-back covers both networks
+    vis_prev = None
+    if scone_vis is not None and hasattr(scone_vis, "range_guard"):
+        vis_prev = (scone_vis.range_guard, scone_vis._range_flag)
+        scone_vis.range_guard = scone_occ.range_guard
     try:
         # the flag exists on every rank before the step (not only on ranks that run a guarded forward: a rank with an empty query
         # shard runs none), so that whether the all-reduce below is entered depends on rank-invariant state only
         scone_occ.clear_range_flag(device if guard else None)
+        if vis_prev is not None:
+            scone_vis._range_flag = scone_occ.range_flag()
         kw = draws() if (guard and not capturing) else {}
         out = impl(**kw)
         flag = scone_occ.range_flag() if ops.current_variant() == 6 else None
@@ -89,6 +96,8 @@ def _guarded(impl, scone_occ, range_guard, group, draws, device):
                 out.pop("host", None)
     finally:
         scone_occ.range_guard = prev
+        if vis_prev is not None:
+            scone_vis.range_guard, scone_vis._range_flag = vis_prev
     return out
 
 
@@ -118,7 +127,7 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
                          true_monte_carlo_sampling, fixed["occ_perms"], fixed["samples"], group, view_proj, filter_tol, return_samples)
     if mdist.group_world_rank(group)[0] > 1:
         draws = lambda: {}                          # noqa: E731  (sharded: rank 0's draws are broadcast inside the step; a repeat redraws)
-    return _guarded(impl, scone_occ, range_guard, group, draws, X.device)
+    return _guarded(impl, scone_occ, range_guard, group, draws, X.device, scone_vis)
 
 
 def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1,
@@ -265,7 +274,7 @@ def nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=204
     def impl():
         return _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len, min_occ, true_monte_carlo_sampling,
                                fixed["occ_perms"], fixed["samples"], group, return_samples)
-    return _guarded(impl, scone_occ, range_guard, group, draws, X.device)
+    return _guarded(impl, scone_occ, range_guard, group, draws, X.device, scone_vis)
 
 
 def _nbv_step_batch(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1, true_monte_carlo_sampling=True,

@@ -17,7 +17,7 @@ from .. import ops, _lib
 from .Attention import (Embedding, Encoder, FeedForward, MultiHeadSelfAttention, attention, knn_gather,   # noqa: F401
                         _f32c, _inference_only)     # the public ones are what upstream's `from .Attention import *` hands on
 from ..utility.utils import get_knn_points   # noqa: F401  (SconeOcc.py:4)
-from .packing import BlobCache, HeadPlaneCache, TableCache, param_key, invalidate as _invalidate_key, freeze as _freeze_key
+from .packing import RangeGuard, BlobCache, HeadPlaneCache, TableCache, param_key, invalidate as _invalidate_key, freeze as _freeze_key
 
 
 class XEmbedding(nn.Module):
@@ -85,7 +85,7 @@ class PCTransformer(nn.Module):
         return ops.pc_transformer_forward(pc, self.weight_table(), self.feature_dim)
 
 
-class SconeOcc(nn.Module):
+class SconeOcc(RangeGuard, nn.Module):
     def __init__(self, seq_len=2048, pts_dim=3, pts_embedding_dim=128, concatenate_input=True, n_code=2, n_heads=4,
                  FF=True, gelu=True, global_feature_dim=512, n_scale=3, local_feature_dim=256, k_for_knn=16, x_dim=3,
                  x_embedding_dim=512, n_harmonics=64, output_dim=1, dropout=None, offset=True):
@@ -137,52 +137,6 @@ class SconeOcc(nn.Module):
         self._range_flag = None
         self._range_pending = []            # (pinned host int32 [1], event) of forwards whose flag has not been looked at yet
         self._full_range = False            # True once an overflow was seen: variant 5 from then on
-
-    def range_flag(self):
-        """int32 device tensor [1]: 1 if a forward since clear_range_flag() produced a non-finite occupancy (None before the first
-        guarded forward)."""
-        return self._range_flag
-
-    def _post_range_check(self, flag):
-        """"async" guard: queue a copy of the flag to pinned host memory behind the forward's kernels (no stall)."""
-        host = torch.empty(1, dtype=torch.int32).pin_memory() if not self._range_pool else self._range_pool.pop()
-        host.copy_(flag, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(flag.device))
-        self._range_pending.append((host, ev))
-
-    _range_pool = ()
-
-    def check_range(self, wait=False):
-        """Look at the range flags of earlier forwards ("async" guard).  wait=False: only copies that have already landed (never stalls);
-        wait=True: wait for all of them.  -> True if an overflow of the fp16-split path was seen (now or earlier); from then on this
-        module runs on the full-range variant 5.  The forward that overflowed returned non-finite occupancies."""
-        keep = []
-        for host, ev in self._range_pending:
-            if wait:
-                ev.synchronize()
-            if wait or ev.query():
-                if int(host[0]) and not self._full_range:
-                    import warnings
-                    warnings.warn("SconeOcc: an activation left the fp16 range of the default matrix path (variant 6) -- that forward "
-                                  "returned non-finite occupancies; this module runs on the full-range variant 5 from now on "
-                                  "(range_guard='sync' repeats the forward itself at the price of a read-back per call)", RuntimeWarning, stacklevel=3)
-                    self._full_range = True
-                if not isinstance(self._range_pool, list):
-                    self._range_pool = []
-                self._range_pool.append(host)
-            else:
-                keep.append((host, ev))
-        self._range_pending = keep
-        return self._full_range
-
-    def clear_range_flag(self, device=None):
-        """Zero the flag; with `device`, create it there first if this module has not run a guarded forward on it yet (a rank whose
-        query shard is empty never runs one, yet has to bring a flag to the step's all-reduce)."""
-        if device is not None and (self._range_flag is None or self._range_flag.device != torch.device(device)):
-            self._range_flag = torch.zeros(1, dtype=torch.int32, device=device)
-        elif self._range_flag is not None:
-            self._range_flag.zero_()
 
     def freeze_weight_caches(self, on=True):
         """Inference mode: fingerprint the parameters once, now, and trust them unchanged until freeze_weight_caches(False) or

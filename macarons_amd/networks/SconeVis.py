@@ -21,10 +21,10 @@ from .. import ops
 from .Attention import Embedding, Encoder, FeedForward, MultiHeadSelfAttention, attention, knn_gather, _f32c   # noqa: F401
 from ..utility.CustomGeometry import get_spherical_coords                                                # noqa: F401
 from ..utility.spherical_harmonics import clear_spherical_harmonics_cache, get_spherical_harmonics       # noqa: F401
-from .packing import TableCache, freeze as _freeze_key
+from .packing import RangeGuard, TableCache, freeze as _freeze_key
 
 
-class SconeVis(nn.Module):
+class SconeVis(RangeGuard, nn.Module):
     def __init__(self, pts_dim=4, seq_len=2048, pts_embedding_dim=256, n_heads=4, n_code=3, n_harmonics=64,
                  max_harmonic_rank=8, FF=True, gelu=True, dropout=None, use_view_state=True, use_global_feature=True,
                  view_state_mode="end", concatenate_input=True, k_for_knn=0, alt=False, use_sigmoid=True):
@@ -107,7 +107,31 @@ class SconeVis(nn.Module):
             res = ops.linear(res, _f32c(self.fc1.weight), _f32c(self.fc1.bias), gelu=True)
             res = ops.linear(torch.cat((res, view_harmonics), dim=-1), _f32c(self.fc2.weight), _f32c(self.fc2.bias), gelu=True)
             return ops.linear(res, _f32c(self.fc3.weight), _f32c(self.fc3.bias)).view(n_clouds, seq_len, self.n_harmonics)
-        hip = lambda p, vh: ops.scone_vis_forward(p, vh, self._table_cache.get(self, self.weight_table), lengths)
+        # Range guard (packing.RangeGuard): on variant 6 the encoders of a cloud of >= 512 points run their GEMMs on fp16 hi/lo planes
+        # (|activation| < 65504); harmonics that come out non-finite raise the flag.  "async" (default): looked at without a stall by a
+        # later forward / check_range(); "defer": left in range_flag() (nbv_step and macarons_nbv_decision share SconeOcc's flag and
+        # read it once per decision); "sync": read now, repeat on variant 5; "off": nothing.
+        if self.range_guard == "async" and (self._range_pending or self._full_range):
+            self.check_range()
+        if self._full_range and ops.current_variant() == 6:
+            with ops.variant(5):
+                return self.forward(pts, mask, view_harmonics, lengths)
+        guarded = ops.current_variant() == 6 and seq_len >= 512 and self.range_guard != "off" and not torch.cuda.is_current_stream_capturing()
+
+        def hip(p, vh):
+            res_ = ops.scone_vis_forward(p, vh, self._table_cache.get(self, self.weight_table), lengths)
+            if guarded:
+                if self._range_flag is None or self._range_flag.device != p.device:
+                    self._range_flag = torch.zeros(1, dtype=torch.int32, device=p.device)
+                elif self.range_guard in ("sync", "async"):
+                    self._range_flag.zero_()
+                ops.nonfinite_flag_(res_, self._range_flag)
+                if self.range_guard == "sync" and int(self._range_flag):
+                    with ops.variant(5):
+                        res_ = ops.scone_vis_forward(p, vh, self._table_cache.get(self, self.weight_table), lengths)
+                elif self.range_guard == "async":
+                    self._post_range_check(self._range_flag)
+            return res_
         if A.needs_grad(self, pts, view_harmonics):     # trainers (pretrain_scone_vis.py:224): HIP forward, composite-torch backward
             res = A.with_torch_backward(hip, lambda p, vh: A.scone_vis(self, p, vh, lengths), (pts, view_harmonics), self)
         else:

@@ -311,3 +311,62 @@ class HeadPlaneCache:
                          (ctypes.c_float * 4)(*[inv for _, inv in packed]))
             self._key = key
         return self._val
+
+
+class RangeGuard:
+    """Range guard of the default numerics (variant 6: matrix operands as fp16 hi/lo planes, valid for |activation| < 65504; the
+    reference is plain fp32), shared by SconeOcc and SconeVis.  The kernels OR a device flag when an output comes out non-finite --
+    what an out-of-range activation turns into; `range_guard` says who looks at it (see SconeOcc.__init__).  A module that saw an
+    overflow runs on the full-range variant 5 from then on."""
+    range_guard = "async"
+    _range_flag = None
+    _range_pending = ()
+    _range_pool = ()
+    _full_range = False
+
+    def range_flag(self):
+        """int32 device tensor [1]: 1 if a forward since clear_range_flag() produced a non-finite occupancy (None before the first
+        guarded forward)."""
+        return self._range_flag
+
+    def _post_range_check(self, flag):
+        """"async" guard: queue a copy of the flag to pinned host memory behind the forward's kernels (no stall)."""
+        host = torch.empty(1, dtype=torch.int32).pin_memory() if not self._range_pool else self._range_pool.pop()
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(flag.device))
+        self._range_pending = list(self._range_pending) + [(host, ev)]
+
+    _range_pool = ()
+
+    def check_range(self, wait=False):
+        """Look at the range flags of earlier forwards ("async" guard).  wait=False: only copies that have already landed (never stalls);
+        wait=True: wait for all of them.  -> True if an overflow of the fp16-split path was seen (now or earlier); from then on this
+        module runs on the full-range variant 5.  The forward that overflowed returned non-finite occupancies."""
+        keep = []
+        for host, ev in self._range_pending:
+            if wait:
+                ev.synchronize()
+            if wait or ev.query():
+                if int(host[0]) and not self._full_range:
+                    import warnings
+                    warnings.warn(type(self).__name__ + ": an activation left the fp16 range of the default matrix path (variant 6) -- that forward "
+                                  "returned non-finite values; this module runs on the full-range variant 5 from now on "
+                                  "(range_guard='sync' repeats the forward itself at the price of a read-back per call)", RuntimeWarning, stacklevel=3)
+                    self._full_range = True
+                if not isinstance(self._range_pool, list):
+                    self._range_pool = []
+                self._range_pool.append(host)
+            else:
+                keep.append((host, ev))
+        self._range_pending = keep
+        return self._full_range
+
+    def clear_range_flag(self, device=None):
+        """Zero the flag; with `device`, create it there first if this module has not run a guarded forward on it yet (a rank whose
+        query shard is empty never runs one, yet has to bring a flag to the step's all-reduce)."""
+        if device is not None and (self._range_flag is None or self._range_flag.device != torch.device(device)):
+            self._range_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        elif self._range_flag is not None:
+            self._range_flag.zero_()
+

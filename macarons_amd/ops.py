@@ -400,6 +400,15 @@ def scone_vis_forward(pts, view_harmonics, weights, lengths=None):
     return out
 
 
+def nonfinite_flag_(x, flag):
+    """flag (int32 device [1]) |= 1 if x holds an inf / NaN (mcr_nonfinite_flag); no read-back."""
+    x = _req(x, "x")
+    if x.numel():
+        with torch.cuda.device(x.device):
+            check(lib().mcr_nonfinite_flag(_p(x), c_i64(x.numel()), _p(_req(flag, "flag", torch.int32)), _stream()), "mcr_nonfinite_flag")
+    return flag
+
+
 def local_pct_forward(offsets, blob):
     """offsets [S,16,3] -> [S,256]: fused local PCTransformer (local_pct.hip)."""
     offsets, blob = _req(offsets, "offsets"), _req(blob, "blob")

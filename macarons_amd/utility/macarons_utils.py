@@ -260,9 +260,13 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     guard_before = getattr(occ_net, "range_guard", None)
     deferred = range_guard and guard_before in ("sync", "async") and hasattr(occ_net, "forward_ragged")
     record = {}
+    vis_prev = None
     if deferred:
         occ_net.range_guard = "defer"
         occ_net.clear_range_flag(device)                # (exists on every rank before the pass: the all-reduce below is rank-invariant)
+        if hasattr(vis_model, "range_guard"):           # SconeVis reports into the SAME flag: one read-back covers both networks
+            vis_prev = (vis_model.range_guard, vis_model._range_flag)
+            vis_model.range_guard, vis_model._range_flag = "defer", occ_net.range_flag()
     try:
         X_world, view_harmonics, occ_probs, gains = field_and_gains(None, samples, record)
         # `if coverage_gain > max_coverage_gain` from -1: the first strict maximum (a NaN gain never wins upstream; here it would)
@@ -285,6 +289,8 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     finally:
         if deferred:
             occ_net.range_guard = guard_before
+        if vis_prev is not None:
+            vis_model.range_guard, vis_model._range_flag = vis_prev
     if xch:                                             # ties -> the lowest index over all ranks = the first strict maximum
         max_gain, next_idx = mdist.allgather_best(gains.view(1, -1), k0, group)
         out = {"next_idx": next_idx[0], "max_gain": max_gain[0], "cam_range": (k0, k1)}

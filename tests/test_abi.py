@@ -59,3 +59,17 @@ def test_torch_ops_registered_without_cpu_fallback():
         assert hasattr(torch.ops.macarons, name)
     with pytest.raises(NotImplementedError):
         torch.ops.macarons.sh_coverage_gain(torch.zeros(1, 4, 3), torch.zeros(1, 4, 64), torch.zeros(1, 2, 3), True)
+
+
+def test_header_is_valid_c():
+    """include/macarons_hip.h is what a non-Python host compiles against (and what libmacarons_torch.so is built with): it must parse as
+    plain C -- a comment left open once broke the extension's build without any Python test noticing."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-Wall", os.path.join(root, "include", "macarons_hip.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -410,6 +410,7 @@ def test_macarons_trajectory_matches_reference(dev):
                 for j_, v_ in fixes.get((step, int(a) * 8 + int(e)), {}).items():
                     u[k, j_] = v_
             r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, depth, dmask, nrec, T(n_eyes, dev), dev, samples=u.to(dev))
+            assert "fallback_variant" not in r                       # (the range guard of both networks stayed quiet)
             bits = lambda t_: np.packbits(t_.cpu().numpy().reshape(-1).astype(np.uint8))
             assert np.array_equal(bits(r["fov_mask"]), g[f"fov_mask_{step}"]), step
             assert np.array_equal(bits(proxy.proxy_supervision_occ), g[f"sup_occ_{step}"]), step

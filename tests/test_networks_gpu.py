@@ -404,6 +404,49 @@ def test_range_guard_falls_back_to_full_range_variant(dev, where):
     assert int(r0["range_flag"]) == 1 and "fallback_variant" not in r0
 
 
+def test_scone_vis_encoders_on_planes_and_their_range_guard(dev):
+    """Variant 6 runs the encoder GEMMs of clouds of >= 512 points on fp16 hi/lo planes (LayerNorm / GELU epilogues write the planes,
+    linear3p.hip): against the fp64 oracle at 1e-4 like every other path (scone_vis.npz holds it to the reference), a batch gives each
+    cloud the bits of its single call, and activations beyond the fp16 range are caught: the harmonics come out non-finite, the
+    default ("async") guard notices without a read-back inside forward and moves the module to variant 5; "sync" repeats at once."""
+    from macarons_amd.networks import SconeVis
+    from macarons_amd import _lib, ops
+    if _lib.lib().mcr_get_local_pct_variant() != 6:
+        pytest.skip("the planes encoders belong to variant 6 (suite running on another variant)")
+    m, sd = _mod(SconeVis, 1, dev)
+    rng = np.random.default_rng(77)
+    pts = np.concatenate([rng.uniform(-.5, .5, (3, 700, 3)), rng.uniform(.1, 1., (3, 700, 1))], -1).astype(np.float32)
+    vh = (rng.standard_normal((3, 700, 64)) * 0.3).astype(np.float32)
+    with torch.no_grad():
+        y = m(T(pts, dev), view_harmonics=T(vh, dev))
+        for b in range(3):
+            assert torch.equal(y[b:b + 1], m(T(pts[b:b + 1], dev), view_harmonics=T(vh[b:b + 1], dev))), b
+        with ops.variant(5):
+            y5 = m(T(pts, dev), view_harmonics=T(vh, dev))
+    ref = nets.scone_vis_forward(sd, pts, vh, np.float64)
+    assert rel_err(y.cpu().numpy(), ref) < 1e-5 and rel_err(y5.cpu().numpy(), ref) < 1e-5
+    assert not torch.equal(y, y5)                                      # (two different matrix paths did run)
+    assert m.check_range(wait=True) is False
+    # out of range: an FF layer scaled by 2^17
+    sd2 = {k: v.copy() for k, v in sd.items()}
+    for k in ("encoders.1.ff.linear1.weight", "encoders.1.ff.linear1.bias"):
+        sd2[k] = sd2[k] * np.float32(131072.0)
+    m2, _ = _mod(SconeVis, 1, dev)
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    ref2 = nets.scone_vis_forward(sd2, pts[:1], vh[:1], np.float64)
+    with torch.no_grad():
+        ya = m2(T(pts[:1], dev), view_harmonics=T(vh[:1], dev))
+        assert not torch.isfinite(ya).all()
+        with pytest.warns(RuntimeWarning, match="full-range variant 5"):
+            assert m2.check_range(wait=True) is True
+        yb = m2(T(pts[:1], dev), view_harmonics=T(vh[:1], dev))
+        m3, _ = _mod(SconeVis, 1, dev)
+        m3.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+        m3.range_guard = "sync"
+        yc = m3(T(pts[:1], dev), view_harmonics=T(vh[:1], dev))
+    assert torch.isfinite(yb).all() and rel_err(yb.cpu().numpy(), ref2) < 1e-4 and torch.equal(yb, yc)
+
+
 def test_scone_occ_ragged_equals_job_by_job(dev):
     """SconeOcc.forward_ragged (J clouds / query chunks of different sizes in one launch sequence: segmented kNN, padded global
     down-samples with lengths, per-row job bias in the head) == J forward() calls with the same draws: local features, x-embedding
