@@ -136,10 +136,15 @@ static void run_encoder_planes(hipStream_t s, const EncW& w, float* x, float* h,
     launch_layernorm_planes(s, x, E, w.n1g, w.n1b, hh, hl, E, T, E);                         // Attention.py:287
     const _Float16* Wq = wsplit(w.qkv.w, W3, E, ff);
     launch_linear3p(s, hh, hl, E, Wq, Wq + (size_t)W3 * E, E, w.qkv.b, qkv, nullptr, nullptr, W3, T, W3, E, ACT_NONE, inv, nullptr, 0, nullptr);   // :186-188
-    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, /*split_by_length=*/true, attn_pv_half());   // :191-198
-    launch_split_to_planes(s, h, E, fh, fh + (size_t)T * E, E, T, E);
-    const _Float16* Wo = wsplit(w.out.w, E, E, qkv);
-    launch_linear3p(s, fh, fh + (size_t)T * E, E, Wo, Wo + (size_t)E * E, E, w.out.b, x, nullptr, nullptr, E, T, E, E, ACT_NONE, inv, nullptr, 0,
+    // attention: fp32 parts in h / ff (key-split scratch); its combine pass writes the result straight as planes into qkv (free by then)
+    _Float16* ah = reinterpret_cast<_Float16*>(qkv);
+    bool planes_done = false;
+    static const bool fuse = []() { const char* e = getenv("MCR_ENC_COMBINE_PLANES"); return !(e && e[0] == '0'); }();   // (A/B)
+    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, /*split_by_length=*/true, attn_pv_half(), nullptr, 0, 0, 0,
+                     fuse ? ah : nullptr, ah + (size_t)T * E, E, &planes_done);              // :191-198
+    if (!planes_done) launch_split_to_planes(s, h, E, ah, ah + (size_t)T * E, E, T, E);
+    const _Float16* Wo = wsplit(w.out.w, E, E, ff);
+    launch_linear3p(s, ah, ah + (size_t)T * E, E, Wo, Wo + (size_t)E * E, E, w.out.b, x, nullptr, nullptr, E, T, E, E, ACT_NONE, inv, nullptr, 0,
                     nullptr, x, E);                                                            // :201-202 + residual :290
     launch_layernorm_planes(s, x, E, w.n2g, w.n2b, hh, hl, E, T, E);                         // :293
     const _Float16* W1 = wsplit(w.ff1.w, 2 * E, E, qkv);

@@ -53,7 +53,10 @@ void launch_layernorm(hipStream_t s, const float* X, int64_t ldx, const float* g
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
                       int DQK, int DV, const int* lens = nullptr, float* split_ws = nullptr, size_t split_ws_floats = 0,
                       bool split_by_length = false, bool pv_half = false, const unsigned char* mask = nullptr,
-                      int64_t mask_seq_stride = 0, int64_t mask_head_stride = 0, int64_t mask_query_stride = 0);
+                      int64_t mask_seq_stride = 0, int64_t mask_head_stride = 0, int64_t mask_query_stride = 0,
+                      void* planes_h = nullptr, void* planes_l = nullptr, int64_t ldp = 0, bool* planes_done = nullptr);
+// planes_h / planes_l (optional): when the key-split form runs, its combine pass writes the result as fp16 hi/lo planes (row stride ldp
+// halves) INSTEAD of fp32 rows of `out`; *planes_done says whether that happened (else `out` holds fp32 rows as usual)
 size_t attention_split_floats(int64_t S, int L, int H, int DV);
 
 // Column max over the L rows of each of S sequences, broadcast into a column slice of every row:

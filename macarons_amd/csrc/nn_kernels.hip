@@ -832,8 +832,11 @@ __global__ __launch_bounds__(256, att_occ(DQ, QG)) void attention_mfma_kernel(co
 
 
 // out[t, h, :] = (w0 o0 + w1 o1) / (w0 l0 + w1 l1),  w_p = exp(m_p - max(m0, m1)); a part without keys has m = -inf, l = 0
+// Ph / Pl (optional, row stride ldp halves): the result leaves as fp16 hi/lo planes INSTEAD of fp32 rows -- the input of a planes GEMM
+// (the out-projection of an encoder on the fp16-split matrix path), split where it is produced
 __global__ void attention_combine_kernel(float* __restrict__ out, long long ldo, const float* __restrict__ part1,
-                                         const float* __restrict__ ml, long long T, int H, int DV) {
+                                         const float* __restrict__ ml, long long T, int H, int DV, _Float16* __restrict__ Ph,
+                                         _Float16* __restrict__ Pl, long long ldp) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int E = H * DV;
     if (idx >= T * E) return;
@@ -844,14 +847,23 @@ __global__ void attention_combine_kernel(float* __restrict__ out, long long ldo,
     const float m0 = p0[0], l0 = p0[1], m1 = p1[0], l1 = p1[1];
     const float M = fmaxf(m0, m1);
     const float w0 = __expf(m0 - M), w1 = l1 > 0.f ? __expf(m1 - M) : 0.f;
-    out[t * ldo + c] = (w0 * out[t * ldo + c] + w1 * part1[t * E + c]) / (w0 * l0 + w1 * l1);
+    const float y = (w0 * out[t * ldo + c] + w1 * part1[t * E + c]) / (w0 * l0 + w1 * l1);
+    if (Ph) {
+        const _Float16 hi = (_Float16)y;
+        Ph[t * ldp + c] = hi;
+        Pl[t * ldp + c] = (_Float16)(y - (float)hi);
+    } else {
+        out[t * ldo + c] = y;
+    }
 }
 
 size_t attention_split_floats(int64_t S, int L, int H, int DV) { return (size_t)S * L * DV + (size_t)4 * S * L * H; }
 
 void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int L, int H,
                       int DQK, int DV, const int* lens, float* split_ws, size_t split_ws_floats, bool split_by_length, bool pv_half,
-                      const unsigned char* mask, int64_t mask_seq_stride, int64_t mask_head_stride, int64_t mask_query_stride) {
+                      const unsigned char* mask, int64_t mask_seq_stride, int64_t mask_head_stride, int64_t mask_query_stride,
+                      void* planes_h, void* planes_l, int64_t ldp, bool* planes_done) {
+    if (planes_done) *planes_done = false;
     if (S <= 0 || L <= 0) return;
     const int dq = DQK / H, dv = DV / H;
     const AttnMask mk{mask, (long long)mask_seq_stride, (long long)mask_head_stride, (long long)mask_query_stride};
@@ -908,7 +920,9 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
                 MCR_ATT(16, 64, true, g2, part1, ml);
             }
             hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv(S * L * DV, 256)), dim3(256), 0, s, out, (long long)ldo,
-                               (const float*)part1, (const float*)ml, (long long)(S * L), H, dv);
+                               (const float*)part1, (const float*)ml, (long long)(S * L), H, dv, (_Float16*)planes_h, (_Float16*)planes_l,
+                               (long long)ldp);
+            if (planes_done) *planes_done = planes_h != nullptr;
         } else if (qg2) {
             if (dq == 8) MCR_ATT2(8, 32, false, grid2, (float*)nullptr, (float*)nullptr);
             else MCR_ATT2(16, 64, false, grid2, (float*)nullptr, (float*)nullptr);
