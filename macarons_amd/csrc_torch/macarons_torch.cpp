@@ -4,12 +4,16 @@
 // through torch's caching allocator, one call.  Registered on the CUDA (= HIP on ROCm) dispatch key only: there is no CPU kernel.
 // Reference op sequences (file:line, upstream tree) are cited per operator in include/macarons_hip.h.
 #include <ATen/ATen.h>
+#include <ATen/CPUGeneratorImpl.h>
+#include <ATen/core/MT19937RNGEngine.h>
 // torch on ROCm keeps the device type "cuda": the guard / stream accessors are the Masquerading-As-CUDA flavours of c10::hip
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
 #include <algorithm>
+#include <limits>
+#include <optional>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -200,6 +204,87 @@ at::Tensor scone_occ_forward(const at::Tensor& pcg_, c10::List<at::Tensor> pc_sc
 // calls in the SAME order on the SAME generator -- the stream of draws is the reference's, bit for bit -- and return the index arrays
 // the launches need, ready to upload.
 
+// Only a PREFIX of most of these permutations is used (2048 of up to 27 000 points for the global transformer, 1 / ds of them for the
+// coarser scales), and at::randperm's Fisher-Yates loop fixes position i in iteration i: the first k outputs are final after k
+// iterations.  So the loop is restated here (randperm_cpu's branch for n < 2^32 / 20: z = random() % (n - i), swap(r[i], r[i + z]) for
+// i < n - 1, random() = the next 32-bit output of the generator's mt19937 engine), run for the iterations that matter, and the engine
+// is ADVANCED over the outputs the remaining iterations would have consumed (whole state blocks by the twist alone, no tempering, no
+// division, no swap): the prefix and the generator state afterwards are at::randperm's, bit for bit (tests/test_draws_cpu.py holds
+// both operators to loops of torch.randperm), at a third of the host time.
+struct Mt19937 {
+    at::mt19937_data_pod d;
+    static inline uint32_t twist(uint32_t u, uint32_t v) { return (((u & at::UMASK) | (v & at::LMASK)) >> 1) ^ (v & 1 ? at::MATRIX_A : 0); }
+    void next_state() {                                    // at::mt19937_engine::next_state
+        uint32_t* p = d.state_.data();
+        d.left_ = at::MERSENNE_STATE_N;
+        d.next_ = 0;
+        for (int j = at::MERSENNE_STATE_N - at::MERSENNE_STATE_M + 1; --j; p++) *p = p[at::MERSENNE_STATE_M] ^ twist(p[0], p[1]);
+        for (int j = at::MERSENNE_STATE_M; --j; p++) *p = p[at::MERSENNE_STATE_M - at::MERSENNE_STATE_N] ^ twist(p[0], p[1]);
+        *p = p[at::MERSENNE_STATE_M - at::MERSENNE_STATE_N] ^ twist(p[0], d.state_[0]);
+    }
+    inline uint32_t next() {                               // at::mt19937_engine::operator()
+        if (--d.left_ == 0) next_state();
+        uint32_t y = d.state_[d.next_++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680;
+        y ^= (y << 15) & 0xefc60000;
+        y ^= (y >> 18);
+        return y;
+    }
+    void discard(int64_t n) {                              // n calls of next() whose values nobody looks at
+        while (n > 0) {
+            const int64_t avail = d.left_ - 1;             // calls before the one that regenerates the state
+            if (n <= avail) {
+                d.left_ -= (int)n;
+                d.next_ += (uint32_t)n;
+                return;
+            }
+            n -= avail + 1;                                // ... those, and the regenerating call itself (it consumes state_[0])
+            next_state();
+            d.next_ = 1;
+        }
+    }
+};
+
+struct CpuDraws {                                          // the default CPU generator's engine, held under its mutex for a batch of draws
+    at::CPUGeneratorImpl* gen;
+    std::unique_lock<std::mutex> lock;
+    Mt19937 mt;
+    std::vector<int32_t> r;                                // identity permutation, restored after every draw
+    std::vector<int32_t> touched;
+    CpuDraws() : gen(at::get_generator_or_default<at::CPUGeneratorImpl>(std::nullopt, at::detail::getDefaultCPUGenerator())), lock(gen->mutex_) {
+        mt.d = gen->engine().data();
+    }
+    ~CpuDraws() {
+        at::mt19937 e = gen->engine();
+        e.set_data(mt.d);
+        gen->set_engine(e);
+    }
+    // out[t] = base + randperm(n)[t] for t < min(k, n)
+    void prefix(int64_t n, int64_t k, int64_t base, int64_t* out) {
+        TORCH_CHECK(n >= 0 && n < (int64_t)(std::numeric_limits<uint32_t>::max() / 20), "randperm prefix: n out of the 32-bit branch of at::randperm");
+        if ((int64_t)r.size() < n) {
+            const size_t o = r.size();
+            r.resize((size_t)n);
+            for (size_t i = o; i < (size_t)n; ++i) r[i] = (int32_t)i;
+        }
+        k = std::min(k, n);
+        const int64_t iters = std::min(k, std::max<int64_t>(n - 1, 0));   // position i is final after iteration i (the last one after n - 2)
+        touched.clear();
+        for (int64_t i = 0; i < iters; ++i) {
+            const int64_t z = (int64_t)mt.next() % (n - i);
+            const int32_t sav = r[i];
+            r[i] = r[z + i];
+            r[z + i] = sav;
+            touched.push_back((int32_t)(z + i));
+        }
+        for (int64_t t = 0; t < k; ++t) out[t] = base + r[t];
+        for (int64_t i = 0; i < iters; ++i) r[i] = (int32_t)i;
+        for (int32_t p : touched) r[p] = p;
+        if (n - 1 > iters) mt.discard(n - 1 - iters);
+    }
+};
+
 // randperm(n[i])[:keep[i]] for every i, concatenated.
 at::Tensor randperm_prefixes(c10::IntArrayRef n, c10::IntArrayRef keep) {
     TORCH_CHECK(n.size() == keep.size(), "randperm_prefixes: one prefix length per draw");
@@ -207,11 +292,10 @@ at::Tensor randperm_prefixes(c10::IntArrayRef n, c10::IntArrayRef keep) {
     for (size_t i = 0; i < n.size(); ++i) total += std::min<int64_t>(n[i], keep[i]);
     at::Tensor out = at::empty({total}, at::kLong);
     int64_t* o = out.data_ptr<int64_t>();
+    CpuDraws draws;
     for (size_t i = 0; i < n.size(); ++i) {
-        const at::Tensor p = at::randperm(n[i], at::TensorOptions().dtype(at::kLong));
-        const int64_t k = std::min<int64_t>(n[i], keep[i]);
-        std::memcpy(o, p.data_ptr<int64_t>(), (size_t)k * sizeof(int64_t));
-        o += k;
+        draws.prefix(n[i], keep[i], 0, o);
+        o += std::min<int64_t>(n[i], keep[i]);
     }
     return out;
 }
@@ -237,20 +321,14 @@ at::Tensor scone_occ_draws(c10::IntArrayRef m0, c10::IntArrayRef m1, c10::IntArr
     int64_t* glen = off2 + J + 1;
     int64_t c0 = 0, a1 = 0, a2 = 0;
     off1[0] = off2[0] = 0;
-    const at::TensorOptions opt = at::TensorOptions().dtype(at::kLong);
+    CpuDraws draws;
     for (int64_t j = 0; j < J; ++j) {
-        const at::Tensor p0 = at::randperm(m0[j], opt);                  // SconeOcc.py:269
         const int64_t n0 = std::min<int64_t>(m0[j], Lg);
-        const int64_t* q = p0.data_ptr<int64_t>();
-        for (int64_t t = 0; t < n0; ++t) g[j * Lg + t] = c0 + q[t];
+        draws.prefix(m0[j], Lg, c0, g + j * Lg);                         // SconeOcc.py:269
         for (int64_t t = n0; t < Lg; ++t) g[j * Lg + t] = c0;
         glen[j] = n0;
-        const at::Tensor p1 = at::randperm(m0[j], opt);                  // :311, scale 0 -> 1
-        q = p1.data_ptr<int64_t>();
-        for (int64_t t = 0; t < m1[j]; ++t) i1[a1 + t] = c0 + q[t];
-        const at::Tensor p2 = at::randperm(m1[j], opt);                  // :311, scale 1 -> 2 (rows of scale 1's cloud)
-        q = p2.data_ptr<int64_t>();
-        for (int64_t t = 0; t < m2[j]; ++t) i2[a2 + t] = a1 + q[t];
+        draws.prefix(m0[j], m1[j], c0, i1 + a1);                         // :311, scale 0 -> 1
+        draws.prefix(m1[j], m2[j], a1, i2 + a2);                         // :311, scale 1 -> 2 (rows of scale 1's cloud)
         c0 += m0[j]; a1 += m1[j]; a2 += m2[j];
         off1[j + 1] = a1; off2[j + 1] = a2;
     }

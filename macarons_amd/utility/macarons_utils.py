@@ -473,12 +473,14 @@ def _field_select(proxy_scene, device, use_supervision_occ_mask=True, pending=No
 
 def _job_groups(cloud_sizes):
     """Consecutive groups of (cell, chunk) jobs with about the same amount of hidden draws (a job draws ~2.3 indices per surface point
-    of its cloud): one group below ~350k indices, at most three (every extra group repeats ~40 launches).  env MCR_FIELD_GROUPS=n forces n."""
+    of its cloud).  The batched draws (torch.ops.macarons.scone_occ_draws: prefix-only Fisher-Yates, the engine advanced over the rest)
+    cost ~0.4 ms per million indices, less than the ~40 launches an extra group repeats: ONE group below 3 M indices (the bench scene
+    draws 1 M: 7.8 / 8.4 / 9.0 ms for 1 / 2 / 3 groups), at most three.  env MCR_FIELD_GROUPS=n forces n."""
     import os
     J = len(cloud_sizes)
     work = np.cumsum(np.asarray(cloud_sizes, np.float64))
     forced = os.environ.get("MCR_FIELD_GROUPS")
-    G = int(forced) if forced else int(min(3, max(1, round(2.3 * work[-1] / 350e3))))
+    G = int(forced) if forced else int(min(3, max(1, round(2.3 * work[-1] / 3e6))))
     G = max(1, min(G, J))
     cuts = [0] + [int(np.searchsorted(work, work[-1] * g / G)) + 1 for g in range(1, G)] + [J]
     cuts = sorted(set(min(max(c, 0), J) for c in cuts))
