@@ -33,6 +33,13 @@ constexpr int LP_F32 = 0, LP_PLANES = 1, LP_DOT = 2;
 constexpr int LP_STAGE = 2 * 256 * 4 + 2 * 128 * 4;       // chunks per stage (Xh | Xl | Wh | Wl) = 3072 = 48 KB in either tile shape
 constexpr int LP_STAGES = 3;
 constexpr int LP_LDS_BYTES = LP_STAGES * LP_STAGE * 16;   // 147 456
+// SMALL form for short K (the encoders' K = 128 ... 512, eight to sixteen chunks): 4 waves = 128 features x 128 rows, TWO stages of
+// 32 KB = 64 KB, two blocks per CU -- with so few chunks a block that owns its CU cannot hide its DMA prologue and its GELU / split
+// epilogue behind anything; two resident blocks cover each other.  Same products in the same order per output element: the bits do
+// not depend on the form.
+constexpr int LPS_STAGE = 2 * 128 * 4 + 2 * 128 * 4;      // 2048 chunks = 32 KB
+constexpr int LPS_STAGES = 2;
+constexpr int LPS_LDS_BYTES = LPS_STAGES * LPS_STAGE * 16;   // 65 536
 
 typedef const __attribute__((address_space(1))) void* lp_gptr;
 typedef __attribute__((address_space(3))) void* lp_lptr;
@@ -48,8 +55,8 @@ __device__ __forceinline__ f32x16 mfma_u(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(512, 1) void linear3p_kernel(const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, long long ldx,
+template <int MODE, bool SMALL = false>
+__global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_kernel(const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, long long ldx,
                                                           const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, long long ldw,
                                                           const float* __restrict__ bias, const float* __restrict__ row_bias,
                                                           long long rows_per_group, const int* __restrict__ row_group,
@@ -57,14 +64,18 @@ __global__ __launch_bounds__(512, 1) void linear3p_kernel(const _Float16* __rest
                                                           long long ldy, long long M, int N, int K, int act, float wscale_inv,
                                                           const float* __restrict__ dot_v, const float* __restrict__ dot_c, int act2,
                                                           const float* __restrict__ R, long long ldr) {
-    constexpr int LP_TN = MODE == LP_DOT ? 256 : 128, LP_TM = MODE == LP_DOT ? 128 : 256;     // features / activation rows per block
+    static_assert(!(SMALL && MODE == LP_DOT), "the dot form keeps the large tile");
+    constexpr int NW = SMALL ? 4 : 8;                                                         // waves per block
+    constexpr int LP_TN = MODE == LP_DOT ? 256 : 128, LP_TM = (MODE == LP_DOT || SMALL) ? 128 : 256;   // features / activation rows per block
     constexpr int LP_XC = LP_TM * 4, LP_WC = LP_TN * 4;                                       // 16-byte chunks per X / W tile and plane
-    constexpr int GX = LP_TM / 128, GW = LP_TN / 128;                                         // DMA chunk groups (64 chunks) per wave and plane
+    constexpr int GX = LP_XC / (NW * 64), GW = LP_WC / (NW * 64);                             // DMA chunk groups (64 chunks) per wave and plane
+    constexpr int STAGE = 2 * LP_XC + 2 * LP_WC, STAGES = SMALL ? LPS_STAGES : LP_STAGES;     // chunks per stage; stages
+    constexpr int PER = 2 * (GX + GW);                                                        // DMA instructions per wave and chunk
     constexpr bool PLANES_OUT = MODE == LP_PLANES;
     extern __shared__ __attribute__((aligned(16))) uint4 S[];                     // [stage][Xh | Xl | Wh | Wl]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = MODE == LP_DOT ? wave : (wave & 3), wm = MODE == LP_DOT ? 0 : (wave >> 2);   // the wave's 32 features x 128 rows
+    const int wn = MODE == LP_DOT ? wave : (wave & 3), wm = (MODE == LP_DOT || SMALL) ? 0 : (wave >> 2);   // the wave's 32 features x 128 rows
     // XCD-aware block order: workgroup b runs on XCD b % 8 (its own L2).  The N / 128 column blocks of one 256-row block read the
     // SAME activation rows: they get consecutive slots of ONE XCD, so the rows come from HBM once and from that L2 afterwards
     // (with the plain (row block, column block) grid the 1344 -> 512 layer fetched its 537 MB of activations four times).
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(512, 1) void linear3p_kernel(const _Float16* __rest
         sw[g][0] = Wh + wr * ldw + c * 8; sw[g][1] = Wl + wr * ldw + c * 8;
     }
     auto stage = [&](int st, int k0) {                     // 6 DMA instructions per wave
-        uint4* b = S + st * LP_STAGE;
+        uint4* b = S + st * STAGE;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
@@ -126,15 +137,21 @@ __global__ __launch_bounds__(512, 1) void linear3p_kernel(const _Float16* __rest
         aw[s_] = lds0 + (unsigned)((2 * LP_XC + (wn * 32 + i) * 4 + cs) * 16);
     }
     const int n_chunks = K / LP_BK;
+    static_assert(PER == 6 || PER == 8, "the counted waits below are written for 6 or 8 DMA instructions per chunk");
     stage(0, 0);
-    if (n_chunks > 1) stage(1, LP_BK);
+    if (STAGES == 3 && n_chunks > 1) stage(1, LP_BK);
     for (int kc = 0; kc < n_chunks; ++kc) {
-        // chunk kc has landed (my share: the counted wait; everybody's: the barrier) and everybody is done reading chunk kc - 1
-        if (kc + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // chunk kc has landed (my share: the counted wait; everybody's: the barrier) and everybody is done reading chunk kc - 1.
+        // Three stages: the DMA runs two chunks ahead (chunk kc + 1 may stay in flight); two stages: one chunk ahead.
+        if (STAGES == 3 && kc + 1 < n_chunks) {
+            if (PER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        if (kc + 2 < n_chunks) stage((kc + 2) % LP_STAGES, (kc + 2) * LP_BK);
-        const unsigned sb = (unsigned)((kc % LP_STAGES) * LP_STAGE * 16);
+        if (kc + STAGES - 1 < n_chunks) stage((kc + STAGES - 1) % STAGES, (kc + STAGES - 1) * LP_BK);
+        const unsigned sb = (unsigned)((kc % STAGES) * STAGE * 16);
         u32x4 w_hi[2], w_lo[2], x_hi[2][4], x_lo[2][4];
 #pragma unroll
         for (int s_ = 0; s_ < 2; ++s_) {
@@ -267,13 +284,37 @@ static bool lp_reserve_lds() {                              // 144 KB of dynamic
 }
 
 // Y (fp32, ldy floats) or Yh / Yl (fp16 planes, ldy halves) = act(X W^T * wscale_inv + bias (+ row bias)); exactly one of Y, Yh is set
+static bool lps_reserve_lds() {
+    static const bool ok =
+        hipFuncSetAttribute((const void*)linear3p_kernel<LP_F32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LPS_LDS_BYTES) == hipSuccess &&
+        hipFuncSetAttribute((const void*)linear3p_kernel<LP_PLANES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LPS_LDS_BYTES) == hipSuccess;
+    return ok;
+}
+
 void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
                      const float* bias, float* Y, void* Yh, void* Yl, int64_t ldy, int64_t M, int N, int K, int act, float wscale_inv,
                      const float* row_bias, int64_t rows_per_group, const int* row_group, const float* R, int64_t ldr) {
     if (M <= 0 || N <= 0) return;
+    const long long rpg = rows_per_group > 0 ? rows_per_group : 1;
+    // short K: the two-blocks-per-CU form (same bits); MCR_L3P_SMALL=0: the large tile whatever K is (A/B), =2: the small one always
+    static const int small_mode = []() { const char* e = getenv("MCR_L3P_SMALL"); return e ? atoi(e) : 1; }();
+    if (small_mode == 2 || (small_mode == 1 && K <= 512)) {
+        if (!lps_reserve_lds()) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LPS_LDS_BYTES); return; }
+        dim3 g((unsigned)(cdiv(cdiv(M, 128), 8) * 8 * cdiv(N, 128)));
+        if (Yh)
+            hipLaunchKernelGGL((linear3p_kernel<LP_PLANES, true>), g, dim3(256), LPS_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl,
+                               (long long)ldx, (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group,
+                               (float*)nullptr, (_Float16*)Yh, (_Float16*)Yl, (long long)ldy, (long long)M, N, K, act, wscale_inv,
+                               (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0ll);
+        else
+            hipLaunchKernelGGL((linear3p_kernel<LP_F32, true>), g, dim3(256), LPS_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl,
+                               (long long)ldx, (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group, Y,
+                               (_Float16*)nullptr, (_Float16*)nullptr, (long long)ldy, (long long)M, N, K, act, wscale_inv,
+                               (const float*)nullptr, (const float*)nullptr, 0, R, (long long)ldr);
+        return;
+    }
     if (!lp_reserve_lds()) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LP_LDS_BYTES); return; }
     dim3 grid((unsigned)(cdiv(cdiv(M, 256), 8) * 8 * cdiv(N, 128)));             // 1-D: see the XCD-aware block order in the kernel
-    const long long rpg = rows_per_group > 0 ? rows_per_group : 1;
     if (Yh)
         hipLaunchKernelGGL((linear3p_kernel<LP_PLANES>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
                            (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group, (float*)nullptr,
