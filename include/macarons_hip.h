@@ -126,6 +126,11 @@ int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t
  *   SCONE_VIS (48): embedding.linear1.{w,b}, embedding.linear2.{w,b}, ENCODER x3, norm.{w,b}, fc1.{w,b}, fc2.{w,b}, fc3.{w,b}
  *   SCONE_OCC (140): PCT global_transformer, PCT local_transformers.{0,1,2}, x_embedding.linear{1,2,3}.{w,b},
  *                 linear1.{w,b}, linear2.{w,b}, linear3.{w,b}
+ *   PLANES (optional tail; n_weights = 32 + 8 / 48 + 12 / 140 + 8): per ENCODER of the long-sequence networks (PCT's two, SCONE_VIS's
+ *                 three, SCONE_OCC's global_transformer's two) four more pointers -- qkv.weight, out.weight, ff.linear1.weight,
+ *                 ff.linear2.weight as fp16 hi/lo planes [2][N][K] of W * 2^8 (hi = fp16(x), lo = fp16(x - hi);
+ *                 networks/packing.py: encoder_weight_planes) -- for the planes GEMMs of variant 6 (sequences of >= 512 tokens).
+ *                 Without the tail the weights are split by one small launch per GEMM and call.
  *
  * mcr_pc_transformer_forward: PCTransformer.forward (macarons/networks/SconeOcc.py:104-130); pc [S,L,3] ->
  *   features [S, feature_dim] (max || avg), feature_dim in {256, 512}.

@@ -26,7 +26,13 @@ struct EncW {                       // 12 pointers
     LinW out;
     const float *n2g, *n2b;         // norm2
     LinW ff1, ff2;
+    // optional (NULL: split per call): the four weight matrices as fp16 hi/lo planes [2][N][K] of W * 2^8, built by the host once per
+    // parameter version (networks/packing.py: encoder_weight_planes) -- pointers 4 per encoder appended to the weight table
+    const void *p_qkv = nullptr, *p_out = nullptr, *p_ff1 = nullptr, *p_ff2 = nullptr;
 };
+static void read_enc_planes(const float* const*& p, EncW& e) {
+    e.p_qkv = *p++; e.p_out = *p++; e.p_ff1 = *p++; e.p_ff2 = *p++;
+}
 static EncW read_enc(const float* const*& p) {
     EncW e;
     e.n1g = *p++; e.n1b = *p++;
@@ -129,12 +135,13 @@ static void run_encoder_planes(hipStream_t s, const EncW& w, float* x, float* h,
     const float inv = 1.0f / 256.0f;
     _Float16 *hh = reinterpret_cast<_Float16*>(h), *hl = hh + (size_t)T * E;                 // planes [2][T][E] over h
     _Float16 *fh = reinterpret_cast<_Float16*>(ff);                                          // planes over ff: [2][T][E] or [2][T][2E]
-    auto wsplit = [&](const float* W, int N, int K, void* dst) {
+    auto wsplit = [&](const float* W, int N, int K, void* dst, const void* given = nullptr) {
+        if (given) return (const _Float16*)given;            // host-built planes (one split per parameter version instead of per call)
         launch_split_weights(s, W, K, dst, N, K);
         return (const _Float16*)dst;
     };
     launch_layernorm_planes(s, x, E, w.n1g, w.n1b, hh, hl, E, T, E);                         // Attention.py:287
-    const _Float16* Wq = wsplit(w.qkv.w, W3, E, ff);
+    const _Float16* Wq = wsplit(w.qkv.w, W3, E, ff, w.p_qkv);
     launch_linear3p(s, hh, hl, E, Wq, Wq + (size_t)W3 * E, E, w.qkv.b, qkv, nullptr, nullptr, W3, T, W3, E, ACT_NONE, inv, nullptr, 0, nullptr);   // :186-188
     // attention: fp32 parts in h / ff (key-split scratch); its combine pass writes the result straight as planes into qkv (free by then)
     _Float16* ah = reinterpret_cast<_Float16*>(qkv);
@@ -143,14 +150,14 @@ static void run_encoder_planes(hipStream_t s, const EncW& w, float* x, float* h,
     launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, /*split_by_length=*/true, attn_pv_half(), nullptr, 0, 0, 0,
                      fuse ? ah : nullptr, ah + (size_t)T * E, E, &planes_done);              // :191-198
     if (!planes_done) launch_split_to_planes(s, h, E, ah, ah + (size_t)T * E, E, T, E);
-    const _Float16* Wo = wsplit(w.out.w, E, E, ff);
+    const _Float16* Wo = wsplit(w.out.w, E, E, ff, w.p_out);
     launch_linear3p(s, ah, ah + (size_t)T * E, E, Wo, Wo + (size_t)E * E, E, w.out.b, x, nullptr, nullptr, E, T, E, E, ACT_NONE, inv, nullptr, 0,
                     nullptr, x, E);                                                            // :201-202 + residual :290
     launch_layernorm_planes(s, x, E, w.n2g, w.n2b, hh, hl, E, T, E);                         // :293
-    const _Float16* W1 = wsplit(w.ff1.w, 2 * E, E, qkv);
+    const _Float16* W1 = wsplit(w.ff1.w, 2 * E, E, qkv, w.p_ff1);
     launch_linear3p(s, hh, hl, E, W1, W1 + (size_t)2 * E * E, E, w.ff1.b, nullptr, fh, fh + (size_t)T * 2 * E, 2 * E, T, 2 * E, E, ACT_GELU, inv,
                     nullptr, 0, nullptr);                                                      // :232 (planes out)
-    const _Float16* W2 = wsplit(w.ff2.w, E, 2 * E, qkv);
+    const _Float16* W2 = wsplit(w.ff2.w, E, 2 * E, qkv, w.p_ff2);
     launch_linear3p(s, fh, fh + (size_t)T * 2 * E, 2 * E, W2, W2 + (size_t)E * 2 * E, 2 * E, w.ff2.b, x, nullptr, nullptr, E, T, E, 2 * E, ACT_NONE,
                     inv, nullptr, 0, nullptr, x, E);                                           // :235 + residual :298
 }
@@ -429,7 +436,7 @@ int mcr_pc_transformer_forward(const float* pc, float* features, int64_t S, int6
                                void* stream) {
     VariantScope variant_scope_;
     MCR_REQUIRE(pc && features && weights, "mcr_pc_transformer_forward: null pointer");
-    MCR_REQUIRE(n_weights == PCT_NW, "mcr_pc_transformer_forward: expected %d weight pointers, got %d", PCT_NW, n_weights);
+    MCR_REQUIRE(n_weights == PCT_NW || n_weights == PCT_NW + 8, "mcr_pc_transformer_forward: expected %d weight pointers (+ 8 plane pointers), got %d", PCT_NW, n_weights);
     MCR_REQUIRE(S > 0 && L > 0, "mcr_pc_transformer_forward: empty problem");
     MCR_REQUIRE(feature_dim == 256 || feature_dim == 512, "mcr_pc_transformer_forward: feature_dim must be 256 or 512");
     MCR_REQUIRE(L == 16 || S <= 65535, "mcr_pc_transformer_forward: too many long sequences");
@@ -437,7 +444,8 @@ int mcr_pc_transformer_forward(const float* pc, float* features, int64_t S, int6
                 "mcr_pc_transformer_forward: workspace too small");
     for (int i = 0; i < n_weights; ++i) MCR_REQUIRE(weights[i], "mcr_pc_transformer_forward: weight %d is null", i);
     const float* const* p = weights;
-    const PctW w = read_pct(p);
+    PctW w = read_pct(p);
+    if (n_weights == PCT_NW + 8) { read_enc_planes(p, w.enc[0]); read_enc_planes(p, w.enc[1]); }
     Arena a{(char*)workspace, workspace_bytes, 0};
     run_pct((hipStream_t)stream, w, pc, features, feature_dim, S, (int)L, feature_dim / 2, a);
     MCR_LAUNCH_CHECK("mcr_pc_transformer_forward");
@@ -458,7 +466,7 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
                           size_t workspace_bytes, void* stream) {
     VariantScope variant_scope_;
     MCR_REQUIRE(pts && view_harmonics && out && weights, "mcr_scone_vis_forward: null pointer");
-    MCR_REQUIRE(n_weights == VIS_NW, "mcr_scone_vis_forward: expected %d weight pointers, got %d", VIS_NW, n_weights);
+    MCR_REQUIRE(n_weights == VIS_NW || n_weights == VIS_NW + 12, "mcr_scone_vis_forward: expected %d weight pointers (+ 12 plane pointers), got %d", VIS_NW, n_weights);
     MCR_REQUIRE(B > 0 && N > 0 && B <= 65535, "mcr_scone_vis_forward: bad problem size B=%ld N=%ld", (long)B, (long)N);
     MCR_REQUIRE(workspace && workspace_bytes >= mcr_scone_vis_workspace_bytes(B, N), "mcr_scone_vis_forward: workspace too small");
     for (int i = 0; i < n_weights; ++i) MCR_REQUIRE(weights[i], "mcr_scone_vis_forward: weight %d is null", i);
@@ -469,6 +477,9 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
     EncW enc[3] = {read_enc(p), read_enc(p), read_enc(p)};
     const float *ng = *p++, *nb = *p++;
     LinW fc1{p[0], p[1]}, fc2{p[2], p[3]}, fc3{p[4], p[5]};
+    p += 6;
+    if (n_weights == VIS_NW + 12)
+        for (int e = 0; e < 3; ++e) read_enc_planes(p, enc[e]);
 
     const int64_t T = B * N;
     Arena a{(char*)workspace, workspace_bytes, 0};
@@ -571,7 +582,7 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
     const bool early = phase != 2, late = phase != 1;
     MCR_REQUIRE(pc_scale && M_scale && x && weights && (!late || (pc_global && view_harmonics && out)), "mcr_scone_occ_forward: null pointer");
     MCR_REQUIRE(!head_planes || head_inv_scales, "mcr_scone_occ_forward: head_planes need head_inv_scales");
-    MCR_REQUIRE(n_weights == OCC_NW, "mcr_scone_occ_forward: expected %d weight pointers, got %d", OCC_NW, n_weights);
+    MCR_REQUIRE(n_weights == OCC_NW || n_weights == OCC_NW + 8, "mcr_scone_occ_forward: expected %d weight pointers (+ 8 plane pointers), got %d", OCC_NW, n_weights);
     MCR_REQUIRE(B > 0 && Q > 0 && Lg > 0 && B <= 65535, "mcr_scone_occ_forward: bad problem size");
     MCR_REQUIRE(workspace && workspace_bytes >= mcr_scone_occ_workspace_bytes(B, Q, Lg), "mcr_scone_occ_forward: workspace too small");
     for (int i = 0; i < n_weights; ++i) MCR_REQUIRE(weights[i], "mcr_scone_occ_forward: weight %d is null", i);
@@ -580,11 +591,13 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
                     (long)M_scale[i]);
     hipStream_t s = (hipStream_t)stream;
     const float* const* p = weights;
-    const PctW wg = read_pct(p);
+    PctW wg = read_pct(p);
     const PctW wl[3] = {read_pct(p), read_pct(p), read_pct(p)};
     LinW xe1{p[0], p[1]}, xe2{p[2], p[3]}, xe3{p[4], p[5]};
     p += 6;
     LinW lin1{p[0], p[1]}, lin2{p[2], p[3]}, lin3{p[4], p[5]};
+    p += 6;
+    if (n_weights == OCC_NW + 8) { read_enc_planes(p, wg.enc[0]); read_enc_planes(p, wg.enc[1]); }     // the global transformer's encoders
 
     Arena head{(char*)workspace, workspace_bytes, 0};
     // per-query feature row: [ local 3x256 | x-embedding 512 | view harmonics 64 ] = 1344   (cat at SconeOcc.py:333
@@ -856,7 +869,7 @@ int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global
     const bool early = phase != 2, late = phase != 1;
     MCR_REQUIRE(pc_scale && scale_off && x && view_harmonics && row_job && knn_blocks && weights && (!late || (pc_global && global_len && out)),
                 "mcr_scone_occ_forward_ragged: null pointer");
-    MCR_REQUIRE(n_weights == OCC_NW, "mcr_scone_occ_forward_ragged: expected %d weight pointers, got %d", OCC_NW, n_weights);
+    MCR_REQUIRE(n_weights == OCC_NW || n_weights == OCC_NW + 8, "mcr_scone_occ_forward_ragged: expected %d weight pointers (+ 8 plane pointers), got %d", OCC_NW, n_weights);
     MCR_REQUIRE(J > 0 && T > 0 && Lg > 0 && J <= 32767 && n_blocks > 0, "mcr_scone_occ_forward_ragged: bad problem size");
     MCR_REQUIRE(local_blobs && local_blobs[0] && local_blobs[1] && local_blobs[2],
                 "mcr_scone_occ_forward_ragged: needs the fused local-transformer blobs");
@@ -866,11 +879,13 @@ int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global
     for (int i = 0; i < (late ? 3 : 1); ++i) MCR_REQUIRE(pc_scale[i] && scale_off[i], "mcr_scone_occ_forward_ragged: scale %d is null", i);
     hipStream_t s = (hipStream_t)stream;
     const float* const* p = weights;
-    const PctW wg = read_pct(p);
+    PctW wg = read_pct(p);
     for (int i = 0; i < 3; ++i) (void)read_pct(p);
     LinW xe1{p[0], p[1]}, xe2{p[2], p[3]}, xe3{p[4], p[5]};
     p += 6;
     LinW lin1{p[0], p[1]}, lin2{p[2], p[3]}, lin3{p[4], p[5]};
+    p += 6;
+    if (n_weights == OCC_NW + 8) { read_enc_planes(p, wg.enc[0]); read_enc_planes(p, wg.enc[1]); }     // the global transformer's encoders
 
     Arena head{(char*)workspace, workspace_bytes, 0};
     constexpr int FEAT = 1344;

@@ -17,7 +17,7 @@ from .. import ops, _lib
 from .Attention import (Embedding, Encoder, FeedForward, MultiHeadSelfAttention, attention, knn_gather,   # noqa: F401
                         _f32c, _inference_only)     # the public ones are what upstream's `from .Attention import *` hands on
 from ..utility.utils import get_knn_points   # noqa: F401  (SconeOcc.py:4)
-from .packing import RangeGuard, BlobCache, HeadPlaneCache, TableCache, param_key, invalidate as _invalidate_key, freeze as _freeze_key
+from .packing import encoder_weight_planes, RangeGuard, BlobCache, HeadPlaneCache, TableCache, param_key, invalidate as _invalidate_key, freeze as _freeze_key
 
 
 class XEmbedding(nn.Module):
@@ -170,6 +170,13 @@ class SconeOcc(RangeGuard, nn.Module):
             t += [_f32c(lin.weight), _f32c(lin.bias)]
         return t
 
+    def weight_table_with_planes(self):
+        """weight_table() + the global transformer's encoder weights as fp16 hi/lo planes (8 blobs): see SconeVis.weight_table_with_planes."""
+        t = self.weight_table()
+        for e in self.global_transformer.encoders:
+            t += encoder_weight_planes(e)
+        return t
+
     def ds_factor(self, full_seq_len):
         """SconeOcc.py:281-288."""
         if self.n_scale > 1:
@@ -280,7 +287,7 @@ class SconeOcc(RangeGuard, nn.Module):
         def caches(v):
             key = param_key(self, self._key_cache)                  # one fingerprint of the parameters for every derived image
             state[v] = ([c.get(t, v, key) for c, t in zip(self._blob_caches, self.local_transformers)],
-                        self._head_cache.get(self, key) if v == 6 else None, self._table_cache.get(self, self.weight_table, key))
+                        self._head_cache.get(self, key) if v == 6 else None, self._table_cache.get(self, self.weight_table_with_planes, key))
             return state[v]
 
         def phase1(v):
@@ -384,7 +391,7 @@ class SconeOcc(RangeGuard, nn.Module):
         key = param_key(self, self._key_cache)                      # one fingerprint of the parameters for every derived image
         blobs = [c.get(t, variant, key) for c, t in zip(self._blob_caches, self.local_transformers)] if self.fused_local else None
         head = self._head_cache.get(self, key) if variant == 6 else None
-        return self._table_cache.get(self, self.weight_table, key), blobs, head
+        return self._table_cache.get(self, self.weight_table_with_planes, key), blobs, head
 
     def forward_begin(self, pc, x):
         """Extension: queue the part of forward(pc, x, ...) that needs neither the view harmonics nor the hidden draws (the query

@@ -21,7 +21,7 @@ from .. import ops
 from .Attention import Embedding, Encoder, FeedForward, MultiHeadSelfAttention, attention, knn_gather, _f32c   # noqa: F401
 from ..utility.CustomGeometry import get_spherical_coords                                                # noqa: F401
 from ..utility.spherical_harmonics import clear_spherical_harmonics_cache, get_spherical_harmonics       # noqa: F401
-from .packing import RangeGuard, TableCache, freeze as _freeze_key
+from .packing import RangeGuard, TableCache, encoder_weight_planes, freeze as _freeze_key
 
 
 class SconeVis(RangeGuard, nn.Module):
@@ -86,6 +86,14 @@ class SconeVis(RangeGuard, nn.Module):
             t += [_f32c(fc.weight), _f32c(fc.bias)]
         return t
 
+    def weight_table_with_planes(self):
+        """weight_table() + per encoder the four weight matrices as fp16 hi/lo planes (the planes GEMMs of variant 6 then skip their
+        per-call split launches: 12 of a forward's launches)."""
+        t = self.weight_table()
+        for e in self.encoders:
+            t += encoder_weight_planes(e)
+        return t
+
     def forward(self, pts, mask=None, view_harmonics=None, lengths=None):
         """pts [n_clouds, seq_len, 4], view_harmonics [n_clouds, seq_len, 64] -> [n_clouds, seq_len, 64].
         lengths (extension, optional int32 device tensor [n_clouds]): cloud b is its first lengths[b] rows; the rest of the
@@ -119,7 +127,7 @@ class SconeVis(RangeGuard, nn.Module):
         guarded = ops.current_variant() == 6 and seq_len >= 512 and self.range_guard != "off" and not torch.cuda.is_current_stream_capturing()
 
         def hip(p, vh):
-            res_ = ops.scone_vis_forward(p, vh, self._table_cache.get(self, self.weight_table), lengths)
+            res_ = ops.scone_vis_forward(p, vh, self._table_cache.get(self, self.weight_table_with_planes), lengths)
             if guarded:
                 if self._range_flag is None or self._range_flag.device != p.device:
                     self._range_flag = torch.zeros(1, dtype=torch.int32, device=p.device)
@@ -128,7 +136,7 @@ class SconeVis(RangeGuard, nn.Module):
                 ops.nonfinite_flag_(res_, self._range_flag)
                 if self.range_guard == "sync" and int(self._range_flag):
                     with ops.variant(5):
-                        res_ = ops.scone_vis_forward(p, vh, self._table_cache.get(self, self.weight_table), lengths)
+                        res_ = ops.scone_vis_forward(p, vh, self._table_cache.get(self, self.weight_table_with_planes), lengths)
                 elif self.range_guard == "async":
                     self._post_range_check(self._range_flag)
             return res_

@@ -155,6 +155,21 @@ class BlobCache:
         return self._blob
 
 
+def weight_planes(W):
+    """[2, N, K] fp16 = hi | lo planes of W * 2^8 (hi = fp16(x), lo = fp16(x - hi)): what split_weights_kernel (linear3h.hip) writes per
+    call, built once per parameter version for the encoders' planes GEMMs (run_encoder_planes, networks.hip)."""
+    with torch.no_grad():
+        x = W.detach().float() * 256.0
+        hi = x.half()
+        return torch.stack((hi, (x - hi.float()).half())).contiguous()
+
+
+def encoder_weight_planes(enc):
+    """The four plane blobs of one Encoder, in the order the C ABI reads them behind the weight table: packed QKV, out, FF 1, FF 2."""
+    w, _ = enc.mhsa.packed_qkv()
+    return [weight_planes(w), weight_planes(enc.mhsa.out.weight), weight_planes(enc.ff.linear1.weight), weight_planes(enc.ff.linear2.weight)]
+
+
 class TableCache:
     """The weight-pointer table of a module (list of contiguous fp32 tensors + the ctypes array handed to the C ABI), rebuilt
     only when a parameter changed."""
