@@ -127,14 +127,20 @@ def view_space_bin_indices(X_cam_inv, n_elev, n_azim):
     return idx_elev.long() * n_azim + idx_azim.long()
 
 
+_REF_DIRECTIONS = {}
+
+
 def view_space_bin_permutation(fov_camera, n_elev, n_azim, device="cpu"):
     """The bin permutation of move_view_state_to_view_space (scone_utils.py:863-931) as int64 indices on the host: column v of the
     rotated view state comes from bin indices[v].  `fov_camera`: see move_view_state_to_view_space; `device`: where a camera object's
     transform runs."""
-    n_view = n_elev * n_azim
-    elev = torch.Tensor([-90. + (i + 1) / (n_elev + 1) * 180. for i in range(n_elev) for j in range(n_azim)])
-    azim = torch.Tensor([360. * j / n_azim for i in range(n_elev) for j in range(n_azim)])
-    X_ref = get_cartesian_coords(r=torch.ones(n_view, 1), elev=elev.view(-1, 1), azim=azim.view(-1, 1), in_degrees=True)
+    X_ref = _REF_DIRECTIONS.get((n_elev, n_azim))
+    if X_ref is None:                                   # the lattice's unit directions: a constant of (n_elev, n_azim)
+        n_view = n_elev * n_azim
+        elev = torch.Tensor([-90. + (i + 1) / (n_elev + 1) * 180. for i in range(n_elev) for j in range(n_azim)])
+        azim = torch.Tensor([360. * j / n_azim for i in range(n_elev) for j in range(n_azim)])
+        X_ref = _REF_DIRECTIONS[(n_elev, n_azim)] = get_cartesian_coords(r=torch.ones(n_view, 1), elev=elev.view(-1, 1), azim=azim.view(-1, 1),
+                                                                           in_degrees=True)
     if torch.is_tensor(fov_camera):
         X_inv = X_ref @ fov_camera.detach().to("cpu", torch.float32).view(3, 3).T
     else:
