@@ -113,6 +113,14 @@ int mcr_attention_ws(const float* qkv, int64_t ldq, float* out, int64_t ldo, int
 int mcr_attention_masked(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim,
                          int v_dim, const unsigned char* mask, int64_t mask_seq_stride, int64_t mask_head_stride,
                          int64_t mask_query_stride, void* workspace, size_t workspace_bytes, void* stream);
+/* The long-sequence attention of the encoders on the fp16-split matrix path (variant 6, sequences of >= 512 tokens), as one call: the
+ * packed rows are split ONCE into fp16 hi/lo planes (inside the networks the QKV projection's epilogue writes them), K / V tiles then
+ * reach LDS by DMA and both products run on fp16 pairs (attention_planes.hip).  Needs |q|, |k|, |v| < 65504 (an inf / NaN output tells).
+ * lens (optional, device int per sequence): keys = the first min(L, lens[s]) rows.  split_mode: 1 = keys of every sequence over two
+ * blocks (L >= 512), 0 = never, -1 = only when the unsplit grid leaves CUs idle.  workspace: mcr_attention_planes_workspace_bytes. */
+size_t mcr_attention_planes_workspace_bytes(int64_t S, int64_t L, int n_heads, int qk_dim, int v_dim);
+int mcr_attention_planes(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim,
+                         int v_dim, const int* lens, int split_mode, void* workspace, size_t workspace_bytes, void* stream);
 int mcr_colmax_broadcast(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int64_t L, int E, void* stream);
 int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int64_t L, int E, void* stream);
 

@@ -142,14 +142,26 @@ static void run_encoder_planes(hipStream_t s, const EncW& w, float* x, float* h,
     };
     launch_layernorm_planes(s, x, E, w.n1g, w.n1b, hh, hl, E, T, E);                         // Attention.py:287
     const _Float16* Wq = wsplit(w.qkv.w, W3, E, ff, w.p_qkv);
-    launch_linear3p(s, hh, hl, E, Wq, Wq + (size_t)W3 * E, E, w.qkv.b, qkv, nullptr, nullptr, W3, T, W3, E, ACT_NONE, inv, nullptr, 0, nullptr);   // :186-188
-    // attention: fp32 parts in h / ff (key-split scratch); its combine pass writes the result straight as planes into qkv (free by then)
-    _Float16* ah = reinterpret_cast<_Float16*>(qkv);
-    bool planes_done = false;
-    static const bool fuse = []() { const char* e = getenv("MCR_ENC_COMBINE_PLANES"); return !(e && e[0] == '0'); }();   // (A/B)
-    launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, /*split_by_length=*/true, attn_pv_half(), nullptr, 0, 0, 0,
-                     fuse ? ah : nullptr, ah + (size_t)T * E, E, &planes_done);              // :191-198
-    if (!planes_done) launch_split_to_planes(s, h, E, ah, ah + (size_t)T * E, E, T, E);
+    _Float16* ah = reinterpret_cast<_Float16*>(qkv);                                         // the attention's result as planes [2][T][E]
+    static const bool att_planes = []() { const char* e = getenv("MCR_ENC_ATT_PLANES"); return !(e && e[0] == '0'); }();   // (A/B)
+    if (att_planes && attention_planes_applicable(H, dqk, E, W3)) {
+        // q | k | v leave the projection as planes [2][T][W3] over qkv (:186-188); the attention stages K / V tiles by DMA (:191-198).  Its
+        // keys are split over two blocks whatever S is (a cloud's result must not depend on how many clouds share the launch): fp32 parts
+        // in h / ff, the combine pass then writes the planes over qkv (dead by then)
+        _Float16 *qh_ = reinterpret_cast<_Float16*>(qkv), *ql_ = qh_ + (size_t)T * W3;
+        launch_linear3p(s, hh, hl, E, Wq, Wq + (size_t)W3 * E, E, w.qkv.b, nullptr, qh_, ql_, W3, T, W3, E, ACT_NONE, inv, nullptr, 0, nullptr);
+        static const int split_mode = []() { const char* e = getenv("MCR_ENC_ATT_SPLIT"); return e ? atoi(e) : 1; }();           // (A/B)
+        if (split_mode == 0) ah = hh;                                                          // unsplit: planes straight from the kernel, over h
+        launch_attention_planes(s, qh_, ql_, W3, h, E, ah, ah + (size_t)T * E, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, split_mode);
+    } else {
+        launch_linear3p(s, hh, hl, E, Wq, Wq + (size_t)W3 * E, E, w.qkv.b, qkv, nullptr, nullptr, W3, T, W3, E, ACT_NONE, inv, nullptr, 0, nullptr);   // :186-188
+        // attention: fp32 parts in h / ff (key-split scratch); its combine pass writes the result straight as planes into qkv (free by then)
+        bool planes_done = false;
+        static const bool fuse = []() { const char* e = getenv("MCR_ENC_COMBINE_PLANES"); return !(e && e[0] == '0'); }();   // (A/B)
+        launch_attention(s, qkv, W3, h, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, /*split_by_length=*/true, attn_pv_half(), nullptr, 0, 0, 0,
+                         fuse ? ah : nullptr, ah + (size_t)T * E, E, &planes_done);              // :191-198
+        if (!planes_done) launch_split_to_planes(s, h, E, ah, ah + (size_t)T * E, E, T, E);
+    }
     const _Float16* Wo = wsplit(w.out.w, E, E, ff, w.p_out);
     launch_linear3p(s, ah, ah + (size_t)T * E, E, Wo, Wo + (size_t)E * E, E, w.out.b, x, nullptr, nullptr, E, T, E, E, ACT_NONE, inv, nullptr, 0,
                     nullptr, x, E);                                                            // :201-202 + residual :290
@@ -365,6 +377,30 @@ int mcr_attention_ws(const float* qkv, int64_t ldq, float* out, int64_t ldo, int
     launch_attention((hipStream_t)stream, qkv, ldq, out, ldo, S, (int)L, n_heads, qk_dim, v_dim, nullptr, (float*)workspace,
                      workspace ? workspace_bytes / sizeof(float) : 0, false, attn_pv_half());
     MCR_LAUNCH_CHECK("mcr_attention_ws");
+    return 0;
+}
+
+size_t mcr_attention_planes_workspace_bytes(int64_t S, int64_t L, int n_heads, int qk_dim, int v_dim) {
+    return al((size_t)S * L * (2 * qk_dim + v_dim)) + attention_split_floats(S, (int)L, n_heads, v_dim) * sizeof(float);   // planes (the bytes of the fp32 rows) + key-split scratch
+}
+
+int mcr_attention_planes(const float* qkv, int64_t ldq, float* out, int64_t ldo, int64_t S, int64_t L, int n_heads, int qk_dim, int v_dim,
+                         const int* lens, int split_mode, void* workspace, size_t workspace_bytes, void* stream) {
+    MCR_REQUIRE(qkv && out && workspace, "mcr_attention_planes: null pointer");
+    MCR_REQUIRE(S > 0 && L > 0 && S <= 32767, "mcr_attention_planes: bad problem size");
+    MCR_REQUIRE(n_heads == 4 && ((qk_dim == 32 && v_dim == 128) || (qk_dim == 64 && v_dim == 256)),
+                "mcr_attention_planes: supported head layouts are 4 heads with (qk,v) = (32,128) or (64,256); got %d heads (%d,%d)",
+                n_heads, qk_dim, v_dim);
+    MCR_REQUIRE(workspace_bytes >= mcr_attention_planes_workspace_bytes(S, L, n_heads, qk_dim, v_dim), "mcr_attention_planes: workspace too small");
+    const int W3 = 2 * qk_dim + v_dim;
+    const int64_t T = S * L;
+    _Float16* ph = reinterpret_cast<_Float16*>(workspace);
+    _Float16* pl = ph + (size_t)T * W3;
+    float* split_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + al((size_t)T * W3));
+    launch_split_to_planes((hipStream_t)stream, qkv, ldq, ph, pl, W3, T, W3);
+    launch_attention_planes((hipStream_t)stream, ph, pl, W3, out, ldo, nullptr, nullptr, 0, S, (int)L, n_heads, qk_dim, v_dim, lens, split_ws,
+                            attention_split_floats(S, (int)L, n_heads, v_dim), split_mode);
+    MCR_LAUNCH_CHECK("mcr_attention_planes");
     return 0;
 }
 

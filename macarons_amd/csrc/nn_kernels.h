@@ -58,6 +58,17 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
 // planes_h / planes_l (optional): when the key-split form runs, its combine pass writes the result as fp16 hi/lo planes (row stride ldp
 // halves) INSTEAD of fp32 rows of `out`; *planes_done says whether that happened (else `out` holds fp32 rows as usual)
 size_t attention_split_floats(int64_t S, int L, int H, int DV);
+// the merge pass of the key-split form: out <- (w0 out + w1 part1) / (w0 l0 + w1 l1) per (row, head), as fp32 rows or as planes
+void launch_attention_combine(hipStream_t s, float* out, int64_t ldo, const float* part1, const float* ml, int64_t T, int H, int dv,
+                              void* planes_h, void* planes_l, int64_t ldp);
+// The same attention on a packed q | k | v operand that already is a pair of fp16 hi/lo planes (attention_planes.hip; row stride ldp
+// halves): K / V tiles by LDS DMA, nothing split inside.  Result: planes Oh / Ol (row stride ldoh halves) when given, else fp32 rows of
+// out (row stride ldo floats; out is also the scratch of the key-split form's first part).  split_mode: 1 = split the keys over two
+// blocks whenever L >= 512 and split_ws is there, 0 = never, -1 = only when the unsplit grid leaves CUs idle.
+bool attention_planes_applicable(int H, int DQK, int DV, int64_t ldp);
+void launch_attention_planes(hipStream_t s, const void* Ph, const void* Pl, int64_t ldp, float* out, int64_t ldo, void* Oh, void* Ol,
+                             int64_t ldoh, int64_t S, int L, int H, int DQK, int DV, const int* lens, float* split_ws, size_t split_ws_floats,
+                             int split_mode);
 
 // Column max over the L rows of each of S sequences, broadcast into a column slice of every row:
 //   Y[(s*L + r)*ldy + c] = max_r' X[(s*L + r')*ldx + c], c < E          (Embedding global feature, Attention.py:117-121)

@@ -571,10 +571,13 @@ __global__ __launch_bounds__(256, att_occ(DQ, QG)) void attention_mfma_kernel(co
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
     constexpr int TK = 64, LDK = DQ + 1, LDV = DV + 4, NT = DV / 16, KQ = DQ / 4, QB = 64 * QG;
-    __shared__ float s_k[TK * LDK];
+    __shared__ __attribute__((aligned(16))) float s_k[TK * LDK];
     __shared__ __attribute__((aligned(16))) float s_v[TK * LDV];
-    // PVH: the bytes of a V buffer hold the fp16 images of V instead: hi | lo, each [NT][64 keys][16 columns] (2 * NT * 2 KB <= the fp32 tile)
+    // PVH: the bytes of a V buffer hold the fp16 images of V instead: hi | lo, each [NT][64 keys][16 columns] (2 * NT * 2 KB <= the fp32 tile);
+    // the K buffer likewise: hi | lo, each [64 keys][DQ]
     static_assert(2 * NT * TK * 16 * 2 <= TK * LDV * 4, "fp16 V images do not fit the fp32 tile");
+    static_assert(2 * TK * DQ * 2 <= TK * LDK * 4, "fp16 K images do not fit the fp32 tile");
+    static_assert(DQ == 8 || DQ == 16, "score fragments are laid out for 8 or 16 query dimensions");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
     const int hh = blockIdx.y;
     const int seq = SPLIT ? blockIdx.z >> 1 : blockIdx.z, part = SPLIT ? blockIdx.z & 1 : 0;
@@ -584,15 +587,30 @@ __global__ __launch_bounds__(256, att_occ(DQ, QG)) void attention_mfma_kernel(co
     const int kb = SPLIT && part ? kmid : 0, Lk = SPLIT && !part ? kmid : Lk_all;                        // this block's keys [kb, Lk)
     const int q0 = blockIdx.x * QB + wave * 16 * QG;    // + 16 qg: the wave's query groups
     const int koff = H * DQ + hh * DQ, voff = 2 * H * DQ + hh * DV;
-    const float scale = 1.0f / sqrtf((float)DQ);
+    // scores are kept in units of log 2: softmax weights are exp2(s' - max s'), s' = s log2(e) -- one v_exp_f32 per weight, no multiply
+    const float scale = 1.4426950408889634f / sqrtf((float)DQ);
 
-    float qb[QG][KQ];                                   // B operand of S^T: Q[q0 + 16 qg + li][4s + g] * scale
+    float qb[QG][KQ];                                   // B operand of S^T on the fp32 pipe: Q[q0 + 16 qg + li][4s + g] * scale
+    f16x8 qh[QG];                                       // ... and on fp16 pairs (PVH), see "scores" below
+    bool q_half[QG];                                    // is the query group inside the fp16 range? (wave-uniform)
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
         const int qi = min(q0 + 16 * qg + li, L - 1);
         const float* qp = qkv + (seq0 + qi) * ldq + hh * DQ;
 #pragma unroll
         for (int sk = 0; sk < KQ; ++sk) qb[qg][sk] = qp[4 * sk + g] * scale;
+        q_half[qg] = false;
+        if (PVH) {
+            const int d0 = DQ == 16 ? 8 * (g & 1) : 0;  // this lane group's 8 query dimensions
+            float4 a = *reinterpret_cast<const float4*>(qp + d0), b = *reinterpret_cast<const float4*>(qp + d0 + 4);
+            a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale; b.x *= scale; b.y *= scale; b.z *= scale; b.w *= scale;
+            const float mx = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                                   fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+            q_half[qg] = !__any(!(mx < 32768.f));
+            const Split2 s2 = split8h(a, b);
+            const bool lo_part = DQ == 16 ? g >= 2 : (g & 1);
+            qh[qg] = __builtin_bit_cast(f16x8, lo_part ? s2.lo : s2.hi);
+        }
     }
     float m[QG], l[QG];                                 // running max (shared by the 4 lanes of a query), this lane's part of the sum
     f32x4 o[QG][NT];
@@ -603,53 +621,64 @@ __global__ __launch_bounds__(256, att_occ(DQ, QG)) void attention_mfma_kernel(co
         for (int nt = 0; nt < NT; ++nt) o[qg][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // staging: every thread moves PT float4 of the [64 keys x (DQ + DV)] tile; a tile's loads are all issued one MFMA phase
+    // staging: the [64 keys x DQ] K slice is one float4 of the first 64 DQ / 4 threads, the [64 keys x DV] V slice DV / 16 float4 of every
+    // thread (K or V is a property of the slot, not of the thread: no divergent commit); a tile's loads are all issued one MFMA phase
     // before they are committed to LDS (the per-element copy loop of the VALU kernel serialises ~20 load latencies per tile and
     // is what bounds it)
-    constexpr int F4K = (DQ + DV) / 4, NF4 = TK * F4K, PT = (NF4 + 255) / 256;
-    float4 stage[PT];
+    constexpr int KF4 = TK * DQ / 4, C4K = DQ / 4, C4V = DV / 4, PV_ = TK * C4V / 256;
+    static_assert(KF4 <= 256 && TK * C4V % 256 == 0, "staging slots");
+    const bool k_thread = (int)threadIdx.x < KF4;       // wave-uniform (KF4 = 128 or 256)
+    const int k_r = threadIdx.x / C4K, k_c4 = threadIdx.x - k_r * C4K;
+    float4 stage_k, stage_v[PV_];
     auto fetch = [&](int t0) {
+        stage_k = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k_thread && t0 + k_r < Lk) stage_k = *reinterpret_cast<const float4*>(qkv + (seq0 + t0 + k_r) * ldq + koff + 4 * k_c4);
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
-            const int idx = threadIdx.x + p * 256, r = idx / F4K, c4 = idx - r * F4K;
-            stage[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NF4 && t0 + r < Lk)
-                stage[p] = *reinterpret_cast<const float4*>(qkv + (seq0 + t0 + r) * ldq + (c4 < DQ / 4 ? koff + 4 * c4 : voff + 4 * (c4 - DQ / 4)));
+        for (int p = 0; p < PV_; ++p) {
+            const int idx = threadIdx.x + p * 256, r = idx / C4V, c4 = idx - r * C4V;
+            stage_v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t0 + r < Lk) stage_v[p] = *reinterpret_cast<const float4*>(qkv + (seq0 + t0 + r) * ldq + voff + 4 * c4);
         }
     };
-    auto out_of_half_range = [&]() -> int {            // does this thread's share of the V tile leave the fp16 range?
-        int big = 0;
+    auto out_of_half_range = [&]() -> int {            // does this thread's share of the K / V tile leave the fp16 range?
+        float mx = fmaxf(fmaxf(fabsf(stage_k.x), fabsf(stage_k.y)), fmaxf(fabsf(stage_k.z), fabsf(stage_k.w)));
+        int big = !(mx < 32768.f);                        // (NaN compares false: caught)
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
-            const int idx = threadIdx.x + p * 256, r = idx / F4K, c4 = idx - r * F4K;
-            if (idx < NF4 && c4 >= DQ / 4) {
-                const float mx = fmaxf(fmaxf(fabsf(stage[p].x), fabsf(stage[p].y)), fmaxf(fabsf(stage[p].z), fabsf(stage[p].w)));
-                big |= !(mx < 32768.f);                   // (NaN compares false: caught)
-            }
-            (void)r;
+        for (int p = 0; p < PV_; ++p) {
+            mx = fmaxf(fmaxf(fabsf(stage_v[p].x), fabsf(stage_v[p].y)), fmaxf(fabsf(stage_v[p].z), fabsf(stage_v[p].w)));
+            big |= !(mx < 32768.f);
         }
         return big;
     };
     _Float16* s_vh = reinterpret_cast<_Float16*>(s_v);
     _Float16* s_vl = s_vh + NT * TK * 16;
+    _Float16* s_kh = reinterpret_cast<_Float16*>(s_k);
+    _Float16* s_kl = s_kh + TK * DQ;
     auto commit = [&](const bool half_v) {
+        if (k_thread) {
+            if (half_v) {
+                uint2 hi, lo;
+                split2h(stage_k.x, stage_k.y, hi.x, lo.x);
+                split2h(stage_k.z, stage_k.w, hi.y, lo.y);
+                *reinterpret_cast<uint2*>(s_kh + k_r * DQ + 4 * k_c4) = hi;
+                *reinterpret_cast<uint2*>(s_kl + k_r * DQ + 4 * k_c4) = lo;
+            } else {
+                float* d = s_k + k_r * LDK + 4 * k_c4;         // odd row stride (bank-conflict-free fragment reads): scalar stores
+                d[0] = stage_k.x; d[1] = stage_k.y; d[2] = stage_k.z; d[3] = stage_k.w;
+            }
+        }
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
-            const int idx = threadIdx.x + p * 256, r = idx / F4K, c4 = idx - r * F4K;
-            if (idx < NF4) {
-                if (c4 < DQ / 4) {
-                    float* d = s_k + r * LDK + 4 * c4;          // odd row stride (bank-conflict-free fragment reads): scalar stores
-                    d[0] = stage[p].x; d[1] = stage[p].y; d[2] = stage[p].z; d[3] = stage[p].w;
-                } else if (half_v) {
-                    const int col = 4 * (c4 - DQ / 4), off = ((col >> 4) * TK + r) * 16 + (col & 15);    // [16-column block][key][16]
-                    uint2 hi, lo;
-                    split2h(stage[p].x, stage[p].y, hi.x, lo.x);
-                    split2h(stage[p].z, stage[p].w, hi.y, lo.y);
-                    *reinterpret_cast<uint2*>(s_vh + off) = hi;
-                    *reinterpret_cast<uint2*>(s_vl + off) = lo;
-                } else {
-                    *reinterpret_cast<float4*>(s_v + r * LDV + 4 * (c4 - DQ / 4)) = stage[p];
-                }
+        for (int p = 0; p < PV_; ++p) {
+            const int idx = threadIdx.x + p * 256, r = idx / C4V, c4 = idx - r * C4V;
+            if (half_v) {
+                const int col = 4 * c4, off = ((col >> 4) * TK + r) * 16 + (col & 15);    // [16-column block][key][16]
+                uint2 hi, lo;
+                split2h(stage_v[p].x, stage_v[p].y, hi.x, lo.x);
+                split2h(stage_v[p].z, stage_v[p].w, hi.y, lo.y);
+                *reinterpret_cast<uint2*>(s_vh + off) = hi;
+                *reinterpret_cast<uint2*>(s_vl + off) = lo;
+            } else {
+                *reinterpret_cast<float4*>(s_v + r * LDV + 4 * c4) = stage_v[p];
             }
         }
     };
@@ -662,32 +691,68 @@ __global__ __launch_bounds__(256, att_occ(DQ, QG)) void attention_mfma_kernel(co
         commit(half_v);
         __syncthreads();
         if (t0 + TK < Lk) fetch(t0 + TK);
-        // ---- scores of the 64 keys of the tile (all A fragments first: LLVM otherwise issues every ds_read right in
-        // front of its MFMA and each one waits out the LDS latency) ----
-        const float* kbase = s_k + li * LDK + g;             // K[sub*16 + li][4 sk + g]
         const float* vbase = s_v + (4 * g) * LDV + li;       // V[sub*16 + 4g + sk][nt*16 + li]
-        float ka[4][KQ];
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-            for (int sk = 0; sk < KQ; ++sk) ka[sub][sk] = kbase[sub * 16 * LDK + 4 * sk];
         float vb[2][4][NT];
-        if (!(PVH && half_v)) {
+        f32x4 st[QG][4];
+        // ---- scores of the 64 keys of the tile ----
+        if (PVH && half_v) {
+            // S^T = K Q^T on fp16 pairs, all four cross terms of (k_hi + k_lo)(q_hi + q_lo) through the k = 32 of v_mfma_f32_16x16x32_f16:
+            // DQ = 16: lane groups 0, 1 carry the dimensions 0..7, 8..15 of q_hi, groups 2, 3 those of q_lo (B); A is K_lo, then K_hi, with
+            // the same 16 dimensions in both halves of k -> two MFMAs per 16 keys x 16 queries (was four exact-fp32 ones of twice the cycles);
+            // DQ = 8: B = q_hi | q_lo | q_hi | q_lo, A = k_hi | k_hi | k_lo | k_lo by lane group -> one MFMA
+            f16x8 kf[4][DQ == 16 ? 2 : 1];
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                if (DQ == 16) {
+                    kf[sub][0] = *reinterpret_cast<const f16x8*>(s_kl + (sub * 16 + li) * DQ + 8 * (g & 1));
+                    kf[sub][DQ == 16 ? 1 : 0] = *reinterpret_cast<const f16x8*>(s_kh + (sub * 16 + li) * DQ + 8 * (g & 1));
+                } else {
+                    kf[sub][0] = *reinterpret_cast<const f16x8*>((g >= 2 ? s_kl : s_kh) + (sub * 16 + li) * DQ);
+                }
+            }
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) {
+                if (q_half[qg]) {
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+                        st[qg][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[sub][0], qh[qg], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        if (DQ == 16) st[qg][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[sub][DQ == 16 ? 1 : 0], qh[qg], st[qg][sub], 0, 0, 0);
+                    }
+                } else {                                  // a query outside the fp16 range: fp32 pipe on k_hi + k_lo (never in the networks' range)
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+                        st[qg][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int sk = 0; sk < KQ; ++sk) {
+                            const int at = (sub * 16 + li) * DQ + 4 * sk + g;
+                            st[qg][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)s_kh[at] + (float)s_kl[at], qb[qg][sk], st[qg][sub], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+            // fp32 pipe (all A fragments first: LLVM otherwise issues every ds_read right in front of its MFMA and each one waits out
+            // the LDS latency)
+            const float* kbase = s_k + li * LDK + g;             // K[sub*16 + li][4 sk + g]
+            float ka[4][KQ];
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int sk = 0; sk < KQ; ++sk) ka[sub][sk] = kbase[sub * 16 * LDK + 4 * sk];
 #pragma unroll
             for (int sk = 0; sk < 4; ++sk)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) vb[0][sk][nt] = vbase[sk * LDV + nt * 16];
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) {
+                    st[qg][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int sk = 0; sk < KQ; ++sk)
+                        st[qg][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[sub][sk], qb[qg][sk], st[qg][sub], 0, 0, 0);
+                }
         }
-        f32x4 st[QG][4];
-#pragma unroll
-        for (int qg = 0; qg < QG; ++qg)
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub) {
-                st[qg][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int sk = 0; sk < KQ; ++sk)
-                    st[qg][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[sub][sk], qb[qg][sk], st[qg][sub], 0, 0, 0);
-            }
         float ar[QG][4];
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
@@ -716,24 +781,27 @@ __global__ __launch_bounds__(256, att_occ(DQ, QG)) void attention_mfma_kernel(co
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m[qg], tmax);
-            const float alpha = __expf(m[qg] - m_new);   // m = -inf on the first tile -> 0 (o = l = 0 anyway)
+            const float alpha = __builtin_amdgcn_exp2f(m[qg] - m_new);   // m = -inf on the first tile -> 0 (o = l = 0 anyway)
             m[qg] = m_new;
             float psum = 0.f;
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    st[qg][sub][r] = __expf(st[qg][sub][r] - m_new);
+                    st[qg][sub][r] = __builtin_amdgcn_exp2f(st[qg][sub][r] - m_new);
                     psum += st[qg][sub][r];
                 }
             l[qg] = fmaf(l[qg], alpha, psum);
-            // ---- rescale O (rows = queries 4g + r live in lane group g) ----
+            // ---- rescale O (rows = queries 4g + r live in lane group g); after the first tiles the maxima rarely move: a wave whose 16
+            // queries all keep theirs skips the exchange and the multiplications by 1 (same bits) ----
+            if (__any(alpha != 1.f)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ar[qg][r] = __shfl(alpha, 4 * g + r, 64);   // alpha of query 4g + r (any lane group holds it)
+                for (int r = 0; r < 4; ++r) ar[qg][r] = __shfl(alpha, 4 * g + r, 64);   // alpha of query 4g + r (any lane group holds it)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[qg][nt][r] *= ar[qg][r];
+                    for (int r = 0; r < 4; ++r) o[qg][nt][r] *= ar[qg][r];
+            }
         }
         // ---- accumulate P V ----
         if (PVH && half_v) {
@@ -846,7 +914,7 @@ __global__ void attention_combine_kernel(float* __restrict__ out, long long ldo,
     const float* p1 = ml + ((T + t) * H + h) * 2;
     const float m0 = p0[0], l0 = p0[1], m1 = p1[0], l1 = p1[1];
     const float M = fmaxf(m0, m1);
-    const float w0 = __expf(m0 - M), w1 = l1 > 0.f ? __expf(m1 - M) : 0.f;
+    const float w0 = __builtin_amdgcn_exp2f(m0 - M), w1 = l1 > 0.f ? __builtin_amdgcn_exp2f(m1 - M) : 0.f;   // the maxima are in units of log 2
     const float y = (w0 * out[t * ldo + c] + w1 * part1[t * E + c]) / (w0 * l0 + w1 * l1);
     if (Ph) {
         const _Float16 hi = (_Float16)y;
@@ -855,6 +923,12 @@ __global__ void attention_combine_kernel(float* __restrict__ out, long long ldo,
     } else {
         out[t * ldo + c] = y;
     }
+}
+
+void launch_attention_combine(hipStream_t s, float* out, int64_t ldo, const float* part1, const float* ml, int64_t T, int H, int dv,
+                              void* planes_h, void* planes_l, int64_t ldp) {
+    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv(T * H * dv, 256)), dim3(256), 0, s, out, (long long)ldo, part1, ml,
+                       (long long)T, H, dv, (_Float16*)planes_h, (_Float16*)planes_l, (long long)ldp);
 }
 
 size_t attention_split_floats(int64_t S, int L, int H, int DV) { return (size_t)S * L * DV + (size_t)4 * S * L * H; }
@@ -919,9 +993,7 @@ void launch_attention(hipStream_t s, const float* qkv, int64_t ldq, float* out, 
             } else {
                 MCR_ATT(16, 64, true, g2, part1, ml);
             }
-            hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv(S * L * DV, 256)), dim3(256), 0, s, out, (long long)ldo,
-                               (const float*)part1, (const float*)ml, (long long)(S * L), H, dv, (_Float16*)planes_h, (_Float16*)planes_l,
-                               (long long)ldp);
+            launch_attention_combine(s, out, ldo, part1, ml, S * L, H, dv, planes_h, planes_l, ldp);
             if (planes_done) *planes_done = planes_h != nullptr;
         } else if (qg2) {
             if (dq == 8) MCR_ATT2(8, 32, false, grid2, (float*)nullptr, (float*)nullptr);

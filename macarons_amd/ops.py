@@ -290,6 +290,28 @@ def attention_packed(qkv, n_heads, qk_dim, v_dim, split=True, mask=None):
     return out
 
 
+def attention_packed_planes(qkv, n_heads, qk_dim, v_dim, lens=None, split_mode=-1):
+    """attention_packed on the planes pipeline of the long-sequence encoders (variant 6): the packed rows are split once into fp16 hi/lo
+    planes, the kernel stages K / V tiles by LDS DMA and multiplies on fp16 pairs (attention_planes.hip).  |q|, |k|, |v| < 65504.
+    lens (optional int32 [S], device): keys of sequence s = its first lens[s] rows.  split_mode: see mcr_attention_planes."""
+    qkv = _req(qkv, "qkv")
+    S, L, W = qkv.shape
+    if W != 2 * qk_dim + v_dim:
+        raise ValueError("packed qkv width mismatch")
+    out = torch.empty((S, L, v_dim), dtype=torch.float32, device=qkv.device)
+    if lens is not None:
+        lens = _req(lens, "lens", torch.int32)
+        if lens.numel() != S:
+            raise ValueError("lens must hold one length per sequence")
+    with torch.cuda.device(qkv.device):
+        nbytes = int(lib().mcr_attention_planes_workspace_bytes(c_i64(S), c_i64(L), c_int(n_heads), c_int(qk_dim), c_int(v_dim)))
+        ws = _workspace(qkv.device, nbytes)
+        check(lib().mcr_attention_planes(_p(qkv), c_i64(W), _p(out), c_i64(v_dim), c_i64(S), c_i64(L), c_int(n_heads), c_int(qk_dim),
+                                         c_int(v_dim), _p(lens) if lens is not None else c_vp(0), c_int(split_mode), _p(ws),
+                                         ctypes.c_size_t(ws.numel()), _stream()), "mcr_attention_planes")
+    return out
+
+
 def colmax_broadcast(x):
     """x [S, L, E] -> [S, L, E] where every row holds the column-wise max over the L rows (Attention.py:117-121)."""
     x = _req(x, "x")

@@ -105,6 +105,48 @@ def test_long_sequence_attention_outside_the_half_range(dev):
     assert (np.abs(y - ref) / np.maximum(col, 1.0)).max() < 2e-5
 
 
+@pytest.mark.parametrize("S,L,H,qk,v", [(1, 2048, 4, 64, 256), (2, 1777, 4, 64, 256), (3, 700, 4, 32, 128), (12, 1100, 4, 32, 128), (9, 1500, 4, 64, 256)])
+def test_attention_on_planes_vs_numpy(dev, S, L, H, qk, v):
+    """The attention of the long-sequence encoders on the fp16-split path takes q | k | v as fp16 hi/lo planes (K / V tiles by LDS DMA, both
+    products on fp16 pairs; attention_planes.hip): against fp64 softmax(QK^T/sqrt(d))V with and without the key split, with per-sequence
+    key counts (padded batches; incl. a sequence shorter than one tile), and batch == single sequence bit for bit (128- vs 64-query blocks)."""
+    from macarons_amd import ops
+    rng = np.random.default_rng(S * 77 + L)
+    qkv = rng.standard_normal((S, L, 2 * qk + v)).astype(np.float32)
+    lens = rng.integers(L // 3, L + 1, size=S).astype(np.int32)
+    lens[0] = L
+    if S > 2:
+        lens[1] = 37
+    x = qkv.astype(np.float64)
+
+    def ref(n_keys):
+        out = np.zeros((S, L, v))
+        for s_ in range(S):
+            q = x[s_, :, :qk].reshape(L, H, qk // H).transpose(1, 0, 2)
+            k = x[s_, :n_keys[s_], qk:2 * qk].reshape(-1, H, qk // H).transpose(1, 0, 2)
+            vv = x[s_, :n_keys[s_], 2 * qk:].reshape(-1, H, v // H).transpose(1, 0, 2)
+            sc = q @ k.transpose(0, 2, 1) / np.sqrt(qk // H)
+            sc = np.exp(sc - sc.max(-1, keepdims=True))
+            out[s_] = ((sc / sc.sum(-1, keepdims=True)) @ vv).transpose(1, 0, 2).reshape(L, v)
+        return out
+
+    xt = T(qkv, dev)
+    full = ref([L] * S)
+    outs = {}
+    for mode in (1, 0, -1):
+        y = ops.attention_packed_planes(xt, H, qk, v, split_mode=mode)
+        outs[mode] = y
+        assert np.abs(y.cpu().numpy() - full).max() < 2e-5 * max(1.0, np.abs(full).max()), mode
+    ragged = ref(lens)
+    for mode in (1, 0):
+        y = ops.attention_packed_planes(xt, H, qk, v, lens=T(lens, dev), split_mode=mode).cpu().numpy()
+        assert np.abs(y - ragged).max() < 2e-5 * max(1.0, np.abs(ragged).max()), mode
+    for b in (0, S - 1):                                               # one sequence alone: 64-query blocks
+        for mode in (1, 0):
+            one = ops.attention_packed_planes(xt[b:b + 1].contiguous(), H, qk, v, split_mode=mode)
+            assert torch.equal(one[0], outs[mode][b]), (mode, b)
+
+
 @pytest.mark.parametrize("S,L,H,qk,v", [(12, 1777, 4, 64, 256), (18, 1500, 4, 32, 128)])
 def test_batched_attention_returns_the_single_sequence_bits(dev, S, L, H, qk, v):
     """A batch that fills the chip runs the long-sequence attention in 128-query blocks (two 16-query groups per wave share every
