@@ -271,6 +271,104 @@ __global__ void split_to_planes_kernel(const float* __restrict__ X, long long ld
     *reinterpret_cast<uint2*>(Pl + m * ldp + c) = lo;
 }
 
+// ---- ONE-SHOT form for a few thousand rows (one cloud of 2048 tokens through an encoder: 48 ... 256 blocks of the pipelined forms, each
+// waiting out eight to sixteen chunk round trips of ~1 us behind a barrier -- 17-20 us per layer for 1.6 GFLOP).  Block = 4 waves = 64
+// features x 64 rows (wave: 32 x 32, one accumulator); the block's whole K slice (up to 256 per shot: X and W, both planes, 128 KB)
+// is queued by DMA at once, ONE wait, ONE barrier, then 16 k16-steps of three MFMAs.  Same products in the same order per output
+// element as the pipelined forms (k ascending; per k16-step w_lo x_hi, w_hi x_lo, w_hi x_hi): the bits do not depend on the form, so a
+// cloud alone and the same cloud inside a batch (pipelined form) agree.  LDS image: [row][K] per plane, the 16-byte chunks of a row
+// XOR-swizzled by the row (conflict-free ds_read_b128 of one chunk column over 32 rows), applied on the DMA's source address.
+constexpr int LPO_T = 64, LPO_KS = 256;                                   // tile edge; k per shot
+constexpr int LPO_LDS_BYTES = 4 * LPO_T * LPO_KS * 2;                     // Xh | Xl | Wh | Wl = 131 072
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void linear3p_once_kernel(const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, long long ldx,
+                                                               const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, long long ldw,
+                                                               const float* __restrict__ bias, float* __restrict__ Y, _Float16* __restrict__ Yh,
+                                                               _Float16* __restrict__ Yl, long long ldy, long long M, int N, int K, int act,
+                                                               float wscale_inv, const float* __restrict__ R, long long ldr) {
+    static_assert(MODE == LP_F32 || MODE == LP_PLANES, "one-shot form: fp32 rows or planes out");
+    extern __shared__ __attribute__((aligned(16))) uint4 S[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int ncb = (N + LPO_T - 1) / LPO_T;
+    const long long m0 = (long long)(blockIdx.x / ncb) * LPO_T;          // column blocks of one row block are neighbours (the rows stay in L2)
+    const int n0 = (blockIdx.x % ncb) * LPO_T;
+    const int i = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += LPO_KS) {
+        const int ks = min(LPO_KS, K - k0);                                // 128 or 256 (the launcher's precondition)
+        const int csh = ks == 256 ? 5 : 4, cpr = 1 << csh;                 // chunks (16 bytes) per row: 32 at a full shot
+        const int plane = LPO_T << csh;                                     // chunks per plane
+        if (k0) __syncthreads();                                            // (the previous shot's fragments are consumed)
+        // DMA: 64 chunks per wave instruction; position p of a plane = (row = p / cpr, c' = p % cpr) receives the row's chunk c' ^ (row & (cpr - 1))
+        for (int q = wave; q < 4 * cpr; q += 4) {                          // (a plane is cpr instructions)
+            const int pl = q >> csh, p = (q & (cpr - 1)) * 64 + lane;
+            const int row = p >> csh, c = (p & (cpr - 1)) ^ (row & (cpr - 1));
+            const _Float16* src;
+            if (pl < 2) src = (pl ? Xl : Xh) + min(m0 + row, M - 1) * ldx + k0 + c * 8;       // rows beyond the matrix repeat its last row
+            else src = (pl == 3 ? Wl : Wh) + (long long)min(n0 + row, N - 1) * ldw + k0 + c * 8;
+            __builtin_amdgcn_global_load_lds((lp_gptr)src, (lp_lptr)(S + pl * plane + (q & (cpr - 1)) * 64), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const uint4* sx_h = S + ((wm * 32 + i) << csh);                      // this lane's X row / W row inside the planes
+        const uint4* sw_h = S + 2 * plane + ((wn * 32 + i) << csh);
+        const int key = i & (cpr - 1);                                       // (wm * 32 + i) & (cpr - 1): cpr <= 32
+        for (int st4 = 0; st4 < ks / 64; ++st4) {                           // four k16-steps per trip: their twelve fragment reads go out together
+            uint4 xh[4], xl[4], wh[4], wl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = (2 * (4 * st4 + u) + h) ^ key;
+                xh[u] = sx_h[c]; xl[u] = sx_h[plane + c]; wh[u] = sw_h[c]; wl[u] = sw_h[plane + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = mfma_h(wl[u], xh[u], acc);                            // smallest terms first (the order of the pipelined forms)
+                acc = mfma_h(wh[u], xl[u], acc);
+                acc = mfma_h(wh[u], xh[u], acc);
+            }
+        }
+    }
+    // ---- epilogue: lane (j, h) holds features n = n0 + 32 wn + 8 g + 4 h + e (register 4 g + e) of row m0 + 32 wm + j
+    const long long m = m0 + wm * 32 + i;
+    if (m >= M) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 32 + 8 * g + 4 * h;
+        if (n >= N) continue;                              // N % 4 == 0: a quad is in or out as a whole
+        const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float y[4] = {fmaf(acc[4 * g], wscale_inv, b4.x), fmaf(acc[4 * g + 1], wscale_inv, b4.y), fmaf(acc[4 * g + 2], wscale_inv, b4.z),
+                      fmaf(acc[4 * g + 3], wscale_inv, b4.w)};
+        if (act == ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = 0.5f * y[e] * (1.f + erff(y[e] * 0.70710678118654752440f));
+        }
+        if (MODE == LP_PLANES) {
+            uint2 hi, lo;
+            split2h(y[0], y[1], hi.x, lo.x);
+            split2h(y[2], y[3], hi.y, lo.y);
+            *reinterpret_cast<uint2*>(Yh + m * ldy + n) = hi;
+            *reinterpret_cast<uint2*>(Yl + m * ldy + n) = lo;
+        } else {
+            if (R) {                                       // residual; R may be Y: read before the store
+                const float4 r4 = *reinterpret_cast<const float4*>(R + m * ldr + n);
+                y[0] += r4.x; y[1] += r4.y; y[2] += r4.z; y[3] += r4.w;
+            }
+            *reinterpret_cast<float4*>(Y + m * ldy + n) = make_float4(y[0], y[1], y[2], y[3]);
+        }
+    }
+}
+
+static bool lpo_reserve_lds() {
+    static const bool ok =
+        hipFuncSetAttribute((const void*)linear3p_once_kernel<LP_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, LPO_LDS_BYTES) == hipSuccess &&
+        hipFuncSetAttribute((const void*)linear3p_once_kernel<LP_PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, LPO_LDS_BYTES) == hipSuccess;
+    return ok;
+}
+
 bool linear3p_applicable(int N, int K, int64_t ldx, int64_t ldw, int64_t ldy) {
     return K % LP_BK == 0 && K >= LP_BK && N % 4 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 4 == 0;
 }
@@ -298,6 +396,21 @@ void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx,
     const long long rpg = rows_per_group > 0 ? rows_per_group : 1;
     // short K: the two-blocks-per-CU form (same bits); MCR_L3P_SMALL=0: the large tile whatever K is (A/B), =2: the small one always
     static const int small_mode = []() { const char* e = getenv("MCR_L3P_SMALL"); return e ? atoi(e) : 1; }();
+    // a few thousand rows: the one-shot form (same bits); MCR_L3P_ONCE=0: off (A/B)
+    static const bool once_on = []() { const char* e = getenv("MCR_L3P_ONCE"); return !(e && e[0] == '0'); }();
+    if (once_on && M <= 4096 && !row_bias && (K == 128 || K % LPO_KS == 0)) {
+        if (!lpo_reserve_lds()) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LPO_LDS_BYTES); return; }
+        dim3 g((unsigned)(cdiv(M, LPO_T) * cdiv(N, LPO_T)));
+        if (Yh)
+            hipLaunchKernelGGL((linear3p_once_kernel<LP_PLANES>), g, dim3(256), LPO_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl,
+                               (long long)ldx, (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, (float*)nullptr, (_Float16*)Yh,
+                               (_Float16*)Yl, (long long)ldy, (long long)M, N, K, act, wscale_inv, (const float*)nullptr, 0ll);
+        else
+            hipLaunchKernelGGL((linear3p_once_kernel<LP_F32>), g, dim3(256), LPO_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl,
+                               (long long)ldx, (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, Y, (_Float16*)nullptr,
+                               (_Float16*)nullptr, (long long)ldy, (long long)M, N, K, act, wscale_inv, R, (long long)ldr);
+        return;
+    }
     if (small_mode == 2 || (small_mode == 1 && K <= 512)) {
         if (!lps_reserve_lds()) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LPS_LDS_BYTES); return; }
         dim3 g((unsigned)(cdiv(cdiv(M, 128), 8) * 8 * cdiv(N, 128)));
