@@ -24,6 +24,10 @@
 
 namespace mcr {
 
+// GELU in the epilogues: l3_gelu (lp_split.h) -- the exact-erf GELU with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, one rcp,
+// one exp2, seven fma: 14 instructions), the function the fused local transformer of this numerics variant already applies.  libm's
+// branchy erff was ~45 vector instructions per value with both branches executed: 43 of the 100 us of an encoder's FF1 at 30 x 2048
+// tokens were its epilogue.
 constexpr int LP_BK = 32;                                 // k per chunk
 // output modes: fp32 rows, fp16 hi/lo planes (128 features x 256 rows per block), or LP_DOT: 256 features x 128 rows per block --
 // the block then owns ALL 256 outputs of its rows and the epilogue reduces them against a vector: out[m] = act2(act(y[m][:]) . v +
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_ker
                               fmaf(acc[t][4 * g + 2], wscale_inv, b4.z), fmaf(acc[t][4 * g + 3], wscale_inv, b4.w)};
                 if (act == ACT_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = 0.5f * y[e] * (1.f + erff(y[e] * 0.70710678118654752440f));
+                    for (int e = 0; e < 4; ++e) y[e] = l3_gelu(y[e]);
                 }
                 sacc = fmaf(y[0], v4.x, sacc); sacc = fmaf(y[1], v4.y, sacc); sacc = fmaf(y[2], v4.z, sacc); sacc = fmaf(y[3], v4.w, sacc);
             }
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_ker
                           fmaf(acc[t][4 * g + 2], wscale_inv, b4.z), fmaf(acc[t][4 * g + 3], wscale_inv, b4.w)};
             if (act == ACT_GELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = 0.5f * y[e] * (1.f + erff(y[e] * 0.70710678118654752440f));
+                for (int e = 0; e < 4; ++e) y[e] = l3_gelu(y[e]);
             }
             if (PLANES_OUT) {
                 uint2 hi, lo;
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void linear3p_once_kernel(const _Float16* _
                       fmaf(acc[4 * g + 3], wscale_inv, b4.w)};
         if (act == ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = 0.5f * y[e] * (1.f + erff(y[e] * 0.70710678118654752440f));
+            for (int e = 0; e < 4; ++e) y[e] = l3_gelu(y[e]);
         }
         if (MODE == LP_PLANES) {
             uint2 hi, lo;

@@ -19,5 +19,5 @@ cp $O/power_trace.txt $R/profiles/${P}_power_local_pct6.txt
 for k in host device; do
   [ -f $R/gpurun_out/${P}_macarons_decision_trace_$k.txt ] && cp $R/gpurun_out/${P}_macarons_decision_trace_$k.txt $R/profiles/
 done
-[ -f $R/gpurun_out/${P}_attention_planes_pmc.txt ] && cp $R/gpurun_out/${P}_attention_planes_pmc.txt $R/profiles/
+[ -f $O/attention_planes_pmc.txt ] && cp $O/attention_planes_pmc.txt $R/profiles/${P}_attention_planes_pmc.txt
 ls -la $R/profiles | grep ${P}_ | wc -l

@@ -40,5 +40,6 @@ rm -rf $R/gpurun_out/pmc_generic; KERNEL=linear3p_kernel $R/tools/pmc_generic.sh
 rm -rf $R/gpurun_out/pmc_generic; MS=10240 KERNEL="knn_grid_kernel<16, true, 0>" $R/tools/pmc_generic.sh python $R/tools/time_knn.py > $OUT/knn_pmc.txt 2>&1
 rm -rf $R/gpurun_out/pmc_generic; MCR_KNN_GRID=0 MS=10240 KERNEL=knn_mfma_kernel $R/tools/pmc_generic.sh python $R/tools/time_knn.py > $OUT/knn_bruteforce_pmc.txt 2>&1
 (for c in shell cube; do for g in 1 0; do CLOUD=$c MCR_KNN_GRID=$g python $R/tools/time_knn.py; done; done) > $OUT/knn_times.txt 2>&1
+rm -rf $R/gpurun_out/pmc_generic; REPS=3 KERNEL=attention_planes_kernel $R/tools/pmc_generic.sh python $R/tools/time_attention_planes.py > $OUT/attention_planes_pmc.txt 2>&1
 cd $R && python tools/power_trace.py > $OUT/power_trace.txt 2>&1
 grep -c . $OUT/local_pct6_pmc.txt $OUT/linear3p_pmc.txt $OUT/knn_pmc.txt $OUT/power_trace.txt
