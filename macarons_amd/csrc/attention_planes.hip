@@ -41,18 +41,6 @@ __device__ __forceinline__ ap_u32x2 ap_read_tr(unsigned addr) {       // 4 keys 
     return v;
 }
 
-// (a, b) -> packed fp16 (hi, lo) with hi = fp16(x), lo = fp16(x - hi): split2h of lp_split.h in three instructions instead of five --
-// v_cvt_pk_f16_f32, then x - hi as a mixed-precision fma (fp16 source, fp32 addend) whose result is rounded to fp16 straight into the
-// low / high half of the destination.  The same values: x - hi is exact in fp32 either way.  (Vector issue bounds the kernel.)
-__device__ __forceinline__ void ap_split2(const float a, const float b, unsigned& hi, unsigned& lo) {
-    const f32x2 x = {a, b};
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
-    unsigned l;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(b));
-    lo = l;
-}
-
 #ifndef MCR_AP_OCC_16
 #define MCR_AP_OCC_16 3
 #endif
@@ -273,10 +261,10 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg) {
                 uint4 ph, pl;
-                ap_split2(st[qg][2 * q][0], st[qg][2 * q][1], ph.x, pl.x);
-                ap_split2(st[qg][2 * q][2], st[qg][2 * q][3], ph.y, pl.y);
-                ap_split2(st[qg][2 * q + 1][0], st[qg][2 * q + 1][1], ph.z, pl.z);
-                ap_split2(st[qg][2 * q + 1][2], st[qg][2 * q + 1][3], ph.w, pl.w);
+                split2h(st[qg][2 * q][0], st[qg][2 * q][1], ph.x, pl.x);
+                split2h(st[qg][2 * q][2], st[qg][2 * q][3], ph.y, pl.y);
+                split2h(st[qg][2 * q + 1][0], st[qg][2 * q + 1][1], ph.z, pl.z);
+                split2h(st[qg][2 * q + 1][2], st[qg][2 * q + 1][3], ph.w, pl.w);
                 p_hi[q][qg] = __builtin_bit_cast(f16x8, ph); p_lo[q][qg] = __builtin_bit_cast(f16x8, pl);
             }
         // first 32 keys, one 16-column block after the other: per accumulator p_lo v_hi, then p_hi v_lo, then p_hi v_hi (smallest terms

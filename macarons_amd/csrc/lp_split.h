@@ -87,13 +87,23 @@ __device__ __forceinline__ f32x16 mfma_bf(uint4 a, uint4 b, f32x16 c) {
 // x - hi is exact in fp32, |lo| <= 2^-11 |x|, so |e| <= max(2^-22 |x|, 2^-25) (the second bound when lo is an fp16
 // subnormal).  Needs |x| < 65504 (fp16 range).  v_cvt_pk_f16_f32 converts two values per instruction.
 struct Split2 { uint4 hi, lo; };
+// Three instructions: v_cvt_pk_f16_f32, then x - hi as a mixed-precision fma (fp16 source, fp32 addend: exact) whose result is rounded
+// to fp16 straight into the low / high half of the destination (v_fma_mixlo_f16 / v_fma_mixhi_f16) -- the same values as converting hi
+// back, subtracting and converting again (five instructions; MCR_SPLIT2H_PLAIN selects that form for the A/B).
 __device__ __forceinline__ void split2h(const float a, const float b, unsigned& hi, unsigned& lo) {
     const f32x2 x = {a, b};
     const f16x2 h = __builtin_convertvector(x, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+#ifdef MCR_SPLIT2H_PLAIN
     const f32x2 r = x - __builtin_convertvector(h, f32x2);
     const f16x2 l = __builtin_convertvector(r, f16x2);
-    hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
+#else
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(b));
+    lo = l;
+#endif
 }
 __device__ __forceinline__ Split2 split8h(const float4 p, const float4 q) {
     Split2 s;
