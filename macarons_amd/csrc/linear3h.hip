@@ -128,6 +128,26 @@ bool linear3h_applicable(const float* X, int64_t ldx, const float* W, int64_t ld
     return K % 8 == 0 && K >= 64 && ldx % 4 == 0 && ldw % 4 == 0 && al(X) && al(W) && N >= 128 &&
            cdiv(M, LH_BM) * cdiv(N, LH_BN) >= 256;
 }
+// W [N, K] (+ bias [N]) -> zero-padded planes Wp[plane][Np][Kp/8] of W * 2^8 and bias_p [Np]: a layer whose width is not a multiple
+// of the planes GEMM's granules (the embeddings' 125 / 126 inner width; Np % 4 == 0, Kp % 32 == 0) joins it with exact zeros
+__global__ void pad_weights_kernel(const float* __restrict__ W, long long ldw, const float* __restrict__ bias, uint4* __restrict__ Wp,
+                                   float* __restrict__ bias_p, int N, int K, int Np, int Kp8) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)Np * Kp8) return;
+    const int n = (int)(gid / Kp8), c = (int)(gid % Kp8);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (n < N && c * 8 + e < K) ? W[(long long)n * ldw + c * 8 + e] * LH_WSCALE : 0.f;
+    const Split2 sp = split8h(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+    Wp[gid] = sp.hi;
+    Wp[(long long)Np * Kp8 + gid] = sp.lo;
+    if (c == 0) bias_p[n] = (bias && n < N) ? bias[n] : 0.f;
+}
+void launch_pad_weights(hipStream_t s, const float* W, int64_t ldw, const float* bias, void* planes, float* bias_p, int N, int K, int Np, int Kp) {
+    hipLaunchKernelGGL(pad_weights_kernel, dim3((unsigned)cdiv((int64_t)Np * (Kp / 8), 256)), dim3(256), 0, s, W, (long long)ldw, bias,
+                       reinterpret_cast<uint4*>(planes), bias_p, N, K, Np, Kp / 8);
+}
+
 size_t linear3h_planes_bytes(int N, int K) { return ((size_t)2 * N * (K / 8) * sizeof(uint4) + 255) & ~(size_t)255; }
 
 void launch_split_weights(hipStream_t s, const float* W, int64_t ldw, void* planes, int N, int K) {

@@ -125,6 +125,13 @@ static inline bool enc_planes(int L, int E) {
     return on && g_local_pct_variant == 6 && L >= 512 && E % 32 == 0;
 }
 
+// The layers either side of the encoders (the embeddings' second layer, the final LayerNorm and the fc / lin0 layers behind it) on the
+// same planes path; MCR_ENDS_PLANES=0: the fp32 / bf16 x 6 kernels as before (A/B)
+static inline bool ends_planes(int L, int E) {
+    static const bool on = []() { const char* e = getenv("MCR_ENDS_PLANES"); return !(e && e[0] == '0'); }();
+    return on && enc_planes(L, E);
+}
+
 // The planes live in the encoder's own scratch (an fp32 row = two fp16 rows): h <- planes of LayerNorm(x) / fp32 attention output,
 // ff <- planes of the attention output, then of the FF's hidden layer; the weights' planes (split per call, 2^8 scale: linear3h.hip)
 // go to whichever of ff / qkv is idle.  L >= 512 makes every region large enough for them.
@@ -218,13 +225,35 @@ static void run_pct(hipStream_t s, const PctW& w, const float* pc, float* feat, 
     float* h = a.f(T * PCT_E);
     float* qkv = a.f(T * (PCT_E + 64));
     float* ff = a.f(T * 2 * PCT_E);
+    const bool planes = ends_planes(L, PCT_E) && half % 4 == 0;
+    const float inv = 1.0f / 256.0f;
+    _Float16 *hh = reinterpret_cast<_Float16*>(h), *hl = hh + (size_t)T * PCT_E;            // planes [2][T][128] over h
     // Embedding (Attention.py:98-128): linear1 3->125, GELU, linear2 125->125, concat raw input -> 128
-    launch_linear(s, pc, 3, w.l1.w, w.l1.b, nullptr, 0, h, PCT_INNER, T, PCT_INNER, 3, ACT_GELU, nullptr, 0, 0, L);
-    launch_linear(s, h, PCT_INNER, w.l2.w, w.l2.b, nullptr, 0, x, PCT_E, T, PCT_INNER, PCT_INNER, ACT_NONE, nullptr, 0, 0, L);
+    if (planes) {
+        // the 125-wide inner layer padded with exact zeros to the planes GEMM's K = 128: linear1 writes planes, linear2 multiplies them
+        // (output columns 125..127 = 0 + 0, then overwritten by the raw input)
+        launch_linear_smallk_planes(s, pc, 3, w.l1.w, w.l1.b, hh, hl, PCT_E, T, PCT_INNER, 3, ACT_GELU, PCT_E);
+        _Float16* wp = reinterpret_cast<_Float16*>(ff);
+        float* bp = ff + (size_t)PCT_E * PCT_E;                                              // behind the [2][128][128] halves
+        launch_pad_weights(s, w.l2.w, PCT_INNER, w.l2.b, wp, bp, PCT_INNER, PCT_INNER, PCT_E, PCT_E);
+        launch_linear3p(s, hh, hl, PCT_E, wp, wp + (size_t)PCT_E * PCT_E, PCT_E, bp, x, nullptr, nullptr, PCT_E, T, PCT_E, PCT_E, ACT_NONE, inv,
+                        nullptr, 0, nullptr);
+    } else {
+        launch_linear(s, pc, 3, w.l1.w, w.l1.b, nullptr, 0, h, PCT_INNER, T, PCT_INNER, 3, ACT_GELU, nullptr, 0, 0, L);
+        launch_linear(s, h, PCT_INNER, w.l2.w, w.l2.b, nullptr, 0, x, PCT_E, T, PCT_INNER, PCT_INNER, ACT_NONE, nullptr, 0, 0, L);
+    }
     launch_copy2d(s, pc, 3, x + PCT_INNER, PCT_E, T, 3);
     for (int e = 0; e < 2; ++e) run_encoder(s, w.enc[e], x, h, qkv, ff, S, L, PCT_E, 4, lens);
-    launch_layernorm(s, x, PCT_E, w.ng, w.nb, h, PCT_E, T, PCT_E);                          // SconeOcc.py:119
-    launch_linear(s, h, PCT_E, w.lin0.w, w.lin0.b, nullptr, 0, ff, half, T, half, PCT_E, ACT_NONE, nullptr, 0, 0, head_route(L));   // :122
+    if (planes) {                                                                            // SconeOcc.py:119-122 on planes
+        launch_layernorm_planes(s, x, PCT_E, w.ng, w.nb, hh, hl, PCT_E, T, PCT_E);
+        _Float16* wp = reinterpret_cast<_Float16*>(qkv);
+        launch_split_weights(s, w.lin0.w, PCT_E, wp, half, PCT_E);
+        launch_linear3p(s, hh, hl, PCT_E, wp, wp + (size_t)half * PCT_E, PCT_E, w.lin0.b, ff, nullptr, nullptr, half, T, half, PCT_E, ACT_NONE, inv,
+                        nullptr, 0, nullptr);
+    } else {
+        launch_layernorm(s, x, PCT_E, w.ng, w.nb, h, PCT_E, T, PCT_E);                      // SconeOcc.py:119
+        launch_linear(s, h, PCT_E, w.lin0.w, w.lin0.b, nullptr, 0, ff, half, T, half, PCT_E, ACT_NONE, nullptr, 0, 0, head_route(L));   // :122
+    }
     launch_pool_max_avg(s, ff, half, feat, ld_feat, S, L, half, lens);                       // :124-126
 }
 
@@ -523,18 +552,50 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
     float* h = a.f(T * VIS_E);
     float* qkv = a.f(T * (VIS_E + 128));
     float* ff = a.f(T * 2 * VIS_E);
+    const bool planes = ends_planes((int)N, VIS_E);
+    const float inv = 1.0f / 256.0f;
+    _Float16 *hh = reinterpret_cast<_Float16*>(h), *hl = hh + (size_t)T * VIS_E;               // planes [2][T][<= 256] over h
     // Embedding: 4 -> 126 GELU -> 126, || cloud-wide max (126) || raw input (4)  = 256   (Attention.py:98-128)
-    launch_linear(s, pts, 4, l1.w, l1.b, nullptr, 0, h, VIS_F, T, VIS_F, 4, ACT_GELU, nullptr, 0, 0, N);
-    launch_linear(s, h, VIS_F, l2.w, l2.b, nullptr, 0, x, VIS_E, T, VIS_F, VIS_F, ACT_NONE, nullptr, 0, 0, N);
+    if (planes) {
+        // the 126-wide inner layer padded with exact zeros to K = 128: linear1 writes planes, linear2 multiplies them (its output
+        // columns 126, 127 = 0 + 0 are overwritten by the cloud-wide max below)
+        _Float16* x1l = hh + (size_t)T * 128;
+        launch_linear_smallk_planes(s, pts, 4, l1.w, l1.b, hh, x1l, 128, T, VIS_F, 4, ACT_GELU, 128);
+        _Float16* wp = reinterpret_cast<_Float16*>(ff);
+        float* bp = ff + (size_t)128 * 128;
+        launch_pad_weights(s, l2.w, VIS_F, l2.b, wp, bp, VIS_F, VIS_F, 128, 128);
+        launch_linear3p(s, hh, x1l, 128, wp, wp + (size_t)128 * 128, 128, bp, x, nullptr, nullptr, VIS_E, T, 128, 128, ACT_NONE, inv, nullptr, 0, nullptr);
+    } else {
+        launch_linear(s, pts, 4, l1.w, l1.b, nullptr, 0, h, VIS_F, T, VIS_F, 4, ACT_GELU, nullptr, 0, 0, N);
+        launch_linear(s, h, VIS_F, l2.w, l2.b, nullptr, 0, x, VIS_E, T, VIS_F, VIS_F, ACT_NONE, nullptr, 0, 0, N);
+    }
     launch_colmax_broadcast(s, x, VIS_E, x + VIS_F, VIS_E, B, (int)N, VIS_F, lengths);
     launch_copy2d(s, pts, 4, x + 2 * VIS_F, VIS_E, T, 4);
     for (int e = 0; e < 3; ++e) run_encoder(s, enc[e], x, h, qkv, ff, B, (int)N, VIS_E, 4, lengths);   // SconeVis.py:139-140
-    launch_layernorm(s, x, VIS_E, ng, nb, h, VIS_E, T, VIS_E);                                   // :143
-    // fc1 256->192 GELU, || view_harmonics (64), fc2 256->128 GELU, fc3 128->64                  (:146-152)
-    launch_linear(s, h, VIS_E, fc1.w, fc1.b, nullptr, 0, ff, VIS_E, T, 192, VIS_E, ACT_GELU, nullptr, 0, 0, head_route(N));
-    launch_copy2d(s, view_harmonics, 64, ff + 192, VIS_E, T, 64);
-    launch_linear(s, ff, VIS_E, fc2.w, fc2.b, nullptr, 0, h, 128, T, 128, VIS_E, ACT_GELU, nullptr, 0, 0, head_route(N));
-    launch_linear(s, h, 128, fc3.w, fc3.b, nullptr, 0, out, 64, T, 64, 128, ACT_NONE, nullptr, 0, 0, N);
+    if (planes) {
+        // :143-152 on planes: LayerNorm -> planes; fc1 (GELU) writes columns 0..191 of the next operand's planes, the view harmonics are
+        // split into columns 192..255; fc2 (GELU) writes planes; fc3 leaves fp32.  Weight planes: split per call into the idle qkv region
+        launch_layernorm_planes(s, x, VIS_E, ng, nb, hh, hl, VIS_E, T, VIS_E);
+        _Float16* w1 = reinterpret_cast<_Float16*>(qkv);
+        _Float16* w2 = w1 + (size_t)2 * 192 * VIS_E;
+        _Float16* w3 = w2 + (size_t)2 * 128 * VIS_E;
+        launch_split_weights(s, fc1.w, VIS_E, w1, 192, VIS_E);
+        launch_split_weights(s, fc2.w, VIS_E, w2, 128, VIS_E);
+        launch_split_weights(s, fc3.w, 128, w3, 64, 128);
+        _Float16 *fh = reinterpret_cast<_Float16*>(ff), *fl = fh + (size_t)T * VIS_E;            // planes [2][T][256] over ff
+        launch_linear3p(s, hh, hl, VIS_E, w1, w1 + (size_t)192 * VIS_E, VIS_E, fc1.b, nullptr, fh, fl, VIS_E, T, 192, VIS_E, ACT_GELU, inv, nullptr, 0, nullptr);
+        launch_split_to_planes(s, view_harmonics, 64, fh + 192, fl + 192, VIS_E, T, 64);
+        _Float16* gl = hh + (size_t)T * 128;                                                       // planes [2][T][128] over h (the LayerNorm's are consumed)
+        launch_linear3p(s, fh, fl, VIS_E, w2, w2 + (size_t)128 * VIS_E, VIS_E, fc2.b, nullptr, hh, gl, 128, T, 128, VIS_E, ACT_GELU, inv, nullptr, 0, nullptr);
+        launch_linear3p(s, hh, gl, 128, w3, w3 + (size_t)64 * 128, 128, fc3.b, out, nullptr, nullptr, 64, T, 64, 128, ACT_NONE, inv, nullptr, 0, nullptr);
+    } else {
+        launch_layernorm(s, x, VIS_E, ng, nb, h, VIS_E, T, VIS_E);                                   // :143
+        // fc1 256->192 GELU, || view_harmonics (64), fc2 256->128 GELU, fc3 128->64                  (:146-152)
+        launch_linear(s, h, VIS_E, fc1.w, fc1.b, nullptr, 0, ff, VIS_E, T, 192, VIS_E, ACT_GELU, nullptr, 0, 0, head_route(N));
+        launch_copy2d(s, view_harmonics, 64, ff + 192, VIS_E, T, 64);
+        launch_linear(s, ff, VIS_E, fc2.w, fc2.b, nullptr, 0, h, 128, T, 128, VIS_E, ACT_GELU, nullptr, 0, 0, head_route(N));
+        launch_linear(s, h, 128, fc3.w, fc3.b, nullptr, 0, out, 64, T, 64, 128, ACT_NONE, nullptr, 0, 0, N);
+    }
     MCR_LAUNCH_CHECK("mcr_scone_vis_forward");
     return 0;
 }

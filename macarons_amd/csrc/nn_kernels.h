@@ -99,13 +99,16 @@ void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx,
 // LayerNorm whose output leaves as fp16 hi/lo planes (row stride ldp halves): the input of a planes GEMM, split where it is produced
 void launch_layernorm_planes(hipStream_t s, const float* X, int64_t ldx, const float* g, const float* b, void* Yh, void* Yl, int64_t ldp,
                              int64_t M, int E);
+// (Np > N: columns N .. Np - 1 of the planes are written as zeros -- a padded K for the consuming GEMM)
 void launch_linear_smallk_planes(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, void* Yh, void* Yl,
-                                 int64_t ldy, int64_t M, int N, int K, int act);
+                                 int64_t ldy, int64_t M, int N, int K, int act, int Np = 0);
 bool linear3p_dot_applicable(int N, int K, int64_t ldx, int64_t ldw);
 void launch_linear3p_dot(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
                          const float* bias, int64_t M, int K, int act, float wscale_inv, const float* v, const float* c, int act2, float* out);
 void launch_split_to_planes(hipStream_t s, const float* X, int64_t ldx, void* Ph, void* Pl, int64_t ldp, int64_t M, int E);
 void launch_split_weights(hipStream_t s, const float* W, int64_t ldw, void* planes, int N, int K);   // linear3h.hip: [2][N][K] fp16 of W * 2^8
+// the same with zero padding to [2][Np][Kp] (Np % 4 == 0, Kp % 32 == 0) and the bias padded to bias_p [Np]
+void launch_pad_weights(hipStream_t s, const float* W, int64_t ldw, const float* bias, void* planes, float* bias_p, int N, int K, int Np, int Kp);
 // segmented kNN-16 with query offsets (knn.hip): see launch_knn16_segmented there
 void launch_knn16_segmented(hipStream_t s, const float* X, const float* pc, const long long* pc_off, const int* blocks,
                             int64_t n_blocks, int64_t T, float* offsets_out, float* split_ws = nullptr, bool large_clouds = false);

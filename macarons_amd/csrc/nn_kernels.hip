@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restr
                                                             long long ldw, const float* __restrict__ bias,
                                                             const float* __restrict__ R, long long ldr, float* __restrict__ Y,
                                                             long long ldy, long long M, int N, int K, int act,
-                                                            _Float16* __restrict__ Yh, _Float16* __restrict__ Yl) {
+                                                            _Float16* __restrict__ Yh, _Float16* __restrict__ Yl, int Nreal) {
+    // N: outputs written per row (a multiple of 4); Nreal <= N: the layer's width -- outputs beyond it are exact zeros (PLANES: the
+    // zero padding of the consuming GEMM's K)
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int n4 = N >> 2;
     if (idx >= M * n4) return;
@@ -169,10 +171,12 @@ __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float acc = 0.f;
-        for (int k = 0; k < K; ++k) acc = fmaf(x[k], W[(long long)(n + j) * ldw + k], acc);
-        acc += bias ? bias[n + j] : 0.f;
-        if (act == ACT_GELU) acc = gelu_erf(acc);
-        if (R) acc += R[m * ldr + n + j];
+        if (n + j < Nreal) {
+            for (int k = 0; k < K; ++k) acc = fmaf(x[k], W[(long long)(n + j) * ldw + k], acc);
+            acc += bias ? bias[n + j] : 0.f;
+            if (act == ACT_GELU) acc = gelu_erf(acc);
+            if (R) acc += R[m * ldr + n + j];
+        }
         y[j] = acc;
     }
     if (PLANES) {
@@ -188,10 +192,11 @@ __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restr
 
 // act(X W^T + bias) for K <= 4, written as fp16 hi/lo planes (N % 4 == 0, ldy % 4 == 0)
 void launch_linear_smallk_planes(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, void* Yh, void* Yl,
-                                 int64_t ldy, int64_t M, int N, int K, int act) {
+                                 int64_t ldy, int64_t M, int N, int K, int act, int Np) {
     if (M <= 0 || N <= 0) return;
-    hipLaunchKernelGGL(linear_smallk_kernel<true>, dim3((unsigned)cdiv(M * (N / 4), 256)), dim3(256), 0, s, X, (long long)ldx, W, (long long)K,
-                       bias, (const float*)nullptr, 0ll, (float*)nullptr, (long long)ldy, (long long)M, N, K, act, (_Float16*)Yh, (_Float16*)Yl);
+    const int Nw = Np > N ? Np : N;                        // outputs written per row
+    hipLaunchKernelGGL(linear_smallk_kernel<true>, dim3((unsigned)cdiv(M * (Nw / 4), 256)), dim3(256), 0, s, X, (long long)ldx, W, (long long)K,
+                       bias, (const float*)nullptr, 0ll, (float*)nullptr, (long long)ldy, (long long)M, Nw, K, act, (_Float16*)Yh, (_Float16*)Yl, N);
 }
 
 void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, const float* R,
@@ -211,7 +216,7 @@ void launch_linear(hipStream_t s, const float* X, int64_t ldx, const float* W, c
     }
     if (K <= 4 && N % 4 == 0 && ldy % 4 == 0 && aligned16(Y) && !row_bias && M * (N / 4) >= 65536) {
         hipLaunchKernelGGL(linear_smallk_kernel<false>, dim3((unsigned)cdiv(M * (N / 4), 256)), dim3(256), 0, s, X, (long long)ldx, W, (long long)ldw,
-                           bias, R, (long long)ldr, Y, (long long)ldy, (long long)M, N, K, act, (_Float16*)nullptr, (_Float16*)nullptr);
+                           bias, R, (long long)ldr, Y, (long long)ldy, (long long)M, N, K, act, (_Float16*)nullptr, (_Float16*)nullptr, N);
         return;
     }
     const int vec_x = (K % 4 == 0) && (ldx % 4 == 0) && aligned16(X);
