@@ -1102,7 +1102,13 @@ using namespace mcr;
 namespace mcr {
 // split_ws (optional, knn16_segmented_split_floats(T) floats): lets a launch with few query blocks split every job's candidates over
 // up to KNN_SEG_SPLIT workgroups per block (+ one merge launch); same neighbours in the same order.  MCR_KNN_SEG_SPLIT=0: never (A/B)
-constexpr int KNN_SEG_SPLIT = 4;
+#ifndef MCR_KNN_SEG_SPLIT_MAX
+#define MCR_KNN_SEG_SPLIT_MAX 4
+#endif
+#ifndef MCR_KNN_SEG_TARGET
+#define MCR_KNN_SEG_TARGET 768
+#endif
+constexpr int KNN_SEG_SPLIT = MCR_KNN_SEG_SPLIT_MAX;
 size_t knn16_segmented_split_floats(int64_t T) { return (size_t)KNN_SEG_SPLIT * T * 16 * 2; }
 void launch_knn16_segmented(hipStream_t s, const float* X, const float* pc, const long long* pc_off, const int* blocks,
                             int64_t n_blocks, int64_t T, float* offsets_out, float* split_ws, bool large_clouds) {
@@ -1111,7 +1117,7 @@ void launch_knn16_segmented(hipStream_t s, const float* X, const float* pc, cons
     static const bool use_mfma = []() { const char* e = getenv("MCR_KNN_MFMA"); return !(e && e[0] == '0'); }();
     // four waves per block: ~3 waves per SIMD need 768 blocks
     int n_split = 1;
-    if (split_on && use_mfma && split_ws && large_clouds) n_split = (int)std::min<int64_t>(KNN_SEG_SPLIT, std::max<int64_t>(1, 768 / n_blocks));
+    if (split_on && use_mfma && split_ws && large_clouds) n_split = (int)std::min<int64_t>(KNN_SEG_SPLIT, std::max<int64_t>(1, MCR_KNN_SEG_TARGET / n_blocks));
     if (n_split > 1) {
         unsigned long long* part = reinterpret_cast<unsigned long long*>(split_ws);
         hipLaunchKernelGGL((knn_mfma_kernel<16, true>), dim3((unsigned)n_blocks, (unsigned)n_split), dim3(KNN_BLOCK), 0, s, X, pc,

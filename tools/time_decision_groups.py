@@ -3,6 +3,9 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from macarons_amd import _lib
+if os.environ.get("MCR_DEV_LIB"):      # experimental build from tools/build_variant.py
+    _lib.LIB_PATH = os.path.join(ROOT, "tools", "_libs", f"libmacarons_hip_{os.environ['MCR_DEV_LIB']}.so")
 import bench
 os.environ["MCR_BENCH_NO_CHECKS"] = "1"
 dev = torch.device("cuda:0")
@@ -13,5 +16,6 @@ for g in sys.argv[1:] or ["1", "2", "3", "4", ""]:
         os.environ.pop("MCR_FIELD_GROUPS", None)
     r = [bench.measure_macarons_step(dev, perm_sources=("host",))["p50_ms"] for _ in range(3)]
     print(f"groups={g or 'auto'}: p50 {sorted(r)[1]:.2f} ms  (runs {', '.join(f'{x:.2f}' for x in r)})", flush=True)
-r = bench.measure_macarons_step(dev, perm_sources=("device",))
-print("device perms p50", r["device_perms"]["p50_ms"])
+if not os.environ.get("NO_DEVICE_PERMS"):
+    r = bench.measure_macarons_step(dev, perm_sources=("device",))
+    print("device perms p50", r["device_perms"]["p50_ms"])
