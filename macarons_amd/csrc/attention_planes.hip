@@ -41,6 +41,18 @@ __device__ __forceinline__ ap_u32x2 ap_read_tr(unsigned addr) {       // 4 keys 
     return v;
 }
 
+// max over the four lanes (li, g = 0..3) that share a query: v_permlane32_swap / v_permlane16_swap exchange halves / neighbouring 16-lane
+// rows between two registers in one instruction each -- no LDS round trip (two dependent ds_bpermute were ~250 cycles of every tile's
+// critical path)
+__device__ __forceinline__ float ap_max_lane_groups(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);          // -> [lo, lo], [hi, hi]
+    x = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
+    const unsigned v = __builtin_bit_cast(unsigned, x);
+    const auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);          // -> rows [0, 0, 2, 2], [1, 1, 3, 3]
+    return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
+}
+
 #ifndef MCR_AP_OCC_16
 #define MCR_AP_OCC_16 3
 #endif
@@ -231,15 +243,10 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (sub * 4 + r >= 3) tmax = fmaxf(tmax, st[qg][sub][r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = ap_max_lane_groups(tmax);
             const float m_new = fmaxf(m[qg], tmax * c2);
             const float alpha = __builtin_amdgcn_exp2f(m[qg] - m_new);   // m = -inf on the first tile -> 0 (o = 0 anyway)
             m[qg] = m_new;
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) st[qg][sub][r] = __builtin_amdgcn_exp2f(fmaf(st[qg][sub][r], c2, -m_new));
             // rescale O and the denominators (rows = queries 4g + r live in lane group g); a wave whose 16 queries all keep their maxima
             // skips the exchange and the multiplications by 1 (same bits)
             if (__any(alpha != 1.f)) {
@@ -254,19 +261,31 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
                     for (int r = 0; r < 4; ++r) o[qg][nt][r] *= ar[r];
             }
         }
-        // ---- O += P V: two 16-key sub-tiles per MFMA (k index 8 g + r <-> key 4 g + r of sub-tile 2 q (r < 4) or 2 q + 1 (r >= 4)) ----
+        // ---- weights and O += P V, 32 keys at a time: p = exp2(s c - m) and its fp16 split for keys 32..63 are issued between the MFMA
+        // groups of keys 0..31 -- the matrix pipe works through a group while the vector unit prepares the next operands (the phases of a
+        // wave are otherwise strictly serial, and measured costs were additive: matrix + vector + staging).  Two 16-key sub-tiles per
+        // MFMA: k index 8 g + r <-> key 4 g + r of sub-tile 2 q (r < 4) or 2 q + 1 (r >= 4)
         f16x8 p_hi[2][QG], p_lo[2][QG];
+        auto weights = [&](const int q, const int qg, const int half) {     // half 0 / 1: sub-tile 2 q / 2 q + 1 of query group qg
+            const int sub = 2 * q + half;
+#ifdef MCR_AP_EXP_NOEXP          // (experiment, wrong results: no exponentials -- prices the transcendental unit)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+            for (int r = 0; r < 4; ++r) st[qg][sub][r] = fmaf(st[qg][sub][r], c2, -m[qg]);
+#else
 #pragma unroll
-            for (int qg = 0; qg < QG; ++qg) {
-                uint4 ph, pl;
-                split2h(st[qg][2 * q][0], st[qg][2 * q][1], ph.x, pl.x);
-                split2h(st[qg][2 * q][2], st[qg][2 * q][3], ph.y, pl.y);
-                split2h(st[qg][2 * q + 1][0], st[qg][2 * q + 1][1], ph.z, pl.z);
-                split2h(st[qg][2 * q + 1][2], st[qg][2 * q + 1][3], ph.w, pl.w);
-                p_hi[q][qg] = __builtin_bit_cast(f16x8, ph); p_lo[q][qg] = __builtin_bit_cast(f16x8, pl);
-            }
+            for (int r = 0; r < 4; ++r) st[qg][sub][r] = __builtin_amdgcn_exp2f(fmaf(st[qg][sub][r], c2, -m[qg]));
+#endif
+        };
+        auto split_q = [&](const int q, const int qg) {
+            uint4 ph, pl;
+            split2h(st[qg][2 * q][0], st[qg][2 * q][1], ph.x, pl.x);
+            split2h(st[qg][2 * q][2], st[qg][2 * q][3], ph.y, pl.y);
+            split2h(st[qg][2 * q + 1][0], st[qg][2 * q + 1][1], ph.z, pl.z);
+            split2h(st[qg][2 * q + 1][2], st[qg][2 * q + 1][3], ph.w, pl.w);
+            p_hi[q][qg] = __builtin_bit_cast(f16x8, ph); p_lo[q][qg] = __builtin_bit_cast(f16x8, pl);
+        };
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) { weights(0, qg, 0); weights(0, qg, 1); split_q(0, qg); }
         // first 32 keys, one 16-column block after the other: per accumulator p_lo v_hi, then p_hi v_lo, then p_hi v_hi (smallest terms
         // first).  As soon as a block's MFMAs are issued its fragments of the SECOND 32 keys (+ 1024 bytes inside an [nt] block) are read
         // into the registers they leave: the reads travel under the remaining MFMAs, and the two halves never hold 2 x 32 registers at once
@@ -287,18 +306,31 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg) ol[qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_hi[q][qg], ones, ol[qg], 0, 0, 0);
         };
-        pv(0, 0, vf[0]); __builtin_amdgcn_sched_barrier(0); MCR_AP_VREAD(vg, 0, 1024); __builtin_amdgcn_sched_barrier(0);
-        pv(0, 1, vf[1]); __builtin_amdgcn_sched_barrier(0); MCR_AP_VREAD(vg, 1, 1024); __builtin_amdgcn_sched_barrier(0);
+        // (a scheduling wall after every group: MFMAs, then the vector work that overlaps them, then the fragment reads of keys 32..63)
+        pv(0, 0, vf[0]); weights(1, 0, 0); weights(1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0); MCR_AP_VREAD(vg, 0, 1024); __builtin_amdgcn_sched_barrier(0);
+        pv(0, 1, vf[1]); split_q(1, 0);
+        __builtin_amdgcn_sched_barrier(0); MCR_AP_VREAD(vg, 1, 1024); __builtin_amdgcn_sched_barrier(0);
         if constexpr (NT == 4) {
-            pv(0, NT - 2, vf[NT - 2]); __builtin_amdgcn_sched_barrier(0); MCR_AP_VREAD(vg, NT - 2, 1024); __builtin_amdgcn_sched_barrier(0);
-            pv(0, NT - 1, vf[NT - 1]); __builtin_amdgcn_sched_barrier(0); MCR_AP_VREAD(vg, NT - 1, 1024); __builtin_amdgcn_sched_barrier(0);
+            pv(0, NT - 2, vf[NT - 2]);
+            if constexpr (QG == 2) { weights(1, QG - 1, 0); weights(1, QG - 1, 1); }
+            __builtin_amdgcn_sched_barrier(0); MCR_AP_VREAD(vg, NT - 2, 1024); __builtin_amdgcn_sched_barrier(0);
+            pv(0, NT - 1, vf[NT - 1]);
+            if constexpr (QG == 2) split_q(1, QG - 1);
+            __builtin_amdgcn_sched_barrier(0); MCR_AP_VREAD(vg, NT - 1, 1024); __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (QG == 2) {
+            weights(1, QG - 1, 0); weights(1, QG - 1, 1); split_q(1, QG - 1);
         }
         pl_sum(0);
         pl_sum(1);
         __builtin_amdgcn_sched_barrier(0);                 // (the wait stays behind those MFMAs)
         MCR_AP_VWAIT(vg);
+#ifdef MCR_AP_EXP_HALFPV         // (experiment, wrong results: the second 32 keys' products dropped -- prices the matrix pipe)
+        asm volatile("" :: "v"(vg[0][0]), "v"(vg[1][0]));
+#else
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) pv(1, nt, vg[nt]);
+#endif
 #undef MCR_AP_VREAD
 #undef MCR_AP_VWAIT
     }
