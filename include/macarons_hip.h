@@ -139,6 +139,10 @@ int mcr_pool_max_avg(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t
  *                 ff.linear2.weight as fp16 hi/lo planes [2][N][K] of W * 2^8 (hi = fp16(x), lo = fp16(x - hi);
  *                 networks/packing.py: encoder_weight_planes) -- for the planes GEMMs of variant 6 (sequences of >= 512 tokens).
  *                 Without the tail the weights are split by one small launch per GEMM and call.
+ *   END PLANES (optional, behind PLANES; n_weights = 32 + 11 / 48 + 17 / 140 + 11): the layers either side of the encoders on the same
+ *                 path -- PCT / SCONE_OCC's global_transformer: embedding.linear2.weight zero-padded to planes [2][128][128],
+ *                 its bias zero-padded to fp32 [128], linear0.weight planes; SCONE_VIS: the same two for its embedding.linear2
+ *                 (126 x 126 -> 128 x 128), then fc1, fc2, fc3 planes (networks/packing.py: padded_weight_planes, weight_planes).
  *
  * mcr_pc_transformer_forward: PCTransformer.forward (macarons/networks/SconeOcc.py:104-130); pc [S,L,3] ->
  *   features [S, feature_dim] (max || avg), feature_dim in {256, 512}.

@@ -203,7 +203,11 @@ static void run_encoder(hipStream_t s, const EncW& w, float* x, float* h, float*
 
 // ---- PCTransformer (SconeOcc.py:45-130): S sequences of L points (pts_dim 3), E = 128, 2 encoders, 4 heads ----
 constexpr int PCT_E = 128, PCT_INNER = 125, PCT_NW = 4 + 2 * 12 + 2 + 2;
-struct PctW { LinW l1, l2; EncW enc[2]; const float *ng, *nb; LinW lin0; };
+struct PctW { LinW l1, l2; EncW enc[2]; const float *ng, *nb; LinW lin0;
+              const void *p_l2 = nullptr; const float* b_l2p = nullptr; const void* p_lin0 = nullptr; };   // host-built planes of the end layers (optional)
+static void read_pct_end_planes(const float* const*& p, PctW& w) {
+    w.p_l2 = *p++; w.b_l2p = *p++; w.p_lin0 = *p++;
+}
 static PctW read_pct(const float* const*& p) {
     PctW w;
     w.l1.w = *p++; w.l1.b = *p++; w.l2.w = *p++; w.l2.b = *p++;
@@ -233,9 +237,13 @@ static void run_pct(hipStream_t s, const PctW& w, const float* pc, float* feat, 
         // the 125-wide inner layer padded with exact zeros to the planes GEMM's K = 128: linear1 writes planes, linear2 multiplies them
         // (output columns 125..127 = 0 + 0, then overwritten by the raw input)
         launch_linear_smallk_planes(s, pc, 3, w.l1.w, w.l1.b, hh, hl, PCT_E, T, PCT_INNER, 3, ACT_GELU, PCT_E);
-        _Float16* wp = reinterpret_cast<_Float16*>(ff);
-        float* bp = ff + (size_t)PCT_E * PCT_E;                                              // behind the [2][128][128] halves
-        launch_pad_weights(s, w.l2.w, PCT_INNER, w.l2.b, wp, bp, PCT_INNER, PCT_INNER, PCT_E, PCT_E);
+        const _Float16* wp = (const _Float16*)w.p_l2;                                        // host-built (once per parameter version) ...
+        const float* bp = w.b_l2p;
+        if (!wp) {                                                                           // ... or padded here, per call
+            float* bq = ff + (size_t)PCT_E * PCT_E;                                          // behind the [2][128][128] halves
+            launch_pad_weights(s, w.l2.w, PCT_INNER, w.l2.b, ff, bq, PCT_INNER, PCT_INNER, PCT_E, PCT_E);
+            wp = reinterpret_cast<const _Float16*>(ff); bp = bq;
+        }
         launch_linear3p(s, hh, hl, PCT_E, wp, wp + (size_t)PCT_E * PCT_E, PCT_E, bp, x, nullptr, nullptr, PCT_E, T, PCT_E, PCT_E, ACT_NONE, inv,
                         nullptr, 0, nullptr);
     } else {
@@ -246,8 +254,8 @@ static void run_pct(hipStream_t s, const PctW& w, const float* pc, float* feat, 
     for (int e = 0; e < 2; ++e) run_encoder(s, w.enc[e], x, h, qkv, ff, S, L, PCT_E, 4, lens);
     if (planes) {                                                                            // SconeOcc.py:119-122 on planes
         launch_layernorm_planes(s, x, PCT_E, w.ng, w.nb, hh, hl, PCT_E, T, PCT_E);
-        _Float16* wp = reinterpret_cast<_Float16*>(qkv);
-        launch_split_weights(s, w.lin0.w, PCT_E, wp, half, PCT_E);
+        const _Float16* wp = (const _Float16*)w.p_lin0;
+        if (!wp) { launch_split_weights(s, w.lin0.w, PCT_E, qkv, half, PCT_E); wp = reinterpret_cast<const _Float16*>(qkv); }
         launch_linear3p(s, hh, hl, PCT_E, wp, wp + (size_t)half * PCT_E, PCT_E, w.lin0.b, ff, nullptr, nullptr, half, T, half, PCT_E, ACT_NONE, inv,
                         nullptr, 0, nullptr);
     } else {
@@ -501,7 +509,8 @@ int mcr_pc_transformer_forward(const float* pc, float* features, int64_t S, int6
                                void* stream) {
     VariantScope variant_scope_;
     MCR_REQUIRE(pc && features && weights, "mcr_pc_transformer_forward: null pointer");
-    MCR_REQUIRE(n_weights == PCT_NW || n_weights == PCT_NW + 8, "mcr_pc_transformer_forward: expected %d weight pointers (+ 8 plane pointers), got %d", PCT_NW, n_weights);
+    MCR_REQUIRE(n_weights == PCT_NW || n_weights == PCT_NW + 8 || n_weights == PCT_NW + 11,
+                "mcr_pc_transformer_forward: expected %d weight pointers (+ 8 or 11 plane pointers), got %d", PCT_NW, n_weights);
     MCR_REQUIRE(S > 0 && L > 0, "mcr_pc_transformer_forward: empty problem");
     MCR_REQUIRE(feature_dim == 256 || feature_dim == 512, "mcr_pc_transformer_forward: feature_dim must be 256 or 512");
     MCR_REQUIRE(L == 16 || S <= 65535, "mcr_pc_transformer_forward: too many long sequences");
@@ -510,7 +519,8 @@ int mcr_pc_transformer_forward(const float* pc, float* features, int64_t S, int6
     for (int i = 0; i < n_weights; ++i) MCR_REQUIRE(weights[i], "mcr_pc_transformer_forward: weight %d is null", i);
     const float* const* p = weights;
     PctW w = read_pct(p);
-    if (n_weights == PCT_NW + 8) { read_enc_planes(p, w.enc[0]); read_enc_planes(p, w.enc[1]); }
+    if (n_weights >= PCT_NW + 8) { read_enc_planes(p, w.enc[0]); read_enc_planes(p, w.enc[1]); }
+    if (n_weights == PCT_NW + 11) read_pct_end_planes(p, w);
     Arena a{(char*)workspace, workspace_bytes, 0};
     run_pct((hipStream_t)stream, w, pc, features, feature_dim, S, (int)L, feature_dim / 2, a);
     MCR_LAUNCH_CHECK("mcr_pc_transformer_forward");
@@ -531,7 +541,8 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
                           size_t workspace_bytes, void* stream) {
     VariantScope variant_scope_;
     MCR_REQUIRE(pts && view_harmonics && out && weights, "mcr_scone_vis_forward: null pointer");
-    MCR_REQUIRE(n_weights == VIS_NW || n_weights == VIS_NW + 12, "mcr_scone_vis_forward: expected %d weight pointers (+ 12 plane pointers), got %d", VIS_NW, n_weights);
+    MCR_REQUIRE(n_weights == VIS_NW || n_weights == VIS_NW + 12 || n_weights == VIS_NW + 17,
+                "mcr_scone_vis_forward: expected %d weight pointers (+ 12 or 17 plane pointers), got %d", VIS_NW, n_weights);
     MCR_REQUIRE(B > 0 && N > 0 && B <= 65535, "mcr_scone_vis_forward: bad problem size B=%ld N=%ld", (long)B, (long)N);
     MCR_REQUIRE(workspace && workspace_bytes >= mcr_scone_vis_workspace_bytes(B, N), "mcr_scone_vis_forward: workspace too small");
     for (int i = 0; i < n_weights; ++i) MCR_REQUIRE(weights[i], "mcr_scone_vis_forward: weight %d is null", i);
@@ -543,8 +554,11 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
     const float *ng = *p++, *nb = *p++;
     LinW fc1{p[0], p[1]}, fc2{p[2], p[3]}, fc3{p[4], p[5]};
     p += 6;
-    if (n_weights == VIS_NW + 12)
+    if (n_weights >= VIS_NW + 12)
         for (int e = 0; e < 3; ++e) read_enc_planes(p, enc[e]);
+    const void *hp_l2 = nullptr, *hp_fc1 = nullptr, *hp_fc2 = nullptr, *hp_fc3 = nullptr;     // host-built planes of the end layers (optional)
+    const float* hb_l2 = nullptr;
+    if (n_weights == VIS_NW + 17) { hp_l2 = p[0]; hb_l2 = p[1]; hp_fc1 = p[2]; hp_fc2 = p[3]; hp_fc3 = p[4]; p += 5; }
 
     const int64_t T = B * N;
     Arena a{(char*)workspace, workspace_bytes, 0};
@@ -561,9 +575,13 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
         // columns 126, 127 = 0 + 0 are overwritten by the cloud-wide max below)
         _Float16* x1l = hh + (size_t)T * 128;
         launch_linear_smallk_planes(s, pts, 4, l1.w, l1.b, hh, x1l, 128, T, VIS_F, 4, ACT_GELU, 128);
-        _Float16* wp = reinterpret_cast<_Float16*>(ff);
-        float* bp = ff + (size_t)128 * 128;
-        launch_pad_weights(s, l2.w, VIS_F, l2.b, wp, bp, VIS_F, VIS_F, 128, 128);
+        const _Float16* wp = (const _Float16*)hp_l2;                                            // host-built (once per parameter version) ...
+        const float* bp = hb_l2;
+        if (!wp) {                                                                              // ... or padded here, per call
+            float* bq = ff + (size_t)128 * 128;
+            launch_pad_weights(s, l2.w, VIS_F, l2.b, ff, bq, VIS_F, VIS_F, 128, 128);
+            wp = reinterpret_cast<const _Float16*>(ff); bp = bq;
+        }
         launch_linear3p(s, hh, x1l, 128, wp, wp + (size_t)128 * 128, 128, bp, x, nullptr, nullptr, VIS_E, T, 128, 128, ACT_NONE, inv, nullptr, 0, nullptr);
     } else {
         launch_linear(s, pts, 4, l1.w, l1.b, nullptr, 0, h, VIS_F, T, VIS_F, 4, ACT_GELU, nullptr, 0, 0, N);
@@ -576,12 +594,16 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
         // :143-152 on planes: LayerNorm -> planes; fc1 (GELU) writes columns 0..191 of the next operand's planes, the view harmonics are
         // split into columns 192..255; fc2 (GELU) writes planes; fc3 leaves fp32.  Weight planes: split per call into the idle qkv region
         launch_layernorm_planes(s, x, VIS_E, ng, nb, hh, hl, VIS_E, T, VIS_E);
-        _Float16* w1 = reinterpret_cast<_Float16*>(qkv);
-        _Float16* w2 = w1 + (size_t)2 * 192 * VIS_E;
-        _Float16* w3 = w2 + (size_t)2 * 128 * VIS_E;
-        launch_split_weights(s, fc1.w, VIS_E, w1, 192, VIS_E);
-        launch_split_weights(s, fc2.w, VIS_E, w2, 128, VIS_E);
-        launch_split_weights(s, fc3.w, 128, w3, 64, 128);
+        const _Float16 *w1 = (const _Float16*)hp_fc1, *w2 = (const _Float16*)hp_fc2, *w3 = (const _Float16*)hp_fc3;
+        if (!w1) {
+            _Float16* q1 = reinterpret_cast<_Float16*>(qkv);
+            _Float16* q2 = q1 + (size_t)2 * 192 * VIS_E;
+            _Float16* q3 = q2 + (size_t)2 * 128 * VIS_E;
+            launch_split_weights(s, fc1.w, VIS_E, q1, 192, VIS_E);
+            launch_split_weights(s, fc2.w, VIS_E, q2, 128, VIS_E);
+            launch_split_weights(s, fc3.w, 128, q3, 64, 128);
+            w1 = q1; w2 = q2; w3 = q3;
+        }
         _Float16 *fh = reinterpret_cast<_Float16*>(ff), *fl = fh + (size_t)T * VIS_E;            // planes [2][T][256] over ff
         launch_linear3p(s, hh, hl, VIS_E, w1, w1 + (size_t)192 * VIS_E, VIS_E, fc1.b, nullptr, fh, fl, VIS_E, T, 192, VIS_E, ACT_GELU, inv, nullptr, 0, nullptr);
         launch_split_to_planes(s, view_harmonics, 64, fh + 192, fl + 192, VIS_E, T, 64);
@@ -679,7 +701,8 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
     const bool early = phase != 2, late = phase != 1;
     MCR_REQUIRE(pc_scale && M_scale && x && weights && (!late || (pc_global && view_harmonics && out)), "mcr_scone_occ_forward: null pointer");
     MCR_REQUIRE(!head_planes || head_inv_scales, "mcr_scone_occ_forward: head_planes need head_inv_scales");
-    MCR_REQUIRE(n_weights == OCC_NW || n_weights == OCC_NW + 8, "mcr_scone_occ_forward: expected %d weight pointers (+ 8 plane pointers), got %d", OCC_NW, n_weights);
+    MCR_REQUIRE(n_weights == OCC_NW || n_weights == OCC_NW + 8 || n_weights == OCC_NW + 11,
+                "mcr_scone_occ_forward: expected %d weight pointers (+ 8 or 11 plane pointers), got %d", OCC_NW, n_weights);
     MCR_REQUIRE(B > 0 && Q > 0 && Lg > 0 && B <= 65535, "mcr_scone_occ_forward: bad problem size");
     MCR_REQUIRE(workspace && workspace_bytes >= mcr_scone_occ_workspace_bytes(B, Q, Lg), "mcr_scone_occ_forward: workspace too small");
     for (int i = 0; i < n_weights; ++i) MCR_REQUIRE(weights[i], "mcr_scone_occ_forward: weight %d is null", i);
@@ -694,7 +717,8 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
     p += 6;
     LinW lin1{p[0], p[1]}, lin2{p[2], p[3]}, lin3{p[4], p[5]};
     p += 6;
-    if (n_weights == OCC_NW + 8) { read_enc_planes(p, wg.enc[0]); read_enc_planes(p, wg.enc[1]); }     // the global transformer's encoders
+    if (n_weights >= OCC_NW + 8) { read_enc_planes(p, wg.enc[0]); read_enc_planes(p, wg.enc[1]); }     // the global transformer's encoders
+    if (n_weights == OCC_NW + 11) read_pct_end_planes(p, wg);                                           // ... and its end layers
 
     Arena head{(char*)workspace, workspace_bytes, 0};
     // per-query feature row: [ local 3x256 | x-embedding 512 | view harmonics 64 ] = 1344   (cat at SconeOcc.py:333
@@ -966,7 +990,8 @@ int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global
     const bool early = phase != 2, late = phase != 1;
     MCR_REQUIRE(pc_scale && scale_off && x && view_harmonics && row_job && knn_blocks && weights && (!late || (pc_global && global_len && out)),
                 "mcr_scone_occ_forward_ragged: null pointer");
-    MCR_REQUIRE(n_weights == OCC_NW || n_weights == OCC_NW + 8, "mcr_scone_occ_forward_ragged: expected %d weight pointers (+ 8 plane pointers), got %d", OCC_NW, n_weights);
+    MCR_REQUIRE(n_weights == OCC_NW || n_weights == OCC_NW + 8 || n_weights == OCC_NW + 11,
+                "mcr_scone_occ_forward_ragged: expected %d weight pointers (+ 8 or 11 plane pointers), got %d", OCC_NW, n_weights);
     MCR_REQUIRE(J > 0 && T > 0 && Lg > 0 && J <= 32767 && n_blocks > 0, "mcr_scone_occ_forward_ragged: bad problem size");
     MCR_REQUIRE(local_blobs && local_blobs[0] && local_blobs[1] && local_blobs[2],
                 "mcr_scone_occ_forward_ragged: needs the fused local-transformer blobs");
@@ -982,7 +1007,8 @@ int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global
     p += 6;
     LinW lin1{p[0], p[1]}, lin2{p[2], p[3]}, lin3{p[4], p[5]};
     p += 6;
-    if (n_weights == OCC_NW + 8) { read_enc_planes(p, wg.enc[0]); read_enc_planes(p, wg.enc[1]); }     // the global transformer's encoders
+    if (n_weights >= OCC_NW + 8) { read_enc_planes(p, wg.enc[0]); read_enc_planes(p, wg.enc[1]); }     // the global transformer's encoders
+    if (n_weights == OCC_NW + 11) read_pct_end_planes(p, wg);                                           // ... and its end layers
 
     Arena head{(char*)workspace, workspace_bytes, 0};
     constexpr int FEAT = 1344;

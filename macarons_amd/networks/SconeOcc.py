@@ -17,7 +17,7 @@ from .. import ops, _lib
 from .Attention import (Embedding, Encoder, FeedForward, MultiHeadSelfAttention, attention, knn_gather,   # noqa: F401
                         _f32c, _inference_only)     # the public ones are what upstream's `from .Attention import *` hands on
 from ..utility.utils import get_knn_points   # noqa: F401  (SconeOcc.py:4)
-from .packing import encoder_weight_planes, RangeGuard, BlobCache, HeadPlaneCache, TableCache, param_key, invalidate as _invalidate_key, freeze as _freeze_key
+from .packing import encoder_weight_planes, padded_weight_planes, weight_planes, RangeGuard, BlobCache, HeadPlaneCache, TableCache, param_key, invalidate as _invalidate_key, freeze as _freeze_key
 
 
 class XEmbedding(nn.Module):
@@ -82,7 +82,20 @@ class PCTransformer(nn.Module):
                 x = enc(x, mask=mask)
             x = ops.linear(ops.layernorm(x, _f32c(self.norm.weight), _f32c(self.norm.bias)), _f32c(self.linear0.weight), _f32c(self.linear0.bias))
             return ops.pool_max_avg(x)
+        if pc.shape[1] >= 512:                          # long sequences: planes of every GEMM's weights, built once per parameter version
+            if not hasattr(self, "_table_cache"):
+                self._table_cache = TableCache()
+            return ops.pc_transformer_forward(pc, self._table_cache.get(self, self.weight_table_with_planes), self.feature_dim)
         return ops.pc_transformer_forward(pc, self.weight_table(), self.feature_dim)
+
+    def weight_table_with_planes(self):
+        """weight_table() + the encoders' weights as fp16 hi/lo planes (8 blobs) + the end layers' (3): include/macarons_hip.h, PLANES / END PLANES."""
+        t = self.weight_table()
+        for e in self.encoders:
+            t += encoder_weight_planes(e)
+        t += list(padded_weight_planes(self.embedding.linear2.weight, self.embedding.linear2.bias, 128, 128))
+        t += [weight_planes(self.linear0.weight)]
+        return t
 
 
 class SconeOcc(RangeGuard, nn.Module):
@@ -173,8 +186,12 @@ class SconeOcc(RangeGuard, nn.Module):
     def weight_table_with_planes(self):
         """weight_table() + the global transformer's encoder weights as fp16 hi/lo planes (8 blobs): see SconeVis.weight_table_with_planes."""
         t = self.weight_table()
-        for e in self.global_transformer.encoders:
+        g = self.global_transformer
+        for e in g.encoders:
             t += encoder_weight_planes(e)
+        # the layers either side of the encoders (3 blobs): the embedding's second layer zero-padded to 128 x 128 (+ its padded bias), linear0
+        t += list(padded_weight_planes(g.embedding.linear2.weight, g.embedding.linear2.bias, 128, 128))
+        t += [weight_planes(g.linear0.weight)]
         return t
 
     def ds_factor(self, full_seq_len):

@@ -21,7 +21,7 @@ from .. import ops
 from .Attention import Embedding, Encoder, FeedForward, MultiHeadSelfAttention, attention, knn_gather, _f32c   # noqa: F401
 from ..utility.CustomGeometry import get_spherical_coords                                                # noqa: F401
 from ..utility.spherical_harmonics import clear_spherical_harmonics_cache, get_spherical_harmonics       # noqa: F401
-from .packing import RangeGuard, TableCache, encoder_weight_planes, freeze as _freeze_key
+from .packing import RangeGuard, TableCache, encoder_weight_planes, padded_weight_planes, weight_planes, freeze as _freeze_key
 
 
 class SconeVis(RangeGuard, nn.Module):
@@ -92,6 +92,9 @@ class SconeVis(RangeGuard, nn.Module):
         t = self.weight_table()
         for e in self.encoders:
             t += encoder_weight_planes(e)
+        # the layers either side of the encoders (5 blobs): the embedding's second layer zero-padded to 128 x 128 (+ its padded bias), fc1 / fc2 / fc3
+        t += list(padded_weight_planes(self.embedding.linear2.weight, self.embedding.linear2.bias, 128, 128))
+        t += [weight_planes(self.fc1.weight), weight_planes(self.fc2.weight), weight_planes(self.fc3.weight)]
         return t
 
     def forward(self, pts, mask=None, view_harmonics=None, lengths=None):

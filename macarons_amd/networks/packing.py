@@ -170,6 +170,20 @@ def encoder_weight_planes(enc):
     return [weight_planes(w), weight_planes(enc.mhsa.out.weight), weight_planes(enc.ff.linear1.weight), weight_planes(enc.ff.linear2.weight)]
 
 
+def padded_weight_planes(W, bias, n_pad, k_pad):
+    """(planes [2, n_pad, k_pad] fp16 of W * 2^8 zero-padded, bias [n_pad] fp32 zero-padded): a layer whose width is not a multiple of
+    the planes GEMM's granules (the embeddings' 125 / 126-wide second layer) joins it with exact zeros (pad_weights_kernel, linear3h.hip,
+    builds the same per call when the host did not)."""
+    with torch.no_grad():
+        n, k = W.shape
+        x = torch.zeros((n_pad, k_pad), dtype=torch.float32, device=W.device)
+        x[:n, :k] = W.detach().float() * 256.0
+        hi = x.half()
+        b = torch.zeros(n_pad, dtype=torch.float32, device=W.device)
+        b[:n] = bias.detach().float()
+        return torch.stack((hi, (x - hi.float()).half())).contiguous(), b.contiguous()
+
+
 class TableCache:
     """The weight-pointer table of a module (list of contiguous fp32 tensors + the ctypes array handed to the C ABI), rebuilt
     only when a parameter changed."""
