@@ -105,7 +105,8 @@ def test_long_sequence_attention_outside_the_half_range(dev):
     assert (np.abs(y - ref) / np.maximum(col, 1.0)).max() < 2e-5
 
 
-@pytest.mark.parametrize("S,L,H,qk,v", [(1, 2048, 4, 64, 256), (2, 1777, 4, 64, 256), (3, 700, 4, 32, 128), (12, 1100, 4, 32, 128), (9, 1500, 4, 64, 256)])
+@pytest.mark.parametrize("S,L,H,qk,v", [(1, 2048, 4, 64, 256), (2, 1777, 4, 64, 256), (3, 700, 4, 32, 128), (12, 1100, 4, 32, 128), (9, 1500, 4, 64, 256),
+                                        (3, 65, 4, 64, 256), (70, 130, 4, 32, 128), (1, 16, 4, 32, 128)])
 def test_attention_on_planes_vs_numpy(dev, S, L, H, qk, v):
     """The attention of the long-sequence encoders on the fp16-split path takes q | k | v as fp16 hi/lo planes (K / V tiles by LDS DMA, both
     products on fp16 pairs; attention_planes.hip): against fp64 softmax(QK^T/sqrt(d))V with and without the key split, with per-sequence
@@ -113,10 +114,10 @@ def test_attention_on_planes_vs_numpy(dev, S, L, H, qk, v):
     from macarons_amd import ops
     rng = np.random.default_rng(S * 77 + L)
     qkv = rng.standard_normal((S, L, 2 * qk + v)).astype(np.float32)
-    lens = rng.integers(L // 3, L + 1, size=S).astype(np.int32)
+    lens = rng.integers(max(1, L // 3), L + 1, size=S).astype(np.int32)
     lens[0] = L
     if S > 2:
-        lens[1] = 37
+        lens[1] = min(37, L)
     x = qkv.astype(np.float64)
 
     def ref(n_keys):
