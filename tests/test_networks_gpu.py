@@ -243,6 +243,45 @@ def test_scone_vis_forward(dev):
         assert rel_err(x.cpu().numpy(), nets_encoders(sd, pts)) < TOL
 
 
+def test_end_layers_on_the_planes_route_with_large_activations(dev):
+    """On the default variant the layers either side of the long-sequence encoders (the embedding's second layer, final LayerNorm,
+    fc1 / fc2 / fc3; the global transformer's linear0) run as planes GEMMs (fp16 hi/lo, three MFMAs per product) instead of exact
+    fp32: against the fp64 oracle at 2048 tokens, with the end layers' weights scaled so that their activations reach the hundreds
+    (pin these layers' tolerance, large magnitudes included), and against the exact-fp32 variant."""
+    import ctypes
+    from macarons_amd import _lib
+    from macarons_amd.networks import SconeVis, SconeOcc
+    vis, sd = _mod(SconeVis, 1, dev)
+    rng = np.random.default_rng(11)
+    for scale in (1.0, 60.0):
+        sd2 = dict(sd)
+        for k in ("fc1.weight", "fc2.weight", "embedding.linear2.weight"):
+            sd2[k] = (sd[k] * scale).astype(np.float32)
+        vis.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()}, strict=True)
+        pts = np.concatenate([rng.uniform(-.5, .5, (2, 2048, 3)), rng.uniform(.1, 1, (2, 2048, 1))], -1).astype(np.float32)
+        vh = (rng.standard_normal((2, 2048, 64)) * .3).astype(np.float32)
+        ref = nets.scone_vis_forward(sd2, pts, vh, np.float64)
+        with torch.no_grad():
+            y = vis(T(pts, dev), view_harmonics=T(vh, dev)).cpu().numpy()
+            assert rel_err(y, ref) < TOL, scale
+            prev = _lib.lib().mcr_get_local_pct_variant()
+            try:
+                _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(1))      # exact-fp32 MFMA everywhere
+                y1 = vis(T(pts, dev), view_harmonics=T(vh, dev)).cpu().numpy()
+            finally:
+                _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(prev))
+            assert rel_err(y, y1) < TOL, scale
+    occ, sdo = _mod(SconeOcc, 2, dev)
+    sd3 = dict(sdo)
+    for k in ("global_transformer.linear0.weight", "global_transformer.embedding.linear2.weight"):
+        sd3[k] = (sdo[k] * 40.0).astype(np.float32)
+    occ.load_state_dict({k: torch.from_numpy(v) for k, v in sd3.items()}, strict=True)
+    pc = rng.uniform(-.5, .5, (3, 2048, 3)).astype(np.float32)
+    with torch.no_grad():
+        gf = occ.global_transformer(T(pc, dev)).cpu().numpy()
+    assert rel_err(gf, nets.pc_transformer(sd3, "global_transformer.", pc, np.float64)) < TOL
+
+
 def nets_encoders(sd, pts):
     x = nets.embedding(sd, "embedding", pts.astype(np.float64), True)
     for i in range(3):
