@@ -335,9 +335,45 @@ at::Tensor scone_occ_draws(c10::IntArrayRef m0, c10::IntArrayRef m1, c10::IntArr
     return out;
 }
 
+// The bin permutation of move_view_state_to_view_space (scone_utils.py:863-931) for a world->view rotation given as a tensor: the same
+// ATen operators in the same order as macarons_amd.utility.scone_utils.view_space_bin_indices / CustomGeometry.get_spherical_coords
+// (so the same bits: torch's own CPU kernels evaluate every element), without ~40 Python dispatcher round trips (200 -> ~60 us on the
+// critical path of a MACARONS decision, whose GPU waits for this host work).  x_ref [n_elev * n_azim, 3] fp32 CPU: the lattice's unit
+// directions; r [3, 3] fp32 CPU.  -> int64 [n_elev * n_azim]
+at::Tensor view_space_bins(const at::Tensor& x_ref, const at::Tensor& r, int64_t n_elev, int64_t n_azim) {
+    TORCH_CHECK(x_ref.device().is_cpu() && r.device().is_cpu() && x_ref.scalar_type() == at::kFloat && r.scalar_type() == at::kFloat,
+                "view_space_bins: CPU fp32 tensors");
+    const double pi = 3.141592653589793;
+    const at::Tensor X = at::matmul(x_ref, r.view({3, 3}).t()).reshape({-1, 3});
+    // get_spherical_coords (CustomGeometry.py:27-45)
+    const at::Tensor r_x = at::linalg_norm(X, c10::nullopt, at::IntArrayRef{1});
+    const at::Tensor x0 = X.select(1, 0), x1 = X.select(1, 1), x2 = X.select(1, 2);
+    const at::Tensor yr = at::div(x1, r_x);
+    at::Tensor elev = at::asin(yr);
+    elev = at::where(at::le(yr, -1), at::full_like(elev, -pi / 2), elev);
+    elev = at::where(at::ge(yr, 1), at::full_like(elev, pi / 2), elev);
+    const at::Tensor q = at::div(x2, at::mul(r_x, at::cos(elev)));
+    at::Tensor azim = at::acos(q);
+    azim = at::where(at::le(q, -1), at::full_like(azim, pi), azim);
+    azim = at::where(at::ge(q, 1), at::zeros_like(azim), azim);
+    azim = at::where(at::lt(x0, 0), at::neg(azim), azim);
+    // view_space_bin_indices (scone_utils.py:901-926)
+    const double elev_step = pi / (double)(n_elev + 1), azim_step = 2 * pi / (double)n_azim;
+    auto fd = [](const at::Tensor& a, double st) { return at::div(at::sub(a, at::remainder(a, st)), st); };     // utils.floor_divide
+    at::Tensor ie = fd(elev, elev_step), ia = fd(azim, azim_step);
+    ie = at::add(ie, at::gt(at::remainder(elev, elev_step), elev_step / 2.).to(ie.scalar_type()));
+    ia = at::add(ia, at::gt(at::remainder(azim, azim_step), azim_step / 2.).to(ia.scalar_type()));
+    ie = at::clamp(ie, -(double)(n_elev / 2), (double)(n_elev / 2));
+    ia = at::where(at::gt(ia, n_azim / 2), at::full_like(ia, -(double)(n_azim / 2)), ia);
+    ie = at::add(ie, n_elev / 2);
+    ia = at::where(at::lt(ia, 0), at::add(ia, n_azim), ia);
+    return at::add(at::mul(ie.to(at::kLong), n_azim), ia.to(at::kLong));
+}
+
 }  // namespace
 
 TORCH_LIBRARY(macarons, m) {
+    m.def("view_space_bins(Tensor x_ref, Tensor r, int n_elev, int n_azim) -> Tensor", &view_space_bins);
     m.def("randperm_prefixes(int[] n, int[] keep) -> Tensor", &randperm_prefixes);
     m.def("scone_occ_draws(int[] m0, int[] m1, int[] m2, int Lg) -> Tensor", &scone_occ_draws);
     m.def("sh_coverage_gain(Tensor pts, Tensor harmonics, Tensor cams, bool use_sigmoid) -> Tensor");

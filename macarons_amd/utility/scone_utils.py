@@ -128,6 +128,22 @@ def view_space_bin_indices(X_cam_inv, n_elev, n_azim):
 
 
 _REF_DIRECTIONS = {}
+_NATIVE_BINS = []
+
+
+def _native_bins():
+    """Is torch.ops.macarons.view_space_bins there (the C++ extension built)?  MCR_NATIVE_BINS=0: the Python restatement (A/B, tests)."""
+    if not _NATIVE_BINS:
+        import os
+        ok = os.environ.get("MCR_NATIVE_BINS", "1") != "0"
+        if ok:
+            try:
+                from .. import torch_ops  # noqa: F401
+                ok = hasattr(torch.ops.macarons, "view_space_bins")
+            except Exception:
+                ok = False
+        _NATIVE_BINS.append(ok)
+    return _NATIVE_BINS[0]
 
 
 def view_space_bin_permutation(fov_camera, n_elev, n_azim, device="cpu"):
@@ -142,7 +158,10 @@ def view_space_bin_permutation(fov_camera, n_elev, n_azim, device="cpu"):
         X_ref = _REF_DIRECTIONS[(n_elev, n_azim)] = get_cartesian_coords(r=torch.ones(n_view, 1), elev=elev.view(-1, 1), azim=azim.view(-1, 1),
                                                                            in_degrees=True)
     if torch.is_tensor(fov_camera):
-        X_inv = X_ref @ fov_camera.detach().to("cpu", torch.float32).view(3, 3).T
+        R = fov_camera.detach().to("cpu", torch.float32)
+        if _native_bins():                              # the same ATen operators from C++ (one dispatcher call instead of ~40: this host work
+            return torch.ops.macarons.view_space_bins(X_ref, R, n_elev, n_azim)     # sits on a MACARONS decision's critical path)
+        X_inv = X_ref @ R.view(3, 3).T
     else:
         X_inv = fov_camera.get_world_to_view_transform().inverse().transform_points(X_ref.to(device)) - fov_camera.get_camera_center()
     return view_space_bin_indices(X_inv.reshape(-1, 3), n_elev, n_azim)

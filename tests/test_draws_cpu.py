@@ -43,3 +43,23 @@ def test_scone_occ_draws_are_draw_perms_job_by_job():
     torch.manual_seed(3)
     got = torch.ops.macarons.scone_occ_draws([s[0] for s in sz], [s[1] for s in sz], [s[2] for s in sz], Lg)
     assert np.array_equal(got.numpy(), want) and torch.equal(torch.randperm(5), after)
+
+
+def test_native_bin_permutation_equals_the_python_restatement():
+    """torch.ops.macarons.view_space_bins (C++: the same ATen operators in the same order, one dispatcher call) returns the bins of
+    scone_utils.view_space_bin_indices for random and for axis-aligned rotations (directions on bin boundaries)."""
+    import torch
+    from macarons_amd.utility import scone_utils as su
+    if not su._native_bins():
+        import pytest
+        pytest.skip("C++ extension not built")
+    torch.manual_seed(5)
+    for n_elev, n_azim in ((7, 14), (5, 10)):
+        for i in range(300):
+            R = torch.linalg.qr(torch.randn(3, 3))[0].float()
+            if i % 5 == 0:
+                R = torch.eye(3)[torch.randperm(3)] * torch.tensor([1., -1., 1.])[torch.randperm(3)]
+            a = su.view_space_bin_permutation(R, n_elev, n_azim, "cpu")
+            x_ref = su._REF_DIRECTIONS[(n_elev, n_azim)]
+            b = su.view_space_bin_indices((x_ref @ R.view(3, 3).T).reshape(-1, 3), n_elev, n_azim)
+            assert torch.equal(a, b), (n_elev, n_azim, i)
