@@ -152,13 +152,15 @@ static void run_encoder_planes(hipStream_t s, const EncW& w, float* x, float* h,
     _Float16* ah = reinterpret_cast<_Float16*>(qkv);                                         // the attention's result as planes [2][T][E]
     static const bool att_planes = []() { const char* e = getenv("MCR_ENC_ATT_PLANES"); return !(e && e[0] == '0'); }();   // (A/B)
     if (att_planes && attention_planes_applicable(H, dqk, E, W3)) {
-        // q | k | v leave the projection as planes [2][T][W3] over qkv (:186-188); the attention stages K / V tiles by DMA (:191-198).  Its
-        // keys are split over two blocks whatever S is (a cloud's result must not depend on how many clouds share the launch): fp32 parts
-        // in h / ff, the combine pass then writes the planes over qkv (dead by then)
+        // q | k | v leave the projection as planes [2][T][W3] over qkv (:186-188); the attention stages K / V tiles by DMA (:191-198) and
+        // writes its result as planes over h (the LayerNorm's, consumed by then).  One block per (query tile, head, sequence) whatever S is
+        // (a cloud's result must not depend on how many clouds share the launch): a batch of clouds saves the combine pass and the fp32
+        // parts of the key-split form (0.23 ms of a MACARONS decision); one cloud alone pays 13 us per attention for it (41 instead of
+        // 23 + 5 us, hidden beside the local transformers in an NBV step).  MCR_ENC_ATT_SPLIT=1: keys over two blocks + combine (A/B)
         _Float16 *qh_ = reinterpret_cast<_Float16*>(qkv), *ql_ = qh_ + (size_t)T * W3;
         launch_linear3p(s, hh, hl, E, Wq, Wq + (size_t)W3 * E, E, w.qkv.b, nullptr, qh_, ql_, W3, T, W3, E, ACT_NONE, inv, nullptr, 0, nullptr);
-        static const int split_mode = []() { const char* e = getenv("MCR_ENC_ATT_SPLIT"); return e ? atoi(e) : 1; }();           // (A/B)
-        if (split_mode == 0) ah = hh;                                                          // unsplit: planes straight from the kernel, over h
+        static const int split_mode = []() { const char* e = getenv("MCR_ENC_ATT_SPLIT"); return e ? atoi(e) : 0; }();
+        if (split_mode == 0) ah = hh;                                                          // (split: the combine pass writes the planes over qkv, dead by then)
         launch_attention_planes(s, qh_, ql_, W3, h, E, ah, ah + (size_t)T * E, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, split_mode);
     } else {
         launch_linear3p(s, hh, hl, E, Wq, Wq + (size_t)W3 * E, E, w.qkv.b, qkv, nullptr, nullptr, W3, T, W3, E, ACT_NONE, inv, nullptr, 0, nullptr);   // :186-188
