@@ -401,8 +401,9 @@ def measure_macarons_step(dev, rank=0, world=1, perm_sources=("host", "device"))
         hit = disc > 0
         tt = (-Bq - np.sqrt(np.where(hit, disc, 0))) / (2 * A)
         hit &= tt > 0
-        cam = mu.SceneCamera(mu.camera_record(Mv, Mv @ Pm, ndc, eye, params.sensor_range).to(dev),
-                             torch.tensor([eye], dtype=torch.float32, device=dev), zfar)
+        # (a pose is host data: the camera's record stays on the host -- the decision uploads it without a stall and does its host-side
+        # geometry on it without a read-back)
+        cam = mu.SceneCamera(mu.camera_record(Mv, Mv @ Pm, ndc, eye, params.sensor_range), torch.tensor([eye], dtype=torch.float32), zfar)
         ne = np.asarray(eye, float) + rng.uniform(-6, 6, (K, 3))
         recs = torch.stack([mu.camera_record(mv_, mv_ @ Pm, ndc, e_, params.sensor_range)
                             for e_, mv_ in ((e_, look_at(e_, np.asarray(at, float) + rng.uniform(-4, 4, 3))[1]) for e_ in ne)]).to(dev)

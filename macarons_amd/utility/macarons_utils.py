@@ -120,10 +120,20 @@ class SceneCamera:
     def __init__(self, record, X_cam, zfar, fov=60.0):
         self.record, self.X_cam, self.zfar = record.reshape(40).contiguous(), X_cam.reshape(1, 3).contiguous(), float(zfar)
         self.fov = torch.tensor([float(fov)])
+        self._m_view_host = self.record[:16].view(4, 4) if self.record.device.type == "cpu" else None
 
     @property
     def M_view(self):
         return self.record[:16].view(4, 4)
+
+    @property
+    def M_view_host(self):
+        """The world->view matrix on the host: the record's own memory when the caller keeps the record on the host (a pose is host
+        data: hand the record over as a CPU tensor and the decision's host-side geometry never waits for the GPU), else ONE read-back
+        per camera object, kept."""
+        if self._m_view_host is None:
+            self._m_view_host = self.record[:16].view(4, 4).cpu()
+        return self._m_view_host
 
 
 def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, depth, depth_mask, neighbor_records, X_neighbors,
@@ -184,8 +194,10 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     # The range check of the fp16-split path (SconeOcc.range_guard) is DEFERRED to one read-back at the very end: checked inside
     # the occupancy pass it stalls the host until the pass has run.  On a set flag steps 3-4 are repeated on the full-range
     # variant with the SAME hidden draws (cell permutations, sampling uniforms).
-    Mv_field = camera.M_view                          # where the caller keeps it: a host matrix is used on the host, uploaded without a stall
-    Mv = ops.h2d(Mv_field, torch.float32, device)
+    # the world->view matrix where the host-side geometry needs it: a record kept on the host costs nothing, a device record ONE
+    # read-back per camera object (a read-back per decision stalled the host behind the fill / selection launches: 0.2-0.3 ms)
+    Mv_field = camera.M_view_host if hasattr(camera, "M_view_host") else camera.M_view
+    Mv = ops.h2d(camera.M_view, torch.float32, device)
     K = neighbor_records.shape[0]
     th = params.distance_factor_th
     smooth = th == 'smooth'
