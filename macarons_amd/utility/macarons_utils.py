@@ -187,7 +187,9 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     else:                                                   # a reference Scene: its own fill (one Python loop over the cells)
         ps.fill_cells(ps.proxy_points[fov_mask], features=idx_f[fov_mask])
     # 2 ---- carve with the depth map: signed distance, view states, supervision occupancy, out-of-field, one launch
-    sgn = ps.update_from_depth(fov_mask, rec, ops.h2d(camera.X_cam, torch.float32, device), depth2, dmask2, fill=1.1 * camera.zfar,
+    x_cam = rec[36:39].view(1, 3) if camera.X_cam.device.type == "cpu" and torch.equal(camera.X_cam.reshape(3), camera.record[36:39]) \
+        else ops.h2d(camera.X_cam, torch.float32, device)    # (a host record carries the centre: one upload instead of two)
+    sgn = ps.update_from_depth(fov_mask, rec, x_cam, depth2, dmask2, fill=1.1 * camera.zfar,
                                tol=params.carving_tolerance, return_signed_distances=return_signed_distances)
     surface_scene.set_all_features_to_value(value=1.)
     # 3 ---- occupancy probability field, in the current camera's view space; 4 ---- neighbours.
@@ -197,7 +199,7 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     # the world->view matrix where the host-side geometry needs it: a record kept on the host costs nothing, a device record ONE
     # read-back per camera object (a read-back per decision stalled the host behind the fill / selection launches: 0.2-0.3 ms)
     Mv_field = camera.M_view_host if hasattr(camera, "M_view_host") else camera.M_view
-    Mv = ops.h2d(camera.M_view, torch.float32, device)
+    Mv = rec[:16].view(4, 4)                          # (the device copy of the record already holds it: no second upload)
     K = neighbor_records.shape[0]
     th = params.distance_factor_th
     smooth = th == 'smooth'
