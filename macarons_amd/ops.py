@@ -3,6 +3,7 @@
 torch is plumbing here: device memory, streams.  Every function validates layout, allocates outputs /
 scratch on the input's device and launches on the current HIP stream.  No CPU fallback.
 """
+import os
 import ctypes
 import torch
 import numpy as np
@@ -683,6 +684,23 @@ def coverage_gain_multiple(pts, harmonics, cams, n_cam, use_sigmoid=True):
 _pinned_pool = {}        # (device index) -> list of [pinned uint8 buffer, event of its last copy]
 
 
+_NATIVE_H2D = []
+
+
+def _native_h2d():
+    """Is torch.ops.macarons.h2d there (the C++ extension built)?  MCR_NATIVE_H2D=0: the Python restatement below (A/B)."""
+    if not _NATIVE_H2D:
+        ok = os.environ.get("MCR_NATIVE_H2D", "1") != "0"
+        if ok:
+            try:
+                from . import torch_ops  # noqa: F401
+                ok = hasattr(torch.ops.macarons, "h2d")
+            except Exception:
+                ok = False
+        _NATIVE_H2D.append(ok)
+    return _NATIVE_H2D[0]
+
+
 def h2d(data, dtype, device):
     """Host data (list / numpy array / CPU tensor) -> device tensor WITHOUT stalling the host: a `.to(device)` from pageable memory
     is a stream-ordered blocking copy, i.e. the host waits for every kernel queued before it (the glue of a MACARONS decision did
@@ -694,6 +712,8 @@ def h2d(data, dtype, device):
     device = torch.device(device)
     if device.type != "cuda" or t.device.type != "cpu":
         return t.to(device)
+    if _native_h2d():                                   # the same steps from C++ (libmacarons_torch.so): one dispatcher call
+        return torch.ops.macarons.h2d(t, device.index if device.index is not None else torch.cuda.current_device())
     t = t.contiguous()
     nbytes = t.numel() * t.element_size()
     if nbytes == 0:
