@@ -408,9 +408,81 @@ at::Tensor h2d(const at::Tensor& src, int64_t device_index) {
     return out;
 }
 
+// The (cell, chunk) job tables of the occupancy-field pass (macarons_utils.compute_scene_occupancy_probability_field; upstream walks the
+// cells in Python, macarons_utils.py:1443-1478) from the counts the decision has just read back -- the ~30 numpy calls of the Python
+// restatement (100 us between the read-back and the first launch behind it, with the GPU idle) as one loop.  Integer work only: the
+// tables are those of the numpy code, element for element (tests/test_draws_cpu.py).
+//   hostc: int64 CPU = [visit (n_cells) | pad | counts (n_cells) | pad | sel_off (n_cells + 2) | n_oof]   (the layout of mcr_field_select)
+//   s_off [n_cells + 1]: the surface store's cell offsets; nbm [n_cells, 27]: neighbour cells, -1 padded; xf_all [n_cells, 20] fp32;
+//   perm int32: the view-space bin permutation
+// -> (raw uint8 = job table [J,4] int64 | segment table [n_seg,4] int64 | xf [J,20] fp32 | perm,
+//     meta int64 = [J, n_seg, T, tot, n_oof | job_q (J) | job_m (J) | q_start (J+1) | m_start (J+1)])
+std::tuple<at::Tensor, at::Tensor> field_jobs(const at::Tensor& hostc, const at::Tensor& s_off, const at::Tensor& nbm, const at::Tensor& xf_all,
+                                              const at::Tensor& perm, int64_t n_cells, int64_t chunk, int64_t k_for_knn) {
+    TORCH_CHECK(hostc.device().is_cpu() && hostc.scalar_type() == at::kLong && hostc.is_contiguous() && hostc.numel() >= 3 * n_cells + 5,
+                "field_jobs: hostc");
+    TORCH_CHECK(s_off.scalar_type() == at::kLong && s_off.numel() == n_cells + 1 && nbm.scalar_type() == at::kLong && nbm.numel() == n_cells * 27 &&
+                xf_all.scalar_type() == at::kFloat && xf_all.numel() == n_cells * 20 && perm.scalar_type() == at::kInt && chunk > 0,
+                "field_jobs: table shapes");
+    const int64_t* hc = hostc.data_ptr<int64_t>();
+    const int64_t *visit = hc, *counts = hc + n_cells + 1, *sel_off = hc + 2 * n_cells + 2;
+    const int64_t n_oof = hc[3 * n_cells + 4];
+    const at::Tensor s_off_c = s_off.contiguous(), nbm_c = nbm.contiguous(), xf_c = xf_all.contiguous(), perm_c = perm.contiguous();
+    const int64_t *so = s_off_c.data_ptr<int64_t>(), *nb = nbm_c.data_ptr<int64_t>();
+    std::vector<int64_t> m_cell(n_cells, 0);
+    for (int64_t c = 0; c < n_cells; ++c)
+        for (int k = 0; k < 27; ++k) {
+            const int64_t q = nb[c * 27 + k];
+            if (q >= 0) m_cell[c] += so[q + 1] - so[q];
+        }
+    std::vector<int64_t> job_cell, job_lo;
+    for (int64_t c = 0; c < n_cells; ++c)
+        if (visit[c] != 0 && m_cell[c] > 2 * 2 * k_for_knn && counts[c] > 0)                       // :1455-1456
+            for (int64_t lo = 0; lo < counts[c]; lo += chunk) { job_cell.push_back(c); job_lo.push_back(lo); }
+    const int64_t J = (int64_t)job_cell.size();
+    int64_t n_seg = 0;
+    for (int64_t j = 0; j < J; ++j)
+        for (int k = 0; k < 27; ++k) {
+            const int64_t q = nb[job_cell[j] * 27 + k];
+            n_seg += q >= 0 && so[q + 1] - so[q] > 0;
+        }
+    at::Tensor meta = at::empty({5 + 2 * J + 2 * (J + 1)}, at::kLong);
+    int64_t* me = meta.data_ptr<int64_t>();
+    int64_t *job_q = me + 5, *job_m = job_q + J, *q_start = job_m + J, *m_start = q_start + J + 1;
+    const int64_t perm_bytes = perm_c.numel() * 4;
+    at::Tensor raw = at::empty({32 * (J + n_seg) + 80 * J + perm_bytes}, at::kByte);
+    int64_t* jt = reinterpret_cast<int64_t*>(raw.data_ptr<uint8_t>());
+    int64_t* st = jt + 4 * J;
+    float* xf = reinterpret_cast<float*>(st + 4 * n_seg);
+    q_start[0] = m_start[0] = 0;
+    int64_t seg = 0, seg_dst = 0;
+    const float* xa = xf_c.data_ptr<float>();
+    for (int64_t j = 0; j < J; ++j) {
+        const int64_t c = job_cell[j];
+        job_q[j] = std::min<int64_t>(chunk, counts[c] - job_lo[j]);
+        job_m[j] = m_cell[c];
+        q_start[j + 1] = q_start[j] + job_q[j];
+        m_start[j + 1] = m_start[j] + job_m[j];
+        jt[4 * j] = sel_off[c] + job_lo[j]; jt[4 * j + 1] = q_start[j]; jt[4 * j + 2] = m_start[j]; jt[4 * j + 3] = 0;
+        for (int k = 0; k < 27; ++k) {                                                            // its cell's non-empty neighbours, ascending
+            const int64_t q = nb[c * 27 + k];
+            if (q < 0) continue;
+            const int64_t len = so[q + 1] - so[q];
+            if (len <= 0) continue;
+            st[4 * seg] = so[q]; st[4 * seg + 1] = seg_dst; st[4 * seg + 2] = j; st[4 * seg + 3] = 0;
+            seg_dst += len; ++seg;
+        }
+        std::memcpy(xf + 20 * j, xa + 20 * c, 80);
+    }
+    std::memcpy(reinterpret_cast<uint8_t*>(xf + 20 * J), perm_c.data_ptr<int>(), perm_bytes);
+    me[0] = J; me[1] = n_seg; me[2] = q_start[J]; me[3] = m_start[J]; me[4] = n_oof;
+    return {raw, meta};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(macarons, m) {
+    m.def("field_jobs(Tensor hostc, Tensor s_off, Tensor nbm, Tensor xf_all, Tensor perm, int n_cells, int chunk, int k_for_knn) -> (Tensor, Tensor)", &field_jobs);
     m.def("h2d(Tensor src, int device) -> Tensor", &h2d);
     m.def("view_space_bins(Tensor x_ref, Tensor r, int n_elev, int n_azim) -> Tensor", &view_space_bins);
     m.def("randperm_prefixes(int[] n, int[] keep) -> Tensor", &randperm_prefixes);

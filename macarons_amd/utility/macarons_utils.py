@@ -432,7 +432,8 @@ def _grid_tables(scene, device):
     nbm = np.full((n_cells, 27), -1, np.int64)            # the 27-neighbourhoods as a padded matrix (ascending ids, -1 = none)
     for c, l_ in enumerate(nbl):
         nbm[c, :len(l_)] = l_
-    tab = {"device": str(device), "keys": keys, "lin_of": lin_of, "neighbours": nbl, "neighbour_matrix": nbm, "centers": centers,
+    tab = {"device": str(device), "keys": keys, "lin_of": lin_of, "neighbours": nbl, "neighbour_matrix": nbm,
+           "neighbour_matrix_t": torch.from_numpy(nbm), "centers": centers,
            "diag": diag, "centers_host": centers.cpu(), "diag_host": diag.cpu()}
     try:
         scene._mcr_grid_tables = tab
@@ -517,6 +518,24 @@ def _vh_matrix_t(params, device):
     return m
 
 
+_NATIVE_FIELD_JOBS = []
+
+
+def _native_field_jobs():
+    """Is torch.ops.macarons.field_jobs there (the C++ extension built)?  MCR_NATIVE_FIELD_JOBS=0: the numpy restatement (A/B, tests)."""
+    if not _NATIVE_FIELD_JOBS:
+        import os
+        ok = os.environ.get("MCR_NATIVE_FIELD_JOBS", "1") != "0"
+        if ok:
+            try:
+                from .. import torch_ops  # noqa: F401
+                ok = hasattr(torch.ops.macarons, "field_jobs")
+            except Exception:
+                ok = False
+        _NATIVE_FIELD_JOBS.append(ok)
+    return _NATIVE_FIELD_JOBS[0]
+
+
 def _field_prepare(params, proxy_scene, prediction_camera, device):
     """Host work of the field pass that does not depend on the selection's counts (so that macarons_nbv_decision can do it while the
     GPU still works towards the read-back): the world->view matrix on the host, every cell's prediction-box transform
@@ -529,10 +548,11 @@ def _field_prepare(params, proxy_scene, prediction_camera, device):
     n = cw.shape[0]
     cen_h = (torch.cat((cw, torch.ones(n, 1)), 1) @ Mv_host)[:, :3]
     inv_h = (1.0 / (params.prediction_neighborhood_size * dg)).float()
-    xf_all = torch.cat((Mv_host.reshape(1, 16).expand(n, -1), cen_h, inv_h.view(n, 1)), 1).contiguous().numpy()
-    perm = su.view_space_bin_permutation((Mv_host[:3, :3].contiguous() if torch.is_tensor(prediction_camera) else prediction_camera),
-                                         params.view_state_n_elev, params.view_state_n_azim, device).numpy().astype(np.int32)
-    return {"tab": tab, "xf_all": xf_all, "perm": perm, "vh_mt": _vh_matrix_t(params, device)}
+    xf_all_t = torch.cat((Mv_host.reshape(1, 16).expand(n, -1), cen_h, inv_h.view(n, 1)), 1).contiguous()
+    perm_t = su.view_space_bin_permutation((Mv_host[:3, :3].contiguous() if torch.is_tensor(prediction_camera) else prediction_camera),
+                                           params.view_state_n_elev, params.view_state_n_azim, device).to(torch.int32)
+    return {"tab": tab, "xf_all": xf_all_t.numpy(), "perm": perm_t.numpy(), "xf_all_t": xf_all_t, "perm_t": perm_t,
+            "vh_mt": _vh_matrix_t(params, device)}
 
 
 def compute_scene_occupancy_probability_field(params, macarons, camera, surface_scene, proxy_scene, device,
@@ -595,16 +615,28 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
         for i_, k in enumerate(s_keys):
             s_len[lin_of[k]] = s_st.off[i_ + 1] - s_st.off[i_]; s_start[lin_of[k]] = s_st.off[i_]
     nbm = tab["neighbour_matrix"]                        # [n_cells, 27], -1 padded
-    nb_len = np.where(nbm >= 0, s_len[np.maximum(nbm, 0)], 0)              # surface points of every neighbour cell
-    m_cell = nb_len.sum(1)
-    run = (np.asarray(visit) != 0) & (m_cell > 2 * 2 * params.k_for_knn) & (np.asarray(counts) > 0)       # :1455-1456
-    cells_run = np.nonzero(run)[0]
-    n_chunks = -(-np.asarray(counts)[cells_run] // chunk)
-    job_cell = np.repeat(cells_run, n_chunks)                              # one job per (cell, chunk of <= 20 000 queries)
-    J = int(job_cell.size)
+    native = len(s_keys) == n_cells and _native_field_jobs()
+    if native:
+        # the job tables by ONE C++ call (torch.ops.macarons.field_jobs: the loop form of the numpy code below, same tables element for
+        # element) -- this host work sits between the decision's read-back and the first launch behind it, with the GPU idle
+        raw_t, meta_t = torch.ops.macarons.field_jobs(torch.from_numpy(np.ascontiguousarray(hostc)), torch.from_numpy(np.ascontiguousarray(s_st.off)),
+                                                      tab["neighbour_matrix_t"], prep["xf_all_t"], prep["perm_t"], n_cells, int(chunk),
+                                                      int(params.k_for_knn))
+        meta = meta_t.numpy()
+        J, n_seg, T, tot = int(meta[0]), int(meta[1]), int(meta[2]), int(meta[3])
+        job_q, job_m = meta[5:5 + J], meta[5 + J:5 + 2 * J]
+        q_start, m_start = meta[5 + 2 * J:6 + 3 * J], meta[6 + 3 * J:7 + 4 * J]
+    else:
+        nb_len = np.where(nbm >= 0, s_len[np.maximum(nbm, 0)], 0)          # surface points of every neighbour cell
+        m_cell = nb_len.sum(1)
+        run = (np.asarray(visit) != 0) & (m_cell > 2 * 2 * params.k_for_knn) & (np.asarray(counts) > 0)       # :1455-1456
+        cells_run = np.nonzero(run)[0]
+        n_chunks = -(-np.asarray(counts)[cells_run] // chunk)
+        job_cell = np.repeat(cells_run, n_chunks)                          # one job per (cell, chunk of <= 20 000 queries)
+        J = int(job_cell.size)
+        T = tot = 0
     P = ps.proxy_points.shape[0]
-    T = tot = 0
-    if J:
+    if J and not native:
         lo = (np.arange(J) - np.repeat(np.cumsum(n_chunks) - n_chunks, n_chunks)) * chunk
         job_q = np.minimum(chunk, np.asarray(counts)[job_cell] - lo).astype(np.int64)
         job_m = m_cell[job_cell].astype(np.int64)
@@ -627,11 +659,14 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
     if J:
         # ---- ONE upload: job table, segment table, per-job transform (world->view matrix, box centre in view space, 1 / (neighbourhood
         # size x cell diagonal), :1468-1478), the bin permutation of move_view_state_to_view_space (:863-931)
-        xf = np.ascontiguousarray(prep["xf_all"][job_cell])
-        raw = np.concatenate((jt.reshape(-1).view(np.uint8), st_.reshape(-1).view(np.uint8), xf.reshape(-1).view(np.uint8),
-                              prep["perm"].view(np.uint8)))
-        tables = ops.h2d(raw, torch.uint8, device)
-        n_seg = int(st_.shape[0])
+        if native:
+            tables = ops.h2d(raw_t, torch.uint8, device)
+        else:
+            xf = np.ascontiguousarray(prep["xf_all"][job_cell])
+            raw = np.concatenate((jt.reshape(-1).view(np.uint8), st_.reshape(-1).view(np.uint8), xf.reshape(-1).view(np.uint8),
+                                  prep["perm"].view(np.uint8)))
+            tables = ops.h2d(raw, torch.uint8, device)
+            n_seg = int(st_.shape[0])
         perm_d = tables[32 * (J + n_seg) + 80 * J:].view(torch.int32)
         rows, row_job, X_q, pc_all = ops.field_build(tables, J, n_seg, sel, ps.proxy_points, s_st.pts, ps.view_states, perm_d,
                                                      prep["vh_mt"], T, tot, X_world, view_harmonics)

@@ -63,3 +63,61 @@ def test_native_bin_permutation_equals_the_python_restatement():
             x_ref = su._REF_DIRECTIONS[(n_elev, n_azim)]
             b = su.view_space_bin_indices((x_ref @ R.view(3, 3).T).reshape(-1, 3), n_elev, n_azim)
             assert torch.equal(a, b), (n_elev, n_azim, i)
+
+
+def test_native_field_jobs_equal_the_numpy_tables():
+    """torch.ops.macarons.field_jobs (C++ loop) builds the (cell, chunk) job tables of the occupancy-field pass element for element
+    as the numpy restatement in macarons_utils.compute_scene_occupancy_probability_field does: random grids, empty cells, cells that
+    do not run (too few surface points, no queries, never visited), several chunks per cell."""
+    import numpy as np
+    import torch
+    from macarons_amd.utility import macarons_utils as mu
+    if not mu._native_field_jobs():
+        import pytest
+        pytest.skip("C++ extension not built")
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        n_cells = int(rng.integers(1, 80))
+        chunk = int(rng.choice([7, 50, 20000]))
+        k = int(rng.choice([1, 16]))
+        visit = (rng.random(n_cells) < 0.7).astype(np.int64)
+        counts = (rng.integers(0, 300, n_cells) * (rng.random(n_cells) < 0.8)).astype(np.int64)
+        sel_off = np.concatenate(([0], np.cumsum(counts), [counts.sum()])).astype(np.int64)        # n_cells + 2 entries
+        n_oof = int(rng.integers(0, 50))
+        hostc = np.concatenate((visit, [0], counts, [0], sel_off, [n_oof])).astype(np.int64)
+        s_len = (rng.integers(0, 400, n_cells) * (rng.random(n_cells) < 0.7)).astype(np.int64)
+        s_off = np.concatenate(([0], np.cumsum(s_len))).astype(np.int64)
+        nbm = np.full((n_cells, 27), -1, np.int64)
+        for c in range(n_cells):
+            nb = np.unique(rng.integers(0, n_cells, int(rng.integers(1, 28))))
+            nbm[c, :nb.size] = nb
+        xf_all = rng.standard_normal((n_cells, 20)).astype(np.float32)
+        perm = rng.permutation(98).astype(np.int32)
+        raw_t, meta_t = torch.ops.macarons.field_jobs(torch.from_numpy(hostc), torch.from_numpy(s_off), torch.from_numpy(nbm),
+                                                      torch.from_numpy(xf_all), torch.from_numpy(perm), n_cells, chunk, k)
+        meta = meta_t.numpy()
+        # ---- the numpy restatement (macarons_utils.py)
+        s_start = s_off[:-1]
+        nb_len = np.where(nbm >= 0, s_len[np.maximum(nbm, 0)], 0)
+        m_cell = nb_len.sum(1)
+        run = (visit != 0) & (m_cell > 2 * 2 * k) & (counts > 0)
+        cells_run = np.nonzero(run)[0]
+        n_chunks = -(-counts[cells_run] // chunk)
+        job_cell = np.repeat(cells_run, n_chunks)
+        J = int(job_cell.size)
+        lo = (np.arange(J) - np.repeat(np.cumsum(n_chunks) - n_chunks, n_chunks)) * chunk
+        job_q = np.minimum(chunk, counts[job_cell] - lo).astype(np.int64)
+        job_m = m_cell[job_cell].astype(np.int64)
+        q_start = np.concatenate(([0], np.cumsum(job_q))).astype(np.int64)
+        m_start = np.concatenate(([0], np.cumsum(job_m))).astype(np.int64)
+        jt = np.stack((sel_off[job_cell] + lo, q_start[:-1], m_start[:-1], np.zeros(J, np.int64)), 1).astype(np.int64) if J else np.zeros((0, 4), np.int64)
+        seg_len = nb_len[job_cell]
+        keep = seg_len > 0
+        seg_l = seg_len[keep]
+        st_ = np.stack((s_start[nbm[job_cell][keep]], np.cumsum(seg_l) - seg_l, np.nonzero(keep)[0], np.zeros(seg_l.size, np.int64)), 1).astype(np.int64)
+        raw = np.concatenate((jt.reshape(-1).view(np.uint8), st_.reshape(-1).view(np.uint8),
+                              np.ascontiguousarray(xf_all[job_cell]).reshape(-1).view(np.uint8), perm.view(np.uint8)))
+        assert int(meta[0]) == J and int(meta[1]) == st_.shape[0] and int(meta[2]) == int(q_start[-1]) and int(meta[3]) == int(m_start[-1]) and int(meta[4]) == n_oof
+        assert np.array_equal(meta[5:5 + J], job_q) and np.array_equal(meta[5 + J:5 + 2 * J], job_m)
+        assert np.array_equal(meta[5 + 2 * J:6 + 3 * J], q_start) and np.array_equal(meta[6 + 3 * J:7 + 4 * J], m_start)
+        assert np.array_equal(raw_t.numpy(), raw), trial
