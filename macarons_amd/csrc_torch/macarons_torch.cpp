@@ -479,9 +479,34 @@ std::tuple<at::Tensor, at::Tensor> field_jobs(const at::Tensor& hostc, const at:
     return {raw, meta};
 }
 
+// The host tables SconeOcc.forward_ragged uploads before its first launch, as one loop instead of a dozen numpy calls:
+//   [ off0 (J+1): cloud offsets | blocks (n_blocks x 4): (job, first query row, rows <= rows_per_block, 0) | row_job (T, optional) ]  int64
+at::Tensor ragged_tables(c10::IntArrayRef cloud_sizes, c10::IntArrayRef query_sizes, int64_t rows_per_block, bool with_row_job) {
+    const int64_t J = (int64_t)cloud_sizes.size();
+    TORCH_CHECK((int64_t)query_sizes.size() == J && rows_per_block > 0, "ragged_tables: one (cloud, query) size per job");
+    int64_t nb = 0, T = 0;
+    for (int64_t j = 0; j < J; ++j) { nb += (query_sizes[j] + rows_per_block - 1) / rows_per_block; T += query_sizes[j]; }
+    at::Tensor out = at::empty({J + 1 + 4 * nb + (with_row_job ? T : 0)}, at::kLong);
+    int64_t* off0 = out.data_ptr<int64_t>();
+    int64_t* blk = off0 + J + 1;
+    int64_t* rj = blk + 4 * nb;
+    off0[0] = 0;
+    int64_t q0 = 0, b = 0;
+    for (int64_t j = 0; j < J; ++j) {
+        off0[j + 1] = off0[j] + cloud_sizes[j];
+        for (int64_t r = 0; r < query_sizes[j]; r += rows_per_block, ++b) {
+            blk[4 * b] = j; blk[4 * b + 1] = q0 + r; blk[4 * b + 2] = std::min<int64_t>(rows_per_block, query_sizes[j] - r); blk[4 * b + 3] = 0;
+        }
+        if (with_row_job) std::fill(rj + q0, rj + q0 + query_sizes[j], j);
+        q0 += query_sizes[j];
+    }
+    return out;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(macarons, m) {
+    m.def("ragged_tables(int[] cloud_sizes, int[] query_sizes, int rows_per_block, bool with_row_job) -> Tensor", &ragged_tables);
     m.def("field_jobs(Tensor hostc, Tensor s_off, Tensor nbm, Tensor xf_all, Tensor perm, int n_cells, int chunk, int k_for_knn) -> (Tensor, Tensor)", &field_jobs);
     m.def("h2d(Tensor src, int device) -> Tensor", &h2d);
     m.def("view_space_bins(Tensor x_ref, Tensor r, int n_elev, int n_azim) -> Tensor", &view_space_bins);

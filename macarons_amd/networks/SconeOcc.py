@@ -40,6 +40,24 @@ class XEmbedding(nn.Module):
         return ops.linear(res, _f32c(self.linear3.weight), _f32c(self.linear3.bias), gelu=True)
 
 
+_NATIVE_RAGGED = []
+
+
+def _native_ragged_tables():
+    """Is torch.ops.macarons.ragged_tables there (the C++ extension built)?  MCR_NATIVE_RAGGED_TABLES=0: the numpy restatement (A/B, tests)."""
+    if not _NATIVE_RAGGED:
+        import os
+        ok = os.environ.get("MCR_NATIVE_RAGGED_TABLES", "1") != "0"
+        if ok:
+            try:
+                from .. import torch_ops  # noqa: F401
+                ok = hasattr(torch.ops.macarons, "ragged_tables")
+            except Exception:
+                ok = False
+        _NATIVE_RAGGED.append(ok)
+    return _NATIVE_RAGGED[0]
+
+
 class PCTransformer(nn.Module):
     """SconeOcc.py:45-130."""
 
@@ -284,21 +302,28 @@ class SconeOcc(RangeGuard, nn.Module):
         Lg = self.seq_len
         pc = pc.contiguous()
         variant = ops.current_variant()
-        off0 = np.concatenate(([0], np.cumsum(cloud_sizes))).astype(np.int64)
         rows = int(L.mcr_knn_rows_per_block())
-        qs = np.asarray(query_sizes, np.int64)
-        q0 = np.concatenate(([0], np.cumsum(qs)))
-        nb = -(-qs // rows)                                              # query blocks per job
-        bj = np.repeat(np.arange(J, dtype=np.int64), nb)                 # job of every block
-        b_in = np.arange(int(nb.sum()), dtype=np.int64) - np.repeat(np.cumsum(nb) - nb, nb)     # block index inside its job
-        blocks = np.stack((bj, q0[bj] + b_in * rows, np.minimum(rows, qs[bj] - b_in * rows), np.zeros_like(bj)), 1)
-        parts = [off0, blocks.reshape(-1)]
-        if row_job is None:
-            parts.append(np.repeat(np.arange(J, dtype=np.int64), qs))
-        early = ops.h2d(np.concatenate(parts), torch.int64, dev)
+        if _native_ragged_tables():                                      # one C++ loop (this runs in front of the pass's first launch)
+            host = torch.ops.macarons.ragged_tables([int(m) for m in cloud_sizes], [int(q) for q in query_sizes], rows, row_job is None)
+            n_blk4 = host.numel() - (J + 1) - (sum(int(q) for q in query_sizes) if row_job is None else 0)
+            off0 = host[:J + 1].numpy()
+            early = ops.h2d(host, torch.int64, dev)
+        else:
+            off0 = np.concatenate(([0], np.cumsum(cloud_sizes))).astype(np.int64)
+            qs = np.asarray(query_sizes, np.int64)
+            q0 = np.concatenate(([0], np.cumsum(qs)))
+            nb = -(-qs // rows)                                              # query blocks per job
+            bj = np.repeat(np.arange(J, dtype=np.int64), nb)                 # job of every block
+            b_in = np.arange(int(nb.sum()), dtype=np.int64) - np.repeat(np.cumsum(nb) - nb, nb)     # block index inside its job
+            blocks = np.stack((bj, q0[bj] + b_in * rows, np.minimum(rows, qs[bj] - b_in * rows), np.zeros_like(bj)), 1)
+            parts = [off0, blocks.reshape(-1)]
+            if row_job is None:
+                parts.append(np.repeat(np.arange(J, dtype=np.int64), qs))
+            early = ops.h2d(np.concatenate(parts), torch.int64, dev)
+            n_blk4 = blocks.size
         d_off0 = early[:J + 1]
-        d_blocks = early[J + 1:J + 1 + blocks.size].to(torch.int32).view(-1, 4)
-        d_row_job = early[J + 1 + blocks.size:].to(torch.int32) if row_job is None else row_job
+        d_blocks = early[J + 1:J + 1 + n_blk4].to(torch.int32).view(-1, 4)
+        d_row_job = early[J + 1 + n_blk4:].to(torch.int32) if row_job is None else row_job
         state = {}
 
         def caches(v):

@@ -121,3 +121,25 @@ def test_native_field_jobs_equal_the_numpy_tables():
         assert np.array_equal(meta[5:5 + J], job_q) and np.array_equal(meta[5 + J:5 + 2 * J], job_m)
         assert np.array_equal(meta[5 + 2 * J:6 + 3 * J], q_start) and np.array_equal(meta[6 + 3 * J:7 + 4 * J], m_start)
         assert np.array_equal(raw_t.numpy(), raw), trial
+
+
+def test_native_ragged_tables_equal_the_numpy_tables():
+    """torch.ops.macarons.ragged_tables == the numpy tables of SconeOcc.forward_ragged_begin (cloud offsets, query blocks, row -> job)."""
+    import numpy as np
+    import torch
+    import importlib
+    so = importlib.import_module("macarons_amd.networks.SconeOcc")     # (the package re-exports the CLASS under the module's name)
+    if not so._native_ragged_tables():
+        import pytest
+        pytest.skip("C++ extension not built")
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        J = int(rng.integers(1, 30)); cs = rng.integers(16, 5000, J).tolist(); qs = rng.integers(0, 900, J).tolist(); rows = int(rng.choice([64, 128]))
+        for wr in (True, False):
+            a = torch.ops.macarons.ragged_tables(cs, qs, rows, wr).numpy()
+            off0 = np.concatenate(([0], np.cumsum(cs))).astype(np.int64); q = np.asarray(qs, np.int64); q0 = np.concatenate(([0], np.cumsum(q)))
+            nb = -(-q // rows); bj = np.repeat(np.arange(J, dtype=np.int64), nb)
+            b_in = np.arange(int(nb.sum()), dtype=np.int64) - np.repeat(np.cumsum(nb) - nb, nb)
+            blocks = np.stack((bj, q0[bj] + b_in * rows, np.minimum(rows, q[bj] - b_in * rows), np.zeros_like(bj)), 1)
+            parts = [off0, blocks.reshape(-1)] + ([np.repeat(np.arange(J, dtype=np.int64), q)] if wr else [])
+            assert np.array_equal(a, np.concatenate(parts))
