@@ -503,9 +503,27 @@ at::Tensor ragged_tables(c10::IntArrayRef cloud_sizes, c10::IntArrayRef query_si
     return out;
 }
 
+// The count-independent host geometry of the occupancy-field pass (macarons_utils._field_prepare) as ONE call: every cell's
+// prediction-box transform (world->view matrix | box centre in view space | 1 / (neighbourhood size x cell diagonal); :1468-1478) and
+// the view-space bin permutation -- the same ATen operators in the same order as the Python restatement (same bits), callable from a
+// worker thread (the dispatcher releases the GIL) while the main thread queues the decision's first launches.
+std::tuple<at::Tensor, at::Tensor> field_prepare(const at::Tensor& mv, const at::Tensor& centers, const at::Tensor& diag, const at::Tensor& x_ref,
+                                                 double pns, int64_t n_elev, int64_t n_azim) {
+    TORCH_CHECK(mv.device().is_cpu() && mv.scalar_type() == at::kFloat && mv.numel() == 16 && centers.device().is_cpu() && diag.device().is_cpu(),
+                "field_prepare: CPU fp32 tensors");
+    const at::Tensor M = mv.reshape({4, 4});
+    const int64_t n = centers.size(0);
+    const at::Tensor cen_h = at::matmul(at::cat({centers, at::ones({n, 1}, centers.options())}, 1), M).slice(1, 0, 3);
+    const at::Tensor inv_h = at::mul(at::reciprocal(at::mul(diag, pns)), 1.0).to(at::kFloat);
+    const at::Tensor xf_all = at::cat({M.reshape({1, 16}).expand({n, -1}), cen_h, inv_h.view({n, 1})}, 1).contiguous();
+    const at::Tensor perm = view_space_bins(x_ref, M.slice(0, 0, 3).slice(1, 0, 3).contiguous(), n_elev, n_azim).to(at::kInt);
+    return {xf_all, perm};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(macarons, m) {
+    m.def("field_prepare(Tensor mv, Tensor centers, Tensor diag, Tensor x_ref, float pns, int n_elev, int n_azim) -> (Tensor, Tensor)", &field_prepare);
     m.def("ragged_tables(int[] cloud_sizes, int[] query_sizes, int rows_per_block, bool with_row_job) -> Tensor", &ragged_tables);
     m.def("field_jobs(Tensor hostc, Tensor s_off, Tensor nbm, Tensor xf_all, Tensor perm, int n_cells, int chunk, int k_for_knn) -> (Tensor, Tensor)", &field_jobs);
     m.def("h2d(Tensor src, int device) -> Tensor", &h2d);

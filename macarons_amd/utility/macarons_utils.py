@@ -546,6 +546,15 @@ def _field_prepare(params, proxy_scene, prediction_camera, device):
     Mv_host = Mv_any.detach().to("cpu", torch.float32).reshape(4, 4)    # (a device matrix is read back here)
     cw, dg = tab["centers_host"], tab["diag_host"]
     n = cw.shape[0]
+    if torch.is_tensor(prediction_camera) and _native_field_jobs() and hasattr(torch.ops.macarons, "field_prepare"):
+        # the same ATen operators from ONE C++ call (bit-identical; tests/test_draws_cpu.py)
+        su.view_space_bin_permutation(torch.eye(3), params.view_state_n_elev, params.view_state_n_azim) \
+            if (params.view_state_n_elev, params.view_state_n_azim) not in su._REF_DIRECTIONS else None
+        xf_all_t, perm_t = torch.ops.macarons.field_prepare(Mv_host, cw, dg, su._REF_DIRECTIONS[(params.view_state_n_elev, params.view_state_n_azim)],
+                                                            float(params.prediction_neighborhood_size), params.view_state_n_elev,
+                                                            params.view_state_n_azim)
+        return {"tab": tab, "xf_all": xf_all_t.numpy(), "perm": perm_t.numpy(), "xf_all_t": xf_all_t, "perm_t": perm_t,
+                "vh_mt": _vh_matrix_t(params, device)}
     cen_h = (torch.cat((cw, torch.ones(n, 1)), 1) @ Mv_host)[:, :3]
     inv_h = (1.0 / (params.prediction_neighborhood_size * dg)).float()
     xf_all_t = torch.cat((Mv_host.reshape(1, 16).expand(n, -1), cen_h, inv_h.view(n, 1)), 1).contiguous()

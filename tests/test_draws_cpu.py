@@ -143,3 +143,29 @@ def test_native_ragged_tables_equal_the_numpy_tables():
             blocks = np.stack((bj, q0[bj] + b_in * rows, np.minimum(rows, q[bj] - b_in * rows), np.zeros_like(bj)), 1)
             parts = [off0, blocks.reshape(-1)] + ([np.repeat(np.arange(J, dtype=np.int64), q)] if wr else [])
             assert np.array_equal(a, np.concatenate(parts))
+
+
+def test_native_field_prepare_equals_the_python_restatement():
+    """torch.ops.macarons.field_prepare (the cells' prediction-box transforms + the view-space bin permutation in one C++ call over the
+    same ATen operators) == macarons_utils._field_prepare's tensor code, bit for bit."""
+    import torch
+    from macarons_amd.utility import scone_utils as su, macarons_utils as mu
+    if not (mu._native_field_jobs() and hasattr(torch.ops.macarons, "field_prepare")):
+        import pytest
+        pytest.skip("C++ extension not built")
+    torch.manual_seed(1)
+    su.view_space_bin_permutation(torch.eye(3), 7, 14, "cpu")
+    x_ref = su._REF_DIRECTIONS[(7, 14)]
+    for i in range(200):
+        R = torch.linalg.qr(torch.randn(3, 3))[0].float()
+        if i % 5 == 0:
+            R = torch.eye(3)[torch.randperm(3)] * torch.tensor([1., -1., 1.])[torch.randperm(3)]
+        Mv = torch.eye(4); Mv[:3, :3] = R; Mv[3, :3] = torch.randn(3) * 20
+        n = int(torch.randint(1, 100, (1,)))
+        cw, dg, pns = torch.randn(n, 3) * 10, torch.rand(n) * 5 + 1, 1.5
+        a, b = torch.ops.macarons.field_prepare(Mv, cw, dg, x_ref, pns, 7, 14)
+        cen_h = (torch.cat((cw, torch.ones(n, 1)), 1) @ Mv)[:, :3]
+        inv_h = (1.0 / (pns * dg)).float()
+        xf = torch.cat((Mv.reshape(1, 16).expand(n, -1), cen_h, inv_h.view(n, 1)), 1).contiguous()
+        perm = su.view_space_bin_indices((x_ref @ Mv[:3, :3].contiguous().view(3, 3).T).reshape(-1, 3), 7, 14).to(torch.int32)
+        assert torch.equal(a, xf) and torch.equal(b, perm), i
