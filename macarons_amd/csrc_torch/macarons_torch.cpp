@@ -15,9 +15,15 @@
 #include <algorithm>
 #include <limits>
 #include <optional>
+#include <set>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <exception>
+#include <functional>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -520,9 +526,79 @@ std::tuple<at::Tensor, at::Tensor> field_prepare(const at::Tensor& mv, const at:
     return {xf_all, perm};
 }
 
+// field_prepare on a worker thread of this library (no Python, no GIL): field_prepare_async queues the job and returns a ticket at once,
+// field_prepare_wait hands the result over (blocking until it is there; an exception of the job is rethrown here).  The decision starts
+// the job before its first launch and collects it in front of the read-back: ~170 us of host geometry off its critical path.
+struct PrepWorker {
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::deque<std::pair<int64_t, std::function<std::tuple<at::Tensor, at::Tensor>()>>> jobs;
+    std::map<int64_t, std::tuple<at::Tensor, at::Tensor>> results;
+    std::map<int64_t, std::exception_ptr> errors;
+    std::set<int64_t> open;                                               // tickets handed out and not collected yet
+    int64_t next_ticket = 1;
+    std::thread th;
+    bool started = false;
+    void run() {
+        c10::InferenceMode no_grad;
+        for (;;) {
+            std::pair<int64_t, std::function<std::tuple<at::Tensor, at::Tensor>()>> job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return !jobs.empty(); });
+                job = std::move(jobs.front());
+                jobs.pop_front();
+            }
+            std::tuple<at::Tensor, at::Tensor> out;
+            std::exception_ptr err;
+            try { out = job.second(); } catch (...) { err = std::current_exception(); }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (err) errors[job.first] = err; else results[job.first] = std::move(out);
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
+PrepWorker& prep_worker() {
+    static PrepWorker* w = new PrepWorker();                               // (never destroyed: the thread outlives static teardown)
+    return *w;
+}
+
+int64_t field_prepare_async(const at::Tensor& mv, const at::Tensor& centers, const at::Tensor& diag, const at::Tensor& x_ref,
+                            double pns, int64_t n_elev, int64_t n_azim) {
+    PrepWorker& w = prep_worker();
+    std::lock_guard<std::mutex> lk(w.mu);
+    if (!w.started) { w.th = std::thread([&w] { w.run(); }); w.th.detach(); w.started = true; }
+    const int64_t ticket = w.next_ticket++;
+    w.open.insert(ticket);
+    const at::Tensor a = mv.detach().clone(), b = centers, c = diag, d = x_ref;      // (mv may be a view of a record the caller rewrites)
+    w.jobs.emplace_back(ticket, [a, b, c, d, pns, n_elev, n_azim] { return field_prepare(a, b, c, d, pns, n_elev, n_azim); });
+    w.cv_job.notify_one();
+    return ticket;
+}
+
+std::tuple<at::Tensor, at::Tensor> field_prepare_wait(int64_t ticket) {
+    PrepWorker& w = prep_worker();
+    std::unique_lock<std::mutex> lk(w.mu);
+    TORCH_CHECK(w.open.erase(ticket) == 1, "field_prepare_wait: unknown or already collected ticket ", ticket);
+    w.cv_done.wait(lk, [&] { return w.results.count(ticket) || w.errors.count(ticket); });
+    if (w.errors.count(ticket)) {
+        std::exception_ptr e = w.errors[ticket];
+        w.errors.erase(ticket);
+        std::rethrow_exception(e);
+    }
+    std::tuple<at::Tensor, at::Tensor> out = std::move(w.results[ticket]);
+    w.results.erase(ticket);
+    return out;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(macarons, m) {
+    m.def("field_prepare_async(Tensor mv, Tensor centers, Tensor diag, Tensor x_ref, float pns, int n_elev, int n_azim) -> int", &field_prepare_async);
+    m.def("field_prepare_wait(int ticket) -> (Tensor, Tensor)", &field_prepare_wait);
     m.def("field_prepare(Tensor mv, Tensor centers, Tensor diag, Tensor x_ref, float pns, int n_elev, int n_azim) -> (Tensor, Tensor)", &field_prepare);
     m.def("ragged_tables(int[] cloud_sizes, int[] query_sizes, int rows_per_block, bool with_row_job) -> Tensor", &ragged_tables);
     m.def("field_jobs(Tensor hostc, Tensor s_off, Tensor nbm, Tensor xf_all, Tensor perm, int n_cells, int chunk, int k_for_knn) -> (Tensor, Tensor)", &field_jobs);

@@ -4,6 +4,8 @@
 PyTorch3D camera objects stay outside: cameras are passed as the 40-float records of mcr_points_in_fov
 (M_view, M_proj, ndc bounds, centre, range) and a prediction-view matrix.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -168,8 +170,11 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     H, W = params.image_height, params.image_width
     depth2 = depth.reshape(H, W).contiguous().float()
     dmask2 = depth_mask.reshape(H, W) if depth_mask is not None else None
-    rec = ops.h2d(camera.record, torch.float32, device)
     ps = proxy_scene
+    # the field pass's host geometry (every cell's prediction transform, the bin permutation) starts NOW on the extension's worker thread
+    Mv_field = camera.M_view_host if hasattr(camera, "M_view_host") else camera.M_view
+    prep_ticket = _field_prepare_begin(params, ps, Mv_field, device) if hasattr(ps, "fill_cells_begin") else None
+    rec = ops.h2d(camera.record, torch.float32, device)
     # 1 ---- proxy points in the current field of view, offered to their grid cells with their index as feature (every point is offered,
     # the ones outside the frustum flagged invalid: compacting them first -- `points[mask]` -- is a read-back of the count)
     fov_mask = ops.points_in_fov(ps.proxy_points, rec.view(1, 40))[0]
@@ -198,7 +203,6 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     # variant with the SAME hidden draws (cell permutations, sampling uniforms).
     # the world->view matrix where the host-side geometry needs it: a record kept on the host costs nothing, a device record ONE
     # read-back per camera object (a read-back per decision stalled the host behind the fill / selection launches: 0.2-0.3 ms)
-    Mv_field = camera.M_view_host if hasattr(camera, "M_view_host") else camera.M_view
     Mv = rec[:16].view(4, 4)                          # (the device copy of the record already holds it: no second upload)
     K = neighbor_records.shape[0]
     th = params.distance_factor_th
@@ -223,7 +227,7 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     field_state = {"selection": None, "between": None, "after": None}
     if fused:
         sel = _field_select(ps, device, True, pending=fill)
-        prep = _field_prepare(params, ps, Mv_field, device)        # (count-independent host work, while the GPU runs the launches above)
+        prep = _field_prepare(params, ps, Mv_field, device, prep_ticket)   # (count-independent host work: from the worker thread)
         nkf = 4 * fill.nk + 6
         host = torch.cat((fill.counts, sel.counts)).cpu().numpy()                                  # THE read-back of the decision's first half
         cand, adm = ps.fill_counts(host[:nkf])
@@ -536,7 +540,24 @@ def _native_field_jobs():
     return _NATIVE_FIELD_JOBS[0]
 
 
-def _field_prepare(params, proxy_scene, prediction_camera, device):
+def _field_prepare_begin(params, proxy_scene, prediction_camera, device):
+    """Start _field_prepare's geometry on the extension's worker thread (torch.ops.macarons.field_prepare_async: a C++ thread, no
+    GIL) and return the ticket _field_prepare collects, or None where the inline form applies (no host matrix, opt-out
+    MCR_FIELD_PREPARE_ASYNC=0, extension without the op)."""
+    if not (torch.is_tensor(prediction_camera) and prediction_camera.device.type == "cpu" and _native_field_jobs()
+            and os.environ.get("MCR_FIELD_PREPARE_ASYNC", "1") != "0" and hasattr(torch.ops.macarons, "field_prepare_async")):
+        return None
+    from . import scone_utils as su
+    tab = _grid_tables(proxy_scene, device)
+    key = (params.view_state_n_elev, params.view_state_n_azim)
+    if key not in su._REF_DIRECTIONS:
+        su.view_space_bin_permutation(torch.eye(3), *key)
+    return torch.ops.macarons.field_prepare_async(prediction_camera.detach().to(torch.float32).reshape(4, 4), tab["centers_host"],
+                                                  tab["diag_host"], su._REF_DIRECTIONS[key], float(params.prediction_neighborhood_size),
+                                                  *key)
+
+
+def _field_prepare(params, proxy_scene, prediction_camera, device, ticket=None):
     """Host work of the field pass that does not depend on the selection's counts (so that macarons_nbv_decision can do it while the
     GPU still works towards the read-back): the world->view matrix on the host, every cell's prediction-box transform
     (:1468-1478), the bin permutation of move_view_state_to_view_space (:863-931)."""
@@ -546,6 +567,10 @@ def _field_prepare(params, proxy_scene, prediction_camera, device):
     Mv_host = Mv_any.detach().to("cpu", torch.float32).reshape(4, 4)    # (a device matrix is read back here)
     cw, dg = tab["centers_host"], tab["diag_host"]
     n = cw.shape[0]
+    if ticket is not None:
+        xf_all_t, perm_t = torch.ops.macarons.field_prepare_wait(ticket)
+        return {"tab": tab, "xf_all": xf_all_t.numpy(), "perm": perm_t.numpy(), "xf_all_t": xf_all_t, "perm_t": perm_t,
+                "vh_mt": _vh_matrix_t(params, device)}
     if torch.is_tensor(prediction_camera) and _native_field_jobs() and hasattr(torch.ops.macarons, "field_prepare"):
         # the same ATen operators from ONE C++ call (bit-identical; tests/test_draws_cpu.py)
         su.view_space_bin_permutation(torch.eye(3), params.view_state_n_elev, params.view_state_n_azim) \

@@ -169,3 +169,19 @@ def test_native_field_prepare_equals_the_python_restatement():
         xf = torch.cat((Mv.reshape(1, 16).expand(n, -1), cen_h, inv_h.view(n, 1)), 1).contiguous()
         perm = su.view_space_bin_indices((x_ref @ Mv[:3, :3].contiguous().view(3, 3).T).reshape(-1, 3), 7, 14).to(torch.int32)
         assert torch.equal(a, xf) and torch.equal(b, perm), i
+        if i % 10 == 0:                 # the worker-thread form: same tensors; the caller may rewrite its matrix once the ticket is out
+            Mv2 = Mv.clone()
+            t = torch.ops.macarons.field_prepare_async(Mv2, cw, dg, x_ref, pns, 7, 14)
+            Mv2.zero_()
+            a2, b2 = torch.ops.macarons.field_prepare_wait(t)
+            assert torch.equal(a2, a) and torch.equal(b2, b), i
+    import pytest
+    tickets = [torch.ops.macarons.field_prepare_async(Mv, cw, dg, x_ref, pns, 7, 14) for _ in range(4)]     # collected out of order
+    for t in reversed(tickets):
+        a2, b2 = torch.ops.macarons.field_prepare_wait(t)
+        assert torch.equal(a2, a) and torch.equal(b2, b)
+    with pytest.raises(RuntimeError):
+        torch.ops.macarons.field_prepare_wait(tickets[0])          # a ticket is good for one collection
+    t = torch.ops.macarons.field_prepare_async(torch.zeros(3, 3), cw, dg, x_ref, pns, 7, 14)
+    with pytest.raises(RuntimeError):                               # the job's error surfaces at the wait
+        torch.ops.macarons.field_prepare_wait(t)
