@@ -589,8 +589,7 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
         launch_linear(s, pts, 4, l1.w, l1.b, nullptr, 0, h, VIS_F, T, VIS_F, 4, ACT_GELU, nullptr, 0, 0, N);
         launch_linear(s, h, VIS_F, l2.w, l2.b, nullptr, 0, x, VIS_E, T, VIS_F, VIS_F, ACT_NONE, nullptr, 0, 0, N);
     }
-    launch_colmax_broadcast(s, x, VIS_E, x + VIS_F, VIS_E, B, (int)N, VIS_F, lengths);
-    launch_copy2d(s, pts, 4, x + 2 * VIS_F, VIS_E, T, 4);
+    launch_colmax_broadcast(s, x, VIS_E, x + VIS_F, VIS_E, B, (int)N, VIS_F, lengths, pts, 4, 4, x + 2 * VIS_F);   // (+ the raw input columns)
     for (int e = 0; e < 3; ++e) run_encoder(s, enc[e], x, h, qkv, ff, B, (int)N, VIS_E, 4, lengths);   // SconeVis.py:139-140
     if (planes) {
         // :143-152 on planes: LayerNorm -> planes; fc1 (GELU) writes columns 0..191 of the next operand's planes, the view harmonics are

@@ -72,8 +72,10 @@ void launch_attention_planes(hipStream_t s, const void* Ph, const void* Pl, int6
 
 // Column max over the L rows of each of S sequences, broadcast into a column slice of every row:
 //   Y[(s*L + r)*ldy + c] = max_r' X[(s*L + r')*ldx + c], c < E          (Embedding global feature, Attention.py:117-121)
+// `ex` (optional): ex_cols columns of a second [S*L, ex_ld] array copied to ex_dst (leading dimension ldy) on the way -- inside the
+// same launch for the long sequences (L >= 512, ex_cols <= 16), by a copy launch otherwise.
 void launch_colmax_broadcast(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E,
-                             const int* lens = nullptr);
+                             const int* lens = nullptr, const float* ex = nullptr, int ex_ld = 0, int ex_cols = 0, float* ex_dst = nullptr);
 
 // PCTransformer tail (SconeOcc.py:123-126): per sequence, max over rows then mean over rows:
 //   Y[s*ldy + c] = max_r X[(s*L+r)*ldx + c],  Y[s*ldy + E + c] = mean_r X[...]

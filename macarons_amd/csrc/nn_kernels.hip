@@ -1081,15 +1081,92 @@ __global__ __launch_bounds__(64 * POOL_RL) void pool_kernel(const float* __restr
     }
 }
 
+// The same reductions for LONG sequences (L >= POOL_LONG_MIN rows; a launch holds 1 ... 41 of them): 16 columns x 64 row lanes per block,
+// grid = (S, ceil(E/16)).  With 64 columns per block a single cloud of 2048 tokens was TWO blocks, each a chain of 16 rounds of exposed
+// load latency (17 us of a 0.33 ms SconeVis forward); here it is E/16 blocks of 4 rounds.  The choice is made on L alone, so a cloud's
+// mean has the same summation tree at every batch size (the max is exact in any order).  `ex` (BROADCAST only): ex_cols <= 16 columns of a
+// second [S*L, ex_ld] array copied to ex_dst (leading dimension ldy) by the first column block: SconeVis's raw-input columns, without a
+// launch of their own.
+void launch_copy2d(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t M, int E);
+constexpr int POOL_LONG_MIN = 512, POOL_LONG_RL = 64;
+template <bool BROADCAST>
+__global__ __launch_bounds__(16 * POOL_LONG_RL) void pool_long_kernel(const float* __restrict__ X, long long ldx, float* __restrict__ Y,
+                                                                      long long ldy, int L, int E, const int* __restrict__ lens,
+                                                                      const float* __restrict__ ex, int ex_ld, int ex_cols,
+                                                                      float* __restrict__ ex_dst) {
+    __shared__ float s_max[16][16];
+    __shared__ float s_sum[16][16];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4, w = threadIdx.x >> 6;
+    const int c = blockIdx.y * 16 + cl;
+    const long long row0 = (long long)blockIdx.x * L;
+    const int Lr = lens ? max(1, min(L, lens[blockIdx.x])) : L;
+    float mx = -__builtin_inff(), sm = 0.f;
+    if (c < E) {
+        int r = g;
+        for (; r + 7 * POOL_LONG_RL < Lr; r += 8 * POOL_LONG_RL) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = X[(row0 + r + j * POOL_LONG_RL) * ldx + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                mx = fmaxf(mx, v[j]);
+                sm += v[j];
+            }
+        }
+        for (; r < Lr; r += POOL_LONG_RL) {
+            const float v = X[(row0 + r) * ldx + c];
+            mx = fmaxf(mx, v);
+            sm += v;
+        }
+    }
+    // the 4 row lanes of a wave (lanes cl, cl+16, cl+32, cl+48), then the 16 waves in order
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    sm += __shfl_xor(sm, 16);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    sm += __shfl_xor(sm, 32);
+    if ((threadIdx.x & 63) < 16) {
+        s_max[w][cl] = mx;
+        s_sum[w][cl] = sm;
+    }
+    __syncthreads();
+    mx = s_max[0][cl];
+    sm = s_sum[0][cl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        mx = fmaxf(mx, s_max[k][cl]);
+        sm += s_sum[k][cl];
+    }
+    if (BROADCAST) {
+        if (c < E)
+            for (int r = g; r < L; r += POOL_LONG_RL) Y[(row0 + r) * ldy + c] = mx;
+        if (ex && blockIdx.y == 0 && cl < ex_cols)
+            for (int r = g; r < L; r += POOL_LONG_RL) ex_dst[(row0 + r) * ldy + cl] = ex[(row0 + r) * ex_ld + cl];
+    } else if (g == 0 && c < E) {
+        Y[(long long)blockIdx.x * ldy + c] = mx;
+        Y[(long long)blockIdx.x * ldy + E + c] = sm / (float)Lr;
+    }
+}
+
 void launch_colmax_broadcast(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E,
-                             const int* lens) {
+                             const int* lens, const float* ex, int ex_ld, int ex_cols, float* ex_dst) {
     if (S <= 0) return;
+    if (L >= POOL_LONG_MIN && ex_cols <= 16) {
+        hipLaunchKernelGGL((pool_long_kernel<true>), dim3((unsigned)S, (unsigned)cdiv(E, 16)), dim3(16 * POOL_LONG_RL), 0, s, X,
+                           (long long)ldx, Y, (long long)ldy, L, E, lens, ex, ex_ld, ex_cols, ex_dst);
+        return;
+    }
     hipLaunchKernelGGL((pool_kernel<true>), dim3((unsigned)S, (unsigned)cdiv(E, 64)), dim3(64 * POOL_RL), 0, s, X, (long long)ldx, Y,
                        (long long)ldy, L, E, lens);
+    if (ex) launch_copy2d(s, ex, ex_ld, ex_dst, ldy, S * (int64_t)L, ex_cols);
 }
 
 void launch_pool_max_avg(hipStream_t s, const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t S, int L, int E, const int* lens) {
     if (S <= 0) return;
+    if (L >= POOL_LONG_MIN) {
+        hipLaunchKernelGGL((pool_long_kernel<false>), dim3((unsigned)S, (unsigned)cdiv(E, 16)), dim3(16 * POOL_LONG_RL), 0, s, X,
+                           (long long)ldx, Y, (long long)ldy, L, E, lens, (const float*)nullptr, 0, 0, (float*)nullptr);
+        return;
+    }
     hipLaunchKernelGGL((pool_kernel<false>), dim3((unsigned)S, (unsigned)cdiv(E, 64)), dim3(64 * POOL_RL), 0, s, X, (long long)ldx, Y,
                        (long long)ldy, L, E, lens);
 }

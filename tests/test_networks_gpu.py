@@ -214,6 +214,14 @@ def test_layernorm_and_pools(dev):
         assert np.abs(y - ref).max() < 2e-5
     x = rng.standard_normal((3, 333, 126)).astype(np.float32)
     assert np.array_equal(ops.colmax_broadcast(T(x, dev)).cpu().numpy(), np.broadcast_to(x.max(1, keepdims=True), x.shape))
+    for S, L, E in ((1, 2048, 126), (3, 513, 126), (2, 1000, 64), (5, 640, 250)):         # the long-sequence kernels (L >= 512)
+        x = rng.standard_normal((S, L, E)).astype(np.float32)
+        assert np.array_equal(ops.colmax_broadcast(T(x, dev)).cpu().numpy(), np.broadcast_to(x.max(1, keepdims=True), x.shape))
+        y = ops.pool_max_avg(T(x, dev)).cpu().numpy()
+        assert np.array_equal(y[:, :E], x.max(1)) and np.abs(y[:, E:] - x.mean(1)).max() < 1e-6
+        if S > 1:                                  # a cloud's mean has the same bits alone and in a batch
+            y1 = ops.pool_max_avg(T(x[1:2].copy(), dev)).cpu().numpy()
+            assert np.array_equal(y1[0], y[1])
     x = rng.standard_normal((70000, 16, 128)).astype(np.float32)        # > 65535 sequences
     y = ops.pool_max_avg(T(x, dev)).cpu().numpy()
     assert np.array_equal(y[:, :128], x.max(1)) and np.abs(y[:, 128:] - x.mean(1)).max() < 1e-6
