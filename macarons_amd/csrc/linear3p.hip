@@ -223,6 +223,101 @@ __global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_ker
         return;
     }
     // ---- epilogue: lane (j, h) of tile t holds features n = n0 + 32 wn + 8 g + 4 h + e (register 4 g + e) of row m0 + 128 wm + 32 t + j
+#ifndef MCR_L3P_NO_TR
+    // Out through the LDS (the stages are free once every wave has left the K loop).  A lane's register quad is 8 bytes of a row per
+    // plane (16 bytes of fp32): a store instruction of the direct form below touches 32 rows with 16 (32) bytes each -- eight partial
+    // writes per 128-byte line, issued by two waves; knocked out, those stores were 20-37 us of a 70-110 us encoder layer at 30 x 2048
+    // tokens, the MFMAs 4 us.  Here the block's tile is laid out [plane][row][128 features] in the LDS (8-byte units XOR-swizzled by the
+    // row: 4 lanes per bank pair, the minimum for 64 x 8 bytes) and leaves in whole rows: 16 lanes x 16 bytes = the 256 bytes of a row
+    // and plane, four rows per store instruction.  Same values, same bits.
+    constexpr int TR_THREADS = NW * 64;
+    if (MODE == LP_PLANES && N % 8 == 0 && ldy % 8 == 0 && (((size_t)Yh | (size_t)Yl) & 15) == 0) {
+        __syncthreads();
+        char* tb = reinterpret_cast<char*>(S);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = wm * 128 + t * 32 + i;
+            const long long mr = min(m0 + row, M - 1);
+            const long long grp = row_bias ? (row_group ? (long long)row_group[mr] : mr / rows_per_group) : 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 32 + 8 * g + 4 * h;
+                if (n >= N) continue;
+                float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row_bias) {
+                    const float4 rb = *reinterpret_cast<const float4*>(row_bias + grp * N + n);
+                    b4.x += rb.x; b4.y += rb.y; b4.z += rb.z; b4.w += rb.w;
+                }
+                float y[4] = {fmaf(acc[t][4 * g], wscale_inv, b4.x), fmaf(acc[t][4 * g + 1], wscale_inv, b4.y),
+                              fmaf(acc[t][4 * g + 2], wscale_inv, b4.z), fmaf(acc[t][4 * g + 3], wscale_inv, b4.w)};
+                if (act == ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = l3_gelu(y[e]);
+                }
+                uint2 hi, lo;
+                split2h(y[0], y[1], hi.x, lo.x);
+                split2h(y[2], y[3], hi.y, lo.y);
+                const int u = 8 * wn + 2 * g + h;
+                const int off = row * 256 + ((u ^ ((row & 15) << 1)) << 3);
+                *reinterpret_cast<uint2*>(tb + off) = hi;
+                *reinterpret_cast<uint2*>(tb + LP_TM * 256 + off) = lo;
+            }
+        }
+        __syncthreads();
+        constexpr int RPP = TR_THREADS / 16, PASSES = LP_TM / RPP;            // rows per pass; passes per plane
+#pragma unroll
+        for (int q = 0; q < 2 * PASSES; ++q) {
+            const int pl = q / PASSES, r = (q % PASSES) * RPP + (tid >> 4), pp = tid & 15;
+            const uint4 v = *reinterpret_cast<const uint4*>(tb + pl * (LP_TM * 256) + r * 256 + ((pp ^ (r & 15)) << 4));
+            const long long m = m0 + r;
+            const int n = n0 + 8 * pp;
+            if (m < M && n < N) *reinterpret_cast<uint4*>((pl ? Yl : Yh) + m * ldy + n) = v;
+        }
+        return;
+    }
+    // fp32 rows the same way: [row][128 floats], 16-byte units XOR-swizzled by the row; 32 lanes x 16 bytes = the 512 bytes of a row, the
+    // residual read and the result written by the same lane in full lines
+    if (MODE == LP_F32 && !row_bias && ldy % 4 == 0 && ((size_t)Y & 15) == 0 && (!R || (ldr % 4 == 0 && ((size_t)R & 15) == 0))) {
+        __syncthreads();
+        char* tb = reinterpret_cast<char*>(S);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = wm * 128 + t * 32 + i;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 32 + 8 * g + 4 * h;
+                if (n >= N) continue;
+                const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float y[4] = {fmaf(acc[t][4 * g], wscale_inv, b4.x), fmaf(acc[t][4 * g + 1], wscale_inv, b4.y),
+                              fmaf(acc[t][4 * g + 2], wscale_inv, b4.z), fmaf(acc[t][4 * g + 3], wscale_inv, b4.w)};
+                if (act == ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = l3_gelu(y[e]);
+                }
+                const int u = 8 * wn + 2 * g + h;
+                *reinterpret_cast<float4*>(tb + row * 512 + ((u ^ (row & 31)) << 4)) = make_float4(y[0], y[1], y[2], y[3]);
+            }
+        }
+        __syncthreads();
+        constexpr int RPP = TR_THREADS / 32;
+#pragma unroll
+        for (int q = 0; q < LP_TM / RPP; ++q) {
+            const int r = q * RPP + (tid >> 5), cc = tid & 31;
+            float4 v = *reinterpret_cast<const float4*>(tb + r * 512 + ((cc ^ (r & 31)) << 4));
+            const long long m = m0 + r;
+            const int n = n0 + 4 * cc;
+            if (m < M && n < N) {
+                if (R) {                                   // residual (Attention.py:290, :298); R may be Y: read before the store
+                    const float4 r4 = *reinterpret_cast<const float4*>(R + m * ldr + n);
+                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                }
+                *reinterpret_cast<float4*>(Y + m * ldy + n) = v;
+            }
+        }
+        return;
+    }
+#endif
+    // the direct form (operands that are not 16-byte aligned, N % 8 != 0, a row bias on fp32 rows)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const long long m = m0 + wm * 128 + t * 32 + i;

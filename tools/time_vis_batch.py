@@ -10,6 +10,8 @@ from macarons_amd.networks import SconeVis, SconeOcc
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 vis, occ = SconeVis().to(dev).eval(), SconeOcc().to(dev).eval()
+if os.environ.get("GUARD_OFF"):
+    vis.range_guard = occ.range_guard = "off"
 pts = torch.rand(30, 2048, 4, device=dev)
 vh = torch.randn(30, 2048, 64, device=dev) * 0.3
 pc = torch.rand(41, 2048, 3, device=dev) - 0.5
