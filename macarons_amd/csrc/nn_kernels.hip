@@ -190,11 +190,64 @@ __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restr
     }
 }
 
+// The planes form at many rows (the xyz / xyz+occupancy embeddings of a batch of clouds, the query embedding of the SconeOcc head:
+// 60k ... 100k rows x 128 outputs).  The kernel above re-reads 16 weights per thread through the vector memory path and calls libm's
+// branchy erff: 79 us for 61 440 x 128 outputs.  Here a thread keeps the weights and the bias of its 4 outputs in registers and walks
+// the rows of its block (up to LSK_ROWS per block -- fewer when that leaves the chip short of blocks; a row's result does not depend on
+// it --, 256 / (N / 4) at a time); the fmaf chain (ascending k from 0, then + bias) is the one above,
+// the GELU is l3_gelu -- the exact-erf GELU of every other epilogue of the planes path (|erf error| <= 1.5e-7).
+constexpr int LSK_ROWS = 64;
+__global__ __launch_bounds__(256) void linear_smallk_rows_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ W,
+                                                                 long long ldw, const float* __restrict__ bias, long long ldy, long long M,
+                                                                 int N, int K, int act, _Float16* __restrict__ Yh, _Float16* __restrict__ Yl,
+                                                                 int Nreal, int rows) {
+    const int qpr = N >> 2, rpp = 256 / qpr;               // quads per row; rows per pass
+    const int q = threadIdx.x % qpr, rl = threadIdx.x / qpr, n = q * 4;
+    float w[4][4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        b[j] = (bias && n + j < Nreal) ? bias[n + j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[j][k] = (k < K && n + j < Nreal) ? W[(long long)(n + j) * ldw + k] : 0.f;
+    }
+    const long long r0 = (long long)blockIdx.x * rows;
+    for (int i = rl; i < rows; i += rpp) {
+        const long long m = r0 + i;
+        if (m >= M) break;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < K; ++k) x[k] = X[m * ldx + k];
+        float y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.f;
+            for (int k = 0; k < K; ++k) acc = fmaf(x[k], w[j][k], acc);
+            acc += b[j];
+            if (act == ACT_GELU) acc = l3_gelu(acc);
+            y[j] = n + j < Nreal ? acc : 0.f;
+        }
+        uint2 hi, lo;
+        split2h(y[0], y[1], hi.x, lo.x);
+        split2h(y[2], y[3], hi.y, lo.y);
+        *reinterpret_cast<uint2*>(Yh + m * ldy + n) = hi;
+        *reinterpret_cast<uint2*>(Yl + m * ldy + n) = lo;
+    }
+}
+
 // act(X W^T + bias) for K <= 4, written as fp16 hi/lo planes (N % 4 == 0, ldy % 4 == 0)
 void launch_linear_smallk_planes(hipStream_t s, const float* X, int64_t ldx, const float* W, const float* bias, void* Yh, void* Yl,
                                  int64_t ldy, int64_t M, int N, int K, int act, int Np) {
     if (M <= 0 || N <= 0) return;
     const int Nw = Np > N ? Np : N;                        // outputs written per row
+    static const bool rows_on = []() { const char* e = getenv("MCR_SMALLK_ROWS"); return !(e && e[0] == '0'); }();
+    if (rows_on && Nw % 4 == 0 && Nw / 4 <= 256 && 256 % (Nw / 4) == 0 && K <= 4) {   // (the GELU differs from the form below by <= 2e-7: every size takes this one)
+        const int rpp = 256 / (Nw / 4);
+        int rows = LSK_ROWS;
+        while (rows > rpp && cdiv(M, rows) < 1024) rows >>= 1;
+        rows = std::max(rows, rpp);
+        hipLaunchKernelGGL(linear_smallk_rows_kernel, dim3((unsigned)cdiv(M, rows)), dim3(256), 0, s, X, (long long)ldx, W, (long long)K, bias,
+                           (long long)ldy, (long long)M, Nw, K, act, (_Float16*)Yh, (_Float16*)Yl, N, rows);
+        return;
+    }
     hipLaunchKernelGGL(linear_smallk_kernel<true>, dim3((unsigned)cdiv(M * (Nw / 4), 256)), dim3(256), 0, s, X, (long long)ldx, W, (long long)K,
                        bias, (const float*)nullptr, 0ll, (float*)nullptr, (long long)ldy, (long long)M, Nw, K, act, (_Float16*)Yh, (_Float16*)Yl, N);
 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dev: the launch list of ONE SconeVis forward on a single cloud of 2048 tokens (kernel trace of 30 forwards; the last one printed in
-# launch order with durations and the gaps in front of each launch).
+# launch order with durations and the gaps in front of each launch).  N_CLOUDS=30: the batch of a decision.
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
 cat > /tmp/_vis1.py <<PY
@@ -9,7 +9,7 @@ sys.path.insert(0, "$R")
 from macarons_amd.networks import SconeVis
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 vis = SconeVis().to(dev).eval()
-pts = torch.rand(1, 2048, 4, device=dev); vh = torch.randn(1, 2048, 64, device=dev) * 0.3
+import os; NC = int(os.environ.get("N_CLOUDS", "1")); pts = torch.rand(NC, 2048, 4, device=dev); vh = torch.randn(NC, 2048, 64, device=dev) * 0.3
 with torch.no_grad():
     for _ in range(30):
         vis(pts, view_harmonics=vh); torch.cuda.synchronize()
