@@ -19,5 +19,8 @@ cp $O/power_trace.txt $R/profiles/${P}_power_local_pct6.txt
 for k in host device; do
   [ -f $R/gpurun_out/${P}_macarons_decision_trace_$k.txt ] && cp $R/gpurun_out/${P}_macarons_decision_trace_$k.txt $R/profiles/
 done
+for f in decision_host_timeline scone_vis_batch_launches scone_vis_single_launches; do
+  [ -f $R/gpurun_out/${P}_$f.txt ] && cp $R/gpurun_out/${P}_$f.txt $R/profiles/
+done
 [ -f $O/attention_planes_pmc.txt ] && cp $O/attention_planes_pmc.txt $R/profiles/${P}_attention_planes_pmc.txt
 ls -la $R/profiles | grep ${P}_ | wc -l
