@@ -214,7 +214,7 @@ def test_layernorm_and_pools(dev):
         assert np.abs(y - ref).max() < 2e-5
     x = rng.standard_normal((3, 333, 126)).astype(np.float32)
     assert np.array_equal(ops.colmax_broadcast(T(x, dev)).cpu().numpy(), np.broadcast_to(x.max(1, keepdims=True), x.shape))
-    for S, L, E in ((1, 2048, 126), (3, 513, 126), (2, 1000, 64), (5, 640, 250)):         # the long-sequence kernels (L >= 512)
+    for S, L, E in ((1, 2048, 126), (3, 513, 126), (2, 1000, 64), (5, 640, 250), (20, 600, 126)):   # the long-sequence kernels (L >= 512)
         x = rng.standard_normal((S, L, E)).astype(np.float32)
         assert np.array_equal(ops.colmax_broadcast(T(x, dev)).cpu().numpy(), np.broadcast_to(x.max(1, keepdims=True), x.shape))
         y = ops.pool_max_avg(T(x, dev)).cpu().numpy()
