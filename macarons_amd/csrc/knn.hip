@@ -222,7 +222,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_mfma_kernel(const float* __rest
                                                              long long* __restrict__ out_idx, float* __restrict__ out_dist,
                                                              float* __restrict__ out_pts, int Q, int M, const int4* __restrict__ blocks,
                                                              const long long* __restrict__ pc_off, int n_split = 1,
-                                                             unsigned long long* __restrict__ part_out = nullptr) {
+                                                             unsigned long long* __restrict__ part_out = nullptr, int seg_cand = 0) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     __shared__ __attribute__((aligned(16))) float s_p[4][KM_TILE];           // x | y | z | |p|^2
     __shared__ int s_q[KM_QCAP * KNN_BLOCK];                                  // queue; reused as the merge buffer
@@ -245,6 +245,12 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_mfma_kernel(const float* __rest
     }
     int c_first = 0;
     if (n_split > 1) {                             // this workgroup's candidates [c_first, M)
+        // seg_cand > 0: a job's candidates are cut into slices of ~seg_cand (at most n_split of them): the jobs of a ragged pass hold
+        // 1 000 ... 15 000 candidates, and with one slice count for all of them the launch waited for the largest clouds' blocks
+        if (seg_cand > 0) {
+            n_split = min(n_split, max(1, (M + seg_cand - 1) / seg_cand));
+            if (sp >= n_split) return;
+        }
         const int chunk = (((M + n_split - 1) / n_split) + 31) & ~31;
         c_first = min(M, sp * chunk);
         M = min(M, c_first + chunk);
@@ -1036,43 +1042,93 @@ __global__ __launch_bounds__(MODE ? 64 * KG_SPLIT : 64, MODE ? 2 : 4) void knn_g
 // ascending key lists of its query (K smallest, lexicographic = (d2, index)) and the block writes the neighbours' offsets from the
 // query through LDS as one contiguous range (like knn_mfma_kernel's epilogue).
 template <int K>
-__global__ __launch_bounds__(128) void knn_split_merge_kernel(const float* __restrict__ X, const float* __restrict__ pc,
-                                                              const long long* __restrict__ pc_off, const int4* __restrict__ blocks,
-                                                              const unsigned long long* __restrict__ part, int n_split, int Q,
-                                                              float* __restrict__ out_pts) {
-    __shared__ __attribute__((aligned(16))) float st[128 * K * 3];
+__global__ __launch_bounds__(64) void knn_split_merge_kernel(const float* __restrict__ X, const float* __restrict__ pc,
+                                                             const long long* __restrict__ pc_off, const int4* __restrict__ blocks,
+                                                             const unsigned long long* __restrict__ part, int n_split, int Q,
+                                                             float* __restrict__ out_pts, int seg_cand = 0) {
+    // grid = (query blocks, 2): 64 threads = one half of a block's <= 128 query rows.  The key lists of the half (n_split x 64 x K keys:
+    // contiguous per slice) are copied to the LDS in one round of independent loads first -- read straight from global memory, the K
+    // selection rounds were K dependent round trips to L2 / HBM (27-45 us for a merge of 23 k queries).
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sm_keys[];      // [n_split][64][K + 1] keys, then 64 x K x 3 floats
+    constexpr int KP = K + 1;                                                          // (+1: a thread's lists start on different banks)
     const int4 bk = blocks[blockIdx.x];
-    const int q_first = bk.y, n_valid = max(0, min(128, bk.z));
+    const int r0 = blockIdx.y * 64;
+    const int q_first = bk.y + r0, n_valid = max(0, min(64, bk.z - r0));
+    if (n_valid <= 0) return;
     const float* pcb = pc + (size_t)pc_off[bk.x] * 3;
     const int t = threadIdx.x;
+    if (seg_cand > 0) n_split = min(n_split, max(1, (int)((pc_off[bk.x + 1] - pc_off[bk.x] + seg_cand - 1) / seg_cand)));   // (the search's slice count)
+    float* st = reinterpret_cast<float*>(sm_keys + (size_t)n_split * 64 * KP);
+    // a slice's lists of the 64 rows are one contiguous run of 64 x K keys: 16 bytes per lane and load, eight loads in flight per lane
+    // and slice (the run is 16-byte aligned: K * 8 bytes per row); rows beyond n_valid stay unread
+    static_assert(K == 16, "the staging below moves 8 x 64 x 16 bytes per slice");
+    for (int w = 0; w < n_split; ++w) {
+        const uint4* src = reinterpret_cast<const uint4*>(part + ((size_t)w * Q + q_first) * K);
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = u * 64 + t;                                     // 16-byte piece c = (row c / 8, keys 2 (c % 8), + 1)
+            v[u] = (c >> 3) < n_valid ? src[c] : make_uint4(~0u, ~0u, ~0u, ~0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = u * 64 + t;
+            unsigned long long* d = sm_keys + (w * 64 + (c >> 3)) * KP + 2 * (c & 7);
+            d[0] = (unsigned long long)v[u].x | ((unsigned long long)v[u].y << 32);
+            d[1] = (unsigned long long)v[u].z | ((unsigned long long)v[u].w << 32);
+        }
+    }
+    __syncthreads();
     if (t < n_valid) {
         const int q = q_first + t;
         const float qx = X[(size_t)q * 3], qy = X[(size_t)q * 3 + 1], qz = X[(size_t)q * 3 + 2];
-        int head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // the lists' current keys live in registers (slot w of cur[] is only ever indexed by unrolled loops); the K winners first, then
+        // their points in K independent gathers
+        unsigned long long cur[8];
+        int head[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            head[w] = 0;
+            cur[w] = w < n_split ? sm_keys[(w * 64 + t) * KP] : ~0ull;
+        }
+        int ids[K];
+#pragma unroll
         for (int r = 0; r < K; ++r) {
-            unsigned long long best = ~0ull;
+            unsigned long long best = cur[0];
             int best_w = 0;
-            for (int w = 0; w < n_split; ++w) {
-                const unsigned long long k = head[w] < K ? part[((size_t)w * Q + q) * K + head[w]] : ~0ull;
-                if (k < best) { best = k; best_w = w; }
-            }
-            for (int w = 0; w < n_split; ++w) head[w] += (w == best_w) ? 1 : 0;
+#pragma unroll
+            for (int w = 1; w < 8; ++w)
+                if (cur[w] < best) { best = cur[w]; best_w = w; }
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+                if (w == best_w) {
+                    ++head[w];
+                    cur[w] = head[w] < K ? sm_keys[(w * 64 + t) * KP + head[w]] : ~0ull;
+                }
             const unsigned bi = (unsigned)best;
-            const int id = bi == 0x7fffffffu ? 0 : (int)bi;               // (an unfilled slot: cannot happen with >= K candidates)
-            const float* p = pcb + (size_t)id * 3;
-            st[(t * K + r) * 3 + 0] = p[0] - qx;
-            st[(t * K + r) * 3 + 1] = p[1] - qy;
-            st[(t * K + r) * 3 + 2] = p[2] - qz;
+            ids[r] = bi == 0x7fffffffu ? 0 : (int)bi;                     // (an unfilled slot: cannot happen with >= K candidates)
+        }
+        float px[K], py[K], pz[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const float* p = pcb + (size_t)ids[r] * 3;
+            px[r] = p[0]; py[r] = p[1]; pz[r] = p[2];
+        }
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            st[(t * K + r) * 3 + 0] = px[r] - qx;
+            st[(t * K + r) * 3 + 1] = py[r] - qy;
+            st[(t * K + r) * 3 + 2] = pz[r] - qz;
         }
     }
     __syncthreads();
     const int n_f = n_valid * K * 3;
     float* dst = out_pts + (size_t)q_first * K * 3;
-    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-        for (int c = t; c * 4 + 3 < n_f; c += 128) reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(st)[c];
-        for (int e = (n_f & ~3) + t; e < n_f; e += 128) dst[e] = st[e];
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(st) & 15) == 0) {
+        for (int c = t; c * 4 + 3 < n_f; c += 64) reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(st)[c];
+        for (int e = (n_f & ~3) + t; e < n_f; e += 64) dst[e] = st[e];
     } else {
-        for (int e = t; e < n_f; e += 128) dst[e] = st[e];
+        for (int e = t; e < n_f; e += 64) dst[e] = st[e];
     }
 }
 
@@ -1103,7 +1159,7 @@ namespace mcr {
 // split_ws (optional, knn16_segmented_split_floats(T) floats): lets a launch with few query blocks split every job's candidates over
 // up to KNN_SEG_SPLIT workgroups per block (+ one merge launch); same neighbours in the same order.  MCR_KNN_SEG_SPLIT=0: never (A/B)
 #ifndef MCR_KNN_SEG_SPLIT_MAX
-#define MCR_KNN_SEG_SPLIT_MAX 4
+#define MCR_KNN_SEG_SPLIT_MAX 8
 #endif
 #ifndef MCR_KNN_SEG_TARGET
 #define MCR_KNN_SEG_TARGET 768
@@ -1111,19 +1167,28 @@ namespace mcr {
 constexpr int KNN_SEG_SPLIT = MCR_KNN_SEG_SPLIT_MAX;
 size_t knn16_segmented_split_floats(int64_t T) { return (size_t)KNN_SEG_SPLIT * T * 16 * 2; }
 void launch_knn16_segmented(hipStream_t s, const float* X, const float* pc, const long long* pc_off, const int* blocks,
-                            int64_t n_blocks, int64_t T, float* offsets_out, float* split_ws, bool large_clouds) {
+                            int64_t n_blocks, int64_t T, float* offsets_out, float* split_ws, int slice) {
     if (n_blocks <= 0) return;
     static const bool split_on = []() { const char* e = getenv("MCR_KNN_SEG_SPLIT"); return !(e && e[0] == '0'); }();
     static const bool use_mfma = []() { const char* e = getenv("MCR_KNN_MFMA"); return !(e && e[0] == '0'); }();
     // four waves per block: ~3 waves per SIMD need 768 blocks
+    // slice: candidates per slice of a job (0: the launch is not split); MCR_KNN_SEG_CAND=0: one slice count for every job instead (A/B)
+    static const bool per_job = []() { const char* e = getenv("MCR_KNN_SEG_CAND"); return !(e && e[0] == '0'); }();
+    const int seg_cand = per_job ? slice : 0;
     int n_split = 1;
-    if (split_on && use_mfma && split_ws && large_clouds) n_split = (int)std::min<int64_t>(KNN_SEG_SPLIT, std::max<int64_t>(1, MCR_KNN_SEG_TARGET / n_blocks));
+    if (split_on && use_mfma && split_ws && slice > 0)
+        n_split = (int)std::min<int64_t>(KNN_SEG_SPLIT, std::max<int64_t>(1, (seg_cand > 0 ? 4 * MCR_KNN_SEG_TARGET : MCR_KNN_SEG_TARGET) / n_blocks));
     if (n_split > 1) {
         unsigned long long* part = reinterpret_cast<unsigned long long*>(split_ws);
         hipLaunchKernelGGL((knn_mfma_kernel<16, true>), dim3((unsigned)n_blocks, (unsigned)n_split), dim3(KNN_BLOCK), 0, s, X, pc,
-                           (long long*)nullptr, (float*)nullptr, offsets_out, (int)T, 0, reinterpret_cast<const int4*>(blocks), pc_off, n_split, part);
-        hipLaunchKernelGGL((knn_split_merge_kernel<16>), dim3((unsigned)n_blocks), dim3(128), 0, s, X, pc, pc_off,
-                           reinterpret_cast<const int4*>(blocks), (const unsigned long long*)part, n_split, (int)T, offsets_out);
+                           (long long*)nullptr, (float*)nullptr, offsets_out, (int)T, 0, reinterpret_cast<const int4*>(blocks), pc_off, n_split, part,
+                           seg_cand);
+        const size_t merge_lds = (size_t)n_split * 64 * 17 * 8 + 64 * 16 * 3 * 4;                    // <= 81 920 bytes at 8 slices
+        static const bool lds_ok = hipFuncSetAttribute((const void*)knn_split_merge_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       8 * 64 * 17 * 8 + 64 * 16 * 3 * 4) == hipSuccess;
+        if (!lds_ok) { set_error("launch_knn16_segmented: cannot reserve the merge kernel's LDS"); return; }
+        hipLaunchKernelGGL((knn_split_merge_kernel<16>), dim3((unsigned)n_blocks, 2), dim3(64), merge_lds, s, X, pc, pc_off,
+                           reinterpret_cast<const int4*>(blocks), (const unsigned long long*)part, n_split, (int)T, offsets_out, seg_cand);
         return;
     }
     launch_knn<16>(true, dim3((unsigned)n_blocks, 1), s, X, pc, nullptr, nullptr, offsets_out, (int)T, 0,
@@ -1269,7 +1334,7 @@ extern "C" int mcr_knn_offsets_segmented(const float* X, const float* pc, const 
     MCR_REQUIRE(X && pc && pc_off && blocks && offsets_out, "mcr_knn_offsets_segmented: null pointer");
     MCR_REQUIRE(n_blocks >= 0 && T >= 0 && T < (1ll << 31) && n_blocks <= 65535ll * 32768, "mcr_knn_offsets_segmented: bad sizes");
     float* ws = workspace && workspace_bytes >= mcr_knn_offsets_segmented_workspace_bytes(T) ? (float*)workspace : nullptr;
-    launch_knn16_segmented((hipStream_t)stream, X, pc, (const long long*)pc_off, blocks, n_blocks, T, offsets_out, ws, ws != nullptr);
+    launch_knn16_segmented((hipStream_t)stream, X, pc, (const long long*)pc_off, blocks, n_blocks, T, offsets_out, ws, ws != nullptr ? 2048 : 0);
     MCR_LAUNCH_CHECK("mcr_knn_offsets_segmented");
     return 0;
 }

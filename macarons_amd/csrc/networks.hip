@@ -1030,8 +1030,9 @@ int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global
     float* knn_split_ws = scratch.f(knn16_segmented_split_floats(T));
     MCR_REQUIRE(scratch.ok(), "mcr_scone_occ_forward_ragged: workspace overflow (kNN)");
     auto local_scale = [&](int sc) {                      // one segmented kNN + one fused transformer launch over ALL rows
-        // (the whole clouds of scale 0 are the large ones: a launch with few query blocks splits their candidates over workgroups)
-        launch_knn16_segmented(s, x, pc_scale[sc], (const long long*)scale_off[sc], knn_blocks, n_blocks, T, offs, knn_split_ws, sc == 0);
+        // (the whole clouds of scale 0 are the large ones: a launch with few query blocks cuts every job's candidates into slices of
+        // ~2048 for more workgroups; slicing the down-sampled clouds of the coarser scales too -- 512 per slice -- measured no better)
+        launch_knn16_segmented(s, x, pc_scale[sc], (const long long*)scale_off[sc], knn_blocks, n_blocks, T, offs, knn_split_ws, sc == 0 ? 2048 : 0);
         if (planes) run_local_pct(s, offs, nullptr, FEAT, T, local_blobs[sc], featP + sc * 256, featP + T * FEAT + sc * 256);
         else run_local_pct(s, offs, feat + sc * 256, FEAT, T, local_blobs[sc]);
     };

@@ -113,7 +113,7 @@ void launch_split_weights(hipStream_t s, const float* W, int64_t ldw, void* plan
 void launch_pad_weights(hipStream_t s, const float* W, int64_t ldw, const float* bias, void* planes, float* bias_p, int N, int K, int Np, int Kp);
 // segmented kNN-16 with query offsets (knn.hip): see launch_knn16_segmented there
 void launch_knn16_segmented(hipStream_t s, const float* X, const float* pc, const long long* pc_off, const int* blocks,
-                            int64_t n_blocks, int64_t T, float* offsets_out, float* split_ws = nullptr, bool large_clouds = false);
+                            int64_t n_blocks, int64_t T, float* offsets_out, float* split_ws = nullptr, int slice = 0);
 size_t knn16_segmented_split_floats(int64_t T);
 int knn_rows_per_block();
 // grid-pruned exact kNN-16 (knn.hip: K1-grid): query order once per query set, one sorted copy per candidate cloud
