@@ -577,7 +577,7 @@ def self_launch(args):
     sys.exit(r.returncode if last_json is not None or r.returncode else 3)
 
 
-def timed_scorer_loop(step, finish, steps, warmup, dev, dist):
+def timed_scorer_loop(step, finish, steps, warmup, dev, dist, streams=None):
     """W untimed + exactly `steps` timed calls of step(), bracketed by barrier + synchronize on both sides; returns
     (wall seconds = max over ranks, device ms between HIP events on the launch stream)."""
     for _ in range(warmup):
@@ -601,6 +601,8 @@ def timed_scorer_loop(step, finish, steps, warmup, dev, dist):
     for _ in range(steps):
         out = step()
     out = finish(out)
+    for st in streams or ():                                # steps issued on side streams: the closing event sits behind all of them
+        torch.cuda.current_stream(dev).wait_stream(st)
     ev1.record()
     if os.environ.get("MCR_BENCH_SPIN_SYNC", "1") != "0":
         # hipDeviceSynchronize may put the host thread to sleep and be woken by an interrupt tens of microseconds after the last kernel
@@ -625,6 +627,7 @@ def main():
     ap.add_argument("--cams", type=int, default=200)
     ap.add_argument("--strong-cams", type=int, default=512, help="total cameras of the strong-scaling scorer run (config 4)")
     ap.add_argument("--waves-per-simd", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=2, help="streams the scorer steps are issued on, round-robin (1: every step on the current stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc FETCH_SIZE pass (roofline.traffic then comes from profiles/)")
     ap.add_argument("--no-nbv", action="store_true", help="skip the NBV-step latency measurement")
@@ -688,20 +691,33 @@ def main():
         score_best = lambda p_, h_, c_: ops.sh_coverage_gain_best(p_, h_, c_, True, args.waves_per_simd)
 
     def scorer_run(pts, harm, cams, cam_offset, steps, warmup):
-        pipe = mdist.PipelinedBest(1, dev, batch=16, depth=3) if dist is not None else None
+        # --streams S (default 2): consecutive steps are independent batches and are issued round-robin on S streams, each step whole
+        # and stream-ordered on its own stream (fresh outputs and scratch from the stream-aware allocator): the reduce / record launch of
+        # one step runs beside the gain kernel of the next, and two gain kernels fill each other's ramp and tail (43 us per step against
+        # 56 on one stream; --streams 1 is the one-stream figure)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+        pipe = mdist.PipelinedBest(1, dev, batch=16, depth=3, producers=streams or ()) if dist is not None else None
+        issued = [0]
 
         def step():
-            gains, record = score_best(pts, harm, cams)    # record [B,2] = (max gain, arg-max camera): the decision (torch.max semantics)
-            if pipe is not None:                           # records of 16 decisions per all-gather, on a side stream
-                return pipe.submit(gains, cam_offset)
-            return record
+            def one():
+                gains, record = score_best(pts, harm, cams)    # record [B,2] = (max gain, arg-max camera): the decision (torch.max semantics)
+                if pipe is not None:                           # records of 16 decisions per all-gather, on a side stream
+                    return pipe.submit(gains, cam_offset)      # (the record kernel on the step's own stream; the exchange waits for all of them)
+                return record
+            if streams is None:
+                return one()
+            st = streams[issued[0] % len(streams)]
+            issued[0] += 1
+            with torch.cuda.stream(st):
+                return one()
 
         def finish(handle):
             if pipe is None:
                 return handle
             pipe.flush()
             return pipe.result(handle) if handle is not None else None    # the last decision (and all earlier ones) is complete
-        return timed_scorer_loop(step, finish, steps, warmup, dev, dist)
+        return timed_scorer_loop(step, finish, steps, warmup, dev, dist, streams)
 
     # ---- (A) weak scaling: every rank its own shard of C cameras out of world*C -------------------------------------------
     pts, harm, cams = make_inputs(N, C, 1234, dev, cam_offset=rank * C, n_cam_total=world * C)
@@ -793,7 +809,11 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_source,
                 "hbm_algorithmic_GBs": N * BYTES_PER_POINT / (kern_ms * 1e-3) / 1e9,
                 "step_device_ms": step_ms, "step_achieved": alg_flop / (step_ms * 1e-3) / 1e12,
-                "step_frac": alg_flop / (step_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
+                "step_frac": alg_flop / (step_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                "step_meaning": f"device time of the timed region / steps, with the steps issued on {args.streams} stream(s): with two steps in "
+                                "flight the gain kernels overlap each other's ramp and tail and the reduce launches, so a step costs less than "
+                                "the kernel ALONE (device_ms_per_launch, what `achieved` / `frac` price); step_frac counts the reference "
+                                "formulation's flop and may pass 1 (the kernel executes fewer instructions: executed_valu_frac)"}
         if valu:
             # wave-level vector instructions issued per launch (PMC) x 2 cycles each (a SIMD retires 32 fp32 lanes per cycle:
             # 157.3 TFLOP/s = 1024 SIMDs x 2.4 GHz x 64 flop) / (SIMDs x kernel cycles at 2.4 GHz)
@@ -809,7 +829,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"scorer: B=1 cloud x N={N} points x C={C} cameras per GPU "
                                    f"(BASELINE headline 100k pts / 200 cams), inputs resident in HBM",
-                       "points": N, "cams_per_gpu": C, "parallelism": f"camera-shard x{world}", "entry": scorer_entry},
+                       "points": N, "cams_per_gpu": C, "parallelism": f"camera-shard x{world}", "entry": scorer_entry,
+                       "streams": args.streams},
             "ranks_seen": ranks_seen,
             "roofline": roof,
             "scorer_strong": strong,

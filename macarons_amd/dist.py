@@ -174,9 +174,13 @@ class PipelinedBest:
     than the 90 us scoring pass it follows.  `depth` batches may be in flight; every slot owns its buffers, so nothing is
     allocated (or freed across streams) inside the loop."""
 
-    def __init__(self, B, device, group=None, batch=8, depth=3):
+    def __init__(self, B, device, group=None, batch=8, depth=3, producers=()):
+        """producers (optional): the streams decisions are submitted from when there is more than one (independent decisions scored
+        round-robin on several streams): a batch's exchange then waits for all of them, not only for the stream of the submit that
+        filled it."""
         from . import ops
         self._ops, self.group, self.depth, self.batch, self.B = ops, group, depth, batch, B
+        self.producers = tuple(producers)
         self.world = dist.get_world_size(group)
         self.comm = torch.cuda.Stream(device=device)
         mk = lambda *shape, dtype=torch.float32: torch.empty(shape, dtype=dtype, device=device)
@@ -188,8 +192,9 @@ class PipelinedBest:
     def submit(self, gains, idx_offset):
         """Queue the exchange for `gains` [B, C_local] (produced on the current stream); returns a handle for result()."""
         s = self.slots[self._cur]
-        if s["fill"] == 0 and s["used"]:
+        if s["used"] and (s["fill"] == 0 or self.producers):
             torch.cuda.current_stream(gains.device).wait_event(s["done"])   # its previous exchange has consumed the send buffer
+            # (several producer streams: every one of them writes into the slot, so every submit waits)
         j = s["fill"]
         self._ops.best_record(gains, idx_offset, out=s["send"][j])
         s["fill"] = j + 1
@@ -205,7 +210,11 @@ class PipelinedBest:
         dev = s["send"].device
         if n < self.batch:
             s["send"][n:].zero_()                            # a short last batch: defined bytes on the wire
-        s["ready"].record(torch.cuda.current_stream(dev))
+        cur = torch.cuda.current_stream(dev)
+        for p in self.producers:                             # records written on the other scoring streams
+            if p != cur:
+                cur.wait_stream(p)
+        s["ready"].record(cur)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(s["ready"])
             all_gather_into(s["recv"].view(-1), s["send"].view(-1), self.group)

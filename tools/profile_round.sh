@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd $R && python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats -o bench -- python $R/bench.py --steps 500 --warmup 100 --no-cpu-baseline --nbv-iters 20 > $OUT/kstats.log 2>&1
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_scorer -o bench -- python $R/bench.py --steps 500 --warmup 100 --no-cpu-baseline --no-nbv --no-strong > $OUT/kstats_scorer.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_scorer -o bench -- python $R/bench.py --steps 500 --warmup 100 --no-cpu-baseline --no-nbv --no-strong --streams 1 > $OUT/kstats_scorer.log 2>&1
 rm -rf $OUT/ktrace; timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/ktrace -o t -- python $R/tools/run_nbv_steps.py 40 > $OUT/ktrace.log 2>&1
 T=$(find $OUT/ktrace -name "*kernel_trace.csv" | head -1)
 python $R/tools/step_breakdown.py $T > $OUT/nbv_step_breakdown.txt 2>&1
