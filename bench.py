@@ -601,21 +601,26 @@ def timed_scorer_loop(step, finish, steps, warmup, dev, dist, streams=None):
     for _ in range(steps):
         out = step()
     out = finish(out)
-    for st in streams or ():                                # steps issued on side streams: the closing event sits behind all of them
-        torch.cuda.current_stream(dev).wait_stream(st)
+    # steps issued on side streams: one closing event per stream (a join on the current stream costs a cross-stream wait of tens of
+    # microseconds after the last kernel); the device time of the region ends with the latest of them
+    ends = [ev1]
     ev1.record()
+    for st in streams or ():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(st)
+        ends.append(e)
     if os.environ.get("MCR_BENCH_SPIN_SYNC", "1") != "0":
         # hipDeviceSynchronize may put the host thread to sleep and be woken by an interrupt tens of microseconds after the last kernel
-        # retired -- 5 us per step of a 20-step run; polling the event notices the end within a microsecond, the synchronize behind it
+        # retired -- 5 us per step of a 20-step run; polling the events notices the end within a microsecond, the synchronize behind it
         # (still there: the contract's bracket) then returns at once
-        while not ev1.query():
+        while not all(e.query() for e in ends):
             pass
     torch.cuda.synchronize()
     if dist is not None:                                    # (one rank: the synchronize above already is the closing bracket)
         dist.barrier()
         torch.cuda.synchronize()
     wall = max_over_ranks(time.perf_counter() - t0, dev, dist)
-    return wall, ev0.elapsed_time(ev1), out
+    return wall, max(ev0.elapsed_time(e) for e in ends), out
 
 
 def main():
@@ -695,6 +700,7 @@ def main():
         # and stream-ordered on its own stream (fresh outputs and scratch from the stream-aware allocator): the reduce / record launch of
         # one step runs beside the gain kernel of the next, and two gain kernels fill each other's ramp and tail (43 us per step against
         # 56 on one stream; --streams 1 is the one-stream figure)
+        # (side streams only: with the current -- default -- stream as one of the two, short runs measured erratically)
         streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
         pipe = mdist.PipelinedBest(1, dev, batch=16, depth=3, producers=streams or ()) if dist is not None else None
         issued = [0]
