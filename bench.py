@@ -695,13 +695,18 @@ def main():
         scorer_entry = "macarons_amd.ops.sh_coverage_gain_best (ctypes -> mcr_sh_coverage_gain_best)"
         score_best = lambda p_, h_, c_: ops.sh_coverage_gain_best(p_, h_, c_, True, args.waves_per_simd)
 
+    scorer_streams = []
+
     def scorer_run(pts, harm, cams, cam_offset, steps, warmup):
         # --streams S (default 2): consecutive steps are independent batches and are issued round-robin on S streams, each step whole
         # and stream-ordered on its own stream (fresh outputs and scratch from the stream-aware allocator): the reduce / record launch of
         # one step runs beside the gain kernel of the next, and two gain kernels fill each other's ramp and tail (43 us per step against
         # 56 on one stream; --streams 1 is the one-stream figure)
-        # (side streams only: with the current -- default -- stream as one of the two, short runs measured erratically)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+        # (side streams only: with the current -- default -- stream as one of the two, short runs measured erratically; ONE set of
+        # streams for every leg: a second pair, created for the strong leg, shared a hardware queue and its steps did not overlap)
+        if args.streams > 1 and not scorer_streams:
+            scorer_streams.extend(torch.cuda.Stream(device=dev) for _ in range(args.streams))
+        streams = scorer_streams if args.streams > 1 else None
         pipe = mdist.PipelinedBest(1, dev, batch=16, depth=3, producers=streams or ()) if dist is not None else None
         issued = [0]
 

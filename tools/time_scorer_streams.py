@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import macarons_amd.torch_ops  # noqa: F401
 dev = torch.device("cuda:0")
-pts, harm, cams = bench.make_inputs(100_000, 200, 1234, dev)
+C = int(os.environ.get("CAMS", "200"))
+pts, harm, cams = bench.make_inputs(100_000, C, 1234, dev)
 f = lambda: torch.ops.macarons.sh_coverage_gain_best(pts, harm, cams, True)
 for _ in range(1500):
     f()
@@ -25,4 +26,4 @@ for ns in (1, 2, 3, 1, 2):
                 out = f()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(f"{ns} stream(s), {K} steps: {dt / K * 1e6:.2f} us per step  ->  {200 * K / dt / 1e6:.3f} M evals/s")
+        print(f"{ns} stream(s), {K} steps: {dt / K * 1e6:.2f} us per step  ->  {C * K / dt / 1e6:.3f} M evals/s")
