@@ -259,7 +259,8 @@ class SconeOcc(RangeGuard, nn.Module):
             """-> (seg [total], rank-sorted local index [total]): position off_j + r holds the r-th element of a random permutation of
             [0, len_j).  Composite key = segment + uniform in [0, 1) in float64 (no collisions worth a bias), one sort."""
             seg = torch.repeat_interleave(torch.arange(J, device=device), lens, output_size=total)
-            order = torch.argsort(seg.double() + torch.rand(total, dtype=torch.float64, device=device))
+            u = torch.rand(total, dtype=torch.float64, device=device).clamp_(max=1.0 - 2.0 ** -30)   # seg + u never rounds up to seg + 1
+            order = torch.argsort(seg.double() + u)
             return seg, order - offs[seg]
         T0, T1, T2 = int(o0[-1]), int(o1[-1]), int(o2[-1])
         seg0, loc0 = seg_perm(d_m0, d_o0, T0)                                   # global down-sample: randperm(M)[:Lg]
