@@ -5,6 +5,7 @@ P=${1:?round prefix}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/round
 cp $O/bench.json $R/profiles/${P}_bench_full.json
+[ -s $O/bench_driver_cmd.json ] && cp $O/bench_driver_cmd.json $R/profiles/${P}_bench_driver_cmd.json
 cp $(find $O/kstats -name "*kernel_stats.csv" | head -1) $R/profiles/${P}_bench_kernel_stats.csv
 cp $(find $O/kstats_scorer -name "*kernel_stats.csv" | head -1) $R/profiles/${P}_scorer_only_kernel_stats.csv
 cp $O/nbv_step_breakdown.txt $R/profiles/${P}_nbv_step_breakdown.txt

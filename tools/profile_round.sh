@@ -6,6 +6,7 @@ R=/root/repo
 OUT=$R/gpurun_out/round
 mkdir -p $OUT
 cd $R && python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+cd $R && python bench.py --gpus 1 --steps 20 --warmup 5 2> $OUT/bench_driver_cmd.err | tail -1 > $OUT/bench_driver_cmd.json   # the driver's own command line
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats -o bench -- python $R/bench.py --steps 500 --warmup 100 --no-cpu-baseline --nbv-iters 20 > $OUT/kstats.log 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_scorer -o bench -- python $R/bench.py --steps 500 --warmup 100 --no-cpu-baseline --no-nbv --no-strong --streams 1 > $OUT/kstats_scorer.log 2>&1
