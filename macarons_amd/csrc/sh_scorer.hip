@@ -43,7 +43,10 @@ __device__ __forceinline__ constexpr int shk(int l, int m) { return l * l + l + 
 // = 49 Horner FMAs + 24 ops for the powers + 14 to combine + 7 to normalise: 94 VALU ops per (point, camera) pair --
 // the floor for 64 per-point coefficients (the rescaled-recurrence form this replaces needed 130).
 // Measured on MI355X (tools/ubench): a dependent v_fma_f32 chain issues every ~8.8 cycles per wave; the 15 Horner
-// chains are independent; v_pk_fma_f32 is half rate and buys nothing.
+// chains are independent.  A packed form ((U_m, V_m) as ONE v_pk_fma_f32 chain per order, the powers as a packed complex
+// multiply: 70 instead of 106 vector instructions per pair) was built and measured (sh_dot_pk_rate.hip, NOTES): a packed
+// instruction costs two scalar ones in this stream -- sh_dot alone 295 -> 275 cycles per pair and SIMD at 6 waves, the kernel
+// 50.3 -> 50.0 us at 84 instead of 80 VGPRs -- so the scalar form stays.
 __device__ __forceinline__ float sh_dot(float dx, float dy, float dz, const float (&a)[64]) {
     const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const float ir = __builtin_amdgcn_rsqf(r2);

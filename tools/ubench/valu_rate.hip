@@ -1,4 +1,6 @@
 // Micro-benchmark: issue rate of v_fma_f32 vs v_pk_fma_f32 on gfx950 at several occupancies / ILP.
+// READ WITH CARE: at ILP >= 4 hipcc SLP-packs the independent scalar FMAs of the "fma" rows into v_pk_fma_f32 (check the ISA):
+// only the ILP = 1 "fma" rows are scalar instructions.
 // Build: hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
