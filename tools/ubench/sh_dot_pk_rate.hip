@@ -1,5 +1,5 @@
 // Micro-benchmark: pure-compute rate of sh_dot (no memory traffic), scalar-FMA form vs the packed form (-DSC_PK=1), at several
-// occupancies.  Build twice: hipcc --offload-arch=gfx950 -O3 -ffp-contract=fast [-DSC_PK=1] sh_dot_pk_rate.hip -o sh_dot_pk_rate[_pk]
+// occupancies (and -DNC=2/3: that many cameras side by side).  Build twice: hipcc --offload-arch=gfx950 -O3 -ffp-contract=fast [-DSC_PK=1] sh_dot_pk_rate.hip -o sh_dot_pk_rate[_pk]
 #include "../../macarons_amd/csrc/sh_scorer.hip"
 #include "../../macarons_amd/csrc/errors.hip"
 #include <stdio.h>
@@ -31,12 +31,54 @@ __device__ __forceinline__ float sh_dot_pk(float dx, float dy, float dz, const f
     }
     return z + (acc.x + acc.y);
 }
-#ifdef SC_PK
+
+// The powers form: every polynomial as a sum over precomputed powers of cos(polar) so that all but one multiply-add of the stream is
+// a two-address v_fmac_f32 / v_mul_f32 (32-bit VOP2 encoding); Horner needs the three-address v_fma_f32 (64-bit VOP3 encoding).
+__device__ __forceinline__ float sh_dot_pw(float dx, float dy, float dz, const float (&a)[64]) {
+    const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const float ir = __builtin_amdgcn_rsqf(r2);
+    const float nx = dx * ir, ct = dy * ir, nz = dz * ir;
+    float xp[8];
+    xp[1] = ct; xp[2] = ct * ct; xp[3] = xp[2] * ct; xp[4] = xp[2] * xp[2]; xp[5] = xp[3] * xp[2]; xp[6] = xp[3] * xp[3]; xp[7] = xp[4] * xp[3];
+    float z = fmaf(ct, a[shk(1, 0)], a[shk(0, 0)]);
+#pragma unroll
+    for (int k = 2; k < 8; ++k) z = fmaf(a[shk(k, 0)], xp[k], z);
+    float mnx = -nx;
+    asm volatile("" : "+v"(mnx));            // a value of its own: folded into the multiply as a modifier it needs the 64-bit encoding
+    float cm = nz, sm = nx;
+#pragma unroll
+    for (int m = 1; m < 8; ++m) {
+        if (m < 7) {
+            float U = a[shk(m + 1, m)] * xp[1], V = a[shk(m + 1, -m)] * xp[1];
+#pragma unroll
+            for (int k = 2; k + m < 8; ++k) {
+                U = fmaf(a[shk(m + k, m)], xp[k], U);
+                V = fmaf(a[shk(m + k, -m)], xp[k], V);
+            }
+            z = fmaf(cm, U, z);
+            z = fmaf(sm, V, z);
+        }
+        z = fmaf(cm, a[shk(m, m)], z);
+        z = fmaf(sm, a[shk(m, -m)], z);
+        if (m < 7) {
+            float cn = mnx * sm, sn = nx * cm;
+            cn = fmaf(nz, cm, cn); sn = fmaf(nz, sm, sn);
+            cm = cn; sm = sn;
+        }
+    }
+    return z;
+}
+#if defined(SC_PW)
+#define SH_DOT sh_dot_pw
+#elif defined(SC_PK)
 #define SH_DOT sh_dot_pk
 #else
 #define SH_DOT sh_dot
 #endif
 
+#ifndef NC
+#define NC 1              // cameras evaluated side by side per iteration (independent dot products for the scheduler to interleave)
+#endif
 __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
     float hs[64];
     for (int i = 0; i < 64; ++i) hs[i] = seed * (i + 1) + threadIdx.x * 1e-4f;
@@ -44,10 +86,14 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
     for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(hs[i]));
     float acc = 0.f;
     const float px = threadIdx.x * 1e-3f, py = 0.1f, pz = -0.2f;
-    for (int it = 0; it < iters; ++it) {
-        float z = SH_DOT(1.5f + it * 1e-3f - px, 0.3f - py, 1.f - pz + it * 1e-4f, hs);
-        asm volatile("" : "+v"(z));
-        acc += z;
+    for (int it = 0; it < iters; it += NC) {
+        float z[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) z[c] = SH_DOT(1.5f + (it + c) * 1e-3f - px, 0.3f + c - py, 1.f - pz + (it + c) * 1e-4f, hs);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(z[c]));
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc += z[c];
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
@@ -72,10 +118,12 @@ void run(int blocks_per_cu) {
 }
 
 int main() {
-#ifdef SC_PK
-    printf("packed form\n");
+#if defined(SC_PW)
+    printf("powers form, NC=%d\n", NC);
+#elif defined(SC_PK)
+    printf("packed form, NC=%d\n", NC);
 #else
-    printf("scalar form\n");
+    printf("scalar form, NC=%d\n", NC);
 #endif
     for (int bpc : {1, 2, 3, 4, 5, 6}) run(bpc);
     return 0;
