@@ -580,13 +580,19 @@ def self_launch(args):
 def timed_scorer_loop(step, finish, steps, warmup, dev, dist, streams=None):
     """W untimed + exactly `steps` timed calls of step(), bracketed by barrier + synchronize on both sides; returns
     (wall seconds = max over ranks, device ms between HIP events on the launch stream)."""
-    for _ in range(warmup):
-        step()
     # The W warm-up steps of a short run (the driver's --steps 20 --warmup 5 = 0.3 ms of GPU work) end before the shader clock has
-    # left its idle state: 1000 more UNTIMED steps (>= 50 ms of GPU work) follow, so that the K timed steps measure the kernel and not
-    # the clock ramp.  A FIXED count: every rank must submit the same number of decisions to the exchange (a time-based loop ran a
+    # left its idle state: 1000 more UNTIMED steps (>= 50 ms of GPU work) come first, so that the K timed steps measure the kernel and
+    # not the clock ramp.  A FIXED count: every rank must submit the same number of decisions to the exchange (a time-based loop ran a
     # different number of steps on each rank, their record batches fell out of step and the ranks met in different collectives).
     for _ in range(1000):
+        step()
+    torch.cuda.synchronize()
+    # ... and the W warm-up steps proper run LAST, behind that burst's synchronize: the FIRST operation submitted after the synchronize
+    # that ends a long burst costs the host 250-350 us, once, whatever it is (a step, a lone event record: tools/time_scorer_short2.py).
+    # That is the untimed burst's cost; with the burst last it landed on the first timed launch (60 us per step at 20 steps instead
+    # of 47-49).  (W = 0: an event record takes the place of the warm-up steps.)
+    torch.cuda.Event(enable_timing=True).record()
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     finish(None)
