@@ -7,7 +7,7 @@
 // which materialise [B*C*N,64] SH tensors three times.  Here: one lane owns one point (its 64 SH
 // coefficients live in VGPRs, turned once into the monomial coefficients of 15 polynomials in cos(polar)), cameras
 // come from wave-uniform scalar loads, the dot with the 64 real SH of the ray direction is evaluated trig-free by
-// Horner steps (94 VALU ops per (point,camera) pair, 106 with activation and reduction), sigmoid/relu applied, and the per-camera sum over points
+// Horner steps (82 VALU ops per (point,camera) pair, 94 with activation and reduction), sigmoid/relu applied, and the per-camera sum over points
 // is a wave64 DPP reduction -> per-wave-tile partials -> a deterministic second-pass reduce (bit-stable
 // run to run).  Bound: fp32 VALU (370 algorithmic flop / pair; N*268 B of HBM per cloud).
 //
@@ -40,38 +40,39 @@ __device__ __forceinline__ constexpr int shk(int l, int m) { return l * l + l + 
 // ONE polynomial per (m, cos|sin):  U_m(x) = sum_k a[m+k,+m] x^k,  V_m(x) = sum_k a[m+k,-m] x^k, whose coefficients
 // a (64 per point, same storage as the SH coefficients) are produced once per point by to_mono_coeffs.  Then
 //   z = U_0(x) + sum_{m>=1} ( Re w^m U_m(x) + Im w^m V_m(x) ),   w = n_z + i n_x
-// = 49 Horner FMAs + 24 ops for the powers + 14 to combine + 7 to normalise: 94 VALU ops per (point, camera) pair --
-// the floor for 64 per-point coefficients (the rescaled-recurrence form this replaces needed 130).
+// and the sum over the orders is itself a Horner evaluation, in w over the complex numbers (below): 49 Horner FMAs in x
+// + 24 for the six complex steps + 2 for the last real part + 7 to normalise = 82 VALU ops per (point, camera) pair (94 in the
+// gain kernel's loop with the ray, the activation and the wave reduction).  The form this replaces kept the powers w^m
+// (4 ops per order) and combined cm U_m + sm V_m into z (2 per order, a serial 14-step chain): 94 / 106 ops, gain kernel
+// 50.4 -> 46.5 us at N = 100k, C = 200 (results 1.2e-7 apart); the rescaled-recurrence form before that needed 130.
 // Measured on MI355X (tools/ubench): a dependent v_fma_f32 chain issues every ~8.8 cycles per wave; the 15 Horner
-// chains are independent.  A packed form ((U_m, V_m) as ONE v_pk_fma_f32 chain per order, the powers as a packed complex
-// multiply: 70 instead of 106 vector instructions per pair) was built and measured (sh_dot_pk_rate.hip, NOTES): a packed
-// instruction costs two scalar ones in this stream -- sh_dot alone 295 -> 275 cycles per pair and SIMD at 6 waves, the kernel
-// 50.3 -> 50.0 us at 84 instead of 80 VGPRs -- so the scalar form stays.
+// chains are independent.  A packed form ((U_m, V_m) as ONE v_pk_fma_f32 chain per order: 70 instead of 106 vector
+// instructions per pair) was built and measured (sh_dot_pk_rate.hip, NOTES): a packed instruction costs two scalar ones in
+// this stream -- sh_dot alone 295 -> 275 cycles per pair and SIMD at 6 waves, the kernel 50.3 -> 50.0 us -- not kept.
+// z = U_0(x) + Re( sum_{m>=1} w^m (U_m - i V_m) ): the sum over the orders as ONE complex Horner evaluation in w
+//   A_7 = P_7,  A_m = A_{m+1} w + P_m  (m = 6..1),  z = U_0 + Re(w A_1),   P_m = U_m(x) - i V_m(x),  A = ar - i bi
+// -- 4 FMAs per order instead of 4 for the power w^m and 2 to combine, and no serial 14-step accumulation into z.
 __device__ __forceinline__ float sh_dot(float dx, float dy, float dz, const float (&a)[64]) {
     const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     const float ir = __builtin_amdgcn_rsqf(r2);
     const float nx = dx * ir, ct = dy * ir, nz = dz * ir;
-
     float z = a[shk(7, 0)];
 #pragma unroll
     for (int l = 6; l >= 0; --l) z = fmaf(ct, z, a[shk(l, 0)]);
-    float cm = nz, sm = nx;                     // (n_z + i n_x)^m
+    float ar = a[shk(7, 7)], bi = a[shk(7, -7)];
 #pragma unroll
-    for (int m = 1; m < 8; ++m) {
+    for (int m = 6; m >= 1; --m) {
         float U = a[shk(7, m)], V = a[shk(7, -m)];
 #pragma unroll
         for (int l = 6; l >= m; --l) {
             U = fmaf(ct, U, a[shk(l, m)]);
             V = fmaf(ct, V, a[shk(l, -m)]);
         }
-        z = fmaf(cm, U, z);
-        z = fmaf(sm, V, z);
-        if (m < 7) {
-            const float cn = fmaf(nz, cm, -nx * sm), sn = fmaf(nz, sm, nx * cm);
-            cm = cn; sm = sn;
-        }
+        const float nr = fmaf(ar, nz, fmaf(bi, nx, U));
+        const float nb = fmaf(bi, nz, fmaf(-ar, nx, V));
+        ar = nr; bi = nb;
     }
-    return z;
+    return fmaf(nz, ar, fmaf(nx, bi, z));
 }
 
 // One point's 64 SH coefficients -> VGPRs as the monomial coefficients of its 15 polynomials in cos(polar):

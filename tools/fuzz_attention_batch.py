@@ -15,12 +15,17 @@ for it in range(int(os.environ.get("N", 40))):
     if rng.random() < 0.3:
         b, t = int(rng.integers(S)), int(rng.integers(L))
         qkv[b, t:t + 7, 2 * qk:] *= 1e6
-    big = ops.attention_packed(qkv, H, qk, v)
+    big = ops.attention_packed(qkv, H, qk, v, split=False)
+    big_split = ops.attention_packed(qkv, H, qk, v)           # small batches of long sequences split their keys (the kernel's predicate)
     for b in {0, S - 1, int(rng.integers(S))}:
         one = ops.attention_packed(qkv[b:b + 1].contiguous(), H, qk, v, split=False)
         if not torch.equal(one[0], big[b]):
             n_bad += 1
             print("MISMATCH", it, (S, L, qk, v), b, float((one[0] - big[b]).abs().max()))
+        err = float(((one[0] - big_split[b]).abs() / one[0].abs().clamp(min=1.0)).max())
+        if not err <= 5e-6:                                   # the key split: within rounding of the unsplit result
+            n_bad += 1
+            print("SPLIT MISMATCH", it, (S, L, qk, v), b, err)
     if not torch.isfinite(big).all():
         n_bad += 1; print("non-finite", it)
 print("fuzz_attention_batch:", "OK" if n_bad == 0 else f"{n_bad} FAILURES")
