@@ -229,13 +229,19 @@ int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global
 int mcr_local_pct_blob_floats(void);
 int mcr_local_pct3_blob_floats(void);
 int mcr_local_pct6_blob_floats(void);
+int mcr_local_pct7_blob_floats(void);
 /* Kernel variant behind mcr_local_pct_forward / the fused path of mcr_scone_occ_forward.  The blob must have been packed
  * for the selected variant (macarons_amd/networks/packing.py):
  *   1: exact-fp32 MFMA, one workgroup/CU (local_pct.hip; mcr_local_pct_blob_floats() floats);
  *   5: split precision, every fp32 operand as exact bf16 hi/mid/lo, six MFMAs per product, two workgroups per CU, valid
  *      for the whole fp32 range (local_pct5.hip; mcr_local_pct3_blob_floats() floats);
  *   6 (default): two-term fp16 split (hi + lo, 22 significant bits), three MFMAs per product, same structure
- *      (local_pct6.hip; mcr_local_pct6_blob_floats() floats); needs |activation| < 65504. */
+ *      (local_pct6.hip; mcr_local_pct6_blob_floats() floats); needs |activation| < 65504;
+ *   7 (OPT-IN, per call only: mcr_call_variant(7); mcr_set_local_pct_variant refuses it): BASELINE.json config 3's 16-bit matrix
+ *      path -- ONE fp16 plane per matrix operand, one MFMA per product, fp32 accumulation; LayerNorm statistics, soft-max, GELU,
+ *      pooling, SH math and every reduction stay fp32 (local_pct7.hip; mcr_local_pct7_blob_floats() floats; the SconeOcc head's
+ *      planes GEMMs read the high planes alone).  NOT within the 1e-4 of variants 1 / 5 / 6: occupancies within 2e-3 relative
+ *      (measured, tests/test_variant7_gpu.py); same range rule as variant 6. */
 /* The variant is a property of a CALL: mcr_call_variant(v) is the per-call argument -- the NEXT network entry point (mcr_linear,
  * mcr_attention*, mcr_local_pct_forward, mcr_pc_transformer_forward, mcr_scone_vis_forward, mcr_scone_occ_forward*) called on THIS
  * thread runs on variant v (one-shot, thread-local; 0 = the default again).  mcr_set_local_pct_variant only sets the process DEFAULT

@@ -59,7 +59,10 @@ __device__ __forceinline__ f32x16 mfma_u(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int MODE, bool SMALL = false>
+// NP = 2: hi / lo planes, three MFMAs per product (variant 6).  NP = 1 (variant 7, the opt-in 16-bit matrix path): the HIGH planes
+// alone -- one MFMA per product, half the DMA bytes and fragment reads; Xl / Wl / Yl are never touched (the LDS image keeps the
+// two-plane stage layout, its low halves stay unused) and a planes epilogue rounds once (v_cvt_pk_f16_f32) instead of splitting.
+template <int MODE, bool SMALL = false, int NP = 2>
 __global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_kernel(const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, long long ldx,
                                                           const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, long long ldw,
                                                           const float* __restrict__ bias, const float* __restrict__ row_bias,
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_ker
     constexpr int LP_XC = LP_TM * 4, LP_WC = LP_TN * 4;                                       // 16-byte chunks per X / W tile and plane
     constexpr int GX = LP_XC / (NW * 64), GW = LP_WC / (NW * 64);                             // DMA chunk groups (64 chunks) per wave and plane
     constexpr int STAGE = 2 * LP_XC + 2 * LP_WC, STAGES = SMALL ? LPS_STAGES : LP_STAGES;     // chunks per stage; stages
-    constexpr int PER = 2 * (GX + GW);                                                        // DMA instructions per wave and chunk
+    constexpr int PER = NP * (GX + GW);                                                       // DMA instructions per wave and chunk
     constexpr bool PLANES_OUT = MODE == LP_PLANES;
     extern __shared__ __attribute__((aligned(16))) uint4 S[];                     // [stage][Xh | Xl | Wh | Wl]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_ker
     auto stage = [&](int st, int k0) {                     // 6 DMA instructions per wave
         uint4* b = S + st * STAGE;
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
+        for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
             for (int g = 0; g < GX; ++g)
                 __builtin_amdgcn_global_load_lds((lp_gptr)(sx[g][pl] + k0), (lp_lptr)(b + pl * LP_XC + (GX * wave + g) * 64), 16, 0, 0);
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_ker
         aw[s_] = lds0 + (unsigned)((2 * LP_XC + (wn * 32 + i) * 4 + cs) * 16);
     }
     const int n_chunks = K / LP_BK;
-    static_assert(PER == 6 || PER == 8, "the counted waits below are written for 6 or 8 DMA instructions per chunk");
+    static_assert(PER == 6 || PER == 8 || PER == 3 || PER == 4, "the counted waits below are written for 3, 4, 6 or 8 DMA instructions per chunk");
     stage(0, 0);
     if (STAGES == 3 && n_chunks > 1) stage(1, LP_BK);
     for (int kc = 0; kc < n_chunks; ++kc) {
@@ -149,13 +152,33 @@ __global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_ker
         // Three stages: the DMA runs two chunks ahead (chunk kc + 1 may stay in flight); two stages: one chunk ahead.
         if (STAGES == 3 && kc + 1 < n_chunks) {
             if (PER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (PER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (PER == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
         if (kc + STAGES - 1 < n_chunks) stage((kc + STAGES - 1) % STAGES, (kc + STAGES - 1) * LP_BK);
         const unsigned sb = (unsigned)((kc % STAGES) * STAGE * 16);
+        if (NP == 1) {
+            u32x4 w1[2], x1[2][4];
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const unsigned pw = aw[s_] + sb, px = ax[s_] + sb;
+                w1[s_] = lds_read<0>(pw);
+                x1[s_][0] = lds_read<0 * 2048>(px); x1[s_][1] = lds_read<1 * 2048>(px);
+                x1[s_][2] = lds_read<2 * 2048>(px); x1[s_][3] = lds_read<3 * 2048>(px);
+            }
+            asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(w1[0]), "+v"(x1[0][0]), "+v"(x1[0][1]), "+v"(x1[0][2]), "+v"(x1[0][3]));
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                if (s_ == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w1[1]), "+v"(x1[1][0]), "+v"(x1[1][1]), "+v"(x1[1][2]), "+v"(x1[1][3]));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = mfma_u(w1[s_], x1[s_][t], acc[t]);
+            }
+            continue;
+        }
         u32x4 w_hi[2], w_lo[2], x_hi[2][4], x_lo[2][4];
 #pragma unroll
         for (int s_ = 0; s_ < 2; ++s_) {
@@ -231,7 +254,7 @@ __global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_ker
     // row: 4 lanes per bank pair, the minimum for 64 x 8 bytes) and leaves in whole rows: 16 lanes x 16 bytes = the 256 bytes of a row
     // and plane, four rows per store instruction.  Same values, same bits.
     constexpr int TR_THREADS = NW * 64;
-    if (MODE == LP_PLANES && N % 8 == 0 && ldy % 8 == 0 && (((size_t)Yh | (size_t)Yl) & 15) == 0) {
+    if (MODE == LP_PLANES && N % 8 == 0 && ldy % 8 == 0 && (((size_t)Yh | (NP == 2 ? (size_t)Yl : 0)) & 15) == 0) {
         __syncthreads();
         char* tb = reinterpret_cast<char*>(S);
 #pragma unroll
@@ -254,19 +277,23 @@ __global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_ker
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y[e] = l3_gelu(y[e]);
                 }
-                uint2 hi, lo;
-                split2h(y[0], y[1], hi.x, lo.x);
-                split2h(y[2], y[3], hi.y, lo.y);
                 const int u = 8 * wn + 2 * g + h;
                 const int off = row * 256 + ((u ^ ((row & 15) << 1)) << 3);
-                *reinterpret_cast<uint2*>(tb + off) = hi;
-                *reinterpret_cast<uint2*>(tb + LP_TM * 256 + off) = lo;
+                if (NP == 1) {
+                    *reinterpret_cast<uint2*>(tb + off) = make_uint2(pack2h(y[0], y[1]), pack2h(y[2], y[3]));
+                } else {
+                    uint2 hi, lo;
+                    split2h(y[0], y[1], hi.x, lo.x);
+                    split2h(y[2], y[3], hi.y, lo.y);
+                    *reinterpret_cast<uint2*>(tb + off) = hi;
+                    *reinterpret_cast<uint2*>(tb + LP_TM * 256 + off) = lo;
+                }
             }
         }
         __syncthreads();
         constexpr int RPP = TR_THREADS / 16, PASSES = LP_TM / RPP;            // rows per pass; passes per plane
 #pragma unroll
-        for (int q = 0; q < 2 * PASSES; ++q) {
+        for (int q = 0; q < NP * PASSES; ++q) {
             const int pl = q / PASSES, r = (q % PASSES) * RPP + (tid >> 4), pp = tid & 15;
             const uint4 v = *reinterpret_cast<const uint4*>(tb + pl * (LP_TM * 256) + r * 256 + ((pp ^ (r & 15)) << 4));
             const long long m = m0 + r;
@@ -338,7 +365,9 @@ __global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_ker
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = l3_gelu(y[e]);
             }
-            if (PLANES_OUT) {
+            if (PLANES_OUT && NP == 1) {
+                *reinterpret_cast<uint2*>(Yh + m * ldy + n) = make_uint2(pack2h(y[0], y[1]), pack2h(y[2], y[3]));
+            } else if (PLANES_OUT) {
                 uint2 hi, lo;
                 split2h(y[0], y[1], hi.x, lo.x);
                 split2h(y[2], y[3], hi.y, lo.y);
@@ -367,7 +396,7 @@ __global__ void split_to_planes_kernel(const float* __restrict__ X, long long ld
     split2h(v.x, v.y, hi.x, lo.x);
     split2h(v.z, v.w, hi.y, lo.y);
     *reinterpret_cast<uint2*>(Ph + m * ldp + c) = hi;
-    *reinterpret_cast<uint2*>(Pl + m * ldp + c) = lo;
+    if (Pl) *reinterpret_cast<uint2*>(Pl + m * ldp + c) = lo;          // (NULL: the single-plane variant 7 keeps fp16(x) alone)
 }
 
 // ---- ONE-SHOT form for a few thousand rows (one cloud of 2048 tokens through an encoder: 48 ... 256 blocks of the pipelined forms, each
@@ -379,7 +408,7 @@ __global__ void split_to_planes_kernel(const float* __restrict__ X, long long ld
 // XOR-swizzled by the row (conflict-free ds_read_b128 of one chunk column over 32 rows), applied on the DMA's source address.
 constexpr int LPO_T = 64, LPO_KS = 256;                                   // tile edge; k per shot
 constexpr int LPO_LDS_BYTES = 4 * LPO_T * LPO_KS * 2;                     // Xh | Xl | Wh | Wl = 131 072
-template <int MODE>
+template <int MODE, int NP = 2>
 __global__ __launch_bounds__(256, 1) void linear3p_once_kernel(const _Float16* __restrict__ Xh, const _Float16* __restrict__ Xl, long long ldx,
                                                                const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, long long ldw,
                                                                const float* __restrict__ bias, float* __restrict__ Y, _Float16* __restrict__ Yh,
@@ -403,8 +432,8 @@ __global__ __launch_bounds__(256, 1) void linear3p_once_kernel(const _Float16* _
         const int plane = LPO_T << csh;                                     // chunks per plane
         if (k0) __syncthreads();                                            // (the previous shot's fragments are consumed)
         // DMA: 64 chunks per wave instruction; position p of a plane = (row = p / cpr, c' = p % cpr) receives the row's chunk c' ^ (row & (cpr - 1))
-        for (int q = wave; q < 4 * cpr; q += 4) {                          // (a plane is cpr instructions)
-            const int pl = q >> csh, p = (q & (cpr - 1)) * 64 + lane;
+        for (int q = wave; q < 2 * NP * cpr; q += 4) {                     // (a plane is cpr instructions; NP == 1: the two high planes)
+            const int pl = NP == 2 ? q >> csh : (q >> csh) * 2, p = (q & (cpr - 1)) * 64 + lane;
             const int row = p >> csh, c = (p & (cpr - 1)) ^ (row & (cpr - 1));
             const _Float16* src;
             if (pl < 2) src = (pl ? Xl : Xh) + min(m0 + row, M - 1) * ldx + k0 + c * 8;       // rows beyond the matrix repeat its last row
@@ -421,12 +450,15 @@ __global__ __launch_bounds__(256, 1) void linear3p_once_kernel(const _Float16* _
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int c = (2 * (4 * st4 + u) + h) ^ key;
-                xh[u] = sx_h[c]; xl[u] = sx_h[plane + c]; wh[u] = sw_h[c]; wl[u] = sw_h[plane + c];
+                xh[u] = sx_h[c]; wh[u] = sw_h[c];
+                if (NP == 2) { xl[u] = sx_h[plane + c]; wl[u] = sw_h[plane + c]; }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                acc = mfma_h(wl[u], xh[u], acc);                            // smallest terms first (the order of the pipelined forms)
-                acc = mfma_h(wh[u], xl[u], acc);
+                if (NP == 2) {
+                    acc = mfma_h(wl[u], xh[u], acc);                        // smallest terms first (the order of the pipelined forms)
+                    acc = mfma_h(wh[u], xl[u], acc);
+                }
                 acc = mfma_h(wh[u], xh[u], acc);
             }
         }
@@ -445,7 +477,9 @@ __global__ __launch_bounds__(256, 1) void linear3p_once_kernel(const _Float16* _
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = l3_gelu(y[e]);
         }
-        if (MODE == LP_PLANES) {
+        if (MODE == LP_PLANES && NP == 1) {
+            *reinterpret_cast<uint2*>(Yh + m * ldy + n) = make_uint2(pack2h(y[0], y[1]), pack2h(y[2], y[3]));
+        } else if (MODE == LP_PLANES) {
             uint2 hi, lo;
             split2h(y[0], y[1], hi.x, lo.x);
             split2h(y[2], y[3], hi.y, lo.y);
@@ -461,10 +495,16 @@ __global__ __launch_bounds__(256, 1) void linear3p_once_kernel(const _Float16* _
     }
 }
 
-static bool lpo_reserve_lds() {
-    static const bool ok =
-        hipFuncSetAttribute((const void*)linear3p_once_kernel<LP_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, LPO_LDS_BYTES) == hipSuccess &&
-        hipFuncSetAttribute((const void*)linear3p_once_kernel<LP_PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, LPO_LDS_BYTES) == hipSuccess;
+// ---- launchers: one instantiation per (mode, form, planes) ----
+template <int MODE, int NP>
+static bool lpo_reserve() {
+    static const bool ok = hipFuncSetAttribute((const void*)linear3p_once_kernel<MODE, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LPO_LDS_BYTES) == hipSuccess;
+    return ok;
+}
+template <int MODE, bool SMALL, int NP>
+static bool lp_reserve() {
+    static const bool ok = hipFuncSetAttribute((const void*)linear3p_kernel<MODE, SMALL, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               SMALL ? LPS_LDS_BYTES : LP_LDS_BYTES) == hipSuccess;
     return ok;
 }
 
@@ -472,83 +512,81 @@ bool linear3p_applicable(int N, int K, int64_t ldx, int64_t ldw, int64_t ldy) {
     return K % LP_BK == 0 && K >= LP_BK && N % 4 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 4 == 0;
 }
 
-static bool lp_reserve_lds() {                              // 144 KB of dynamic LDS: opt in once per kernel
-    static const bool ok =
-        hipFuncSetAttribute((const void*)linear3p_kernel<LP_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES) == hipSuccess &&
-        hipFuncSetAttribute((const void*)linear3p_kernel<LP_PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES) == hipSuccess &&
-        hipFuncSetAttribute((const void*)linear3p_kernel<LP_DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES) == hipSuccess;
-    return ok;
-}
-
-// Y (fp32, ldy floats) or Yh / Yl (fp16 planes, ldy halves) = act(X W^T * wscale_inv + bias (+ row bias)); exactly one of Y, Yh is set
-static bool lps_reserve_lds() {
-    static const bool ok =
-        hipFuncSetAttribute((const void*)linear3p_kernel<LP_F32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LPS_LDS_BYTES) == hipSuccess &&
-        hipFuncSetAttribute((const void*)linear3p_kernel<LP_PLANES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LPS_LDS_BYTES) == hipSuccess;
-    return ok;
-}
-
-void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
-                     const float* bias, float* Y, void* Yh, void* Yl, int64_t ldy, int64_t M, int N, int K, int act, float wscale_inv,
-                     const float* row_bias, int64_t rows_per_group, const int* row_group, const float* R, int64_t ldr) {
-    if (M <= 0 || N <= 0) return;
+template <int NP>
+static void launch_linear3p_np(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
+                               const float* bias, float* Y, void* Yh, void* Yl, int64_t ldy, int64_t M, int N, int K, int act, float wscale_inv,
+                               const float* row_bias, int64_t rows_per_group, const int* row_group, const float* R, int64_t ldr) {
     const long long rpg = rows_per_group > 0 ? rows_per_group : 1;
     // short K: the two-blocks-per-CU form (same bits); MCR_L3P_SMALL=0: the large tile whatever K is (A/B), =2: the small one always
     static const int small_mode = []() { const char* e = getenv("MCR_L3P_SMALL"); return e ? atoi(e) : 1; }();
     // a few thousand rows: the one-shot form (same bits); MCR_L3P_ONCE=0: off (A/B)
     static const bool once_on = []() { const char* e = getenv("MCR_L3P_ONCE"); return !(e && e[0] == '0'); }();
+    const _Float16 *xh = (const _Float16*)Xh, *xl = (const _Float16*)Xl, *wh = (const _Float16*)Wh, *wl = (const _Float16*)Wl;
+    _Float16 *yh = (_Float16*)Yh, *yl = (_Float16*)Yl;
+    const float* nf = nullptr;
     if (once_on && M <= 4096 && !row_bias && (K == 128 || K % LPO_KS == 0)) {
-        if (!lpo_reserve_lds()) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LPO_LDS_BYTES); return; }
+        if (!(Yh ? lpo_reserve<LP_PLANES, NP>() : lpo_reserve<LP_F32, NP>())) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LPO_LDS_BYTES); return; }
         dim3 g((unsigned)(cdiv(M, LPO_T) * cdiv(N, LPO_T)));
         if (Yh)
-            hipLaunchKernelGGL((linear3p_once_kernel<LP_PLANES>), g, dim3(256), LPO_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl,
-                               (long long)ldx, (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, (float*)nullptr, (_Float16*)Yh,
-                               (_Float16*)Yl, (long long)ldy, (long long)M, N, K, act, wscale_inv, (const float*)nullptr, 0ll);
+            hipLaunchKernelGGL((linear3p_once_kernel<LP_PLANES, NP>), g, dim3(256), LPO_LDS_BYTES, s, xh, xl, (long long)ldx, wh, wl, (long long)ldw, bias,
+                               (float*)nullptr, yh, yl, (long long)ldy, (long long)M, N, K, act, wscale_inv, nf, 0ll);
         else
-            hipLaunchKernelGGL((linear3p_once_kernel<LP_F32>), g, dim3(256), LPO_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl,
-                               (long long)ldx, (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, Y, (_Float16*)nullptr,
-                               (_Float16*)nullptr, (long long)ldy, (long long)M, N, K, act, wscale_inv, R, (long long)ldr);
+            hipLaunchKernelGGL((linear3p_once_kernel<LP_F32, NP>), g, dim3(256), LPO_LDS_BYTES, s, xh, xl, (long long)ldx, wh, wl, (long long)ldw, bias, Y,
+                               (_Float16*)nullptr, (_Float16*)nullptr, (long long)ldy, (long long)M, N, K, act, wscale_inv, R, (long long)ldr);
         return;
     }
     if (small_mode == 2 || (small_mode == 1 && K <= 512)) {
-        if (!lps_reserve_lds()) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LPS_LDS_BYTES); return; }
+        if (!(Yh ? lp_reserve<LP_PLANES, true, NP>() : lp_reserve<LP_F32, true, NP>())) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LPS_LDS_BYTES); return; }
         dim3 g((unsigned)(cdiv(cdiv(M, 128), 8) * 8 * cdiv(N, 128)));
         if (Yh)
-            hipLaunchKernelGGL((linear3p_kernel<LP_PLANES, true>), g, dim3(256), LPS_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl,
-                               (long long)ldx, (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group,
-                               (float*)nullptr, (_Float16*)Yh, (_Float16*)Yl, (long long)ldy, (long long)M, N, K, act, wscale_inv,
-                               (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, 0ll);
+            hipLaunchKernelGGL((linear3p_kernel<LP_PLANES, true, NP>), g, dim3(256), LPS_LDS_BYTES, s, xh, xl, (long long)ldx, wh, wl, (long long)ldw, bias,
+                               row_bias, rpg, row_group, (float*)nullptr, yh, yl, (long long)ldy, (long long)M, N, K, act, wscale_inv, nf, nf, 0, nf, 0ll);
         else
-            hipLaunchKernelGGL((linear3p_kernel<LP_F32, true>), g, dim3(256), LPS_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl,
-                               (long long)ldx, (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group, Y,
-                               (_Float16*)nullptr, (_Float16*)nullptr, (long long)ldy, (long long)M, N, K, act, wscale_inv,
-                               (const float*)nullptr, (const float*)nullptr, 0, R, (long long)ldr);
+            hipLaunchKernelGGL((linear3p_kernel<LP_F32, true, NP>), g, dim3(256), LPS_LDS_BYTES, s, xh, xl, (long long)ldx, wh, wl, (long long)ldw, bias,
+                               row_bias, rpg, row_group, Y, (_Float16*)nullptr, (_Float16*)nullptr, (long long)ldy, (long long)M, N, K, act, wscale_inv,
+                               nf, nf, 0, R, (long long)ldr);
         return;
     }
-    if (!lp_reserve_lds()) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LP_LDS_BYTES); return; }
+    if (!(Yh ? lp_reserve<LP_PLANES, false, NP>() : lp_reserve<LP_F32, false, NP>())) { set_error("launch_linear3p: cannot reserve %d bytes of LDS", LP_LDS_BYTES); return; }
     dim3 grid((unsigned)(cdiv(cdiv(M, 256), 8) * 8 * cdiv(N, 128)));             // 1-D: see the XCD-aware block order in the kernel
     if (Yh)
-        hipLaunchKernelGGL((linear3p_kernel<LP_PLANES>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
-                           (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group, (float*)nullptr,
-                           (_Float16*)Yh, (_Float16*)Yl, (long long)ldy, (long long)M, N, K, act, wscale_inv, (const float*)nullptr,
-                           (const float*)nullptr, 0, (const float*)nullptr, 0ll);
+        hipLaunchKernelGGL((linear3p_kernel<LP_PLANES, false, NP>), grid, dim3(512), LP_LDS_BYTES, s, xh, xl, (long long)ldx, wh, wl, (long long)ldw, bias,
+                           row_bias, rpg, row_group, (float*)nullptr, yh, yl, (long long)ldy, (long long)M, N, K, act, wscale_inv, nf, nf, 0, nf, 0ll);
     else
-        hipLaunchKernelGGL((linear3p_kernel<LP_F32>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
-                           (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, row_bias, rpg, row_group, Y,
-                           (_Float16*)nullptr, (_Float16*)nullptr, (long long)ldy, (long long)M, N, K, act, wscale_inv, (const float*)nullptr,
-                           (const float*)nullptr, 0, R, (long long)ldr);
+        hipLaunchKernelGGL((linear3p_kernel<LP_F32, false, NP>), grid, dim3(512), LP_LDS_BYTES, s, xh, xl, (long long)ldx, wh, wl, (long long)ldw, bias,
+                           row_bias, rpg, row_group, Y, (_Float16*)nullptr, (_Float16*)nullptr, (long long)ldy, (long long)M, N, K, act, wscale_inv, nf,
+                           nf, 0, R, (long long)ldr);
+}
+
+// Y (fp32, ldy floats) or Yh / Yl (fp16 planes, ldy halves) = act(X W^T * wscale_inv + bias (+ row bias)); exactly one of Y, Yh is set.
+// n_planes = 1: the high planes alone (variant 7): Xl / Wl / Yl are ignored
+void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
+                     const float* bias, float* Y, void* Yh, void* Yl, int64_t ldy, int64_t M, int N, int K, int act, float wscale_inv,
+                     const float* row_bias, int64_t rows_per_group, const int* row_group, const float* R, int64_t ldr, int n_planes) {
+    if (M <= 0 || N <= 0) return;
+    if (n_planes == 1)
+        launch_linear3p_np<1>(s, Xh, Xl, ldx, Wh, Wl, ldw, bias, Y, Yh, Yl, ldy, M, N, K, act, wscale_inv, row_bias, rows_per_group, row_group, R, ldr);
+    else
+        launch_linear3p_np<2>(s, Xh, Xl, ldx, Wh, Wl, ldw, bias, Y, Yh, Yl, ldy, M, N, K, act, wscale_inv, row_bias, rows_per_group, row_group, R, ldr);
 }
 
 // out[m] = act2( act(X W^T * wscale_inv + bias)[m][:] . v + c ) for a 256-feature layer (N == 256): two layers, one launch
 bool linear3p_dot_applicable(int N, int K, int64_t ldx, int64_t ldw) { return N == 256 && K % LP_BK == 0 && K >= LP_BK && ldx % 8 == 0 && ldw % 8 == 0; }
-void launch_linear3p_dot(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
-                         const float* bias, int64_t M, int K, int act, float wscale_inv, const float* v, const float* c, int act2, float* out) {
-    if (M <= 0) return;
-    if (!lp_reserve_lds()) { set_error("launch_linear3p_dot: cannot reserve %d bytes of LDS", LP_LDS_BYTES); return; }
+template <int NP>
+static void launch_linear3p_dot_np(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
+                                   const float* bias, int64_t M, int K, int act, float wscale_inv, const float* v, const float* c, int act2, float* out) {
+    if (!lp_reserve<LP_DOT, false, NP>()) { set_error("launch_linear3p_dot: cannot reserve %d bytes of LDS", LP_LDS_BYTES); return; }
     dim3 grid((unsigned)(cdiv(cdiv(M, 128), 8) * 8));
-    hipLaunchKernelGGL((linear3p_kernel<LP_DOT>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
+    hipLaunchKernelGGL((linear3p_kernel<LP_DOT, false, NP>), grid, dim3(512), LP_LDS_BYTES, s, (const _Float16*)Xh, (const _Float16*)Xl, (long long)ldx,
                        (const _Float16*)Wh, (const _Float16*)Wl, (long long)ldw, bias, (const float*)nullptr, 1ll, (const int*)nullptr, out,
                        (_Float16*)nullptr, (_Float16*)nullptr, 1ll, (long long)M, 256, K, act, wscale_inv, v, c, act2, (const float*)nullptr, 0ll);
+}
+void launch_linear3p_dot(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
+                         const float* bias, int64_t M, int K, int act, float wscale_inv, const float* v, const float* c, int act2, float* out,
+                         int n_planes) {
+    if (M <= 0) return;
+    if (n_planes == 1) launch_linear3p_dot_np<1>(s, Xh, Xl, ldx, Wh, Wl, ldw, bias, M, K, act, wscale_inv, v, c, act2, out);
+    else launch_linear3p_dot_np<2>(s, Xh, Xl, ldx, Wh, Wl, ldw, bias, M, K, act, wscale_inv, v, c, act2, out);
 }
 
 void launch_split_to_planes(hipStream_t s, const float* X, int64_t ldx, void* Ph, void* Pl, int64_t ldp, int64_t M, int E) {

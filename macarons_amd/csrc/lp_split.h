@@ -46,6 +46,26 @@ constexpr int L6_MATS_TOTAL = l6_mat_off(15);
 constexpr int L6_SCALES = L3_VECS_TOTAL;                      // offset of the 16 inverse scales inside the vector section
 constexpr int L6_BLOB_FLOATS = L6_MATS_TOTAL + L3_VECS_TOTAL + 32;
 
+// ---- blob of variant 7 (opt-in 16-bit matrix path): matrices as [n-tile][k16 step][lane][8 fp16] -- the HIGH plane of variant 6's
+// blob alone (fp16(W 2^e_i), half a float per weight); then the same vectors and the same 32 scale floats as variant 6
+constexpr int L7_MAT_K16 = 128 * 16 / 2, L7_MAT_128 = 128 * 128 / 2, L7_MAT_QKV = 192 * 128 / 2;
+__host__ __device__ constexpr int l7_mat_off(int idx) {
+    int off = 0;
+    for (int i = 0; i < idx; ++i) {
+        const bool is_qkv = (i >= 2 && i < 14 && ((i - 2) % 6) == 0);
+        off += i == 0 ? L7_MAT_K16 : (is_qkv ? L7_MAT_QKV : L7_MAT_128);
+    }
+    return off;
+}
+constexpr int L7_MATS_TOTAL = l7_mat_off(15);
+constexpr int L7_SCALES = L3_VECS_TOTAL;
+constexpr int L7_BLOB_FLOATS = L7_MATS_TOTAL + L3_VECS_TOTAL + 32;
+
+__device__ __forceinline__ unsigned pack2h(const float a, const float b) {      // {fp16(b), fp16(a)}, round to nearest even: v_cvt_pk_f16_f32
+    const f32x2 x = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+}
+
 __device__ __forceinline__ float l3_gelu(float x) {           // exact-erf GELU, erf by Abramowitz-Stegun 7.1.26
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));

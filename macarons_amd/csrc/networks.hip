@@ -58,7 +58,9 @@ struct Arena {
 static size_t al(size_t n_floats) { return (n_floats * sizeof(float) + 255) & ~(size_t)255; }
 
 // 1: local_pct.hip exact-fp32 MFMA; 5: local_pct5.hip split-precision bf16 hi/mid/lo (6 MFMAs per product, whole fp32
-// range); 6 (default): local_pct6.hip two-term fp16 split (3 MFMAs per product).  Each has its own blob format.
+// range); 6 (default): local_pct6.hip two-term fp16 split (3 MFMAs per product); 7 (OPT-IN, per call only -- never a process
+// default): local_pct7.hip, ONE fp16 plane per matrix operand (1 MFMA per product), BASELINE.json config 3's 16-bit matrix
+// path with its own stated tolerance (tests/test_variant7_gpu.py).  Each has its own blob format.
 #ifdef MCR_DEV_LOCAL_PCT8      // dev builds only (tools/build_variant.py with tools/experiments/local_pct8.hip): the shelved register-resident kernel as variant 8
 void launch_local_pct8(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob);
 #define MCR_VARIANT8_OK(v) ((v) == 8)
@@ -90,6 +92,11 @@ struct VariantScope {
     }
 };
 #define g_local_pct_variant (t_variant ? t_variant : g_default_variant)
+// Variant 7 shares variant 6's routes (operands as fp16 planes in HBM, the same range guard); what differs is how many planes a
+// product multiplies: matrix_planes() = 1 on variant 7 (the high planes alone; low planes are neither written nor read where
+// the single-plane kernels exist: the local transformers and the SconeOcc head), 2 on variant 6.
+static inline bool fp16_planes_variant() { return g_local_pct_variant == 6 || g_local_pct_variant == 7; }
+static inline int matrix_planes() { return g_local_pct_variant == 7 ? 1 : 2; }
 // rows-per-sequence argument of launch_linear for the encoders of the 2048-token networks (SconeVis, SconeOcc's global
 // transformer): on the split-precision variants (5, 6) their GEMMs take the split-precision kernel for EVERY launch size (negative
 // argument = "choose on the layer's shape"; its column-tile width follows the launch, which does not change a single bit) -- one
@@ -111,7 +118,7 @@ static inline int64_t head_route(int64_t L) {
 // long-sequence attention: P V on fp16 hi/lo pairs (nn_kernels.hip: PVH) on the fp16-split variant; MCR_ATTN_PVH=0: fp32 MFMA (A/B)
 static inline bool attn_pv_half() {
     static const bool on = []() { const char* e = getenv("MCR_ATTN_PVH"); return !(e && e[0] == '0'); }();
-    return on && g_local_pct_variant == 6;
+    return on && fp16_planes_variant();
 }
 
 // Encoder GEMMs of the long-sequence networks on fp16 hi/lo PLANES (variant 6, sequences of >= 512 tokens; MCR_ENC_PLANES=0: the
@@ -122,7 +129,7 @@ static inline bool attn_pv_half() {
 // occupancy / harmonics that come out non-finite otherwise are what the range guards look at.
 static inline bool enc_planes(int L, int E) {
     static const bool on = []() { const char* e = getenv("MCR_ENC_PLANES"); return !(e && e[0] == '0'); }();
-    return on && g_local_pct_variant == 6 && L >= 512 && E % 32 == 0;
+    return on && fp16_planes_variant() && L >= 512 && E % 32 == 0;
 }
 
 // The layers either side of the encoders (the embeddings' second layer, the final LayerNorm and the fc / lin0 layers behind it) on the
@@ -305,13 +312,15 @@ static void run_x_embedding_planes(hipStream_t s, const float* x, const float* v
     _Float16* x1l = x1h + (size_t)T * 128;
     const _Float16 *Wh, *Wl;
     float inv;
+    const int np = matrix_planes();                      // 1 on variant 7: the low planes below are neither written (GEMM epilogues) nor read
     launch_linear_smallk_planes(s, x, 3, xe1.w, xe1.b, x1h, x1l, 128, T, 128, 3, ACT_GELU);       // (planes directly: no fp32 rows, no split pass)
     head_planes_weights(s, 0, xe2.w, 128, 256, 128, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
-    launch_linear3p(s, x1h, x1l, 128, Wh, Wl, 128, xe2.b, nullptr, hh, hh + (size_t)T * 256, 256, T, 256, 128, ACT_GELU, inv, nullptr, 0, nullptr);
+    launch_linear3p(s, x1h, x1l, 128, Wh, Wl, 128, xe2.b, nullptr, hh, hh + (size_t)T * 256, 256, T, 256, 128, ACT_GELU, inv, nullptr, 0, nullptr,
+                    nullptr, 0, np);
     head_planes_weights(s, 1, xe3.w, 256, 512, 256, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
     launch_linear3p(s, hh, hh + (size_t)T * 256, 256, Wh, Wl, 256, xe3.b, nullptr, fh + 768, fl + 768, 1344, T, 512, 256, ACT_GELU, inv, nullptr, 0,
-                    nullptr);
-    if (view_harmonics) launch_split_to_planes(s, view_harmonics, 64, fh + 1280, fl + 1280, 1344, T, 64);      // (NULL: the caller splits them later)
+                    nullptr, nullptr, 0, np);
+    if (view_harmonics) launch_split_to_planes(s, view_harmonics, 64, fh + 1280, np == 1 ? nullptr : fl + 1280, 1344, T, 64);   // (NULL: the caller splits them later)
 }
 
 // x_done: the x-embedding part has been queued elsewhere (the side stream: the join covers it)
@@ -324,21 +333,22 @@ static void run_head_planes(hipStream_t s, const float* x, const float* view_har
     _Float16 *hh = w.h1P;
     const _Float16 *Wh, *Wl;
     float inv;
+    const int np = matrix_planes();
     if (!x_done) run_x_embedding_planes(s, x, view_harmonics, T, xe1, xe2, xe3, head_planes, head_inv_scales, w);
     join();                                               // the global feature (side stream) is needed from here on
     // head MLP 1856 -> 512 -> 256 -> 1, GELU after every layer incl. the last (SconeOcc.py:334-345); the global 512 columns are gbias
     head_planes_weights(s, 2, lin1.w + 512, 1856, 512, 1344, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
     launch_linear3p(s, fh, fl, 1344, Wh, Wl, 1344, lin1.b, nullptr, hh, hh + (size_t)T * 512, 512, T, 512, 1344, ACT_GELU, inv, gbias,
-                    rows_per_group, row_group);
+                    rows_per_group, row_group, nullptr, 0, np);
     head_planes_weights(s, 3, lin2.w, 512, 256, 512, head_planes, head_inv_scales, w.wplanes, Wh, Wl, inv);
     static const bool fuse_tail = []() { const char* e = getenv("MCR_HEAD_FUSE_TAIL"); return !(e && e[0] == '0'); }();     // dev A/B knob
     if (fuse_tail && linear3p_dot_applicable(256, 512, 512, 512)) {
         // 512 -> 256 (GELU) -> 1 (GELU) in one launch: the block owns all 256 features of its rows and dots them with linear3.weight
-        launch_linear3p_dot(s, hh, hh + (size_t)T * 512, 512, Wh, Wl, 512, lin2.b, T, 512, ACT_GELU, inv, lin3.w, lin3.b, ACT_GELU, out);
+        launch_linear3p_dot(s, hh, hh + (size_t)T * 512, 512, Wh, Wl, 512, lin2.b, T, 512, ACT_GELU, inv, lin3.w, lin3.b, ACT_GELU, out, np);
         return;
     }
     launch_linear3p(s, hh, hh + (size_t)T * 512, 512, Wh, Wl, 512, lin2.b, w.h2, nullptr, nullptr, 256, T, 256, 512, ACT_GELU, inv, nullptr, 0,
-                    nullptr);
+                    nullptr, nullptr, 0, np);
     launch_linear(s, w.h2, 256, lin3.w, lin3.b, nullptr, 0, out, 1, T, 1, 256, ACT_GELU, nullptr, 0, 0, 1);
 }
 
@@ -470,6 +480,7 @@ int mcr_get_local_pct_variant(void);
 int mcr_local_pct_blob_floats(void) { return local_pct_blob_floats(); }
 int mcr_local_pct3_blob_floats(void) { return local_pct3_blob_floats(); }
 int mcr_local_pct6_blob_floats(void) { return local_pct6_blob_floats(); }
+int mcr_local_pct7_blob_floats(void) { return local_pct7_blob_floats(); }
 
 int mcr_set_local_pct_variant(int v) {
     MCR_REQUIRE(v == 1 || v == 5 || v == 6 || MCR_VARIANT8_OK(v), "mcr_set_local_pct_variant: variant must be 1, 5 or 6 (got %d)", v);
@@ -478,7 +489,8 @@ int mcr_set_local_pct_variant(int v) {
 }
 int mcr_get_local_pct_variant(void) { return g_default_variant; }
 int mcr_call_variant(int v) {
-    MCR_REQUIRE(v == 0 || v == 1 || v == 5 || v == 6 || MCR_VARIANT8_OK(v), "mcr_call_variant: variant must be 0 (default), 1, 5 or 6 (got %d)", v);
+    MCR_REQUIRE(v == 0 || v == 1 || v == 5 || v == 6 || v == 7 || MCR_VARIANT8_OK(v),
+                "mcr_call_variant: variant must be 0 (default), 1, 5, 6 or 7 (the opt-in 16-bit matrix path) (got %d)", v);
     t_next_variant = v;
     return 0;
 }
@@ -489,6 +501,7 @@ static void run_local_pct(hipStream_t s, const float* offs, float* feat, int64_t
 #ifdef MCR_DEV_LOCAL_PCT8
     else if (g_local_pct_variant == 8) launch_local_pct8(s, offs, feat, ld, S, blob);
 #endif
+    else if (g_local_pct_variant == 7) launch_local_pct7(s, offs, feat, ld, S, blob, feat_h);   // ONE plane out when feat_h is set
     else launch_local_pct6(s, offs, feat, ld, S, blob, feat_h, feat_l);       // planes out (variant 6 only) when feat_h is set
 }
 
@@ -762,7 +775,7 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
     // variant 6 with all three fused transformers: the head runs on fp16 hi/lo planes end to end (run_head_planes); the feature
     // buffer then holds planes [2][T][1344] fp16 instead of fp32 [T][1344] (MCR_HEAD_PLANES=0: the fp32-input linear3h path)
     static const bool planes_on = []() { const char* e = getenv("MCR_HEAD_PLANES"); return !(e && e[0] == '0'); }();
-    const bool planes = planes_on && fused_all && g_local_pct_variant == 6;
+    const bool planes = planes_on && fused_all && fp16_planes_variant();
     _Float16* featP = reinterpret_cast<_Float16*>(feat);
     const int64_t Tall = B * Q;
     // the x embedding of the planes head (0.3 ms of GEMMs that need only the queries) rides on the side stream behind the global
@@ -797,7 +810,8 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
         MCR_REQUIRE(garena.ok(), "mcr_scone_occ_forward: workspace overflow (global)");
         // its contribution to linear1: gbias[b, n] = sum_k gfeat[b, k] * W1[n, k]  (columns 0..511 of linear1.weight)
         launch_linear(gs, gfeat, 512, lin1.w, nullptr, nullptr, 0, gbias, 512, B, 512, 512, ACT_NONE, nullptr, 0, 1856, 1);
-        if (x_on_side && x_early) launch_split_to_planes(gs, view_harmonics, 64, featP + 1280, featP + Tall * FEAT + 1280, 1344, B * Q, 64);
+        if (x_on_side && x_early)
+            launch_split_to_planes(gs, view_harmonics, 64, featP + 1280, matrix_planes() == 1 ? nullptr : featP + Tall * FEAT + 1280, 1344, B * Q, 64);
         else if (x_on_side) run_x_embedding_planes(gs, x, view_harmonics, B * Q, xe1, xe2, xe3, head_planes, head_inv_scales, head_scratch);
     }
     if (side) {
@@ -899,7 +913,7 @@ int mcr_scone_occ_forward_phase(const float* pc_global, int64_t Lg, const float*
     // which: 0 xe2, 1 xe3, 2 lin1 (columns 512..1855), 3 lin2 -- the order of the host's pre-split planes (variant 6)
     auto big_linear = [&](int which, const float* X_, int64_t ldx, const float* W_, int64_t ldw, const float* b_, float* Y_, int64_t ldy,
                           int64_t M_, int N_, int K_, const float* rb, int64_t rpg) {
-        if (variant == 6 && linear3h_applicable(X_, ldx, W_, ldw, ANY_M, N_, K_)) {
+        if ((variant == 6 || variant == 7) && linear3h_applicable(X_, ldx, W_, ldw, ANY_M, N_, K_)) {
             const bool pre = head_planes && head_planes[which] && head_inv_scales[which] > 0.f;
             launch_linear3h(s, X_, ldx, W_, ldw, pre ? const_cast<void*>(head_planes[which]) : wplanes, b_, nullptr, 0, Y_, ldy, M_, N_, K_,
                             ACT_GELU, rb, rpg, pre ? head_inv_scales[which] : 0.f);
@@ -1023,7 +1037,7 @@ int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global
     Arena garena{(char*)workspace + head.off, glob_bytes, 0};
     Arena scratch{(char*)workspace + head.off + glob_bytes, workspace_bytes - head.off - glob_bytes, 0};
     static const bool planes_on = []() { const char* e = getenv("MCR_HEAD_PLANES"); return !(e && e[0] == '0'); }();
-    const bool planes = planes_on && g_local_pct_variant == 6;
+    const bool planes = planes_on && fp16_planes_variant();
     _Float16* featP = reinterpret_cast<_Float16*>(feat);
     const HeadScratch head_scratch{featP, reinterpret_cast<_Float16*>(h1), h2, wplanes};
     float* offs = scratch.f(T * 16 * 3);
@@ -1084,7 +1098,7 @@ int mcr_scone_occ_forward_ragged_phase(const float* pc_global, const int* global
     const int64_t ANY_M = (int64_t)1 << 40;
     auto big_linear = [&](int which, const float* X_, int64_t ldx, const float* W_, int64_t ldw, const float* b_, float* Y_, int64_t ldy,
                           int64_t M_, int N_, int K_, const float* rb, const int* rg) {
-        if (variant == 6 && linear3h_applicable(X_, ldx, W_, ldw, ANY_M, N_, K_)) {
+        if ((variant == 6 || variant == 7) && linear3h_applicable(X_, ldx, W_, ldw, ANY_M, N_, K_)) {
             const bool pre = head_planes && head_planes[which] && head_inv_scales[which] > 0.f;
             launch_linear3h(s, X_, ldx, W_, ldw, pre ? const_cast<void*>(head_planes[which]) : wplanes, b_, nullptr, 0, Y_, ldy, M_, N_, K_,
                             ACT_GELU, rb, 0, pre ? head_inv_scales[which] : 0.f, rg);

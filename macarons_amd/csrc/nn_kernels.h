@@ -92,12 +92,15 @@ void launch_local_pct5(hipStream_t s, const float* offs, float* feat, int64_t ld
 // fp16 hi/lo blob; feat_h / feat_l (optional): write the features as fp16 hi/lo planes (row stride ld_feat halves) instead of fp32
 void launch_local_pct6(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob,
                        void* feat_h = nullptr, void* feat_l = nullptr);
+// variant 7 (opt-in 16-bit matrix path): ONE fp16 plane per operand (local_pct7.hip); feat_h (optional): the features as one fp16 plane
+void launch_local_pct7(hipStream_t s, const float* offs, float* feat, int64_t ld_feat, int64_t S, const float* blob, void* feat_h = nullptr);
 
 // Head GEMM on operands that already are fp16 hi/lo planes in HBM (linear3p.hip): Y fp32 or Yh / Yl planes = act(X W^T 2^-e + bias ...)
 bool linear3p_applicable(int N, int K, int64_t ldx, int64_t ldw, int64_t ldy);
 void launch_linear3p(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
                      const float* bias, float* Y, void* Yh, void* Yl, int64_t ldy, int64_t M, int N, int K, int act, float wscale_inv,
-                     const float* row_bias, int64_t rows_per_group, const int* row_group, const float* R = nullptr, int64_t ldr = 0);
+                     const float* row_bias, int64_t rows_per_group, const int* row_group, const float* R = nullptr, int64_t ldr = 0,
+                     int n_planes = 2);                  // n_planes = 1: the high planes alone, one MFMA per product (variant 7); Xl / Wl / Yl unused
 // LayerNorm whose output leaves as fp16 hi/lo planes (row stride ldp halves): the input of a planes GEMM, split where it is produced
 void launch_layernorm_planes(hipStream_t s, const float* X, int64_t ldx, const float* g, const float* b, void* Yh, void* Yl, int64_t ldp,
                              int64_t M, int E);
@@ -106,7 +109,8 @@ void launch_linear_smallk_planes(hipStream_t s, const float* X, int64_t ldx, con
                                  int64_t ldy, int64_t M, int N, int K, int act, int Np = 0);
 bool linear3p_dot_applicable(int N, int K, int64_t ldx, int64_t ldw);
 void launch_linear3p_dot(hipStream_t s, const void* Xh, const void* Xl, int64_t ldx, const void* Wh, const void* Wl, int64_t ldw,
-                         const float* bias, int64_t M, int K, int act, float wscale_inv, const float* v, const float* c, int act2, float* out);
+                         const float* bias, int64_t M, int K, int act, float wscale_inv, const float* v, const float* c, int act2, float* out,
+                         int n_planes = 2);
 void launch_split_to_planes(hipStream_t s, const float* X, int64_t ldx, void* Ph, void* Pl, int64_t ldp, int64_t M, int E);
 void launch_split_weights(hipStream_t s, const float* W, int64_t ldw, void* planes, int N, int K);   // linear3h.hip: [2][N][K] fp16 of W * 2^8
 // the same with zero padding to [2][Np][Kp] (Np % 4 == 0, Kp % 32 == 0) and the bias padded to bias_p [Np]
@@ -130,5 +134,6 @@ void launch_knn16_grid(hipStream_t s, const float* X, const float* pc, int64_t M
 int local_pct_blob_floats();
 int local_pct3_blob_floats();
 int local_pct6_blob_floats();
+int local_pct7_blob_floats();
 
 }  // namespace mcr

@@ -59,7 +59,7 @@ def _guarded(impl, scone_occ, range_guard, group, draws, device, scone_vis=None)
     from . import ops
     capturing = torch.cuda.is_current_stream_capturing()
     prev = scone_occ.range_guard
-    guard = range_guard and prev != "off" and ops.current_variant() == 6
+    guard = range_guard and prev != "off" and ops.current_variant() in (6, 7)
     scone_occ.range_guard = "defer" if (guard or prev != "off") else "off"
     # SconeVis (its encoders run on the same fp16 planes) reports into the SAME flag: one read-back covers both networks
     vis_prev = None
@@ -74,7 +74,7 @@ def _guarded(impl, scone_occ, range_guard, group, draws, device, scone_vis=None)
             scone_vis._range_flag = scone_occ.range_flag()
         kw = draws() if (guard and not capturing) else {}
         out = impl(**kw)
-        flag = scone_occ.range_flag() if ops.current_variant() == 6 else None
+        flag = scone_occ.range_flag() if ops.current_variant() in (6, 7) else None
         out["range_flag"] = flag
         if guard and not capturing:
             xch = mdist.exchange_on(group)

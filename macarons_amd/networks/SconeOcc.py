@@ -330,7 +330,7 @@ class SconeOcc(RangeGuard, nn.Module):
         def caches(v):
             key = param_key(self, self._key_cache)                  # one fingerprint of the parameters for every derived image
             state[v] = ([c.get(t, v, key) for c, t in zip(self._blob_caches, self.local_transformers)],
-                        self._head_cache.get(self, key) if v == 6 else None, self._table_cache.get(self, self.weight_table_with_planes, key))
+                        self._head_cache.get(self, key) if v in (6, 7) else None, self._table_cache.get(self, self.weight_table_with_planes, key))
             return state[v]
 
         def phase1(v):
@@ -407,7 +407,7 @@ class SconeOcc(RangeGuard, nn.Module):
             return ops.scone_occ_forward_ragged(pc_global, g_len_d, [pc, pc1, pc2], [d_off0, d_off1, d_off2], x, view_harmonics,
                                                 d_row_job, d_blocks, table, blobs, head, flag, phase=2, out=out_, arena=h["arena"])
         flag = None
-        if variant == 6 and self.range_guard != "off":
+        if variant in (6, 7) and self.range_guard != "off":
             if self._range_flag is None or self._range_flag.device != dev:
                 self._range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
             elif self.range_guard in ("sync", "async"):
@@ -433,7 +433,7 @@ class SconeOcc(RangeGuard, nn.Module):
     def _images(self, variant):
         key = param_key(self, self._key_cache)                      # one fingerprint of the parameters for every derived image
         blobs = [c.get(t, variant, key) for c, t in zip(self._blob_caches, self.local_transformers)] if self.fused_local else None
-        head = self._head_cache.get(self, key) if variant == 6 else None
+        head = self._head_cache.get(self, key) if variant in (6, 7) else None
         return self._table_cache.get(self, self.weight_table_with_planes, key), blobs, head
 
     def forward_begin(self, pc, x):
@@ -473,7 +473,7 @@ class SconeOcc(RangeGuard, nn.Module):
         L = _lib.lib()
         if self.range_guard == "async" and (self._range_pending or self._full_range):
             self.check_range()
-        if self._full_range and ops.current_variant() == 6:        # an earlier forward overflowed the fp16 split: full range from now on
+        if self._full_range and ops.current_variant() in (6, 7):        # an earlier forward overflowed the fp16 split: full range from now on
             with ops.variant(5):
                 return self.forward(pc, x, view_harmonics, mask, verbose, perms, None)
         variant = ops.current_variant()
@@ -498,7 +498,7 @@ class SconeOcc(RangeGuard, nn.Module):
             return ops.scone_occ_forward(pc_global, scales, x_, vh_, table, blobs, head, flag, phase=phase)
 
         flag = None
-        if variant == 6 and self.range_guard != "off":
+        if variant in (6, 7) and self.range_guard != "off":
             if self._range_flag is None or self._range_flag.device != dev:
                 self._range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
             elif self.range_guard == "sync":

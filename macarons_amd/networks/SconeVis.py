@@ -124,10 +124,10 @@ class SconeVis(RangeGuard, nn.Module):
         # read it once per decision); "sync": read now, repeat on variant 5; "off": nothing.
         if self.range_guard == "async" and (self._range_pending or self._full_range):
             self.check_range()
-        if self._full_range and ops.current_variant() == 6:
+        if self._full_range and ops.current_variant() in (6, 7):
             with ops.variant(5):
                 return self.forward(pts, mask, view_harmonics, lengths)
-        guarded = ops.current_variant() == 6 and seq_len >= 512 and self.range_guard != "off" and not torch.cuda.is_current_stream_capturing()
+        guarded = ops.current_variant() in (6, 7) and seq_len >= 512 and self.range_guard != "off" and not torch.cuda.is_current_stream_capturing()
 
         def hip(p, vh):
             res_ = ops.scone_vis_forward(p, vh, self._table_cache.get(self, self.weight_table_with_planes), lengths)

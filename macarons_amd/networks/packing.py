@@ -58,11 +58,14 @@ def _pack_bf16x3(W):
 def pack_local_pct(pct, variant=1):
     """pct: macarons_amd.networks.SconeOcc.PCTransformer (default local architecture). Returns a 1-D fp32 tensor.
     variant 1: fp32 fragment image (local_pct.hip); variant 5: exact bf16 hi/mid/lo planes (local_pct5.hip);
-    variant 6: fp16 hi/lo planes of the power-of-two scaled weights (local_pct6.hip)."""
+    variant 6: fp16 hi/lo planes of the power-of-two scaled weights (local_pct6.hip); variant 7 (the opt-in 16-bit matrix path):
+    the HIGH plane of variant 6's blob alone (local_pct7.hip)."""
     if variant == 5:
         return _pack_local_pct3(pct)
     if variant == 6:
         return _pack_local_pct6(pct)
+    if variant == 7:
+        return _pack_local_pct6(pct, planes=1)
     if variant != 1:
         raise ValueError(f"unknown fused local transformer variant {variant}")
     with torch.no_grad():
@@ -243,21 +246,22 @@ def _pow2_scale(*Ws):
     return 2.0 ** (13 - math.floor(math.log2(m)))
 
 
-def _pack_f16x2(W, scale):
+def _pack_f16x2(W, scale, planes=2):
     """[N, K] fp32 -> fp16 hi/lo planes of W * scale in the fragment order of local_pct6.hip [N/32][K/16][plane][64 lanes][8],
-    returned as a float32-typed view (1 float per weight).  hi = fp16(Ws), lo = fp16(Ws - hi) (round to nearest even)."""
+    returned as a float32-typed view (1 float per weight).  hi = fp16(Ws), lo = fp16(Ws - hi) (round to nearest even).
+    planes=1: the high plane alone, [N/32][K/16][64 lanes][8] (local_pct7.hip; half a float per weight)."""
     N, K = W.shape
     assert N % 32 == 0 and K % 16 == 0
     Ws = W * scale                                                              # exact (power of two, no overflow: < 2^14)
     hi = Ws.to(torch.float16)
     lo = (Ws - hi.float()).to(torch.float16)
-    planes = torch.stack([hi.view(torch.int16), lo.view(torch.int16)], 0)      # [2, N, K]
-    t = planes.reshape(2, N // 32, 32, K // 16, 2, 8)                           # [pl, nt, j, s, h, e]
+    planes = torch.stack([hi.view(torch.int16), lo.view(torch.int16)][:planes], 0)   # [planes, N, K]
+    t = planes.reshape(planes.shape[0], N // 32, 32, K // 16, 2, 8)             # [pl, nt, j, s, h, e]
     t = t.permute(1, 3, 0, 4, 2, 5).contiguous()                                # [nt, s, pl, h, j, e]
     return t.reshape(-1).view(torch.float32)
 
 
-def _pack_local_pct6(pct):
+def _pack_local_pct6(pct, planes=2):
     with torch.no_grad():
         f = lambda p: p.detach().float()
         mats, vecs, inv = [], [], []
@@ -265,7 +269,7 @@ def _pack_local_pct6(pct):
         def add(*Ws):
             sc = _pow2_scale(*Ws)
             for W in Ws:
-                mats.append(_pack_f16x2(W.contiguous(), sc))
+                mats.append(_pack_f16x2(W.contiguous(), sc, planes))
                 inv.append(1.0 / sc)
             return sc
         # every bias is stored multiplied by its matrix's scale: the kernel starts the accumulator from it
@@ -295,9 +299,9 @@ def _pack_local_pct6(pct):
         dev = mats[0].device
         fwd = [1.0 / v for v in inv]
         blob = torch.cat(mats + vecs + [torch.tensor(inv + [0.0] + fwd + [0.0], dtype=torch.float32, device=dev)]).contiguous()
-    expect = _lib.lib().mcr_local_pct6_blob_floats()
+    expect = _lib.lib().mcr_local_pct6_blob_floats() if planes == 2 else _lib.lib().mcr_local_pct7_blob_floats()
     if blob.numel() != expect:
-        raise RuntimeError(f"packed local transformer (v6) has {blob.numel()} floats, kernel expects {expect}")
+        raise RuntimeError(f"packed local transformer (v{8 - planes}) has {blob.numel()} floats, kernel expects {expect}")
     return blob
 
 
