@@ -14,11 +14,19 @@
 // Structure = local_pct6.hip (4 waves = 64 tokens x 128 channels on chip, products transposed, residual stream in registers,
 // Chan-combined LayerNorm statistics, GELU epilogues beside the next product's MFMAs) minus everything the low planes needed:
 // a third of the MFMAs, half the fragment reads, half the LDS plane stores, half the weight bytes from L2, no split arithmetic.
-// LDS = 50 KB (three workgroups per CU):
-//               P  16 KB  fp16 plane [64 rows][16 chunks of 8], or q|k as fp32 [64][64]
-//               H  32 KB  fp16 plane (FF hidden half / GELU(emb1)) in its first half, or v as fp32 [64][128], or the final fp32 tile
+// No per-matrix power-of-two weight scale either (variant 6 needs it for its LOW plane): weights and biases as they are, rounded to
+// fp16 -- what a 16-bit matrix path means everywhere else; |w| >= 65520 becomes inf and ends in the range guard.
+// The kernel is bound by VECTOR issue once two thirds of the matrix work are gone (first version: 6.5 k vector instructions per
+// wave, vector unit 92 % busy at three waves per SIMD, matrix pipe 33 %), so this version also sheds vector work that variant 6
+// hides under its MFMAs: plane rows are PADDED (272 bytes: 17 chunks) instead of XOR-swizzled -- every fragment address of a
+// product is one base register plus an immediate (the swizzle cost five integer instructions per k-step) --, LayerNorm
+// normalises with one v_rsq and one fma per value, and no epilogue multiplies by a scale.
+// LDS = 51 KB (three workgroups per CU):
+//               P  17 KB  fp16 plane [64 rows][17 chunks of 8, the last one padding], or q|k as fp32 [64][68]
+//               H  32 KB  fp16 plane (FF hidden half / GELU(emb1)) in its first 17 KB, or v as fp32 [64][128], or the final fp32 tile
 //               St  2 KB  LayerNorm partials [4 waves][64 tokens] (mean, M2)
-// 16-byte chunks are XOR-swizzled by (row & 15) in every view.
+// Row stride 272 bytes = 68 banks: the 16 rows a ds_read_b128 / ds_read_b32 group touches land 4 banks apart (conflict-free);
+// the fp32 [64][128] view keeps variant 6's XOR swizzle by (row & 15).
 // MCR_HIPCC_FLAGS: -fno-slp-vectorize
 #include "lp_split.h"
 
@@ -34,7 +42,11 @@ __device__ __forceinline__ int opaque(int v) {
     return v;
 }
 
-constexpr int PF = 3;                              // k16-steps of weights in flight per wave and tile
+#ifndef L7_PF
+#define L7_PF 3
+#endif
+constexpr int PF = L7_PF;                          // k16-steps of weights in flight per wave and tile
+constexpr int PR = 17;                             // 16-byte chunks per plane row (16 + 1 padding)
 struct WRing { uint4 b[PF]; };                     // [slot]
 
 __device__ __forceinline__ const uint4* wptr(const float* Wp, int nt, int S, int lane) {
@@ -69,12 +81,12 @@ template <int S>
 __device__ __forceinline__ void gemm(f32x16 (&acc)[2], const uint4* __restrict__ A, WRing& r, const uint4* __restrict__ bp,
                                      int lane_) {
     const int lane = opaque(lane_);
-    const int i = lane & 31, h = lane >> 5, key = i & 15;
+    const int i = lane & 31, h = lane >> 5;
     uint4 an[2];
     auto fetch = [&](int s) {
-        const int c = (2 * s + h) ^ key;
+        const int c = 2 * s + h;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) an[mt] = A[(mt * 32 + i) * 16 + c];
+        for (int mt = 0; mt < 2; ++mt) an[mt] = A[(mt * 32 + i) * PR + c];
     };
     fetch(0);
     // software pipeline in program order, fenced: [next step's 2 fragment reads][the weight request PF steps ahead] |
@@ -99,12 +111,12 @@ template <int S, class Fn>
 __device__ __forceinline__ void gemm_with(f32x16 (&acc)[2], const uint4* __restrict__ A, WRing& r, const uint4* __restrict__ bp,
                                           int lane_, Fn fn) {
     const int lane = opaque(lane_);
-    const int i = lane & 31, h = lane >> 5, key = i & 15;
+    const int i = lane & 31, h = lane >> 5;
     uint4 an[2];
     auto fetch = [&](int s) {
-        const int c = (2 * s + h) ^ key;
+        const int c = 2 * s + h;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) an[mt] = A[(mt * 32 + i) * 16 + c];
+        for (int mt = 0; mt < 2; ++mt) an[mt] = A[(mt * 32 + i) * PR + c];
     };
     fetch(0);
 #pragma unroll
@@ -128,12 +140,12 @@ __device__ __forceinline__ void gemm_qkv(f32x16 (&acc)[2], f32x16& acch, const u
                                          const uint4* __restrict__ bp0, const uint4* __restrict__ bp1, int wave, int lane_) {
     constexpr int S = 8;
     const int lane = opaque(lane_);
-    const int i = lane & 31, h = lane >> 5, key = i & 15, mh = wave & 1;
+    const int i = lane & 31, h = lane >> 5, mh = wave & 1;
     uint4 an[2];
     auto fetch = [&](int s) {
-        const int c = (2 * s + h) ^ key;
+        const int c = 2 * s + h;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) an[mt] = A[(mt * 32 + i) * 16 + c];
+        for (int mt = 0; mt < 2; ++mt) an[mt] = A[(mt * 32 + i) * PR + c];
     };
     fetch(0);
 #pragma unroll
@@ -157,17 +169,14 @@ __device__ __forceinline__ void gemm_qkv(f32x16 (&acc)[2], f32x16& acch, const u
 
 // ---- epilogue helpers: a C fragment t (n-tile nt, m-tile mt) holds, in lane (j, h), the features 32 nt + 8 g + 4 h + e
 // (register r = 4 g + e) of token 32 mt + j ----------------------------------------------------------------------------------
-// The accumulator of a product starts from its bias (times the matrix's power-of-two scale, folded on the host): the four
-// 16-byte loads land directly in the accumulator registers, the epilogue is a single multiply by 2^-e.  Products whose result
-// is added to the residual stream (out projection, FF2) accumulate IN PLACE: x <- x 2^e + b 2^e, the MFMAs add W' a on top,
-// x <- x 2^-e (power-of-two scalings are exact), so no second accumulator set is live next to the residual registers.
-__device__ __forceinline__ void scale_add_bias(f32x16& x, float scale, const float* __restrict__ vec, int nt, int lane_) {
+// The accumulator of a product starts from its bias: the four 16-byte loads land directly in the accumulator registers.  Products
+// whose result is added to the residual stream (out projection, FF2) accumulate IN PLACE on x + b.
+__device__ __forceinline__ void add_bias(f32x16& x, const float* __restrict__ vec, int nt, int lane_) {
     const float4* p = reinterpret_cast<const float4*>(vec + 32 * nt + 4 * (opaque(lane_) >> 5));
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float4 b = p[2 * g];
-        x[4 * g] = fmaf(x[4 * g], scale, b.x); x[4 * g + 1] = fmaf(x[4 * g + 1], scale, b.y);
-        x[4 * g + 2] = fmaf(x[4 * g + 2], scale, b.z); x[4 * g + 3] = fmaf(x[4 * g + 3], scale, b.w);
+        x[4 * g] += b.x; x[4 * g + 1] += b.y; x[4 * g + 2] += b.z; x[4 * g + 3] += b.w;
     }
 }
 __device__ __forceinline__ void init_bias(f32x16& a, const float* __restrict__ vec, int nt, int lane_) {
@@ -183,32 +192,30 @@ __device__ __forceinline__ void init_bias(f32x16& a, const float* __restrict__ v
 __device__ __forceinline__ void put4(uint2* __restrict__ plane, int idx, float v0, float v1, float v2, float v3) {
     plane[idx] = make_uint2(pack2h(v0, v1), pack2h(v2, v3));
 }
-// planes[...] of one 32-feature column block (n-tile nt) for m-tile mt from t through f(value, g, e)
+// the plane of one 32-feature column block (n-tile nt) for m-tile mt from t through f(value, g, e); uint2 index = row * 34 + 2 chunk + h
 template <class Fn>
 __device__ __forceinline__ void put_planes(uint4* __restrict__ buf, int nt, int mt, const f32x16& t, int lane_, Fn f) {
     const int lane = opaque(lane_);
-    const int j = lane & 31, h = lane >> 5, key = j & 15;
-    uint2* b2 = reinterpret_cast<uint2*>(buf);
-    const int base = (mt * 32 + j) * 32 + h;
+    const int j = lane & 31, h = lane >> 5;
+    uint2* b2 = reinterpret_cast<uint2*>(buf) + (mt * 32 + j) * (2 * PR) + h + 8 * nt;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        put4(b2, base + (((4 * nt + g) ^ key) << 1), f(t[4 * g], g, 0), f(t[4 * g + 1], g, 1), f(t[4 * g + 2], g, 2),
-             f(t[4 * g + 3], g, 3));
+        put4(b2, 2 * g, f(t[4 * g], g, 0), f(t[4 * g + 1], g, 1), f(t[4 * g + 2], g, 2), f(t[4 * g + 3], g, 3));
         __builtin_amdgcn_sched_barrier(0);         // one quad at a time: interleaving all 32 GELUs of an epilogue spills
     }
 }
-// one quad (g) of put_planes: 4 consecutive features of one token, split and stored; `row` = (lane & 31) * 32 + (lane >> 5) and
-// `key` = lane & 15 are computed once per product by the caller
+// one quad (g) of put_planes: `row` = (lane & 31) * 34 + (lane >> 5) is computed once per product by the caller
 template <class Fn>
-__device__ __forceinline__ void put_quad(uint4* __restrict__ buf, int nt, int mt, int g, const f32x16& t, int row, int key, Fn f) {
+__device__ __forceinline__ void put_quad(uint4* __restrict__ buf, int nt, int mt, int g, const f32x16& t, int row, Fn f) {
     uint2* b2 = reinterpret_cast<uint2*>(buf);
-    put4(b2, mt * 1024 + row + (((4 * nt + g) ^ key) << 1), f(t[4 * g]), f(t[4 * g + 1]), f(t[4 * g + 2]), f(t[4 * g + 3]));
+    put4(b2, mt * (32 * 2 * PR) + row + 2 * (4 * nt + g), f(t[4 * g]), f(t[4 * g + 1]), f(t[4 * g + 2]), f(t[4 * g + 3]));
 }
-// fp32 tile with row stride LD floats: features (4 floats = one chunk) chunk0 + 2 g + h of token 32 mt + j, ds_write_b128
+// fp32 tile with row stride LD floats: features (4 floats = one chunk) chunk0 + 2 g + h of token 32 mt + j, ds_write_b128;
+// kmask = 15: chunks XOR-swizzled by the row (the [64][128] view), 0: plain rows (the padded q | k view)
 template <class Fn>
-__device__ __forceinline__ void put_f32(float* __restrict__ buf, int LD, int chunk0, int mt, const f32x16& t, int lane_, Fn f) {
+__device__ __forceinline__ void put_f32(float* __restrict__ buf, int LD, int kmask, int chunk0, int mt, const f32x16& t, int lane_, Fn f) {
     const int lane = opaque(lane_);
-    const int j = lane & 31, h = lane >> 5, key = j & 15;
+    const int j = lane & 31, h = lane >> 5, key = j & kmask;
     float* row = buf + (mt * 32 + j) * LD;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -269,8 +276,9 @@ __device__ __forceinline__ void ln_finish(const f32x16 (&x)[2], const float2* __
             dd = fmaf(d, d, dd);
         }
         m2 = fmaf(32.f, dd, m2);
-        const float rstd = 1.0f / sqrtf(m2 * (1.0f / 128.f) + 1e-5f);
-        put_planes(P, wave, mt, x[mt], lane_, [&](float v, int, int) { return (v - mu) * rstd; });
+        const float rstd = __builtin_amdgcn_rsqf(fmaf(m2, 1.0f / 128.f, 1e-5f));
+        const float shift = -mu * rstd;
+        put_planes(P, wave, mt, x[mt], lane_, [&](float v, int, int) { return fmaf(v, rstd, shift); });
     }
 }
 
@@ -290,16 +298,15 @@ __device__ long long l7_trace_buf[64];
 __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __restrict__ offs, float* __restrict__ feat,
                                                                 long long ld_feat, long long S,
                                                                 const float* __restrict__ blob, _Float16* __restrict__ feat_h) {
-    __shared__ __attribute__((aligned(16))) uint4 P[64 * 16];
+    __shared__ __attribute__((aligned(16))) uint4 P[64 * PR];
     __shared__ __attribute__((aligned(16))) uint4 H[2 * 64 * 16];
     __shared__ __attribute__((aligned(16))) float2 St[4 * 64];
-    float* Pq = reinterpret_cast<float*>(P);               // fp32 [64][64] view: q | k
+    float* Pq = reinterpret_cast<float*>(P);               // fp32 [64][68] view: q | k (columns 64..67 padding)
     float* F = reinterpret_cast<float*>(H);                // fp32 [64][128] view: v / the final tile
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably uniform: weight / bias addresses = SGPR base + lane offset
     const float* mats = blob;
     const float* vecs = blob + L7_MATS_TOTAL;
-    const float* isc = vecs + L7_SCALES;                   // 2^-e of every matrix (the host stores W * 2^e)
     // One workgroup per 4-query group, NOT persistent: persistent workgroups (2 per CU, looping over groups with the next group's
     // offsets prefetched) measured 5 % slower -- the two co-resident workgroups then run in lock-step and collide in the same
     // phase (both on the matrix pipe, then both on the vector ALU); fresh workgroups start staggered and overlap better.
@@ -338,12 +345,9 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
     }
     L7_T();                                        // emb1 product done
     wload<8>(ring, wptr(mats + l7_mat_off(1), wave, 8, lane));
-    {
-        const float sc = isc[0];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-            put_planes(H, wave, mt, acc[mt], lane, [&](float v, int, int) { return l3_gelu(v * sc); });
-    }
+    for (int mt = 0; mt < 2; ++mt)
+        put_planes(H, wave, mt, acc[mt], lane, [&](float v, int, int) { return l3_gelu(v); });
     init_bias(xres[0], vecs + L3_VEC_EMB2, wave, lane);
     init_bias(xres[1], vecs + L3_VEC_EMB2, wave, lane);
     __syncthreads();
@@ -351,11 +355,6 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
     gemm<8>(xres, H, ring, wptr(mats + l7_mat_off(1), wave, 8, lane), lane);
     L7_T();                                        // emb2 gemm
     {
-        const float sc = isc[1];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xres[mt][r] *= sc;
         const bool cat = wave == 3 && lane >= 32;  // features 125..127 = the raw xyz (Attention.py:123-126): n-tile 3, g = 3, h = 1, e = 1..3
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -369,7 +368,6 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
     for (int e = 0; e < 2; ++e) {
         const float* em = mats + l7_mat_off(2) + e * (L7_MAT_QKV + 5 * L7_MAT_128);
         const float* ev = vecs + L3_VEC_ENC0 + e * L3_VEC_ENC_STRIDE;
-        const float* es = isc + 2 + 6 * e;          // 2^-e of qkv, out, ff1a, ff1b, ff2a (= ff2b); the forward scales 2^e sit 16 floats later
         const float* w_out = em + L7_MAT_QKV;
         const float* w_ff1a = w_out + L7_MAT_128;
         const float* w_ff1b = w_out + L7_MAT_128 * 2;
@@ -397,16 +395,15 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
             gemm_qkv(aq, ah, P, ring, ring1, bq0, bq1, wave, lane);
             L7_T();                                // qkv gemm
             wload<8>(ring, wptr(w_out, wave, 8, lane));
-            const float sc = es[0];
             __syncthreads();                       // x^ planes consumed: P may take q|k
             L7_T();                                // barrier
             // n-tiles 0,1 = q,k -> Pq chunks 0..7 / 8..15; n-tiles 2..5 = v -> F chunks 8 (nt - 2) ..
-            auto fb = [&](float v, int, int) { return v * sc; };
+            auto fb = [&](float v, int, int) { return v; };
             float* dst = wave < 2 ? Pq : F;         // branch-free: the whole encoder stays one basic block
-            const int ld = wave < 2 ? 64 : 128, c0 = wave < 2 ? 8 * wave : 8 * (wave - 2);
+            const int ld = wave < 2 ? 4 * PR : 128, km = wave < 2 ? 0 : 15, c0 = wave < 2 ? 8 * wave : 8 * (wave - 2);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) put_f32(dst, ld, c0, mt, aq[mt], lane, fb);
-            put_f32(F, 128, 8 * (nth - 2), wave & 1, ah, lane, fb);
+            for (int mt = 0; mt < 2; ++mt) put_f32(dst, ld, km, c0, mt, aq[mt], lane, fb);
+            put_f32(F, 128, 15, 8 * (nth - 2), wave & 1, ah, lane, fb);
         }
         __syncthreads();
         L7_T();                                    // qkv put + barrier
@@ -418,7 +415,7 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
         {
             const int ln = opaque(lane);
             const int r0 = wave * 16, li = ln & 15, g = ln >> 4;
-            const int wq = ((r0 + li) * 64) | (li << 2) | g;                                   // Pq[row = r0+li][chunk c][g]   = wq ^ (c << 2)
+            const int wq = (r0 + li) * (4 * PR) + g;                                           // Pq[row = r0+li][chunk c][g]   = wq + 4 c
             const int wv = ((r0 + 4 * g) * 128) | ((((li >> 2) | (g << 2)) << 2)) | (li & 3);    // F[row = r0+4g+s][chunk C][li&3] = s*128 + (wv ^ ((C ^ s) << 2))
             f32x4 pr[4];
 #pragma unroll
@@ -426,8 +423,8 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
                 f32x4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int sk = 0; sk < 2; ++sk) {
-                    const float kk = Pq[wq ^ ((8 + 2 * hh + sk) << 2)];                  // A[i = j][k = d]      = k[j][hh*8 + 4 sk + g]
-                    const float qq = Pq[wq ^ ((2 * hh + sk) << 2)];                      // B[k = d][n = qi]     = q[qi][hh*8 + 4 sk + g]
+                    const float kk = Pq[wq + ((8 + 2 * hh + sk) << 2)];                  // A[i = j][k = d]      = k[j][hh*8 + 4 sk + g]
+                    const float qq = Pq[wq + ((2 * hh + sk) << 2)];                      // B[k = d][n = qi]     = q[qi][hh*8 + 4 sk + g]
                     st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk, qq, st, 0, 0, 0);
                 }
                 float mx = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
@@ -459,29 +456,22 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
             // every q | k read of this wave's 16 rows precedes the plane writes over them (other waves own other rows)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             uint2* p2 = reinterpret_cast<uint2*>(P);
-            const int base = (r0 + li) * 32 + (g & 1);
+            const int base = (r0 + li) * (2 * PR) + g;        // chunk 4 hh + 2 nt + (g >> 1), half g & 1  ->  + 2 (4 hh + 2 nt)
 #pragma unroll
             for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    put4(p2, base + (((4 * hh + 2 * nt + (g >> 1)) ^ li) << 1), o[hh][nt][0], o[hh][nt][1], o[hh][nt][2], o[hh][nt][3]);
+                    put4(p2, base + 2 * (4 * hh + 2 * nt), o[hh][nt][0], o[hh][nt][1], o[hh][nt][2], o[hh][nt][3]);
         }
         // ---- out projection + residual (Attention.py:201-202, 290): x += att W_o^T + b, accumulated in place ----
         L7_T();                                    // attention
-        scale_add_bias(xres[0], es[16 + 1], ev + 192, wave, lane);
-        scale_add_bias(xres[1], es[16 + 1], ev + 192, wave, lane);
+        add_bias(xres[0], ev + 192, wave, lane);
+        add_bias(xres[1], ev + 192, wave, lane);
         __syncthreads();
         L7_T();                                    // bias + barrier
         gemm<8>(xres, P, ring, wptr(w_out, wave, 8, lane), lane);
         L7_T();                                    // out gemm
         wload<8>(ring, wptr(w_ff1a, wave, 8, lane));
-        {
-            const float sc = es[1];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xres[mt][r] *= sc;
-        }
         // ---- norm2 (folded) -> planes P ; FF 128 -> 256 (GELU) -> 128 + residual (Attention.py:293-298), two halves ----
         ln_partial(xres, St, wave, lane);
         init_bias(acc[0], ev + 192 + 128, wave, lane);
@@ -500,25 +490,19 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
         f32x16 accb[2];
         init_bias(accb[0], ev + 192 + 128 + 128, wave, lane);
         init_bias(accb[1], ev + 192 + 128 + 128, wave, lane);
-        const int pq_lane = opaque(lane), pq_row = (pq_lane & 31) * 32 + (pq_lane >> 5), pq_key = pq_lane & 15;
-        {
-            const float sc = es[2];
-            gemm_with<8>(accb, P, ring, wptr(w_ff1b, wave, 8, lane), lane, [&](int s_) {
-                put_quad(H, wave, s_ >> 2, s_ & 3, acc[s_ >> 2], pq_row, pq_key, [&](float v) { return l3_gelu(v * sc); });
-            });
-        }
+        const int pq_lane = opaque(lane), pq_row = (pq_lane & 31) * (2 * PR) + (pq_lane >> 5);
+        gemm_with<8>(accb, P, ring, wptr(w_ff1b, wave, 8, lane), lane, [&](int s_) {
+            put_quad(H, wave, s_ >> 2, s_ & 3, acc[s_ >> 2], pq_row, [&](float v) { return l3_gelu(v); });
+        });
         L7_T();                                    // ff1b gemm + gelu a
         wload<8>(ring, wptr(w_ff2a, wave, 8, lane));
-        scale_add_bias(xres[0], es[16 + 4], ev + 192 + 128 + 256, wave, lane);   // FF2 accumulates onto the residual in place
-        scale_add_bias(xres[1], es[16 + 4], ev + 192 + 128 + 256, wave, lane);
+        add_bias(xres[0], ev + 192 + 128 + 256, wave, lane);   // FF2 accumulates onto the residual in place
+        add_bias(xres[1], ev + 192 + 128 + 256, wave, lane);
         __syncthreads();                           // hidden half a visible; x^ planes in P consumed by every wave
         L7_T();                                    // barrier
-        {
-            const float sc = es[3];
-            gemm_with<8>(xres, H, ring, wptr(w_ff2a, wave, 8, lane), lane, [&](int s_) {
-                put_quad(P, wave, s_ >> 2, s_ & 3, accb[s_ >> 2], pq_row, pq_key, [&](float v) { return l3_gelu(v * sc); });
-            });
-        }
+        gemm_with<8>(xres, H, ring, wptr(w_ff2a, wave, 8, lane), lane, [&](int s_) {
+            put_quad(P, wave, s_ >> 2, s_ & 3, accb[s_ >> 2], pq_row, [&](float v) { return l3_gelu(v); });
+        });
         L7_T();                                    // ff2a gemm + gelu b
         wload<8>(ring, wptr(w_ff2b, wave, 8, lane));
         __syncthreads();                           // hidden half b visible
@@ -526,13 +510,6 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
         L7_T();                                    // (spare stamp: keeps the trace table of tools/trace_local_pct.py aligned)
         gemm<8>(xres, P, ring, wptr(w_ff2b, wave, 8, lane), lane);
         L7_T();                                    // ff2b gemm
-        {
-            const float sc = es[4];                 // ff2a and ff2b share one exponent
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xres[mt][r] *= sc;
-        }
     }
     L7_T();
     // ---- final norm (folded) + linear0 128 -> 128 (SconeOcc.py:119-122) ----
@@ -544,12 +521,9 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
     ln_finish(xres, St, P, wave, lane);
     __syncthreads();
     gemm<8>(acc, P, ring, wptr(mats + l7_mat_off(14), wave, 8, lane), lane);
-    {
-        const float sc = isc[14];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-            put_f32(F, 128, 8 * wave, mt, acc[mt], lane, [&](float v, int, int) { return v * sc; });
-    }
+    for (int mt = 0; mt < 2; ++mt)
+        put_f32(F, 128, 15, 8 * wave, mt, acc[mt], lane, [&](float v, int, int) { return v; });
     __syncthreads();
     L7_T();                                        // final norm + lin0
     // ---- max || avg pool over the 16 tokens of each query (SconeOcc.py:124-126) ----

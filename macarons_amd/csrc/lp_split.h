@@ -47,7 +47,7 @@ constexpr int L6_SCALES = L3_VECS_TOTAL;                      // offset of the 1
 constexpr int L6_BLOB_FLOATS = L6_MATS_TOTAL + L3_VECS_TOTAL + 32;
 
 // ---- blob of variant 7 (opt-in 16-bit matrix path): matrices as [n-tile][k16 step][lane][8 fp16] -- the HIGH plane of variant 6's
-// blob alone (fp16(W 2^e_i), half a float per weight); then the same vectors and the same 32 scale floats as variant 6
+// blob WITHOUT the per-matrix power of two (fp16(W), half a float per weight); then the same vectors (biases as they are)
 constexpr int L7_MAT_K16 = 128 * 16 / 2, L7_MAT_128 = 128 * 128 / 2, L7_MAT_QKV = 192 * 128 / 2;
 __host__ __device__ constexpr int l7_mat_off(int idx) {
     int off = 0;
@@ -58,8 +58,7 @@ __host__ __device__ constexpr int l7_mat_off(int idx) {
     return off;
 }
 constexpr int L7_MATS_TOTAL = l7_mat_off(15);
-constexpr int L7_SCALES = L3_VECS_TOTAL;
-constexpr int L7_BLOB_FLOATS = L7_MATS_TOTAL + L3_VECS_TOTAL + 32;
+constexpr int L7_BLOB_FLOATS = L7_MATS_TOTAL + L3_VECS_TOTAL;
 
 __device__ __forceinline__ unsigned pack2h(const float a, const float b) {      // {fp16(b), fp16(a)}, round to nearest even: v_cvt_pk_f16_f32
     const f32x2 x = {a, b};

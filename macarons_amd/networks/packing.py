@@ -267,7 +267,7 @@ def _pack_local_pct6(pct, planes=2):
         mats, vecs, inv = [], [], []
 
         def add(*Ws):
-            sc = _pow2_scale(*Ws)
+            sc = _pow2_scale(*Ws) if planes == 2 else 1.0     # (variant 7: weights and biases as they are, rounded to fp16)
             for W in Ws:
                 mats.append(_pack_f16x2(W.contiguous(), sc, planes))
                 inv.append(1.0 / sc)
@@ -298,7 +298,8 @@ def _pack_local_pct6(pct, planes=2):
         assert len(inv) == 15
         dev = mats[0].device
         fwd = [1.0 / v for v in inv]
-        blob = torch.cat(mats + vecs + [torch.tensor(inv + [0.0] + fwd + [0.0], dtype=torch.float32, device=dev)]).contiguous()
+        tail = [torch.tensor(inv + [0.0] + fwd + [0.0], dtype=torch.float32, device=dev)] if planes == 2 else []
+        blob = torch.cat(mats + vecs + tail).contiguous()
     expect = _lib.lib().mcr_local_pct6_blob_floats() if planes == 2 else _lib.lib().mcr_local_pct7_blob_floats()
     if blob.numel() != expect:
         raise RuntimeError(f"packed local transformer (v{8 - planes}) has {blob.numel()} floats, kernel expects {expect}")

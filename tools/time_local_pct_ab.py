@@ -21,13 +21,13 @@ ref = nets.pc_transformer(sd, "local_transformers.0.", offs[:600].cpu().numpy(),
 variants = [int(v) for v in os.environ.get("VARIANTS", "1,5,6").split(",")]
 for rnd in range(2):
     for v in variants:
-        _lib.lib().mcr_set_local_pct_variant(ctypes.c_int(v))
         blob = pack_local_pct(occ.local_transformers[0], v)
         if os.environ.get("ZERO_BLOB"): blob = torch.zeros_like(blob)      # power experiment: same instruction stream on zero operands
         if os.environ.get("ZERO_INPUT"): offs = torch.zeros_like(offs)
-        for _ in range(3): y = ops.local_pct_forward(offs, blob)
-        torch.cuda.synchronize(); t = time.perf_counter()
-        for _ in range(20): y = ops.local_pct_forward(offs, blob)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 20
+        with ops.variant(v):               # (per-call selection: variant 7 is never a process default)
+            for _ in range(3): y = ops.local_pct_forward(offs, blob)
+            torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(20): y = ops.local_pct_forward(offs, blob)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 20
         err = float(np.abs(y[:600].cpu().numpy() - ref).max() / np.abs(ref).max())
         print(f"[{os.environ.get('MCR_DEV_LIB', 'main')}] variant {v}: {dt*1e3:.3f} ms  {S*8.0e6/dt/1e12:.1f} TFLOP/s-equivalent   rel err vs fp64 oracle {err:.2e}")
