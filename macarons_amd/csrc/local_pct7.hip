@@ -46,6 +46,22 @@ __device__ __forceinline__ int opaque(int v) {
 #define L7_PF 3
 #endif
 constexpr int PF = L7_PF;                          // k16-steps of weights in flight per wave and tile
+// erf-GELU (Attention.py:232, nn.GELU()) for values that are rounded to fp16 right after: erf by Abramowitz-Stegun 7.1.25 (three
+// terms, |error| <= 2.5e-5 -- a tenth of the fp16 rounding unit of the result; measured on the GELU itself: 2.6e-5 absolute, 1.1e-5
+// of |x|) with the constants arranged so that nothing is multiplied twice: w = |x| sqrt(log2(e) / 2), exp(-x^2 / 2) = exp2(-w w),
+// 1 + p |x| / sqrt(2) = fma(w, p / sqrt(log2 e), 1).  Nine vector instructions + rcp + exp2 (l3_gelu: thirteen + two).
+__device__ __forceinline__ float l7_gelu(float x) {
+    const float w = fabsf(x) * 0.84932180028801904f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(w, 0.39169198f, 1.0f));
+    float q = fmaf(0.7478556f, t, -0.0958798f);
+    q = fmaf(q, t, 0.3480242f);
+    q *= t;
+    const float e = __builtin_amdgcn_exp2f(-(w * w));
+    const float erfa = fmaf(-q, e, 1.0f);
+    const float hx = 0.5f * x;
+    return fmaf(fabsf(hx), erfa, hx);
+}
+
 constexpr int PR = 17;                             // 16-byte chunks per plane row (16 + 1 padding)
 struct WRing { uint4 b[PF]; };                     // [slot]
 
@@ -239,23 +255,22 @@ __device__ __forceinline__ float rows_allreduce(float v, Op op) {           // o
     return op(__builtin_bit_cast(float, (unsigned)q[0]), __builtin_bit_cast(float, (unsigned)q[1]));
 }
 
-// LayerNorm, part 1: this wave's (mean, M2) over its 32 features of every token -> St[wave][token]
+// LayerNorm, part 1: this wave's (mean, M2) over its 32 features of every token -> St[wave][token].  One pass (sum and sum of
+// squares in fp32, M2 = sum x^2 - 32 mean^2: exact enough for an fp16 result unless |mean| > ~30 standard deviations inside a
+// 32-feature slice); variant 6 subtracts the mean first (32 more instructions per token and wave).
 __device__ __forceinline__ void ln_partial(const f32x16 (&x)[2], float2* __restrict__ St, int wave, int lane_) {
     const int lane = opaque(lane_);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        float s = 0.f;
+        float s = 0.f, q = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r += 4) s += (x[mt][r] + x[mt][r + 1]) + (x[mt][r + 2] + x[mt][r + 3]);
-        const float m = halves_sum(s) * (1.0f / 32.f);
-        float q = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float d = x[mt][r] - m;
-            q = fmaf(d, d, q);
-        }
+        for (int r = 0; r < 16; ++r) q = fmaf(x[mt][r], x[mt][r], q);
+        s = halves_sum(s);
         q = halves_sum(q);
-        St[wave * 64 + mt * 32 + (lane & 31)] = make_float2(m, q);      // both lane halves hold (and store) the same pair: no branch
+        const float m = s * (1.0f / 32.f);
+        St[wave * 64 + mt * 32 + (lane & 31)] = make_float2(m, fmaxf(fmaf(-s, m, q), 0.f));   // both lane halves hold (and store) the same pair: no branch
     }
 }
 // part 2 (after a barrier): combine the 4 partials (Chan), normalise (eps 1e-5; gamma / beta are folded into the next
@@ -347,7 +362,7 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
     wload<8>(ring, wptr(mats + l7_mat_off(1), wave, 8, lane));
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
-        put_planes(H, wave, mt, acc[mt], lane, [&](float v, int, int) { return l3_gelu(v); });
+        put_planes(H, wave, mt, acc[mt], lane, [&](float v, int, int) { return l7_gelu(v); });
     init_bias(xres[0], vecs + L3_VEC_EMB2, wave, lane);
     init_bias(xres[1], vecs + L3_VEC_EMB2, wave, lane);
     __syncthreads();
@@ -492,7 +507,7 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
         init_bias(accb[1], ev + 192 + 128 + 128, wave, lane);
         const int pq_lane = opaque(lane), pq_row = (pq_lane & 31) * (2 * PR) + (pq_lane >> 5);
         gemm_with<8>(accb, P, ring, wptr(w_ff1b, wave, 8, lane), lane, [&](int s_) {
-            put_quad(H, wave, s_ >> 2, s_ & 3, acc[s_ >> 2], pq_row, [&](float v) { return l3_gelu(v); });
+            put_quad(H, wave, s_ >> 2, s_ & 3, acc[s_ >> 2], pq_row, [&](float v) { return l7_gelu(v); });
         });
         L7_T();                                    // ff1b gemm + gelu a
         wload<8>(ring, wptr(w_ff2a, wave, 8, lane));
@@ -501,7 +516,7 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
         __syncthreads();                           // hidden half a visible; x^ planes in P consumed by every wave
         L7_T();                                    // barrier
         gemm_with<8>(xres, H, ring, wptr(w_ff2a, wave, 8, lane), lane, [&](int s_) {
-            put_quad(P, wave, s_ >> 2, s_ & 3, accb[s_ >> 2], pq_row, [&](float v) { return l3_gelu(v); });
+            put_quad(P, wave, s_ >> 2, s_ & 3, accb[s_ >> 2], pq_row, [&](float v) { return l7_gelu(v); });
         });
         L7_T();                                    // ff2a gemm + gelu b
         wload<8>(ring, wptr(w_ff2b, wave, 8, lane));
