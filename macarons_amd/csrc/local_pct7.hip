@@ -262,6 +262,20 @@ __device__ __forceinline__ void ln_partial(const f32x16 (&x)[2], float2* __restr
     const int lane = opaque(lane_);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+#ifdef L7_LN_TWO_PASS
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) s += (x[mt][r] + x[mt][r + 1]) + (x[mt][r + 2] + x[mt][r + 3]);
+        const float m = halves_sum(s) * (1.0f / 32.f);
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = x[mt][r] - m;
+            q = fmaf(d, d, q);
+        }
+        q = halves_sum(q);
+        St[wave * 64 + mt * 32 + (lane & 31)] = make_float2(m, q);
+#else
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r += 4) s += (x[mt][r] + x[mt][r + 1]) + (x[mt][r + 2] + x[mt][r + 3]);
@@ -271,6 +285,7 @@ __device__ __forceinline__ void ln_partial(const f32x16 (&x)[2], float2* __restr
         q = halves_sum(q);
         const float m = s * (1.0f / 32.f);
         St[wave * 64 + mt * 32 + (lane & 31)] = make_float2(m, fmaxf(fmaf(-s, m, q), 0.f));   // both lane halves hold (and store) the same pair: no branch
+#endif
     }
 }
 // part 2 (after a barrier): combine the 4 partials (Chan), normalise (eps 1e-5; gamma / beta are folded into the next

@@ -335,8 +335,11 @@ def test_coverage_metrics_match_reference(dev):
     assert float(gain) == float(g["cov_gain"])
 
 
-def test_macarons_trajectory_matches_reference(dev):
-    """TEN consecutive decisions with the state accumulating (BASELINE config 5: "10 trajectory steps ... achieved surface coverage vs
+def run_macarons_trajectory(dev, variant=None, strict=True):
+    """strict=False (with `variant`): the exact / 1e-4 value assertions of the default numerics become entries of the returned report
+    (per step: differing mask bits, value errors, the choice), for a variant with its own stated tolerance (tests/test_variant7_gpu.py);
+    the replay itself -- the reference's poses, clouds and hidden draws -- is the same.
+    TEN consecutive decisions with the state accumulating (BASELINE config 5: "10 trajectory steps ... achieved surface coverage vs
     reference"): the golden is the REFERENCE's tester body (testers/scene.py:284-454) driven pose after pose on its own Scene / Cell /
     Camera objects -- 3 x 2 x 3 grid, 24 000 proxy points, the surface scene empty at the start and fed by every depth map, 5-8
     neighbour poses per step, the camera MOVING to the chosen one (make_golden.py: gen_trajectory).  Replayed here through
@@ -345,8 +348,11 @@ def test_macarons_trajectory_matches_reference(dev):
     coverage EXACT, frustum mask / supervision occupancy / out-of-field flags / counters / view-state row sums exact, the number of
     field rows, occupancies 1e-4, view harmonics 1e-5, every neighbour's gain 1e-4, the SAME ten choices; at the end the whole
     view-state table exact and the stored probabilities at 1e-4."""
+    import contextlib
     import keyed_rng as KR
+    from macarons_amd import ops
     from macarons_amd.utility import macarons_utils as mu
+    report = {"steps": []}
     from macarons_amd.utility.scene import Scene
     g = golden("macarons_trajectory")
     m = _models(dev)
@@ -409,9 +415,25 @@ def test_macarons_trajectory_matches_reference(dev):
             for k, (a, e) in enumerate(nb.tolist()):
                 for j_, v_ in fixes.get((step, int(a) * 8 + int(e)), {}).items():
                     u[k, j_] = v_
-            r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, depth, dmask, nrec, T(n_eyes, dev), dev, samples=u.to(dev))
+            with (ops.variant(variant) if variant else contextlib.nullcontext()):
+                r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, depth, dmask, nrec, T(n_eyes, dev), dev, samples=u.to(dev))
             assert "fallback_variant" not in r                       # (the range guard of both networks stayed quiet)
             bits = lambda t_: np.packbits(t_.cpu().numpy().reshape(-1).astype(np.uint8))
+            if not strict:
+                nbits = lambda t_, ref: int(np.unpackbits(bits(t_) ^ ref).sum())
+                occ_ref = g[f"occ_{step}"]
+                gains, gref = r["gains"].cpu().numpy().reshape(-1), g[f"gains_{step}"].reshape(-1)
+                order = np.argsort(-gref)
+                report["steps"].append({
+                    "fov_mask_bits": nbits(r["fov_mask"], g[f"fov_mask_{step}"]), "sup_occ_bits": nbits(proxy.proxy_supervision_occ, g[f"sup_occ_{step}"]),
+                    "oof_bits": nbits(proxy.out_of_field, g[f"oof_{step}"]),
+                    "vs_rowsum_diff": int((proxy.view_states.sum(-1).cpu().numpy().astype(np.uint8) != g[f"vs_rowsum_{step}"]).sum()),
+                    "field_rows": int(r["X_world"].shape[0]), "field_rows_ref": int(g[f"field_n_{step}"]),
+                    "occ_rel_err": (float(np.abs(r["occ_probs"].cpu().numpy()[::7, 0] - occ_ref).max() / np.abs(occ_ref).max())
+                                    if r["X_world"].shape[0] == int(g[f"field_n_{step}"]) else None),
+                    "gains_rel_err": rel_err(gains, gref), "next_idx": int(r["next_idx"]), "next_idx_ref": int(g["next_idx"][step]),
+                    "ref_gain_margin_rel": float((gref[order[0]] - gref[order[1]]) / np.abs(gref).max()) if len(gref) > 1 else None})
+                continue
             assert np.array_equal(bits(r["fov_mask"]), g[f"fov_mask_{step}"]), step
             assert np.array_equal(bits(proxy.proxy_supervision_occ), g[f"sup_occ_{step}"]), step
             assert np.array_equal(bits(proxy.out_of_field), g[f"oof_{step}"]), step
@@ -424,9 +446,23 @@ def test_macarons_trajectory_matches_reference(dev):
             assert rel_err(r["view_harmonics"].cpu().numpy()[::37], g[f"vh_{step}"]) < 1e-5, step
             assert rel_err(r["gains"].cpu().numpy(), g[f"gains_{step}"]) < 1e-4, (step, r["gains"].cpu().numpy(), g[f"gains_{step}"])
             assert int(r["next_idx"]) == int(g["next_idx"][step]), step
+    if not strict:
+        report["view_state_bits_final"] = int(np.unpackbits(np.packbits(proxy.view_states.cpu().numpy().astype(np.uint8), axis=-1) ^ g["view_states_final"]).sum())
+        report["proxy_proba_final_rel_err"] = float(np.abs(proxy.proxy_proba.cpu().numpy()[:, 0] - g["proxy_proba_final"]).max()
+                                                    / np.abs(g["proxy_proba_final"]).max())
+        report["draws_missing"] = [str(k_) for k_ in expect if len(expect[k_]) != len(kr.sizes().get(k_, []))]
+        return report
     assert np.array_equal(np.packbits(proxy.view_states.cpu().numpy().astype(np.uint8), axis=-1), g["view_states_final"])
     assert np.abs(proxy.proxy_proba.cpu().numpy()[:, 0] - g["proxy_proba_final"]).max() < 1e-4 * np.abs(g["proxy_proba_final"]).max()
     assert [k_ for k_ in expect if len(expect[k_]) != len(kr.sizes().get(k_, []))] == []       # every draw the reference made was made
+    return report
+
+
+def test_macarons_trajectory_matches_reference(dev):
+    """The ten-decision trajectory golden on the default numerics: every exact / 1e-4 assertion of run_macarons_trajectory."""
+    run_macarons_trajectory(dev)
+
+
 
 
 def test_device_permutation_source(dev):

@@ -31,19 +31,45 @@ def _models(dev):
     return occ.to(dev).eval(), vis.to(dev).eval(), sdo, sdv
 
 
+def run_end_to_end_on_grid(dev, name, variant=None):
+    """One whole NBV decision on a grid golden, optionally on a numerics variant (ops.variant): -> (result dict, golden, report) where
+    report holds the comparison figures (the callers assert their own bars on them)."""
+    import contextlib
+    from macarons_amd import ops
+    from macarons_amd.nbv import nbv_step, ViewStateGrid
+    g = golden(name)
+    occ, vis, sdo, sdv = _models(dev)
+    grid = ViewStateGrid(dev)
+    perms = [torch.from_numpy(g[f"perm{i}"].astype(np.int64)) for i in range(3)]
+    with (ops.variant(variant) if variant else contextlib.nullcontext()):
+        r = nbv_step(occ, vis, T(g["pc"], dev), T(g["X"], dev), T(g["X_view"], dev), T(g["X_cam"], dev), grid,
+                     occ_perms=perms, samples=T(g["samples"], dev), return_samples=True)
+    o = r["occ"].cpu().numpy()
+    nu = int(r["n_unique"])
+    si, gi = r["sample_idx"].cpu().numpy().reshape(-1), g["sample_idx"].reshape(-1)
+    gains = r["gains"].cpu().numpy()
+    pp = r["proxy_points"].cpu().numpy()
+    mine, theirs = pp[:nu, :3][np.clip(si, 0, max(nu - 1, 0))], g["proxy"][:, :3][gi]         # the 3-D point every one of the samples landed on
+    same_point = (mine == theirs).all(-1) if mine.shape == theirs.shape else np.zeros(len(gi), bool)
+    uniq = lambda a: {tuple(v) for v in a.tolist()}
+    common = len(uniq(pp[:nu, :3]) & uniq(g["proxy"][:, :3]))
+    order = np.argsort(-g["gains"].reshape(-1))
+    rep = {"occ_rel_err": float(np.abs(o - g["occ"]).max() / np.abs(g["occ"]).max()), "n_unique": nu, "n_unique_ref": int(g["n_unique"]),
+           "samples_on_another_point": int((~same_point).sum()), "n_samples": int(gi.size), "unique_points_in_common": common,
+           "gains_rel_err": rel_err(gains, g["gains"]), "nbv_idx": int(r["nbv_idx"]), "nbv_idx_ref": int(g["nbv_idx"]),
+           "ref_gain_margin_rel": float((g["gains"].reshape(-1)[order[0]] - g["gains"].reshape(-1)[order[1]]) / np.abs(g["gains"]).max()),
+           "fallback_variant": r.get("fallback_variant")}
+    return r, g, rep, (occ, vis, grid)
+
+
 @pytest.mark.parametrize("name", ["e2e_grid_config1", "e2e_grid_config2"])
 def test_end_to_end_matches_reference_on_grid(dev, name):
     """One whole NBV decision vs the golden the REFERENCE produced on 2^-10-grid clouds (config 1: M=1024, Q=2048, C=20;
     config-2 shape: M=4096, Q=16384, C=100).  On the grid every squared distance is exact in fp32 in any formulation and the
     golden inputs have no k / k+1 distance tie, so the reference's cdist + topk and the HIP kNN see the same neighbour sets
     (SURVEY §7): occupancies, the sampled point set, its inverse map, the gains (1e-4) and the arg-max must all match."""
-    from macarons_amd.nbv import nbv_step, ViewStateGrid
-    g = golden(name)
-    occ, vis, sdo, sdv = _models(dev)
-    grid = ViewStateGrid(dev)
-    perms = [torch.from_numpy(g[f"perm{i}"].astype(np.int64)) for i in range(3)]
-    r = nbv_step(occ, vis, T(g["pc"], dev), T(g["X"], dev), T(g["X_view"], dev), T(g["X_cam"], dev), grid,
-                 occ_perms=perms, samples=T(g["samples"], dev), return_samples=True)
+    from macarons_amd.nbv import nbv_step
+    r, g, rep, (occ, vis, grid) = run_end_to_end_on_grid(dev, name)
     o = r["occ"].cpu().numpy()
     assert np.abs(o - g["occ"]).max() < 1e-4 * np.abs(g["occ"]).max()
     nu = int(r["n_unique"])

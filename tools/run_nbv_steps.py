@@ -23,6 +23,10 @@ u = torch.rand(2048, generator=g).to(dev)
 grid = ViewStateGrid(dev)
 torch.manual_seed(11)
 perms = [p.to(dev) for p in occ.draw_perms(M)]
+import contextlib
+from macarons_amd import ops
+vctx = ops.variant(int(os.environ["VARIANT"])) if os.environ.get("VARIANT") else contextlib.nullcontext()   # e.g. VARIANT=7: the opt-in 16-bit matrix path
+vctx.__enter__()
 ts = []
 for it in range(n):
     torch.cuda.synchronize(); t0 = time.perf_counter()
