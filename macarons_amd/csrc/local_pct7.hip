@@ -5,10 +5,11 @@
 // of variants 1 / 5 / 6).
 // Reference mapping (SconeOcc.py:104-130: Embedding -> 2 x Encoder -> LayerNorm -> linear0 -> max || avg pool) in local_pct.hip.
 //
-// What stays fp32: the accumulators, the residual stream, LayerNorm statistics, the 16-token attention (scores, soft-max and P V
-// on v_mfma_f32_16x16x4_f32, exact fp32 -- q | k | v are kept as fp32 rows), GELU, the pooling.  What is fp16: the operands of
-// the twelve 128-wide products per encoder pair, the embeddings and linear0 (weights: the high plane of variant 6's blob,
-// fp16(W 2^e) with the per-matrix power of two; activations rounded once where they are produced, v_cvt_pk_f16_f32).
+// What stays fp32: the accumulators, the residual stream, LayerNorm statistics, the attention SCORES and the soft-max over them, GELU,
+// the pooling.  What is fp16: the operands of every matrix product -- the twelve 128-wide products per encoder pair, the embeddings,
+// linear0, and the 16-token attention's q | k | v and soft-max weights (v_mfma_f32_16x16x16_f16; variant 6 keeps them fp32 on
+// v_mfma_f32_16x16x4_f32: 80 long fp32 MFMAs and 112 LDS dword reads per workgroup-wave against 24 short ones and 32 eight-byte reads
+// here).  Weights: fp16(W); activations rounded once where they are produced (v_cvt_pk_f16_f32).
 // Range: |activation| < 65504 as on variant 6 (a non-finite occupancy raises the same range flag).
 //
 // Structure = local_pct6.hip (4 waves = 64 tokens x 128 channels on chip, products transposed, residual stream in registers,
@@ -22,8 +23,8 @@
 // product is one base register plus an immediate (the swizzle cost five integer instructions per k-step) --, LayerNorm
 // normalises with one v_rsq and one fma per value, and no epilogue multiplies by a scale.
 // LDS = 51 KB (three workgroups per CU):
-//               P  17 KB  fp16 plane [64 rows][17 chunks of 8, the last one padding], or q|k as fp32 [64][68]
-//               H  32 KB  fp16 plane (FF hidden half / GELU(emb1)) in its first 17 KB, or v as fp32 [64][128], or the final fp32 tile
+//               P  17 KB  fp16 plane [64 rows][17 chunks of 8, the last one padding], or q | k as fp16 in halves 0..63 of the rows
+//               H  32 KB  fp16 plane (FF hidden half / GELU(emb1) / v) in its first 17 KB, or the final fp32 tile [64][128]
 //               St  2 KB  LayerNorm partials [4 waves][64 tokens] (mean, M2)
 // Row stride 272 bytes = 68 banks: the 16 rows a ds_read_b128 / ds_read_b32 group touches land 4 banks apart (conflict-free);
 // the fp32 [64][128] view keeps variant 6's XOR swizzle by (row & 15).
@@ -331,10 +332,11 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
     __shared__ __attribute__((aligned(16))) uint4 P[64 * PR];
     __shared__ __attribute__((aligned(16))) uint4 H[2 * 64 * 16];
     __shared__ __attribute__((aligned(16))) float2 St[4 * 64];
-    float* Pq = reinterpret_cast<float*>(P);               // fp32 [64][68] view: q | k (columns 64..67 padding)
+    __shared__ __attribute__((aligned(16))) uint4 Z[4];            // 64 bytes of zeros: the k = 8..15 half of the Q fragments (attention)
     float* F = reinterpret_cast<float*>(H);                // fp32 [64][128] view: v / the final tile
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably uniform: weight / bias addresses = SGPR base + lane offset
+    if (tid < 4) Z[tid] = make_uint4(0, 0, 0, 0);                     // (visible to every wave behind the first barrier)
     const float* mats = blob;
     const float* vecs = blob + L7_MATS_TOTAL;
     // One workgroup per 4-query group, NOT persistent: persistent workgroups (2 per CU, looping over groups with the next group's
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
         const float* w_ff1b = w_out + L7_MAT_128 * 2;
         const float* w_ff2a = w_out + L7_MAT_128 * 3;
         const float* w_ff2b = w_out + L7_MAT_128 * 4;
-        // ---- norm1 (folded) -> planes P ; QKV (Attention.py:186-188, 287): q|k -> Pq, v -> F ----
+        // ---- norm1 (folded) -> planes P ; QKV (Attention.py:186-188, 287): q | k -> P rows (fp16), v -> the H plane ----
         WRing ring1;
         const uint4* bq0 = wptr(em, wave, 8, lane);
         const uint4* bq1 = wptr(em, 4 + (wave >> 1), 8, lane);
@@ -427,36 +429,40 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
             wload<8>(ring, wptr(w_out, wave, 8, lane));
             __syncthreads();                       // x^ planes consumed: P may take q|k
             L7_T();                                // barrier
-            // n-tiles 0,1 = q,k -> Pq chunks 0..7 / 8..15; n-tiles 2..5 = v -> F chunks 8 (nt - 2) ..
+            // n-tiles 0, 1 = q, k -> halves 0..31 / 32..63 of the P rows; n-tiles 2..5 = v -> the H plane (halves 32 (nt - 2) ..): one
+            // rounding to fp16 where the values are produced, like every other matrix operand of this variant
             auto fb = [&](float v, int, int) { return v; };
-            float* dst = wave < 2 ? Pq : F;         // branch-free: the whole encoder stays one basic block
-            const int ld = wave < 2 ? 4 * PR : 128, km = wave < 2 ? 0 : 15, c0 = wave < 2 ? 8 * wave : 8 * (wave - 2);
+            uint4* dst = wave < 2 ? P : H;          // branch-free: the whole encoder stays one basic block
+            const int ntd = wave < 2 ? wave : wave - 2;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) put_f32(dst, ld, km, c0, mt, aq[mt], lane, fb);
-            put_f32(F, 128, 15, 8 * (nth - 2), wave & 1, ah, lane, fb);
+            for (int mt = 0; mt < 2; ++mt) put_planes(dst, ntd, mt, aq[mt], lane, fb);
+            put_planes(H, nth - 2, wave & 1, ah, lane, fb);
         }
         __syncthreads();
         L7_T();                                    // qkv put + barrier
-        // ---- attention (Attention.py:8-36) on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32 = exact fp32 fma chains):
-        // wave = query (16 tokens); per head  S^T = K Q^T (key rows, query columns: lane (qi, g) then owns S[qi][4g..4g+3]),
-        // softmax over the keys = 4 registers x the 4 lane groups, O^T = V^T P^T with the key index j = 4g + s: lane (qi, g)
-        // ends up with the features 4g..4g+3 of every 16-feature block of its token -> the fp16 plane, written over the wave's
-        // own q | k rows (a row of the plane and a q | k row are the same 256 bytes).
+        // ---- attention (Attention.py:8-36) on v_mfma_f32_16x16x16_f16 (fp16 q | k | v and soft-max weights, fp32 scores / soft-max /
+        // accumulation): wave = query (16 tokens); per head  S^T = K Q^T (A = K: lane (key li, g) holds dims 4 (g & 1) .., B = Q^T: lane
+        // (query li, g) holds dims 4 g .. for g < 2 and ZEROS for g >= 2 -- the head has 8 dims, the MFMA's k is 16), so lane (qi, g) owns
+        // S[qi][4g..4g+3]; soft-max over the keys = 4 registers x the 4 lane groups; O^T = V^T P^T: A = V^T through the transposing LDS
+        // read (lane (li, g) addresses token 4 g + (li >> 2), columns 4 (li & 3) ..; lane c receives tokens 4 g .. 4 g + 3 of column c),
+        // B = P^T = the soft-max registers rounded to fp16: lane (qi, g) ends up with the features 4g..4g+3 of every 16-feature block of
+        // its token -> the fp16 plane, written over the wave's own q | k rows.
         {
+            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
             const int ln = opaque(lane);
             const int r0 = wave * 16, li = ln & 15, g = ln >> 4;
-            const int wq = (r0 + li) * (4 * PR) + g;                                           // Pq[row = r0+li][chunk c][g]   = wq + 4 c
-            const int wv = ((r0 + 4 * g) * 128) | ((((li >> 2) | (g << 2)) << 2)) | (li & 3);    // F[row = r0+4g+s][chunk C][li&3] = s*128 + (wv ^ ((C ^ s) << 2))
-            f32x4 pr[4];
+            const char* Pb = reinterpret_cast<const char*>(P);
+            const char* ka = Pb + (r0 + li) * (16 * PR) + 64 + (g & 1) * 8;                     // k[token r0 + li][8 hh + 4 (g & 1) ..]: + 16 hh
+            const char* qa = g < 2 ? Pb + (r0 + li) * (16 * PR) + g * 8 : reinterpret_cast<const char*>(Z);   // q[...][8 hh + 4 g ..] or zeros
+            const char* va = reinterpret_cast<const char*>(H) + (r0 + 4 * g + (li >> 2)) * (16 * PR) + (li & 3) * 8;   // v[token][16 blk + 4 (li & 3) ..]: + 32 blk
+            h16x4 pf[4];
 #pragma unroll
             for (int hh = 0; hh < 4; ++hh) {
-                f32x4 st = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int sk = 0; sk < 2; ++sk) {
-                    const float kk = Pq[wq + ((8 + 2 * hh + sk) << 2)];                  // A[i = j][k = d]      = k[j][hh*8 + 4 sk + g]
-                    const float qq = Pq[wq + ((2 * hh + sk) << 2)];                      // B[k = d][n = qi]     = q[qi][hh*8 + 4 sk + g]
-                    st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk, qq, st, 0, 0, 0);
-                }
+                const h16x4 kf = *reinterpret_cast<const h16x4*>(ka + 16 * hh);
+                const h16x4 qf = *reinterpret_cast<const h16x4*>(qa + 16 * hh);
+                f32x4 st = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 float mx = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
                 mx = rows_allreduce(mx, [](float a, float b) { return fmaxf(a, b); });
                 mx *= 0.35355339059327376220f;                                           // scores / sqrt(8)
@@ -468,20 +474,16 @@ __global__ __launch_bounds__(256, L7_WGS) void local_pct7_kernel(const float* __
                 }
                 den = rows_allreduce(den, [](float a, float b) { return a + b; });
                 const float inv = __builtin_amdgcn_rcpf(den);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pr[hh][r] = st[r] * inv;
+                const uint2 pk = make_uint2(pack2h(st[0] * inv, st[1] * inv), pack2h(st[2] * inv, st[3] * inv));
+                pf[hh] = __builtin_bit_cast(h16x4, pk);
             }
             f32x4 o[4][2];
 #pragma unroll
             for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    o[hh][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int sk = 0; sk < 4; ++sk) {
-                        const float vv = F[sk * 128 + (wv ^ (((hh * 8 + nt * 4) ^ sk) << 2))];   // A[i = c][k = g] = V[j = 4g + sk][hh*32 + nt*16 + c]
-                        o[hh][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pr[hh][sk], o[hh][nt], 0, 0, 0);
-                    }
+                    const s16x4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va + 64 * hh + 32 * nt));
+                    o[hh][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, vt), pf[hh], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 }
             // every q | k read of this wave's 16 rows precedes the plane writes over them (other waves own other rows)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
