@@ -374,7 +374,7 @@ def measure_nbv_batch(dev, rank, world, args, variant=None):
             "nbv_idx": r["nbv_idx"].tolist()}
 
 
-def measure_macarons_step(dev, rank=0, world=1, perm_sources=("host", "device")):
+def measure_macarons_step(dev, rank=0, world=1):
     """BASELINE config 5 minus the depth network: p50 latency of one MACARONS next-best-view decision
     (macarons_utils.macarons_nbv_decision = testers/scene.py:391-454) on a synthetic scene of liberty's proportions: 3 x 8 x 3
     grid, 100 000 proxy points, surface = an ellipsoid shell (capacity 1000 points per cell), 256 x 456 analytic depth maps,
@@ -447,7 +447,7 @@ def measure_macarons_step(dev, rank=0, world=1, perm_sources=("host", "device"))
     # each -- the checks read tensors back and leave the GPU idle for milliseconds, which cost the next timed decision 0.4 ms when
     # they sat between the timed ones
     n_timed, n_checked = 2 + 9, 4
-    for it in range((n_timed + n_checked) if "host" in perm_sources else 0):
+    for it in range(n_timed + n_checked):
         cam, depth, dmask, recs, ne = poses[it % 3]
         n_in_before = float(proxy.proxy_n_inside_fov.sum()) if it >= n_timed else 0.0
         torch.cuda.synchronize()
@@ -491,27 +491,28 @@ def measure_macarons_step(dev, rank=0, world=1, perm_sources=("host", "device"))
         info = {"field_points": int(r["X_world"].shape[0]), "proxy_in_fov": n_fov, "next_idx": nxt}
     p50 = float(np.median(times)) if times else float("nan")
     checks["all_hold"] = all(v for k_, v in checks.items() if k_ != "iterations")
-    # the same decision with the hidden permutations drawn on the device (opt-in perm_source="device": no host randperm loop)
-    times_d = []
-    for it in range((2 + 9) if "device" in perm_sources else 0):
-        cam, depth, dmask, recs, ne = poses[it % 3]
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, depth, dmask, recs, ne, dev, group=group, perm_source="device")
-        r["host"]["next_idx"] if "host" in r else int(r["next_idx"])
-        torch.cuda.synchronize()
-        dt = max_over_ranks(time.perf_counter() - t0, dev, dist)
-        if it >= 2:
-            times_d.append(dt)
-    p50_d = float(np.median(times_d)) if times_d else float("nan")
+    # the same decision on the opt-in 16-bit matrix path (variant 7: its own tolerance, never the default)
+    from macarons_amd import ops
+    times_7 = []
+    with ops.variant(7):
+        for it in range(2 + 9):
+            cam, depth, dmask, recs, ne = poses[it % 3]
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, depth, dmask, recs, ne, dev, group=group)
+            r["host"]["next_idx"] if "host" in r else int(r["next_idx"])
+            torch.cuda.synchronize()
+            dt = max_over_ranks(time.perf_counter() - t0, dev, dist)
+            if it >= 2:
+                times_7.append(dt)
+    p50_7 = float(np.median(times_7))
     return {"p50_ms": p50 * 1e3, "evals_per_s": K / p50, "iters": len(times), "last": info, "checks": checks, "scaling": "strong",
-            "device_perms": {"p50_ms": p50_d * 1e3, "evals_per_s": K / p50_d,
-                             "note": "perm_source='device' (opt-in): Cell.fill subsets and SconeOcc down-samples drawn on the GPU by segmented "
-                                     "sorts instead of ~190 torch.randperm calls on the CPU generator; p50_ms above is the default "
-                                     "(the reference's CPU-generator order, the one the goldens pin)"},
+            "variant_7": {"p50_ms": p50_7 * 1e3, "evals_per_s": K / p50_7, "fell_back_to_variant": r.get("fallback_variant"),
+                          "note": "the opt-in 16-bit matrix path (ops.variant(7): one fp16 plane per operand in the local transformers and "
+                                  "the SconeOcc head); p50_ms above is the default numerics (variant 6, the 1e-4 contract)"},
             "config": {"workload": "MACARONS decision (BASELINE config 5 minus the depth network): 100000 proxy points, 3x8x3 grid, "
                                    "30 neighbour cameras, 256x456 depth map, seq_len 2048", "cams": K, "proxy_points": P,
                        "parallelism": f"field-row + neighbour-camera shard x{world}" if world > 1 else "1 GPU"}}

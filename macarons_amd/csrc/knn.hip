@@ -1184,9 +1184,20 @@ void launch_knn16_segmented(hipStream_t s, const float* X, const float* pc, cons
                            (long long*)nullptr, (float*)nullptr, offsets_out, (int)T, 0, reinterpret_cast<const int4*>(blocks), pc_off, n_split, part,
                            seg_cand);
         const size_t merge_lds = (size_t)n_split * 64 * 17 * 8 + 64 * 16 * 3 * 4;                    // <= 81 920 bytes at 8 slices
-        static const bool lds_ok = hipFuncSetAttribute((const void*)knn_split_merge_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       8 * 64 * 17 * 8 + 64 * 16 * 3 * 4) == hipSuccess;
-        if (!lds_ok) { set_error("launch_knn16_segmented: cannot reserve the merge kernel's LDS"); return; }
+        // the opt-in to > 64 KB of dynamic LDS is a per-DEVICE attribute of the function: set once for every device this process drives
+        static bool lds_set[64] = {};
+        int dev_id = 0;
+        if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) dev_id = 0;
+        if (!lds_set[dev_id]) {
+            if (hipFuncSetAttribute((const void*)knn_split_merge_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    8 * 64 * 17 * 8 + 64 * 16 * 3 * 4) != hipSuccess) {
+                // (the HIP error stays pending: the caller's MCR_LAUNCH_CHECK returns it -- offsets_out was not written)
+                set_error("launch_knn16_segmented: cannot reserve %d bytes of LDS for the merge kernel on device %d", 8 * 64 * 17 * 8 + 64 * 16 * 3 * 4,
+                          dev_id);
+                return;
+            }
+            lds_set[dev_id] = true;
+        }
         hipLaunchKernelGGL((knn_split_merge_kernel<16>), dim3((unsigned)n_blocks, 2), dim3(64), merge_lds, s, X, pc, pc_off,
                            reinterpret_cast<const int4*>(blocks), (const unsigned long long*)part, n_split, (int)T, offsets_out, seg_cand);
         return;

@@ -156,15 +156,18 @@ class SconeOcc(RangeGuard, nn.Module):
         # Range guard of the default numerics (variant 6: matrix products on fp16 hi/lo planes, valid for |activation| < 65504;
         # the reference is plain fp32, Attention.py:98-128): the kernels flag a non-finite occupancy -- what an out-of-range
         # activation turns into -- and the forward is repeated on variant 5 (bf16 hi/mid/lo, the whole fp32 range).
-        #   "async" (default) never stalls: after every forward the flag is copied to pinned host memory behind the kernels; the NEXT
+        #   "sync"  (default: correct for a drop-in caller -- the reference never returns NaN here) read the flag after every forward
+        #           (one 4-byte read-back = a pipeline drain) and repeat that forward at once on variant 5: the FIRST overflowed
+        #           stand-alone forward already returns finite occupancies within the 1e-4 contract;
+        #   "defer" leave it in range_flag() for the caller: nbv_step / macarons_nbv_decision switch to this for their duration and
+        #           check ONE flag once, at the end of the decision (the performance paths never pay the per-forward read-back);
+        #   "async" (opt-in) never stalls: after every forward the flag is copied to pinned host memory behind the kernels; the NEXT
         #           forward (or check_range()) looks at copies that have landed.  A set flag means an earlier forward returned
         #           non-finite occupancies (visible as such to the caller): it is reported once (RuntimeWarning) and every later
-        #           forward of this module runs on variant 5 -- a drop-in caller that keeps upstream's chunk loop pays no
-        #           device->host round trip per chunk;
-        #   "sync"  read the flag after every forward (one 4-byte read-back = a pipeline drain) and repeat that forward at once;
-        #   "defer" leave it in range_flag() for the caller (nbv_step / macarons_nbv_decision check it once, at the end of the decision);
+        #           forward of this module runs on variant 5 -- for a caller that keeps upstream's chunk loop and cannot afford a
+        #           device->host round trip per chunk, and checks check_range(wait=True) at its own boundaries;
         #   "off"   no check.
-        self.range_guard = "async"
+        self.range_guard = "sync"
         self._range_flag = None
         self._range_pending = []            # (pinned host int32 [1], event) of forwards whose flag has not been looked at yet
         self._full_range = False            # True once an overflow was seen: variant 5 from then on
@@ -238,57 +241,16 @@ class SconeOcc(RangeGuard, nn.Module):
             return pc[:, p].contiguous()
         return torch.gather(pc, 1, p[..., None].expand(-1, -1, pc.shape[-1])).contiguous()
 
-    def ragged_index_arrays_device(self, cloud_sizes, device):
-        """The down-sample index arrays of forward_ragged drawn ON THE DEVICE (perm_source="device"): per job three uniformly random
-        permutation prefixes, as SconeOcc.py:269 / :311 take them, from torch's device generator -- one float64 key per element, ONE
-        segmented sort per scale, no host loop (the ~3 J torch.randperm draws of the default path are 2 ms of CPU generator work per
-        MACARONS decision).  Not the reference's CPU-generator stream: statistically the same draws, different numbers (opt-in).
-        -> dict(g_idx int64 [J*Lg], g_len int32 [J], idx1, idx2 int64, off1, off2 int64 [J+1]) as forward_ragged(index_arrays=...) takes."""
-        J, Lg = len(cloud_sizes), self.seq_len
-        sizes = [self.scale_sizes(int(m)) for m in cloud_sizes]
-        m0, m1, m2 = [s_[0] for s_ in sizes], [s_[1] for s_ in sizes], [s_[2] for s_ in sizes]
-        cum = lambda v: np.concatenate(([0], np.cumsum(v))).astype(np.int64)
-        o0, o1, o2 = cum(m0), cum(m1), cum(m2)
-        n0 = [min(m, Lg) for m in m0]
-        host = ops.h2d(np.concatenate([o0, o1, o2, np.asarray(m0, np.int64), np.asarray(m1, np.int64), np.asarray(m2, np.int64),
-                                       np.asarray(n0, np.int64)]), torch.int64, device)
-        d_o0, d_o1, d_o2 = host[:J + 1], host[J + 1:2 * J + 2], host[2 * J + 2:3 * J + 3]
-        d_m0, d_m1, d_m2, d_n0 = (host[3 * J + 3 + k * J:3 * J + 3 + (k + 1) * J] for k in range(4))
-
-        def seg_perm(lens, offs, total):
-            """-> (seg [total], rank-sorted local index [total]): position off_j + r holds the r-th element of a random permutation of
-            [0, len_j).  Composite key = segment + uniform in [0, 1) in float64 (no collisions worth a bias), one sort."""
-            seg = torch.repeat_interleave(torch.arange(J, device=device), lens, output_size=total)
-            u = torch.rand(total, dtype=torch.float64, device=device).clamp_(max=1.0 - 2.0 ** -30)   # seg + u never rounds up to seg + 1
-            order = torch.argsort(seg.double() + u)
-            return seg, order - offs[seg]
-        T0, T1, T2 = int(o0[-1]), int(o1[-1]), int(o2[-1])
-        seg0, loc0 = seg_perm(d_m0, d_o0, T0)                                   # global down-sample: randperm(M)[:Lg]
-        r0 = torch.arange(T0, device=device) - d_o0[seg0]
-        keep = r0 < Lg
-        g_idx = d_o0[:J].view(J, 1).expand(J, Lg).clone()                       # padding rows: any valid point (masked by global_len)
-        g_idx[seg0[keep], r0[keep]] = (d_o0[seg0] + loc0)[keep]
-        seg1, loc1 = seg_perm(d_m0, d_o0, T0)                                   # scale 0 -> 1: randperm(M)[:M // ds]
-        r1 = torch.arange(T0, device=device) - d_o0[seg1]
-        k1 = r1 < d_m1[seg1]
-        idx1 = (d_o0[seg1] + loc1)[k1]
-        seg2, loc2 = seg_perm(d_m1, d_o1, T1)                                   # scale 1 -> 2: randperm(M // ds)[:(M // ds) // ds]
-        r2 = torch.arange(T1, device=device) - d_o1[seg2]
-        k2 = r2 < d_m2[seg2]
-        idx2 = (d_o1[seg2] + loc2)[k2]
-        assert idx1.numel() == T1 and idx2.numel() == T2
-        return {"g_idx": g_idx.reshape(-1), "g_len": d_n0.to(torch.int32), "idx1": idx1, "idx2": idx2, "off1": d_o1, "off2": d_o2}
-
-    def forward_ragged(self, pc, cloud_sizes, x, view_harmonics, query_sizes, perms=None, index_arrays=None, perm_source="host", out=None):
+    def forward_ragged(self, pc, cloud_sizes, x, view_harmonics, query_sizes, perms=None, index_arrays=None, out=None):
         """J forward() calls of different sizes as ONE launch sequence (extension; the reference calls forward once per grid cell and
         chunk from a Python loop, macarons_utils.py:1395-1540).  Job j: surface cloud = the next cloud_sizes[j] rows of pc [sum M, 3],
         queries = the next query_sizes[j] rows of x [T,3] / view_harmonics [T,64] (host lists).  perms: per job the three index
         tensors draw_perms(cloud_sizes[j]) returns; None = drawn here in job order on the CPU generator, exactly the draws J
-        sequential forward() calls would make -- or, perm_source="device" (opt-in), on the device by ragged_index_arrays_device();
-        index_arrays: what that function returns (a caller that repeats a pass, or hands rank 0's draws to every rank).
+        sequential forward() calls would make; index_arrays: the uploaded index arrays of an earlier pass (`last_ragged_perms`: a
+        caller that repeats a pass, or hands rank 0's draws to every rank).
         -> [T,1] (`out`: written there).  Inference only (no autograd graph).  = forward_ragged_begin + forward_ragged_finish."""
         h = self.forward_ragged_begin(pc, cloud_sizes, x, view_harmonics, query_sizes)
-        return self.forward_ragged_finish(h, perms=perms, index_arrays=index_arrays, perm_source=perm_source, out=out)
+        return self.forward_ragged_finish(h, perms=perms, index_arrays=index_arrays, out=out)
 
     def forward_ragged_begin(self, pc, cloud_sizes, x, view_harmonics, query_sizes, row_job=None, arena="scone_occ_ragged"):
         """First half of forward_ragged: what needs no hidden draw is uploaded and LAUNCHED (phase 1: the x embedding, the scale-0 search
@@ -344,15 +306,13 @@ class SconeOcc(RangeGuard, nn.Module):
                 "d_row_job": d_row_job, "d_blocks": d_blocks, "state": state, "caches": caches, "phase1": phase1,
                 "cloud_sizes": cloud_sizes, "arena": arena, "epoch1": ops.scone_occ_epoch(dev, arena)}
 
-    def forward_ragged_finish(self, h, perms=None, index_arrays=None, perm_source="host", out=None):
+    def forward_ragged_finish(self, h, perms=None, index_arrays=None, out=None):
         """Second half of forward_ragged: the hidden draws (unless given), the down-sampled clouds, phase 2."""
         L = _lib.lib()
         pc, x, view_harmonics, J, Lg, variant, off0 = h["pc"], h["x"], h["vh"], h["J"], h["Lg"], h["variant"], h["off0"]
         cloud_sizes, d_off0, d_row_job, d_blocks, state, caches, phase1 = (h["cloud_sizes"], h["d_off0"], h["d_row_job"], h["d_blocks"],
                                                                           h["state"], h["caches"], h["phase1"])
         dev = x.device
-        if index_arrays is None and perms is None and perm_source == "device":
-            index_arrays = self.ragged_index_arrays_device(cloud_sizes, dev)
         if index_arrays is not None:
             ia = index_arrays
             self.last_ragged_perms = ia                                    # (a caller that repeats the pass on another variant re-uses the draws)

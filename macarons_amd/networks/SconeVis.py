@@ -119,9 +119,10 @@ class SconeVis(RangeGuard, nn.Module):
             res = ops.linear(torch.cat((res, view_harmonics), dim=-1), _f32c(self.fc2.weight), _f32c(self.fc2.bias), gelu=True)
             return ops.linear(res, _f32c(self.fc3.weight), _f32c(self.fc3.bias)).view(n_clouds, seq_len, self.n_harmonics)
         # Range guard (packing.RangeGuard): on variant 6 the encoders of a cloud of >= 512 points run their GEMMs on fp16 hi/lo planes
-        # (|activation| < 65504); harmonics that come out non-finite raise the flag.  "async" (default): looked at without a stall by a
-        # later forward / check_range(); "defer": left in range_flag() (nbv_step and macarons_nbv_decision share SconeOcc's flag and
-        # read it once per decision); "sync": read now, repeat on variant 5; "off": nothing.
+        # (|activation| < 65504); harmonics that come out non-finite raise the flag.  "sync" (default): read now, repeat on variant 5 --
+        # a stand-alone forward never returns non-finite harmonics; "defer": left in range_flag() (nbv_step and macarons_nbv_decision
+        # share SconeOcc's flag and read it once per decision); "async" (opt-in): looked at without a stall by a later forward /
+        # check_range(); "off": nothing.
         if self.range_guard == "async" and (self._range_pending or self._full_range):
             self.check_range()
         if self._full_range and ops.current_variant() in (6, 7):

@@ -350,9 +350,11 @@ class HeadPlaneCache:
 class RangeGuard:
     """Range guard of the default numerics (variant 6: matrix operands as fp16 hi/lo planes, valid for |activation| < 65504; the
     reference is plain fp32), shared by SconeOcc and SconeVis.  The kernels OR a device flag when an output comes out non-finite --
-    what an out-of-range activation turns into; `range_guard` says who looks at it (see SconeOcc.__init__).  A module that saw an
-    overflow runs on the full-range variant 5 from then on."""
-    range_guard = "async"
+    what an out-of-range activation turns into; `range_guard` says who looks at it (see SconeOcc.__init__).  Default "sync": a
+    stand-alone forward never hands back non-finite values (the reference is plain fp32 and cannot); nbv_step / macarons_nbv_decision
+    switch to "defer" for their duration (one read-back per decision).  With "async" (opt-in) a module that saw an overflow runs on the
+    full-range variant 5 from then on."""
+    range_guard = "sync"
     _range_flag = None
     _range_pending = ()
     _range_pool = ()

@@ -139,8 +139,7 @@ class SceneCamera:
 
 
 def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, depth, depth_mask, neighbor_records, X_neighbors,
-                          device, samples=None, return_signed_distances=False, range_guard=True, group=None, perm_source="host",
-                          uniform_draws="per_camera"):
+                          device, samples=None, return_signed_distances=False, range_guard=True, group=None, uniform_draws="per_camera"):
     """One next-best-view decision of the MACARONS loop after the depth map of the current pose is known -- the body of
     testers/scene.py:391-454 (everything between the depth network and the move to the chosen pose):
       1. proxy points in the current frustum (Camera.get_points_in_fov :391), registered in the proxy grid (:394-395);
@@ -154,9 +153,9 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
     block-partitioned over the ranks, the occupancies (4 B per proxy point) and one 8-byte (gain, index) record per rank are
     all-gathered, the hidden draws (Cell.fill subsets, SconeOcc's down-samples, the sampling uniforms) are rank 0's; the cheap state
     updates run replicated.  Bit for bit the 1-rank decision; `gains` then holds this rank's cameras only (`cam_range`).
-    perm_source: "host" (default) draws the hidden permutations (Cell.fill's subsets, SconeOcc's down-samples) with torch.randperm on
-    the CPU generator in upstream's order -- what the reference goldens pin; "device" (opt-in, production) draws them on the GPU in
-    two segmented sorts (statistically the same, a different stream).  uniform_draws: see predict_coverage_gain_for_cameras.
+    The hidden permutations (Cell.fill's subsets, SconeOcc's down-samples) are drawn with torch.randperm on the CPU generator in
+    upstream's order -- what the reference goldens pin (an opt-in device-generator source existed until round 6: slower than this path
+    once the draws had become two C++ calls, and removed).  uniform_draws: see predict_coverage_gain_for_cameras.
     Returns dict(next_idx (device int64: index into the neighbour list), gains [K], fov_mask [P] bool, X_world, view_harmonics,
     occ_probs).  The scene objects are updated in place like upstream.
     Host synchronisations: ONE in the middle (the per-cell counts of fill_cells and of the field's selection come back together: the
@@ -233,23 +232,40 @@ def macarons_nbv_decision(params, macarons, proxy_scene, surface_scene, camera, 
         cand, adm = ps.fill_counts(host[:nkf])
         gfill = group if xch else None
         if ps.fill_overflows(cand, adm):            # a full cell: WHICH points stay is random -> the selection has to wait for the draws
-            ps.fill_cells_end(fill, cand, adm, 0, gfill, perm_source)
+            ps.fill_cells_end(fill, cand, adm, 0, gfill)
         else:
             plan = {}
             field_state["selection"] = (sel, host[nkf:], prep)
             # the fill's draws come before the occupancy pass's on the CPU generator (upstream's order); its gather can wait until the
             # pass is queued -- nothing of THIS decision reads the proxy cells any more
-            field_state["between"] = lambda: plan.update(p=ps.fill_cells_draw(fill, cand, adm, 0, gfill, perm_source))   # noqa: E731
-            field_state["after"] = lambda: ps.fill_cells_apply(plan.get("p"))                                         # noqa: E731
+            def _draw_fill():
+                if "p" not in plan:
+                    plan["p"] = ps.fill_cells_draw(fill, cand, adm, 0, gfill)
+
+            def _apply_fill():                          # (once: the plan is consumed)
+                if not plan.get("applied"):
+                    plan["applied"] = True
+                    ps.fill_cells_apply(plan.get("p"))
+            field_state["between"], field_state["after"] = _draw_fill, _apply_fill
 
     def field_and_gains(ragged_perms, smp, record):
         selection, between, after = field_state["selection"], field_state["between"], field_state["after"]
         field_state["selection"] = field_state["between"] = field_state["after"] = None   # (a repeat selects again: the stores are final by then)
-        X_world, view_harmonics, occ_probs = compute_scene_occupancy_probability_field(params, macarons, None, surface_scene, ps,
-                                                                                       device, prediction_camera=Mv_field, ragged_perms=ragged_perms,
-                                                                                       group=group if xch else None, record=record,
-                                                                                       perm_source=perm_source, _selection=selection,
-                                                                                       _between=between, _after=after)
+        try:
+            X_world, view_harmonics, occ_probs = compute_scene_occupancy_probability_field(params, macarons, None, surface_scene, ps,
+                                                                                           device, prediction_camera=Mv_field, ragged_perms=ragged_perms,
+                                                                                           group=group if xch else None, record=record,
+                                                                                           _selection=selection,
+                                                                                           _between=between, _after=after)
+        except BaseException:
+            # the pass raised between the fill's two halves (the draws may or may not have been made, the gather has not run): finish the
+            # fill -- draw if that is still due, then apply -- so that the proxy scene has received this frustum's points as upstream's
+            # Cell.fill would have left it before the occupancy pass started, and the CPU generator is where upstream's would be
+            if between is not None:
+                between()
+            if after is not None:
+                after()
+            raise
         if xch:                                         # the uniforms of ALL cameras are rank 0's
             if smp is None:
                 smp = ops.uniform_rows(K, S, device) if uniform_draws == "per_camera" else torch.rand(K, S, device=device)
@@ -486,6 +502,9 @@ def _field_select(proxy_scene, device, use_supervision_occ_mask=True, pending=No
     if st.fts is None:
         raise ValueError("the proxy scene's cells must carry the proxy indices as feature (feature_dim >= 1)")
     gc, grid = _grid_consts(ps, device)
+    if grid[0] * grid[1] * grid[2] > 1023:              # the counting sort of csrc/scene.hip: one LDS counter per cell (Scene.MAX_CELLS)
+        raise NotImplementedError(f"the fused field pass handles grids of up to 1023 cells, this one has {grid[0] * grid[1] * grid[2]} "
+                                  f"({grid[0]} x {grid[1]} x {grid[2]}); the reference's scenes use 18 .. 72")
     return ops.field_select(ps.proxy_points, ps.proxy_supervision_occ, ps.out_of_field, ps.proxy_proba, st.fts, int(st.off[-1]), st.off_dev,
                             gc, grid, use_supervision_occ_mask, pending)
 
@@ -592,7 +611,7 @@ def _field_prepare(params, proxy_scene, prediction_camera, device, ticket=None):
 def compute_scene_occupancy_probability_field(params, macarons, camera, surface_scene, proxy_scene, device,
                                               use_supervision_occ_mask=True, prediction_camera=None,
                                               use_supervision_occ_instead_of_predicted=False, chunk=20000, ragged_perms=None,
-                                              group=None, record=None, perm_source="host", _selection=None, _between=None, _after=None):
+                                              group=None, record=None, _selection=None, _between=None, _after=None):
     """Occupancy probability of every proxy point the cameras have seen (macarons_utils.py:1395-1540), as ONE batched pass.
 
     Upstream walks the grid cells that hold seen proxy points from Python: per cell it gathers the surface points of the 27-cell
@@ -611,9 +630,7 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
     block-partitioned over the ranks (every (cell, chunk) job is independent, and so is every query of a job given the
     job's cloud and draws), each rank runs the jobs its rows belong to, the occupancies (4 B per proxy point) are all-gathered; the
     hidden draws of ALL jobs are rank 0's, in job order, in one broadcast -- the result is bit for bit the 1-rank field.  `record`
-    (dict): receives the draws used (`ragged_perms`) so that a caller can repeat the pass.  perm_source="device" (opt-in): SconeOcc's
-    hidden down-samples are drawn on the device (SconeOcc.ragged_index_arrays_device) instead of ~3 torch.randperm calls per job on
-    the host.  `_selection` / `_between` / `_after` (macarons_nbv_decision): a selection whose counts are already on the host (with the
+    (dict): receives the draws used (`ragged_perms`) so that a caller can repeat the pass.  `_selection` / `_between` / `_after` (macarons_nbv_decision): a selection whose counts are already on the host (with the
     count-independent host work, _field_prepare); host work to run once the first launches of the occupancy pass are queued and BEFORE
     the network's draws (the fill's draws: upstream's order on the CPU generator); host work to run once the whole pass is queued
     (the fill's gather: the GPU is busy meanwhile)."""
@@ -718,8 +735,7 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
                 if _between is not None:
                     _between()
                 if ragged_perms is None:                # rank 0 draws for every job, in job order (what the 1-rank pass draws)
-                    ragged_perms = (_broadcast_job_index_arrays(occ_net, sizes_m, device, group, rank) if perm_source == "device"
-                                    else _broadcast_job_perms(occ_net, sizes_m, device, group, rank))
+                    ragged_perms = _broadcast_job_perms(occ_net, sizes_m, device, group, rank)
                 t0, t1 = mdist.shard_range(T, rank, world)
                 mine = [j for j in range(J) if q_start[j] < t1 and q_start[j + 1] > t0]
                 if mine:
@@ -727,7 +743,7 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
                     p0, p1 = int(m_start[mine[0]]), int(m_start[mine[-1] + 1])
                     draws_l = (_slice_index_arrays(occ_net, ragged_perms, sizes_m, mine[0], mine[-1] + 1) if isinstance(ragged_perms, dict)
                                else [ragged_perms[j] for j in mine])
-                    kw = {"index_arrays": draws_l} if isinstance(draws_l, dict) else {"perms": draws_l, "perm_source": perm_source}
+                    kw = {"index_arrays": draws_l} if isinstance(draws_l, dict) else {"perms": draws_l}
                     occ_l = occ_net.forward_ragged(pc_all[p0:p1].contiguous(), [sizes_m[j] for j in mine], X_q[t0:t1].contiguous(),
                                                    vh[t0:t1].contiguous(), q_l, **kw).view(-1, 1)
                 else:                                   # empty row shard (T < world): no kernels, the all-gather is joined
@@ -742,7 +758,7 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
                 given = ragged_perms["groups"] if (isinstance(ragged_perms, dict) and "groups" in ragged_perms) else None
                 if given is not None:
                     groups = [(j0, j1) for j0, j1, _ in given]
-                elif ragged_perms is None and perm_source == "host":
+                elif ragged_perms is None:
                     groups = _job_groups(sizes_m)
                 else:
                     groups = [(0, J)]
@@ -759,7 +775,7 @@ def compute_scene_occupancy_probability_field(params, macarons, camera, surface_
                 for gi, (j0, j1) in enumerate(groups):
                     t0, t1 = int(q_start[j0]), int(q_start[j1])
                     src = given[gi][2] if given is not None else ragged_perms
-                    kw = {"index_arrays": src} if isinstance(src, dict) else {"perms": src, "perm_source": perm_source}
+                    kw = {"index_arrays": src} if isinstance(src, dict) else {"perms": src}
                     occ_net.forward_ragged_finish(hdls[gi], out=occ_out if (j0, j1) == (0, J) else occ_out[t0:t1], **kw)
                     used.append((j0, j1, occ_net.last_ragged_perms))
                 ragged_perms = used[0][2] if len(used) == 1 else {"groups": used}
@@ -810,26 +826,6 @@ def _broadcast_job_perms(occ_net, cloud_sizes, device, group, rank):
             job.append(host[o:o + n_]); o += n_
         out.append(job)
     return out
-
-
-def _broadcast_job_index_arrays(occ_net, cloud_sizes, device, group, rank):
-    """perm_source="device" on several ranks: rank 0 draws the index arrays of ALL jobs on its device; one broadcast of
-    [g_idx | idx1 | idx2] (the offsets and lengths follow from the cloud sizes on every rank)."""
-    from .. import dist as mdist
-    J, Lg = len(cloud_sizes), occ_net.seq_len
-    sz = [occ_net.scale_sizes(int(m_)) for m_ in cloud_sizes]
-    n1, n2 = sum(s_[1] for s_ in sz), sum(s_[2] for s_ in sz)
-    if rank == 0:
-        ia = occ_net.ragged_index_arrays_device(cloud_sizes, device)
-        buf = torch.cat((ia["g_idx"], ia["idx1"], ia["idx2"]))
-    else:
-        buf = torch.empty(J * Lg + n1 + n2, dtype=torch.int64, device=device)
-    mdist.broadcast(buf, 0, group)
-    cum = lambda v: np.concatenate(([0], np.cumsum(v))).astype(np.int64)
-    offs = ops.h2d(np.concatenate([cum([s_[1] for s_ in sz]), cum([s_[2] for s_ in sz]), np.asarray([min(s_[0], Lg) for s_ in sz], np.int64)]),
-                   torch.int64, device)
-    return {"g_idx": buf[:J * Lg], "idx1": buf[J * Lg:J * Lg + n1], "idx2": buf[J * Lg + n1:], "off1": offs[:J + 1],
-            "off2": offs[J + 1:2 * J + 2], "g_len": offs[2 * J + 2:].to(torch.int32)}
 
 
 def _slice_index_arrays(occ_net, ia, cloud_sizes, j0, j1):

@@ -211,8 +211,17 @@ class Scene:
             pts = torch.cat([c._pts for c, n in zip(cells, lens) if n] + [torch.zeros(0, 3, device=dev)]).contiguous()
             fts = None
             if self.feature_dim > 0:
-                fts = torch.cat([c._fts.to(torch.float32).view(-1, self.feature_dim) for c, n in zip(cells, lens) if n]
-                                + [torch.zeros(0, self.feature_dim, device=dev)]).contiguous()
+                # one feature row per stored point: upstream's Cell.fill(features=None) leaves cell_features behind the points, which
+                # would silently shift every later cell's rows in the flat store -- refuse instead of mis-aligning
+                rows = []
+                for c, n in zip(cells, lens):
+                    if n:
+                        f_ = None if c._fts is None else c._fts.reshape(-1, self.feature_dim)
+                        if f_ is None or f_.shape[0] != n:
+                            raise ValueError(f"Scene.flat_store: a cell holds {n} points but {0 if f_ is None else f_.shape[0]} feature rows "
+                                             f"(feature_dim={self.feature_dim}): fill cells with `features=` of one row per point")
+                        rows.append(f_.to(torch.float32))
+                fts = torch.cat(rows + [torch.zeros(0, self.feature_dim, device=dev)]).contiguous()
             self._store = _Store(pts, fts, off, ops.h2d(off, torch.int64, dev))
             for c in cells:
                 c._pts = c._fts = None
@@ -233,12 +242,21 @@ class Scene:
         """Device part of fill_cells (ops.scene_fill_begin): nothing returns to the host.  -> handle for fill_cells_end; its `.counts`
         (device int64) holds, per cell, the number of candidates and of admitted candidates."""
         from .. import ops
+        self._check_grid_size()
         cells, lo, hi = self._cell_table()
         st = self.flat_store()
         with_fts = self.feature_dim > 0 and features is not None
         h = ops.scene_fill_begin(pts, valid, self._consts(self.device)["gc"], (self.grid_l, self.grid_w, self.grid_h), lo, hi, st.pts, st.off_dev,
                                  cells[0].resolution, n_point_min, features.reshape(pts.shape[0], self.feature_dim) if with_fts else None)
         return h
+
+    MAX_CELLS = 1023        # the counting sort of csrc/scene.hip (grp_* kernels: one LDS counter per cell) covers grids of < 1024 cells
+
+    def _check_grid_size(self):
+        n = self.grid_l * self.grid_w * self.grid_h
+        if n > self.MAX_CELLS:
+            raise NotImplementedError(f"Scene: the fused fill / field passes handle grids of up to {self.MAX_CELLS} cells, this one has {n} "
+                                      f"({self.grid_l} x {self.grid_w} x {self.grid_h}); the reference's scenes use 18 .. 72")
 
     def fill_counts(self, host_counts):
         """(candidates per cell, admitted per cell) out of a host copy of a fill handle's counts."""
@@ -253,7 +271,7 @@ class Scene:
         b_len = np.diff(st.off)
         return bool(np.any((cand > n_point_min) & (b_len + adm > cap)))
 
-    def fill_cells_draw(self, h, cand, adm, n_point_min=0, group=None, perm_source="host"):
+    def fill_cells_draw(self, h, cand, adm, n_point_min=0, group=None):
         """Host part of fill_cells, first half: the touched cells' torch.randperm draws on the CPU generator in cell order (Cell.fill
         :2573 -- the reference's draws).  -> plan for fill_cells_apply (None: no cell was touched).  Nothing is launched."""
         from .. import dist as mdist
@@ -270,8 +288,8 @@ class Scene:
         n_keep = np.where(touched, np.minimum(n_comb, cap), b_len)
         world, rank_ = mdist.group_world_rank(group)           # group=None: local, whatever process groups exist
         plan = {"h": h, "touched": touched, "n_keep": n_keep, "adm": adm, "b_len": b_len, "group": group, "world": world,
-                "perm_source": perm_source, "pm": None}
-        if perm_source != "device" and rank_ == 0:
+                "pm": None}
+        if rank_ == 0:
             # torch.randperm(n_comb)[:capacity] per touched cell, cell order, CPU generator (:2573) -- the reference's draws, made by one
             # call into the C++ extension (the same at::randperm calls without ~70 dispatcher round trips)
             from .host import batched_draws_ok
@@ -300,46 +318,27 @@ class Scene:
         new_off = np.concatenate(([0], np.cumsum(n_keep))).astype(np.int64)
         n_new = int(new_off[-1])
         F = self.feature_dim
-        if plan["perm_source"] == "device":
-            # every cell's rows of the virtual table [store | admitted]: a random order per touched cell by ONE sort of (cell + uniform)
-            # float64 keys (the uniform capped below 1: cell + u never rounds up to the next cell), the stored order for the others
-            tab = ops.h2d(np.concatenate([b_len, adm, n_keep, b_off[:-1], n_store + adm_off[:-1], touched.astype(np.int64)]), torch.int64, dev)
-            d_nb, d_na, d_nk, d_b0, d_a0, d_t = (tab[k_ * n_cells:(k_ + 1) * n_cells] for k_ in range(6))
-            d_n = d_nb + d_na * d_t
-            total = int((b_len + adm * touched).sum())
-            off = torch.cumsum(d_n, 0) - d_n
-            seg = torch.repeat_interleave(torch.arange(n_cells, device=dev), d_n, output_size=total)
-            local = torch.arange(total, device=dev) - off[seg]
-            comb = torch.where(local < d_nb[seg], d_b0[seg] + local, d_a0[seg] + local - d_nb[seg])
-            u = torch.rand(total, dtype=torch.float64, device=dev).clamp_(max=1.0 - 2.0 ** -30)
-            u = torch.where(d_t[seg] > 0, u, local.double() / d_n[seg].double().clamp(min=1.0) * (1.0 - 2.0 ** -30))
-            order = torch.argsort(seg.double() + u)
-            g = comb[order][local < d_nk[seg]]                   # (sorted position p of segment s has rank p - off[s] = local[p])
-            if mdist.exchange_on(group):
-                mdist.broadcast(g, 0, group)
-            new_pts, new_fts = ops.scene_fill_gather(g, h, st.pts, st.fts, n_store, F)
-        else:
-            # ONE upload: the cells' tables and the permutation prefixes; the gather maps every new row to its source on the device
-            n_pm_cell = np.where(touched, n_keep, 0)
-            pm_off = np.concatenate(([0], np.cumsum(n_pm_cell))).astype(np.int64)
-            n_pm = int(pm_off[-1])
-            pm = plan["pm"] if plan["pm"] is not None else np.zeros(n_pm, np.int64)
-            tabs = np.concatenate([new_off, b_off, adm_off, pm_off, np.concatenate((touched.astype(np.int64), [0]))])
-            pm32 = np.ascontiguousarray(pm, dtype=np.int32)
-            if n_pm % 2:
-                pm32 = np.concatenate((pm32, np.zeros(1, np.int32)))
-            buf = ops.h2d(np.concatenate((tabs, pm32.view(np.int64))), torch.int64, dev)
-            if mdist.exchange_on(group):                        # rank 0's draws for every replica
-                mdist.broadcast(buf, 0, group)
-            new_pts, new_fts = ops.scene_fill_gather_perm(buf, n_pm, n_cells, n_new, h, st.pts, st.fts, n_store, F)
+        # ONE upload: the cells' tables and the permutation prefixes; the gather maps every new row to its source on the device
+        n_pm_cell = np.where(touched, n_keep, 0)
+        pm_off = np.concatenate(([0], np.cumsum(n_pm_cell))).astype(np.int64)
+        n_pm = int(pm_off[-1])
+        pm = plan["pm"] if plan["pm"] is not None else np.zeros(n_pm, np.int64)
+        tabs = np.concatenate([new_off, b_off, adm_off, pm_off, np.concatenate((touched.astype(np.int64), [0]))])
+        pm32 = np.ascontiguousarray(pm, dtype=np.int32)
+        if n_pm % 2:
+            pm32 = np.concatenate((pm32, np.zeros(1, np.int32)))
+        buf = ops.h2d(np.concatenate((tabs, pm32.view(np.int64))), torch.int64, dev)
+        if mdist.exchange_on(group):                        # rank 0's draws for every replica
+            mdist.broadcast(buf, 0, group)
+        new_pts, new_fts = ops.scene_fill_gather_perm(buf, n_pm, n_cells, n_new, h, st.pts, st.fts, n_store, F)
         from .. import ops as _o
         self._store = _Store(new_pts, new_fts, new_off, _o.h2d(new_off, torch.int64, dev))
 
-    def fill_cells_end(self, h, cand, adm, n_point_min=0, group=None, perm_source="host"):
+    def fill_cells_end(self, h, cand, adm, n_point_min=0, group=None):
         """Host part of fill_cells (fill_cells_draw + fill_cells_apply)."""
-        self.fill_cells_apply(self.fill_cells_draw(h, cand, adm, n_point_min, group, perm_source))
+        self.fill_cells_apply(self.fill_cells_draw(h, cand, adm, n_point_min, group))
 
-    def fill_cells(self, pts, features=None, n_point_min=0, group=None, perm_source="host", valid=None):
+    def fill_cells(self, pts, features=None, n_point_min=0, group=None, valid=None):
         """Scene.fill_cells (macarons_utils.py:2727-2737) over Cell.fill (:2551-2577) for ALL touched cells at once: upstream loops
         the cells from Python, each testing every point against its box and its store.  Here (fill_cells_begin) a counting sort groups
         the points by cell (floor rule, then the strict box test of that cell), ONE segmented fp64 nearest-distance launch runs every
@@ -350,15 +349,12 @@ class Scene:
         process groups exist): the permutations are rank 0's, broadcast once -- every rank drawing its own would let the replicas
         diverge.
         `valid` (bool [N], optional): only these rows of pts are offered -- the same as fill_cells(pts[valid], features[valid]) without
-        the read-back that boolean indexing costs.
-        perm_source="device" (opt-in): every touched cell's random subset / order comes from the device generator in ONE segmented
-        sort instead of one torch.randperm per cell on the host (72 draws = 0.7 ms of a MACARONS decision): statistically the same,
-        not the reference's CPU-generator stream."""
+        the read-back that boolean indexing costs."""
         if pts.shape[0] == 0:
             return
         h = self.fill_cells_begin(pts, features, n_point_min, valid)
         cand, adm = self.fill_counts(h.counts.cpu().numpy())                                       # the one read-back
-        self.fill_cells_end(h, cand, adm, n_point_min, group, perm_source)
+        self.fill_cells_end(h, cand, adm, n_point_min, group)
 
     def get_pt_cloud_from_cells(self, cell_indices, return_features=True):
         with_fts = return_features and self.feature_dim > 0

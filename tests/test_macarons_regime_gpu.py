@@ -304,7 +304,7 @@ def test_macarons_decision_range_guard_is_deferred_and_falls_back(dev):
             with torch.no_grad():
                 r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, T(g["depth"][0], dev), T(dmask[0], dev), nrec,
                                              T(g["n_eyes"][0], dev), dev, samples=T(g["u_0"], dev))
-            assert m.occupancy.range_guard == "async"                   # restored (the default)
+            assert m.occupancy.range_guard == "sync"                    # restored (the default)
         finally:
             L.mcr_set_local_pct_variant(ctypes.c_int(v0))
         return r
@@ -461,92 +461,3 @@ def run_macarons_trajectory(dev, variant=None, strict=True):
 def test_macarons_trajectory_matches_reference(dev):
     """The ten-decision trajectory golden on the default numerics: every exact / 1e-4 assertion of run_macarons_trajectory."""
     run_macarons_trajectory(dev)
-
-
-
-
-def test_device_permutation_source(dev):
-    """perm_source="device" (opt-in): the hidden permutations of a MACARONS decision drawn on the GPU in segmented sorts instead of
-    ~190 torch.randperm calls on the host.  (i) SconeOcc.ragged_index_arrays_device returns, per job, prefixes of genuine permutations
-    (unique indices of the job's own rows, the sizes SconeOcc.py:269 / :311 take); read back as host perms they give, bit for bit,
-    the same occupancies through the default path.  (ii) Scene.fill_cells(perm_source="device") stores exactly the points the
-    default path stores (another order) and, over capacity, a subset of `capacity` distinct candidates.  (iii) a whole decision on
-    the reference golden's scene: the proxy-scene state (which no draw touches) equals the golden's, every gain is finite and the
-    decision is valid."""
-    from macarons_amd.networks import SconeOcc
-    from macarons_amd.utility import macarons_utils as mu
-    from macarons_amd.utility.scene import Scene
-    m = _models(dev)
-    occ = m.occupancy
-    rng = np.random.default_rng(5)
-    sizes_m, sizes_q = [700, 2300, 130, 5000], [50, 400, 7, 900]
-    pc = T(rng.uniform(-.4, .4, (sum(sizes_m), 3)).astype(np.float32), dev)
-    x = T(rng.uniform(-.5, .5, (sum(sizes_q), 3)).astype(np.float32), dev)
-    vh = T((rng.standard_normal((sum(sizes_q), 64)) * .3).astype(np.float32), dev)
-    torch.manual_seed(11)
-    ia = occ.ragged_index_arrays_device(sizes_m, dev)
-    off0 = np.concatenate(([0], np.cumsum(sizes_m)))
-    off1, off2 = ia["off1"].cpu().numpy(), ia["off2"].cpu().numpy()
-    g_idx, idx1, idx2 = ia["g_idx"].cpu().numpy().reshape(len(sizes_m), -1), ia["idx1"].cpu().numpy(), ia["idx2"].cpu().numpy()
-    perms = []
-    for j, M in enumerate(sizes_m):
-        sz = occ.scale_sizes(M)
-        n0 = min(M, occ.seq_len)
-        assert int(ia["g_len"][j]) == n0 and off1[j + 1] - off1[j] == sz[1] and off2[j + 1] - off2[j] == sz[2]
-        p0, p1, p2 = g_idx[j, :n0] - off0[j], idx1[off1[j]:off1[j + 1]] - off0[j], idx2[off2[j]:off2[j + 1]] - off1[j]
-        for p_, hi in ((p0, M), (p1, M), (p2, sz[1])):
-            assert len(np.unique(p_)) == len(p_) and p_.min() >= 0 and p_.max() < hi, j
-        assert (g_idx[j, n0:] == off0[j]).all()
-        perms.append([torch.from_numpy(p0.copy()), torch.from_numpy(p1.copy()), torch.from_numpy(p2.copy())])
-    with torch.no_grad():
-        a = occ.forward_ragged(pc, sizes_m, x, vh, sizes_q, index_arrays=ia)
-        b = occ.forward_ragged(pc, sizes_m, x, vh, sizes_q, perms=perms)
-        c = occ.forward_ragged(pc, sizes_m, x, vh, sizes_q, perm_source="device")
-    assert torch.equal(a, b) and torch.isfinite(c).all() and not torch.equal(a, c)
-    # two draws differ, and small-sample statistics look uniform: every point of the 130-point cloud is taken about equally often
-    cnt = np.zeros(130)
-    for _ in range(60):
-        ia2 = occ.ragged_index_arrays_device([130], dev)
-        cnt[ia2["idx1"].cpu().numpy()] += 1
-    n1 = occ.scale_sizes(130)[1]
-    assert abs(cnt.mean() - 60 * n1 / 130) < 1e-9 and cnt.min() > 0.3 * cnt.mean() and cnt.max() < 2.0 * cnt.mean()
-    # ---- (ii) fill_cells
-    x_min, x_max = torch.tensor([-8., -4., -8.], device=dev), torch.tensor([8., 4., 8.], device=dev)
-    pts = T((rng.uniform(-1, 1, (6000, 3)) * [7.9, 3.9, 7.9]).astype(np.float32), dev)
-    fts = torch.arange(6000, device=dev).float().view(-1, 1)
-    for cap in (100000, 300):
-        sa = Scene(x_min, x_max, 2, 1, 2, cell_capacity=cap, cell_resolution=1e-4, n_proxy_points=6000, device=dev, feature_dim=1)
-        sb = Scene(x_min, x_max, 2, 1, 2, cell_capacity=cap, cell_resolution=1e-4, n_proxy_points=6000, device=dev, feature_dim=1)
-        for lo, hi in ((0, 2500), (1500, 6000)):                       # the second fill re-offers 1000 stored points: refused by both
-            sa.fill_cells(pts[lo:hi], features=fts[lo:hi])
-            sb.fill_cells(pts[lo:hi], features=fts[lo:hi], perm_source="device")
-        for k in sa.cells:
-            ia_, ib_ = sa.cells[k].cell_features[:, 0].cpu().numpy(), sb.cells[k].cell_features[:, 0].cpu().numpy()
-            assert len(ia_) == len(ib_) == min(cap, len(ia_)) and len(np.unique(ib_)) == len(ib_)
-            assert torch.equal(sb.cells[k].cell_pts, pts[sb.cells[k].cell_features[:, 0].long()])
-            if cap == 100000:
-                assert np.array_equal(np.sort(ia_), np.sort(ib_)) and not np.array_equal(ia_, ib_)
-    # ---- (iii) a decision
-    g = golden("macarons_decision")
-    surface, proxy = _decision_scenes(g, dev)
-    H, W = int(g["hw"][0]), int(g["hw"][1])
-    n = len(g["proxy"])
-    params = NS(n_harmonics=64, harmonic_degree=8, view_state_n_elev=7, view_state_n_azim=14, k_for_knn=16,
-                prediction_neighborhood_size=3, n_view_state_cameras=98, sensor_range=40., min_occ_for_proxy_points=0.1, seq_len=2048,
-                distance_factor_th=17., image_height=H, image_width=W, carving_tolerance=0.05)
-    dmask = np.unpackbits(g["dmask"])[:2 * H * W].reshape(2, H, W).astype(bool)
-    cam = mu.SceneCamera(mu.camera_record(g["Mview"][0], g["Mfull"][0], g["ndc"], g["eyes"][0], params.sensor_range).to(dev),
-                         T(g["eyes"][0:1], dev), float(g["zfar"]))
-    nrec = torch.stack([mu.camera_record(g["nMview_0"][k], g["nMfull_0"][k], g["ndc"], g["n_eyes"][0, k], params.sensor_range)
-                        for k in range(5)]).to(dev)
-    with torch.no_grad():
-        r = mu.macarons_nbv_decision(params, m, proxy, surface, cam, T(g["depth"][0], dev), T(dmask[0], dev), nrec, T(g["n_eyes"][0], dev), dev,
-                                     perm_source="device")
-    assert np.array_equal(r["fov_mask"].cpu().numpy(), np.unpackbits(g["fov_mask_0"])[:n].astype(bool))
-    assert np.array_equal(proxy.view_states.cpu().numpy().astype(np.uint8), np.unpackbits(g["view_states_0"], axis=-1)[:, :98])
-    assert np.array_equal(proxy.proxy_supervision_occ.cpu().numpy()[:, 0].astype(np.uint8), g["sup_occ_0"])
-    assert np.array_equal(r["X_world"].cpu().numpy(), g["X_world_0"])
-    gains = r["gains"].cpu().numpy()
-    assert np.isfinite(gains).all() and gains[4] == 0.0 and (gains[:4] > 0).all() and int(r["next_idx"]) == int(np.argmax(gains))
-    # other down-samples, other features: the gains move, but stay the same quantity (within 25 % of the reference-stream ones)
-    assert np.abs(gains[:4] / g["gains_0"][:4] - 1).max() < 0.25

@@ -7,7 +7,7 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 code = {
     "nbv": "import torch, bench, argparse; a = argparse.Namespace(cams=200, nbv_iters=60); r = bench.measure_nbv_step(torch.device('cuda:0'), 0, 1, a); print('RES', r['p50_ms'])",
     "batch": "import torch, bench, argparse; a = argparse.Namespace(cams=200, nbv_iters=60); r = bench.measure_nbv_batch(torch.device('cuda:0'), 0, 1, a); print('RES', r['p50_ms'])",
-    "mac": "import torch, bench; r = bench.measure_macarons_step(torch.device('cuda:0')); print('RES', r['p50_ms'], r['device_perms']['p50_ms'])",
+    "mac": "import torch, bench; r = bench.measure_macarons_step(torch.device('cuda:0')); print('RES', r['p50_ms'], r['variant_7']['p50_ms'])",
 }[leg]
 for rep in range(reps):
     for off in ("0", None):

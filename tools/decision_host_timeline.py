@@ -28,7 +28,7 @@ for m, n in ((mu, "macarons_nbv_decision"), (mu, "compute_scene_occupancy_probab
     if hasattr(m, n):
         wrap(m, n)
 os.environ["MCR_BENCH_NO_CHECKS"] = "1"
-r = bench.measure_macarons_step(torch.device("cuda:0"), perm_sources=("host",))
+r = bench.measure_macarons_step(torch.device("cuda:0"))
 print("p50 ms", r["p50_ms"])
 dec = [e for e in log if e[3] == "macarons_nbv_decision"]
 d0, d1 = dec[len(dec) // 2][0], dec[len(dec) // 2][1]

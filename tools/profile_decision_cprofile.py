@@ -6,10 +6,10 @@ sys.path.insert(0, ROOT)
 import bench
 os.environ["MCR_BENCH_NO_CHECKS"] = "1"
 dev = torch.device("cuda:0")
-bench.measure_macarons_step(dev, perm_sources=("host",))           # warm: caches, arenas
+bench.measure_macarons_step(dev)           # warm: caches, arenas
 pr = cProfile.Profile()
 pr.enable()
-r = bench.measure_macarons_step(dev, perm_sources=("host",))
+r = bench.measure_macarons_step(dev)
 pr.disable()
 print("p50", r["p50_ms"])
 s = io.StringIO()

@@ -14,8 +14,5 @@ for g in sys.argv[1:] or ["1", "2", "3", "4", ""]:
         os.environ["MCR_FIELD_GROUPS"] = g
     else:
         os.environ.pop("MCR_FIELD_GROUPS", None)
-    r = [bench.measure_macarons_step(dev, perm_sources=("host",))["p50_ms"] for _ in range(3)]
+    r = [bench.measure_macarons_step(dev)["p50_ms"] for _ in range(3)]
     print(f"groups={g or 'auto'}: p50 {sorted(r)[1]:.2f} ms  (runs {', '.join(f'{x:.2f}' for x in r)})", flush=True)
-if not os.environ.get("NO_DEVICE_PERMS"):
-    r = bench.measure_macarons_step(dev, perm_sources=("device",))
-    print("device perms p50", r["device_perms"]["p50_ms"])

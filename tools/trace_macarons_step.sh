@@ -6,7 +6,7 @@ export MCR_BENCH_NO_CHECKS=1
 rm -rf /tmp/mtrace; timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/mtrace -o t -- python -c "
 import sys; sys.path.insert(0, '/root/repo')
 import torch, bench
-r = bench.measure_macarons_step(torch.device('cuda:0'), perm_sources=('${PERM:-host}',)); print(r['p50_ms'], r['device_perms']['p50_ms'])" > /tmp/mtrace.log 2>&1
+r = bench.measure_macarons_step(torch.device('cuda:0')); print(r['p50_ms'], r['variant_7']['p50_ms'])" > /tmp/mtrace.log 2>&1
 tail -1 /tmp/mtrace.log
 python - <<'PY'
 import csv, glob, collections
