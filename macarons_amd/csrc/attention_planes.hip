@@ -64,7 +64,11 @@ __device__ __forceinline__ float ap_max_lane_groups(float x) {
 // Oh / Ol (row stride ldo halves) when given, else as fp32 rows of `out` (row stride ldo floats).  SPLIT: the two blocks of a (query tile,
 // head, sequence) take the two halves of the keys and write unnormalised fp32 parts (part 0 -> out, part 1 -> part1 [T, H DV]) plus their
 // (running max in units of log 2, sum) per query -> ml [2][T][H][2]; attention_combine_kernel merges them.
-template <int DQ, int DV, bool SPLIT, int QG>
+// NP = 2: hi / lo planes (variant 6).  NP = 1 (variant 7, the opt-in 16-bit matrix path): the HIGH planes alone -- the low planes are
+// neither staged nor read (their LDS regions stay unused), the Q fragment's low half is zero (DQ = 16: the MFMA's k = 16 .. 31; DQ = 8:
+// k = 8 .. 31), one MFMA per score tile and per P V tile instead of two / three, the soft-max weights are rounded once instead of split,
+// and the result leaves as ONE plane (Ol is not written).  Scores, soft-max and accumulation stay fp32.
+template <int DQ, int DV, bool SPLIT, int QG, int NP = 2>
 __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void attention_planes_kernel(
     const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl, long long ldp, float* __restrict__ out, _Float16* __restrict__ Oh,
     _Float16* __restrict__ Ol, long long ldo, int L, int H, const int* __restrict__ lens, float* __restrict__ part1, float* __restrict__ ml) {
@@ -118,6 +122,7 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
             const int j = wave + 4 * n;                   // wave-uniform
             if (j < NI) {
                 const bool lo = j < 2 * NK ? j >= NK : j - 2 * NK >= NV;
+                if (NP == 1 && lo) continue;              // (wave-uniform: the low planes are not staged)
                 int off = d_off[n];
                 if (!whole) {                             // (rows past the keys repeat the last key: finite, and their scores are masked)
                     int row, col;
@@ -137,8 +142,9 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
     for (int qg = 0; qg < QG; ++qg) {
         const int qi = min(q0 + 16 * qg + li, L - 1);
         const bool lo_part = DQ == 16 ? g >= 2 : (g & 1);
-        const _Float16* qp = (lo_part ? bl : bh) + (long long)qi * ldp + hh * DQ + (DQ == 16 ? 8 * (g & 1) : 0);
+        const _Float16* qp = ((NP == 2 && lo_part) ? bl : bh) + (long long)qi * ldp + hh * DQ + (DQ == 16 ? 8 * (g & 1) : 0);
         qh[qg] = *reinterpret_cast<const f16x8*>(qp);
+        if (NP == 1 && (DQ == 16 ? g >= 2 : g >= 1)) qh[qg] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};      // k beyond the head's DQ dims: zeros
     }
     float m[QG];                                        // running max (units of log 2; lane (li, any g): query li)
     // O and the softmax denominators in C layout (lane (c, g): queries 4g + r): the denominators are one more column block of P V, with
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
     // fragment addresses inside a stage (bytes)
     const unsigned lds0 = (unsigned)(size_t)((ap_lptr)smem);
     // K: DQ = 16: row (sub 16 + li), chunk (g & 1) ^ (li >> 3) of the hi plane (+ KBYTES: lo); DQ = 8: row of the plane the lane group reads
-    const unsigned a_k = DQ == 16 ? lds0 + (unsigned)(li * 32 + (((g & 1) ^ (li >> 3)) * 16)) : lds0 + (unsigned)(li * 16 + (g >= 2 ? KBYTES : 0));
+    const unsigned a_k = DQ == 16 ? lds0 + (unsigned)(li * 32 + (((g & 1) ^ (li >> 3)) * 16)) : lds0 + (unsigned)(li * 16 + ((NP == 2 && g >= 2) ? KBYTES : 0));
     // V: [nt][key][16]: lane (li, g) -> keys 4 g.., columns 4 (li & 3).. of the 16-key group; the transposing read hands lane (c, g) keys 4 g.. of column c
     const unsigned a_v = lds0 + (unsigned)(2 * KBYTES + ((4 * g) * 16 + li * 4) * 2);
 
@@ -174,7 +180,10 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
         // ---- scores of the 64 keys: two MFMAs (K_lo, then K_hi: smallest terms first) per 16 keys x 16 queries at DQ = 16, one at DQ = 8
         constexpr int KF = DQ == 16 ? 2 : 1;
         ap_u32x4 kf[4][KF];
-        if constexpr (DQ == 16) {
+        if constexpr (DQ == 16 && NP == 1) {                // (the K_hi fragments alone, in slot 0: the second MFMA is skipped; no copy of a
+            kf[0][0] = ap_read128<0>(a_k + sb); kf[1][0] = ap_read128<512>(a_k + sb);      // fragment may be made before the counted wait below)
+            kf[2][0] = ap_read128<1024>(a_k + sb); kf[3][0] = ap_read128<1536>(a_k + sb);
+        } else if constexpr (DQ == 16) {
             kf[0][0] = ap_read128<KBYTES>(a_k + sb); kf[0][KF - 1] = ap_read128<0>(a_k + sb);
             kf[1][0] = ap_read128<KBYTES + 512>(a_k + sb); kf[1][KF - 1] = ap_read128<512>(a_k + sb);
             kf[2][0] = ap_read128<KBYTES + 1024>(a_k + sb); kf[2][KF - 1] = ap_read128<1024>(a_k + sb);
@@ -187,12 +196,19 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
 #define MCR_AP_VREAD(V_, NT_, BASE_)                                                                                                  \
     do {                                                                                                                               \
         V_[NT_][0] = ap_read_tr<(NT_) * 2048 + (BASE_)>(a_v + sb); V_[NT_][1] = ap_read_tr<(NT_) * 2048 + (BASE_) + 512>(a_v + sb);      \
-        V_[NT_][2] = ap_read_tr<VBYTES + (NT_) * 2048 + (BASE_)>(a_v + sb);                                                             \
-        V_[NT_][3] = ap_read_tr<VBYTES + (NT_) * 2048 + (BASE_) + 512>(a_v + sb);                                                       \
+        if constexpr (NP == 2) {                                                                                                       \
+            V_[NT_][2] = ap_read_tr<VBYTES + (NT_) * 2048 + (BASE_)>(a_v + sb);                                                         \
+            V_[NT_][3] = ap_read_tr<VBYTES + (NT_) * 2048 + (BASE_) + 512>(a_v + sb);                                                   \
+        }                                                                                                                              \
     } while (0)
 #define MCR_AP_VWAIT(V_)                                                                                                              \
     do {                                                                                                                               \
-        if constexpr (NT == 4)                                                                                                         \
+        if constexpr (NP == 1 && NT == 4)                                                                                              \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V_[0][0]), "+v"(V_[0][1]), "+v"(V_[1][0]), "+v"(V_[1][1]), "+v"(V_[NT - 2][0]),   \
+                         "+v"(V_[NT - 2][1]), "+v"(V_[NT - 1][0]), "+v"(V_[NT - 1][1]));                                                  \
+        else if constexpr (NP == 1)                                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V_[0][0]), "+v"(V_[0][1]), "+v"(V_[1][0]), "+v"(V_[1][1]));                       \
+        else if constexpr (NT == 4)                                                                                                    \
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V_[0][0]), "+v"(V_[0][1]), "+v"(V_[0][2]), "+v"(V_[0][3]), "+v"(V_[1][0]), "+v"(V_[1][1]), \
                          "+v"(V_[1][2]), "+v"(V_[1][3]), "+v"(V_[NT - 2][0]), "+v"(V_[NT - 2][1]), "+v"(V_[NT - 2][2]), "+v"(V_[NT - 2][3]),  \
                          "+v"(V_[NT - 1][0]), "+v"(V_[NT - 1][1]), "+v"(V_[NT - 1][2]), "+v"(V_[NT - 1][3]));                            \
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V_[0][0]), "+v"(V_[0][1]), "+v"(V_[0][2]), "+v"(V_[0][3]), "+v"(V_[1][0]), "+v"(V_[1][1]), \
                          "+v"(V_[1][2]), "+v"(V_[1][3]));                                                                              \
     } while (0)
-        if constexpr (DQ == 16)
+        if constexpr (DQ == 16 && NP == 2)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][KF - 1]), "+v"(kf[1][0]), "+v"(kf[1][KF - 1]), "+v"(kf[2][0]),
                          "+v"(kf[2][KF - 1]), "+v"(kf[3][0]), "+v"(kf[3][KF - 1]));
         else
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg)
                 st[qg][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[sub][0]), qh[qg], ap_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        if constexpr (DQ == 16) {
+        if constexpr (DQ == 16 && NP == 2) {
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
@@ -277,6 +293,12 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
 #endif
         };
         auto split_q = [&](const int q, const int qg) {
+            if constexpr (NP == 1) {                          // rounded once: v_cvt_pk_f16_f32
+                const uint4 ph1 = make_uint4(pack2h(st[qg][2 * q][0], st[qg][2 * q][1]), pack2h(st[qg][2 * q][2], st[qg][2 * q][3]),
+                                             pack2h(st[qg][2 * q + 1][0], st[qg][2 * q + 1][1]), pack2h(st[qg][2 * q + 1][2], st[qg][2 * q + 1][3]));
+                p_hi[q][qg] = __builtin_bit_cast(f16x8, ph1);
+                return;
+            }
             uint4 ph, pl;
             split2h(st[qg][2 * q][0], st[qg][2 * q][1], ph.x, pl.x);
             split2h(st[qg][2 * q][2], st[qg][2 * q][3], ph.y, pl.y);
@@ -292,17 +314,21 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
         // (the kernel runs three waves per SIMD at 168 registers)
         auto pv = [&](const int q, const int nt, const ap_u32x2* v) {
             const f16x8 v_hi = __builtin_bit_cast(f16x8, ap_u32x4{v[0][0], v[0][1], v[1][0], v[1][1]});
-            const f16x8 v_lo = __builtin_bit_cast(f16x8, ap_u32x4{v[2][0], v[2][1], v[3][0], v[3][1]});
+            if constexpr (NP == 2) {
+                const f16x8 v_lo = __builtin_bit_cast(f16x8, ap_u32x4{v[2][0], v[2][1], v[3][0], v[3][1]});
 #pragma unroll
-            for (int qg = 0; qg < QG; ++qg) o[qg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_lo[q][qg], v_hi, o[qg][nt], 0, 0, 0);
+                for (int qg = 0; qg < QG; ++qg) o[qg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_lo[q][qg], v_hi, o[qg][nt], 0, 0, 0);
 #pragma unroll
-            for (int qg = 0; qg < QG; ++qg) o[qg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_hi[q][qg], v_lo, o[qg][nt], 0, 0, 0);
+                for (int qg = 0; qg < QG; ++qg) o[qg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_hi[q][qg], v_lo, o[qg][nt], 0, 0, 0);
+            }
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg) o[qg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_hi[q][qg], v_hi, o[qg][nt], 0, 0, 0);
         };
         auto pl_sum = [&](const int q) {
+            if constexpr (NP == 2) {
 #pragma unroll
-            for (int qg = 0; qg < QG; ++qg) ol[qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_lo[q][qg], ones, ol[qg], 0, 0, 0);
+                for (int qg = 0; qg < QG; ++qg) ol[qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_lo[q][qg], ones, ol[qg], 0, 0, 0);
+            }
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg) ol[qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p_hi[q][qg], ones, ol[qg], 0, 0, 0);
         };
@@ -368,7 +394,7 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
                         if (Oh) {
                             const _Float16 hi = (_Float16)y;
                             Oh[at + nt * 16] = hi;
-                            Ol[at + nt * 16] = (_Float16)(y - (float)hi);
+                            if (NP == 2) Ol[at + nt * 16] = (_Float16)(y - (float)hi);
                         } else {
                             out[at + nt * 16] = y;
                         }
@@ -388,11 +414,11 @@ bool attention_planes_applicable(int H, int DQK, int DV, int64_t ldp) {
 // (out then receives fp32 parts and the combine pass writes the planes Oh / Ol, or fp32 rows of `out` when Oh is null).
 void launch_attention_planes(hipStream_t s, const void* Ph_, const void* Pl_, int64_t ldp, float* out, int64_t ldo, void* Oh_, void* Ol_,
                              int64_t ldoh, int64_t S, int L, int H, int DQK, int DV, const int* lens, float* split_ws, size_t split_ws_floats,
-                             int split_mode) {
+                             int split_mode, int n_planes) {
     if (S <= 0 || L <= 0) return;
     const int dq = DQK / H, dv = DV / H;
     if ((int64_t)L * ldp >= ((int64_t)1 << 31)) { set_error("launch_attention_planes: sequence too long for 32-bit row offsets"); return; }
-    if (!attention_planes_applicable(H, DQK, DV, ldp) || (reinterpret_cast<uintptr_t>(Ph_) & 15) || (reinterpret_cast<uintptr_t>(Pl_) & 15)) {
+    if (!attention_planes_applicable(H, DQK, DV, ldp) || (reinterpret_cast<uintptr_t>(Ph_) & 15) || (n_planes != 1 && (reinterpret_cast<uintptr_t>(Pl_) & 15))) {
         set_error("launch_attention_planes: unsupported head dims / alignment (dq=%d dv=%d ldp=%lld)", dq, dv, (long long)ldp);
         return;
     }
@@ -400,7 +426,7 @@ void launch_attention_planes(hipStream_t s, const void* Ph_, const void* Pl_, in
     _Float16 *Oh = (_Float16*)Oh_, *Ol = (_Float16*)Ol_;
     // split_mode: 1 = always (when L >= 512 and the scratch is there), 0 = never, -1 = when the unsplit grid leaves CUs idle
     const int64_t blocks64 = (int64_t)cdiv(L, 64) * H * S;
-    const bool can_split = split_ws && split_ws_floats >= attention_split_floats(S, L, H, DV) && L >= 512 && 2 * S <= 65535;
+    const bool can_split = n_planes != 1 && split_ws && split_ws_floats >= attention_split_floats(S, L, H, DV) && L >= 512 && 2 * S <= 65535;   // (single-plane form: never split)
     const bool split = can_split && (split_mode == 1 || (split_mode < 0 && blocks64 <= 256));
     const unsigned gz = (unsigned)(split ? 2 * S : S);
     const bool qg2 = (int64_t)cdiv(L, 128) * H * gz >= 512;
@@ -411,7 +437,14 @@ void launch_attention_planes(hipStream_t s, const void* Ph_, const void* Pl_, in
     hipLaunchKernelGGL((attention_planes_kernel<DQ_, DV_, SPLIT_, QG_>), grid, dim3(256), 0, s, Ph, Pl, (long long)ldp, out,            \
                        SPLIT_ ? (_Float16*)nullptr : Oh, SPLIT_ ? (_Float16*)nullptr : Ol, (long long)(SPLIT_ || !Oh ? ldo : ldoh), L, H, \
                        lens, part1, ml)
-    if (dq == 16) {
+    if (n_planes == 1) {                                  // variant 7: the high planes alone (never the key-split form)
+#define MCR_AP1(DQ_, DV_, QG_)                                                                                                         \
+    hipLaunchKernelGGL((attention_planes_kernel<DQ_, DV_, false, QG_, 1>), grid, dim3(256), 0, s, Ph, Pl, (long long)ldp, out, Oh,       \
+                       (_Float16*)nullptr, (long long)(!Oh ? ldo : ldoh), L, H, lens, part1, ml)
+        if (dq == 16) { if (qg2) MCR_AP1(16, 64, 2); else MCR_AP1(16, 64, 1); }
+        else { if (qg2) MCR_AP1(8, 32, 2); else MCR_AP1(8, 32, 1); }
+#undef MCR_AP1
+    } else if (dq == 16) {
         if (split) { if (qg2) MCR_AP(16, 64, true, 2); else MCR_AP(16, 64, true, 1); }
         else { if (qg2) MCR_AP(16, 64, false, 2); else MCR_AP(16, 64, false, 1); }
     } else {

@@ -147,7 +147,9 @@ static void run_encoder_planes(hipStream_t s, const EncW& w, float* x, float* h,
     const int64_t T = S * L;
     const int dqk = E / 4, W3 = 2 * dqk + E;
     const float inv = 1.0f / 256.0f;
-    _Float16 *hh = reinterpret_cast<_Float16*>(h), *hl = hh + (size_t)T * E;                 // planes [2][T][E] over h
+    // 1 on variant 7 (with head dims the planes attention covers: the default architectures): the low planes below are neither written nor read
+    const int np = attention_planes_applicable(H, dqk, E, W3) ? matrix_planes() : 2;
+    _Float16 *hh = reinterpret_cast<_Float16*>(h), *hl = np == 1 ? nullptr : hh + (size_t)T * E;   // planes [2][T][E] over h
     _Float16 *fh = reinterpret_cast<_Float16*>(ff);                                          // planes over ff: [2][T][E] or [2][T][2E]
     auto wsplit = [&](const float* W, int N, int K, void* dst, const void* given = nullptr) {
         if (given) return (const _Float16*)given;            // host-built planes (one split per parameter version instead of per call)
@@ -158,17 +160,19 @@ static void run_encoder_planes(hipStream_t s, const EncW& w, float* x, float* h,
     const _Float16* Wq = wsplit(w.qkv.w, W3, E, ff, w.p_qkv);
     _Float16* ah = reinterpret_cast<_Float16*>(qkv);                                         // the attention's result as planes [2][T][E]
     static const bool att_planes = []() { const char* e = getenv("MCR_ENC_ATT_PLANES"); return !(e && e[0] == '0'); }();   // (A/B)
-    if (att_planes && attention_planes_applicable(H, dqk, E, W3)) {
+    if ((att_planes || np == 1) && attention_planes_applicable(H, dqk, E, W3)) {
         // q | k | v leave the projection as planes [2][T][W3] over qkv (:186-188); the attention stages K / V tiles by DMA (:191-198) and
         // writes its result as planes over h (the LayerNorm's, consumed by then).  One block per (query tile, head, sequence) whatever S is
         // (a cloud's result must not depend on how many clouds share the launch): a batch of clouds saves the combine pass and the fp32
         // parts of the key-split form (0.23 ms of a MACARONS decision); one cloud alone pays 13 us per attention for it (41 instead of
         // 23 + 5 us, hidden beside the local transformers in an NBV step).  MCR_ENC_ATT_SPLIT=1: keys over two blocks + combine (A/B)
         _Float16 *qh_ = reinterpret_cast<_Float16*>(qkv), *ql_ = qh_ + (size_t)T * W3;
-        launch_linear3p(s, hh, hl, E, Wq, Wq + (size_t)W3 * E, E, w.qkv.b, nullptr, qh_, ql_, W3, T, W3, E, ACT_NONE, inv, nullptr, 0, nullptr);
-        static const int split_mode = []() { const char* e = getenv("MCR_ENC_ATT_SPLIT"); return e ? atoi(e) : 0; }();
+        launch_linear3p(s, hh, hl, E, Wq, Wq + (size_t)W3 * E, E, w.qkv.b, nullptr, qh_, ql_, W3, T, W3, E, ACT_NONE, inv, nullptr, 0, nullptr,
+                        nullptr, 0, np);
+        static const int split_mode_env = []() { const char* e = getenv("MCR_ENC_ATT_SPLIT"); return e ? atoi(e) : 0; }();
+        const int split_mode = np == 1 ? 0 : split_mode_env;                                   // (the single-plane form never splits its keys)
         if (split_mode == 0) ah = hh;                                                          // (split: the combine pass writes the planes over qkv, dead by then)
-        launch_attention_planes(s, qh_, ql_, W3, h, E, ah, ah + (size_t)T * E, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, split_mode);
+        launch_attention_planes(s, qh_, ql_, W3, h, E, ah, ah + (size_t)T * E, E, S, L, H, dqk, E, lens, ff, (size_t)T * 2 * E, split_mode, np);
     } else {
         launch_linear3p(s, hh, hl, E, Wq, Wq + (size_t)W3 * E, E, w.qkv.b, qkv, nullptr, nullptr, W3, T, W3, E, ACT_NONE, inv, nullptr, 0, nullptr);   // :186-188
         // attention: fp32 parts in h / ff (key-split scratch); its combine pass writes the result straight as planes into qkv (free by then)
@@ -180,14 +184,14 @@ static void run_encoder_planes(hipStream_t s, const EncW& w, float* x, float* h,
     }
     const _Float16* Wo = wsplit(w.out.w, E, E, ff, w.p_out);
     launch_linear3p(s, ah, ah + (size_t)T * E, E, Wo, Wo + (size_t)E * E, E, w.out.b, x, nullptr, nullptr, E, T, E, E, ACT_NONE, inv, nullptr, 0,
-                    nullptr, x, E);                                                            // :201-202 + residual :290
+                    nullptr, x, E, np);                                                        // :201-202 + residual :290
     launch_layernorm_planes(s, x, E, w.n2g, w.n2b, hh, hl, E, T, E);                         // :293
     const _Float16* W1 = wsplit(w.ff1.w, 2 * E, E, qkv, w.p_ff1);
     launch_linear3p(s, hh, hl, E, W1, W1 + (size_t)2 * E * E, E, w.ff1.b, nullptr, fh, fh + (size_t)T * 2 * E, 2 * E, T, 2 * E, E, ACT_GELU, inv,
-                    nullptr, 0, nullptr);                                                      // :232 (planes out)
+                    nullptr, 0, nullptr, nullptr, 0, np);                                      // :232 (planes out)
     const _Float16* W2 = wsplit(w.ff2.w, E, 2 * E, qkv, w.p_ff2);
     launch_linear3p(s, fh, fh + (size_t)T * 2 * E, 2 * E, W2, W2 + (size_t)E * 2 * E, 2 * E, w.ff2.b, x, nullptr, nullptr, E, T, E, 2 * E, ACT_NONE,
-                    inv, nullptr, 0, nullptr, x, E);                                           // :235 + residual :298
+                    inv, nullptr, 0, nullptr, x, E, np);                                       // :235 + residual :298
 }
 
 // x <- Encoder(x)  in place.  x [T, E]; scratch h [T, E], qkv [T, 2*dqk + E], ff [T, 2E]
@@ -240,6 +244,7 @@ static void run_pct(hipStream_t s, const PctW& w, const float* pc, float* feat, 
     float* ff = a.f(T * 2 * PCT_E);
     const bool planes = ends_planes(L, PCT_E) && half % 4 == 0;
     const float inv = 1.0f / 256.0f;
+    const int np = matrix_planes();                       // 1 on variant 7: the GEMMs below read / write the high planes alone
     _Float16 *hh = reinterpret_cast<_Float16*>(h), *hl = hh + (size_t)T * PCT_E;            // planes [2][T][128] over h
     // Embedding (Attention.py:98-128): linear1 3->125, GELU, linear2 125->125, concat raw input -> 128
     if (planes) {
@@ -254,7 +259,7 @@ static void run_pct(hipStream_t s, const PctW& w, const float* pc, float* feat, 
             wp = reinterpret_cast<const _Float16*>(ff); bp = bq;
         }
         launch_linear3p(s, hh, hl, PCT_E, wp, wp + (size_t)PCT_E * PCT_E, PCT_E, bp, x, nullptr, nullptr, PCT_E, T, PCT_E, PCT_E, ACT_NONE, inv,
-                        nullptr, 0, nullptr);
+                        nullptr, 0, nullptr, nullptr, 0, np);
     } else {
         launch_linear(s, pc, 3, w.l1.w, w.l1.b, nullptr, 0, h, PCT_INNER, T, PCT_INNER, 3, ACT_GELU, nullptr, 0, 0, L);
         launch_linear(s, h, PCT_INNER, w.l2.w, w.l2.b, nullptr, 0, x, PCT_E, T, PCT_INNER, PCT_INNER, ACT_NONE, nullptr, 0, 0, L);
@@ -262,11 +267,11 @@ static void run_pct(hipStream_t s, const PctW& w, const float* pc, float* feat, 
     launch_copy2d(s, pc, 3, x + PCT_INNER, PCT_E, T, 3);
     for (int e = 0; e < 2; ++e) run_encoder(s, w.enc[e], x, h, qkv, ff, S, L, PCT_E, 4, lens);
     if (planes) {                                                                            // SconeOcc.py:119-122 on planes
-        launch_layernorm_planes(s, x, PCT_E, w.ng, w.nb, hh, hl, PCT_E, T, PCT_E);
+        launch_layernorm_planes(s, x, PCT_E, w.ng, w.nb, hh, np == 1 ? nullptr : hl, PCT_E, T, PCT_E);
         const _Float16* wp = (const _Float16*)w.p_lin0;
         if (!wp) { launch_split_weights(s, w.lin0.w, PCT_E, qkv, half, PCT_E); wp = reinterpret_cast<const _Float16*>(qkv); }
         launch_linear3p(s, hh, hl, PCT_E, wp, wp + (size_t)half * PCT_E, PCT_E, w.lin0.b, ff, nullptr, nullptr, half, T, half, PCT_E, ACT_NONE, inv,
-                        nullptr, 0, nullptr);
+                        nullptr, 0, nullptr, nullptr, 0, np);
     } else {
         launch_layernorm(s, x, PCT_E, w.ng, w.nb, h, PCT_E, T, PCT_E);                      // SconeOcc.py:119
         launch_linear(s, h, PCT_E, w.lin0.w, w.lin0.b, nullptr, 0, ff, half, T, half, PCT_E, ACT_NONE, nullptr, 0, 0, head_route(L));   // :122
@@ -583,6 +588,7 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
     float* ff = a.f(T * 2 * VIS_E);
     const bool planes = ends_planes((int)N, VIS_E);
     const float inv = 1.0f / 256.0f;
+    const int np = matrix_planes();                       // 1 on variant 7: the GEMMs below read / write the high planes alone
     _Float16 *hh = reinterpret_cast<_Float16*>(h), *hl = hh + (size_t)T * VIS_E;               // planes [2][T][<= 256] over h
     // Embedding: 4 -> 126 GELU -> 126, || cloud-wide max (126) || raw input (4)  = 256   (Attention.py:98-128)
     if (planes) {
@@ -597,7 +603,8 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
             launch_pad_weights(s, l2.w, VIS_F, l2.b, ff, bq, VIS_F, VIS_F, 128, 128);
             wp = reinterpret_cast<const _Float16*>(ff); bp = bq;
         }
-        launch_linear3p(s, hh, x1l, 128, wp, wp + (size_t)128 * 128, 128, bp, x, nullptr, nullptr, VIS_E, T, 128, 128, ACT_NONE, inv, nullptr, 0, nullptr);
+        launch_linear3p(s, hh, x1l, 128, wp, wp + (size_t)128 * 128, 128, bp, x, nullptr, nullptr, VIS_E, T, 128, 128, ACT_NONE, inv, nullptr, 0, nullptr,
+                        nullptr, 0, np);
     } else {
         launch_linear(s, pts, 4, l1.w, l1.b, nullptr, 0, h, VIS_F, T, VIS_F, 4, ACT_GELU, nullptr, 0, 0, N);
         launch_linear(s, h, VIS_F, l2.w, l2.b, nullptr, 0, x, VIS_E, T, VIS_F, VIS_F, ACT_NONE, nullptr, 0, 0, N);
@@ -607,7 +614,7 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
     if (planes) {
         // :143-152 on planes: LayerNorm -> planes; fc1 (GELU) writes columns 0..191 of the next operand's planes, the view harmonics are
         // split into columns 192..255; fc2 (GELU) writes planes; fc3 leaves fp32.  Weight planes: split per call into the idle qkv region
-        launch_layernorm_planes(s, x, VIS_E, ng, nb, hh, hl, VIS_E, T, VIS_E);
+        launch_layernorm_planes(s, x, VIS_E, ng, nb, hh, np == 1 ? nullptr : hl, VIS_E, T, VIS_E);
         const _Float16 *w1 = (const _Float16*)hp_fc1, *w2 = (const _Float16*)hp_fc2, *w3 = (const _Float16*)hp_fc3;
         if (!w1) {
             _Float16* q1 = reinterpret_cast<_Float16*>(qkv);
@@ -619,11 +626,14 @@ int mcr_scone_vis_forward(const float* pts, const float* view_harmonics, float* 
             w1 = q1; w2 = q2; w3 = q3;
         }
         _Float16 *fh = reinterpret_cast<_Float16*>(ff), *fl = fh + (size_t)T * VIS_E;            // planes [2][T][256] over ff
-        launch_linear3p(s, hh, hl, VIS_E, w1, w1 + (size_t)192 * VIS_E, VIS_E, fc1.b, nullptr, fh, fl, VIS_E, T, 192, VIS_E, ACT_GELU, inv, nullptr, 0, nullptr);
-        launch_split_to_planes(s, view_harmonics, 64, fh + 192, fl + 192, VIS_E, T, 64);
+        launch_linear3p(s, hh, hl, VIS_E, w1, w1 + (size_t)192 * VIS_E, VIS_E, fc1.b, nullptr, fh, fl, VIS_E, T, 192, VIS_E, ACT_GELU, inv, nullptr, 0, nullptr,
+                        nullptr, 0, np);
+        launch_split_to_planes(s, view_harmonics, 64, fh + 192, np == 1 ? nullptr : fl + 192, VIS_E, T, 64);
         _Float16* gl = hh + (size_t)T * 128;                                                       // planes [2][T][128] over h (the LayerNorm's are consumed)
-        launch_linear3p(s, fh, fl, VIS_E, w2, w2 + (size_t)128 * VIS_E, VIS_E, fc2.b, nullptr, hh, gl, 128, T, 128, VIS_E, ACT_GELU, inv, nullptr, 0, nullptr);
-        launch_linear3p(s, hh, gl, 128, w3, w3 + (size_t)64 * 128, 128, fc3.b, out, nullptr, nullptr, 64, T, 64, 128, ACT_NONE, inv, nullptr, 0, nullptr);
+        launch_linear3p(s, fh, fl, VIS_E, w2, w2 + (size_t)128 * VIS_E, VIS_E, fc2.b, nullptr, hh, gl, 128, T, 128, VIS_E, ACT_GELU, inv, nullptr, 0, nullptr,
+                        nullptr, 0, np);
+        launch_linear3p(s, hh, gl, 128, w3, w3 + (size_t)64 * 128, 128, fc3.b, out, nullptr, nullptr, 64, T, 64, 128, ACT_NONE, inv, nullptr, 0, nullptr,
+                        nullptr, 0, np);
     } else {
         launch_layernorm(s, x, VIS_E, ng, nb, h, VIS_E, T, VIS_E);                                   // :143
         // fc1 256->192 GELU, || view_harmonics (64), fc2 256->128 GELU, fc3 128->64                  (:146-152)

@@ -68,7 +68,7 @@ void launch_attention_combine(hipStream_t s, float* out, int64_t ldo, const floa
 bool attention_planes_applicable(int H, int DQK, int DV, int64_t ldp);
 void launch_attention_planes(hipStream_t s, const void* Ph, const void* Pl, int64_t ldp, float* out, int64_t ldo, void* Oh, void* Ol,
                              int64_t ldoh, int64_t S, int L, int H, int DQK, int DV, const int* lens, float* split_ws, size_t split_ws_floats,
-                             int split_mode);
+                             int split_mode, int n_planes = 2);     // n_planes = 1: the high planes alone (variant 7); Pl / Ol unused
 
 // Column max over the L rows of each of S sequences, broadcast into a column slice of every row:
 //   Y[(s*L + r)*ldy + c] = max_r' X[(s*L + r')*ldx + c], c < E          (Embedding global feature, Attention.py:117-121)

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float* __re
             const float y = (v[e] - mean) * rstd * g[c] + b[c];
             const _Float16 hi = (_Float16)y;
             Yh[m * ldp + c] = hi;
-            Yl[m * ldp + c] = (_Float16)(y - (float)hi);
+            if (Yl) Yl[m * ldp + c] = (_Float16)(y - (float)hi);          // (NULL: the single-plane variant 7 keeps fp16(y) alone)
         }
     }
 }

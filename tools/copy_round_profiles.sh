@@ -23,5 +23,9 @@ done
 for f in decision_host_timeline scone_vis_batch_launches scone_vis_single_launches; do
   [ -f $R/gpurun_out/${P}_$f.txt ] && cp $R/gpurun_out/${P}_$f.txt $R/profiles/
 done
+for f in local_pct7_pmc power_local_pct7 nbv_step_breakdown_variant7 linear3p_variant7_pmc variant7_test_report; do
+  [ -s $O/$f.txt ] && cp $O/$f.txt $R/profiles/${P}_$f.txt
+done
+[ -s $O/nbv_gaps_variant7.txt ] && cp $O/nbv_gaps_variant7.txt $R/profiles/${P}_nbv_step_gaps_variant7.txt
 [ -f $O/attention_planes_pmc.txt ] && cp $O/attention_planes_pmc.txt $R/profiles/${P}_attention_planes_pmc.txt
 ls -la $R/profiles | grep ${P}_ | wc -l

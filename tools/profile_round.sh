@@ -43,4 +43,17 @@ rm -rf $R/gpurun_out/pmc_generic; MCR_KNN_GRID=0 MS=10240 KERNEL=knn_mfma_kernel
 (for c in shell cube; do for g in 1 0; do CLOUD=$c MCR_KNN_GRID=$g python $R/tools/time_knn.py; done; done) > $OUT/knn_times.txt 2>&1
 rm -rf $R/gpurun_out/pmc_generic; REPS=3 KERNEL=attention_planes_kernel $R/tools/pmc_generic.sh python $R/tools/time_attention_planes.py > $OUT/attention_planes_pmc.txt 2>&1
 cd $R && python tools/power_trace.py > $OUT/power_trace.txt 2>&1
+# ---- variant 7 (the opt-in 16-bit matrix path): PMC of local_pct7_kernel, energy per query beside variant 6, the step's breakdown, the
+# single-plane head GEMMs
+VARIANT=7 $R/tools/pmc_local_pct.sh > $OUT/local_pct7_pmc.txt 2>&1
+VARIANT=7 $R/tools/pmc_local_pct_mem.sh >> $OUT/local_pct7_pmc.txt 2>&1
+cd $R && python tools/energy_local_pct7.py > $OUT/power_local_pct7.txt 2>&1
+cd /tmp
+rm -rf $OUT/ktrace7; VARIANT=7 timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/ktrace7 -o t -- python $R/tools/run_nbv_steps.py 40 > $OUT/ktrace7.log 2>&1
+T7=$(find $OUT/ktrace7 -name "*kernel_trace.csv" | head -1)
+(grep p50 $OUT/ktrace7.log; python $R/tools/step_breakdown.py $T7) > $OUT/nbv_step_breakdown_variant7.txt 2>&1
+python $R/tools/trace_gaps.py $T7 > $OUT/nbv_gaps_variant7.txt 2>&1
+rm -rf $OUT/ktrace7 $OUT/ktrace
+rm -rf $R/gpurun_out/pmc_generic; VARIANT=7 KERNEL=linear3p_kernel $R/tools/pmc_generic.sh python $R/tools/run_nbv_steps.py 12 > $OUT/linear3p_variant7_pmc.txt 2>&1
+cd $R && python -m pytest tests/test_variant7_gpu.py -q -m gpu -s 2>&1 | grep "^\[variant 7\]\|passed\|failed" > $OUT/variant7_test_report.txt
 grep -c . $OUT/local_pct6_pmc.txt $OUT/linear3p_pmc.txt $OUT/knn_pmc.txt $OUT/power_trace.txt
