@@ -1,14 +1,16 @@
 """Variant 7 -- BASELINE.json config 3 as it is named ("bf16": a 16-bit matrix path) -- the OPT-IN numerics of the network path:
-ONE fp16 plane per matrix operand (one MFMA per product, fp32 accumulation) in the fused local transformers (local_pct7.hip) and the
-SconeOcc head (linear3p.hip, single-plane forms); LayerNorm statistics, soft-max, GELU, pooling, the SH scorer and every reduction stay
-fp32.  Selected per call only (`with ops.variant(7)` / mcr_call_variant(7)); never a process default.
+ONE fp16 plane per matrix operand (one MFMA per product, fp32 accumulation) in the fused local transformers (local_pct7.hip), the
+SconeOcc head (linear3p.hip, single-plane forms) and -- for sequences of >= 512 tokens -- the encoders of SconeVis and of SconeOcc's
+global transformer (their GEMMs and attention_planes.hip's single-plane form); LayerNorm statistics, attention scores and soft-max,
+GELU, pooling, the SH scorer and every reduction stay fp32.  Selected per call only (`with ops.variant(7)` / mcr_call_variant(7)); never a process default.
 
 ITS OWN TOLERANCE, measured here and stated -- NOT the 1e-4 of variants 1 / 5 / 6.  Occupancies (relative, max-norm, against the fp64
 oracle on the inputs of scone_occ.npz; measured value -> asserted bound, per weight set):
-    golden weights (seed 2)   8.9e-4 -> 2e-3   (also against the REFERENCE's own fp32 output: the same)
-    seed 11                   6.9e-4 -> 2e-3
-    seed 7                    5.0e-3 -> 8e-3   (this network amplifies operand errors 8x more: variant 6 has 7e-6 there, 9e-7-1.4e-6 on the others)
-    seed 2, local weights x4  2.4e-3 -> 4e-3   (pooled local features alone: 9e-2, variant 6: 8e-5 -- soft-max logits 16x larger)
+    golden weights (seed 2)   1.0e-3 -> 2e-3   (also against the REFERENCE's own fp32 output: the same)
+    seed 11                   8.1e-4 -> 2e-3
+    seed 7                    4.7e-3 -> 8e-3   (this network amplifies operand errors 8x more: variant 6 has 7e-6 there, 9e-7-1.4e-6 on the others)
+    seed 2, local weights x4  3.5e-3 -> 6e-3   (pooled local features alone: 9e-2, variant 6: 8e-5 -- soft-max logits 16x larger)
+SconeVis harmonics (2048 points, fp64 oracle): measured -> VIS_TOL = 3e-3.
 The bound is a property of (path, checkpoint): a network amplifies ANY operand error by its own factor (round 5's pricing table).  What
 is checkpoint-INDEPENDENT is the ratio: variant 7 carries 11 of variant 6's 22 operand bits, so its error stays below AMPLIFICATION =
 2^12 times variant 6's on the same inputs (measured ratios 340 .. 2100); asserted for every weight set.
@@ -20,7 +22,7 @@ inverse-CDF sampling is a step function of the cumulative occupancies, so a few 
 measured 48-179 of 2048 samples (2.3-8.7 %), 91-99 % of the unique points in common with the reference's set (asserted: <= 15 % /
 >= 85 %; the counts move with every change of the kernel's rounding pattern: they are a property of the CDF's steps, not of the kernel).
 The gains are a Monte-Carlo estimate over that sample and move with it: measured 0.4-2.6e-2 relative end to end (bound asserted:
-GAIN_E2E_TOL = 5e-2) while the same networks on the REFERENCE's sampled set reproduce its gains at 3e-7 .. 9e-7.  All of this is REPORTED
+GAIN_E2E_TOL = 5e-2) while the same networks on the REFERENCE's sampled set reproduce its gains at 5e-4 .. 7e-4 (GAIN_TOL = 2e-3).  All of this is REPORTED
 (gpurun_out/variant7_report.json, printed with -s), not hidden behind a looser comparison."""
 import contextlib
 import io
@@ -40,7 +42,8 @@ from oracle import nets  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 OCC_TOL = 2e-3        # |occ - occ_ref| / max |occ_ref| on the golden weights (the table above for other weight sets)
-OCC_TOL_BY_WEIGHTS = {(2, 1.0): 2e-3, (11, 1.0): 2e-3, (7, 1.0): 8e-3, (2, 4.0): 4e-3}
+OCC_TOL_BY_WEIGHTS = {(2, 1.0): 2e-3, (11, 1.0): 2e-3, (7, 1.0): 8e-3, (2, 4.0): 6e-3}
+VIS_TOL = 3e-3        # SconeVis harmonics vs the fp64 oracle (encoders + attention on one plane)
 GAIN_E2E_TOL = 5e-2   # gains of a whole decision: Monte-Carlo noise of a different sampled set (measured <= 2.6e-2)
 GAIN_TOL = 2e-3       # gains on the SAME sampled set
 LOCAL_TOL = 2e-3      # pooled local features of one fused transformer vs the fp64 oracle (measured: 6e-4 .. 1.3e-3 at unit scale)
@@ -140,6 +143,38 @@ def test_occupancies_within_the_stated_bound(dev, seed, local_scale):
     assert worst < AMPLIFICATION * max(worst6, 2.0 ** -22)
     assert worst < OCC_TOL_BY_WEIGHTS[(seed, local_scale)] and worst6 < 1e-5
     assert m._full_range is False                                            # (the range guard stayed quiet: nothing fell back to variant 5)
+
+
+@pytest.mark.parametrize("seed", [1, 5])
+def test_scone_vis_single_plane(dev, seed):
+    """SconeVis.forward at 2048 and 700 points (>= 512: the planes encoders, single-plane attention) on variant 7 against the fp64
+    oracle; a batch gives every cloud the bits of its single call (launch-shape independence holds on this variant too); short clouds
+    (< 512 points: the fp32-class kernels of every variant) stay at 1e-5."""
+    from macarons_amd import ops
+    from macarons_amd.networks import SconeVis
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = SconeVis()
+    sd = weights.make_state_dict(weights.shapes_of(m), seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    rng = np.random.default_rng(70 + seed)
+    worst = 0.0
+    for B, N in ((1, 2048), (3, 700), (2, 100)):
+        pts = np.concatenate([rng.uniform(-.5, .5, (B, N, 3)), rng.uniform(.1, 1., (B, N, 1))], -1).astype(np.float32)
+        vh = (rng.standard_normal((B, N, 64)) * 0.3).astype(np.float32)
+        with ops.variant(7), torch.no_grad():
+            y = m(T(pts, dev), view_harmonics=T(vh, dev))
+            for b in range(B):
+                assert torch.equal(y[b:b + 1], m(T(pts[b:b + 1], dev), view_harmonics=T(vh[b:b + 1], dev))), (B, N, b)
+        ref = nets.scone_vis_forward(sd, pts, vh, np.float64)
+        e = rel_err(y.cpu().numpy(), ref)
+        assert np.isfinite(y.cpu().numpy()).all()
+        if N < 512:
+            assert e < 1e-5
+        else:
+            worst = max(worst, e)
+    _report(f"scone_vis_rel_err_seed{seed}", worst)
+    assert worst < VIS_TOL and m._full_range is False
 
 
 def test_variant7_is_deterministic_and_launch_shape_independent(dev):
