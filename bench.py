@@ -267,23 +267,90 @@ def measure_nbv_step(dev, rank, world, args):
     # size -- the per-rank critical path apart from collective latency, so that the projected strong scaling is a measurement
     shard8 = None
     if world == 1:
-        from macarons_amd.nbv import _nbv_step
-        te = []
-        for it in range(5 + 20):
+        from macarons_amd import ops
+        from macarons_amd.nbv import nbv_step_one_rank_of, GraphedNbvStep
+
+        def one_rank(variant, n=20):
+            te = []
+            with ops.variant(variant):
+                for it in range(5 + n):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    re_ = nbv_step_one_rank_of(8, occ, vis, pc, X, X_view, cams, grid, perms, u)
+                    int(re_["nbv_idx"])
+                    torch.cuda.synchronize()
+                    if it >= 5:
+                        te.append(time.perf_counter() - t0)
+                eager = float(np.median(te))
+                # the same share replayed as ONE hipGraph: the GPU-side critical path without the host's launch rate (a 1/8-size step is
+                # ~60 short launches: eager it is bound by the host)
+                try:
+                    gs8 = GraphedNbvStep(occ, vis, pc, X, X_view, cams, grid, one_rank_of=8)
+                    tg = []
+                    for it in range(5 + n):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        rg8 = gs8(occ_perms=perms, samples=u)
+                        int(rg8["nbv_idx"])
+                        torch.cuda.synchronize()
+                        if it >= 5:
+                            tg.append(time.perf_counter() - t0)
+                    graph8 = float(np.median(tg))
+                except Exception as e:
+                    graph8 = None
+                    sys.stderr.write(f"bench.py: one_rank_of_8 graph capture failed: {e!r}\n")
+            return eager, graph8
+
+        def part_ms(fn, n=20):                              # device time of one component, back to back (HIP events on the current stream)
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            return e0.elapsed_time(e1) / n
+        p50_e, p50_g = one_rank(6)
+        # replicated vs sharded: the components of a rank's share timed alone (variant 6).  Sharded = SconeOcc on Q/8 queries (its global
+        # transformer -- replicated work -- runs on a side stream beside the local path) + the scorer on C/8 cameras; replicated = the part
+        # every rank repeats on the full sampled set
+        from macarons_amd.utility import scone_utils as su
+        q8, c8 = Q // 8, C // 8
+        Xs, vhs = X[:, :q8].contiguous(), torch.zeros(1, q8, 64, device=dev)
+        prev_guard = (occ.range_guard, vis.range_guard)
+        occ.range_guard = vis.range_guard = "off"
+        try:
             with torch.no_grad():
-                re_ = _nbv_step(occ, vis, pc, X, X_view, cams, grid, occ_perms=perms, samples=u, _emulate=(0, 8))
-            int(re_["nbv_idx"])
-            torch.cuda.synchronize()
-            if it >= 5:
-                te.append(time.perf_counter() - t0)
-        p50_e = float(np.median(te))
-        shard8 = {"world": 8, "rank": 0, "p50_ms": p50_e * 1e3, "full_step_p50_ms": p50 * 1e3,
-                  "speedup_before_collective_latency": p50 / p50_e,
+                t_occ = part_ms(lambda: occ(pc, Xs, vhs, perms=perms))
+                t_glob = part_ms(lambda: occ.global_transformer(pc[:, perms[0]].contiguous()))
+                pp = torch.cat((X[0, :2048], torch.rand(2048, 1, device=dev)), 1)
+                vs = su.compute_view_harmonics(su.compute_view_state(pp[None, :, :3].contiguous(), X_view, grid.n_elev, grid.n_azim),
+                                               grid.base_harmonics, grid.h_polar, grid.h_azim, grid.n_elev, grid.n_azim)
+                t_vis = part_ms(lambda: vis(pp[None], view_harmonics=vs))
+                occ_full = torch.rand(Q, device=dev) * 0.8 + 0.15
+                t_smp = part_ms(lambda: ops.sample_proxy(X[0].contiguous(), occ_full, None, u.reshape(-1), 0.1, padded=True))
+                hm = torch.randn(1, 2048, 64, device=dev) * 0.3
+                t_sc = part_ms(lambda: vis.compute_coverage_gain(pp[None], hm, cams[:c8].contiguous().view(1, -1, 3)))
+        finally:
+            occ.range_guard, vis.range_guard = prev_guard
+        shard8 = {"world": 8, "rank": 0, "p50_ms": p50_e * 1e3, "p50_ms_hipgraph": None if p50_g is None else p50_g * 1e3,
+                  "full_step_p50_ms": p50 * 1e3, "speedup_before_collective_latency": p50 / p50_e,
+                  "speedup_hipgraph_before_collective_latency": None if p50_g is None else (graph["p50_ms"] * 1e-3 if graph and "p50_ms" in graph else p50) / p50_g,
+                  "split_device_ms": {"sharded": {"scone_occ_on_Q_over_8": t_occ, "scorer_on_C_over_8": t_sc},
+                                      "replicated": {"global_transformer_inside_scone_occ_side_stream": t_glob, "sampler": t_smp, "scone_vis_2048": t_vis},
+                                      "note": "components timed alone, back to back (HIP events); the global transformer's time is INSIDE scone_occ's "
+                                              "(side stream, beside the local path): replicated work that does not add to the path unless it "
+                                              "outlasts the sharded local part"},
                   "note": "one rank's critical path of an 8-rank step emulated on one GPU (its query shard + the redundant sampling / "
                           "SconeVis / decision + its camera shard; exchanges = local copies of the same size): the 8-GPU step costs this "
-                          "plus the latency of one occupancy all-gather (50 KB per rank) and one 8-byte record all-gather"}
+                          "plus the latency of one occupancy all-gather (50 KB per rank) and one 8-byte record all-gather.  Eager, a 1/8-size "
+                          "step is ~60 short launches and host-bound; p50_ms_hipgraph is the same share replayed as one hipGraph"}
+        try:
+            e7, g7 = one_rank(7, n=12)
+            shard8["variant_7"] = {"p50_ms": e7 * 1e3, "p50_ms_hipgraph": None if g7 is None else g7 * 1e3}
+        except Exception as e:
+            shard8["variant_7"] = {"error": repr(e)[:200]}
     # the same step on the other numerics of the matrix path (1: exact fp32 MFMA, 5: bf16 hi/mid/lo x6, 6: fp16 hi/lo x3 = default) and on
     # the OPT-IN 16-bit matrix path (7: one fp16 plane per operand, BASELINE config 3's "bf16"; its own tolerance, never the default)
     by_variant = None
@@ -841,12 +908,16 @@ def main():
             state["emit"](f"extra legs stopped at the {args.legs_deadline} s deadline; finished: {sorted(legs)}")
         os._exit(0)
 
+    leg_seconds = {}
+
     def run_leg(name, fn):
+        t_leg = time.perf_counter()
         try:
             legs[name] = fn()
         except Exception as e:                              # reported in the leg's field, never fatal for the contract line
             legs[name] = {"error": repr(e)[:300]}
             sys.stderr.write(f"bench.py: rank {rank}: leg {name} failed: {e!r}\n")
+        leg_seconds[name] = round(time.perf_counter() - t_leg, 2)
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
@@ -933,6 +1004,7 @@ def main():
         if out.get("nbv_step") and out["nbv_step"].get("one_rank_of_8"):
             summ["nbv_step_one_rank_of_8_p50_ms"] = out["nbv_step"]["one_rank_of_8"]["p50_ms"]
         out["scaling_summary"] = summ
+        out["leg_seconds"] = dict(leg_seconds)
         if note:
             out["legs_incomplete"] = note
         sys.stdout.flush()

@@ -130,6 +130,15 @@ def nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min
     return _guarded(impl, scone_occ, range_guard, group, draws, X.device, scone_vis)
 
 
+def nbv_step_one_rank_of(world, scone_occ, scone_vis, pc, X, X_view, X_cam, grid, occ_perms, samples, rank=0, seq_len=2048, min_occ=0.1):
+    """MEASUREMENT AID (bench.py: nbv_step.one_rank_of_8): what ONE rank of a `world`-rank sharded step computes for this decision, run
+    on this GPU alone -- its 1/world of the queries through SconeOcc, then the part every rank repeats (sampling, SconeVis, the decision)
+    and its 1/world of the cameras, with the two exchanges replaced by local copies of the same size.  The per-rank critical path apart
+    from collective latency; the decision it returns is NOT the real one.  No read-back inside (range check deferred: range_flag)."""
+    return _guarded(lambda: _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len, min_occ, occ_perms=occ_perms, samples=samples,
+                                      _emulate=(rank, world)), scone_occ, False, None, lambda: {}, X.device, scone_vis)
+
+
 def _nbv_step(scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1,
               max_points_per_pass=300000, true_monte_carlo_sampling=True, occ_perms=None, samples=None, group=None,
               view_proj=None, filter_tol=0.01, return_samples=False, _emulate=None):
@@ -379,7 +388,10 @@ class GraphedNbvStep:
     the eager step would, copies them and the scene tensors into the static input buffers, and replays.  Shapes are fixed at
     construction.  Returns the same dict as `nbv_step` (static output tensors: clone what must survive the next call)."""
 
-    def __init__(self, scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1, warmup=2):
+    def __init__(self, scone_occ, scone_vis, pc, X, X_view, X_cam, grid, seq_len=2048, min_occ=0.1, warmup=2, one_rank_of=None):
+        """one_rank_of (measurement aid): capture nbv_step_one_rank_of(one_rank_of, ...) -- rank 0's share of a sharded step -- instead
+        of the whole step."""
+        self.one_rank_of = one_rank_of
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             raise RuntimeError("GraphedNbvStep captures the single-GPU step; use nbv_step under torchrun")
         self.occ, self.vis, self.grid, self.seq_len, self.min_occ = scone_occ, scone_vis, grid, seq_len, min_occ
@@ -401,6 +413,9 @@ class GraphedNbvStep:
 
     def _run(self):
         i = self._in
+        if self.one_rank_of:
+            return nbv_step_one_rank_of(self.one_rank_of, self.occ, self.vis, i["pc"], i["X"], i["X_view"], i["X_cam"], self.grid, i["perms"],
+                                        i["samples"], seq_len=self.seq_len, min_occ=self.min_occ)
         return nbv_step(self.occ, self.vis, i["pc"], i["X"], i["X_view"], i["X_cam"], self.grid, seq_len=self.seq_len,
                         min_occ=self.min_occ, occ_perms=i["perms"], samples=i["samples"], return_samples=True, range_guard=False)
 

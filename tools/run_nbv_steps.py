@@ -7,7 +7,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
-from macarons_amd.nbv import nbv_step, _nbv_step, ViewStateGrid
+from macarons_amd.nbv import nbv_step, nbv_step_one_rank_of, ViewStateGrid
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 dev = torch.device("cuda:0")
@@ -31,8 +31,7 @@ ts = []
 for it in range(n):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     if os.environ.get("EMULATE_WORLD"):       # one rank's share of an EMULATE_WORLD-rank step (bench.py: nbv_step.one_rank_of_8)
-        with torch.no_grad():
-            r = _nbv_step(occ, vis, pc, X, cams[:3].contiguous(), cams, grid, occ_perms=perms, samples=u, _emulate=(0, int(os.environ["EMULATE_WORLD"])))
+        r = nbv_step_one_rank_of(int(os.environ["EMULATE_WORLD"]), occ, vis, pc, X, cams[:3].contiguous(), cams, grid, perms, u)
     else:
         r = nbv_step(occ, vis, pc, X, cams[:3].contiguous(), cams, grid, occ_perms=perms, samples=u)
     int(r["host"]["nbv_idx"][0]) if "host" in r else int(r["nbv_idx"]); torch.cuda.synchronize()
