@@ -1,12 +1,15 @@
 #!/bin/bash
 # Dev: GPU busy / idle inside one MACARONS decision (kernel trace of bench.measure_macarons_step): decisions are delimited by the
-# fused depth update (proxy_update_kernel)
+# fused depth update (proxy_update_kernel).   [VARIANT=7] tools/trace_macarons_step.sh > gpurun_out/r06_macarons_decision_trace_<tag>.txt
 cd /tmp && export TMPDIR=/tmp
 export MCR_BENCH_NO_CHECKS=1
 rm -rf /tmp/mtrace; timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/mtrace -o t -- python -c "
 import sys; sys.path.insert(0, '/root/repo')
-import torch, bench
-r = bench.measure_macarons_step(torch.device('cuda:0')); print(r['p50_ms'], r['variant_7']['p50_ms'])" > /tmp/mtrace.log 2>&1
+import os, contextlib, torch, bench
+from macarons_amd import ops
+with (ops.variant(int(os.environ['VARIANT'])) if os.environ.get('VARIANT') else contextlib.nullcontext()):     # VARIANT=7: every decision of the trace on the 16-bit path
+    r = bench.measure_macarons_step(torch.device('cuda:0'))
+print(r['p50_ms'], r['variant_7']['p50_ms'])" > /tmp/mtrace.log 2>&1
 tail -1 /tmp/mtrace.log
 python - <<'PY'
 import csv, glob, collections
