@@ -23,6 +23,29 @@ def test_blob_sizes_match_the_kernels():
     assert pack_local_pct(pct, 1).numel() == L.mcr_local_pct_blob_floats()
     assert pack_local_pct(pct, 5).numel() == L.mcr_local_pct3_blob_floats()
     assert pack_local_pct(pct, 6).numel() == L.mcr_local_pct6_blob_floats()
+    assert pack_local_pct(pct, 7).numel() == L.mcr_local_pct7_blob_floats()
+
+
+def test_variant_7_blob_is_the_unscaled_fp16_weights_in_fragment_order():
+    """The opt-in 16-bit matrix path (local_pct7.hip): matrices as ONE fp16 plane in the MFMA-fragment order [n-tile][k16][lane][8] --
+    fp16(W) without variant 6's per-matrix power of two -- followed by the UNSCALED bias vectors and nothing else."""
+    from macarons_amd.networks.packing import pack_local_pct
+    pct = _pct()
+    b7, b6 = pack_local_pct(pct, 7), pack_local_pct(pct, 6)
+    n_vec = 2 * 128 + 2 * (192 + 128 + 256 + 128) + 128
+    n_mat7 = b7.numel() - n_vec
+    assert 2 * n_mat7 == b6.numel() - n_vec - 32                          # half a float per weight against variant 6's one
+    # matrix 14 (the last one): linear0 with the final LayerNorm's gamma folded, rows = features, 128 x 128
+    with torch.no_grad():
+        W = (pct.linear0.weight * pct.norm.weight[None, :]).float()
+    halves = b7[:n_mat7].view(torch.float16)
+    frag = halves[-128 * 128:].view(4, 8, 2, 32, 8)                        # [nt][k16 step][lane half h][lane j][8]
+    nt, s_, h, j = 2, 5, 1, 17
+    assert torch.equal(frag[nt, s_, h, j], W[32 * nt + j, 16 * s_ + 8 * h:16 * s_ + 8 * h + 8].to(torch.float16))
+    # the bias of linear0 (+ W @ beta of the folded LayerNorm) closes the blob, unscaled
+    with torch.no_grad():
+        c = pct.linear0.bias + pct.linear0.weight @ pct.norm.bias
+    assert torch.allclose(b7[-128:], c.float(), rtol=0, atol=1e-6)
 
 
 def test_param_fingerprint_sees_every_kind_of_weight_change():
