@@ -291,3 +291,36 @@ def test_scene_batch_config3_on_variant_7(dev):
         assert torch.equal(rb["occ"][b], singles[b]["occ"]) and torch.equal(rb["gains"][b], singles[b]["gains"]), b
     assert torch.equal(rb["nbv_idx"].view(-1).cpu(), r6["nbv_idx"].view(-1).cpu())
     assert float((rb["occ"] - r6["occ"]).abs().max() / r6["occ"].abs().max()) < OCC_TOL
+
+
+def test_sharded_step_on_variant_7_through_rccl_single_rank(dev, monkeypatch):
+    """The variant is a property of the calling thread's calls, so a sharded step (rank-0 draws broadcast, occupancy all-gather, record
+    merge -- run through RCCL on a one-rank group, MCR_FORCE_DIST_PATH) inside `ops.variant(7)` runs every network on variant 7 and
+    reproduces the local variant-7 step bit for bit; the emulated share of an 8-rank step (bench.py: one_rank_of_8) runs on it too."""
+    import socket
+    import torch.distributed as dist
+    from macarons_amd import ops
+    from macarons_amd.nbv import nbv_step, nbv_step_one_rank_of, ViewStateGrid
+    from test_nbv_gpu import _models
+    g = golden("e2e_grid_config1")
+    occ, vis, _, _ = _models(dev)
+    grid = ViewStateGrid(dev)
+    args = (occ, vis, T(g["pc"], dev), T(g["X"], dev), T(g["X_view"], dev), T(g["X_cam"], dev), grid)
+    perms = [torch.from_numpy(g[f"perm{i}"].astype(np.int64)) for i in range(3)]
+    with ops.variant(7):
+        a = nbv_step(*args, occ_perms=perms, samples=T(g["samples"], dev))
+    with ops.variant(6):
+        a6 = nbv_step(*args, occ_perms=perms, samples=T(g["samples"], dev))
+    assert not torch.equal(a["occ"], a6["occ"])                            # (variant 7 did run)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    monkeypatch.setenv("MCR_FORCE_DIST_PATH", "1")
+    try:
+        with ops.variant(7):
+            b = nbv_step(*args, occ_perms=[p.to(dev) for p in perms], samples=T(g["samples"], dev), group=dist.group.WORLD)
+        assert torch.equal(a["occ"], b["occ"]) and torch.equal(a["gains"], b["gains"]) and int(a["nbv_idx"]) == int(b["nbv_idx"])
+    finally:
+        dist.destroy_process_group()
+    with ops.variant(7):
+        e = nbv_step_one_rank_of(8, *args, [p.to(dev) for p in perms], T(g["samples"], dev))
+    assert torch.isfinite(e["gains"]).all() and e["gains"].numel() >= 1
