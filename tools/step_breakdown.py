@@ -1,4 +1,4 @@
-"""Dev: per-kernel time inside the median NBV step of a rocprofv3 kernel trace (csv); steps = spans between view_state_kernel launches."""
+"""Dev: per-kernel time inside the median NBV step of a rocprofv3 kernel trace (csv); steps = spans between the decisions' read-backs (tools/_trace_steps.py)."""
 import csv, sys, collections
 raw = list(csv.DictReader(open(sys.argv[1])))
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in raw))
@@ -6,7 +6,10 @@ def _wg(r):
     t = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
     return int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(1, t), t
 grid = {int(r["Start_Timestamp"]): _wg(r) for r in raw}
-starts = [i for i, r in enumerate(rows) if "view_state_kernel" in r[2]]
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _trace_steps import step_starts
+starts = step_starts(rows)                       # a step = from the first kernel after a decision's read-back to the next read-back
 steps = []
 for a, b in zip(starts[8:-1], starts[9:]):
     seg = rows[a:b]

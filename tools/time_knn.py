@@ -7,7 +7,7 @@ if os.environ.get("MCR_DEV_LIB"):
 from macarons_amd import ops
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(1)
-Q = 100_000
+Q = int(os.environ.get("Q", 100_000))
 X = (torch.rand(1, Q, 3, generator=g) - 0.5).to(dev)
 for M in [int(m) for m in os.environ.get("MS", "10240,1137,126").split(",")]:
     d = torch.randn(M, 3, generator=g); pc = (d / d.norm(dim=1, keepdim=True) * 0.3)[None].to(dev)      # a shell (surface-like)

@@ -3,8 +3,11 @@
     python tools/trace_gaps.py out/t_kernel_trace.csv"""
 import csv, sys
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1]))))
-# steps = spans between consecutive view_state_kernel launches
-starts = [i for i, r in enumerate(rows) if "view_state_kernel" in r[2]]
+# steps = spans between the decisions' read-backs (tools/_trace_steps.py)
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _trace_steps import step_starts
+starts = step_starts(rows)                       # a step = from the first kernel after a decision's read-back to the next read-back
 res = []
 for a, b in zip(starts[10:-1], starts[11:]):
     seg = rows[a:b]
