@@ -373,6 +373,23 @@ def measure_nbv_step(dev, rank, world, args):
                                   "max_rel_gain_diff_vs_default": float((rv["gains"] - r["gains"]).abs().max() / r["gains"].abs().max()),
                                   "max_rel_occ_diff_vs_default": float((rv["occ"] - r["occ"]).abs().max() / r["occ"].abs().max()),
                                   "fell_back_to_variant": rv.get("fallback_variant")}
+        try:                                                # the variant-7 step replayed as ONE hipGraph (captured inside the variant's scope)
+            from macarons_amd.nbv import GraphedNbvStep
+            with ops.variant(7):
+                gs7 = GraphedNbvStep(occ, vis, pc, X, X_view, cams, grid)
+                tg7 = []
+                for it in range(5 + 20):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    rg7 = gs7(occ_perms=perms, samples=u)
+                    int(rg7["nbv_idx"])
+                    torch.cuda.synchronize()
+                    if it >= 5:
+                        tg7.append(time.perf_counter() - t0)
+            by_variant["7"]["hipgraph_replay"] = {"p50_ms": float(np.median(tg7)) * 1e3, "same_decision_as_eager": int(rg7["nbv_idx"]) == int(rv["nbv_idx"]),
+                                                  "same_gains_as_eager": bool(torch.equal(rg7["gains"], rv["gains"]))}
+        except Exception as e:
+            by_variant["7"]["hipgraph_replay"] = {"error": repr(e)[:200]}
         by_variant["7"].update({
             "dtype": "f16 matrix operands, ONE plane (1 MFMA per product, fp32 accumulation) in the local transformers and the SconeOcc head; "
                      "LayerNorm statistics, soft-max, GELU, pooling, SH scorer, reductions fp32",
