@@ -324,3 +324,39 @@ def test_sharded_step_on_variant_7_through_rccl_single_rank(dev, monkeypatch):
     with ops.variant(7):
         e = nbv_step_one_rank_of(8, *args, [p.to(dev) for p in perms], T(g["samples"], dev))
     assert torch.isfinite(e["gains"]).all() and e["gains"].numel() >= 1
+
+
+def test_ragged_pass_on_variant_7_equals_job_by_job(dev):
+    """SconeOcc.forward_ragged (the occupancy-field pass of a MACARONS decision: J clouds / query chunks of different sizes in one launch
+    sequence, incl. clouds of fewer than 2048 points -- padded global down-samples -- and a 1-row job) on variant 7 against the J
+    forward() calls on variant 7 with the same draws: BIT-EQUAL for clouds of >= 512 points (the same kernels on the same rows); a
+    cloud of fewer than 512 points runs its global transformer on the fp32-class short-sequence kernels when called alone and on the
+    single-plane encoders inside the padded batch -- two different matrix paths, so those jobs agree within the variant's bound (variant 6
+    has the same split at 1e-6); and everything within the bound of the fp64 oracle."""
+    from macarons_amd import ops
+    m, sd = _occ(dev, 2)
+    rng = np.random.default_rng(12)
+    sizes_m, sizes_q = [100, 3000, 65, 2048, 900], [17, 300, 1, 129, 4097]
+    clouds = [rng.uniform(-.4, .4, (n, 3)).astype(np.float32) for n in sizes_m]
+    xs = [rng.uniform(-.5, .5, (q, 3)).astype(np.float32) for q in sizes_q]
+    vhs = [(rng.standard_normal((q, 64)) * .3).astype(np.float32) for q in sizes_q]
+    torch.manual_seed(21)
+    perms = [m.draw_perms(n) for n in sizes_m]
+    with ops.variant(7), torch.no_grad():
+        y = m.forward_ragged(T(np.concatenate(clouds), dev), sizes_m, T(np.concatenate(xs), dev), T(np.concatenate(vhs), dev), sizes_q,
+                             perms=perms).cpu().numpy()
+        refs = [m(T(c[None], dev), T(x[None], dev), T(v[None], dev), perms=p).cpu().numpy().reshape(-1, 1)
+                for c, x, v, p in zip(clouds, xs, vhs, perms)]
+    assert y.shape == (sum(sizes_q), 1) and np.isfinite(y).all()
+    o = 0
+    for M, r in zip(sizes_m, refs):
+        if M >= 512:
+            assert np.array_equal(y[o:o + len(r)], r), M
+        else:
+            assert rel_err(y[o:o + len(r)], r) < OCC_TOL, M
+        o += len(r)
+    o64 = np.concatenate([nets.scone_occ_forward(sd, c[None], x[None], v[None], [q.numpy() for q in p], np.float64).reshape(-1, 1)
+                          for c, x, v, p in zip(clouds[:3], xs[:3], vhs[:3], perms[:3])])
+    e = rel_err(y[:len(o64)], o64)
+    _report("ragged_pass_rel_err", e)
+    assert e < OCC_TOL
