@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, DQ == 16 ? MCR_AP_OCC_16 : MCR_AP_OCC_8) void 
     // ---- this wave's DMA instructions j = wave + 4 n of a tile: the plane (wave-uniform), and per lane the key row inside the tile and the
     // column (halves) of the 16 bytes it moves.  Whole tiles advance one 32-bit offset per instruction (relative to the sequence's first
     // row: L ldp < 2^31, checked by the launcher); only a sequence's last, partial tile decodes again and clamps its rows.
-    const _Float16 *bh = Ph + seq0 * ldp, *bl = Pl + seq0 * ldp;
+    const _Float16 *bh = Ph + seq0 * ldp, *bl = NP == 2 ? Pl + seq0 * ldp : bh;          // (NP == 1: Pl may be NULL, never formed)
     auto decode = [&](int j, int& row, int& col) -> bool {   // -> lo plane?
         bool lo;
         if (j < 2 * NK) {

@@ -102,13 +102,13 @@ __global__ __launch_bounds__(SMALL ? 256 : 512, SMALL ? 2 : 1) void linear3p_ker
     for (int g = 0; g < GX; ++g) {
         const int p = (GX * wave + g) * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
         const long long xr = min(m0 + row, M - 1);         // rows beyond the matrix repeat its last row (results discarded)
-        sx[g][0] = Xh + xr * ldx + c * 8; sx[g][1] = Xl + xr * ldx + c * 8;
+        sx[g][0] = Xh + xr * ldx + c * 8; sx[g][1] = NP == 2 ? Xl + xr * ldx + c * 8 : sx[g][0];     // (NP == 1: Xl may be NULL, never formed)
     }
 #pragma unroll
     for (int g = 0; g < GW; ++g) {
         const int p = (GW * wave + g) * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
         const long long wr = min((long long)n0 + row, (long long)N - 1);
-        sw[g][0] = Wh + wr * ldw + c * 8; sw[g][1] = Wl + wr * ldw + c * 8;
+        sw[g][0] = Wh + wr * ldw + c * 8; sw[g][1] = NP == 2 ? Wl + wr * ldw + c * 8 : sw[g][0];
     }
     auto stage = [&](int st, int k0) {                     // 6 DMA instructions per wave
         uint4* b = S + st * STAGE;

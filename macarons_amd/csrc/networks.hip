@@ -488,7 +488,7 @@ int mcr_local_pct6_blob_floats(void) { return local_pct6_blob_floats(); }
 int mcr_local_pct7_blob_floats(void) { return local_pct7_blob_floats(); }
 
 int mcr_set_local_pct_variant(int v) {
-    MCR_REQUIRE(v == 1 || v == 5 || v == 6 || MCR_VARIANT8_OK(v), "mcr_set_local_pct_variant: variant must be 1, 5 or 6 (got %d)", v);
+    MCR_REQUIRE(v == 1 || v == 5 || v == 6 || MCR_VARIANT8_OK(v), "mcr_set_local_pct_variant: the process default must be 1, 5 or 6 (got %d; 7, the opt-in 16-bit matrix path, is per call only: mcr_call_variant)", v);
     g_default_variant = v;
     return 0;
 }
