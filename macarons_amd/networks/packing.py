@@ -140,10 +140,11 @@ def invalidate(cache):
 
 
 class BlobCache:
-    """Re-pack only when a parameter changed (data_ptr / version / device)."""
+    """Re-pack only when a parameter changed (data_ptr / version / device).  One image per numerics variant is kept: a caller that
+    alternates `ops.variant(7)` and the default per call does not re-pack on every switch."""
 
     def __init__(self):
-        self._key, self._blob, self._c = None, None, {}
+        self._entries, self._c = {}, {}
 
     def invalidate(self):
         invalidate(self._c)
@@ -152,10 +153,13 @@ class BlobCache:
         """key: a fingerprint that covers at least pct's parameters (the owner's whole-module key, taken once per forward: the three
         local transformers, the pointer table and the head planes of a SconeOcc otherwise fingerprint ~400 parameters per call,
         ~150 us of host time in front of the first launch)."""
-        key = (variant,) + (key if key is not None else _param_key(pct, self._c))
-        if key != self._key:
-            self._blob, self._key = pack_local_pct(pct, variant), key
-        return self._blob
+        key = key if key is not None else _param_key(pct, self._c)
+        hit = self._entries.get(variant)
+        if hit is None or hit[0] != key:
+            hit = self._entries[variant] = (key, pack_local_pct(pct, variant))
+            for v in [v for v, e in self._entries.items() if e[0] != key]:      # images of older parameter versions: drop
+                del self._entries[v]
+        return hit[1]
 
 
 def weight_planes(W):
