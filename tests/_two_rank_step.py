@@ -100,6 +100,10 @@ def main():
     s_b3 = nbv_step_batch(*ab, occ_perms=permb, samples=ub)
     s_b1 = nbv_step_batch(occ, vis, pcb[:1], Xb[:1], Xvb[:1], camb, grid, occ_perms=[p[:1] for p in permb], samples=ub[:1])
     mac1, gmac = macarons_decisions(dev)
+    from macarons_amd import ops as _ops
+    with _ops.variant(7):                                                # the opt-in 16-bit matrix path: 1-rank answers (case V below)
+        s7_full = nbv_step(*a2, occ_perms=P(g2), samples=T(g2["samples"]))
+        s7_b3 = nbv_step_batch(*ab, occ_perms=permb, samples=ub)
     torch.cuda.synchronize()
 
     dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
@@ -143,6 +147,18 @@ def main():
     expect(torch.equal(r["occ"], s_b1["occ"]) and torch.equal(r["gains"], s_b1["gains"][:, c0:c1]), "D shards")
     expect(torch.equal(r["max_gain"], s_b1["max_gain"]) and torch.equal(r["nbv_idx"], s_b1["nbv_idx"]), "D decision")
     expect(torch.equal(s_b1["max_gain"], s_b3["max_gain"][:1]) and torch.equal(s_b1["occ"], s_b3["occ"][:1]), "D batch-of-1 == first of 3")
+    # V: the same on VARIANT 7 (selected per call, on every rank's calling thread): the sharded step / the cloud-sharded batch reproduce
+    # the 1-rank variant-7 answers bit for bit (a query's numerics do not depend on the shard it falls into on this variant either)
+    with _ops.variant(7):
+        r = nbv_step(*a2, occ_perms=P(g2), samples=T(g2["samples"]), group=dist.group.WORLD)
+        c0, c1 = r["cam_range"]
+        expect(torch.equal(r["occ"], s7_full["occ"]) and torch.equal(r["gains"], s7_full["gains"][c0:c1]), "V sharded step on variant 7")
+        expect(torch.equal(r["max_gain"], s7_full["max_gain"]) and int(r["nbv_idx"]) == int(s7_full["nbv_idx"]) == int(g2["nbv_idx"]), "V decision")
+        expect(not torch.equal(s7_full["occ"], s_full["occ"]), "V (variant 7 did run)")
+        r = nbv_step_batch(*ab, occ_perms=permb, samples=ub, group=dist.group.WORLD)
+        b0, b1 = r["cloud_range"]
+        expect(torch.equal(r["occ"], s7_b3["occ"][b0:b1]) and torch.equal(r["gains"], s7_b3["gains"][b0:b1]), "V batch own clouds")
+        expect(torch.equal(r["max_gain"], s7_b3["max_gain"]) and torch.equal(r["nbv_idx"], s7_b3["nbv_idx"]), "V batch decisions")
     # F: BASELINE config 4's scorer shape on two ranks: 100 000 points x 512 cameras, 256 cameras per rank, the decision through the
     # record exchange == the 1-rank arg-max over all 512
     from macarons_amd import ops
