@@ -172,6 +172,14 @@ class SconeOcc(RangeGuard, nn.Module):
         self._range_pending = []            # (pinned host int32 [1], event) of forwards whose flag has not been looked at yet
         self._full_range = False            # True once an overflow was seen: variant 5 from then on
 
+    def _effective_guard(self):
+        """range_guard, except under stream capture: a read-back ("sync") or a host copy ("async") cannot be part of a graph, so a
+        captured forward leaves the flag in range_flag() ("defer") for whoever replays the graph to look at."""
+        g = self.range_guard
+        if g in ("sync", "async") and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return "defer"
+        return g
+
     def freeze_weight_caches(self, on=True):
         """Inference mode: fingerprint the parameters once, now, and trust them unchanged until freeze_weight_caches(False) or
         invalidate_weight_caches() (an optimizer step or load_state_dict in between would go unnoticed: opt-in)."""
@@ -367,19 +375,20 @@ class SconeOcc(RangeGuard, nn.Module):
             return ops.scone_occ_forward_ragged(pc_global, g_len_d, [pc, pc1, pc2], [d_off0, d_off1, d_off2], x, view_harmonics,
                                                 d_row_job, d_blocks, table, blobs, head, flag, phase=2, out=out_, arena=h["arena"])
         flag = None
-        if variant in (6, 7) and self.range_guard != "off":
+        guard = self._effective_guard()
+        if variant in (6, 7) and guard != "off":
             if self._range_flag is None or self._range_flag.device != dev:
                 self._range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
-            elif self.range_guard in ("sync", "async"):
+            elif guard in ("sync", "async"):
                 self._range_flag.zero_()
             flag = self._range_flag
         with torch.no_grad():
             # (phase 1's results live in the stream's arena: if anything else wrote it since -- another thread on this stream -- redo it)
             res = run(variant, flag, ops.scone_occ_epoch(dev, h["arena"]) != h["epoch1"], out)
-            if flag is not None and self.range_guard == "sync" and int(flag):
+            if flag is not None and guard == "sync" and int(flag):
                 with ops.variant(5):
                     res = run(5, None, True, out)
-            elif flag is not None and self.range_guard == "async":
+            elif flag is not None and guard == "async":
                 self._post_range_check(flag)
         return res
 
@@ -458,12 +467,11 @@ class SconeOcc(RangeGuard, nn.Module):
             return ops.scone_occ_forward(pc_global, scales, x_, vh_, table, blobs, head, flag, phase=phase)
 
         flag = None
-        if variant in (6, 7) and self.range_guard != "off":
+        guard = self._effective_guard()
+        if variant in (6, 7) and guard != "off":
             if self._range_flag is None or self._range_flag.device != dev:
                 self._range_flag = torch.zeros(1, dtype=torch.int32, device=dev)
-            elif self.range_guard == "sync":
-                self._range_flag.zero_()
-            elif self.range_guard == "async":
+            elif guard in ("sync", "async"):
                 self._range_flag.zero_()
             flag = self._range_flag
         if A.needs_grad(self, pc, x, view_harmonics):   # trainers: HIP forward, composite-torch backward (autograd.py)
@@ -487,9 +495,9 @@ class SconeOcc(RangeGuard, nn.Module):
             res = A.with_torch_backward(hip, composite, (pc, x, view_harmonics), self)
         else:
             res = run(variant, pc_global, scales, x, view_harmonics, flag, phase)
-            if flag is not None and self.range_guard == "sync" and int(flag):      # out of the fp16 range: the full-range path
+            if flag is not None and guard == "sync" and int(flag):      # out of the fp16 range: the full-range path
                 with ops.variant(5):
                     res = run(5, pc_global, scales, x, view_harmonics, None)
-            elif flag is not None and self.range_guard == "async":
+            elif flag is not None and guard == "async":
                 self._post_range_check(flag)
         return res.view(n_clouds, n_sample, self.output_dim)

@@ -826,3 +826,35 @@ def test_one_cloud_returns_the_bits_it_has_inside_a_batch_of_30(dev):
             for b in (0, 17, 29):
                 one = vis(pts[b:b + 1].contiguous(), view_harmonics=vh[b:b + 1].contiguous())
                 assert torch.equal(one[0], big[b]), (N, b)
+
+
+def test_stand_alone_forwards_can_be_captured_under_the_default_guard(dev):
+    """The default range guard reads the flag back after a stand-alone forward -- which a stream capture forbids: under capture both
+    networks leave the flag in range_flag() instead ("defer"), so a user who records `scone_occ(...)` / `scone_vis(...)` in a graph of
+    their own is not broken by the default; the replay reproduces the eager bits."""
+    from macarons_amd.networks import SconeOcc, SconeVis
+    occ, _ = _mod(SconeOcc, 2, dev)
+    vis, _ = _mod(SconeVis, 1, dev)
+    assert occ.range_guard == "sync" and vis.range_guard == "sync"
+    g = golden("scone_occ")
+    tag = "m1024_q300"
+    perms = [torch.from_numpy(g[f"{tag}_perm{i}"].astype(np.int64)).to(dev) for i in range(3)]
+    pc, x, vh = T(g[f"{tag}_pc"], dev), T(g[f"{tag}_x"], dev), T(g[f"{tag}_vh"], dev)
+    rng = np.random.default_rng(3)
+    pts = T(np.concatenate([rng.uniform(-.5, .5, (1, 700, 3)), rng.uniform(.1, 1., (1, 700, 1))], -1).astype(np.float32), dev)
+    vhs = T((rng.standard_normal((1, 700, 64)) * 0.3).astype(np.float32), dev)
+    with torch.no_grad():
+        y_e, h_e = occ(pc, x, vh, perms=perms), vis(pts, view_harmonics=vhs)          # eager (also builds every cache and arena)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            occ(pc, x, vh, perms=perms); vis(pts, view_harmonics=vhs)                  # warm-up on the capture stream
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            y_g, h_g = occ(pc, x, vh, perms=perms), vis(pts, view_harmonics=vhs)
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(y_g, y_e) and torch.equal(h_g, h_e)
+    assert int(occ.range_flag()) == 0
