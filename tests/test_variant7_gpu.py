@@ -21,7 +21,7 @@ DECISIONS.  What must hold exactly is the arg-max camera on every golden decisio
 inverse-CDF sampling is a step function of the cumulative occupancies, so a few of the 2048 uniforms land on a neighbouring point --
 measured 48-179 of 2048 samples (2.3-8.7 %), 91-99 % of the unique points in common with the reference's set (asserted: <= 15 % /
 >= 85 %; the counts move with every change of the kernel's rounding pattern: they are a property of the CDF's steps, not of the kernel).
-The gains are a Monte-Carlo estimate over that sample and move with it: measured 0.4-2.6e-2 relative end to end (bound asserted:
+The gains are a Monte-Carlo estimate over that sample and move with it: measured 0.4-3.3e-2 relative end to end (bound asserted:
 GAIN_E2E_TOL = 5e-2) while the same networks on the REFERENCE's sampled set reproduce its gains at 5e-4 .. 7e-4 (GAIN_TOL = 2e-3).  All of this is REPORTED
 (gpurun_out/variant7_report.json, printed with -s), not hidden behind a looser comparison."""
 import contextlib
@@ -44,7 +44,7 @@ pytestmark = pytest.mark.gpu
 OCC_TOL = 2e-3        # |occ - occ_ref| / max |occ_ref| on the golden weights (the table above for other weight sets)
 OCC_TOL_BY_WEIGHTS = {(2, 1.0): 2e-3, (11, 1.0): 2e-3, (7, 1.0): 8e-3, (2, 4.0): 6e-3}
 VIS_TOL = 3e-3        # SconeVis harmonics vs the fp64 oracle (encoders + attention on one plane)
-GAIN_E2E_TOL = 5e-2   # gains of a whole decision: Monte-Carlo noise of a different sampled set (measured <= 2.6e-2)
+GAIN_E2E_TOL = 5e-2   # gains of a whole decision: Monte-Carlo noise of a different sampled set (measured <= 3.3e-2)
 GAIN_TOL = 2e-3       # gains on the SAME sampled set
 LOCAL_TOL = 2e-3      # pooled local features of one fused transformer vs the fp64 oracle (measured: 6e-4 .. 1.3e-3 at unit scale)
 AMPLIFICATION = 4096.0   # variant 7's error <= 2^12 x variant 6's on the same inputs and weights (measured ratios: 340 .. 2100)
