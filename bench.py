@@ -1029,7 +1029,8 @@ def main():
         summ = {"weak_scorer_evals_per_s": out.get("value"), "n_gpus": out.get("n_gpus")}
         if out.get("scorer_strong"):
             summ["strong_scorer_config4_evals_per_s"] = out["scorer_strong"]["value"]
-        for key, leg in (("nbv_step", "nbv_step"), ("nbv_batch", "nbv_batch"), ("macarons_decision", "macarons_step")):
+        for key, leg in (("nbv_step", "nbv_step"), ("nbv_batch", "nbv_batch"), ("nbv_batch_16bit_variant7", "nbv_batch_16bit"),
+                         ("macarons_decision", "macarons_step")):
             if out.get(leg):
                 summ[f"strong_{key}_p50_ms"] = out[leg]["p50_ms"]
                 summ[f"strong_{key}_evals_per_s"] = out[leg]["evals_per_s"]
